@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Compile the in-scope URDFs of the reference asset tree into the JSON model fixtures
+under mppi-isaac_amd/assets/compiled/.  Runs only where /root/reference exists (this
+container); the GPU box uses the committed JSON.  Usage: python tools/compile_models.py"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "mppi-isaac_amd"))
+from mppiisaac.backend.urdf_compile import compile_urdf, save_model
+
+REF = os.environ.get("MPPI_REFERENCE", "/root/reference")
+# urdf_file value used in conf/actors/*.yaml  ->  fixture name
+URDFS = {
+    "point_robot.urdf": "point_robot",
+    "panda_isaac/robots/franka_panda_stick.urdf": "franka_panda_stick",
+    "panda_isaac/robots/franka_panda_gripper.urdf": "franka_panda_gripper",
+    "panda_isaac/robots/franka_panda.urdf": "franka_panda",
+    "boxer/boxer.urdf": "boxer",
+    "heijn.urdf": "heijn",
+}
+out_dir = os.path.join(ROOT, "mppi-isaac_amd", "assets", "compiled")
+os.makedirs(out_dir, exist_ok=True)
+for rel, name in URDFS.items():
+    path = os.path.join(REF, "assets", "urdf", rel)
+    if not os.path.exists(path):
+        print("skip (missing)", rel); continue
+    m = compile_urdf(path, name=name)
+    m["urdf_file"] = rel
+    save_model(m, os.path.join(out_dir, name + ".json"))
+    print(f"{name}: {len(m['links'])} links, {len(m['bodies'])} dof;",
+          "masses", [round(b['inertia']['mass'], 3) for b in m['bodies']], "base", round(m['base']['inertia']['mass'], 3))
