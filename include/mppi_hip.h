@@ -1,0 +1,219 @@
+/*
+ * mppi_hip.h - C-ABI of the MI355X-native MPPI rollout backend (libmppi_hip.so).
+ *
+ * The reference (tud-airlab/mppi-isaac) has no FFI: its hot path sits behind Python
+ * callables bound to two absent native engines (Isaac Gym / PhysX and mppi_torch).
+ * Each entry point below names the reference interface it replaces (paths relative
+ * to the reference tree).  Host code (Python, mppi-isaac_amd/mppiisaac/backend/capi.py)
+ * binds these with ctypes; no torch types cross this boundary - only plain pointers,
+ * sizes and an opaque hipStream_t.
+ *
+ * Conventions
+ *  - All model/config parameters are double; device arithmetic is fp32.
+ *  - Device buffers are sample-minor ("SoA"): element (row r, sample k) of a K-wide
+ *    buffer lives at r*K + k, so a wavefront reads 64 consecutive floats.
+ *  - Reference-layout ("AoS", env-major) tensors exist only at the materialise
+ *    boundary (mppi_sim_materialise), as the reference's gym state tensors do
+ *    (mppiisaac/planner/isaacgym_wrapper.py:186-199).
+ *  - Every function returns 0 on success, a negative MPPI_E* code on failure;
+ *    mppi_last_error() returns the message of the last failure in this thread.
+ *  - One context per (process, device); contexts are not thread-safe.
+ */
+#ifndef MPPI_HIP_H
+#define MPPI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPPI_ABI_VERSION 1
+
+#define MPPI_MAX_BODIES 12   /* moving bodies (= DOF) of the articulated robot        */
+#define MPPI_MAX_LINKS 24    /* reported rigid bodies of the robot (URDF links)      */
+#define MPPI_MAX_ACTORS 8    /* actors per env (robot + boxes/spheres)               */
+#define MPPI_MAX_NU 12       /* control dimension                                    */
+#define MPPI_MAX_H 64        /* horizon                                              */
+#define MPPI_MAX_KNOTS 16    /* spline knots of the halton-spline sampler            */
+#define MPPI_MAX_COST_W 16
+
+enum { MPPI_OK = 0, MPPI_EINVAL = -1, MPPI_EHIP = -2, MPPI_EUNSUPPORTED = -3, MPPI_ESTATE = -4 };
+enum { MPPI_JOINT_REVOLUTE = 0, MPPI_JOINT_PRISMATIC = 1 };
+/* dof_mode of the reference's ActorWrapper (isaacgym_wrapper.py:52, drive gains :491-507) */
+enum { MPPI_DRIVE_VELOCITY = 0, MPPI_DRIVE_EFFORT = 1, MPPI_DRIVE_POSITION = 2 };
+/* ActorWrapper.type (isaacgym_wrapper.py:42-46, isaacgym_utils.py:19-54) */
+enum { MPPI_ACTOR_ROBOT = 0, MPPI_ACTOR_BOX = 1, MPPI_ACTOR_SPHERE = 2 };
+/* fused stage costs: restatements of the reference's example Objectives */
+enum {
+    MPPI_COST_NONE = 0,        /* generic mode: cost comes from the host callback          */
+    MPPI_COST_POINT_REACH = 1, /* benchmarks/point_robot/mppi_planner/mppi_planner_wrapper.py:17-35 (nav term) */
+    MPPI_COST_PANDA_REACH = 2, /* examples/panda/planner.py:22-40                           */
+    MPPI_COST_BOXER_PUSH = 3,  /* examples/boxer_push/planner.py:26-67                      */
+    MPPI_COST_PANDA_PICK = 4   /* examples/panda_pick/planner.py:24-53                      */
+};
+enum { MPPI_SAMPLE_HALTON_SPLINE = 0, MPPI_SAMPLE_EXTERNAL = 1 };
+
+/* One moving body = one 1-DOF joint + the links welded to its child link.
+ * Transform convention: x_parent = R * x_child + p (R row-major 3x3). */
+typedef struct mppi_body {
+    int32_t parent;      /* moving-body index, -1 = robot base                           */
+    int32_t jtype;       /* MPPI_JOINT_*                                                 */
+    double axis[3];      /* unit joint axis in the body (child) frame                    */
+    double R_tree[9];    /* joint frame in the parent body frame at q = 0                */
+    double p_tree[3];
+    double mass;         /* composite rigid inertia about the body-frame origin:        */
+    double h[3];         /*   first moment m*c                                           */
+    double Io[6];        /*   xx xy xz yy yz zz                                          */
+    int32_t limited;     /* joint position limits active (URDF revolute/prismatic)       */
+    int32_t pad_;
+    double lower, upper; /* URDF <limit lower upper>                                     */
+    double effort;       /* URDF <limit effort>: drive force clamp, 0 = none             */
+    double velocity;     /* URDF <limit velocity>: |qdot| clamp, 0 = none                */
+} mppi_body_t;
+
+/* A reported rigid body (URDF link): welded to `body` (-1 = base) at (R,p). */
+typedef struct mppi_link {
+    int32_t body;
+    int32_t pad_;
+    double R[9];
+    double p[3];
+} mppi_link_t;
+
+/* conf/actors/<name>.yaml -> ActorWrapper (isaacgym_wrapper.py:49-77) */
+typedef struct mppi_actor {
+    int32_t type;      /* MPPI_ACTOR_*        */
+    int32_t fixed;     /* fix_base_link       */
+    int32_t collision; /* collision group on  */
+    int32_t gravity;   /* !disable_gravity    */
+    double size[3];
+    double mass;
+    double friction;
+    int32_t first_rb;  /* first rigid-body row of this actor in rigid_body_state         */
+    int32_t n_rb;      /* robot: n_links, box/sphere: 1                                  */
+} mppi_actor_t;
+
+/* Scene of one env: one articulated robot + simple actors, in env_cfg (= root_state) order. */
+typedef struct mppi_model {
+    int32_t abi_version;
+    int32_t n_actors;
+    mppi_actor_t actors[MPPI_MAX_ACTORS];
+    int32_t robot_actor; /* index of the robot in the actor list                          */
+    int32_t n_bodies;    /* = number of DOF                                               */
+    mppi_body_t bodies[MPPI_MAX_BODIES];
+    int32_t n_links;
+    int32_t n_rb;        /* total rigid bodies per env (all actors)                       */
+    mppi_link_t links[MPPI_MAX_LINKS];
+    double base_mass;    /* composite inertia of the root-link cluster (floating base)    */
+    double base_h[3];
+    double base_Io[6];
+    int32_t drive_mode;  /* MPPI_DRIVE_*                                                  */
+    int32_t substeps;    /* conf/isaacgym/<x>.yaml                                        */
+    double drive_kd;     /* 600 velocity / 10 effort (isaacgym_wrapper.py:491-500)        */
+    double dt;
+    double gravity[3];   /* (0,0,-9.8) isaacgym_wrapper.py:29                             */
+    /* command scatter of apply_robot_cmd (isaacgym_wrapper.py:524-572), folded into at
+     * most two (column, coefficient) terms per DOF: target_i = c0*u[col0] + c1*u[col1].
+     * Plain DOFs use (col,1),(0,0); diff-drive wheels use (0,1/r),(1,-+L/2r) (_ik :510-522). */
+    int32_t nu;
+    int32_t cmd_col[MPPI_MAX_BODIES][2];
+    double cmd_coef[MPPI_MAX_BODIES][2];
+} mppi_model_t;
+
+/* mppi_torch.MPPIConfig fields (reference conf/mppi/ + benchmarks/point_robot/setup/mppi.yaml:5-37) */
+typedef struct mppi_config {
+    int32_t abi_version;
+    int32_t num_samples;   /* K: samples owned by THIS context (one shard)               */
+    int32_t horizon;       /* H                                                          */
+    int32_t nu;
+    int32_t k_offset;      /* global id of local sample 0 (sharding)          */
+    int32_t k_total;       /* global number of samples over all shards                   */
+    int32_t sample_null_action; /* global sample k_total-1 uses u = 0                    */
+    int32_t use_priors;    /* global sample k_total-2 uses the prior sequence            */
+    int32_t sampling;      /* MPPI_SAMPLE_*                                              */
+    int32_t n_knots;       /* halton-spline: knots per control dim (H/4; = H if < 3)     */
+    int32_t noise_abs_cost;
+    int32_t want_rollouts; /* record visualize_link positions [H][K][3] (get_rollouts)   */
+    int32_t viz_link;      /* link index recorded when want_rollouts                     */
+    int32_t seed;
+    double lambda_;
+    double rollout_var_discount; /* gamma                                                */
+    double u_init;
+    double u_min[MPPI_MAX_NU], u_max[MPPI_MAX_NU];
+    double noise_sigma_diag[MPPI_MAX_NU]; /* diagonal of noise_sigma (variances)        */
+    double spline_basis[MPPI_MAX_H * MPPI_MAX_KNOTS]; /* [H][n_knots] row-major          */
+} mppi_config_t;
+
+typedef struct mppi_cost {
+    int32_t kind;          /* MPPI_COST_*                                                */
+    int32_t link[4];       /* rigid-body / link indices used by the cost                 */
+    int32_t actor[6];      /* actor indices used by the cost                             */
+    double w[MPPI_MAX_COST_W]; /* weights / scalar parameters            */
+} mppi_cost_t;
+
+typedef struct mppi_ctx mppi_ctx_t;
+
+const char *mppi_last_error(void);
+int mppi_abi_version(void);
+int mppi_device_count(int *count);
+
+/* ---- lifetime: replaces IsaacGymWrapper.__init__/start_sim (isaacgym_wrapper.py:84-236)
+ *      + MPPIPlanner(cfg.mppi, ...) construction (mppi_isaac.py:43-49).  Allocates all
+ *      device buffers on `device`.  `stream` is a hipStream_t (NULL = default stream).   */
+int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device, mppi_ctx_t **out);
+int mppi_destroy(mppi_ctx_t *ctx);
+int mppi_set_stream(mppi_ctx_t *ctx, void *hip_stream);
+int mppi_synchronize(mppi_ctx_t *ctx);
+
+/* ---- state in: replaces reset_rollout_sim (mppi_isaac.py:87-105): ONE env state
+ *      (dof_state [2n] interleaved q,qdot; root_state [A][13] pos,quat xyzw,linvel,angvel)
+ *      is broadcast to all K samples inside the kernel (no [K,..] copy is written). */
+int mppi_set_state(mppi_ctx_t *ctx, const float *dof_state_host, const float *root_state_host);
+int mppi_set_state_dev(mppi_ctx_t *ctx, const float *dof_state_dev, const float *root_state_dev);
+int mppi_get_state(mppi_ctx_t *ctx, float *dof_state_host, float *root_state_host);
+
+/* ---- MPPI core: replaces mppi_torch.MPPIPlanner.command (call sites mppi_isaac.py:84,113) */
+int mppi_set_cost(mppi_ctx_t *ctx, const mppi_cost_t *cost);
+int mppi_sample(mppi_ctx_t *ctx, uint32_t index_base);        /* halton-spline -> eps [H][nu][K] */
+int mppi_set_noise_dev(mppi_ctx_t *ctx, const float *eps_dev); /* external eps [H][nu][K]        */
+int mppi_set_prior(mppi_ctx_t *ctx, const float *prior_host);  /* [H][nu] for sample k_total-2   */
+int mppi_set_nominal(mppi_ctx_t *ctx, const float *U_host);    /* [H][nu]                        */
+int mppi_get_nominal(mppi_ctx_t *ctx, float *U_host);
+int mppi_rollout(mppi_ctx_t *ctx);   /* persistent kernel: K samples x H steps, fused cost -> S[K], du */
+int mppi_reduce(mppi_ctx_t *ctx, float *record_out_dev); /* shard record (beta, eta, N[H*nu]); NULL = internal buffer */
+int mppi_record_floats(const mppi_ctx_t *ctx);               /* 2 + H*nu                             */
+int mppi_record_dev(mppi_ctx_t *ctx, float **record_dev);    /* device pointer of this shard's record */
+/* combine n shard records (device, [n][2+H*nu]; NULL = own record), update U, emit action, shift */
+int mppi_update(mppi_ctx_t *ctx, const float *records_dev, int n_records);
+int mppi_get_action(mppi_ctx_t *ctx, float *action_host);     /* [nu]; synchronises the stream        */
+int mppi_action_dev(mppi_ctx_t *ctx, float **action_dev);
+int mppi_command(mppi_ctx_t *ctx, float *action_host);        /* rollout+reduce+update+get_action     */
+int mppi_get_costs(mppi_ctx_t *ctx, float *S_host);           /* [K] total trajectory costs           */
+int mppi_get_weights_stats(mppi_ctx_t *ctx, float *beta_eta_host); /* [2]                             */
+int mppi_get_rollouts(mppi_ctx_t *ctx, float *viz_host);      /* [H][K][3], get_rollouts mppi_isaac.py:118-124 */
+int mppi_get_perturbations(mppi_ctx_t *ctx, float *du_host);  /* [H][nu][K] effective perturbations   */
+int mppi_get_noise(mppi_ctx_t *ctx, float *eps_host);         /* [H][nu][K]                           */
+
+/* ---- batched simulator (generic Objective mode and the K=1 "world"):
+ *      replaces IsaacGymWrapper.apply_robot_cmd + step (isaacgym_wrapper.py:524-572,639-655)
+ *      and the four gym state tensors (:186-199). */
+int mppi_sim_reset(mppi_ctx_t *ctx);                       /* all K envs <- current x0              */
+int mppi_sim_step(mppi_ctx_t *ctx, const float *u_dev, int u_is_shared); /* u [K][nu] (AoS) or [nu] */
+int mppi_sim_step_horizon(mppi_ctx_t *ctx, int t);         /* u = clamp(U[t]+eps[t]) per sample     */
+/* reference-layout tensors: dof [K][2n], root [K][A][13], rb [K][B][13], cf [K][B][3]; NULL = skip */
+int mppi_sim_materialise(mppi_ctx_t *ctx, float *dof_dev, float *root_dev, float *rb_dev, float *cf_dev);
+int mppi_sim_accumulate_cost(mppi_ctx_t *ctx, int t, const float *cost_dev); /* S += gamma^t c      */
+int mppi_sim_finish(mppi_ctx_t *ctx);                      /* S += control cost                     */
+/* device-resident closed loop: step a K=1 world with the planner's action, feed its state back */
+int mppi_world_step_from(mppi_ctx_t *world, mppi_ctx_t *planner);
+int mppi_set_state_from_world(mppi_ctx_t *planner, mppi_ctx_t *world);
+
+/* ---- instrumentation (reference has only print(FPS), examples/panda/world.py:53-59) */
+int mppi_set_profiling(mppi_ctx_t *ctx, int on);            /* bracket every launch with hipEvents on the context's stream */
+int mppi_kernel_ms(mppi_ctx_t *ctx, int which, float *ms); /* mean launch duration since profiling was enabled: 0 rollout 1 reduce 2 update */
+int mppi_kernel_info(mppi_ctx_t *ctx, char *buf, int buflen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPPI_HIP_H */

@@ -1,0 +1,620 @@
+// mppi_device.hpp - per-sample device code of the MPPI rollout (gfx950).
+//
+// One lane integrates one sample: the whole articulated-body working set (joint subspaces,
+// articulated inertias, bias forces) lives in VGPRs - with <=2 waves per SIMD the lane has the
+// full 512-entry unified register file - and the kinematic tree is a COMPILE-TIME template
+// parameter, so every per-body array index is static and nothing is spilled or indexed through
+// scratch.  All spatial quantities are expressed in WORLD axes about the WORLD origin, which
+// makes the inertia/force propagation of the articulated-body algorithm a plain addition
+// (no 6x6 congruence transforms in the hot loop).
+//
+// The model handed to this code is "z-framed": the host re-frames every body so that its joint
+// axis is the local z axis (csrc/mppi_pack.hpp: pack_model), so a revolute joint
+// costs one sincos and 12 multiplies.
+//
+// This header is plain C++17: hipcc compiles it for the GPU kernels (mppi_hip.hip); the
+// test-only host harness (tests/hostemu) compiles the very same functions with g++ so the
+// arithmetic can be checked against the oracle without a GPU.  It is NOT a product CPU path.
+//
+// Reference behaviour restated here (paths in the reference tree):
+//   apply_robot_cmd / _ik   mppiisaac/planner/isaacgym_wrapper.py:510-572
+//   step (dt, substeps)     mppiisaac/planner/isaacgym_wrapper.py:639-645, conf/isaacgym/*.yaml
+//   drive gains             mppiisaac/planner/isaacgym_wrapper.py:491-507
+//   stage costs             examples/panda/planner.py:22-40, benchmarks/point_robot/.../mppi_planner_wrapper.py:17-35
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define MPPI_HD __host__ __device__ __forceinline__
+#else
+#define MPPI_HD inline
+#endif
+
+namespace mppi {
+
+constexpr int kMaxBodies = 12;
+constexpr int kMaxLinks = 24;
+constexpr int kMaxActors = 8;
+constexpr int kMaxNu = 12;
+
+// ---- device-side model (fp32, z-framed) ------------------------------------------------
+struct DevBody {
+    int parent, jtype, limited, pad;
+    float Rt[9];  // joint frame in parent body frame (child->parent), q = 0
+    float pt[3];
+    float m;
+    float hb[3];  // m * com, body frame
+    float Ic[6];  // inertia about the COM, body axes: xx xy xz yy yz zz
+    float lower, upper, effort, vmax;
+    float cmd[kMaxNu];  // dense row of the command map: target_i = sum_c cmd[c] * u[c]
+};
+struct DevLink {
+    int body, pad[3];
+    float R[9];
+    float p[3];
+};
+struct DevModel {
+    int nb, nl, n_actors, robot_actor, n_rb, robot_first_rb, drive_mode, substeps, gravity_on, nu, pad[2];
+    float kd, h, g[3], pad2[3];
+    int actor_first_rb[kMaxActors];
+    DevBody b[kMaxBodies];
+    DevLink l[kMaxLinks];
+};
+struct DevCfg {
+    int K, H, nu, k_offset, k_total, sample_null_action, use_priors, noise_abs_cost, want_rollouts, viz_link, pad[2];
+    float lambda, inv_lambda, gamma, u_init;
+    float u_min[kMaxNu], u_max[kMaxNu], inv_sigma[kMaxNu];  // inv_sigma = 1 / noise_sigma[c][c]
+};
+struct DevCost {
+    int kind, link[4], actor[6], pad;
+    float w[16];
+};
+
+// Uniform (per-launch constant) structs are read through the CONSTANT address space on the GPU:
+// such loads are selected as scalar loads (s_load_*, operands stay in SGPRs, zero VGPR cost)
+// whatever stores the kernel performs.  launder() makes the base pointer opaque at a chosen point so
+// the ~300 model constants are re-fetched from the scalar cache where they are used instead of being
+// hoisted out of the time loop and parked in (then spilled from) vector registers.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MPPI_CONST_AS __attribute__((address_space(4)))
+#else
+#define MPPI_CONST_AS
+#endif
+typedef const MPPI_CONST_AS DevModel CModel;
+typedef const MPPI_CONST_AS DevBody CBody;
+typedef const MPPI_CONST_AS DevLink CLink;
+typedef const MPPI_CONST_AS DevCfg CCfg;
+typedef const MPPI_CONST_AS DevCost CCost;
+typedef const MPPI_CONST_AS float cfloat;
+
+template <class P>
+MPPI_HD P *launder(P *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(p));
+#endif
+    return p;
+}
+
+enum { kCostNone = 0, kCostPointReach = 1, kCostPandaReach = 2, kCostBoxerPush = 3, kCostPandaPick = 4 };
+enum { kDriveVelocity = 0, kDriveEffort = 1, kDrivePosition = 2 };
+
+// ---- compile-time kinematic tree -------------------------------------------------------
+template <int... P>
+struct Topo {
+    static constexpr int NB = sizeof...(P);
+    static constexpr int par[sizeof...(P) ? sizeof...(P) : 1] = {P...};
+};
+template <int I>
+struct IC {
+    static constexpr int value = I;
+    constexpr operator int() const { return I; }
+};
+template <int B, int E, class F>
+MPPI_HD void static_for(F &&f) {
+    if constexpr (B < E) {
+        f(IC<B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+template <int B, int E, class F>
+MPPI_HD void static_rfor(F &&f) {  // E-1 down to B
+    if constexpr (B < E) {
+        f(IC<E - 1>{});
+        static_rfor<B, E - 1>(f);
+    }
+}
+
+// ---- small vector helpers --------------------------------------------------------------
+struct V3 {
+    float x, y, z;
+};
+MPPI_HD V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+MPPI_HD V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+MPPI_HD V3 operator*(float s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+MPPI_HD float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+MPPI_HD V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+struct M3 {  // row-major
+    float a[9];
+};
+MPPI_HD V3 mul(const M3 &A, V3 v) {
+    return {A.a[0] * v.x + A.a[1] * v.y + A.a[2] * v.z, A.a[3] * v.x + A.a[4] * v.y + A.a[5] * v.z, A.a[6] * v.x + A.a[7] * v.y + A.a[8] * v.z};
+}
+MPPI_HD M3 mul(const M3 &A, const M3 &B) {
+    M3 C;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) C.a[3 * i + j] = A.a[3 * i] * B.a[j] + A.a[3 * i + 1] * B.a[3 + j] + A.a[3 * i + 2] * B.a[6 + j];
+    return C;
+}
+template <class F>
+MPPI_HD M3 load3(F *p) {
+    M3 A;
+    for (int i = 0; i < 9; i++) A.a[i] = p[i];
+    return A;
+}
+template <class F>
+MPPI_HD V3 loadv(F *p) {
+    return {p[0], p[1], p[2]};
+}
+// symmetric 3x3: xx xy xz yy yz zz
+struct S3 {
+    float xx, xy, xz, yy, yz, zz;
+};
+MPPI_HD V3 mul(const S3 &A, V3 v) { return {A.xx * v.x + A.xy * v.y + A.xz * v.z, A.xy * v.x + A.yy * v.y + A.yz * v.z, A.xz * v.x + A.yz * v.y + A.zz * v.z}; }
+
+// quaternion xyzw -> rotation (root_state layout, reference isaacgym_wrapper.py:186-188)
+MPPI_HD M3 quat_to_R(const float *q) {
+    float x = q[0], y = q[1], z = q[2], w = q[3];
+    float n = x * x + y * y + z * z + w * w;
+    float s = n > 0.f ? 2.f / n : 0.f;
+    M3 R;
+    R.a[0] = 1 - s * (y * y + z * z); R.a[1] = s * (x * y - z * w);     R.a[2] = s * (x * z + y * w);
+    R.a[3] = s * (x * y + z * w);     R.a[4] = 1 - s * (x * x + z * z); R.a[5] = s * (y * z - x * w);
+    R.a[6] = s * (x * z - y * w);     R.a[7] = s * (y * z + x * w);     R.a[8] = 1 - s * (x * x + y * y);
+    return R;
+}
+// rotation -> quaternion xyzw, canonical sign w >= 0
+MPPI_HD void R_to_quat(const M3 &Rm, float *q) {
+    const float *R = Rm.a;
+    float tr = R[0] + R[4] + R[8], x, y, z, w;
+    if (tr > 0.f) {
+        float s = sqrtf(tr + 1.f) * 2.f;
+        w = 0.25f * s; x = (R[7] - R[5]) / s; y = (R[2] - R[6]) / s; z = (R[3] - R[1]) / s;
+    } else if (R[0] > R[4] && R[0] > R[8]) {
+        float s = sqrtf(1.f + R[0] - R[4] - R[8]) * 2.f;
+        w = (R[7] - R[5]) / s; x = 0.25f * s; y = (R[1] + R[3]) / s; z = (R[2] + R[6]) / s;
+    } else if (R[4] > R[8]) {
+        float s = sqrtf(1.f + R[4] - R[0] - R[8]) * 2.f;
+        w = (R[2] - R[6]) / s; x = (R[1] + R[3]) / s; y = 0.25f * s; z = (R[5] + R[7]) / s;
+    } else {
+        float s = sqrtf(1.f + R[8] - R[0] - R[4]) * 2.f;
+        w = (R[3] - R[1]) / s; x = (R[2] + R[6]) / s; y = (R[5] + R[7]) / s; z = 0.25f * s;
+    }
+    if (w < 0.f) { x = -x; y = -y; z = -z; w = -w; }
+    q[0] = x; q[1] = y; q[2] = z; q[3] = w;
+}
+
+// ---- spatial quantities in world axes about the world origin ----------------------------
+struct SV {  // motion (w, vO) or force (nO, f)
+    V3 a, l;
+};
+MPPI_HD SV operator+(SV p, SV q) { return {p.a + q.a, p.l + q.l}; }
+MPPI_HD float dot(SV p, SV q) { return dot(p.a, q.a) + dot(p.l, q.l); }
+// general symmetric 6x6 [[I, H],[H^T, M]]
+struct AI {
+    S3 I;
+    float H[9];
+    S3 M;
+};
+MPPI_HD SV mul(const AI &A, SV v) {
+    V3 n = mul(A.I, v.a), f = mul(A.M, v.l);
+    n.x += A.H[0] * v.l.x + A.H[1] * v.l.y + A.H[2] * v.l.z;
+    n.y += A.H[3] * v.l.x + A.H[4] * v.l.y + A.H[5] * v.l.z;
+    n.z += A.H[6] * v.l.x + A.H[7] * v.l.y + A.H[8] * v.l.z;
+    f.x += A.H[0] * v.a.x + A.H[3] * v.a.y + A.H[6] * v.a.z;
+    f.y += A.H[1] * v.a.x + A.H[4] * v.a.y + A.H[7] * v.a.z;
+    f.z += A.H[2] * v.a.x + A.H[5] * v.a.y + A.H[8] * v.a.z;
+    return {n, f};
+}
+MPPI_HD void add_to(AI &A, const AI &B) {
+    A.I.xx += B.I.xx; A.I.xy += B.I.xy; A.I.xz += B.I.xz; A.I.yy += B.I.yy; A.I.yz += B.I.yz; A.I.zz += B.I.zz;
+    for (int i = 0; i < 9; i++) A.H[i] += B.H[i];
+    A.M.xx += B.M.xx; A.M.xy += B.M.xy; A.M.xz += B.M.xz; A.M.yy += B.M.yy; A.M.yz += B.M.yz; A.M.zz += B.M.zz;
+}
+// A -= U U^T * s
+MPPI_HD void rank1_sub(AI &A, SV U, float s) {
+    V3 n = s * U.a, f = s * U.l;
+    A.I.xx -= U.a.x * n.x; A.I.xy -= U.a.x * n.y; A.I.xz -= U.a.x * n.z; A.I.yy -= U.a.y * n.y; A.I.yz -= U.a.y * n.z; A.I.zz -= U.a.z * n.z;
+    A.H[0] -= U.a.x * f.x; A.H[1] -= U.a.x * f.y; A.H[2] -= U.a.x * f.z;
+    A.H[3] -= U.a.y * f.x; A.H[4] -= U.a.y * f.y; A.H[5] -= U.a.y * f.z;
+    A.H[6] -= U.a.z * f.x; A.H[7] -= U.a.z * f.y; A.H[8] -= U.a.z * f.z;
+    A.M.xx -= U.l.x * f.x; A.M.xy -= U.l.x * f.y; A.M.xz -= U.l.x * f.z; A.M.yy -= U.l.y * f.y; A.M.yz -= U.l.y * f.z; A.M.zz -= U.l.z * f.z;
+}
+
+// World pose of every moving body for joint positions q (z-framed joints).
+template <class T>
+struct Pose {
+    M3 R[T::NB ? T::NB : 1];
+    V3 p[T::NB ? T::NB : 1];
+    M3 Rb;
+    V3 pb;
+};
+
+#define MPPI_LAMBDA __attribute__((always_inline))
+
+// sin and cos with a 3-term Cody-Waite reduction by pi/2 and cephes minimax polynomials on
+// [-pi/4, pi/4] (~1 ulp for |x| < 1e4).  Replaces ocml's sincosf, whose large-argument path keeps a
+// private array in scratch memory; identical arithmetic on host and device.
+MPPI_HD void fast_sincos(float x, float &s, float &c) {
+    float k = rintf(x * 0.636619772367581343f);
+    float r = fmaf(k, -1.5703125f, x);
+    r = fmaf(k, -4.837512969970703125e-4f, r);
+    r = fmaf(k, -7.54978995489188216e-8f, r);
+    int ki = (int)k;
+    float r2 = r * r;
+    float sp = fmaf(fmaf(fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f), r2 * r, r);
+    float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f), r2 * r2, fmaf(-0.5f, r2, 1.0f));
+    float ss = (ki & 1) ? cp : sp;
+    float cc = (ki & 1) ? sp : cp;
+    s = (ki & 2) ? -ss : ss;
+    c = ((ki + 1) & 2) ? -cc : cc;
+}
+
+template <class T>
+MPPI_HD void forward_kinematics(CModel &m, const float *root, const float *q, Pose<T> &P) {
+    const float *rs = root + 13 * m.robot_actor;
+    P.pb = loadv(rs);
+    P.Rb = quat_to_R(rs + 3);
+    static_for<0, T::NB>([&](auto ic) MPPI_LAMBDA {
+        constexpr int i = ic;
+        constexpr int par = T::par[i];
+        CBody &b = m.b[i];
+        const M3 &Rp = par < 0 ? P.Rb : P.R[par < 0 ? 0 : par];
+        const V3 pp = par < 0 ? P.pb : P.p[par < 0 ? 0 : par];
+        M3 RT = mul(Rp, load3(b.Rt));
+        V3 pw = pp + mul(Rp, loadv(b.pt));
+        if (b.jtype == 0) {  // revolute about local z: R = RT * Rz(q)
+            float s, c;
+            fast_sincos(q[i], s, c);
+            M3 R;
+            for (int r = 0; r < 3; r++) {
+                R.a[3 * r + 0] = c * RT.a[3 * r] + s * RT.a[3 * r + 1];
+                R.a[3 * r + 1] = c * RT.a[3 * r + 1] - s * RT.a[3 * r];
+                R.a[3 * r + 2] = RT.a[3 * r + 2];
+            }
+            P.R[i] = R;
+            P.p[i] = pw;
+        } else {  // prismatic along local z
+            V3 az = {RT.a[2], RT.a[5], RT.a[8]};
+            P.R[i] = RT;
+            P.p[i] = pw + q[i] * az;
+        }
+    });
+}
+
+// joint motion subspace (world axes, about the world origin) of body i
+template <class T, int i>
+MPPI_HD SV joint_subspace(CModel &m, const Pose<T> &P) {
+    V3 az = {P.R[i].a[2], P.R[i].a[5], P.R[i].a[8]};
+    if (m.b[i].jtype == 0) return {az, cross(P.p[i], az)};
+    return {{0.f, 0.f, 0.f}, az};
+}
+
+// One articulated-body solve (Featherstone ABA, world-frame form) with the implicit joint drive
+// folded into the joint-space inertia: d_i = S_i^T IA_i S_i + kdh[i];  tau_exp = explicit part.
+// Register diet: only poses (12) and velocities (6) per body are carried between the passes; the
+// rigid inertia, bias force, S and c of a body are formed when the backward sweep reaches it.
+template <class T>
+MPPI_HD void aba_world(CModel &m, const Pose<T> &P, const float *qd, const float *tau_exp, const float *kdh, float *qdd) {
+    constexpr int NB = T::NB;
+    SV v[NB], U[NB];
+    AI acc[NB];   // children's articulated inertia, accumulated on the parent (live only while pending)
+    SV pacc[NB];
+    float invd[NB], u[NB];
+    bool has_acc[NB];
+    // pass 1: spatial velocities, root to leaves
+    static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
+        constexpr int i = ic;
+        constexpr int par = T::par[i];
+        SV S = joint_subspace<T, i>(m, P);
+        SV sj = {qd[i] * S.a, qd[i] * S.l};
+        if constexpr (par < 0) v[i] = sj;
+        else v[i] = v[par < 0 ? 0 : par] + sj;
+        has_acc[i] = false;
+    });
+    // pass 2: articulated inertias, leaves to root (world frame: propagation is an addition)
+    static_rfor<0, NB>([&](auto ic) MPPI_LAMBDA {
+        constexpr int i = ic;
+        constexpr int par = T::par[i];
+        CBody &b = m.b[i];
+        const M3 &R = P.R[i];
+        SV S = joint_subspace<T, i>(m, P);
+        // rigid inertia about the world origin: I_O = R Ic R^T + m(|cw|^2 1 - cw cw^T), h = m cw
+        V3 h = mul(R, loadv(b.hb)) + b.m * P.p[i];
+        float T9[9];  // T = R * Ic
+        for (int r = 0; r < 3; r++) {
+            float r0 = R.a[3 * r], r1 = R.a[3 * r + 1], r2 = R.a[3 * r + 2];
+            T9[3 * r + 0] = r0 * b.Ic[0] + r1 * b.Ic[1] + r2 * b.Ic[2];
+            T9[3 * r + 1] = r0 * b.Ic[1] + r1 * b.Ic[3] + r2 * b.Ic[4];
+            T9[3 * r + 2] = r0 * b.Ic[2] + r1 * b.Ic[4] + r2 * b.Ic[5];
+        }
+        float invm = b.m > 0.f ? 1.f / b.m : 0.f;
+        V3 cw = invm * h;
+        float hh = dot(h, cw);
+        AI A;
+        A.I.xx = T9[0] * R.a[0] + T9[1] * R.a[1] + T9[2] * R.a[2] + hh - h.x * cw.x;
+        A.I.xy = T9[0] * R.a[3] + T9[1] * R.a[4] + T9[2] * R.a[5] - h.x * cw.y;
+        A.I.xz = T9[0] * R.a[6] + T9[1] * R.a[7] + T9[2] * R.a[8] - h.x * cw.z;
+        A.I.yy = T9[3] * R.a[3] + T9[4] * R.a[4] + T9[5] * R.a[5] + hh - h.y * cw.y;
+        A.I.yz = T9[3] * R.a[6] + T9[4] * R.a[7] + T9[5] * R.a[8] - h.y * cw.z;
+        A.I.zz = T9[6] * R.a[6] + T9[7] * R.a[7] + T9[8] * R.a[8] + hh - h.z * cw.z;
+        A.H[0] = 0.f;  A.H[1] = -h.z; A.H[2] = h.y;
+        A.H[3] = h.z;  A.H[4] = 0.f;  A.H[5] = -h.x;
+        A.H[6] = -h.y; A.H[7] = h.x;  A.H[8] = 0.f;
+        A.M = {b.m, 0.f, 0.f, b.m, 0.f, b.m};
+        // bias force v x* (I v) of the rigid body
+        V3 n = mul(A.I, v[i].a) + cross(h, v[i].l);
+        V3 f = b.m * v[i].l + cross(v[i].a, h);
+        SV pA = {cross(v[i].a, n) + cross(v[i].l, f), cross(v[i].a, f)};
+        if (has_acc[i]) {
+            add_to(A, acc[i]);
+            pA = pA + pacc[i];
+        }
+        U[i] = mul(A, S);
+        float d = dot(S, U[i]) + kdh[i];
+        invd[i] = 1.f / d;
+        u[i] = tau_exp[i] - dot(S, pA);
+        if constexpr (par >= 0) {
+            // c = v_parent x (S qd);  pa = pA + IA c + U (u - U.c)/d;  Ia = IA - U U^T / d
+            const SV vp = v[par < 0 ? 0 : par];
+            SV sj = {qd[i] * S.a, qd[i] * S.l};
+            SV c = {cross(vp.a, sj.a), cross(vp.a, sj.l) + cross(vp.l, sj.a)};
+            SV Ic_ = mul(A, c);
+            float k = (u[i] - dot(U[i], c)) * invd[i];
+            SV pa = {pA.a + Ic_.a + k * U[i].a, pA.l + Ic_.l + k * U[i].l};
+            rank1_sub(A, U[i], invd[i]);
+            constexpr int pj = par < 0 ? 0 : par;
+            if (has_acc[pj]) {
+                add_to(acc[pj], A);
+                pacc[pj] = pacc[pj] + pa;
+            } else {
+                acc[pj] = A;
+                pacc[pj] = pa;
+                has_acc[pj] = true;
+            }
+        }
+    });
+    // pass 3: accelerations, root to leaves.  Gravity = fictitious base acceleration -g.
+    SV a[NB];
+    SV a0 = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    if (m.gravity_on) a0.l = {-m.g[0], -m.g[1], -m.g[2]};
+    static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
+        constexpr int i = ic;
+        constexpr int par = T::par[i];
+        SV S = joint_subspace<T, i>(m, P);
+        SV ap = a0;
+        if constexpr (par >= 0) {
+            const SV vp = v[par < 0 ? 0 : par];
+            SV sj = {qd[i] * S.a, qd[i] * S.l};
+            SV c = {cross(vp.a, sj.a), cross(vp.a, sj.l) + cross(vp.l, sj.a)};
+            ap = a[par < 0 ? 0 : par] + c;
+        }
+        float dd = (u[i] - dot(U[i], ap)) * invd[i];
+        qdd[i] = dd;
+        a[i] = {ap.a + dd * S.a, ap.l + dd * S.l};
+    });
+}
+
+// apply_robot_cmd: control u[nu] -> per-DOF drive target (reference isaacgym_wrapper.py:524-572)
+template <class T>
+MPPI_HD void cmd_map(CModel &m, const float *u, float *target) {
+    static_for<0, T::NB>([&](auto ic) MPPI_LAMBDA {
+        constexpr int i = ic;
+        CBody &b = m.b[i];
+        float t = 0.f;
+#pragma unroll
+        for (int c = 0; c < kMaxNu; c++)
+            if (c < m.nu) t += b.cmd[c] * u[c];
+        target[i] = t;
+    });
+}
+
+// One simulator step dt = substeps * h (semi-implicit Euler, implicit velocity-level drive,
+// drive-force clamp by one re-solve, velocity clamp, inelastic joint limits).  SURVEY.md B.
+template <class T>
+MPPI_HD void step(CModel &m0, const float *root, float *q, float *qd, const float *target) {
+    constexpr int NB = T::NB;
+    CModel *mp = &m0;
+    for (int s = 0; s < m0.substeps; s++) {
+        CModel &m = *launder(mp);  // re-fetch model constants per substep (see launder())
+        const float h = m.h, kd = m.kd;
+        Pose<T> P;
+        forward_kinematics<T>(m, root, q, P);
+        float tau[NB], kdh[NB], qdd[NB], ff[NB], vs[NB];
+        static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
+            constexpr int i = ic;
+            ff[i] = m.drive_mode == kDriveEffort ? target[i] : 0.f;
+            vs[i] = m.drive_mode == kDriveVelocity ? target[i] : 0.f;
+            tau[i] = ff[i] + kd * (vs[i] - qd[i]);
+            kdh[i] = kd * h;
+        });
+        aba_world<T>(m, P, qd, tau, kdh, qdd);
+        bool any = false;
+        static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
+            constexpr int i = ic;
+            float lim = m.b[i].effort;
+            float tt = ff[i] + kd * (vs[i] - qd[i] - h * qdd[i]);
+            if (lim > 0.f && fabsf(tt) > lim) {
+                any = true;
+                tau[i] = tt > 0.f ? lim : -lim;
+                kdh[i] = 0.f;
+            }
+        });
+        if (any) aba_world<T>(*launder(mp), P, qd, tau, kdh, qdd);
+        static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
+            constexpr int i = ic;
+            CBody &b = m.b[i];
+            float v = qd[i] + h * qdd[i];
+            if (b.vmax > 0.f) v = fminf(fmaxf(v, -b.vmax), b.vmax);
+            float x = q[i] + h * v;
+            if (b.limited) {
+                if (x < b.lower) { x = b.lower; v = fmaxf(v, 0.f); }
+                if (x > b.upper) { x = b.upper; v = fminf(v, 0.f); }
+            }
+            q[i] = x;
+            qd[i] = v;
+        });
+    }
+}
+
+// world pose of link l (R, p) from body poses.  The body a link is welded to is a run-time
+// (wave-uniform) index; it is resolved by a 0/1-weighted blend over the compile-time body list
+// instead of a select chain, because the optimiser turns "select between array elements" into an
+// indexed load and then keeps the whole Pose in scratch memory.
+template <class T>
+MPPI_HD void link_pose(CModel &m, const Pose<T> &P, int l, M3 &R, V3 &p) {
+    CLink &L = m.l[l];
+    const int body = L.body;
+    float wb = body < 0 ? 1.f : 0.f;
+    M3 Rb;
+    for (int j = 0; j < 9; j++) Rb.a[j] = wb * P.Rb.a[j];
+    V3 pb = wb * P.pb;
+    static_for<0, T::NB>([&](auto ic) MPPI_LAMBDA {
+        constexpr int i = ic;
+        const float w = body == i ? 1.f : 0.f;
+        for (int j = 0; j < 9; j++) Rb.a[j] += w * P.R[i].a[j];
+        pb = pb + w * P.p[i];
+    });
+    R = mul(Rb, load3(L.R));
+    p = pb + mul(Rb, loadv(L.p));
+}
+
+MPPI_HD float clamp1(float x) { return fminf(fmaxf(x, -1.f), 1.f); }
+
+// Fused stage cost (DevCost.kind).  See include/mppi_hip.h for the reference Objective each restates.
+template <class T>
+MPPI_HD float stage_cost(CModel &m, CCost &c, const float *root, const float *q, const float *qd) {
+    if (c.kind == kCostPointReach) {
+        float gx = c.actor[0] >= 0 ? root[13 * c.actor[0]] : c.w[1];
+        float gy = c.actor[0] >= 0 ? root[13 * c.actor[0] + 1] : c.w[2];
+        float dx = q[0] - gx, dy = q[T::NB > 1 ? 1 : 0] - gy;
+        return c.w[0] * sqrtf(dx * dx + dy * dy);
+    }
+    if (c.kind == kCostPandaReach) {
+        Pose<T> P;
+        forward_kinematics<T>(m, root, q, P);
+        M3 R;
+        V3 p;
+        link_pose<T>(m, P, c.link[0], R, p);
+        V3 d = p - loadv(root + 13 * c.actor[0]);
+        float dist = sqrtf(dot(d, d));
+        // The reference feeds the xyzw link quaternion to pytorch3d's (r,i,j,k) API and takes the first
+        // two ZYX Euler angles (examples/panda/planner.py:30-32).  For a unit quaternion the permuted
+        // matrix entries are linear in the true rotation: M00 = -R22, M10 = R21, M20 = -R20.
+        float a0 = atan2f(R.a[7], -R.a[8]);
+        float a1 = asinf(clamp1(R.a[6]));
+        return c.w[0] * dist + c.w[1] * sqrtf(a0 * a0 + a1 * a1);
+    }
+    return 0.f;
+}
+
+// Whole-horizon rollout of ONE sample (lane).  eps/du are sample-minor: [(t*nu+c)*K + k].
+// Returns S_k = sum_t gamma^t c_t + lambda * sum_t U_t^T Sigma^-1 du_t   (SURVEY.md A).
+template <class T>
+MPPI_HD float rollout_sample(CModel &m0, CCfg &cfg0, CCost &cost0, const float *dof0, const float *root, const float *U, const float *eps,
+                             const float *prior, float *du, float *viz, int k) {
+    constexpr int NB = T::NB;
+    const int K = cfg0.K, nu = cfg0.nu, H = cfg0.H;
+    const int g = cfg0.k_offset + k;
+    const bool is_null = cfg0.sample_null_action && g == cfg0.k_total - 1;
+    const bool is_prior = cfg0.use_priors && prior != nullptr && g == cfg0.k_total - 2;
+    float q[NB], qd[NB], target[NB], u[kMaxNu];
+    static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
+        constexpr int i = ic;
+        q[i] = dof0[2 * i];
+        qd[i] = dof0[2 * i + 1];
+    });
+    float S = 0.f, ctrl = 0.f, disc = 1.f;
+    CModel *mp = &m0;
+    CCfg *cp = &cfg0;
+    CCost *kp = &cost0;
+    for (int t = 0; t < H; t++) {
+        CCfg &cfg = *launder(cp);
+#pragma unroll
+        for (int c = 0; c < kMaxNu; c++) {
+            if (c < nu) {
+                float Ut = U[t * nu + c];
+                float v = Ut + eps[(size_t)(t * nu + c) * K + k];
+                if (is_null) v = 0.f;
+                if (is_prior) v = prior[t * nu + c];
+                v = fminf(fmaxf(v, cfg.u_min[c]), cfg.u_max[c]);
+                u[c] = v;
+                float d = v - Ut;
+                du[(size_t)(t * nu + c) * K + k] = d;
+                float term = Ut * d * cfg.inv_sigma[c];
+                ctrl += cfg.lambda * (cfg.noise_abs_cost ? fabsf(term) : term);
+            } else {
+                u[c] = 0.f;
+            }
+        }
+        cmd_map<T>(*launder(mp), u, target);
+        step<T>(*mp, root, q, qd, target);
+        S += disc * stage_cost<T>(*launder(mp), *launder(kp), root, q, qd);
+        disc *= cfg.gamma;
+        if (cfg.want_rollouts && viz != nullptr) {
+            CModel &m = *launder(mp);
+            Pose<T> P;
+            forward_kinematics<T>(m, root, q, P);
+            M3 R;
+            V3 p;
+            link_pose<T>(m, P, cfg.viz_link, R, p);
+            float *o = viz + ((size_t)t * K + k) * 3;
+            o[0] = p.x; o[1] = p.y; o[2] = p.z;
+        }
+    }
+    return S + ctrl;
+}
+
+// rigid_body_state rows [n_rb][13] + net_contact_force [n_rb][3] of one env, reference layout.
+template <class T>
+MPPI_HD void rigid_body_state(CModel &m, const float *root, const float *q, const float *qd, float *rb, float *cf) {
+    constexpr int NB = T::NB;
+    Pose<T> P;
+    forward_kinematics<T>(m, root, q, P);
+    // body spatial velocities (world frame, about the world origin)
+    SV v[NB ? NB : 1];
+    static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
+        constexpr int i = ic;
+        constexpr int par = T::par[i];
+        SV S = joint_subspace<T, i>(m, P);
+        SV sj = {qd[i] * S.a, qd[i] * S.l};
+        if constexpr (par < 0) v[i] = sj;
+        else v[i] = v[par < 0 ? 0 : par] + sj;
+    });
+    for (int a = 0; a < m.n_actors; a++) {
+        if (a == m.robot_actor) continue;
+        float *o = rb + 13 * m.actor_first_rb[a];
+        for (int j = 0; j < 13; j++) o[j] = root[13 * a + j];
+    }
+    for (int l = 0; l < m.nl; l++) {
+        M3 R;
+        V3 p;
+        link_pose<T>(m, P, l, R, p);
+        SV vb = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+        static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
+            constexpr int i = ic;
+            const float w = m.l[l].body == i ? 1.f : 0.f;
+            vb = {vb.a + w * v[i].a, vb.l + w * v[i].l};
+        });
+        V3 lv = vb.l + cross(vb.a, p);  // velocity of the link origin
+        float *o = rb + 13 * (m.robot_first_rb + l);
+        o[0] = p.x; o[1] = p.y; o[2] = p.z;
+        R_to_quat(R, o + 3);
+        o[7] = lv.x; o[8] = lv.y; o[9] = lv.z;
+        o[10] = vb.a.x; o[11] = vb.a.y; o[12] = vb.a.z;
+    }
+    if (cf != nullptr)
+        for (int j = 0; j < 3 * m.n_rb; j++) cf[j] = 0.f;
+}
+
+}  // namespace mppi

@@ -1,0 +1,725 @@
+// mppi_hip.hip - gfx950 kernels and the C-ABI (include/mppi_hip.h) of the MPPI rollout backend.
+//
+// Launch structure of one control iteration (replaces the reference's Python horizon loop with
+// ~H x (gym set + simulate + fetch + 4 refresh + 15-40 torch kernels), reference
+// mppiisaac/planner/mppi_isaac.py:57-69 / SURVEY.md 3.1):
+//   k_rollout<Topo>      one lane = one sample, persistent over the whole horizon: perturb/clamp the
+//                        nominal controls, H x substeps articulated-body steps, fused stage cost,
+//                        discounted sum.  State never leaves registers; HBM traffic = eps in, du/S out.
+//   k_reduce             one wave per 64 samples: beta = min S, w = exp(-(S-beta)/lambda), eta, N = sum w du
+//                        by wavefront shuffles -> one partial record per wave.
+//   k_combine            rescales and sums partial / shard records (the same formula joins waves,
+//                        and GPUs after the RCCL all-gather), updates and shifts the nominal U, emits
+//                        the action.
+// Buffers are sample-minor so every per-sample access of a wave is one coalesced 256-B request.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mppi_pack.hpp"
+
+using namespace mppi;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                         \
+    do {                                                                                                      \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess) return fail(MPPI_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+    } while (0)
+
+constexpr int kWave = 64;
+
+// ------------------------------------------------------------------------------ wave helpers
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, kWave));
+    return v;
+}
+
+// ------------------------------------------------------------------------------ kernels
+template <class T>
+__global__ __launch_bounds__(kWave) void k_rollout(const DevModel *__restrict__ m, const DevCfg *__restrict__ cfg,
+                                                   const DevCost *__restrict__ cost, const float *__restrict__ x0_dof,
+                                                   const float *__restrict__ x0_root, const float *__restrict__ U,
+                                                   const float *__restrict__ eps, const float *__restrict__ prior,
+                                                   float *__restrict__ du, float *__restrict__ S, float *__restrict__ viz) {
+    const int k = blockIdx.x * kWave + threadIdx.x;
+    if (k >= cfg->K) return;
+    S[k] = rollout_sample<T>(*(CModel *)m, *(CCfg *)cfg, *(CCost *)cost, x0_dof, x0_root, U, eps, prior, du, viz, k);
+}
+
+// one wave per 64 samples -> partial record [beta, eta, N[HN]]
+__global__ __launch_bounds__(kWave) void k_reduce(const DevCfg *__restrict__ cfg, const float *__restrict__ S,
+                                                  const float *__restrict__ du, float *__restrict__ partials) {
+    const int K = cfg->K, HN = cfg->H * cfg->nu;
+    const int k = blockIdx.x * kWave + threadIdx.x;
+    const bool live = k < K;
+    float s = live ? S[k] : INFINITY;
+    const bool fin = live && isfinite(s);  // NaN / Inf trajectory cost -> weight 0
+    float beta = wave_min(fin ? s : INFINITY);
+    float w = fin ? __expf(-(s - beta) * cfg->inv_lambda) : 0.f;
+    float eta = wave_sum(w);
+    float *rec = partials + (size_t)blockIdx.x * (2 + HN);
+    if (threadIdx.x == 0) {
+        rec[0] = beta;
+        rec[1] = eta;
+    }
+    for (int j = 0; j < HN; j++) {
+        float x = live ? w * du[(size_t)j * K + k] : 0.f;
+        x = wave_sum(x);
+        if (threadIdx.x == 0) rec[2 + j] = x;
+    }
+}
+
+// Combine n records; mode 0: write the combined record to `out`; mode 1: U += N/eta, action, shift.
+__global__ __launch_bounds__(256) void k_combine(const DevCfg *__restrict__ cfg, const float *__restrict__ recs, int nrec, int mode,
+                                                 float *__restrict__ out, float *__restrict__ U, float *__restrict__ action,
+                                                 float *__restrict__ beta_eta) {
+    __shared__ float s_red[256];
+    __shared__ float s_U[MPPI_MAX_H * MPPI_MAX_NU];
+    const int HN = cfg->H * cfg->nu, RF = 2 + HN, nu = cfg->nu;
+    const int tid = threadIdx.x;
+    float b = INFINITY;
+    for (int r = tid; r < nrec; r += 256)
+        if (recs[(size_t)r * RF + 1] > 0.f) b = fminf(b, recs[(size_t)r * RF]);
+    s_red[tid] = b;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) s_red[tid] = fminf(s_red[tid], s_red[tid + o]);
+        __syncthreads();
+    }
+    const float beta = s_red[0];
+    __syncthreads();
+    float e = 0.f;
+    for (int r = tid; r < nrec; r += 256) {
+        float er = recs[(size_t)r * RF + 1];
+        if (er > 0.f) e += er * __expf(-(recs[(size_t)r * RF] - beta) * cfg->inv_lambda);
+    }
+    s_red[tid] = e;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) s_red[tid] += s_red[tid + o];
+        __syncthreads();
+    }
+    const float eta = s_red[0];
+    for (int j = tid; j < HN; j += 256) {
+        float N = 0.f;
+        for (int r = 0; r < nrec; r++) {
+            float er = recs[(size_t)r * RF + 1];
+            if (er > 0.f) N += recs[(size_t)r * RF + 2 + j] * __expf(-(recs[(size_t)r * RF] - beta) * cfg->inv_lambda);
+        }
+        if (mode == 0) out[2 + j] = N;
+        else s_U[j] = U[j] + (eta > 0.f ? N / eta : 0.f);
+    }
+    if (mode == 0) {
+        if (tid == 0) {
+            out[0] = beta;
+            out[1] = eta;
+        }
+        return;
+    }
+    __syncthreads();
+    if (tid < nu) action[tid] = s_U[tid];
+    if (tid == 0) {
+        beta_eta[0] = beta;
+        beta_eta[1] = eta;
+    }
+    for (int j = tid; j < HN; j += 256) U[j] = (j + nu < HN) ? s_U[j + nu] : cfg->u_init;  // shift, append u_init
+}
+
+// ---- halton-spline sampler -------------------------------------------------------------------
+__constant__ int c_primes[MPPI_MAX_KNOTS * MPPI_MAX_NU] = {
+    2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37, 41, 43, 47, 53, 59, 61, 67, 71, 73, 79, 83, 89, 97, 101, 103, 107, 109, 113,
+    127, 131, 137, 139, 149, 151, 157, 163, 167, 173, 179, 181, 191, 193, 197, 199, 211, 223, 227, 229, 233, 239, 241, 251,
+    257, 263, 269, 271, 277, 281, 283, 293, 307, 311, 313, 317, 331, 337, 347, 349, 353, 359, 367, 373, 379, 383, 389, 397,
+    401, 409, 419, 421, 431, 433, 439, 443, 449, 457, 461, 463, 467, 479, 487, 491, 499, 503, 509, 521, 523, 541, 547, 557,
+    563, 569, 571, 577, 587, 593, 599, 601, 607, 613, 617, 619, 631, 641, 643, 647, 653, 659, 661, 673, 677, 683, 691, 701,
+    709, 719, 727, 733, 739, 743, 751, 757, 761, 769, 773, 787, 797, 809, 811, 821, 823, 827, 829, 839, 853, 857, 859, 863,
+    877, 881, 883, 887, 907, 911, 919, 929, 937, 941, 947, 953, 967, 971, 977, 983, 991, 997, 1009, 1013, 1019, 1021, 1031,
+    1033, 1039, 1049, 1051, 1061, 1063, 1069, 1087, 1091, 1093, 1097, 1103, 1109, 1117, 1123, 1129, 1151, 1153, 1163};
+
+// linearly digit-scrambled radical inverse in double (digit -> digit*mult mod p, mult = round(0.618 p))
+__device__ double halton_scrambled(uint32_t n, int dim) {
+    const uint32_t p = (uint32_t)c_primes[dim];
+    uint32_t mult = (uint32_t)(0.6180339887498949 * (double)p + 0.5);
+    if (mult < 1u) mult = 1u;
+    double f = 1.0 / (double)p, r = 0.0;
+    const double invp = f;
+    while (n > 0u) {
+        uint32_t dgt = n % p;
+        r += f * (double)((dgt * mult) % p);
+        n /= p;
+        f *= invp;
+    }
+    return r;
+}
+
+// eps[(t*nu+c)*K + k] = sigma_c * sum_i B[t][i] * Phi^-1(halton(g+1+base, i*nu+c))
+__global__ __launch_bounds__(kWave) void k_sample(const DevCfg *__restrict__ cfg, const double *__restrict__ basis, const double *__restrict__ sigma,
+                                                  int n_knots, uint32_t index_base, float *__restrict__ eps) {
+    const int K = cfg->K, H = cfg->H, nu = cfg->nu;
+    const int k = blockIdx.x * kWave + threadIdx.x;
+    if (k >= K) return;
+    const uint32_t n = (uint32_t)(cfg->k_offset + k) + 1u + index_base;
+    for (int c = 0; c < nu; c++) {
+        double z[MPPI_MAX_KNOTS];
+        for (int i = 0; i < n_knots; i++) z[i] = normcdfinv(halton_scrambled(n, i * nu + c));
+        for (int t = 0; t < H; t++) {
+            double s = 0.0;
+            for (int i = 0; i < n_knots; i++) s += basis[t * n_knots + i] * z[i];
+            eps[(size_t)(t * nu + c) * K + k] = (float)(sigma[c] * s);
+        }
+    }
+}
+
+// ---- batched simulator (generic Objective mode, K=1 world) -------------------------------------
+__global__ void k_sim_reset(int K, int n, const float *__restrict__ x0_dof, float *__restrict__ q, float *__restrict__ qd,
+                            float *__restrict__ S, float *__restrict__ ctrl) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    for (int i = 0; i < n; i++) {
+        q[(size_t)i * K + k] = x0_dof[2 * i];
+        qd[(size_t)i * K + k] = x0_dof[2 * i + 1];
+    }
+    S[k] = 0.f;
+    ctrl[k] = 0.f;
+}
+
+// mode 0: u_ext is [K][nu] (reference layout), mode 1: u_ext is one shared [nu], mode 2: horizon step t
+template <class T>
+__global__ __launch_bounds__(kWave) void k_sim_step(const DevModel *__restrict__ m, const DevCfg *__restrict__ cfg, int mode, int t,
+                                                    const float *__restrict__ u_ext, const float *__restrict__ x0_root,
+                                                    const float *__restrict__ U, const float *__restrict__ eps, const float *__restrict__ prior,
+                                                    float *__restrict__ du, float *__restrict__ ctrl, float *__restrict__ q_, float *__restrict__ qd_) {
+    constexpr int NB = T::NB;
+    const int K = cfg->K, nu = cfg->nu;
+    const int k = blockIdx.x * kWave + threadIdx.x;
+    if (k >= K) return;
+    float q[NB], qd[NB], target[NB], u[kMaxNu];
+    static_for<0, NB>([&](auto ic) {
+        constexpr int i = ic;
+        q[i] = q_[(size_t)i * K + k];
+        qd[i] = qd_[(size_t)i * K + k];
+    });
+    const int g = cfg->k_offset + k;
+    float cc = 0.f;
+#pragma unroll
+    for (int c = 0; c < kMaxNu; c++) {
+        float v = 0.f;
+        if (c < nu) {
+            if (mode == 0) v = u_ext[(size_t)k * nu + c];
+            else if (mode == 1) v = u_ext[c];
+            else {
+                float Ut = U[t * nu + c];
+                v = Ut + eps[(size_t)(t * nu + c) * K + k];
+                if (cfg->sample_null_action && g == cfg->k_total - 1) v = 0.f;
+                if (cfg->use_priors && prior != nullptr && g == cfg->k_total - 2) v = prior[t * nu + c];
+                v = fminf(fmaxf(v, cfg->u_min[c]), cfg->u_max[c]);
+                float d = v - Ut;
+                du[(size_t)(t * nu + c) * K + k] = d;
+                float term = Ut * d * cfg->inv_sigma[c];
+                cc += cfg->lambda * (cfg->noise_abs_cost ? fabsf(term) : term);
+            }
+        }
+        u[c] = v;
+    }
+    if (mode == 2) ctrl[k] += cc;
+    cmd_map<T>(*(CModel *)m, u, target);
+    step<T>(*(CModel *)m, x0_root, q, qd, target);
+    static_for<0, NB>([&](auto ic) {
+        constexpr int i = ic;
+        q_[(size_t)i * K + k] = q[i];
+        qd_[(size_t)i * K + k] = qd[i];
+    });
+}
+
+// sample-minor sim state -> reference-layout tensors (isaacgym_wrapper.py:186-199)
+template <class T>
+__global__ __launch_bounds__(kWave) void k_materialise(const DevModel *__restrict__ m, int K, const float *__restrict__ x0_root,
+                                                       const float *__restrict__ q_, const float *__restrict__ qd_, float *__restrict__ dof,
+                                                       float *__restrict__ root, float *__restrict__ rb, float *__restrict__ cf) {
+    constexpr int NB = T::NB;
+    const int k = blockIdx.x * kWave + threadIdx.x;
+    if (k >= K) return;
+    float q[NB ? NB : 1], qd[NB ? NB : 1];
+    static_for<0, NB>([&](auto ic) {
+        constexpr int i = ic;
+        q[i] = q_[(size_t)i * K + k];
+        qd[i] = qd_[(size_t)i * K + k];
+        if (dof != nullptr) {
+            dof[(size_t)k * 2 * NB + 2 * i] = q[i];
+            dof[(size_t)k * 2 * NB + 2 * i + 1] = qd[i];
+        }
+    });
+    const int A = m->n_actors, B = m->n_rb;
+    if (root != nullptr)
+        for (int j = 0; j < 13 * A; j++) root[(size_t)k * 13 * A + j] = x0_root[j];
+    if (rb != nullptr) rigid_body_state<T>(*(CModel *)m, x0_root, q, qd, rb + (size_t)k * 13 * B, cf != nullptr ? cf + (size_t)k * 3 * B : nullptr);
+    else if (cf != nullptr)
+        for (int j = 0; j < 3 * B; j++) cf[(size_t)k * 3 * B + j] = 0.f;
+}
+
+__global__ void k_accumulate_cost(int K, float disc, const float *__restrict__ c, float *__restrict__ S) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < K) S[k] += disc * c[k];
+}
+__global__ void k_sim_finish(int K, const float *__restrict__ ctrl, float *__restrict__ S) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < K) S[k] += ctrl[k];
+}
+// planner.x0_dof <- world env 0 (K_world = 1: sample-minor == plain arrays)
+__global__ void k_state_from_world(int n, const float *__restrict__ wq, const float *__restrict__ wqd, float *__restrict__ x0_dof) {
+    const int i = threadIdx.x;
+    if (i < n) {
+        x0_dof[2 * i] = wq[i];
+        x0_dof[2 * i + 1] = wqd[i];
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------ context
+struct mppi_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    mppi_model_t model;
+    mppi_config_t cfg;
+    DevModel hm;
+    DevCfg hc;
+    DevCost hk;
+    int n = 0, A = 0, B = 0, K = 0, H = 0, nu = 0, HN = 0, RF = 0, n_waves = 0;
+    DevModel *d_model = nullptr;
+    DevCfg *d_cfg = nullptr;
+    DevCost *d_cost = nullptr;
+    float *d_x0_dof = nullptr, *d_x0_root = nullptr, *d_U = nullptr, *d_eps = nullptr, *d_du = nullptr, *d_S = nullptr;
+    float *d_prior = nullptr, *d_viz = nullptr, *d_partials = nullptr, *d_record = nullptr, *d_action = nullptr, *d_beta_eta = nullptr;
+    float *d_q = nullptr, *d_qd = nullptr, *d_ctrl = nullptr;
+    double *d_basis = nullptr, *d_sigma = nullptr;
+    const float *eps_in = nullptr;  // d_eps or an external noise buffer
+    bool has_prior = false, has_cost = false, profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[3];
+    size_t ev_used[3] = {0, 0, 0};
+    void (*launch_rollout)(mppi_ctx *) = nullptr;
+    void (*launch_sim_step)(mppi_ctx *, int, int, const float *) = nullptr;
+    void (*launch_materialise)(mppi_ctx *, float *, float *, float *, float *) = nullptr;
+    std::string topo;
+};
+
+namespace {
+
+template <class T>
+void launch_rollout_t(mppi_ctx *c) {
+    hipLaunchKernelGGL(k_rollout<T>, dim3(c->n_waves), dim3(kWave), 0, c->stream, c->d_model, c->d_cfg, c->d_cost, c->d_x0_dof, c->d_x0_root,
+                       c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_S, c->cfg.want_rollouts ? c->d_viz : nullptr);
+}
+template <class T>
+void launch_sim_step_t(mppi_ctx *c, int mode, int t, const float *u_ext) {
+    hipLaunchKernelGGL(k_sim_step<T>, dim3(c->n_waves), dim3(kWave), 0, c->stream, c->d_model, c->d_cfg, mode, t, u_ext, c->d_x0_root, c->d_U,
+                       c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_ctrl, c->d_q, c->d_qd);
+}
+template <class T>
+void launch_materialise_t(mppi_ctx *c, float *dof, float *root, float *rb, float *cf) {
+    hipLaunchKernelGGL(k_materialise<T>, dim3(c->n_waves), dim3(kWave), 0, c->stream, c->d_model, c->K, c->d_x0_root, c->d_q, c->d_qd, dof, root,
+                       rb, cf);
+}
+
+struct EvScope {  // optional hipEvent bracket around one launch (profiling mode)
+    mppi_ctx *c;
+    int which;
+    hipEvent_t stop = nullptr;
+    EvScope(mppi_ctx *c_, int w) : c(c_), which(w) {
+        if (!c->profiling) return;
+        auto &v = c->ev[which];
+        if (c->ev_used[which] == v.size()) {
+            hipEvent_t a, b;
+            hipEventCreate(&a);
+            hipEventCreate(&b);
+            v.emplace_back(a, b);
+        }
+        auto &p = v[c->ev_used[which]++];
+        hipEventRecord(p.first, c->stream);
+        stop = p.second;
+    }
+    ~EvScope() {
+        if (stop) hipEventRecord(stop, c->stream);
+    }
+};
+
+template <class P>
+int dev_alloc(P **p, size_t bytes) {
+    HIP_TRY(hipMalloc((void **)p, bytes ? bytes : 4));
+    HIP_TRY(hipMemset(*p, 0, bytes ? bytes : 4));
+    return MPPI_OK;
+}
+#define ALLOC_TRY(p, bytes)                 \
+    do {                                    \
+        int rc_ = dev_alloc(&(p), (bytes)); \
+        if (rc_) return rc_;                \
+    } while (0)
+
+int check_ctx(const mppi_ctx *c) { return c ? MPPI_OK : fail(MPPI_EINVAL, "null context"); }
+#define CTX_TRY(c)            \
+    do {                      \
+        int rc_ = check_ctx(c); \
+        if (rc_) return rc_;  \
+        hipError_t e_ = hipSetDevice((c)->device); \
+        if (e_ != hipSuccess) return fail(MPPI_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(e_)); \
+    } while (0)
+
+int launch_check() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MPPI_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return MPPI_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------ C-ABI
+extern "C" {
+
+const char *mppi_last_error(void) { return g_err.c_str(); }
+int mppi_abi_version(void) { return MPPI_ABI_VERSION; }
+int mppi_device_count(int *count) {
+    if (!count) return fail(MPPI_EINVAL, "null count");
+    HIP_TRY(hipGetDeviceCount(count));
+    return MPPI_OK;
+}
+
+int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device, mppi_ctx_t **out) {
+    if (!model || !cfg || !out) return fail(MPPI_EINVAL, "null argument");
+    std::string err;
+    mppi_ctx *c = new mppi_ctx();
+    c->model = *model;
+    c->cfg = *cfg;
+    c->device = device;
+    if (!pack_model(*model, c->hm, err) || !pack_config(*cfg, c->hc, err)) {
+        delete c;
+        return fail(MPPI_EINVAL, err);
+    }
+    if (cfg->nu != model->nu) {
+        delete c;
+        return fail(MPPI_EINVAL, "config.nu != model.nu");
+    }
+    std::memset(&c->hk, 0, sizeof c->hk);
+    int parents[MPPI_MAX_BODIES];
+    for (int i = 0; i < c->hm.nb; i++) parents[i] = c->hm.b[i].parent;
+    c->topo = topology_string(c->hm.nb, parents);
+    bool ok = dispatch_topology(c->hm.nb, parents, [&](auto topo) {
+        using T = decltype(topo);
+        c->launch_rollout = &launch_rollout_t<T>;
+        c->launch_sim_step = &launch_sim_step_t<T>;
+        c->launch_materialise = &launch_materialise_t<T>;
+    });
+    if (!ok) {
+        std::string t = c->topo;
+        delete c;
+        return fail(MPPI_EUNSUPPORTED, "kinematic tree " + t +
+                                           " is not instantiated in this build: add its compiled model under assets/compiled/ and "
+                                           "re-run __graft_entry__.build()");
+    }
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(MPPI_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    }
+    c->n = c->hm.nb; c->A = c->hm.n_actors; c->B = c->hm.n_rb; c->K = cfg->num_samples; c->H = cfg->horizon; c->nu = cfg->nu;
+    c->HN = c->H * c->nu; c->RF = 2 + c->HN; c->n_waves = (c->K + kWave - 1) / kWave;
+    const size_t K = c->K;
+    ALLOC_TRY(c->d_model, sizeof(DevModel));
+    ALLOC_TRY(c->d_cfg, sizeof(DevCfg));
+    ALLOC_TRY(c->d_cost, sizeof(DevCost));
+    ALLOC_TRY(c->d_x0_dof, sizeof(float) * 2 * c->n);
+    ALLOC_TRY(c->d_x0_root, sizeof(float) * 13 * c->A);
+    ALLOC_TRY(c->d_U, sizeof(float) * c->HN);
+    ALLOC_TRY(c->d_eps, sizeof(float) * c->HN * K);
+    ALLOC_TRY(c->d_du, sizeof(float) * c->HN * K);
+    ALLOC_TRY(c->d_S, sizeof(float) * K);
+    ALLOC_TRY(c->d_prior, sizeof(float) * c->HN);
+    ALLOC_TRY(c->d_viz, sizeof(float) * (cfg->want_rollouts ? (size_t)c->H * K * 3 : 1));
+    ALLOC_TRY(c->d_partials, sizeof(float) * (size_t)c->n_waves * c->RF);
+    ALLOC_TRY(c->d_record, sizeof(float) * c->RF);
+    ALLOC_TRY(c->d_action, sizeof(float) * c->nu);
+    ALLOC_TRY(c->d_beta_eta, sizeof(float) * 2);
+    ALLOC_TRY(c->d_q, sizeof(float) * c->n * K);
+    ALLOC_TRY(c->d_qd, sizeof(float) * c->n * K);
+    ALLOC_TRY(c->d_ctrl, sizeof(float) * K);
+    ALLOC_TRY(c->d_basis, sizeof(double) * MPPI_MAX_H * MPPI_MAX_KNOTS);
+    ALLOC_TRY(c->d_sigma, sizeof(double) * MPPI_MAX_NU);
+    c->eps_in = c->d_eps;
+    double sig[MPPI_MAX_NU] = {0};
+    for (int j = 0; j < c->nu; j++) sig[j] = std::sqrt(cfg->noise_sigma_diag[j]);
+    HIP_TRY(hipMemcpy(c->d_model, &c->hm, sizeof(DevModel), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_cfg, &c->hc, sizeof(DevCfg), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_cost, &c->hk, sizeof(DevCost), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_basis, cfg->spline_basis, sizeof(double) * MPPI_MAX_H * MPPI_MAX_KNOTS, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_sigma, sig, sizeof sig, hipMemcpyHostToDevice));
+    std::vector<float> U0(c->HN, (float)cfg->u_init);
+    HIP_TRY(hipMemcpy(c->d_U, U0.data(), sizeof(float) * c->HN, hipMemcpyHostToDevice));
+    *out = c;
+    return MPPI_OK;
+}
+
+int mppi_destroy(mppi_ctx_t *c) {
+    if (!c) return MPPI_OK;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    void *bufs[] = {c->d_model, c->d_cfg, c->d_cost, c->d_x0_dof, c->d_x0_root, c->d_U, c->d_eps, c->d_du, c->d_S, c->d_prior, c->d_viz,
+                    c->d_partials, c->d_record, c->d_action, c->d_beta_eta, c->d_q, c->d_qd, c->d_ctrl, c->d_basis, c->d_sigma};
+    for (void *b : bufs)
+        if (b) hipFree(b);
+    for (auto &v : c->ev)
+        for (auto &p : v) {
+            hipEventDestroy(p.first);
+            hipEventDestroy(p.second);
+        }
+    delete c;
+    return MPPI_OK;
+}
+
+int mppi_set_stream(mppi_ctx_t *c, void *hip_stream) {
+    CTX_TRY(c);
+    c->stream = (hipStream_t)hip_stream;
+    return MPPI_OK;
+}
+int mppi_synchronize(mppi_ctx_t *c) {
+    CTX_TRY(c);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MPPI_OK;
+}
+
+int mppi_set_state(mppi_ctx_t *c, const float *dof, const float *root) {
+    CTX_TRY(c);
+    if (dof) HIP_TRY(hipMemcpyAsync(c->d_x0_dof, dof, sizeof(float) * 2 * c->n, hipMemcpyHostToDevice, c->stream));
+    if (root) HIP_TRY(hipMemcpyAsync(c->d_x0_root, root, sizeof(float) * 13 * c->A, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // the host buffers may be reused by the caller right away
+    return MPPI_OK;
+}
+int mppi_set_state_dev(mppi_ctx_t *c, const float *dof, const float *root) {
+    CTX_TRY(c);
+    if (dof) HIP_TRY(hipMemcpyAsync(c->d_x0_dof, dof, sizeof(float) * 2 * c->n, hipMemcpyDeviceToDevice, c->stream));
+    if (root) HIP_TRY(hipMemcpyAsync(c->d_x0_root, root, sizeof(float) * 13 * c->A, hipMemcpyDeviceToDevice, c->stream));
+    return MPPI_OK;
+}
+int mppi_get_state(mppi_ctx_t *c, float *dof, float *root) {
+    CTX_TRY(c);
+    if (dof) HIP_TRY(hipMemcpyAsync(dof, c->d_x0_dof, sizeof(float) * 2 * c->n, hipMemcpyDeviceToHost, c->stream));
+    if (root) HIP_TRY(hipMemcpyAsync(root, c->d_x0_root, sizeof(float) * 13 * c->A, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MPPI_OK;
+}
+
+int mppi_set_cost(mppi_ctx_t *c, const mppi_cost_t *cost) {
+    CTX_TRY(c);
+    if (!cost) return fail(MPPI_EINVAL, "null cost");
+    std::string err;
+    DevCost hk;
+    if (!pack_cost(*cost, c->hm, hk, err)) return fail(cost->kind > MPPI_COST_PANDA_PICK || cost->kind < 0 ? MPPI_EINVAL : MPPI_EUNSUPPORTED, err);
+    c->hk = hk;
+    HIP_TRY(hipMemcpyAsync(c->d_cost, &c->hk, sizeof(DevCost), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->has_cost = true;
+    return MPPI_OK;
+}
+
+int mppi_sample(mppi_ctx_t *c, uint32_t index_base) {
+    CTX_TRY(c);
+    if (c->cfg.sampling != MPPI_SAMPLE_HALTON_SPLINE) return fail(MPPI_ESTATE, "mppi_sample: config.sampling is not halton-spline");
+    hipLaunchKernelGGL(k_sample, dim3(c->n_waves), dim3(kWave), 0, c->stream, c->d_cfg, c->d_basis, c->d_sigma, c->cfg.n_knots, index_base, c->d_eps);
+    c->eps_in = c->d_eps;
+    return launch_check();
+}
+int mppi_set_noise_dev(mppi_ctx_t *c, const float *eps_dev) {
+    CTX_TRY(c);
+    c->eps_in = eps_dev ? eps_dev : c->d_eps;
+    return MPPI_OK;
+}
+int mppi_set_prior(mppi_ctx_t *c, const float *prior) {
+    CTX_TRY(c);
+    c->has_prior = prior != nullptr;
+    if (prior) {
+        HIP_TRY(hipMemcpyAsync(c->d_prior, prior, sizeof(float) * c->HN, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return MPPI_OK;
+}
+int mppi_set_nominal(mppi_ctx_t *c, const float *U) {
+    CTX_TRY(c);
+    if (!U) return fail(MPPI_EINVAL, "null U");
+    HIP_TRY(hipMemcpyAsync(c->d_U, U, sizeof(float) * c->HN, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MPPI_OK;
+}
+int mppi_get_nominal(mppi_ctx_t *c, float *U) {
+    CTX_TRY(c);
+    HIP_TRY(hipMemcpyAsync(U, c->d_U, sizeof(float) * c->HN, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MPPI_OK;
+}
+
+int mppi_rollout(mppi_ctx_t *c) {
+    CTX_TRY(c);
+    if (!c->has_cost) return fail(MPPI_ESTATE, "mppi_rollout: no fused cost set (mppi_set_cost); use the mppi_sim_* path for host-side costs");
+    {
+        EvScope ev(c, 0);
+        c->launch_rollout(c);
+    }
+    return launch_check();
+}
+int mppi_reduce(mppi_ctx_t *c, float *record_out_dev) {
+    CTX_TRY(c);
+    {
+        EvScope ev(c, 1);
+        hipLaunchKernelGGL(k_reduce, dim3(c->n_waves), dim3(kWave), 0, c->stream, c->d_cfg, c->d_S, c->d_du, c->d_partials);
+    }
+    if (record_out_dev)  // one shard record for the cross-GPU all-gather
+        hipLaunchKernelGGL(k_combine, dim3(1), dim3(256), 0, c->stream, c->d_cfg, c->d_partials, c->n_waves, 0, record_out_dev, c->d_U, c->d_action,
+                           c->d_beta_eta);
+    return launch_check();
+}
+int mppi_record_floats(const mppi_ctx_t *c) { return c ? c->RF : 0; }
+int mppi_record_dev(mppi_ctx_t *c, float **record_dev) {
+    CTX_TRY(c);
+    hipLaunchKernelGGL(k_combine, dim3(1), dim3(256), 0, c->stream, c->d_cfg, c->d_partials, c->n_waves, 0, c->d_record, c->d_U, c->d_action, c->d_beta_eta);
+    *record_dev = c->d_record;
+    return launch_check();
+}
+int mppi_update(mppi_ctx_t *c, const float *records_dev, int n_records) {
+    CTX_TRY(c);
+    const float *recs = records_dev ? records_dev : c->d_partials;
+    int n = records_dev ? n_records : c->n_waves;
+    if (n < 1) return fail(MPPI_EINVAL, "n_records < 1");
+    {
+        EvScope ev(c, 2);
+        hipLaunchKernelGGL(k_combine, dim3(1), dim3(256), 0, c->stream, c->d_cfg, recs, n, 1, (float *)nullptr, c->d_U, c->d_action, c->d_beta_eta);
+    }
+    return launch_check();
+}
+int mppi_get_action(mppi_ctx_t *c, float *action) {
+    CTX_TRY(c);
+    HIP_TRY(hipMemcpyAsync(action, c->d_action, sizeof(float) * c->nu, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MPPI_OK;
+}
+int mppi_action_dev(mppi_ctx_t *c, float **action_dev) {
+    CTX_TRY(c);
+    *action_dev = c->d_action;
+    return MPPI_OK;
+}
+int mppi_command(mppi_ctx_t *c, float *action) {
+    int rc;
+    if ((rc = mppi_rollout(c))) return rc;
+    if ((rc = mppi_reduce(c, nullptr))) return rc;
+    if ((rc = mppi_update(c, nullptr, 1))) return rc;
+    return action ? mppi_get_action(c, action) : MPPI_OK;
+}
+
+static int d2h(mppi_ctx_t *c, float *dst, const float *src, size_t nfloats) {
+    CTX_TRY(c);
+    if (!dst) return fail(MPPI_EINVAL, "null destination");
+    HIP_TRY(hipMemcpyAsync(dst, src, sizeof(float) * nfloats, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MPPI_OK;
+}
+int mppi_get_costs(mppi_ctx_t *c, float *S) { return d2h(c, S, c ? c->d_S : nullptr, c ? c->K : 0); }
+int mppi_get_weights_stats(mppi_ctx_t *c, float *be) { return d2h(c, be, c ? c->d_beta_eta : nullptr, 2); }
+int mppi_get_rollouts(mppi_ctx_t *c, float *viz) {
+    if (c && !c->cfg.want_rollouts) return fail(MPPI_ESTATE, "config.want_rollouts is off");
+    return d2h(c, viz, c ? c->d_viz : nullptr, c ? (size_t)c->H * c->K * 3 : 0);
+}
+int mppi_get_perturbations(mppi_ctx_t *c, float *du) { return d2h(c, du, c ? c->d_du : nullptr, c ? (size_t)c->HN * c->K : 0); }
+int mppi_get_noise(mppi_ctx_t *c, float *eps) { return d2h(c, eps, c ? c->eps_in : nullptr, c ? (size_t)c->HN * c->K : 0); }
+
+int mppi_sim_reset(mppi_ctx_t *c) {
+    CTX_TRY(c);
+    hipLaunchKernelGGL(k_sim_reset, dim3((c->K + 255) / 256), dim3(256), 0, c->stream, c->K, c->n, c->d_x0_dof, c->d_q, c->d_qd, c->d_S, c->d_ctrl);
+    return launch_check();
+}
+int mppi_sim_step(mppi_ctx_t *c, const float *u_dev, int u_is_shared) {
+    CTX_TRY(c);
+    if (!u_dev) return fail(MPPI_EINVAL, "null command");
+    c->launch_sim_step(c, u_is_shared ? 1 : 0, 0, u_dev);
+    return launch_check();
+}
+int mppi_sim_step_horizon(mppi_ctx_t *c, int t) {
+    CTX_TRY(c);
+    if (t < 0 || t >= c->H) return fail(MPPI_EINVAL, "t outside the horizon");
+    c->launch_sim_step(c, 2, t, nullptr);
+    return launch_check();
+}
+int mppi_sim_materialise(mppi_ctx_t *c, float *dof, float *root, float *rb, float *cf) {
+    CTX_TRY(c);
+    c->launch_materialise(c, dof, root, rb, cf);
+    return launch_check();
+}
+int mppi_sim_accumulate_cost(mppi_ctx_t *c, int t, const float *cost_dev) {
+    CTX_TRY(c);
+    if (!cost_dev) return fail(MPPI_EINVAL, "null cost");
+    float disc = std::pow((float)c->cfg.rollout_var_discount, (float)t);
+    hipLaunchKernelGGL(k_accumulate_cost, dim3((c->K + 255) / 256), dim3(256), 0, c->stream, c->K, disc, cost_dev, c->d_S);
+    return launch_check();
+}
+int mppi_sim_finish(mppi_ctx_t *c) {
+    CTX_TRY(c);
+    hipLaunchKernelGGL(k_sim_finish, dim3((c->K + 255) / 256), dim3(256), 0, c->stream, c->K, c->d_ctrl, c->d_S);
+    return launch_check();
+}
+int mppi_world_step_from(mppi_ctx_t *world, mppi_ctx_t *planner) {
+    CTX_TRY(world);
+    if (!planner || world->nu != planner->nu || world->device != planner->device) return fail(MPPI_EINVAL, "world/planner mismatch");
+    world->launch_sim_step(world, 1, 0, planner->d_action);
+    return launch_check();
+}
+int mppi_set_state_from_world(mppi_ctx_t *planner, mppi_ctx_t *world) {
+    CTX_TRY(planner);
+    if (!world || world->K != 1 || world->n != planner->n || world->A != planner->A) return fail(MPPI_EINVAL, "world must be a K=1 context of the same scene");
+    hipLaunchKernelGGL(k_state_from_world, dim3(1), dim3(64), 0, planner->stream, planner->n, world->d_q, world->d_qd, planner->d_x0_dof);
+    HIP_TRY(hipMemcpyAsync(planner->d_x0_root, world->d_x0_root, sizeof(float) * 13 * planner->A, hipMemcpyDeviceToDevice, planner->stream));
+    return launch_check();
+}
+
+int mppi_set_profiling(mppi_ctx_t *c, int on) {
+    CTX_TRY(c);
+    c->profiling = on != 0;
+    for (int w = 0; w < 3; w++) c->ev_used[w] = 0;
+    return MPPI_OK;
+}
+/* average hipEvent duration (ms) of the launches of kernel `which` since mppi_set_profiling(ctx,1) */
+int mppi_kernel_ms(mppi_ctx_t *c, int which, float *ms) {
+    CTX_TRY(c);
+    if (which < 0 || which > 2 || !ms) return fail(MPPI_EINVAL, "bad argument");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    size_t n = c->ev_used[which];
+    if (n == 0) return fail(MPPI_ESTATE, "no profiled launches recorded");
+    double tot = 0;
+    for (size_t i = 0; i < n; i++) {
+        float t = 0;
+        HIP_TRY(hipEventElapsedTime(&t, c->ev[which][i].first, c->ev[which][i].second));
+        tot += t;
+    }
+    *ms = (float)(tot / n);
+    c->ev_used[which] = 0;
+    return MPPI_OK;
+}
+int mppi_kernel_info(mppi_ctx_t *c, char *buf, int buflen) {
+    CTX_TRY(c);
+    std::snprintf(buf, buflen, "topology=%s K=%d H=%d nu=%d waves=%d block=%d bytes_alg=%zu", c->topo.c_str(), c->K, c->H, c->nu, c->n_waves, kWave,
+                  (size_t)4 * (3 * (size_t)c->K * c->HN + 2 * (size_t)c->K + c->HN));
+    return MPPI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,145 @@
+"""ctypes binding of include/mppi_hip.h (libmppi_hip.so).
+
+The structures mirror the header field by field; `check_abi()` compares sizeof() on
+both sides when the library is loaded.  There is NO CPU fallback here: if the HIP
+library is missing or does not load, importing the product path fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+MAX_BODIES, MAX_LINKS, MAX_ACTORS, MAX_NU, MAX_H, MAX_KNOTS, MAX_COST_W = 12, 24, 8, 12, 64, 16, 16
+ABI_VERSION = 1
+
+JOINT_REVOLUTE, JOINT_PRISMATIC = 0, 1
+DRIVE_VELOCITY, DRIVE_EFFORT, DRIVE_POSITION = 0, 1, 2
+ACTOR_ROBOT, ACTOR_BOX, ACTOR_SPHERE = 0, 1, 2
+COST_NONE, COST_POINT_REACH, COST_PANDA_REACH, COST_BOXER_PUSH, COST_PANDA_PICK = 0, 1, 2, 3, 4
+SAMPLE_HALTON_SPLINE, SAMPLE_EXTERNAL = 0, 1
+
+_d, _i = C.c_double, C.c_int32
+
+
+class Body(C.Structure):
+    _fields_ = [("parent", _i), ("jtype", _i), ("axis", _d * 3), ("R_tree", _d * 9), ("p_tree", _d * 3),
+                ("mass", _d), ("h", _d * 3), ("Io", _d * 6), ("limited", _i), ("pad_", _i),
+                ("lower", _d), ("upper", _d), ("effort", _d), ("velocity", _d)]
+
+
+class Link(C.Structure):
+    _fields_ = [("body", _i), ("pad_", _i), ("R", _d * 9), ("p", _d * 3)]
+
+
+class Actor(C.Structure):
+    _fields_ = [("type", _i), ("fixed", _i), ("collision", _i), ("gravity", _i), ("size", _d * 3),
+                ("mass", _d), ("friction", _d), ("first_rb", _i), ("n_rb", _i)]
+
+
+class Model(C.Structure):
+    _fields_ = [("abi_version", _i), ("n_actors", _i), ("actors", Actor * MAX_ACTORS), ("robot_actor", _i),
+                ("n_bodies", _i), ("bodies", Body * MAX_BODIES), ("n_links", _i), ("n_rb", _i),
+                ("links", Link * MAX_LINKS), ("base_mass", _d), ("base_h", _d * 3), ("base_Io", _d * 6),
+                ("drive_mode", _i), ("substeps", _i), ("drive_kd", _d), ("dt", _d), ("gravity", _d * 3),
+                ("nu", _i), ("cmd_col", (_i * 2) * MAX_BODIES), ("cmd_coef", (_d * 2) * MAX_BODIES)]
+
+
+class Config(C.Structure):
+    _fields_ = [("abi_version", _i), ("num_samples", _i), ("horizon", _i), ("nu", _i), ("k_offset", _i),
+                ("k_total", _i), ("sample_null_action", _i), ("use_priors", _i), ("sampling", _i),
+                ("n_knots", _i), ("noise_abs_cost", _i), ("want_rollouts", _i), ("viz_link", _i), ("seed", _i),
+                ("lambda_", _d), ("rollout_var_discount", _d), ("u_init", _d),
+                ("u_min", _d * MAX_NU), ("u_max", _d * MAX_NU), ("noise_sigma_diag", _d * MAX_NU),
+                ("spline_basis", _d * (MAX_H * MAX_KNOTS))]
+
+
+class Cost(C.Structure):
+    _fields_ = [("kind", _i), ("link", _i * 4), ("actor", _i * 6), ("w", _d * MAX_COST_W)]
+
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+LIB_PATH = os.path.join(_PKG_ROOT, "csrc", "libmppi_hip.so")
+
+_fp = C.POINTER(C.c_float)
+_vp = C.c_void_p
+_SIGNATURES = {
+    "mppi_last_error": (C.c_char_p, []),
+    "mppi_abi_version": (C.c_int, []),
+    "mppi_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "mppi_create": (C.c_int, [C.POINTER(Model), C.POINTER(Config), C.c_int, C.POINTER(_vp)]),
+    "mppi_destroy": (C.c_int, [_vp]),
+    "mppi_set_stream": (C.c_int, [_vp, _vp]),
+    "mppi_synchronize": (C.c_int, [_vp]),
+    "mppi_set_state": (C.c_int, [_vp, _fp, _fp]),
+    "mppi_set_state_dev": (C.c_int, [_vp, _vp, _vp]),
+    "mppi_get_state": (C.c_int, [_vp, _fp, _fp]),
+    "mppi_set_cost": (C.c_int, [_vp, C.POINTER(Cost)]),
+    "mppi_sample": (C.c_int, [_vp, C.c_uint32]),
+    "mppi_set_noise_dev": (C.c_int, [_vp, _vp]),
+    "mppi_set_prior": (C.c_int, [_vp, _fp]),
+    "mppi_set_nominal": (C.c_int, [_vp, _fp]),
+    "mppi_get_nominal": (C.c_int, [_vp, _fp]),
+    "mppi_rollout": (C.c_int, [_vp]),
+    "mppi_reduce": (C.c_int, [_vp, _vp]),
+    "mppi_record_floats": (C.c_int, [_vp]),
+    "mppi_record_dev": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "mppi_update": (C.c_int, [_vp, _vp, C.c_int]),
+    "mppi_get_action": (C.c_int, [_vp, _fp]),
+    "mppi_action_dev": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "mppi_command": (C.c_int, [_vp, _fp]),
+    "mppi_get_costs": (C.c_int, [_vp, _fp]),
+    "mppi_get_weights_stats": (C.c_int, [_vp, _fp]),
+    "mppi_get_rollouts": (C.c_int, [_vp, _fp]),
+    "mppi_get_perturbations": (C.c_int, [_vp, _fp]),
+    "mppi_get_noise": (C.c_int, [_vp, _fp]),
+    "mppi_sim_reset": (C.c_int, [_vp]),
+    "mppi_sim_step": (C.c_int, [_vp, _vp, C.c_int]),
+    "mppi_sim_step_horizon": (C.c_int, [_vp, C.c_int]),
+    "mppi_sim_materialise": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "mppi_sim_accumulate_cost": (C.c_int, [_vp, C.c_int, _vp]),
+    "mppi_sim_finish": (C.c_int, [_vp]),
+    "mppi_world_step_from": (C.c_int, [_vp, _vp]),
+    "mppi_set_state_from_world": (C.c_int, [_vp, _vp]),
+    "mppi_set_profiling": (C.c_int, [_vp, C.c_int]),
+    "mppi_kernel_ms": (C.c_int, [_vp, C.c_int, _fp]),
+    "mppi_kernel_info": (C.c_int, [_vp, C.c_char_p, C.c_int]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+class MppiHipError(RuntimeError):
+    pass
+
+
+def load_library(path: str = None) -> C.CDLL:
+    """dlopen libmppi_hip.so and attach signatures.  Raises (never falls back) if absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise MppiHipError(
+            f"{p} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
+    lib = C.CDLL(p)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
+        fn.restype, fn.argtypes = res, args
+    if lib.mppi_abi_version() != ABI_VERSION:
+        raise MppiHipError(f"ABI mismatch: library {lib.mppi_abi_version()} vs binding {ABI_VERSION}")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(lib, rc: int) -> None:
+    if rc != 0:
+        msg = lib.mppi_last_error()
+        raise MppiHipError(f"libmppi_hip error {rc}: {msg.decode() if msg else ''}")
+
+
+def fptr(arr):
+    """float32 numpy array -> float*"""
+    return arr.ctypes.data_as(_fp)

@@ -1,0 +1,72 @@
+"""Stage-cost Objectives for the BASELINE workloads, honouring the reference's Objective contract
+(`compute_cost(sim) -> [K]`, `reset()`, mutable `.weights`; reference examples/*/planner.py) and
+additionally declaring `fused_spec(sim)` so the planner can evaluate the same cost inside the
+persistent rollout kernel.  `compute_cost` is the reference's torch code path (generic mode);
+tests check fused == generic."""
+import torch
+
+from mppiisaac.backend import capi
+from mppiisaac.utils.conversions import matrix_to_euler_angles, quaternion_to_matrix
+
+
+class PandaReachObjective(object):
+    """reference examples/panda/planner.py:10-40 (incl. the xyzw-into-wxyz quirk, kept as is)."""
+
+    def __init__(self, cfg=None, actor="panda", link="panda_ee_tip", goal="goal"):
+        self.weights = {"robot_to_goal": 1.0, "robot_ori": 0.5}
+        self.actor, self.link, self.goal = actor, link, goal
+        self.reset()
+
+    def reset(self):
+        pass
+
+    def compute_cost(self, sim):
+        r_pos = sim.get_actor_link_by_name(self.actor, self.link)
+        goal_pos = sim.get_actor_position_by_name(self.goal)
+        robot_to_goal = r_pos[:, 0:3] - goal_pos[:, 0:3]
+        robot_to_goal_dist = torch.linalg.norm(robot_to_goal, axis=1)
+        robot_rpy = matrix_to_euler_angles(quaternion_to_matrix(r_pos[:, 3:7]), "ZYX")[:, 0:2]
+        robot_rpy_dist = torch.linalg.norm(robot_rpy, axis=1)
+        return self.weights["robot_to_goal"] * robot_to_goal_dist + self.weights["robot_ori"] * robot_rpy_dist
+
+    def fused_spec(self, sim) -> capi.Cost:
+        c = capi.Cost()
+        c.kind = capi.COST_PANDA_REACH
+        c.link[0] = sim.scene.rigid_body_index(self.actor, self.link)
+        c.actor[0] = sim.scene.actor_index(self.goal)
+        c.w[0], c.w[1] = self.weights["robot_to_goal"], self.weights["robot_ori"]
+        return c
+
+
+class PointReachObjective(object):
+    """Navigation term of reference benchmarks/point_robot/mppi_planner/mppi_planner_wrapper.py:10-35:
+    w_nav * || (x, y) - goal ||, x/y = DOF positions 0 and 1.  `goal` is either an actor name or [x, y]."""
+
+    def __init__(self, cfg=None, goal="goal", w_nav=2.0):
+        self.weights = {"w_nav": w_nav}
+        self.goal = goal
+        self.reset()
+
+    def reset(self):
+        pass
+
+    def _goal_xy(self, sim):
+        if isinstance(self.goal, str):
+            return sim.get_actor_position_by_name(self.goal)[:, 0:2]
+        return torch.tensor(self.goal, dtype=torch.float32, device=sim.device).view(1, 2)
+
+    def compute_cost(self, sim):
+        dof_state = sim.get_dof_state()
+        pos = torch.cat((dof_state[:, 0].unsqueeze(1), dof_state[:, 2].unsqueeze(1)), 1)
+        return self.weights["w_nav"] * torch.linalg.norm(pos - self._goal_xy(sim), axis=1)
+
+    def fused_spec(self, sim) -> capi.Cost:
+        c = capi.Cost()
+        c.kind = capi.COST_POINT_REACH
+        c.w[0] = self.weights["w_nav"]
+        if isinstance(self.goal, str):
+            c.actor[0] = sim.scene.actor_index(self.goal)
+        else:
+            c.actor[0] = -1
+            c.w[1], c.w[2] = float(self.goal[0]), float(self.goal[1])
+        return c

@@ -1,0 +1,427 @@
+"""Batched rigid-body simulator with the reference's `IsaacGymWrapper` surface
+(reference mppiisaac/planner/isaacgym_wrapper.py:83-774), backed by libmppi_hip.so.
+
+What is kept from the reference: the constructor signature, `env_cfg` (list of ActorWrapper),
+`num_envs`, `device`, the four state tensors `_dof_state [K,2n]`, `_root_state [K,A,13]`,
+`_rigid_body_state [K,B,13]`, `_net_contact_force [K,B,3]` (same layouts, :186-199), the name-based
+getters used by Objectives (:298-356), `apply_robot_cmd` (:524-572), `step` (:639-655),
+`reset_robot_state` (:574-619), `save/reset_root_state` (:662-675), `visualize_link_buffer`.
+What is different: the state of truth lives in sample-minor device buffers inside the HIP
+library; the reference-layout tensors are materialised after each `step()`.  Viewer, keyboard
+listeners and line drawing are graphics and out of scope.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from dataclasses import dataclass, field
+from enum import Enum
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from mppiisaac.backend import capi
+
+
+@dataclass
+class IsaacGymConfig(object):
+    # reference isaacgym_wrapper.py:10-18; only dt and substeps act on the HIP simulator
+    dt: float = 0.05
+    substeps: int = 2
+    use_gpu_pipeline: bool = True
+    num_client_threads: int = 0
+    viewer: bool = False
+    num_obstacles: int = 10
+    spacing: float = 6.0
+
+
+class SupportedActorTypes(Enum):
+    Axis = 1
+    Robot = 2
+    Sphere = 3
+    Box = 4
+
+
+@dataclass
+class ActorWrapper:
+    # field names and defaults: reference isaacgym_wrapper.py:49-77 (pinned by tests/golden/actor_cfgs.json)
+    type: SupportedActorTypes
+    name: str
+    dof_mode: str = "velocity"
+    init_pos: List[float] = field(default_factory=lambda: [0, 0, 0])
+    init_ori: List[float] = field(default_factory=lambda: [0, 0, 0, 1])
+    size: List[float] = field(default_factory=lambda: [0.1, 0.1, 0.1])
+    mass: float = 1.0
+    color: List[float] = field(default_factory=lambda: [1.0, 1.0, 1.0])
+    fixed: bool = False
+    collision: bool = True
+    friction: float = 1.0
+    handle: Optional[int] = None
+    flip_visual: bool = False
+    urdf_file: str = None
+    visualize_link: str = None
+    gravity: bool = True
+    differential_drive: bool = False
+    init_joint_pose: List[float] = None
+    wheel_radius: Optional[float] = None
+    wheel_base: Optional[float] = None
+    wheel_count: Optional[float] = None
+    left_wheel_joints: Optional[List[str]] = None
+    right_wheel_joints: Optional[List[str]] = None
+    caster_links: Optional[List[str]] = None
+    noise_sigma_size: Optional[List[float]] = None
+    noise_percentage_mass: float = 0.0
+    noise_percentage_friction: float = 0.0
+
+
+DRIVE_GAINS = {"velocity": (capi.DRIVE_VELOCITY, 600.0), "effort": (capi.DRIVE_EFFORT, 10.0),
+               "position": (capi.DRIVE_POSITION, 0.0)}  # reference :491-507
+GRAVITY = (0.0, 0.0, -9.8)  # reference :29
+
+
+def diff_drive_ik(actor: ActorWrapper, u: torch.Tensor):
+    """(v, omega) -> (left, right) wheel velocity; reference IsaacGymWrapper._ik :510-522."""
+    r, L = actor.wheel_radius, actor.wheel_base
+    left = (u[:, 0] / r) - ((L * u[:, 1]) / (2 * r))
+    right = (u[:, 0] / r) + ((L * u[:, 1]) / (2 * r))
+    return left, right
+
+
+class Scene:
+    """Host description of one env: actors + compiled robot model -> C-ABI mppi_model_t."""
+
+    def __init__(self, env_cfg: List[ActorWrapper], cfg: IsaacGymConfig, robot_model: dict):
+        robots = [i for i, a in enumerate(env_cfg) if a.type == "robot"]
+        if len(robots) != 1:
+            raise NotImplementedError(f"exactly one robot actor per env is supported, got {len(robots)}")
+        if len(env_cfg) > capi.MAX_ACTORS:
+            raise ValueError("too many actors")
+        self.env_cfg = env_cfg
+        self.cfg = cfg
+        self.robot_idx = robots[0]
+        self.robot = env_cfg[self.robot_idx]
+        self.robot_model = robot_model
+        self.dof_names = [b["joint"] for b in robot_model["bodies"]]
+        self.n_dof = len(self.dof_names)
+        self.link_names = [l["name"] for l in robot_model["links"]]
+        # rigid-body rows: actors in env order; a robot contributes its links, box/sphere one body
+        self.first_rb, self.rb_names = [], []
+        for a in env_cfg:
+            self.first_rb.append(len(self.rb_names))
+            if a.type == "robot":
+                self.rb_names += [(a.name, n) for n in self.link_names]
+            else:
+                self.rb_names.append((a.name, a.type))  # primitive bodies are named "box"/"sphere"
+        self.n_rb = len(self.rb_names)
+        self.cmd_terms, self.nu = self._command_map()
+
+    def _command_map(self):
+        """apply_robot_cmd's scatter (reference :524-559) as <=2 (column, coefficient) terms per DOF."""
+        a = self.robot
+        idx, terms = 0, []
+        if a.differential_drive:
+            idx = 2
+        for name in self.dof_names:
+            if a.differential_drive and name in (a.left_wheel_joints or []):
+                terms.append(((0, 1.0 / a.wheel_radius), (1, -a.wheel_base / (2 * a.wheel_radius))))
+            elif a.differential_drive and name in (a.right_wheel_joints or []):
+                terms.append(((0, 1.0 / a.wheel_radius), (1, a.wheel_base / (2 * a.wheel_radius))))
+            else:
+                terms.append(((idx, 1.0), (0, 0.0)))
+                idx += 1
+        return terms, idx
+
+    def viz_link_index(self) -> int:
+        """link index (within the robot) of ActorWrapper.visualize_link, -1 if unset."""
+        v = self.robot.visualize_link
+        return self.link_names.index(v) if v else -1
+
+    def actor_index(self, name: str) -> int:
+        return [a.name for a in self.env_cfg].index(name)
+
+    def rigid_body_index(self, actor_name: str, link_name: str) -> int:
+        return self.rb_names.index((actor_name, link_name))
+
+    def initial_state(self):
+        """dof_state [2n] (interleaved q, qdot) and root_state [A,13] of the initial pose
+        (reference :219-236 and reset_to_initial_poses :238-246)."""
+        dof = np.zeros(2 * self.n_dof, np.float32)
+        if self.robot.init_joint_pose:
+            pose = np.asarray(self.robot.init_joint_pose, np.float32)
+            dof[:len(pose)] = pose
+        root = np.zeros((len(self.env_cfg), 13), np.float32)
+        for i, a in enumerate(self.env_cfg):
+            root[i, 0:3] = a.init_pos
+            root[i, 3:7] = a.init_ori
+        return dof, root
+
+    def to_c(self) -> capi.Model:
+        m = capi.Model()
+        m.abi_version = capi.ABI_VERSION
+        m.n_actors = len(self.env_cfg)
+        kinds = {"robot": capi.ACTOR_ROBOT, "box": capi.ACTOR_BOX, "sphere": capi.ACTOR_SPHERE}
+        for i, a in enumerate(self.env_cfg):
+            ca = m.actors[i]
+            if a.type not in kinds:
+                raise NotImplementedError(f"actor asset of type {a.type} is not yet implemented!")
+            ca.type = kinds[a.type]
+            ca.fixed, ca.collision, ca.gravity = int(a.fixed), int(a.collision), int(a.gravity)
+            size = list(a.size) + [0.0] * (3 - len(a.size))
+            for j in range(3):
+                ca.size[j] = float(size[j])
+            ca.mass, ca.friction = float(a.mass), float(a.friction)
+            ca.first_rb = self.first_rb[i]
+            ca.n_rb = len(self.link_names) if a.type == "robot" else 1
+        m.robot_actor = self.robot_idx
+        rm = self.robot_model
+        if len(rm["bodies"]) > capi.MAX_BODIES or len(rm["links"]) > capi.MAX_LINKS:
+            raise ValueError("robot exceeds MPPI_MAX_BODIES / MPPI_MAX_LINKS")
+        m.n_bodies = len(rm["bodies"])
+        for i, b in enumerate(rm["bodies"]):
+            cb = m.bodies[i]
+            cb.parent = b["parent"]
+            cb.jtype = capi.JOINT_PRISMATIC if b["jtype"] == "prismatic" else capi.JOINT_REVOLUTE
+            for j in range(3):
+                cb.axis[j] = b["axis"][j]
+                cb.p_tree[j] = b["p_tree"][j]
+                cb.h[j] = b["inertia"]["h"][j]
+            for j in range(9):
+                cb.R_tree[j] = b["R_tree"][j // 3][j % 3]
+            cb.mass = b["inertia"]["mass"]
+            for j in range(6):
+                cb.Io[j] = b["inertia"]["Io"][j]
+            cb.limited = int(b["limited"])
+            cb.lower, cb.upper, cb.effort, cb.velocity = b["lower"], b["upper"], b["effort"], b["velocity"]
+            (c0, k0), (c1, k1) = self.cmd_terms[i]
+            m.cmd_col[i][0], m.cmd_col[i][1] = c0, c1
+            m.cmd_coef[i][0], m.cmd_coef[i][1] = k0, k1
+        m.n_links = len(rm["links"])
+        m.n_rb = self.n_rb
+        for i, l in enumerate(rm["links"]):
+            cl = m.links[i]
+            cl.body = l["body"]
+            for j in range(9):
+                cl.R[j] = l["R"][j // 3][j % 3]
+            for j in range(3):
+                cl.p[j] = l["p"][j]
+        bi = rm["base"]["inertia"]
+        m.base_mass = bi["mass"]
+        for j in range(3):
+            m.base_h[j] = bi["h"][j]
+        for j in range(6):
+            m.base_Io[j] = bi["Io"][j]
+        if self.robot.dof_mode not in DRIVE_GAINS:
+            raise ValueError("Invalid dof_mode")
+        m.drive_mode, m.drive_kd = DRIVE_GAINS[self.robot.dof_mode]
+        m.substeps = int(self.cfg.substeps)
+        m.dt = float(self.cfg.dt)
+        for j in range(3):
+            m.gravity[j] = GRAVITY[j]
+        m.nu = self.nu
+        return m
+
+
+def _dev_ptr(t: Optional[torch.Tensor]):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class IsaacGymWrapper:
+    def __init__(self, cfg: IsaacGymConfig, actors: List[str], init_positions: List[List[float]] = None,
+                 num_envs: int = 1, viewer: bool = False, device: str = "cuda:0", interactive_goal=True,
+                 mppi_config=None):
+        from mppiisaac.utils.isaacgym_utils import load_actor_cfgs, load_asset
+
+        if viewer or getattr(cfg, "viewer", False):
+            raise NotImplementedError("the Isaac Gym viewer is graphics and out of scope of the HIP backend")
+        if not str(device).startswith(("cuda", "hip")):
+            raise capi.MppiHipError(
+                f"device '{device}': this backend runs on an AMD GPU only (no CPU pipeline, no fallback)")
+        self.env_cfg = load_actor_cfgs(actors)
+        self.device = str(device).replace("hip", "cuda")
+        robots = [a for a in self.env_cfg if a.type == "robot"]
+        if init_positions is not None:
+            assert len(robots) == len(init_positions)
+            for init_pos, actor_cfg in zip(init_positions, robots):
+                actor_cfg.init_pos = list(init_pos)
+        for i, a in enumerate(self.env_cfg):
+            a.handle = i
+        self.cfg = cfg
+        self.interactive_goal = interactive_goal
+        self.num_envs = int(num_envs)
+        self.viewer = None
+        self.saved_root_state = None
+        self._mppi_config = mppi_config
+        self.scene = Scene(self.env_cfg, cfg, load_asset(robots[0]) if robots else None)
+        self.start_sim()
+
+    # ------------------------------------------------------------------ lifetime
+    def start_sim(self):
+        self._lib = capi.load_library()
+        sc = self.scene
+        self._c_model = sc.to_c()
+        if callable(self._mppi_config):  # built once the scene (viz link, nu) is known
+            self._mppi_config = self._mppi_config(sc)
+        if self._mppi_config is None:  # plain simulator (e.g. the K=1 "world"): minimal MPPI block
+            c = capi.Config()
+            c.abi_version = capi.ABI_VERSION
+            c.num_samples = c.k_total = self.num_envs
+            c.horizon, c.nu, c.n_knots, c.sampling = 1, sc.nu, 1, capi.SAMPLE_EXTERNAL
+            c.lambda_, c.rollout_var_discount = 1.0, 1.0
+            for j in range(sc.nu):
+                c.u_min[j], c.u_max[j], c.noise_sigma_diag[j] = -1e30, 1e30, 1.0
+            self._mppi_config = c
+        if self._mppi_config.num_samples != self.num_envs:
+            raise ValueError("mppi_config.num_samples must equal num_envs")
+        if self._mppi_config.nu != sc.nu:
+            raise ValueError(f"control dimension mismatch: noise_sigma is {self._mppi_config.nu}x{self._mppi_config.nu}, "
+                             f"the actors take {sc.nu} commands")
+        dev_index = torch.device(self.device).index or 0
+        torch.cuda.set_device(dev_index)
+        ctx = ctypes.c_void_p()
+        capi.check(self._lib, self._lib.mppi_create(ctypes.byref(self._c_model), ctypes.byref(self._mppi_config),
+                                                    dev_index, ctypes.byref(ctx)))
+        self._ctx = ctx
+        capi.check(self._lib, self._lib.mppi_set_stream(ctx, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        K, A, B, n = self.num_envs, len(self.env_cfg), sc.n_rb, sc.n_dof
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self._dof_state = torch.zeros((K, 2 * n), **f32)
+        self._root_state = torch.zeros((K, A, 13), **f32)
+        self._rigid_body_state = torch.zeros((K, B, 13), **f32)
+        self._net_contact_force = torch.zeros((K, B, 3), **f32)
+        self._visualize_link_present = any([a.visualize_link for a in self.env_cfg])
+        self.visualize_link_buffer = []
+        if self._visualize_link_present:
+            self.robot_rigid_body_viz_idx = sc.rigid_body_index(sc.robot.name, sc.robot.visualize_link)
+            self.visualize_link_pos = self._rigid_body_state[:, self.robot_rigid_body_viz_idx, 0:3]
+        self.robot_indices = torch.tensor([i for i, a in enumerate(self.env_cfg) if a.type == "robot"], device=self.device)
+        self.obstacle_indices = torch.tensor(
+            [i for i, a in enumerate(self.env_cfg) if (a.type in ["sphere", "box"] and a.name != "dummy")], device=self.device)
+        self._pending_cmd = None
+        self.reset_to_initial_poses()
+
+    def stop_sim(self):
+        if getattr(self, "_ctx", None):
+            self._lib.mppi_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.stop_sim()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ state in / out
+    def _push_single_state(self, dof: np.ndarray, root: np.ndarray):
+        """one env state -> x0 of the HIP context, broadcast to all K envs."""
+        dof = np.ascontiguousarray(dof, np.float32).reshape(-1)
+        root = np.ascontiguousarray(root, np.float32).reshape(-1)
+        capi.check(self._lib, self._lib.mppi_set_state(self._ctx, capi.fptr(dof), capi.fptr(root)))
+        capi.check(self._lib, self._lib.mppi_sim_reset(self._ctx))
+        self._materialise()
+
+    def _materialise(self):
+        capi.check(self._lib, self._lib.mppi_sim_materialise(
+            self._ctx, _dev_ptr(self._dof_state), _dev_ptr(self._root_state),
+            _dev_ptr(self._rigid_body_state), _dev_ptr(self._net_contact_force)))
+
+    def reset_to_initial_poses(self):
+        dof, root = self.scene.initial_state()
+        self._push_single_state(dof, root)
+
+    def set_state_from_env0(self, dof_state: torch.Tensor, root_state: torch.Tensor):
+        """reset_rollout_sim path (reference mppi_isaac.py:87-99): a [1,2n] / [1,A,13] world state is
+        broadcast to every env.  Only the single state crosses to the device."""
+        self._push_single_state(dof_state.detach().reshape(-1)[: 2 * self.scene.n_dof].cpu().numpy(),
+                                root_state.detach().reshape(-1, 13)[: len(self.env_cfg)].cpu().numpy())
+
+    def reset_robot_state(self, q, qdot):
+        """reference :574-619 (urdfenvs compatibility): q, qdot lists -> interleaved DOF state in all envs."""
+        if self.scene.robot.differential_drive:
+            raise NotImplementedError("reset_robot_state for differential-drive robots (reference branch raises, SURVEY.md C)")
+        n = self.scene.n_dof
+        dof = np.zeros(2 * n, np.float32)
+        dof[0::2] = np.asarray(q, np.float32)[:n]
+        dof[1::2] = np.asarray(qdot, np.float32)[:n]
+        root = (self.saved_root_state if self.saved_root_state is not None else self._root_state)[0].cpu().numpy()
+        self._push_single_state(dof, root)
+
+    def save_root_state(self):
+        self.saved_root_state = self._root_state.clone()
+
+    def get_saved_root_state(self):
+        return self.saved_root_state
+
+    def reset_root_state(self):
+        if self._visualize_link_present:
+            self.visualize_link_buffer = []
+        if self.saved_root_state is not None:
+            self._push_single_state(self._dof_state[0].cpu().numpy(), self.saved_root_state[0].cpu().numpy())
+
+    # ------------------------------------------------------------------ stepping
+    def apply_robot_cmd(self, u_desired: torch.Tensor):
+        """Latch the command for the next step().  [nu] applies to all envs, [K,nu] per env.  The
+        scatter to DOF targets incl. the diff-drive map happens in the step kernel (reference :524-572)."""
+        u = torch.as_tensor(u_desired, dtype=torch.float32, device=self.device)
+        if u.dim() == 1:
+            u = u.unsqueeze(0)
+        if u.shape[-1] != self.scene.nu:
+            raise ValueError(f"command has {u.shape[-1]} entries, expected {self.scene.nu}")
+        self._pending_cmd = u.contiguous()
+
+    def step(self):
+        u = self._pending_cmd
+        if u is None:
+            u = torch.zeros((1, self.scene.nu), dtype=torch.float32, device=self.device)
+        shared = 1 if u.shape[0] == 1 and self.num_envs != 1 else 0
+        if not shared and u.shape[0] != self.num_envs:
+            raise ValueError("command batch does not match num_envs")
+        capi.check(self._lib, self._lib.mppi_sim_step(self._ctx, _dev_ptr(u), shared))
+        self._materialise()
+        if self._visualize_link_present:
+            self.visualize_link_buffer.append(self.visualize_link_pos.clone())
+
+    # ------------------------------------------------------------------ getters (reference :268-356)
+    @property
+    def num_robots(self):
+        return len(self.robot_indices)
+
+    @property
+    def robot_positions(self):
+        return torch.index_select(self._root_state, 1, self.robot_indices)[:, :, 0:3]
+
+    @property
+    def robot_velocities(self):
+        return torch.index_select(self._root_state, 1, self.robot_indices)[:, :, 7:10]
+
+    @property
+    def obstacle_positions(self):
+        return torch.index_select(self._root_state, 1, self.obstacle_indices)[:, :, 0:3]
+
+    def _get_actor_index_by_name(self, name: str):
+        return self.scene.actor_index(name)
+
+    def get_actor_position_by_name(self, name: str):
+        return self._root_state[:, self.scene.actor_index(name), 0:3]
+
+    def get_actor_velocity_by_name(self, name: str):
+        return self._root_state[:, self.scene.actor_index(name), 7:10]
+
+    def get_actor_orientation_by_name(self, name: str):
+        return self._root_state[:, self.scene.actor_index(name), 3:7]
+
+    def get_actor_link_by_name(self, actor_name: str, link_name: str):
+        return self._rigid_body_state[:, self.scene.rigid_body_index(actor_name, link_name), :]
+
+    def get_actor_contact_forces_by_name(self, actor_name: str, link_name: str):
+        return self._net_contact_force[:, self.scene.rigid_body_index(actor_name, link_name)]
+
+    def get_dof_state(self):
+        return self._dof_state
+
+    def set_actor_position_by_name(self, position, name: str) -> None:
+        """Move an actor (e.g. the goal) in every env; takes effect for the next rollout/step."""
+        idx = self.scene.actor_index(name)
+        root = self._root_state[0].clone()
+        root[idx, 0:3] = torch.as_tensor(position, dtype=torch.float32, device=self.device).reshape(-1)[:3]
+        self._push_single_state(self._dof_state[0].cpu().numpy(), root.cpu().numpy())

@@ -1,0 +1,271 @@
+"""MPPI core: stands in for the reference's external dependency `mppi_torch.mppi`
+(MPPIConfig / MPPIPlanner; call sites reference mppiisaac/planner/mppi_isaac.py:3,43-49,84,113
+and mppiisaac/utils/config_store.py:2,13).  The arithmetic runs in the HIP library
+(sample / rollout / reduce / update kernels); this module is the thin host driver.
+
+Field list of MPPIConfig: reference benchmarks/point_robot/setup/mppi.yaml:5-37 plus
+eta_u_bound / eta_l_bound / seed_val (reference conf/mppi/omnipanda_effort.yaml:29-31).
+Semantics: SURVEY.md section A (build-normative; mppi_torch itself is not in the reference tree).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional
+
+import numpy as np
+import torch
+
+from mppiisaac.backend import capi
+
+
+@dataclass
+class MPPIConfig:
+    num_samples: int = 100
+    horizon: int = 30
+    mppi_mode: str = "halton-spline"      # "halton-spline" | "simple"
+    sampling_method: str = "halton"       # "halton" | "random"
+    noise_sigma: Optional[List[List[float]]] = None
+    noise_mu: Optional[List[float]] = None
+    device: str = "cuda:0"
+    lambda_: float = 1.0
+    update_lambda: bool = False
+    update_cov: bool = False
+    u_min: Optional[List[float]] = None
+    u_max: Optional[List[float]] = None
+    u_init: float = 0.0
+    U_init: Optional[List[List[float]]] = None
+    u_scale: float = 1.0
+    u_per_command: int = 1
+    rollout_var_discount: float = 0.95
+    sample_null_action: bool = False
+    noise_abs_cost: bool = False
+    filter_u: bool = False
+    use_priors: bool = False
+    seed_val: int = 0
+    eta_u_bound: float = 10.0
+    eta_l_bound: float = 5.0
+
+
+def bspline_basis(horizon: int, n_knots: int, degree: int = 2) -> np.ndarray:
+    """[H, n_knots] clamped uniform B-spline basis evaluated at t/(H-1) (Cox-de Boor)."""
+    H, n, p = horizon, n_knots, degree
+    if n <= p:  # too few control points for the degree: piecewise-constant hold
+        B = np.zeros((H, n))
+        for t in range(H):
+            B[t, min(n - 1, t * n // H)] = 1.0
+        return B
+    knots = np.concatenate([np.zeros(p), np.linspace(0.0, 1.0, n - p + 1), np.ones(p)])
+    xs = np.linspace(0.0, 1.0, H) if H > 1 else np.zeros(1)
+    B = np.zeros((H, n))
+    for ti, x in enumerate(xs):
+        N = np.zeros(len(knots) - 1)
+        for j in range(len(knots) - 1):  # degree 0
+            if (knots[j] <= x < knots[j + 1]) or (x == 1.0 and knots[j] < knots[j + 1] == 1.0):
+                N[j] = 1.0
+        for d in range(1, p + 1):
+            Nn = np.zeros(len(knots) - 1 - d)
+            for j in range(len(Nn)):
+                a = 0.0 if knots[j + d] == knots[j] else (x - knots[j]) / (knots[j + d] - knots[j]) * N[j]
+                b = 0.0 if knots[j + d + 1] == knots[j + 1] else (knots[j + d + 1] - x) / (knots[j + d + 1] - knots[j + 1]) * N[j + 1]
+                Nn[j] = a + b
+            N = Nn
+        B[ti] = N[:n]
+    return B
+
+
+def knots_for_horizon(horizon: int) -> int:
+    """halton-spline: n_knots = H // 4; below 3 knots sample every step directly."""
+    nk = horizon // 4
+    return nk if nk >= 3 else horizon
+
+
+def make_config(cfg: MPPIConfig, *, k_offset: int = 0, k_local: Optional[int] = None, viz_link: int = -1) -> capi.Config:
+    """MPPIConfig -> C-ABI mppi_config_t for the shard [k_offset, k_offset + k_local)."""
+    if cfg.update_cov:
+        raise NotImplementedError("update_cov=True is not supported (False in every shipped conf/mppi file)")
+    if cfg.u_per_command != 1:
+        raise NotImplementedError("u_per_command != 1 is not supported")
+    sigma = np.asarray(cfg.noise_sigma, dtype=np.float64)
+    nu = sigma.shape[0]
+    if sigma.shape != (nu, nu) or np.abs(sigma - np.diag(np.diag(sigma))).max() > 0:
+        raise NotImplementedError("noise_sigma must be a diagonal [nu x nu] matrix")
+    if nu > capi.MAX_NU or cfg.horizon > capi.MAX_H:
+        raise ValueError(f"nu={nu} / horizon={cfg.horizon} exceed MPPI_MAX_NU / MPPI_MAX_H")
+    c = capi.Config()
+    c.abi_version = capi.ABI_VERSION
+    c.num_samples = int(cfg.num_samples if k_local is None else k_local)
+    c.horizon = int(cfg.horizon)
+    c.nu = nu
+    c.k_offset = int(k_offset)
+    c.k_total = int(cfg.num_samples)
+    c.sample_null_action = int(bool(cfg.sample_null_action))
+    c.use_priors = int(bool(cfg.use_priors))
+    halton = cfg.mppi_mode == "halton-spline" and cfg.sampling_method == "halton"
+    c.sampling = capi.SAMPLE_HALTON_SPLINE if halton else capi.SAMPLE_EXTERNAL
+    nk = knots_for_horizon(cfg.horizon) if halton else 1
+    if nk > capi.MAX_KNOTS:
+        raise ValueError(f"n_knots={nk} exceeds MPPI_MAX_KNOTS")
+    c.n_knots = nk
+    c.noise_abs_cost = int(bool(cfg.noise_abs_cost))
+    c.want_rollouts = int(viz_link >= 0)
+    c.viz_link = max(int(viz_link), 0)
+    c.seed = int(cfg.seed_val)
+    c.lambda_ = float(cfg.lambda_)
+    c.rollout_var_discount = float(cfg.rollout_var_discount)
+    c.u_init = float(cfg.u_init)
+
+    def bcast(v, default):
+        if v is None:
+            return [default] * nu
+        v = list(v)
+        return v * nu if len(v) == 1 else v
+    umin, umax = bcast(cfg.u_min, -1e30), bcast(cfg.u_max, 1e30)
+    for j in range(nu):
+        c.u_min[j], c.u_max[j] = float(umin[j]) * cfg.u_scale, float(umax[j]) * cfg.u_scale
+        c.noise_sigma_diag[j] = float(sigma[j, j])
+    if halton:
+        B = bspline_basis(cfg.horizon, nk) if nk != cfg.horizon else np.eye(cfg.horizon)
+        flat = B.reshape(-1)
+        for j, v in enumerate(flat):
+            c.spline_basis[j] = float(v)
+    return c
+
+
+class MPPIPlanner:
+    """Host driver with the call surface the reference uses from mppi_torch.MPPIPlanner
+    (constructed at reference mppi_isaac.py:43-49, driven by `.command(state)` :84,113).
+
+    Two execution modes, chosen per call:
+      fused    the Objective declares a cost spec (`fused_spec(sim)`): ONE persistent rollout kernel runs
+               all K samples over the whole horizon with the stage cost evaluated in-kernel.
+      generic  any Objective with `compute_cost(sim) -> [K]`: H step launches; after each the
+               reference-layout state tensors are materialised and the Python callback runs, exactly
+               the loop of reference mppi_isaac.py:57-69 (apply -> step -> cost).
+    Sharded over `torch.distributed` ranks when a process group is initialised and `shard=True`:
+    each rank owns K/world samples; the shard records (beta, eta, sum w*du) are all-gathered
+    (RCCL on GPUs) and combined identically on every rank.
+    """
+
+    def __init__(self, cfg: MPPIConfig, nx: int, dynamics: Callable = None, running_cost: Callable = None,
+                 prior: Optional[Callable] = None, *, sim=None, process_group=None, shard: bool = False):
+        if sim is None:
+            raise ValueError("MPPIPlanner needs the HIP simulator context (sim=IsaacGymWrapper)")
+        self.cfg, self.nx = cfg, nx
+        self._dynamics, self._running_cost, self._prior = dynamics, running_cost, prior
+        self.sim = sim
+        self._lib, self._ctx = sim._lib, sim._ctx
+        self.K, self.T = sim.num_envs, cfg.horizon
+        self.nu = len(cfg.noise_sigma)
+        self.lambda_ = cfg.lambda_
+        self._pg, self._shard = process_group, shard
+        self._world = 1
+        if shard:
+            import torch.distributed as dist
+            self._world = dist.get_world_size(process_group)
+        self._rec_floats = self._lib.mppi_record_floats(self._ctx)
+        self._records = torch.zeros((self._world, self._rec_floats), dtype=torch.float32, device=sim.device)
+        self._fused_cost = None
+        self._sample_index = 0
+        self._action = np.zeros(self.nu, np.float32)
+        if cfg.U_init is not None:
+            U = np.ascontiguousarray(np.asarray(cfg.U_init, np.float32).reshape(self.T, self.nu))
+            capi.check(self._lib, self._lib.mppi_set_nominal(self._ctx, capi.fptr(U)))
+        self._external_noise = None
+        if sim._mppi_config.sampling == capi.SAMPLE_HALTON_SPLINE:
+            capi.check(self._lib, self._lib.mppi_sample(self._ctx, np.uint32(cfg.seed_val)))
+        else:
+            self._gen = torch.Generator(device=sim.device)
+            self._gen.manual_seed(int(cfg.seed_val) + 7919 * int(sim._mppi_config.k_offset))
+            self._resample_external()
+
+    # -- sampling -----------------------------------------------------------------------
+    def _resample_external(self):
+        """`random` sampling: Gaussian noise drawn with torch on the device, layout [H][nu][K]."""
+        sig = torch.tensor([self.cfg.noise_sigma[j][j] for j in range(self.nu)], device=self.sim.device).sqrt()
+        eps = torch.randn((self.T, self.nu, self.K), generator=self._gen, device=self.sim.device) * sig.view(1, -1, 1)
+        if self.cfg.noise_mu is not None:
+            eps = eps + torch.tensor(self.cfg.noise_mu, device=self.sim.device).view(1, -1, 1)
+        self._external_noise = eps.contiguous()
+        capi.check(self._lib, self._lib.mppi_set_noise_dev(self._ctx, C_void(self._external_noise)))
+
+    # -- properties mirroring mppi_torch attributes used by callers -----------------------
+    @property
+    def U(self) -> torch.Tensor:
+        out = np.zeros((self.T, self.nu), np.float32)
+        capi.check(self._lib, self._lib.mppi_get_nominal(self._ctx, capi.fptr(out)))
+        return torch.from_numpy(out)
+
+    def set_fused_cost(self, cost: Optional[capi.Cost]):
+        self._fused_cost = cost
+        if cost is not None:
+            capi.check(self._lib, self._lib.mppi_set_cost(self._ctx, C.byref(cost)))
+
+    # -- one control iteration ---------------------------------------------------------------
+    def command(self, state=None) -> torch.Tensor:
+        lib, ctx = self._lib, self._ctx
+        if self._external_noise is not None and self.cfg.sampling_method == "random":
+            self._resample_external()
+        if self._prior is not None and self.cfg.use_priors:
+            pr = np.ascontiguousarray(np.stack([np.asarray(self._prior(state, t), np.float32).reshape(-1) for t in range(self.T)]))
+            capi.check(lib, lib.mppi_set_prior(ctx, capi.fptr(pr)))
+        if self._fused_cost is not None:
+            capi.check(lib, lib.mppi_rollout(ctx))
+        else:
+            capi.check(lib, lib.mppi_sim_reset(ctx))
+            for t in range(self.T):
+                # dynamics(): apply the perturbed command of step t and step the simulator
+                capi.check(lib, lib.mppi_sim_step_horizon(ctx, t))
+                self.sim._materialise()
+                if self.sim._visualize_link_present:
+                    self.sim.visualize_link_buffer.append(self.sim.visualize_link_pos.clone())
+                c = self._running_cost(state)
+                c = c.to(dtype=torch.float32, device=self.sim.device).contiguous()
+                if c.shape != (self.K,):
+                    raise ValueError(f"compute_cost must return a [{self.K}] tensor, got {tuple(c.shape)}")
+                capi.check(lib, lib.mppi_sim_accumulate_cost(ctx, t, C_void(c)))
+            capi.check(lib, lib.mppi_sim_finish(ctx))
+        if self._world > 1:
+            rank = _dist_rank(self._pg)
+            capi.check(lib, lib.mppi_reduce(ctx, C_void(self._records[rank])))
+            allgather_records(self._records, rank, self._pg)
+            capi.check(lib, lib.mppi_update(ctx, C_void(self._records), self._world))
+        else:
+            capi.check(lib, lib.mppi_reduce(ctx, None))
+            capi.check(lib, lib.mppi_update(ctx, None, 1))
+        capi.check(lib, lib.mppi_get_action(ctx, capi.fptr(self._action)))
+        return torch.from_numpy(self._action.copy()).unsqueeze(0) if self.cfg.u_per_command > 1 else torch.from_numpy(self._action.copy())
+
+    def get_costs(self) -> torch.Tensor:
+        S = np.zeros(self.K, np.float32)
+        capi.check(self._lib, self._lib.mppi_get_costs(self._ctx, capi.fptr(S)))
+        return torch.from_numpy(S)
+
+
+import ctypes as C  # noqa: E402
+
+
+def C_void(t: torch.Tensor):
+    return C.c_void_p(t.data_ptr())
+
+
+def _dist_rank(group=None) -> int:
+    import torch.distributed as dist
+    return dist.get_rank(group)
+
+
+def allgather_records(records: torch.Tensor, rank: int, group=None) -> None:
+    """All-gather the per-shard records [world, 2+H*nu] in place (row `rank` holds this shard's
+    record on entry).  One small collective per control iteration: RCCL over xGMI for device
+    tensors (backend "nccl"), gloo for the CPU tests.  ~1 KB per rank: latency-bound."""
+    import torch.distributed as dist
+    dist.all_gather_into_tensor(records.view(-1), records[rank].clone(), group=group)
+
+
+def _get_rollouts(self) -> torch.Tensor:
+    """[H, K, 3] positions of the robot's visualize_link over the last fused rollout."""
+    out = np.zeros((self.T, self.K, 3), np.float32)
+    capi.check(self._lib, self._lib.mppi_get_rollouts(self._ctx, capi.fptr(out)))
+    return torch.from_numpy(out)
+
+
+MPPIPlanner.get_rollouts = _get_rollouts

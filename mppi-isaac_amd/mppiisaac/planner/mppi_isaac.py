@@ -1,0 +1,103 @@
+"""Planner facade with the reference's public surface (reference mppiisaac/planner/mppi_isaac.py:18-138):
+`MPPIisaacPlanner(cfg, objective, prior=None)`, `compute_action`, `compute_action_tensor`, `command`,
+`get_rollouts`, `update_objective`, `update_weights`, `update_mppi_params`, attributes `.sim`, `.mppi`,
+`.cfg`.  The K rollout envs and the MPPI core both live in ONE HIP context (libmppi_hip.so); the
+Isaac Gym + mppi_torch pair of the reference is what that library replaces."""
+from typing import Callable, Optional
+
+import torch
+
+from mppiisaac.planner.isaacgym_wrapper import IsaacGymWrapper
+from mppiisaac.planner.mppi import MPPIPlanner, make_config
+from mppiisaac.utils.transport import bytes_to_torch, torch_to_bytes
+
+
+class MPPIisaacPlanner(object):
+    def __init__(self, cfg, objective: Callable, prior: Optional[Callable] = None, *, shard: bool = False, process_group=None):
+        self.cfg = cfg
+        self.objective = objective
+        self.done = False
+        K_total = int(cfg.mppi.num_samples)
+        k_off, k_loc = 0, K_total
+        if shard:  # sample sharding over torch.distributed ranks
+            import torch.distributed as dist
+            world, rank = dist.get_world_size(process_group), dist.get_rank(process_group)
+            if K_total % world:
+                raise ValueError(f"num_samples={K_total} is not divisible by world_size={world}")
+            k_loc = K_total // world
+            k_off = rank * k_loc
+        self._shard, self._pg = shard, process_group
+        self._k_off, self._k_loc = k_off, k_loc
+        self._build(prior)
+
+    def _build(self, prior):
+        cfg = self.cfg
+        # the C config is built once the scene is known (viz link from the robot's `visualize_link`)
+        probe = lambda scene: make_config(cfg.mppi, k_offset=self._k_off, k_local=self._k_loc,
+                                          viz_link=scene.viz_link_index())
+        self.sim = IsaacGymWrapper(cfg.isaacgym, actors=cfg.actors, init_positions=cfg.initial_actor_positions,
+                                   num_envs=self._k_loc, device=cfg.mppi.device, mppi_config=probe)
+        self.prior = (lambda state, t: prior.compute_command(self.sim)) if prior else None
+        self.mppi = MPPIPlanner(cfg.mppi, cfg.nx, dynamics=self.dynamics, running_cost=self.running_cost,
+                                prior=self.prior, sim=self.sim, shard=self._shard, process_group=self._pg)
+        self._prior_obj = prior
+        self.state_place_holder = torch.zeros((self._k_loc, self.cfg.nx))
+        self._bind_objective()
+
+    def _bind_objective(self):
+        spec = getattr(self.objective, "fused_spec", None)
+        self.mppi.set_fused_cost(spec(self.sim) if callable(spec) else None)
+
+    def update_objective(self, objective):
+        self.objective = objective
+        self._bind_objective()
+
+    # callbacks with the reference's signatures (mppi_isaac.py:57-69); used by the generic mode
+    def dynamics(self, _, u, t=None):
+        self.sim.apply_robot_cmd(u)
+        self.sim.step()
+        return (self.state_place_holder, u)
+
+    def running_cost(self, _):
+        return self.objective.compute_cost(self.sim)
+
+    def compute_action(self, q, qdot, obst=None, obst_tensor=None):
+        if obst or obst_tensor is not None:
+            raise NotImplementedError("dynamic obstacles (SURVEY.md 8f rank 3) are not part of this scope row yet")
+        self.sim.reset_root_state()
+        self.sim.reset_robot_state(q, qdot)
+        self.sim.save_root_state()
+        self._bind_objective()
+        return self.mppi.command(self.state_place_holder).cpu()
+
+    def reset_rollout_sim(self, dof_state_tensor, root_state_tensor, rigid_body_state_tensor=None):
+        self.sim.visualize_link_buffer = []
+        self.sim.set_state_from_env0(bytes_to_torch(dof_state_tensor), bytes_to_torch(root_state_tensor))
+
+    def compute_action_tensor(self, dof_state_tensor, root_state_tensor):
+        self.objective.reset()
+        self.reset_rollout_sim(dof_state_tensor, root_state_tensor)
+        return self.command()
+
+    def command(self):
+        self._bind_objective()
+        return torch_to_bytes(self.mppi.command(self.state_place_holder))
+
+    def add_to_env(self, env_cfg_additions):
+        raise NotImplementedError("add_to_env (SURVEY.md 8f rank 3) is not part of this scope row yet")
+
+    def get_rollouts(self):
+        if not self.sim._visualize_link_present:
+            return torch_to_bytes(torch.zeros((1, 1, 1)))
+        if self.mppi._fused_cost is not None:
+            return torch_to_bytes(self.mppi.get_rollouts())
+        return torch_to_bytes(torch.stack(self.sim.visualize_link_buffer))
+
+    def update_weights(self, weights):
+        self.objective.weights = weights
+        self._bind_objective()
+
+    def update_mppi_params(self, params):
+        self.cfg.mppi.noise_sigma = params["noise_sigma"]
+        self.sim.stop_sim()
+        self._build(self._prior_obj)

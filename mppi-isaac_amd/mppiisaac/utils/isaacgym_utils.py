@@ -1,0 +1,41 @@
+"""Asset / actor loading (reference mppiisaac/utils/isaacgym_utils.py:14-78).
+
+`load_actor_cfgs` keeps the reference behaviour: conf/actors/<name>.yaml -> ActorWrapper(**yaml)
+with PyYAML's SafeLoader (:70-78).  `load_asset` replaces gym.load_asset (:14-29): instead of
+importing a URDF into PhysX it returns the compiled model (assets/compiled/*.json) produced by
+mppiisaac.backend.urdf_compile from that URDF."""
+import glob
+import json
+import os
+from typing import List
+
+import yaml
+
+import mppiisaac
+from mppiisaac.planner.isaacgym_wrapper import ActorWrapper
+
+PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(mppiisaac.__file__)))
+CONF_DIR = os.path.join(PKG_ROOT, "conf")
+COMPILED_DIR = os.path.join(PKG_ROOT, "assets", "compiled")
+
+
+def load_actor_cfgs(actors: List[str]) -> List[ActorWrapper]:
+    actor_cfgs = []
+    for actor_name in actors:
+        with open(os.path.join(CONF_DIR, "actors", f"{actor_name}.yaml")) as f:
+            actor_cfgs.append(ActorWrapper(**yaml.load(f, Loader=yaml.SafeLoader)))
+    return actor_cfgs
+
+
+def load_asset(actor_cfg: ActorWrapper) -> dict:
+    """Compiled model of a robot actor, looked up by its `urdf_file`."""
+    if actor_cfg.type != "robot":
+        raise NotImplementedError("only robot actors have a compiled asset; boxes/spheres are described by the actor cfg")
+    for path in sorted(glob.glob(os.path.join(COMPILED_DIR, "*.json"))):
+        with open(path) as f:
+            model = json.load(f)
+        if model.get("urdf_file") == actor_cfg.urdf_file:
+            return model
+    raise FileNotFoundError(
+        f"no compiled model for urdf_file='{actor_cfg.urdf_file}' under {COMPILED_DIR}; compile it with "
+        "mppiisaac.backend.urdf_compile.compile_urdf (tools/compile_models.py) and rebuild the HIP library")

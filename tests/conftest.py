@@ -1,0 +1,36 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "mppi-isaac_amd"))
+sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
+
+
+@pytest.fixture(scope="session")
+def oracle64():
+    from oracle.oracle import Oracle
+    return Oracle("f64")
+
+
+@pytest.fixture(scope="session")
+def oracle32():
+    from oracle.oracle import Oracle
+    return Oracle("f32")
+
+
+@pytest.fixture(scope="session")
+def hostemu():
+    """test-only g++ build of the per-sample device functions (tests/hostemu/hostemu.cpp)."""
+    import ctypes as C
+    d = os.path.join(ROOT, "tests", "hostemu")
+    subprocess.run(["make", "-C", d, "-s"], check=True)
+    lib = C.CDLL(os.path.join(d, "libhostemu.so"))
+    lib.emu_cost.restype = C.c_float
+    return lib

@@ -1,0 +1,67 @@
+// hostemu.cpp - TEST-ONLY host build of the per-sample device functions (csrc/mppi_device.hpp).
+// g++ compiles the very same templates the GPU kernels instantiate, so the fp32 world-frame
+// arithmetic can be compared with the oracle on a machine without a GPU (pytest -m "not gpu").
+// Nothing in the product path loads this library; the wave-level reductions and launches in
+// mppi_hip.hip are only exercised by the -m gpu tests.
+#include <string>
+#include <vector>
+
+#include "../../mppi-isaac_amd/csrc/mppi_pack.hpp"
+
+using namespace mppi;
+
+extern "C" {
+
+int emu_rollout(const mppi_model_t *model, const mppi_config_t *cfg, const mppi_cost_t *cost, const float *dof0, const float *root0,
+                const float *U, const float *eps, const float *prior, float *S, float *du, float *viz) {
+    DevModel m; DevCfg c; DevCost k; std::string err;
+    if (!pack_model(*model, m, err) || !pack_config(*cfg, c, err) || !pack_cost(*cost, m, k, err)) return -1;
+    int parents[MPPI_MAX_BODIES];
+    for (int i = 0; i < m.nb; i++) parents[i] = m.b[i].parent;
+    bool ok = dispatch_topology(m.nb, parents, [&](auto topo) {
+        using T = decltype(topo);
+        for (int s = 0; s < c.K; s++) S[s] = rollout_sample<T>(m, c, k, dof0, root0, U, eps, prior, du, viz, s);
+    });
+    return ok ? 0 : -3;
+}
+
+int emu_step(const mppi_model_t *model, const float *root, float *q, float *qd, const float *u) {
+    DevModel m; std::string err;
+    if (!pack_model(*model, m, err)) return -1;
+    int parents[MPPI_MAX_BODIES];
+    for (int i = 0; i < m.nb; i++) parents[i] = m.b[i].parent;
+    bool ok = dispatch_topology(m.nb, parents, [&](auto topo) {
+        using T = decltype(topo);
+        float target[MPPI_MAX_BODIES], uu[kMaxNu] = {0};
+        for (int c = 0; c < m.nu; c++) uu[c] = u[c];
+        cmd_map<T>(m, uu, target);
+        step<T>(m, root, q, qd, target);
+    });
+    return ok ? 0 : -3;
+}
+
+int emu_rigid_body_state(const mppi_model_t *model, const float *root, const float *q, const float *qd, float *rb, float *cf) {
+    DevModel m; std::string err;
+    if (!pack_model(*model, m, err)) return -1;
+    int parents[MPPI_MAX_BODIES];
+    for (int i = 0; i < m.nb; i++) parents[i] = m.b[i].parent;
+    bool ok = dispatch_topology(m.nb, parents, [&](auto topo) {
+        using T = decltype(topo);
+        rigid_body_state<T>(m, root, q, qd, rb, cf);
+    });
+    return ok ? 0 : -3;
+}
+
+float emu_cost(const mppi_model_t *model, const mppi_cost_t *cost, const float *root, const float *q, const float *qd) {
+    DevModel m; DevCost k; std::string err;
+    if (!pack_model(*model, m, err) || !pack_cost(*cost, m, k, err)) return -1e30f;
+    int parents[MPPI_MAX_BODIES];
+    for (int i = 0; i < m.nb; i++) parents[i] = m.b[i].parent;
+    float out = -1e30f;
+    dispatch_topology(m.nb, parents, [&](auto topo) {
+        using T = decltype(topo);
+        out = stage_cost<T>(m, k, root, q, qd);
+    });
+    return out;
+}
+}

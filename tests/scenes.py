@@ -1,0 +1,56 @@
+"""Shared builders for the BASELINE workloads: scene + MPPI config + cost spec."""
+import numpy as np
+
+from mppiisaac.backend import capi
+from mppiisaac.planner.isaacgym_wrapper import IsaacGymConfig, Scene
+from mppiisaac.planner.mppi import make_config
+from mppiisaac.utils.config_store import load_config
+from mppiisaac.utils.isaacgym_utils import load_actor_cfgs, load_asset
+
+
+def build_scene(actors, init_positions=None, isaacgym="normal", overrides=None):
+    env_cfg = load_actor_cfgs(actors)
+    robots = [a for a in env_cfg if a.type == "robot"]
+    if init_positions:
+        for p, a in zip(init_positions, robots):
+            a.init_pos = list(p)
+    cfg = load_config({"defaults": [{"isaacgym": isaacgym}]}).isaacgym
+    for k, v in (overrides or {}).items():
+        setattr(cfg, k, v)
+    return Scene(env_cfg, cfg, load_asset(robots[0]))
+
+
+def panda_reach(K=64, H=20, goal=(0.5, -0.4, 0.3), **mppi_over):
+    """BASELINE config 3: panda_stick + goal, conf/mppi/panda.yaml with K/H overridden."""
+    scene = build_scene(["panda_stick", "goal"], [[0.0, 0.0, 0.0]])
+    ex = load_config({"defaults": [{"mppi": "panda"}, {"isaacgym": "normal"}]})
+    ex.mppi.num_samples, ex.mppi.horizon = K, H
+    for k, v in mppi_over.items():
+        setattr(ex.mppi, k, v)
+    cfg = make_config(ex.mppi, viz_link=scene.viz_link_index())
+    dof, root = scene.initial_state()
+    root[scene.actor_index("goal"), 0:3] = goal
+    cost = capi.Cost()
+    cost.kind = capi.COST_PANDA_REACH
+    cost.link[0] = scene.rigid_body_index("panda", "panda_ee_tip")
+    cost.actor[0] = scene.actor_index("goal")
+    cost.w[0], cost.w[1] = 1.0, 0.5
+    return scene, scene.to_c(), cfg, cost, dof, root
+
+
+def point_reach(K=64, H=10, goal=(4.5, 0.2), **mppi_over):
+    """BASELINE configs 1/2: point_robot + goal, conf/mppi/pointbot.yaml with K/H overridden."""
+    scene = build_scene(["point_robot", "goal"], [[0.0, 0.0, 0.05]])
+    ex = load_config({"defaults": [{"mppi": "pointbot"}, {"isaacgym": "normal"}]})
+    ex.mppi.num_samples, ex.mppi.horizon, ex.mppi.use_priors = K, H, False
+    for k, v in mppi_over.items():
+        setattr(ex.mppi, k, v)
+    cfg = make_config(ex.mppi, viz_link=-1)
+    dof, root = scene.initial_state()
+    dof[0] = 0.1
+    root[scene.actor_index("goal"), 0:2] = goal
+    cost = capi.Cost()
+    cost.kind = capi.COST_POINT_REACH
+    cost.actor[0] = scene.actor_index("goal")
+    cost.w[0] = 2.0
+    return scene, scene.to_c(), cfg, cost, dof, root

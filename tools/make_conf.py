@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Restate the reference's actor descriptions (conf/actors/*.yaml) in this repo's own conf tree.
+Input: tests/golden/actor_cfgs.json (ActorWrapper field dicts captured by tools/make_golden.py);
+output: mppi-isaac_amd/conf/actors/<name>.yaml holding only the non-default fields."""
+import json, os, sys
+import yaml
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "mppi-isaac_amd"))
+from mppiisaac.planner.isaacgym_wrapper import ActorWrapper
+import dataclasses
+
+gold = json.load(open(os.path.join(ROOT, "tests", "golden", "actor_cfgs.json")))
+out = os.path.join(ROOT, "mppi-isaac_amd", "conf", "actors")
+os.makedirs(out, exist_ok=True)
+for fname, fields in gold.items():
+    dflt = dataclasses.asdict(ActorWrapper(type=fields["type"], name=fields["name"]))
+    keep = {"type": fields["type"], "name": fields["name"]}
+    for k, v in fields.items():
+        if k in ("type", "name"):
+            continue
+        if v != dflt[k]:
+            keep[k] = v
+    with open(os.path.join(out, fname + ".yaml"), "w") as f:
+        f.write(f"# actor '{fname}': restated from the reference's conf/actors/{fname}.yaml (non-default ActorWrapper fields)\n")
+        yaml.safe_dump(keep, f, default_flow_style=None, sort_keys=False, width=120)
+print("wrote", len(gold), "actor files")
