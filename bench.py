@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Closed-loop MPPI benchmark on the BASELINE.json workload (Panda 7-DoF reach, K=4096, H=20).
+
+One "step" = one control iteration: rollout kernel (K samples x H horizon steps of articulated-body
+dynamics + fused cost) -> reduce -> (all-gather of shard records when --gpus > 1) -> nominal update
+-> the K=1 world is stepped with the action and its new state is fed back (closed loop, everything
+device-resident) -> the action is copied to the host.  Weak scaling: every GPU owns 4096 samples, the
+softmax weights are combined over all ranks; `value` counts 4096-sample control iterations per second
+summed over ranks (at --gpus 1 it is exactly the control-loop Hz at K=4096, H=20).
+
+Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement" for how roofline/cpu_baseline are defined.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "mppi-isaac_amd"))
+sys.path.insert(0, ROOT)
+
+K_PER_GPU, HORIZON = 4096, 20
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
+Q0 = [0.0, -0.94, 0.0, -2.8, 0.0, 1.8675, 0.0]  # conf/actors/panda_stick.yaml init_joint_pose
+GOAL = [0.5, -0.4, 0.3]                          # reference benchmarks/panda_arm/setup/exp.yaml:21-24
+
+
+def make_cfg(k_total):
+    from mppiisaac.utils.config_store import load_config
+    return load_config({"defaults": [{"mppi": "panda"}, {"isaacgym": "normal"}], "actors": ["panda_stick", "goal"],
+                        "initial_actor_positions": [[0.0, 0.0, 0.0]], "nx": 14},
+                       overrides={"mppi.num_samples": k_total, "mppi.horizon": HORIZON, "mppi.filter_u": False})
+
+
+def cpu_baseline(planner, seconds_budget=20.0):
+    """The oracle (C restatement, fp32, OpenMP over samples) timed on this box's host cores on the same
+    K=4096 x H=20 control iteration.  Bounded sample: as many iterations as fit ~seconds_budget."""
+    from mppiisaac.backend import capi
+    from oracle.oracle import Oracle
+    sim = planner.sim
+    cores = os.cpu_count() or 1
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    o = Oracle("f32")
+    eps = np.zeros((HORIZON, 7, K_PER_GPU), np.float32)
+    capi.check(sim._lib, sim._lib.mppi_get_noise(sim._ctx, capi.fptr(eps)))
+    dof = np.zeros(14, np.float32)
+    dof[0::2] = Q0
+    root = sim._root_state[0].cpu().numpy()
+    U = np.zeros((HORIZON, 7), np.float32)
+    cost = planner.objective.fused_spec(sim)
+    t0 = time.perf_counter()
+    U, a, S = o.command(sim._c_model, sim._mppi_config, cost, dof, root, U, eps)
+    first = time.perf_counter() - t0
+    n = max(1, min(20, int(seconds_budget / max(first, 1e-3)) - 1))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        U, a, S = o.command(sim._c_model, sim._mppi_config, cost, dof, root, U, eps)
+    dt = (time.perf_counter() - t0) / n
+    return {"value": 1.0 / dt, "unit": "Hz (K=4096,H=20 control iterations/s)", "cores": cores, "kind": "port",
+            "sample": f"{n} open-loop control iterations of the same K=4096xH=20 panda workload, oracle/mppi_oracle.c fp32, "
+                      f"OpenMP over samples on {cores} host threads ({dt * 1e3:.1f} ms/iteration)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--async-loop", action="store_true", help="do not copy the action to the host every iteration")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from mppiisaac.backend import capi
+    from mppiisaac.objectives import PandaReachObjective
+    from mppiisaac.planner.isaacgym_wrapper import IsaacGymWrapper
+    from mppiisaac.planner.mppi_isaac import MPPIisaacPlanner
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world_size:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    if world_size > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", local_rank))
+
+    cfg = make_cfg(K_PER_GPU * world_size)
+    cfg.mppi.device = f"cuda:{local_rank}"
+    objective = PandaReachObjective(cfg)
+    planner = MPPIisaacPlanner(cfg, objective, shard=world_size > 1)
+    world = IsaacGymWrapper(cfg.isaacgym, actors=cfg.actors, init_positions=cfg.initial_actor_positions, num_envs=1,
+                            device=cfg.mppi.device)
+    lib, P, W = planner.sim._lib, planner.sim._ctx, world._ctx
+    for sim in (planner.sim, world):
+        sim.set_actor_position_by_name(GOAL, "goal")
+    dof0 = np.zeros(14, np.float32)
+    dof0[0::2] = Q0
+    root0 = world._root_state[0].cpu().numpy()
+    for sim in (planner.sim, world):
+        sim._push_single_state(dof0, root0)
+    planner._bind_objective()
+    records = planner.mppi._records
+    action = np.zeros(7, np.float32)
+    ap_ = capi.fptr(action)
+
+    def iterate(sync):
+        capi.check(lib, lib.mppi_rollout(P))
+        if world_size > 1:
+            capi.check(lib, lib.mppi_reduce(P, ctypes.c_void_p(records[rank].data_ptr())))
+            dist.all_gather_into_tensor(records.view(-1), records[rank].clone())
+            capi.check(lib, lib.mppi_update(P, ctypes.c_void_p(records.data_ptr()), world_size))
+        else:
+            capi.check(lib, lib.mppi_reduce(P, None))
+            capi.check(lib, lib.mppi_update(P, None, 1))
+        capi.check(lib, lib.mppi_world_step_from(W, P))
+        capi.check(lib, lib.mppi_set_state_from_world(P, W))
+        if sync:
+            capi.check(lib, lib.mppi_get_action(P, ap_))  # D2H + stream sync: the controller output
+
+    def barrier():
+        if world_size > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sync = not args.async_loop
+    for _ in range(args.warmup):
+        iterate(sync)
+    capi.check(lib, lib.mppi_set_profiling(P, 1))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        iterate(sync)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kms = []
+    for which in range(3):
+        ms = ctypes.c_float()
+        capi.check(lib, lib.mppi_kernel_ms(P, which, ctypes.byref(ms)))
+        kms.append(ms.value)
+    capi.check(lib, lib.mppi_set_profiling(P, 0))
+    if world_size > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # final state sanity: the closed loop must have moved the end effector towards the goal
+    world._materialise()
+    ee = world.get_actor_link_by_name("panda", "panda_ee_tip")[0, 0:3].cpu().numpy()
+    dist_to_goal = float(np.linalg.norm(ee - np.asarray(GOAL)))
+
+    if rank == 0:
+        loop_hz = args.steps / elapsed
+        nu, K, H = 7, K_PER_GPU, HORIZON
+        bytes_alg = 4 * (3 * K * H * nu + 2 * K + H * nu)  # SURVEY.md 8d, per GPU per control iteration
+        achieved = bytes_alg / (kms[0] * 1e-3) / 1e9
+        out = {
+            "metric": "MPPI control-loop Hz (K samples x H horizon), Panda 7-DoF K=4096 H=20",
+            "value": loop_hz * world_size,
+            "unit": "Hz (4096-sample x 20-step control iterations per second, summed over GPUs)",
+            "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "panda_stick reach (BASELINE configs[2]): ABA from URDF, no contact, fused reach cost",
+                       "K_per_gpu": K, "K_total": K * world_size, "H": H, "nu": nu, "dt": cfg.isaacgym.dt,
+                       "substeps": cfg.isaacgym.substeps, "closed_loop": True, "action_to_host_every_step": sync,
+                       "parallelism": f"sample-shard x{world_size}" if world_size > 1 else "single GPU",
+                       "loop_hz": loop_hz, "env_steps_per_s": loop_hz * K * H * world_size,
+                       "final_ee_to_goal_m": dist_to_goal},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_rollout",
+                         "kernel_ms": kms[0], "bytes_alg_per_launch": bytes_alg,
+                         "note": "latency/occupancy-bound path (SURVEY 8d): 64 waves on 256 CUs; see DESIGN.md for the fp32-VALU view"},
+            "kernels_ms": {"k_rollout": kms[0], "k_reduce": kms[1], "k_combine_update": kms[2]},
+        }
+        if world_size == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(planner)
+        print(json.dumps(out))
+    if world_size > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

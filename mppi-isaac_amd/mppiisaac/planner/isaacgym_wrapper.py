@@ -88,6 +88,14 @@ def diff_drive_ik(actor: ActorWrapper, u: torch.Tensor):
     return left, right
 
 
+def interleave_dof_state(q, qdot, n_dof: int) -> np.ndarray:
+    """[q0, qd0, q1, qd1, ...] as float32 - the dof_state row reset_robot_state builds (reference :606-612)."""
+    dof = np.zeros(2 * n_dof, np.float32)
+    dof[0::2] = np.asarray(q, np.float32)[:n_dof]
+    dof[1::2] = np.asarray(qdot, np.float32)[:n_dof]
+    return dof
+
+
 class Scene:
     """Host description of one env: actors + compiled robot model -> C-ABI mppi_model_t."""
 
@@ -339,10 +347,7 @@ class IsaacGymWrapper:
         """reference :574-619 (urdfenvs compatibility): q, qdot lists -> interleaved DOF state in all envs."""
         if self.scene.robot.differential_drive:
             raise NotImplementedError("reset_robot_state for differential-drive robots (reference branch raises, SURVEY.md C)")
-        n = self.scene.n_dof
-        dof = np.zeros(2 * n, np.float32)
-        dof[0::2] = np.asarray(q, np.float32)[:n]
-        dof[1::2] = np.asarray(qdot, np.float32)[:n]
+        dof = interleave_dof_state(q, qdot, self.scene.n_dof)
         root = (self.saved_root_state if self.saved_root_state is not None else self._root_state)[0].cpu().numpy()
         self._push_single_state(dof, root)
 

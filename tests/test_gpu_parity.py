@@ -1,0 +1,256 @@
+"""Parity of the HIP path (through the C-ABI, libmppi_hip.so) with the CPU oracle on a real MI355X.
+
+Tolerances (fp32 device arithmetic vs the fp64 oracle): sampled noise 1e-6 absolute,
+trajectory cost 1e-4 relative, effective perturbation 1e-6, action 1e-3 * |u_max|, joint position
+1e-4 rad after a 20-step rollout."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from mppiisaac.backend import capi
+from scenes import panda_reach, point_reach
+
+pytestmark = pytest.mark.gpu
+
+
+class Ctx:
+    """thin test harness over the raw C-ABI (what a host binding does)."""
+
+    def __init__(self, model, cfg, cost=None, device=0):
+        self.lib = capi.load_library()
+        self.model, self.cfg = model, cfg
+        self.ctx = C.c_void_p()
+        capi.check(self.lib, self.lib.mppi_create(C.byref(model), C.byref(cfg), device, C.byref(self.ctx)))
+        if cost is not None:
+            capi.check(self.lib, self.lib.mppi_set_cost(self.ctx, C.byref(cost)))
+        self.K, self.H, self.nu = cfg.num_samples, cfg.horizon, cfg.nu
+
+    def call(self, name, *args):
+        capi.check(self.lib, getattr(self.lib, name)(self.ctx, *args))
+
+    def get(self, name, shape):
+        out = np.zeros(shape, np.float32)
+        self.call(name, capi.fptr(out))
+        return out
+
+    def set_state(self, dof, root):
+        d, r = np.ascontiguousarray(dof, np.float32), np.ascontiguousarray(root, np.float32)
+        self.call("mppi_set_state", capi.fptr(d), capi.fptr(r))
+
+    def set_U(self, U):
+        u = np.ascontiguousarray(U, np.float32)
+        self.call("mppi_set_nominal", capi.fptr(u))
+
+    def close(self):
+        self.lib.mppi_destroy(self.ctx)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    assert torch.cuda.is_available()
+    return capi.load_library()
+
+
+@pytest.mark.parametrize("make,K,H", [(point_reach, 1024, 15), (panda_reach, 512, 20)])
+def test_sample_rollout_update_match_oracle(make, K, H, lib, oracle64):
+    scene, m, cfg, cost, dof, root = make(K=K, H=H)
+    c = Ctx(m, cfg, cost)
+    c.call("mppi_sample", C.c_uint32(0))
+    eps = c.get("mppi_get_noise", (H, cfg.nu, K))
+    np.testing.assert_allclose(eps, oracle64.sample(cfg), atol=1e-6)
+    rng = np.random.default_rng(0)
+    U0 = (0.05 * rng.normal(size=(H, cfg.nu))).astype(np.float32)
+    c.set_state(dof, root)
+    c.set_U(U0)
+    c.call("mppi_rollout")
+    S = c.get("mppi_get_costs", (K,))
+    du = c.get("mppi_get_perturbations", (H, cfg.nu, K))
+    So, duo, vizo = oracle64.rollout(m, cfg, cost, dof, root, U0, eps, want_viz=True)
+    np.testing.assert_allclose(S, So, rtol=1e-4)
+    np.testing.assert_allclose(du, duo, atol=1e-6)
+    if cfg.want_rollouts:
+        np.testing.assert_allclose(c.get("mppi_get_rollouts", (H, K, 3)), vizo, atol=1e-4)
+    c.call("mppi_reduce", None)
+    c.call("mppi_update", None, 1)
+    action = c.get("mppi_get_action", (cfg.nu,))
+    U1 = c.get("mppi_get_nominal", (H, cfg.nu))
+    be = c.get("mppi_get_weights_stats", (2,))
+    Uo, ao, beo = oracle64.update(cfg, oracle64.record(cfg, So, duo), U0)
+    umax = max(abs(cfg.u_max[0]), abs(cfg.u_min[0]))
+    np.testing.assert_allclose(action, ao, atol=1e-3 * umax)
+    np.testing.assert_allclose(U1, Uo, atol=1e-3 * umax)
+    np.testing.assert_allclose(be, beo, rtol=2e-3)
+    c.close()
+
+
+def test_closed_loop_matches_oracle(lib, oracle64):
+    """5 closed-loop iterations: planner (K=256) + K=1 world on the device vs the same loop on the oracle."""
+    scene, m, cfg, cost, dof, root = panda_reach(K=256, H=12)
+    from mppiisaac.planner.mppi import make_config
+    from mppiisaac.utils.config_store import load_config
+    wcfg = make_config(load_config({"defaults": [{"mppi": "panda"}]}, overrides={"mppi.num_samples": 1, "mppi.horizon": 1}).mppi)
+    p, w = Ctx(m, cfg, cost), Ctx(m, wcfg)
+    p.call("mppi_sample", C.c_uint32(0))
+    eps = p.get("mppi_get_noise", (12, 7, 256))
+    for c in (p, w):
+        c.set_state(dof, root)
+    w.call("mppi_sim_reset")
+    q, qd, U = dof[0::2].astype(np.float64), dof[1::2].astype(np.float64), np.zeros((12, 7))
+    for it in range(5):
+        action = np.zeros(7, np.float32)
+        p.call("mppi_command", capi.fptr(action))
+        capi.check(lib, lib.mppi_world_step_from(w.ctx, p.ctx))
+        capi.check(lib, lib.mppi_set_state_from_world(p.ctx, w.ctx))
+        d = np.zeros(14); d[0::2], d[1::2] = q, qd
+        U, ao, _ = oracle64.command(m, cfg, cost, d, root, U, eps)
+        q, qd = oracle64.step(m, root, q, qd, oracle64.cmd_map(m, ao))
+        np.testing.assert_allclose(action, ao, atol=2e-4)
+    dev_dof = np.zeros(14, np.float32)
+    p.call("mppi_get_state", capi.fptr(dev_dof), None)
+    np.testing.assert_allclose(dev_dof[0::2], q, atol=1e-4)
+    np.testing.assert_allclose(dev_dof[1::2], qd, atol=1e-3)
+    p.close(); w.close()
+
+
+def test_two_shards_combine_to_single_context(lib, oracle64):
+    """the N-GPU arithmetic on one GPU: two contexts own samples [0,K/2) and [K/2,K); their shard records
+    combined by mppi_update must reproduce the single-context action."""
+    K, H = 512, 12
+    scene, m, cfg, cost, dof, root = panda_reach(K=K, H=H)
+    from mppiisaac.planner.mppi import make_config
+    from mppiisaac.utils.config_store import load_config
+    ex = load_config({"defaults": [{"mppi": "panda"}]}, overrides={"mppi.num_samples": K, "mppi.horizon": H})
+    full = Ctx(m, cfg, cost)
+    full.call("mppi_sample", C.c_uint32(0)); full.set_state(dof, root)
+    a_full = np.zeros(7, np.float32)
+    full.call("mppi_command", capi.fptr(a_full))
+    eps_full = full.get("mppi_get_noise", (H, 7, K))
+    RF = lib.mppi_record_floats(full.ctx)
+    records = torch.zeros((2, RF), dtype=torch.float32, device="cuda")
+    shards = []
+    for r in range(2):
+        sc = make_config(ex.mppi, k_offset=r * K // 2, k_local=K // 2, viz_link=scene.viz_link_index())
+        s = Ctx(m, sc, cost)
+        s.call("mppi_sample", C.c_uint32(0)); s.set_state(dof, root)
+        np.testing.assert_array_equal(s.get("mppi_get_noise", (H, 7, K // 2)), eps_full[:, :, r * K // 2:(r + 1) * K // 2])
+        s.call("mppi_rollout")
+        s.call("mppi_reduce", C.c_void_p(records[r].data_ptr()))
+        shards.append(s)
+    for s in shards:
+        s.call("mppi_update", C.c_void_p(records.data_ptr()), 2)
+        np.testing.assert_allclose(s.get("mppi_get_action", (7,)), a_full, atol=2e-6)
+        s.close()
+    full.close()
+
+
+def test_full_size_properties(lib, oracle64):
+    """BASELINE size K=4096, H=20 through size-independent properties (the oracle is only sampled)."""
+    K, H = 4096, 20
+    scene, m, cfg, cost, dof, root = panda_reach(K=K, H=H)
+    c = Ctx(m, cfg, cost)
+    c.call("mppi_sample", C.c_uint32(0)); c.set_state(dof, root)
+    a = np.zeros(7, np.float32)
+    c.call("mppi_command", capi.fptr(a))
+    S, du = c.get("mppi_get_costs", (K,)), c.get("mppi_get_perturbations", (H, 7, K))
+    eps = c.get("mppi_get_noise", (H, 7, K))
+    assert np.isfinite(S).all() and (S > 0).all()
+    assert (np.abs(du) <= 0.2 + 1e-6).all()                       # clamp to u_min/u_max around U = 0
+    np.testing.assert_array_equal(du[:, :, -1], 0.0)              # null-action sample
+    # the action is the softmax-weighted mean of the effective perturbations (U0 = 0)
+    w = np.exp(-(S.astype(np.float64) - S.min()) / cfg.lambda_)
+    np.testing.assert_allclose(a, (du[0].astype(np.float64) * w).sum(1) / w.sum(), atol=2e-6)
+    # spot-check 64 scattered samples against the oracle
+    idx = np.arange(0, K, 64)
+    from mppiisaac.planner.mppi import make_config
+    from mppiisaac.utils.config_store import load_config
+    ex = load_config({"defaults": [{"mppi": "panda"}]}, overrides={"mppi.num_samples": K, "mppi.horizon": H})
+    for k in idx[:8]:
+        sc = make_config(ex.mppi, k_offset=int(k), k_local=1, viz_link=scene.viz_link_index())
+        So, _, _ = oracle64.rollout(m, sc, cost, dof, root, np.zeros((H, 7)), eps[:, :, k:k + 1])
+        assert S[k] == pytest.approx(So[0], rel=1e-4)
+    # determinism: same inputs -> bitwise same outputs
+    c.set_U(np.zeros((H, 7)))
+    c.call("mppi_rollout")
+    S2 = c.get("mppi_get_costs", (K,))
+    np.testing.assert_array_equal(S, S2)
+    c.close()
+
+
+def test_generic_objective_mode_equals_fused(lib):
+    """Objective contract (compute_cost(sim) per horizon step, reference mppi_isaac.py:57-69) == fused kernel."""
+    from mppiisaac.objectives import PandaReachObjective, PointReachObjective
+    from mppiisaac.planner.mppi_isaac import MPPIisaacPlanner
+    from mppiisaac.utils.config_store import load_config
+    for actors, mppi, nx, Obj, q in ((["panda_stick", "goal"], "panda", 14, PandaReachObjective, [0, -0.94, 0, -2.8, 0, 1.8675, 0]),
+                                     (["point_robot", "goal"], "pointbot", 6, PointReachObjective, [0.1, 0, 0])):
+        cfg = load_config({"defaults": [{"mppi": mppi}, {"isaacgym": "normal"}], "actors": actors,
+                           "initial_actor_positions": [[0.0, 0.0, 0.05]], "nx": nx},
+                          overrides={"mppi.num_samples": 256, "mppi.horizon": 12, "mppi.use_priors": False, "mppi.filter_u": False})
+
+        class Generic(Obj):      # same cost, but no fused_spec -> host callback path
+            fused_spec = None
+        fused = MPPIisaacPlanner(cfg, Obj(cfg))
+        generic = MPPIisaacPlanner(cfg, Generic(cfg))
+        for pl in (fused, generic):
+            pl.sim.set_actor_position_by_name([0.5, -0.4, 0.3], "goal")
+        af = fused.compute_action(q, [0.0] * len(q)).numpy()
+        ag = generic.compute_action(q, [0.0] * len(q)).numpy()
+        Sf, Sg = fused.mppi.get_costs().numpy(), generic.mppi.get_costs().numpy()
+        np.testing.assert_allclose(Sg, Sf, rtol=2e-4)
+        np.testing.assert_allclose(ag, af, atol=1e-4)
+        # get_rollouts: [H, K, 3] in both modes
+        from mppiisaac.utils.transport import bytes_to_torch
+        if fused.sim._visualize_link_present:
+            rf, rg = bytes_to_torch(fused.get_rollouts()), bytes_to_torch(generic.get_rollouts()).cpu()
+            assert tuple(rf.shape) == (12, 256, 3)
+            np.testing.assert_allclose(rg.numpy(), rf.numpy(), atol=1e-4)
+
+
+def test_world_sim_matches_oracle_and_reference_layouts(lib, oracle64):
+    """IsaacGymWrapper(num_envs=1): apply_robot_cmd + step and the four reference-layout tensors."""
+    from mppiisaac.planner.isaacgym_wrapper import IsaacGymWrapper
+    from mppiisaac.utils.config_store import load_config
+    cfg = load_config({"defaults": [{"isaacgym": "normal"}]})
+    sim = IsaacGymWrapper(cfg.isaacgym, actors=["panda_stick", "goal"], init_positions=[[0, 0, 0]], num_envs=1)
+    m = sim._c_model
+    dof, root = sim.scene.initial_state()
+    assert sim._dof_state.shape == (1, 14) and sim._root_state.shape == (1, 2, 13)
+    assert sim._rigid_body_state.shape == (1, 11, 13) and sim._net_contact_force.shape == (1, 11, 3)
+    np.testing.assert_allclose(sim._dof_state[0].cpu().numpy(), dof)
+    u = torch.tensor([0.1, -0.2, 0.05, 0.2, -0.1, 0.15, 0.0])
+    q, qd = dof[0::2].astype(np.float64), dof[1::2].astype(np.float64)
+    for _ in range(10):
+        sim.apply_robot_cmd(u)
+        sim.step()
+        q, qd = oracle64.step(m, root, q, qd, oracle64.cmd_map(m, u.numpy()))
+    got = sim.get_dof_state()[0].cpu().numpy()
+    np.testing.assert_allclose(got[0::2], q, atol=1e-4)
+    np.testing.assert_allclose(got[1::2], qd, atol=5e-4)
+    rb, _ = oracle64.rigid_body_state(m, root, q, qd)
+    np.testing.assert_allclose(sim._rigid_body_state[0].cpu().numpy(), rb, atol=1e-4)
+    tip = sim.get_actor_link_by_name("panda", "panda_ee_tip")
+    assert tuple(tip.shape) == (1, 13)
+    np.testing.assert_allclose(sim.get_actor_position_by_name("goal")[0].cpu().numpy(), root[1, 0:3])
+    assert len(sim.visualize_link_buffer) == 10 and tuple(sim.visualize_link_buffer[0].shape) == (1, 3)
+
+
+def test_error_paths(lib):
+    scene, m, cfg, cost, dof, root = panda_reach(K=64, H=12)
+    ctx = C.c_void_p()
+    bad = capi.Cost(); bad.kind = capi.COST_BOXER_PUSH
+    c = Ctx(m, cfg)
+    assert lib.mppi_rollout(c.ctx) == -4 and b"no fused cost" in lib.mppi_last_error()      # MPPI_ESTATE
+    assert lib.mppi_set_cost(c.ctx, C.byref(bad)) == -3                                       # MPPI_EUNSUPPORTED
+    c.close()
+    from scenes import build_scene
+    boxer = build_scene(["boxer", "block", "goal"]).to_c()
+    from mppiisaac.planner.mppi import make_config
+    from mppiisaac.utils.config_store import load_config
+    bc = make_config(load_config({"defaults": [{"mppi": "boxer_push"}]}).mppi)
+    assert lib.mppi_create(C.byref(boxer), C.byref(bc), 0, C.byref(ctx)) == -1
+    assert b"floating-base" in lib.mppi_last_error()
+    cfg.lambda_ = 0.0
+    assert lib.mppi_create(C.byref(m), C.byref(cfg), 0, C.byref(ctx)) == -1

@@ -1,0 +1,97 @@
+"""Host-side logic that needs no GPU: config composition, C-ABI struct packing, the spline basis,
+the built library's symbol table, loud failure of the product path without a GPU."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from mppiisaac.backend import capi
+from mppiisaac.planner.mppi import MPPIConfig, bspline_basis, knots_for_horizon, make_config
+from mppiisaac.utils.config_store import ExampleConfig, load_config
+from scenes import build_scene
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_example_config_composition():
+    cfg = load_config({"defaults": [{"mppi": "panda"}, {"isaacgym": "normal"}], "n_steps": 10000,
+                       "actors": ["panda_stick", "goal"], "initial_actor_positions": [[0.0, 0.0, 0.0]], "nx": 14,
+                       "hydra": {"searchpath": ["pkg://conf"]}})
+    assert isinstance(cfg, ExampleConfig) and cfg.nx == 14
+    # values of the reference's conf/mppi/panda.yaml:6-22 and conf/isaacgym/normal.yaml:4-5
+    assert (cfg.mppi.num_samples, cfg.mppi.horizon, cfg.mppi.lambda_) == (200, 12, 0.05)
+    assert cfg.mppi.u_min == [-0.2] and cfg.mppi.u_max == [0.2] and cfg.mppi.sample_null_action is True
+    assert np.allclose(np.diag(np.asarray(cfg.mppi.noise_sigma)), 0.1) and len(cfg.mppi.noise_sigma) == 7
+    assert (cfg.isaacgym.dt, cfg.isaacgym.substeps) == (0.05, 2)
+    with pytest.raises(KeyError):
+        load_config({"defaults": [{"mppi": "panda"}]}, overrides={"mppi.not_a_field": 1})
+
+
+def test_make_config_fields_and_broadcast():
+    cfg = load_config({"defaults": [{"mppi": "boxer_push"}]}).mppi
+    c = make_config(cfg, k_offset=100, k_local=50)
+    assert (c.num_samples, c.k_offset, c.k_total, c.nu, c.horizon) == (50, 100, 400, 2, 12)
+    assert list(c.u_min)[:2] == [-1.2, -3.5] and list(c.noise_sigma_diag)[:2] == [2.0, 8.0]
+    p = make_config(load_config({"defaults": [{"mppi": "panda"}]}).mppi)
+    assert list(p.u_max)[:7] == [0.2] * 7 and p.n_knots == 3 and p.sampling == capi.SAMPLE_HALTON_SPLINE
+    with pytest.raises(NotImplementedError):
+        make_config(MPPIConfig(noise_sigma=[[1.0, 0.1], [0.1, 1.0]]))
+    with pytest.raises(NotImplementedError):
+        make_config(MPPIConfig(noise_sigma=[[1.0]], update_cov=True))
+
+
+def test_bspline_basis_properties():
+    for H in (12, 15, 20, 30):
+        nk = knots_for_horizon(H)
+        B = bspline_basis(H, nk)
+        assert B.shape == (H, nk) and (B >= -1e-12).all()
+        np.testing.assert_allclose(B.sum(1), 1.0, atol=1e-12)     # partition of unity
+        assert B[0, 0] == pytest.approx(1.0) and B[-1, -1] == pytest.approx(1.0)  # clamped ends
+    assert knots_for_horizon(8) == 8                               # < 3 knots: sample every step
+
+
+def test_scene_layout_matches_survey_tables():
+    s = build_scene(["panda_stick", "goal"])
+    assert s.n_dof == 7 and s.nu == 7 and s.n_rb == 11             # B = 10 + 1
+    assert s.link_names[-2:] == ["panda_ee_finger", "panda_ee_tip"]
+    m = s.to_c()
+    assert [m.bodies[i].effort for i in range(7)] == [87, 87, 87, 87, 12, 12, 12]
+    assert m.drive_kd == 600.0 and m.substeps == 2 and m.dt == 0.05 and m.gravity[2] == -9.8
+    masses = [m.bodies[i].mass for i in range(7)]
+    np.testing.assert_allclose(masses, [2.975, 3.004, 2.328, 2.374, 3.419, 1.435, 0.537], atol=2e-3)
+    b = build_scene(["boxer", "block", "paper_obst1", "paper_obst2", "goal"])
+    assert b.nu == 2 and b.dof_names == ["wheel_right_joint", "wheel_left_joint"] and b.n_rb == 8 + 4
+    g = build_scene(["panda_gripper", "xaxis", "yaxis", "panda_pick_block", "table", "goal"])
+    assert g.nu == 9 and g.n_rb == 12 + 5
+    p = build_scene(["point_robot", "goal"])
+    assert [x["inertia"]["mass"] for x in p.robot_model["bodies"]] == [1.0, 1.0, 21.0]  # SURVEY D
+
+
+def test_library_exports_every_declared_symbol():
+    lib_path = capi.LIB_PATH
+    assert os.path.exists(lib_path), "run __graft_entry__.build() first"
+    lib = C.CDLL(lib_path)                       # loads without a GPU
+    for sym in capi.EXPORTED_SYMBOLS:
+        assert hasattr(lib, sym), sym
+    header = open(os.path.join(ROOT, "include", "mppi_hip.h")).read()
+    import re
+    declared = set(re.findall(r"\b(mppi_[a-z_]+)\s*\(", header))
+    assert declared == set(capi.EXPORTED_SYMBOLS), declared ^ set(capi.EXPORTED_SYMBOLS)
+    lib.mppi_abi_version.restype = C.c_int
+    assert lib.mppi_abi_version() == capi.ABI_VERSION
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from mppiisaac.objectives import PandaReachObjective
+    from mppiisaac.planner.mppi_isaac import MPPIisaacPlanner
+    cfg = load_config({"defaults": [{"mppi": "panda"}, {"isaacgym": "normal"}], "actors": ["panda_stick", "goal"],
+                       "initial_actor_positions": [[0.0, 0.0, 0.0]], "nx": 14})
+    with pytest.raises(Exception):               # no CPU pipeline, no silent fallback
+        MPPIisaacPlanner(cfg, PandaReachObjective(cfg))
+    cfg.mppi.device = "cpu"
+    with pytest.raises(capi.MppiHipError):
+        MPPIisaacPlanner(cfg, PandaReachObjective(cfg))
