@@ -1,0 +1,18 @@
+#!/bin/bash
+# rocprofv3 passes of the bench command (run on the GPU box via gpurun):
+#   1. --kernel-trace --stats            per-kernel durations
+#   2. --pmc FETCH_SIZE                  HBM read bytes   (own pass, per MI355X_MICROARCH.md)
+#   3. --pmc WRITE_SIZE                  HBM write bytes  (own pass)
+# Summaries land in gpurun_out/prof_<tag>/ ; copy what should be judged into profiles/.
+set -u
+TAG=${1:-r01}
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+CMD="python $REPO/bench.py --steps 300 --warmup 30 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace_bench.json 2> $OUT/trace.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $CMD > $OUT/pmc_fetch_bench.json 2> $OUT/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- $CMD > $OUT/pmc_write_bench.json 2> $OUT/pmc_write.err
+find $OUT -name "*.csv" | head -30
+for f in $(find $OUT/trace -name "*kernel_stats.csv"); do echo "== $f"; cat $f; done
