@@ -142,8 +142,8 @@ def main():
     kms = []
     for which in range(3):
         ms = ctypes.c_float()
-        capi.check(lib, lib.mppi_kernel_ms(P, which, ctypes.byref(ms)))
-        kms.append(ms.value)
+        rc = lib.mppi_kernel_ms(P, which, ctypes.byref(ms))  # rc != 0: that kernel was not launched (fused tail)
+        kms.append(ms.value if rc == 0 else 0.0)
     capi.check(lib, lib.mppi_set_profiling(P, 0))
     if world_size > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -160,6 +160,12 @@ def main():
         nu, K, H = 7, K_PER_GPU, HORIZON
         bytes_alg = 4 * (3 * K * H * nu + 2 * K + H * nu)  # SURVEY.md 8d, per GPU per control iteration
         achieved = bytes_alg / (kms[0] * 1e-3) / 1e9
+        traffic, traffic_src = None, None  # HBM bytes/launch from the last committed rocprofv3 PMC passes
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path))
+            traffic = pmc.get("k_rollout", {}).get("hbm_traffic_bytes_per_launch")
+            traffic_src = f"profiles/{pmc.get('tag')}_pmc_summary.json (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes of this command)"
         out = {
             "metric": "MPPI control-loop Hz (K samples x H horizon), Panda 7-DoF K=4096 H=20",
             "value": loop_hz * world_size,
@@ -175,10 +181,10 @@ def main():
                        "loop_hz": loop_hz, "env_steps_per_s": loop_hz * K * H * world_size,
                        "final_ee_to_goal_m": dist_to_goal},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_rollout",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_rollout",
                          "kernel_ms": kms[0], "bytes_alg_per_launch": bytes_alg,
                          "note": "latency/occupancy-bound path (SURVEY 8d): 64 waves on 256 CUs; see DESIGN.md for the fp32-VALU view"},
-            "kernels_ms": {"k_rollout": kms[0], "k_reduce": kms[1], "k_combine_update": kms[2]},
+            "kernels_ms": {"k_rollout(+record tail)": kms[0], "k_reduce(generic mode only)": kms[1], "k_combine_update": kms[2]},
         }
         if world_size == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(planner)

@@ -568,8 +568,10 @@ MPPI_HD float rollout_sample(CModel &m0, CCfg &cfg0, CCost &cost0, const float *
             M3 R;
             V3 p;
             link_pose<T>(m, P, cfg.viz_link, R, p);
-            float *o = viz + ((size_t)t * K + k) * 3;
-            o[0] = p.x; o[1] = p.y; o[2] = p.z;
+            // sample-minor [H][3][K]: three full-line coalesced stores per wave
+            viz[((size_t)t * 3 + 0) * K + k] = p.x;
+            viz[((size_t)t * 3 + 1) * K + k] = p.y;
+            viz[((size_t)t * 3 + 2) * K + k] = p.z;
         }
     }
     return S + ctrl;

@@ -57,33 +57,68 @@ __global__ __launch_bounds__(kWave) void k_rollout(const DevModel *__restrict__ 
                                                    const DevCost *__restrict__ cost, const float *__restrict__ x0_dof,
                                                    const float *__restrict__ x0_root, const float *__restrict__ U,
                                                    const float *__restrict__ eps, const float *__restrict__ prior,
-                                                   float *__restrict__ du, float *__restrict__ S, float *__restrict__ viz) {
-    const int k = blockIdx.x * kWave + threadIdx.x;
-    if (k >= cfg->K) return;
-    S[k] = rollout_sample<T>(*(CModel *)m, *(CCfg *)cfg, *(CCost *)cost, x0_dof, x0_root, U, eps, prior, du, viz, k);
-}
+                                                   float *__restrict__ du, float *__restrict__ S, float *__restrict__ viz,
+                                                   float *__restrict__ partials);
 
-// one wave per 64 samples -> partial record [beta, eta, N[HN]]
-__global__ __launch_bounds__(kWave) void k_reduce(const DevCfg *__restrict__ cfg, const float *__restrict__ S,
-                                                  const float *__restrict__ du, float *__restrict__ partials) {
-    const int K = cfg->K, HN = cfg->H * cfg->nu;
-    const int k = blockIdx.x * kWave + threadIdx.x;
-    const bool live = k < K;
-    float s = live ? S[k] : INFINITY;
+// Partial record [beta, eta, N[HN]] of the 64 samples of one wave (all 64 lanes must be active):
+// beta = min S, w = exp(-(S-beta)/lambda), eta = sum w, N[j] = sum_k w_k du[j][k].  The du rows are
+// read back 4 at a time so the shuffle reductions of one row overlap the loads of the next.
+__device__ __forceinline__ void wave_record(CCfg &cfg, float s, bool live, const float *__restrict__ du, int k, float *__restrict__ rec) {
+    const int K = cfg.K, HN = cfg.H * cfg.nu;
     const bool fin = live && isfinite(s);  // NaN / Inf trajectory cost -> weight 0
-    float beta = wave_min(fin ? s : INFINITY);
-    float w = fin ? __expf(-(s - beta) * cfg->inv_lambda) : 0.f;
-    float eta = wave_sum(w);
-    float *rec = partials + (size_t)blockIdx.x * (2 + HN);
-    if (threadIdx.x == 0) {
+    const float beta = wave_min(fin ? s : INFINITY);
+    const float w = fin ? __expf(-(s - beta) * cfg.inv_lambda) : 0.f;
+    const float eta = wave_sum(w);
+    const int lane = threadIdx.x & (kWave - 1);
+    if (lane == 0) {
         rec[0] = beta;
         rec[1] = eta;
     }
-    for (int j = 0; j < HN; j++) {
-        float x = live ? w * du[(size_t)j * K + k] : 0.f;
-        x = wave_sum(x);
-        if (threadIdx.x == 0) rec[2 + j] = x;
+    const size_t kk = live ? (size_t)k : 0;
+    int j = 0;
+    for (; j + 4 <= HN; j += 4) {
+        float x0 = w * du[(size_t)(j + 0) * K + kk], x1 = w * du[(size_t)(j + 1) * K + kk];
+        float x2 = w * du[(size_t)(j + 2) * K + kk], x3 = w * du[(size_t)(j + 3) * K + kk];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            x0 += __shfl_xor(x0, o, kWave);
+            x1 += __shfl_xor(x1, o, kWave);
+            x2 += __shfl_xor(x2, o, kWave);
+            x3 += __shfl_xor(x3, o, kWave);
+        }
+        if (lane == 0) {
+            rec[2 + j] = x0; rec[3 + j] = x1; rec[4 + j] = x2; rec[5 + j] = x3;
+        }
     }
+    for (; j < HN; j++) {
+        float x = wave_sum(w * du[(size_t)j * K + kk]);
+        if (lane == 0) rec[2 + j] = x;
+    }
+}
+
+__global__ __launch_bounds__(kWave) void k_reduce(const DevCfg *__restrict__ cfg, const float *__restrict__ S,
+                                                  const float *__restrict__ du, float *__restrict__ partials) {
+    const int k = blockIdx.x * kWave + threadIdx.x;
+    const bool live = k < cfg->K;
+    wave_record(*(CCfg *)cfg, live ? S[k] : INFINITY, live, du, k, partials + (size_t)blockIdx.x * (2 + cfg->H * cfg->nu));
+}
+
+template <class T>
+__global__ __launch_bounds__(kWave) void k_rollout(const DevModel *__restrict__ m, const DevCfg *__restrict__ cfg,
+                                                   const DevCost *__restrict__ cost, const float *__restrict__ x0_dof,
+                                                   const float *__restrict__ x0_root, const float *__restrict__ U,
+                                                   const float *__restrict__ eps, const float *__restrict__ prior,
+                                                   float *__restrict__ du, float *__restrict__ S, float *__restrict__ viz,
+                                                   float *__restrict__ partials) {
+    const int k = blockIdx.x * kWave + threadIdx.x;
+    const bool live = k < cfg->K;
+    float s = INFINITY;
+    if (live) {
+        s = rollout_sample<T>(*(CModel *)m, *(CCfg *)cfg, *(CCost *)cost, x0_dof, x0_root, U, eps, prior, du, viz, k);
+        S[k] = s;
+    }
+    // fused tail: this wave's partial record (its own du writes are visible to its own lanes)
+    wave_record(*(CCfg *)cfg, s, live, du, k, partials + (size_t)blockIdx.x * (2 + cfg->H * cfg->nu));
 }
 
 // Combine n records; mode 0: write the combined record to `out`; mode 1: U += N/eta, action, shift.
@@ -92,6 +127,8 @@ __global__ __launch_bounds__(256) void k_combine(const DevCfg *__restrict__ cfg,
                                                  float *__restrict__ beta_eta) {
     __shared__ float s_red[256];
     __shared__ float s_U[MPPI_MAX_H * MPPI_MAX_NU];
+    constexpr int kMaxScale = 2048;
+    __shared__ float s_scale[kMaxScale];
     const int HN = cfg->H * cfg->nu, RF = 2 + HN, nu = cfg->nu;
     const int tid = threadIdx.x;
     float b = INFINITY;
@@ -105,10 +142,13 @@ __global__ __launch_bounds__(256) void k_combine(const DevCfg *__restrict__ cfg,
     }
     const float beta = s_red[0];
     __syncthreads();
+    // scale factor of every record: e^{-(beta_r - beta)/lambda} (0 for empty records), staged in LDS
     float e = 0.f;
     for (int r = tid; r < nrec; r += 256) {
         float er = recs[(size_t)r * RF + 1];
-        if (er > 0.f) e += er * __expf(-(recs[(size_t)r * RF] - beta) * cfg->inv_lambda);
+        float sc = er > 0.f ? __expf(-(recs[(size_t)r * RF] - beta) * cfg->inv_lambda) : 0.f;
+        if (r < kMaxScale) s_scale[r] = sc;
+        e += er * sc;
     }
     s_red[tid] = e;
     __syncthreads();
@@ -118,11 +158,19 @@ __global__ __launch_bounds__(256) void k_combine(const DevCfg *__restrict__ cfg,
     }
     const float eta = s_red[0];
     for (int j = tid; j < HN; j += 256) {
-        float N = 0.f;
-        for (int r = 0; r < nrec; r++) {
-            float er = recs[(size_t)r * RF + 1];
-            if (er > 0.f) N += recs[(size_t)r * RF + 2 + j] * __expf(-(recs[(size_t)r * RF] - beta) * cfg->inv_lambda);
+        float N0 = 0.f, N1 = 0.f;
+        int r = 0;
+        const int nfast = nrec < kMaxScale ? nrec : kMaxScale;
+        for (; r + 2 <= nfast; r += 2) {
+            N0 += recs[(size_t)r * RF + 2 + j] * s_scale[r];
+            N1 += recs[(size_t)(r + 1) * RF + 2 + j] * s_scale[r + 1];
         }
+        for (; r < nrec; r++) {
+            float er = recs[(size_t)r * RF + 1];
+            float sc = r < kMaxScale ? s_scale[r] : (er > 0.f ? __expf(-(recs[(size_t)r * RF] - beta) * cfg->inv_lambda) : 0.f);
+            N0 += recs[(size_t)r * RF + 2 + j] * sc;
+        }
+        const float N = N0 + N1;
         if (mode == 0) out[2 + j] = N;
         else s_U[j] = U[j] + (eta > 0.f ? N / eta : 0.f);
     }
@@ -312,6 +360,7 @@ struct mppi_ctx {
     double *d_basis = nullptr, *d_sigma = nullptr;
     const float *eps_in = nullptr;  // d_eps or an external noise buffer
     bool has_prior = false, has_cost = false, profiling = false;
+    bool partials_valid = false;  // d_partials holds the records of the current S (written by the fused rollout tail)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[3];
     size_t ev_used[3] = {0, 0, 0};
     void (*launch_rollout)(mppi_ctx *) = nullptr;
@@ -325,7 +374,7 @@ namespace {
 template <class T>
 void launch_rollout_t(mppi_ctx *c) {
     hipLaunchKernelGGL(k_rollout<T>, dim3(c->n_waves), dim3(kWave), 0, c->stream, c->d_model, c->d_cfg, c->d_cost, c->d_x0_dof, c->d_x0_root,
-                       c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_S, c->cfg.want_rollouts ? c->d_viz : nullptr);
+                       c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_S, c->cfg.want_rollouts ? c->d_viz : nullptr, c->d_partials);
 }
 template <class T>
 void launch_sim_step_t(mppi_ctx *c, int mode, int t, const float *u_ext) {
@@ -347,16 +396,16 @@ struct EvScope {  // optional hipEvent bracket around one launch (profiling mode
         auto &v = c->ev[which];
         if (c->ev_used[which] == v.size()) {
             hipEvent_t a, b;
-            hipEventCreate(&a);
-            hipEventCreate(&b);
+            (void)hipEventCreate(&a);
+            (void)hipEventCreate(&b);
             v.emplace_back(a, b);
         }
         auto &p = v[c->ev_used[which]++];
-        hipEventRecord(p.first, c->stream);
+        (void)hipEventRecord(p.first, c->stream);
         stop = p.second;
     }
     ~EvScope() {
-        if (stop) hipEventRecord(stop, c->stream);
+        if (stop) (void)hipEventRecord(stop, c->stream);
     }
 };
 
@@ -476,16 +525,16 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
 
 int mppi_destroy(mppi_ctx_t *c) {
     if (!c) return MPPI_OK;
-    hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
     void *bufs[] = {c->d_model, c->d_cfg, c->d_cost, c->d_x0_dof, c->d_x0_root, c->d_U, c->d_eps, c->d_du, c->d_S, c->d_prior, c->d_viz,
                     c->d_partials, c->d_record, c->d_action, c->d_beta_eta, c->d_q, c->d_qd, c->d_ctrl, c->d_basis, c->d_sigma};
     for (void *b : bufs)
-        if (b) hipFree(b);
+        if (b) (void)hipFree(b);
     for (auto &v : c->ev)
         for (auto &p : v) {
-            hipEventDestroy(p.first);
-            hipEventDestroy(p.second);
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
         }
     delete c;
     return MPPI_OK;
@@ -578,13 +627,15 @@ int mppi_rollout(mppi_ctx_t *c) {
         EvScope ev(c, 0);
         c->launch_rollout(c);
     }
+    c->partials_valid = true;
     return launch_check();
 }
 int mppi_reduce(mppi_ctx_t *c, float *record_out_dev) {
     CTX_TRY(c);
-    {
+    if (!c->partials_valid) {  // generic mode: S came from host-side costs, build the per-wave records now
         EvScope ev(c, 1);
         hipLaunchKernelGGL(k_reduce, dim3(c->n_waves), dim3(kWave), 0, c->stream, c->d_cfg, c->d_S, c->d_du, c->d_partials);
+        c->partials_valid = true;
     }
     if (record_out_dev)  // one shard record for the cross-GPU all-gather
         hipLaunchKernelGGL(k_combine, dim3(1), dim3(256), 0, c->stream, c->d_cfg, c->d_partials, c->n_waves, 0, record_out_dev, c->d_U, c->d_action,
@@ -639,13 +690,22 @@ int mppi_get_costs(mppi_ctx_t *c, float *S) { return d2h(c, S, c ? c->d_S : null
 int mppi_get_weights_stats(mppi_ctx_t *c, float *be) { return d2h(c, be, c ? c->d_beta_eta : nullptr, 2); }
 int mppi_get_rollouts(mppi_ctx_t *c, float *viz) {
     if (c && !c->cfg.want_rollouts) return fail(MPPI_ESTATE, "config.want_rollouts is off");
-    return d2h(c, viz, c ? c->d_viz : nullptr, c ? (size_t)c->H * c->K * 3 : 0);
+    if (!c) return check_ctx(c);
+    // device layout is sample-minor [H][3][K] (full-line coalesced stores); hand out [H][K][3]
+    std::vector<float> tmp((size_t)c->H * 3 * c->K);
+    int rc = d2h(c, tmp.data(), c->d_viz, tmp.size());
+    if (rc) return rc;
+    for (int t = 0; t < c->H; t++)
+        for (int j = 0; j < 3; j++)
+            for (int k = 0; k < c->K; k++) viz[((size_t)t * c->K + k) * 3 + j] = tmp[((size_t)t * 3 + j) * c->K + k];
+    return MPPI_OK;
 }
 int mppi_get_perturbations(mppi_ctx_t *c, float *du) { return d2h(c, du, c ? c->d_du : nullptr, c ? (size_t)c->HN * c->K : 0); }
 int mppi_get_noise(mppi_ctx_t *c, float *eps) { return d2h(c, eps, c ? c->eps_in : nullptr, c ? (size_t)c->HN * c->K : 0); }
 
 int mppi_sim_reset(mppi_ctx_t *c) {
     CTX_TRY(c);
+    c->partials_valid = false;
     hipLaunchKernelGGL(k_sim_reset, dim3((c->K + 255) / 256), dim3(256), 0, c->stream, c->K, c->n, c->d_x0_dof, c->d_q, c->d_qd, c->d_S, c->d_ctrl);
     return launch_check();
 }
@@ -669,6 +729,7 @@ int mppi_sim_materialise(mppi_ctx_t *c, float *dof, float *root, float *rb, floa
 int mppi_sim_accumulate_cost(mppi_ctx_t *c, int t, const float *cost_dev) {
     CTX_TRY(c);
     if (!cost_dev) return fail(MPPI_EINVAL, "null cost");
+    c->partials_valid = false;
     float disc = std::pow((float)c->cfg.rollout_var_discount, (float)t);
     hipLaunchKernelGGL(k_accumulate_cost, dim3((c->K + 255) / 256), dim3(256), 0, c->stream, c->K, disc, cost_dev, c->d_S);
     return launch_check();

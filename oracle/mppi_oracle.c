@@ -286,11 +286,10 @@ void orc_step(const mppi_model_t *m, const real *root, real *q, real *qd, const 
         kin_t k;
         kinematics(m, root, q, qd, &k);
         real ff[NBMAX], vs[NBMAX], tau[NBMAX], kdh[NBMAX], qdd[NBMAX];
-        int sat[NBMAX];
         for (int i = 0; i < n; i++) {
             ff[i] = m->drive_mode == MPPI_DRIVE_EFFORT ? target[i] : 0;
             vs[i] = m->drive_mode == MPPI_DRIVE_VELOCITY ? target[i] : 0;
-            sat[i] = 0;
+
             tau[i] = ff[i] + kd * (vs[i] - qd[i]);
             kdh[i] = kd * h;
         }
@@ -301,7 +300,7 @@ void orc_step(const mppi_model_t *m, const real *root, real *q, real *qd, const 
         for (int i = 0; i < n; i++) {
             real lim = (real)m->bodies[i].effort;
             real tt = ff[i] + kd * (vs[i] - qd[i] - h * qdd[i]);
-            if (lim > 0 && (real)fabs((double)tt) > lim) { sat[i] = 1; any = 1; tau[i] = tt > 0 ? lim : -lim; kdh[i] = 0; }
+            if (lim > 0 && (real)fabs((double)tt) > lim) { any = 1; tau[i] = tt > 0 ? lim : -lim; kdh[i] = 0; }
         }
         if (any) aba_solve(m, &k, tau, kdh, qdd);
         for (int i = 0; i < n; i++) {

@@ -20,7 +20,12 @@ int emu_rollout(const mppi_model_t *model, const mppi_config_t *cfg, const mppi_
     for (int i = 0; i < m.nb; i++) parents[i] = m.b[i].parent;
     bool ok = dispatch_topology(m.nb, parents, [&](auto topo) {
         using T = decltype(topo);
-        for (int s = 0; s < c.K; s++) S[s] = rollout_sample<T>(m, c, k, dof0, root0, U, eps, prior, du, viz, s);
+        std::vector<float> v(viz ? (size_t)c.H * 3 * c.K : 0);
+        for (int s = 0; s < c.K; s++) S[s] = rollout_sample<T>(m, c, k, dof0, root0, U, eps, prior, du, viz ? v.data() : nullptr, s);
+        if (viz)  // device layout [H][3][K] -> reference layout [H][K][3]
+            for (int t = 0; t < c.H; t++)
+                for (int j = 0; j < 3; j++)
+                    for (int s = 0; s < c.K; s++) viz[((size_t)t * c.K + s) * 3 + j] = v[((size_t)t * 3 + j) * c.K + s];
     });
     return ok ? 0 : -3;
 }
