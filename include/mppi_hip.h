@@ -37,6 +37,9 @@ extern "C" {
 #define MPPI_MAX_H 64        /* horizon                                              */
 #define MPPI_MAX_KNOTS 16    /* spline knots of the halton-spline sampler            */
 #define MPPI_MAX_COST_W 16
+#define MPPI_MAX_SHAPES 24   /* collision primitives per env                              */
+#define MPPI_MAX_PAIRS 48    /* candidate contact pairs per env                           */
+#define MPPI_MAX_FREE 2      /* free (non-fixed) box/sphere actors per env                */
 
 enum { MPPI_OK = 0, MPPI_EINVAL = -1, MPPI_EHIP = -2, MPPI_EUNSUPPORTED = -3, MPPI_ESTATE = -4 };
 enum { MPPI_JOINT_REVOLUTE = 0, MPPI_JOINT_PRISMATIC = 1 };
@@ -53,6 +56,25 @@ enum {
     MPPI_COST_PANDA_PICK = 4   /* examples/panda_pick/planner.py:24-53                      */
 };
 enum { MPPI_SAMPLE_HALTON_SPLINE = 0, MPPI_SAMPLE_EXTERNAL = 1 };
+/* collision primitives: URDF <collision> boxes / meshes (as their AABB) / spheres / thin cylinders
+ * (wheels, casters: "disc", axis = local z of the shape frame); box and sphere actors
+ * (isaacgym_utils.py:26-52).  Contact model: DESIGN.md section 3 (build-normative). */
+enum { MPPI_SHAPE_BOX = 0, MPPI_SHAPE_SPHERE = 1, MPPI_SHAPE_DISC = 2 };
+
+typedef struct mppi_shape {
+    int32_t actor;     /* owning actor                                                   */
+    int32_t body;      /* robot shapes: moving body it is welded to, -1 = robot base; others: -1 */
+    int32_t type;      /* MPPI_SHAPE_*                                                   */
+    int32_t rb;        /* rigid-body row that receives its net contact force             */
+    double size[3];    /* box: half extents; sphere/disc: radius in size[0]              */
+    double R[9];       /* shape frame in the body (or actor) frame                       */
+    double p[3];
+    double friction;   /* per-shape friction (isaacgym_wrapper.py:467-480; casters 0)    */
+} mppi_shape_t;
+
+typedef struct mppi_pair {
+    int32_t a, b;      /* shape indices; b = -1: ground plane z = 0                      */
+} mppi_pair_t;
 
 /* One moving body = one 1-DOF joint + the links welded to its child link.
  * Transform convention: x_parent = R * x_child + p (R row-major 3x3). */
@@ -118,6 +140,15 @@ typedef struct mppi_model {
     int32_t nu;
     int32_t cmd_col[MPPI_MAX_BODIES][2];
     double cmd_coef[MPPI_MAX_BODIES][2];
+    /* contact scene (all zero for contact-free scenes) */
+    int32_t n_shapes;
+    int32_t n_pairs;
+    mppi_shape_t shapes[MPPI_MAX_SHAPES];
+    mppi_pair_t pairs[MPPI_MAX_PAIRS];
+    double ground_friction;   /* add_ground_plane: 1.0 (isaacgym_utils.py:61-68)              */
+    double contact_alpha;     /* penalty stiffness  k = alpha * m_eff / h^2 per contact patch */
+    double contact_beta;      /* normal damping     c = beta  * m_eff / h                     */
+    double friction_beta;     /* stick damping      c_t = friction_beta * m_eff / h           */
 } mppi_model_t;
 
 /* mppi_torch.MPPIConfig fields (reference conf/mppi/ + benchmarks/point_robot/setup/mppi.yaml:5-37) */

@@ -37,6 +37,9 @@ constexpr int kMaxBodies = 12;
 constexpr int kMaxLinks = 24;
 constexpr int kMaxActors = 8;
 constexpr int kMaxNu = 12;
+constexpr int kMaxShapes = 24;
+constexpr int kMaxPairs = 48;
+constexpr int kMaxFree = 2;
 
 // ---- device-side model (fp32, z-framed) ------------------------------------------------
 struct DevBody {
@@ -54,12 +57,39 @@ struct DevLink {
     float R[9];
     float p[3];
 };
+// Contact scene.  A "frame" is anything a shape can be welded to: moving body i (0..nb-1), the robot
+// base (nb) and free actor f (nb+1+f) are DYNAMIC frames whose pose/velocity live in per-sample
+// memory; everything else is static and posed by the root state of `src_actor`.
+struct DevShape {
+    int ent;        // dynamic frame index, -1 = static
+    int src_actor;  // static shapes: actor whose root pose carries the shape
+    int type, rb;   // MPPI_SHAPE_*, rigid-body row for net_contact_force
+    float half[3];  // box half extents | radius in half[0]
+    float mu;
+    float R[9], p[3];
+};
+struct DevPair {
+    int a, b;       // shapes; b = -1: ground plane
+    int mode;       // 0: both dynamic (explicit penalty), 1: a dynamic / b static (implicit), 2: b dynamic / a static
+    int pad;
+    float mu, k, cn, ct;  // combined friction, stiffness and damping per contact point
+    float kh, pad2[3];    // k * h (implicit spring term of static contacts)
+};
+struct DevFree {
+    int actor, rb, gravity, pad;
+    float m, Ic[3];  // box / sphere principal inertia about the centre
+};
 struct DevModel {
-    int nb, nl, n_actors, robot_actor, n_rb, robot_first_rb, drive_mode, substeps, gravity_on, nu, pad[2];
-    float kd, h, g[3], pad2[3];
+    int nb, nl, n_actors, robot_actor, n_rb, robot_first_rb, drive_mode, substeps, gravity_on, nu, floating, n_free;
+    float kd, h, g[3], base_m, pad2[2];
+    float base_hb[3], base_Ic[6], pad3[3];
     int actor_first_rb[kMaxActors];
+    int n_shapes, n_pairs, pad4[2];
     DevBody b[kMaxBodies];
     DevLink l[kMaxLinks];
+    DevFree fr[kMaxFree];
+    DevShape sh[kMaxShapes];
+    DevPair pr[kMaxPairs];
 };
 struct DevCfg {
     int K, H, nu, k_offset, k_total, sample_null_action, use_priors, noise_abs_cost, want_rollouts, viz_link, pad[2];
@@ -84,6 +114,9 @@ struct DevCost {
 typedef const MPPI_CONST_AS DevModel CModel;
 typedef const MPPI_CONST_AS DevBody CBody;
 typedef const MPPI_CONST_AS DevLink CLink;
+typedef const MPPI_CONST_AS DevShape CShape;
+typedef const MPPI_CONST_AS DevPair CPair;
+typedef const MPPI_CONST_AS DevFree CFree;
 typedef const MPPI_CONST_AS DevCfg CCfg;
 typedef const MPPI_CONST_AS DevCost CCost;
 typedef const MPPI_CONST_AS float cfloat;
@@ -261,10 +294,19 @@ MPPI_HD void fast_sincos(float x, float &s, float &c) {
 }
 
 template <class T>
+MPPI_HD void forward_kinematics_base(CModel &m, const float *q, Pose<T> &P);
+
+template <class T>
 MPPI_HD void forward_kinematics(CModel &m, const float *root, const float *q, Pose<T> &P) {
     const float *rs = root + 13 * m.robot_actor;
     P.pb = loadv(rs);
     P.Rb = quat_to_R(rs + 3);
+    forward_kinematics_base<T>(m, q, P);
+}
+
+// body poses from the base pose already stored in P.Rb / P.pb
+template <class T>
+MPPI_HD void forward_kinematics_base(CModel &m, const float *q, Pose<T> &P) {
     static_for<0, T::NB>([&](auto ic) MPPI_LAMBDA {
         constexpr int i = ic;
         constexpr int par = T::par[i];

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "mppi_pack.hpp"
+#include "mppi_scene.hpp"
 
 using namespace mppi;
 
@@ -190,6 +191,135 @@ __global__ __launch_bounds__(256) void k_combine(const DevCfg *__restrict__ cfg,
     for (int j = tid; j < HN; j += 256) U[j] = (j + nu < HN) ? s_U[j + nu] : cfg->u_init;  // shift, append u_init
 }
 
+// ---- contact scenes (floating base, free bodies, penalty contact): per-lane working set in LDS ----
+template <class T>
+__global__ __launch_bounds__(kWave) void k_rollout_scene(const DevModel *__restrict__ m, const DevCfg *__restrict__ cfg,
+                                                         const DevCost *__restrict__ cost, const float *__restrict__ x0_dof,
+                                                         const float *__restrict__ x0_root, const float *__restrict__ U,
+                                                         const float *__restrict__ eps, const float *__restrict__ prior,
+                                                         float *__restrict__ du, float *__restrict__ S, float *__restrict__ viz,
+                                                         float *__restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int k = blockIdx.x * kWave + threadIdx.x;
+    const bool live = k < cfg->K;
+    const LMem L{lds + threadIdx.x, kWave};  // lane-minor rows: conflict-free ds_read/ds_write
+    float s = INFINITY;
+    if (live) {
+        s = rollout_scene<T>(*(CModel *)m, *(CCfg *)cfg, *(CCost *)cost, x0_dof, x0_root, U, eps, prior, du, viz, k, L);
+        S[k] = s;
+    }
+    wave_record(*(CCfg *)cfg, s, live, du, k, partials + (size_t)blockIdx.x * (2 + cfg->H * cfg->nu));
+}
+
+// env state of contact scenes in HBM (sample-minor): base [13][K], free [kMaxFree*13][K], cf [n_rb*3][K]
+template <class T>
+__global__ __launch_bounds__(kWave) void k_sim_step_scene(const DevModel *__restrict__ m, const DevCfg *__restrict__ cfg, int mode, int t,
+                                                          const float *__restrict__ u_ext, const float *__restrict__ x0_root,
+                                                          const float *__restrict__ U, const float *__restrict__ eps, const float *__restrict__ prior,
+                                                          float *__restrict__ du, float *__restrict__ ctrl, float *__restrict__ q_, float *__restrict__ qd_,
+                                                          float *__restrict__ base_, float *__restrict__ fr_, float *__restrict__ cf_) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NB = T::NB;
+    const int K = cfg->K, nu = cfg->nu;
+    const int k = blockIdx.x * kWave + threadIdx.x;
+    if (k >= K) return;
+    const LMem L{lds + threadIdx.x, kWave};
+    CModel &M = *(CModel *)m;
+    SceneState<T> s;
+    static_for<0, NB>([&](auto ic) {
+        constexpr int i = ic;
+        s.q[i] = q_[(size_t)i * K + k];
+        s.qd[i] = qd_[(size_t)i * K + k];
+    });
+    for (int j = 0; j < 13; j++) s.base[j] = base_[(size_t)j * K + k];
+    for (int f = 0; f < kMaxFree; f++)
+        for (int j = 0; j < 13; j++) s.fr[f][j] = fr_[(size_t)(f * 13 + j) * K + k];
+    float target[NB ? NB : 1], u[kMaxNu];
+    const int g = cfg->k_offset + k;
+    float cc = 0.f;
+#pragma unroll
+    for (int c = 0; c < kMaxNu; c++) {
+        float v = 0.f;
+        if (c < nu) {
+            if (mode == 0) v = u_ext[(size_t)k * nu + c];
+            else if (mode == 1) v = u_ext[c];
+            else {
+                float Ut = U[t * nu + c];
+                v = Ut + eps[(size_t)(t * nu + c) * K + k];
+                if (cfg->sample_null_action && g == cfg->k_total - 1) v = 0.f;
+                if (cfg->use_priors && prior != nullptr && g == cfg->k_total - 2) v = prior[t * nu + c];
+                v = fminf(fmaxf(v, cfg->u_min[c]), cfg->u_max[c]);
+                float d = v - Ut;
+                du[(size_t)(t * nu + c) * K + k] = d;
+                float term = Ut * d * cfg->inv_sigma[c];
+                cc += cfg->lambda * (cfg->noise_abs_cost ? fabsf(term) : term);
+            }
+        }
+        u[c] = v;
+    }
+    if (mode == 2) ctrl[k] += cc;
+    cmd_map<T>(M, u, target);
+    step_scene<T>(M, x0_root, s, target, L);
+    static_for<0, NB>([&](auto ic) {
+        constexpr int i = ic;
+        q_[(size_t)i * K + k] = s.q[i];
+        qd_[(size_t)i * K + k] = s.qd[i];
+    });
+    for (int j = 0; j < 13; j++) base_[(size_t)j * K + k] = s.base[j];
+    for (int f = 0; f < kMaxFree; f++)
+        for (int j = 0; j < 13; j++) fr_[(size_t)(f * 13 + j) * K + k] = s.fr[f][j];
+    for (int j = 0; j < 3 * M.n_rb; j++) cf_[(size_t)j * K + k] = L[SceneLayout<T>::kCf + j];
+}
+
+template <class T>
+__global__ __launch_bounds__(kWave) void k_materialise_scene(const DevModel *__restrict__ m, int K, const float *__restrict__ x0_root,
+                                                             const float *__restrict__ q_, const float *__restrict__ qd_, const float *__restrict__ base_,
+                                                             const float *__restrict__ fr_, const float *__restrict__ cf_, float *__restrict__ dof,
+                                                             float *__restrict__ root, float *__restrict__ rb, float *__restrict__ cf) {
+    constexpr int NB = T::NB;
+    const int k = blockIdx.x * kWave + threadIdx.x;
+    if (k >= K) return;
+    CModel &M = *(CModel *)m;
+    SceneState<T> s;
+    static_for<0, NB>([&](auto ic) {
+        constexpr int i = ic;
+        s.q[i] = q_[(size_t)i * K + k];
+        s.qd[i] = qd_[(size_t)i * K + k];
+        if (dof != nullptr) {
+            dof[(size_t)k * 2 * NB + 2 * i] = s.q[i];
+            dof[(size_t)k * 2 * NB + 2 * i + 1] = s.qd[i];
+        }
+    });
+    for (int j = 0; j < 13; j++) s.base[j] = base_[(size_t)j * K + k];
+    for (int f = 0; f < kMaxFree; f++)
+        for (int j = 0; j < 13; j++) s.fr[f][j] = fr_[(size_t)(f * 13 + j) * K + k];
+    const int A = M.n_actors, B = M.n_rb;
+    scene_materialise<T>(M, x0_root, s, nullptr, root != nullptr ? root + (size_t)k * 13 * A : nullptr,
+                         rb != nullptr ? rb + (size_t)k * 13 * B : nullptr, nullptr);
+    if (cf != nullptr)
+        for (int j = 0; j < 3 * B; j++) cf[(size_t)k * 3 * B + j] = cf_[(size_t)j * K + k];
+}
+
+// all envs <- x0 (root rows of the robot base and the free actors)
+__global__ void k_sim_reset_scene(const DevModel *__restrict__ m, int K, const float *__restrict__ x0_root, float *__restrict__ base_,
+                                  float *__restrict__ fr_, float *__restrict__ cf_) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    for (int j = 0; j < 13; j++) base_[(size_t)j * K + k] = x0_root[13 * m->robot_actor + j];
+    for (int f = 0; f < kMaxFree; f++)
+        for (int j = 0; j < 13; j++) fr_[(size_t)(f * 13 + j) * K + k] = f < m->n_free ? x0_root[13 * m->fr[f].actor + j] : 0.f;
+    for (int j = 0; j < 3 * m->n_rb; j++) cf_[(size_t)j * K + k] = 0.f;
+}
+// planner.x0_root rows of the robot base / free actors <- world env 0
+__global__ void k_root_from_world(const DevModel *__restrict__ m, const float *__restrict__ wbase, const float *__restrict__ wfr, float *__restrict__ x0_root) {
+    const int j = threadIdx.x;
+    if (j < 13) {
+        x0_root[13 * m->robot_actor + j] = wbase[j];
+        for (int f = 0; f < kMaxFree; f++)
+            if (f < m->n_free) x0_root[13 * m->fr[f].actor + j] = wfr[f * 13 + j];
+    }
+}
+
 // ---- halton-spline sampler -------------------------------------------------------------------
 __constant__ int c_primes[MPPI_MAX_KNOTS * MPPI_MAX_NU] = {
     2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37, 41, 43, 47, 53, 59, 61, 67, 71, 73, 79, 83, 89, 97, 101, 103, 107, 109, 113,
@@ -357,6 +487,9 @@ struct mppi_ctx {
     float *d_x0_dof = nullptr, *d_x0_root = nullptr, *d_U = nullptr, *d_eps = nullptr, *d_du = nullptr, *d_S = nullptr;
     float *d_prior = nullptr, *d_viz = nullptr, *d_partials = nullptr, *d_record = nullptr, *d_action = nullptr, *d_beta_eta = nullptr;
     float *d_q = nullptr, *d_qd = nullptr, *d_ctrl = nullptr;
+    float *d_base = nullptr, *d_fr = nullptr, *d_cf = nullptr;  // contact scenes: env root rows and contact forces
+    bool scene = false;
+    size_t lds_bytes = 0;
     double *d_basis = nullptr, *d_sigma = nullptr;
     const float *eps_in = nullptr;  // d_eps or an external noise buffer
     bool has_prior = false, has_cost = false, profiling = false;
@@ -370,6 +503,29 @@ struct mppi_ctx {
 };
 
 namespace {
+
+template <class T>
+void launch_rollout_scene_t(mppi_ctx *c) {
+    hipLaunchKernelGGL(k_rollout_scene<T>, dim3(c->n_waves), dim3(kWave), c->lds_bytes, c->stream, c->d_model, c->d_cfg, c->d_cost, c->d_x0_dof,
+                       c->d_x0_root, c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_S, c->cfg.want_rollouts ? c->d_viz : nullptr,
+                       c->d_partials);
+}
+template <class T>
+void launch_sim_step_scene_t(mppi_ctx *c, int mode, int t, const float *u_ext) {
+    hipLaunchKernelGGL(k_sim_step_scene<T>, dim3(c->n_waves), dim3(kWave), c->lds_bytes, c->stream, c->d_model, c->d_cfg, mode, t, u_ext, c->d_x0_root,
+                       c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_ctrl, c->d_q, c->d_qd, c->d_base, c->d_fr, c->d_cf);
+}
+template <class T>
+void launch_materialise_scene_t(mppi_ctx *c, float *dof, float *root, float *rb, float *cf) {
+    hipLaunchKernelGGL(k_materialise_scene<T>, dim3(c->n_waves), dim3(kWave), 0, c->stream, c->d_model, c->K, c->d_x0_root, c->d_q, c->d_qd, c->d_base,
+                       c->d_fr, c->d_cf, dof, root, rb, cf);
+}
+template <class T>
+hipError_t raise_lds_limit(size_t bytes) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rollout_scene<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sim_step_scene<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
 
 template <class T>
 void launch_rollout_t(mppi_ctx *c) {
@@ -468,12 +624,31 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
     int parents[MPPI_MAX_BODIES];
     for (int i = 0; i < c->hm.nb; i++) parents[i] = c->hm.b[i].parent;
     c->topo = topology_string(c->hm.nb, parents);
+    c->scene = is_scene(c->hm);
+    hipError_t lds_err = hipSuccess;
     bool ok = dispatch_topology(c->hm.nb, parents, [&](auto topo) {
         using T = decltype(topo);
-        c->launch_rollout = &launch_rollout_t<T>;
-        c->launch_sim_step = &launch_sim_step_t<T>;
-        c->launch_materialise = &launch_materialise_t<T>;
+        if (c->scene) {
+            c->lds_bytes = sizeof(float) * kWave * (size_t)SceneLayout<T>::floats(c->hm.n_rb);
+            c->launch_rollout = &launch_rollout_scene_t<T>;
+            c->launch_sim_step = &launch_sim_step_scene_t<T>;
+            c->launch_materialise = &launch_materialise_scene_t<T>;
+            if (hipSetDevice(device) == hipSuccess) lds_err = raise_lds_limit<T>(c->lds_bytes);
+        } else {
+            c->launch_rollout = &launch_rollout_t<T>;
+            c->launch_sim_step = &launch_sim_step_t<T>;
+            c->launch_materialise = &launch_materialise_t<T>;
+        }
     });
+    if (ok && c->lds_bytes > 160 * 1024) {
+        delete c;
+        return fail(MPPI_EUNSUPPORTED, "contact scene needs more than 160 KiB of LDS per wavefront");
+    }
+    if (ok && lds_err != hipSuccess) {
+        std::string msg = std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(lds_err);
+        delete c;
+        return fail(MPPI_EHIP, msg);
+    }
     if (!ok) {
         std::string t = c->topo;
         delete c;
@@ -507,6 +682,9 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
     ALLOC_TRY(c->d_q, sizeof(float) * c->n * K);
     ALLOC_TRY(c->d_qd, sizeof(float) * c->n * K);
     ALLOC_TRY(c->d_ctrl, sizeof(float) * K);
+    ALLOC_TRY(c->d_base, sizeof(float) * 13 * K);
+    ALLOC_TRY(c->d_fr, sizeof(float) * kMaxFree * 13 * K);
+    ALLOC_TRY(c->d_cf, sizeof(float) * 3 * c->B * K);
     ALLOC_TRY(c->d_basis, sizeof(double) * MPPI_MAX_H * MPPI_MAX_KNOTS);
     ALLOC_TRY(c->d_sigma, sizeof(double) * MPPI_MAX_NU);
     c->eps_in = c->d_eps;
@@ -528,7 +706,7 @@ int mppi_destroy(mppi_ctx_t *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     void *bufs[] = {c->d_model, c->d_cfg, c->d_cost, c->d_x0_dof, c->d_x0_root, c->d_U, c->d_eps, c->d_du, c->d_S, c->d_prior, c->d_viz,
-                    c->d_partials, c->d_record, c->d_action, c->d_beta_eta, c->d_q, c->d_qd, c->d_ctrl, c->d_basis, c->d_sigma};
+                    c->d_partials, c->d_record, c->d_action, c->d_beta_eta, c->d_q, c->d_qd, c->d_ctrl, c->d_basis, c->d_sigma, c->d_base, c->d_fr, c->d_cf};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (auto &v : c->ev)
@@ -707,6 +885,8 @@ int mppi_sim_reset(mppi_ctx_t *c) {
     CTX_TRY(c);
     c->partials_valid = false;
     hipLaunchKernelGGL(k_sim_reset, dim3((c->K + 255) / 256), dim3(256), 0, c->stream, c->K, c->n, c->d_x0_dof, c->d_q, c->d_qd, c->d_S, c->d_ctrl);
+    if (c->scene)
+        hipLaunchKernelGGL(k_sim_reset_scene, dim3((c->K + 255) / 256), dim3(256), 0, c->stream, c->d_model, c->K, c->d_x0_root, c->d_base, c->d_fr, c->d_cf);
     return launch_check();
 }
 int mppi_sim_step(mppi_ctx_t *c, const float *u_dev, int u_is_shared) {
@@ -750,6 +930,8 @@ int mppi_set_state_from_world(mppi_ctx_t *planner, mppi_ctx_t *world) {
     if (!world || world->K != 1 || world->n != planner->n || world->A != planner->A) return fail(MPPI_EINVAL, "world must be a K=1 context of the same scene");
     hipLaunchKernelGGL(k_state_from_world, dim3(1), dim3(64), 0, planner->stream, planner->n, world->d_q, world->d_qd, planner->d_x0_dof);
     HIP_TRY(hipMemcpyAsync(planner->d_x0_root, world->d_x0_root, sizeof(float) * 13 * planner->A, hipMemcpyDeviceToDevice, planner->stream));
+    if (world->scene)  // the world's robot base and free actors have moved: K = 1, so sample-minor rows are plain arrays
+        hipLaunchKernelGGL(k_root_from_world, dim3(1), dim3(64), 0, planner->stream, planner->d_model, world->d_base, world->d_fr, planner->d_x0_root);
     return launch_check();
 }
 

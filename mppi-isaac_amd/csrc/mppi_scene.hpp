@@ -1,0 +1,724 @@
+// mppi_scene.hpp - contact scenes: floating-base robots, free rigid bodies, penalty contact.
+//
+// Extends the per-sample device code of mppi_device.hpp for scenes in which something can collide
+// (reference scenes such as examples/boxer_push: a differential-drive base pushing a block past two
+// obstacles on a ground plane).  PhysX's TGS contact solver (reference isaacgym_wrapper.py:30-36) is
+// replaced by the build-normative model of DESIGN.md section 3 / SURVEY.md B.5:
+//   * primitives: box, sphere, disc (thin wheel cylinder), ground plane z = 0; meshes as AABB boxes;
+//   * box-box contacts are vertex-in-box tests in both directions, box/disc/sphere-ground analytic;
+//   * contact against STATIC geometry is integrated implicitly: the penalty damper and the stick-regime
+//     friction of a contact point are a 6x6 damping matrix that is added to the articulated inertia of
+//     the body it acts on (exact for forces linear in that body's own acceleration), so wheel traction
+//     and resting contact are unconditionally stable at h = 25 ms;
+//   * contact between two DYNAMIC bodies is an explicit spring-damper with Coulomb-capped viscous friction.
+// Dynamic frames (robot bodies, floating base, free actors), their force/damping accumulators and the
+// net contact force per rigid body are staged in per-lane LDS rows (lane-minor, bank-conflict free) so
+// that shapes can address them with run-time indices; the host harness uses a plain array instead.
+#pragma once
+#include "mppi_device.hpp"
+
+namespace mppi {
+
+// per-sample indexed scratch ("working set staged in LDS"): element i of this lane lives at p[i*stride]
+struct LMem {
+    float *p;
+    int stride;
+    MPPI_HD float &operator[](int i) const { return p[(size_t)i * stride]; }
+};
+
+template <class T>
+struct SceneLayout {
+    static constexpr int NF = T::NB + 1 + kMaxFree;  // dynamic frames
+    static constexpr int kFrame = 0;                 // [NF][18]: R(9) p(3) w(3) vO(3)
+    static constexpr int kAcc = NF * 18;             // [NF][27]: f(6) C(21)
+    static constexpr int kCf = kAcc + NF * 27;       // [n_rb][3] net contact force
+    MPPI_HD static constexpr int floats(int n_rb) { return kCf + 3 * n_rb; }
+};
+constexpr int scene_floats_max(int nb) { return (nb + 1 + kMaxFree) * 45 + 3 * (kMaxLinks + kMaxActors); }
+
+template <class T>
+struct SceneState {
+    float q[T::NB ? T::NB : 1], qd[T::NB ? T::NB : 1];
+    float base[13];           // robot root row: pos, quat xyzw, linvel, angvel
+    float fr[kMaxFree][13];   // free actors' root rows
+};
+
+MPPI_HD V3 vel_at(const SV &v, V3 p) { return v.l + cross(v.a, p); }
+
+// SPD 6x6 solve A x = b (Cholesky, fully unrolled: everything stays in registers)
+MPPI_HD SV solve6(const AI &A, SV b) {
+    float a[6][6];
+    a[0][0] = A.I.xx; a[0][1] = A.I.xy; a[0][2] = A.I.xz; a[1][1] = A.I.yy; a[1][2] = A.I.yz; a[2][2] = A.I.zz;
+    a[1][0] = A.I.xy; a[2][0] = A.I.xz; a[2][1] = A.I.yz;
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) { a[r][3 + c] = A.H[3 * r + c]; a[3 + c][r] = A.H[3 * r + c]; }
+    a[3][3] = A.M.xx; a[3][4] = A.M.xy; a[3][5] = A.M.xz; a[4][4] = A.M.yy; a[4][5] = A.M.yz; a[5][5] = A.M.zz;
+    a[4][3] = A.M.xy; a[5][3] = A.M.xz; a[5][4] = A.M.yz;
+    float x[6] = {b.a.x, b.a.y, b.a.z, b.l.x, b.l.y, b.l.z};
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        float s = a[j][j];
+#pragma unroll
+        for (int k = 0; k < j; k++) s -= a[j][k] * a[j][k];
+        const float inv = 1.f / sqrtf(s);
+        a[j][j] = inv;  // store 1/L_jj
+#pragma unroll
+        for (int i = j + 1; i < 6; i++) {
+            float t = a[i][j];
+#pragma unroll
+            for (int k = 0; k < j; k++) t -= a[i][k] * a[j][k];
+            a[i][j] = t * inv;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        float t = x[i];
+#pragma unroll
+        for (int k = 0; k < i; k++) t -= a[i][k] * x[k];
+        x[i] = t * a[i][i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; i--) {
+        float t = x[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; k++) t -= a[k][i] * x[k];
+        x[i] = t * a[i][i];
+    }
+    return {{x[0], x[1], x[2]}, {x[3], x[4], x[5]}};
+}
+
+// rigid-body inertia about the world origin (world axes) of a body posed at (R, p):
+// I_O = R Ic R^T + m(|cw|^2 1 - cw cw^T), h = m cw; plus the bias force v x* (I v)
+template <class F>
+MPPI_HD void rigid_world(const M3 &R, V3 p, float m, V3 hb, F *Ic, const SV &v, AI &A, SV &pA, V3 &h) {
+    h = mul(R, hb) + m * p;
+    float T9[9];
+    for (int r = 0; r < 3; r++) {
+        float r0 = R.a[3 * r], r1 = R.a[3 * r + 1], r2 = R.a[3 * r + 2];
+        T9[3 * r + 0] = r0 * Ic[0] + r1 * Ic[1] + r2 * Ic[2];
+        T9[3 * r + 1] = r0 * Ic[1] + r1 * Ic[3] + r2 * Ic[4];
+        T9[3 * r + 2] = r0 * Ic[2] + r1 * Ic[4] + r2 * Ic[5];
+    }
+    float invm = m > 0.f ? 1.f / m : 0.f;
+    V3 cw = invm * h;
+    float hh = dot(h, cw);
+    A.I.xx = T9[0] * R.a[0] + T9[1] * R.a[1] + T9[2] * R.a[2] + hh - h.x * cw.x;
+    A.I.xy = T9[0] * R.a[3] + T9[1] * R.a[4] + T9[2] * R.a[5] - h.x * cw.y;
+    A.I.xz = T9[0] * R.a[6] + T9[1] * R.a[7] + T9[2] * R.a[8] - h.x * cw.z;
+    A.I.yy = T9[3] * R.a[3] + T9[4] * R.a[4] + T9[5] * R.a[5] + hh - h.y * cw.y;
+    A.I.yz = T9[3] * R.a[6] + T9[4] * R.a[7] + T9[5] * R.a[8] - h.y * cw.z;
+    A.I.zz = T9[6] * R.a[6] + T9[7] * R.a[7] + T9[8] * R.a[8] + hh - h.z * cw.z;
+    A.H[0] = 0.f;  A.H[1] = -h.z; A.H[2] = h.y;
+    A.H[3] = h.z;  A.H[4] = 0.f;  A.H[5] = -h.x;
+    A.H[6] = -h.y; A.H[7] = h.x;  A.H[8] = 0.f;
+    A.M = {m, 0.f, 0.f, m, 0.f, m};
+    V3 n = mul(A.I, v.a) + cross(h, v.l);
+    V3 f = m * v.l + cross(v.a, h);
+    pA = {cross(v.a, n) + cross(v.l, f), cross(v.a, f)};
+}
+
+// ---- per-lane frame / accumulator access ------------------------------------------------------
+MPPI_HD void frame_store(const LMem &L, int ent, const M3 &R, V3 p, const SV &v) {
+    const int o = ent * 18;
+    for (int j = 0; j < 9; j++) L[o + j] = R.a[j];
+    L[o + 9] = p.x; L[o + 10] = p.y; L[o + 11] = p.z;
+    L[o + 12] = v.a.x; L[o + 13] = v.a.y; L[o + 14] = v.a.z;
+    L[o + 15] = v.l.x; L[o + 16] = v.l.y; L[o + 17] = v.l.z;
+}
+MPPI_HD void frame_load(const LMem &L, int ent, M3 &R, V3 &p, SV &v) {
+    const int o = ent * 18;
+    for (int j = 0; j < 9; j++) R.a[j] = L[o + j];
+    p = {L[o + 9], L[o + 10], L[o + 11]};
+    v = {{L[o + 12], L[o + 13], L[o + 14]}, {L[o + 15], L[o + 16], L[o + 17]}};
+}
+MPPI_HD void acc_add(const LMem &L, int base, int ent, const SV &f, const AI *C) {
+    const int o = base + ent * 27;
+    L[o + 0] += f.a.x; L[o + 1] += f.a.y; L[o + 2] += f.a.z; L[o + 3] += f.l.x; L[o + 4] += f.l.y; L[o + 5] += f.l.z;
+    if (C != nullptr) {
+        L[o + 6] += C->I.xx; L[o + 7] += C->I.xy; L[o + 8] += C->I.xz; L[o + 9] += C->I.yy; L[o + 10] += C->I.yz; L[o + 11] += C->I.zz;
+        for (int j = 0; j < 9; j++) L[o + 12 + j] += C->H[j];
+        L[o + 21] += C->M.xx; L[o + 22] += C->M.xy; L[o + 23] += C->M.xz; L[o + 24] += C->M.yy; L[o + 25] += C->M.yz; L[o + 26] += C->M.zz;
+    }
+}
+MPPI_HD void acc_load(const LMem &L, int base, int ent, SV &f, AI &C) {
+    const int o = base + ent * 27;
+    f = {{L[o + 0], L[o + 1], L[o + 2]}, {L[o + 3], L[o + 4], L[o + 5]}};
+    C.I = {L[o + 6], L[o + 7], L[o + 8], L[o + 9], L[o + 10], L[o + 11]};
+    for (int j = 0; j < 9; j++) C.H[j] = L[o + 12 + j];
+    C.M = {L[o + 21], L[o + 22], L[o + 23], L[o + 24], L[o + 25], L[o + 26]};
+}
+
+// ---- contact points --------------------------------------------------------------------------
+struct PairAcc {
+    SV f;    // explicit wrench on shape A's side (about the world origin)
+    AI C;    // implicit damping on the dynamic side (modes 1, 2)
+    V3 rep;  // reported contact force on A (B receives the opposite)
+    bool any;
+};
+MPPI_HD void pair_zero(PairAcc &a) {
+    a.f = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    a.C.I = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 9; j++) a.C.H[j] = 0.f;
+    a.C.M = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    a.rep = {0.f, 0.f, 0.f};
+    a.any = false;
+}
+
+// One contact point p (world), unit normal n pointing from B to A, penetration depth > 0.
+MPPI_HD void contact_point(CPair &P, V3 p, V3 n, float depth, const SV &vA, const SV &vB, PairAcc &acc) {
+    const V3 vr = vel_at(vA, p) - vel_at(vB, p);
+    const float vn = dot(vr, n);
+    const V3 vt = vr - vn * n;
+    const float vtn = sqrtf(dot(vt, vt));
+    acc.any = true;
+    if (P.mode == 0) {  // both dynamic: explicit spring-damper, viscous friction capped by the Coulomb cone
+        const float fn = fmaxf(0.f, P.k * depth - P.cn * vn);
+        const float sc = fminf(P.ct, P.mu * fn / (vtn + 1e-9f));
+        const V3 f = fn * n - sc * vt;
+        acc.f = {acc.f.a + cross(p, f), acc.f.l + f};
+        acc.rep = acc.rep + f;
+        return;
+    }
+    // one side static: the spring is evaluated at the END of the step, k (depth - h vn+) - hence the h k
+    // term in the implicit normal coefficient (unconditionally stable, no bounce at h = 25 ms); the
+    // damper acts only while approaching; friction is implicit too (see below)
+    const float a = (vn < 0.f ? P.cn : 0.f) + P.kh;
+    const float fn = fmaxf(0.f, P.k * depth - a * vn);
+    // Coulomb friction as an implicit secant viscosity b = min(c_t, mu fn / |v_t|): equals the stick damper
+    // at small slip, delivers mu*fn while sliding, and - being implicit - can never reverse the slip
+    // velocity (an explicit mu*fn chatters: the yaw inertia seen by a wheel contact is far below the mass)
+    const float b = fminf(P.ct, P.mu * fn / (vtn + 1e-9f));
+    const V3 f = (P.k * depth) * n;
+    acc.f = {acc.f.a + cross(p, f), acc.f.l + f};
+    // C6 = J^T (b 1 + (a-b) n n^T) J,  J = [-[p]x  1]
+    const float ab = a - b;
+    const V3 mm = cross(p, n);
+    const float pp = dot(p, p);
+    acc.C.I.xx += b * (pp - p.x * p.x) + ab * mm.x * mm.x; acc.C.I.xy += -b * p.x * p.y + ab * mm.x * mm.y;
+    acc.C.I.xz += -b * p.x * p.z + ab * mm.x * mm.z;       acc.C.I.yy += b * (pp - p.y * p.y) + ab * mm.y * mm.y;
+    acc.C.I.yz += -b * p.y * p.z + ab * mm.y * mm.z;       acc.C.I.zz += b * (pp - p.z * p.z) + ab * mm.z * mm.z;
+    acc.C.H[0] += ab * mm.x * n.x;            acc.C.H[1] += -b * p.z + ab * mm.x * n.y; acc.C.H[2] += b * p.y + ab * mm.x * n.z;
+    acc.C.H[3] += b * p.z + ab * mm.y * n.x;  acc.C.H[4] += ab * mm.y * n.y;            acc.C.H[5] += -b * p.x + ab * mm.y * n.z;
+    acc.C.H[6] += -b * p.y + ab * mm.z * n.x; acc.C.H[7] += b * p.x + ab * mm.z * n.y;  acc.C.H[8] += ab * mm.z * n.z;
+    acc.C.M.xx += b + ab * n.x * n.x; acc.C.M.xy += ab * n.x * n.y; acc.C.M.xz += ab * n.x * n.z;
+    acc.C.M.yy += b + ab * n.y * n.y; acc.C.M.yz += ab * n.y * n.z; acc.C.M.zz += b + ab * n.z * n.z;
+    // reported force = penalty force evaluated with the substep's start velocities
+    acc.rep = acc.rep + f - (ab * vn) * n - b * vr;
+}
+
+struct ShapeW {
+    M3 R;
+    V3 p;
+    SV v;
+};
+MPPI_HD ShapeW shape_world(CShape &S, const float *root, const LMem &L) {
+    M3 Rf;
+    V3 pf;
+    SV vf = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    if (S.ent >= 0) {
+        frame_load(L, S.ent, Rf, pf, vf);
+    } else {
+        const float *rs = root + 13 * S.src_actor;
+        pf = loadv(rs);
+        Rf = quat_to_R(rs + 3);
+    }
+    ShapeW w;
+    w.R = mul(Rf, load3(S.R));
+    w.p = pf + mul(Rf, loadv(S.p));
+    w.v = vf;
+    return w;
+}
+
+// Feature points of box X (8 corners, 12 edge midpoints, 6 face centres) that lie inside box Y; a pure
+// vertex test misses boxes that cross like a plus sign (a tall block against a wide chassis face).
+// sign = +1 when X is shape A (normal from B=Y to A=X)
+MPPI_HD void box_corners_in_box(CPair &P, const ShapeW &X, cfloat *hx, const ShapeW &Y, cfloat *hy, float sign, const SV &vA, const SV &vB, PairAcc &acc) {
+    for (int c = 0; c < 27; c++) {
+        if (c == 13) continue;  // the centre is not a surface feature
+        V3 loc = {(float)(c % 3 - 1) * hx[0], (float)((c / 3) % 3 - 1) * hx[1], (float)(c / 9 - 1) * hx[2]};
+        V3 pw = X.p + mul(X.R, loc);
+        V3 d = pw - Y.p;
+        V3 y = {Y.R.a[0] * d.x + Y.R.a[3] * d.y + Y.R.a[6] * d.z, Y.R.a[1] * d.x + Y.R.a[4] * d.y + Y.R.a[7] * d.z,
+                Y.R.a[2] * d.x + Y.R.a[5] * d.y + Y.R.a[8] * d.z};  // R_Y^T d
+        float dx = hy[0] - fabsf(y.x), dy = hy[1] - fabsf(y.y), dz = hy[2] - fabsf(y.z);
+        if (dx > 0.f && dy > 0.f && dz > 0.f) {
+            V3 nl;
+            float depth;
+            if (dx <= dy && dx <= dz) { nl = {y.x > 0.f ? 1.f : -1.f, 0.f, 0.f}; depth = dx; }
+            else if (dy <= dz) { nl = {0.f, y.y > 0.f ? 1.f : -1.f, 0.f}; depth = dy; }
+            else { nl = {0.f, 0.f, y.z > 0.f ? 1.f : -1.f}; depth = dz; }
+            V3 n = sign * mul(Y.R, nl);  // outward normal of Y, oriented from B to A
+            contact_point(P, pw, n, depth, vA, vB, acc);
+        }
+    }
+}
+
+// All candidate pairs of the scene -> per-frame wrench / damping accumulators and net contact forces.
+template <class T>
+MPPI_HD void contact_forces(CModel &m, const float *root, const LMem &L) {
+    using Lay = SceneLayout<T>;
+    for (int j = Lay::kAcc; j < Lay::floats(m.n_rb); j++) L[j] = 0.f;
+    const SV zero = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    for (int ip = 0; ip < m.n_pairs; ip++) {
+        CPair &P = m.pr[ip];
+        CShape &A = m.sh[P.a];
+        const ShapeW wa = shape_world(A, root, L);
+        PairAcc acc;
+        pair_zero(acc);
+        int rbB = -1, entB = -1;
+        if (P.b < 0) {  // ground plane z = 0, normal +z (from ground to A)
+            const V3 ez = {0.f, 0.f, 1.f};
+            if (A.type == 0) {
+                for (int c = 0; c < 8; c++) {
+                    V3 loc = {(c & 1) ? A.half[0] : -A.half[0], (c & 2) ? A.half[1] : -A.half[1], (c & 4) ? A.half[2] : -A.half[2]};
+                    V3 pw = wa.p + mul(wa.R, loc);
+                    if (pw.z < 0.f) contact_point(P, pw, ez, -pw.z, wa.v, zero, acc);
+                }
+            } else if (A.type == 1) {
+                V3 pw = {wa.p.x, wa.p.y, wa.p.z - A.half[0]};
+                if (pw.z < 0.f) contact_point(P, pw, ez, -pw.z, wa.v, zero, acc);
+            } else {  // disc: lowest point of the rim, axis = local z
+                V3 ax = {wa.R.a[2], wa.R.a[5], wa.R.a[8]};
+                V3 d = {ax.z * ax.x, ax.z * ax.y, ax.z * ax.z - 1.f};
+                float l2 = dot(d, d);
+                if (l2 > 1e-8f) {
+                    V3 pw = wa.p + (A.half[0] / sqrtf(l2)) * d;
+                    if (pw.z < 0.f) contact_point(P, pw, ez, -pw.z, wa.v, zero, acc);
+                }
+            }
+        } else {
+            CShape &B = m.sh[P.b];
+            const ShapeW wb = shape_world(B, root, L);
+            rbB = B.rb;
+            entB = B.ent;
+            if (A.type == 0 && B.type == 0) {
+                box_corners_in_box(P, wa, A.half, wb, B.half, 1.f, wa.v, wb.v, acc);
+                box_corners_in_box(P, wb, B.half, wa, A.half, -1.f, wa.v, wb.v, acc);
+            }
+        }
+        if (acc.any) {
+            const SV neg = {{-acc.f.a.x, -acc.f.a.y, -acc.f.a.z}, {-acc.f.l.x, -acc.f.l.y, -acc.f.l.z}};
+            if (P.mode == 0) {
+                acc_add(L, Lay::kAcc, A.ent, acc.f, nullptr);
+                acc_add(L, Lay::kAcc, entB, neg, nullptr);
+            } else if (P.mode == 1) {
+                acc_add(L, Lay::kAcc, A.ent, acc.f, &acc.C);
+            } else {
+                acc_add(L, Lay::kAcc, entB, neg, &acc.C);
+            }
+            const int oa = Lay::kCf + 3 * A.rb;
+            L[oa] += acc.rep.x; L[oa + 1] += acc.rep.y; L[oa + 2] += acc.rep.z;
+            if (rbB >= 0) {
+                const int ob = Lay::kCf + 3 * rbB;
+                L[ob] -= acc.rep.x; L[ob + 1] -= acc.rep.y; L[ob + 2] -= acc.rep.z;
+            }
+        }
+    }
+}
+
+// quaternion (xyzw) integration q <- normalize(q + h/2 (w,0) * q), world-frame angular velocity
+MPPI_HD void quat_integrate(float *q, V3 w, float h) {
+    const float x = q[0], y = q[1], z = q[2], s = q[3];
+    const float k = 0.5f * h;
+    float nx = x + k * (w.x * s + w.y * z - w.z * y);
+    float ny = y + k * (w.y * s + w.z * x - w.x * z);
+    float nz = z + k * (w.z * s + w.x * y - w.y * x);
+    float ns = s - k * (w.x * x + w.y * y + w.z * z);
+    const float inv = 1.f / sqrtf(nx * nx + ny * ny + nz * nz + ns * ns);
+    q[0] = nx * inv; q[1] = ny * inv; q[2] = nz * inv; q[3] = ns * inv;
+}
+
+// semi-implicit Euler of a 13-float root row under the world-origin spatial acceleration a
+MPPI_HD void root_integrate(float *rs, const SV &a, float h) {
+    V3 p = loadv(rs), v = loadv(rs + 7), w = loadv(rs + 10);
+    // acceleration of the body origin: aO + alpha x p + w x v
+    V3 vd = a.l + cross(a.a, p) + cross(w, v);
+    w = w + h * a.a;
+    v = v + h * vd;
+    p = p + h * v;
+    quat_integrate(rs + 3, w, h);
+    rs[0] = p.x; rs[1] = p.y; rs[2] = p.z;
+    rs[7] = v.x; rs[8] = v.y; rs[9] = v.z;
+    rs[10] = w.x; rs[11] = w.y; rs[12] = w.z;
+}
+
+// Articulated-body solve of the robot with external wrenches f_i and implicit dampings C_i per frame
+// (from contact_forces), explicit gravity, optional floating base.  Returns qdd and the base acceleration.
+template <class T>
+MPPI_HD void aba_scene(CModel &m, const Pose<T> &P, const SV &vbase, const float *qd, const float *tau_exp, const float *kdh,
+                       const LMem &L, float *qdd, SV &abase) {
+    constexpr int NB = T::NB;
+    using Lay = SceneLayout<T>;
+    constexpr int NBs = NB ? NB : 1;
+    SV v[NBs], U[NBs], pacc[NBs + 1];
+    AI acc[NBs + 1];
+    float invd[NBs], u[NBs];
+    bool has_acc[NBs + 1];
+    const float h = m.h;
+    const V3 g = m.gravity_on ? V3{m.g[0], m.g[1], m.g[2]} : V3{0.f, 0.f, 0.f};
+    static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
+        constexpr int i = ic;
+        constexpr int par = T::par[i];
+        SV S = joint_subspace<T, i>(m, P);
+        SV sj = {qd[i] * S.a, qd[i] * S.l};
+        if constexpr (par < 0) v[i] = vbase + sj;
+        else v[i] = v[par < 0 ? 0 : par] + sj;
+        has_acc[i] = false;
+    });
+    has_acc[NB] = false;
+    static_rfor<0, NB>([&](auto ic) MPPI_LAMBDA {
+        constexpr int i = ic;
+        constexpr int par = T::par[i];
+        CBody &b = m.b[i];
+        SV S = joint_subspace<T, i>(m, P);
+        AI A;
+        SV pA;
+        V3 hw;
+        rigid_world(P.R[i], P.p[i], b.m, loadv(b.hb), b.Ic, v[i], A, pA, hw);
+        // gravity, contact wrench, implicit contact damping:  (IA + h C) a + (pA + C v - f - f_g) = 0
+        SV fe;
+        AI C;
+        acc_load(L, Lay::kAcc, i, fe, C);
+        SV Cv = mul(C, v[i]);
+        pA = {pA.a + Cv.a - fe.a - cross(hw, g), pA.l + Cv.l - fe.l - b.m * g};
+        A.I.xx += h * C.I.xx; A.I.xy += h * C.I.xy; A.I.xz += h * C.I.xz; A.I.yy += h * C.I.yy; A.I.yz += h * C.I.yz; A.I.zz += h * C.I.zz;
+        for (int j = 0; j < 9; j++) A.H[j] += h * C.H[j];
+        A.M.xx += h * C.M.xx; A.M.xy += h * C.M.xy; A.M.xz += h * C.M.xz; A.M.yy += h * C.M.yy; A.M.yz += h * C.M.yz; A.M.zz += h * C.M.zz;
+        if (has_acc[i]) {
+            add_to(A, acc[i]);
+            pA = pA + pacc[i];
+        }
+        U[i] = mul(A, S);
+        float d = dot(S, U[i]) + kdh[i];
+        invd[i] = 1.f / d;
+        u[i] = tau_exp[i] - dot(S, pA);
+        const SV vp = par < 0 ? vbase : v[par < 0 ? 0 : par];
+        SV sj = {qd[i] * S.a, qd[i] * S.l};
+        SV c = {cross(vp.a, sj.a), cross(vp.a, sj.l) + cross(vp.l, sj.a)};
+        SV Ic_ = mul(A, c);
+        float k = (u[i] - dot(U[i], c)) * invd[i];
+        SV pa = {pA.a + Ic_.a + k * U[i].a, pA.l + Ic_.l + k * U[i].l};
+        rank1_sub(A, U[i], invd[i]);
+        constexpr int pj = par < 0 ? NB : par;  // base accumulator at index NB
+        if (has_acc[pj]) {
+            add_to(acc[pj], A);
+            pacc[pj] = pacc[pj] + pa;
+        } else {
+            acc[pj] = A;
+            pacc[pj] = pa;
+            has_acc[pj] = true;
+        }
+    });
+    abase = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    if (m.floating) {
+        AI A;
+        SV pA;
+        V3 hw;
+        rigid_world(P.Rb, P.pb, m.base_m, loadv(m.base_hb), m.base_Ic, vbase, A, pA, hw);
+        SV fe;
+        AI C;
+        acc_load(L, Lay::kAcc, NB, fe, C);
+        SV Cv = mul(C, vbase);
+        pA = {pA.a + Cv.a - fe.a - cross(hw, g), pA.l + Cv.l - fe.l - m.base_m * g};
+        A.I.xx += h * C.I.xx; A.I.xy += h * C.I.xy; A.I.xz += h * C.I.xz; A.I.yy += h * C.I.yy; A.I.yz += h * C.I.yz; A.I.zz += h * C.I.zz;
+        for (int j = 0; j < 9; j++) A.H[j] += h * C.H[j];
+        A.M.xx += h * C.M.xx; A.M.xy += h * C.M.xy; A.M.xz += h * C.M.xz; A.M.yy += h * C.M.yy; A.M.yz += h * C.M.yz; A.M.zz += h * C.M.zz;
+        if (has_acc[NB]) {
+            add_to(A, acc[NB]);
+            pA = pA + pacc[NB];
+        }
+        SV rhs = {{-pA.a.x, -pA.a.y, -pA.a.z}, {-pA.l.x, -pA.l.y, -pA.l.z}};
+        abase = solve6(A, rhs);
+    }
+    SV a[NBs];
+    static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
+        constexpr int i = ic;
+        constexpr int par = T::par[i];
+        SV S = joint_subspace<T, i>(m, P);
+        const SV vp = par < 0 ? vbase : v[par < 0 ? 0 : par];
+        SV sj = {qd[i] * S.a, qd[i] * S.l};
+        SV c = {cross(vp.a, sj.a), cross(vp.a, sj.l) + cross(vp.l, sj.a)};
+        SV ap = (par < 0 ? abase : a[par < 0 ? 0 : par]) + c;
+        float dd = (u[i] - dot(U[i], ap)) * invd[i];
+        qdd[i] = dd;
+        a[i] = {ap.a + dd * S.a, ap.l + dd * S.l};
+    });
+}
+
+// kinematics of the whole scene for the current state: robot poses + dynamic frames into L
+template <class T>
+MPPI_HD void scene_frames(CModel &m, const float *root, const SceneState<T> &s, Pose<T> &P, SV &vbase, const LMem &L) {
+    constexpr int NB = T::NB;
+    // the robot row of `root` is replaced by the sample's own base state
+    P.pb = loadv(s.base);
+    P.Rb = quat_to_R(s.base + 3);
+    forward_kinematics_base<T>(m, s.q, P);
+    V3 wb = loadv(s.base + 10), vb = loadv(s.base + 7);
+    vbase = m.floating ? SV{wb, vb - cross(wb, P.pb)} : SV{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    SV v[NB ? NB : 1];
+    static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
+        constexpr int i = ic;
+        constexpr int par = T::par[i];
+        SV S = joint_subspace<T, i>(m, P);
+        SV sj = {s.qd[i] * S.a, s.qd[i] * S.l};
+        if constexpr (par < 0) v[i] = vbase + sj;
+        else v[i] = v[par < 0 ? 0 : par] + sj;
+        frame_store(L, i, P.R[i], P.p[i], v[i]);
+    });
+    frame_store(L, NB, P.Rb, P.pb, vbase);
+    for (int f = 0; f < kMaxFree; f++)
+        if (f < m.n_free) {
+            const float *rs = s.fr[f];
+            V3 p = loadv(rs), w = loadv(rs + 10), vl = loadv(rs + 7);
+            frame_store(L, NB + 1 + f, quat_to_R(rs + 3), p, SV{w, vl - cross(w, p)});
+        }
+}
+
+// One simulator step of a contact scene (dt = substeps * h).  `root` carries the static actors.
+template <class T>
+MPPI_HD void step_scene(CModel &m0, const float *root, SceneState<T> &s, const float *target, const LMem &L) {
+    constexpr int NB = T::NB;
+    CModel *mp = &m0;
+    for (int sub = 0; sub < m0.substeps; sub++) {
+        CModel &m = *launder(mp);
+        const float h = m.h, kd = m.kd;
+        Pose<T> P;
+        SV vbase;
+        scene_frames<T>(m, root, s, P, vbase, L);
+        contact_forces<T>(m, root, L);
+        float tau[NB ? NB : 1], kdh[NB ? NB : 1], qdd[NB ? NB : 1], ff[NB ? NB : 1], vs[NB ? NB : 1];
+        static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
+            constexpr int i = ic;
+            ff[i] = m.drive_mode == kDriveEffort ? target[i] : 0.f;
+            vs[i] = m.drive_mode == kDriveVelocity ? target[i] : 0.f;
+            tau[i] = ff[i] + kd * (vs[i] - s.qd[i]);
+            kdh[i] = kd * h;
+        });
+        SV abase;
+        aba_scene<T>(m, P, vbase, s.qd, tau, kdh, L, qdd, abase);
+        bool any = false;
+        static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
+            constexpr int i = ic;
+            float lim = m.b[i].effort;
+            float tt = ff[i] + kd * (vs[i] - s.qd[i] - h * qdd[i]);
+            if (lim > 0.f && fabsf(tt) > lim) {
+                any = true;
+                tau[i] = tt > 0.f ? lim : -lim;
+                kdh[i] = 0.f;
+            }
+        });
+        if (any) aba_scene<T>(*launder(mp), P, vbase, s.qd, tau, kdh, L, qdd, abase);
+        static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
+            constexpr int i = ic;
+            CBody &b = m.b[i];
+            float v = s.qd[i] + h * qdd[i];
+            if (b.vmax > 0.f) v = fminf(fmaxf(v, -b.vmax), b.vmax);
+            float x = s.q[i] + h * v;
+            if (b.limited) {
+                if (x < b.lower) { x = b.lower; v = fmaxf(v, 0.f); }
+                if (x > b.upper) { x = b.upper; v = fminf(v, 0.f); }
+            }
+            s.q[i] = x;
+            s.qd[i] = v;
+        });
+        if (m.floating) root_integrate(s.base, abase, h);
+        // free rigid bodies: (I + h C) a = -(v x* I v + C v - f - f_g)
+        for (int f = 0; f < kMaxFree; f++)
+            if (f < m.n_free) {
+                CFree &F = m.fr[f];
+                float *rs = s.fr[f];
+                M3 R;
+                V3 p;
+                SV v;
+                frame_load(L, NB + 1 + f, R, p, v);
+                const float Ic6[6] = {F.Ic[0], 0.f, 0.f, F.Ic[1], 0.f, F.Ic[2]};
+                AI A;
+                SV pA;
+                V3 hw;
+                rigid_world(R, p, F.m, V3{0.f, 0.f, 0.f}, Ic6, v, A, pA, hw);
+                SV fe;
+                AI C;
+                acc_load(L, SceneLayout<T>::kAcc, NB + 1 + f, fe, C);
+                const V3 g = F.gravity ? V3{m.g[0], m.g[1], m.g[2]} : V3{0.f, 0.f, 0.f};
+                SV Cv = mul(C, v);
+                pA = {pA.a + Cv.a - fe.a - cross(hw, g), pA.l + Cv.l - fe.l - F.m * g};
+                A.I.xx += h * C.I.xx; A.I.xy += h * C.I.xy; A.I.xz += h * C.I.xz; A.I.yy += h * C.I.yy; A.I.yz += h * C.I.yz; A.I.zz += h * C.I.zz;
+                for (int j = 0; j < 9; j++) A.H[j] += h * C.H[j];
+                A.M.xx += h * C.M.xx; A.M.xy += h * C.M.xy; A.M.xz += h * C.M.xz; A.M.yy += h * C.M.yy; A.M.yz += h * C.M.yz; A.M.zz += h * C.M.zz;
+                SV rhs = {{-pA.a.x, -pA.a.y, -pA.a.z}, {-pA.l.x, -pA.l.y, -pA.l.z}};
+                root_integrate(rs, solve6(A, rhs), h);
+            }
+    }
+}
+
+// ---- scene rollouts -----------------------------------------------------------------------------
+template <class T>
+MPPI_HD void scene_init(CModel &m, const float *dof0, const float *root, SceneState<T> &s) {
+    static_for<0, T::NB>([&](auto ic) MPPI_LAMBDA {
+        constexpr int i = ic;
+        s.q[i] = dof0[2 * i];
+        s.qd[i] = dof0[2 * i + 1];
+    });
+    for (int j = 0; j < 13; j++) s.base[j] = root[13 * m.robot_actor + j];
+    for (int f = 0; f < kMaxFree; f++)
+        for (int j = 0; j < 13; j++) s.fr[f][j] = f < m.n_free ? root[13 * m.fr[f].actor + j] : 0.f;
+}
+
+// yaw of an xyzw quaternion (reference mppiisaac/utils/conversions.py:4-11)
+MPPI_HD float quat_yaw(const float *q) {
+    return atan2f(2.f * (q[3] * q[2] + q[0] * q[1]), q[3] * q[3] + q[0] * q[0] - q[1] * q[1] - q[2] * q[2]);
+}
+
+// Stage cost of a contact scene.  BOXER_PUSH restates examples/boxer_push/planner.py:26-67:
+// link[0] = robot link (ee_link), actor[0] = block, actor[1] = goal, link[1], link[2] = rigid bodies of the
+// two obstacles; w = {robot_to_block, block_to_goal, block_to_goal_ort, push_align, velocity, collision, goal_yaw}.
+template <class T>
+MPPI_HD float stage_cost_scene(CModel &m, CCost &c, const float *root, const SceneState<T> &s, const LMem &L) {
+    using Lay = SceneLayout<T>;
+    if (c.kind == kCostBoxerPush) {
+        Pose<T> P;
+        P.pb = loadv(s.base);
+        P.Rb = quat_to_R(s.base + 3);
+        forward_kinematics_base<T>(m, s.q, P);
+        M3 R;
+        V3 r;
+        link_pose<T>(m, P, c.link[0], R, r);
+        // block = free actor (looked up by actor id), goal = static actor
+        float bx = 0.f, by = 0.f, bvx = 0.f, bvy = 0.f, byaw = 0.f;
+        for (int f = 0; f < kMaxFree; f++)
+            if (f < m.n_free && m.fr[f].actor == c.actor[0]) {
+                bx = s.fr[f][0]; by = s.fr[f][1]; bvx = s.fr[f][7]; bvy = s.fr[f][8];
+                byaw = quat_yaw(s.fr[f] + 3);
+            }
+        const float gx = root[13 * c.actor[1]], gy = root[13 * c.actor[1] + 1];
+        const float rbx = r.x - bx, rby = r.y - by, bgx = gx - bx, bgy = gy - by;
+        const float d_rb = sqrtf(rbx * rbx + rby * rby), d_bg = sqrtf(bgx * bgx + bgy * bgy);
+        const float ort = fabsf(byaw - c.w[6]);
+        const float align = (rbx * bgx + rby * bgy) / (d_rb * d_bg) + 1.f;
+        const int o1 = Lay::kCf + 3 * c.link[1], o2 = Lay::kCf + 3 * c.link[2];
+        const float coll = fabsf(L[o1]) + fabsf(L[o1 + 1]) + fabsf(L[o2]) + fabsf(L[o2 + 1]);
+        const float vel = sqrtf(bvx * bvx + bvy * bvy);
+        return c.w[0] * d_rb + c.w[1] * d_bg + c.w[2] * ort + c.w[3] * align + c.w[4] * vel + c.w[5] * coll;
+    }
+    // fixed-base costs: the robot row of `root` is the (constant) base
+    return stage_cost<T>(m, c, root, s.q, s.qd);
+}
+
+template <class T>
+MPPI_HD float rollout_scene(CModel &m0, CCfg &cfg0, CCost &cost0, const float *dof0, const float *root, const float *U, const float *eps,
+                            const float *prior, float *du, float *viz, int k, const LMem &L) {
+    constexpr int NB = T::NB;
+    const int K = cfg0.K, nu = cfg0.nu, H = cfg0.H;
+    const int g = cfg0.k_offset + k;
+    const bool is_null = cfg0.sample_null_action && g == cfg0.k_total - 1;
+    const bool is_prior = cfg0.use_priors && prior != nullptr && g == cfg0.k_total - 2;
+    SceneState<T> s;
+    scene_init<T>(m0, dof0, root, s);
+    float target[NB ? NB : 1], u[kMaxNu];
+    float S = 0.f, ctrl = 0.f, disc = 1.f;
+    CModel *mp = &m0;
+    CCfg *cp = &cfg0;
+    CCost *kp = &cost0;
+    for (int t = 0; t < H; t++) {
+        CCfg &cfg = *launder(cp);
+#pragma unroll
+        for (int c = 0; c < kMaxNu; c++) {
+            if (c < nu) {
+                float Ut = U[t * nu + c];
+                float v = Ut + eps[(size_t)(t * nu + c) * K + k];
+                if (is_null) v = 0.f;
+                if (is_prior) v = prior[t * nu + c];
+                v = fminf(fmaxf(v, cfg.u_min[c]), cfg.u_max[c]);
+                u[c] = v;
+                float d = v - Ut;
+                du[(size_t)(t * nu + c) * K + k] = d;
+                float term = Ut * d * cfg.inv_sigma[c];
+                ctrl += cfg.lambda * (cfg.noise_abs_cost ? fabsf(term) : term);
+            } else {
+                u[c] = 0.f;
+            }
+        }
+        cmd_map<T>(*launder(mp), u, target);
+        step_scene<T>(*mp, root, s, target, L);
+        S += disc * stage_cost_scene<T>(*launder(mp), *launder(kp), root, s, L);
+        disc *= cfg.gamma;
+        if (cfg.want_rollouts && viz != nullptr) {
+            CModel &m = *launder(mp);
+            Pose<T> P;
+            P.pb = loadv(s.base);
+            P.Rb = quat_to_R(s.base + 3);
+            forward_kinematics_base<T>(m, s.q, P);
+            M3 R;
+            V3 p;
+            link_pose<T>(m, P, cfg.viz_link, R, p);
+            viz[((size_t)t * 3 + 0) * K + k] = p.x;
+            viz[((size_t)t * 3 + 1) * K + k] = p.y;
+            viz[((size_t)t * 3 + 2) * K + k] = p.z;
+        }
+    }
+    return S + ctrl;
+}
+
+// reference-layout rows of ONE env of a contact scene: root [A][13], rigid bodies [n_rb][13], contact forces [n_rb][3]
+template <class T>
+MPPI_HD void scene_materialise(CModel &m, const float *root, const SceneState<T> &s, const float *cf_in /* [n_rb*3] or null */,
+                               float *root_out, float *rb, float *cf) {
+    constexpr int NB = T::NB;
+    // root rows: static actors from x0, robot and free actors from the env state
+    if (root_out != nullptr) {
+        for (int j = 0; j < 13 * m.n_actors; j++) root_out[j] = root[j];
+        for (int j = 0; j < 13; j++) root_out[13 * m.robot_actor + j] = s.base[j];
+        for (int f = 0; f < kMaxFree; f++)
+            if (f < m.n_free)
+                for (int j = 0; j < 13; j++) root_out[13 * m.fr[f].actor + j] = s.fr[f][j];
+    }
+    if (rb != nullptr) {
+        Pose<T> P;
+        P.pb = loadv(s.base);
+        P.Rb = quat_to_R(s.base + 3);
+        forward_kinematics_base<T>(m, s.q, P);
+        V3 wb = loadv(s.base + 10), vb = loadv(s.base + 7);
+        const SV vbase = m.floating ? SV{wb, vb - cross(wb, P.pb)} : SV{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+        SV v[NB ? NB : 1];
+        static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
+            constexpr int i = ic;
+            constexpr int par = T::par[i];
+            SV S = joint_subspace<T, i>(m, P);
+            SV sj = {s.qd[i] * S.a, s.qd[i] * S.l};
+            if constexpr (par < 0) v[i] = vbase + sj;
+            else v[i] = v[par < 0 ? 0 : par] + sj;
+        });
+        for (int a = 0; a < m.n_actors; a++) {
+            if (a == m.robot_actor) continue;
+            float *o = rb + 13 * m.actor_first_rb[a];
+            for (int j = 0; j < 13; j++) o[j] = root[13 * a + j];
+        }
+        for (int f = 0; f < kMaxFree; f++)
+            if (f < m.n_free) {
+                float *o = rb + 13 * m.fr[f].rb;
+                for (int j = 0; j < 13; j++) o[j] = s.fr[f][j];
+            }
+        for (int l = 0; l < m.nl; l++) {
+            M3 R;
+            V3 p;
+            link_pose<T>(m, P, l, R, p);
+            const float w0 = m.l[l].body < 0 ? 1.f : 0.f;
+            SV vl = {w0 * vbase.a, w0 * vbase.l};
+            static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
+                constexpr int i = ic;
+                const float w = m.l[l].body == i ? 1.f : 0.f;
+                vl = {vl.a + w * v[i].a, vl.l + w * v[i].l};
+            });
+            V3 lv = vl.l + cross(vl.a, p);
+            float *o = rb + 13 * (m.robot_first_rb + l);
+            o[0] = p.x; o[1] = p.y; o[2] = p.z;
+            R_to_quat(R, o + 3);
+            o[7] = lv.x; o[8] = lv.y; o[9] = lv.z;
+            o[10] = vl.a.x; o[11] = vl.a.y; o[12] = vl.a.z;
+        }
+    }
+    if (cf != nullptr)
+        for (int j = 0; j < 3 * m.n_rb; j++) cf[j] = cf_in != nullptr ? cf_in[j] : 0.f;
+}
+
+}  // namespace mppi

@@ -10,6 +10,8 @@ import ctypes as C
 import os
 
 MAX_BODIES, MAX_LINKS, MAX_ACTORS, MAX_NU, MAX_H, MAX_KNOTS, MAX_COST_W = 12, 24, 8, 12, 64, 16, 16
+MAX_SHAPES, MAX_PAIRS, MAX_FREE = 24, 48, 2
+SHAPE_BOX, SHAPE_SPHERE, SHAPE_DISC = 0, 1, 2
 ABI_VERSION = 1
 
 JOINT_REVOLUTE, JOINT_PRISMATIC = 0, 1
@@ -36,12 +38,23 @@ class Actor(C.Structure):
                 ("mass", _d), ("friction", _d), ("first_rb", _i), ("n_rb", _i)]
 
 
+class Shape(C.Structure):
+    _fields_ = [("actor", _i), ("body", _i), ("type", _i), ("rb", _i), ("size", _d * 3), ("R", _d * 9), ("p", _d * 3),
+                ("friction", _d)]
+
+
+class Pair(C.Structure):
+    _fields_ = [("a", _i), ("b", _i)]
+
+
 class Model(C.Structure):
     _fields_ = [("abi_version", _i), ("n_actors", _i), ("actors", Actor * MAX_ACTORS), ("robot_actor", _i),
                 ("n_bodies", _i), ("bodies", Body * MAX_BODIES), ("n_links", _i), ("n_rb", _i),
                 ("links", Link * MAX_LINKS), ("base_mass", _d), ("base_h", _d * 3), ("base_Io", _d * 6),
                 ("drive_mode", _i), ("substeps", _i), ("drive_kd", _d), ("dt", _d), ("gravity", _d * 3),
-                ("nu", _i), ("cmd_col", (_i * 2) * MAX_BODIES), ("cmd_coef", (_d * 2) * MAX_BODIES)]
+                ("nu", _i), ("cmd_col", (_i * 2) * MAX_BODIES), ("cmd_coef", (_d * 2) * MAX_BODIES),
+                ("n_shapes", _i), ("n_pairs", _i), ("shapes", Shape * MAX_SHAPES), ("pairs", Pair * MAX_PAIRS),
+                ("ground_friction", _d), ("contact_alpha", _d), ("contact_beta", _d), ("friction_beta", _d)]
 
 
 class Config(C.Structure):

@@ -6,7 +6,7 @@ tests check fused == generic."""
 import torch
 
 from mppiisaac.backend import capi
-from mppiisaac.utils.conversions import matrix_to_euler_angles, quaternion_to_matrix
+from mppiisaac.utils.conversions import matrix_to_euler_angles, quaternion_to_matrix, quaternion_to_yaw
 
 
 class PandaReachObjective(object):
@@ -69,4 +69,55 @@ class PointReachObjective(object):
         else:
             c.actor[0] = -1
             c.w[1], c.w[2] = float(self.goal[0]), float(self.goal[1])
+        return c
+
+
+class BoxerPushObjective(object):
+    """reference examples/boxer_push/planner.py:9-67: push a block to a goal pose with a differential-drive
+    base while avoiding contact with two obstacles."""
+
+    def __init__(self, cfg=None, robot="boxer", link="ee_link", block="block", goal="goal",
+                 obstacles=("paper_obst1", "paper_obst2")):
+        self.weights = {"robot_to_block": 0.1, "block_to_goal": 2.0, "block_to_goal_ort": 3.0, "push_align": 0.6,
+                        "collision": 100, "velocity": 0.0}
+        self.goal_yaw = 0.0
+        self.robot, self.link, self.block, self.goal, self.obstacles = robot, link, block, goal, tuple(obstacles)
+
+    def reset(self):
+        pass
+
+    def compute_cost(self, sim):
+        r_pos = sim.get_actor_link_by_name(actor_name=self.robot, link_name=self.link)
+        block_pos = sim.get_actor_position_by_name(self.block)
+        block_vel = sim.get_actor_velocity_by_name(self.block)
+        block_ort = sim.get_actor_orientation_by_name(self.block)
+        block_goal = sim.get_actor_position_by_name(self.goal)
+        robot_to_block = r_pos[:, 0:2] - block_pos[:, 0:2]
+        block_to_goal = block_goal[:, 0:2] - block_pos[:, 0:2]
+        block_yaws = quaternion_to_yaw(block_ort)
+        robot_to_block_dist = torch.linalg.norm(robot_to_block[:, 0:2], axis=1)
+        block_to_pos_dist = torch.linalg.norm(block_to_goal, axis=1)
+        block_to_ort_dist = torch.abs(block_yaws - self.goal_yaw)
+        push_align = torch.sum(robot_to_block[:, 0:2] * block_to_goal, 1) / (robot_to_block_dist * block_to_pos_dist) + 1
+        obst1_forces = sim.get_actor_contact_forces_by_name(actor_name=self.obstacles[0], link_name="box")
+        obst2_forces = sim.get_actor_contact_forces_by_name(actor_name=self.obstacles[1], link_name="box")
+        coll = torch.sum(torch.abs(obst1_forces[:, 0:2]), axis=1) + torch.sum(torch.abs(obst2_forces[:, 0:2]), axis=1)
+        vel = torch.linalg.norm(block_vel[:, 0:2], axis=1)
+        w = self.weights
+        return (w["robot_to_block"] * robot_to_block_dist + w["block_to_goal"] * block_to_pos_dist
+                + w["block_to_goal_ort"] * block_to_ort_dist + w["push_align"] * push_align
+                + w["velocity"] * vel + w["collision"] * coll)
+
+    def fused_spec(self, sim) -> capi.Cost:
+        c = capi.Cost()
+        c.kind = capi.COST_BOXER_PUSH
+        c.link[0] = sim.scene.rigid_body_index(self.robot, self.link)
+        c.link[1] = sim.scene.rigid_body_index(self.obstacles[0], "box")
+        c.link[2] = sim.scene.rigid_body_index(self.obstacles[1], "box")
+        c.actor[0] = sim.scene.actor_index(self.block)
+        c.actor[1] = sim.scene.actor_index(self.goal)
+        w = self.weights
+        for i, k in enumerate(("robot_to_block", "block_to_goal", "block_to_goal_ort", "push_align", "velocity", "collision")):
+            c.w[i] = float(w[k])
+        c.w[6] = float(self.goal_yaw)
         return c

@@ -123,6 +123,7 @@ class Scene:
                 self.rb_names.append((a.name, a.type))  # primitive bodies are named "box"/"sphere"
         self.n_rb = len(self.rb_names)
         self.cmd_terms, self.nu = self._command_map()
+        self.shapes, self.pairs = self._contact_scene()
 
     def _command_map(self):
         """apply_robot_cmd's scatter (reference :524-559) as <=2 (column, coefficient) terms per DOF."""
@@ -139,6 +140,76 @@ class Scene:
                 terms.append(((idx, 1.0), (0, 0.0)))
                 idx += 1
         return terms, idx
+
+    # contact parameters of the penalty model (build-normative; no reference counterpart)
+    CONTACT_ALPHA, CONTACT_BETA, FRICTION_BETA, GROUND_FRICTION = 0.8, 0.8, 1.0, 1.0
+
+    def _contact_scene(self):
+        """Collision primitives and candidate pairs of one env.
+
+        Robot links contribute their URDF <collision> geometry (meshes as their AABB box, thin cylinders
+        as discs); box/sphere actors their own shape (reference isaacgym_utils.py:26-52).  Pairs follow the
+        reference's collision filter: same env only, both actors `collision: true`
+        (isaacgym_wrapper.py:441), no robot self-collision; wheels/casters collide with the ground only."""
+        shapes = []
+        any_dynamic = any((not a.fixed) for a in self.env_cfg)
+        if not any_dynamic:
+            return [], []  # nothing can move into contact with anything that reacts: contact-free scene
+        for ai, a in enumerate(self.env_cfg):
+            if not a.collision:
+                continue
+            if a.type == "robot":
+                casters = set(a.caster_links or [])
+                for li, l in enumerate(self.robot_model["links"]):
+                    Rl, pl = np.asarray(l["R"]), np.asarray(l["p"])
+                    for c in l["collision"]:
+                        Rc, pc = np.asarray(c["R"]), np.asarray(c["p"])
+                        t = c["type"]
+                        if t == "box":
+                            kind, size = capi.SHAPE_BOX, [0.5 * v for v in c["size"]]
+                        elif t == "sphere":
+                            kind, size = capi.SHAPE_SPHERE, [c["radius"], 0.0, 0.0]
+                        elif t == "cylinder" and c["length"] < 0.25 * c["radius"]:
+                            kind, size = capi.SHAPE_DISC, [c["radius"], 0.0, 0.0]      # wheel / caster
+                        elif t == "cylinder":
+                            kind, size = capi.SHAPE_BOX, [c["radius"], c["radius"], 0.5 * c["length"]]
+                        elif t == "mesh":
+                            lo, hi = np.asarray(c["aabb_min"]), np.asarray(c["aabb_max"])
+                            kind, size = capi.SHAPE_BOX, list(0.5 * (hi - lo))
+                            pc = pc + Rc @ (0.5 * (hi + lo))
+                        else:
+                            continue
+                        shapes.append(dict(actor=ai, body=l["body"], type=kind, rb=self.first_rb[ai] + li, size=size,
+                                           R=Rl @ Rc, p=Rl @ pc + pl, friction=0.0 if l["name"] in casters else a.friction,
+                                           fixed=bool(a.fixed), link=l["name"]))
+            elif a.type == "box":
+                shapes.append(dict(actor=ai, body=-1, type=capi.SHAPE_BOX, rb=self.first_rb[ai], size=[0.5 * v for v in a.size],
+                                   R=np.eye(3), p=np.zeros(3), friction=a.friction, fixed=bool(a.fixed), link="box"))
+            elif a.type == "sphere":
+                shapes.append(dict(actor=ai, body=-1, type=capi.SHAPE_SPHERE, rb=self.first_rb[ai], size=[a.size[0], 0.0, 0.0],
+                                   R=np.eye(3), p=np.zeros(3), friction=a.friction, fixed=bool(a.fixed), link="sphere"))
+        pairs = []
+        for i, si in enumerate(shapes):
+            robot_i = self.env_cfg[si["actor"]].type == "robot"
+            # a robot link welded to a FIXED base never reacts: it only matters as an obstacle
+            static_i = si["fixed"] and (not robot_i or si["body"] < 0)
+            if not si["fixed"]:
+                pairs.append((i, -1))  # ground plane
+            for j in range(i + 1, len(shapes)):
+                sj = shapes[j]
+                robot_j = self.env_cfg[sj["actor"]].type == "robot"
+                static_j = sj["fixed"] and (not robot_j or sj["body"] < 0)
+                if si["actor"] == sj["actor"] or (static_i and static_j):
+                    continue
+                kinds = {si["type"], sj["type"]}
+                if capi.SHAPE_DISC in kinds:
+                    continue
+                if kinds == {capi.SHAPE_SPHERE}:
+                    continue  # no sphere-sphere contacts in the shipped scenes
+                pairs.append((i, j))
+        if len(shapes) > capi.MAX_SHAPES or len(pairs) > capi.MAX_PAIRS:
+            raise ValueError(f"contact scene too large: {len(shapes)} shapes, {len(pairs)} pairs")
+        return shapes, pairs
 
     def viz_link_index(self) -> int:
         """link index (within the robot) of ActorWrapper.visualize_link, -1 if unset."""
@@ -214,11 +285,29 @@ class Scene:
             for j in range(3):
                 cl.p[j] = l["p"][j]
         bi = rm["base"]["inertia"]
-        m.base_mass = bi["mass"]
+        # the reference overwrites the mass of rigid body 0 of every actor with ActorWrapper.mass
+        # (isaacgym_wrapper.py:450-456); the inertia tensor is left as imported.  Only matters for floating bases.
+        own = rm["links"][0]["own_inertia"]
+        dm = float(self.robot.mass) - own["mass"]
+        c0 = np.asarray(own["h"]) / own["mass"] if own["mass"] > 0 else np.zeros(3)
+        m.base_mass = bi["mass"] + dm
         for j in range(3):
-            m.base_h[j] = bi["h"][j]
+            m.base_h[j] = bi["h"][j] + dm * c0[j]
         for j in range(6):
             m.base_Io[j] = bi["Io"][j]
+        m.n_shapes, m.n_pairs = len(self.shapes), len(self.pairs)
+        for i, sh in enumerate(self.shapes):
+            cs = m.shapes[i]
+            cs.actor, cs.body, cs.type, cs.rb, cs.friction = sh["actor"], sh["body"], sh["type"], sh["rb"], float(sh["friction"])
+            for j in range(3):
+                cs.size[j] = float(sh["size"][j])
+                cs.p[j] = float(sh["p"][j])
+            for j in range(9):
+                cs.R[j] = float(sh["R"][j // 3][j % 3])
+        for i, (a, b) in enumerate(self.pairs):
+            m.pairs[i].a, m.pairs[i].b = a, b
+        m.ground_friction = self.GROUND_FRICTION
+        m.contact_alpha, m.contact_beta, m.friction_beta = self.CONTACT_ALPHA, self.CONTACT_BETA, self.FRICTION_BETA
         if self.robot.dof_mode not in DRIVE_GAINS:
             raise ValueError("Invalid dof_mode")
         m.drive_mode, m.drive_kd = DRIVE_GAINS[self.robot.dof_mode]
@@ -345,10 +434,23 @@ class IsaacGymWrapper:
 
     def reset_robot_state(self, q, qdot):
         """reference :574-619 (urdfenvs compatibility): q, qdot lists -> interleaved DOF state in all envs."""
-        if self.scene.robot.differential_drive:
-            raise NotImplementedError("reset_robot_state for differential-drive robots (reference branch raises, SURVEY.md C)")
+        root = (self.saved_root_state if self.saved_root_state is not None else self._root_state)[0].cpu().numpy().copy()
+        robot = self.scene.robot
+        if robot.differential_drive:
+            # q = (x, y, yaw, <arm joints>): the base pose goes to the root state, wheels to 0.  The reference's
+            # branch (:596-604 -> set_state_tensor_by_pos_vel :677-693) writes a misspelled attribute and raises
+            # (SURVEY.md C); this is its intended behaviour.
+            pos, vel = list(q[:3]), list(qdot[:3])
+            yaw = float(pos[2])
+            ri = self.scene.robot_idx
+            root[ri, 0:2] = pos[:2]
+            root[ri, 3:7] = [0.0, 0.0, np.sin(yaw / 2), np.cos(yaw / 2)]
+            root[ri, 7:10] = [vel[0], vel[1], 0.0]
+            root[ri, 10:13] = [0.0, 0.0, vel[2]]
+            n_wheels = int(robot.wheel_count)
+            q = list(q[3:]) + [0.0] * n_wheels
+            qdot = list(qdot[3:]) + [0.0] * n_wheels
         dof = interleave_dof_state(q, qdot, self.scene.n_dof)
-        root = (self.saved_root_state if self.saved_root_state is not None else self._root_state)[0].cpu().numpy()
         self._push_single_state(dof, root)
 
     def save_root_state(self):

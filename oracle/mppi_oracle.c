@@ -168,6 +168,7 @@ typedef struct {
     real Rj[NBMAX][9], pj[NBMAX][3]; /* child->parent transform of each body            */
     real Rw[NBMAX][9], pw[NBMAX][3]; /* body->world                                      */
     real Rb[9], pb[3];               /* base->world                                      */
+    real vb[6];                      /* base spatial velocity, base coordinates          */
     real X[NBMAX][36];               /* Plucker parent->child                            */
     real S[NBMAX][6];
     real v[NBMAX][6];                /* spatial velocity, body coordinates               */
@@ -178,6 +179,9 @@ static void kinematics(const mppi_model_t *m, const real *root, const real *q, c
     const real *rs = root + 13 * m->robot_actor;
     k->pb[0] = rs[0]; k->pb[1] = rs[1]; k->pb[2] = rs[2];
     quat_to_R(rs + 3, k->Rb);
+    /* base spatial velocity in base coordinates (zero for a fixed base) */
+    for (int j = 0; j < 6; j++) k->vb[j] = 0;
+    if (!m->actors[m->robot_actor].fixed) { m3_tvec(k->Rb, rs + 10, k->vb); m3_tvec(k->Rb, rs + 7, k->vb + 3); }
     for (int i = 0; i < m->n_bodies; i++) {
         const mppi_body_t *b = &m->bodies[i];
         real Rt[9], pt[3], ax[3];
@@ -206,8 +210,8 @@ static void kinematics(const mppi_model_t *m, const real *root, const real *q, c
         /* v_i = X v_parent + S qd ; c_i = v_i x (S qd)    (base is fixed: v_base = 0) */
         real vj[6];
         for (int j = 0; j < 6; j++) vj[j] = k->S[i][j] * qd[i];
-        if (b->parent < 0) memcpy(k->v[i], vj, sizeof vj);
-        else { m6_vec(k->X[i], k->v[b->parent], k->v[i]); for (int j = 0; j < 6; j++) k->v[i][j] += vj[j]; }
+        m6_vec(k->X[i], b->parent < 0 ? k->vb : k->v[b->parent], k->v[i]);
+        for (int j = 0; j < 6; j++) k->v[i][j] += vj[j];
         crm(k->v[i], vj, k->c[i]);
     }
 }
@@ -338,8 +342,8 @@ void orc_rigid_body_state(const mppi_model_t *m, const real *root, const real *q
             m3_mul(Rbw, Rl, Rw);
             m3_vec(Rbw, pl, t);
             for (int j = 0; j < 3; j++) pw[j] = pbw[j] + t[j];
-            if (L->body >= 0) { /* velocity of the link origin: R_w (v + w x p_l) */
-                const real *v = k.v[L->body];
+            { /* velocity of the link origin: R_w (v + w x p_l) */
+                const real *v = L->body >= 0 ? k.v[L->body] : k.vb;
                 real wxp[3], vl[3];
                 cross3(v, pl, wxp);
                 for (int j = 0; j < 3; j++) vl[j] = v[3 + j] + wxp[j];
@@ -357,10 +361,430 @@ void orc_rigid_body_state(const mppi_model_t *m, const real *root, const real *q
     if (cf) for (int j = 0; j < 3 * m->n_rb; j++) cf[j] = 0; /* no contact model in this scope row */
 }
 
+/* ------------------------------------------------------------------ contact scenes
+ * Floating-base robots, free rigid bodies and penalty contact.
+ * The reference delegates all of this to PhysX (isaacgym_wrapper.py:21-39 sim params, :429-508 actor and
+ * shape properties, isaacgym_utils.py:61-68 ground plane); PARITY UNPINNED - this is the build-normative
+ * model, checked by physics known-answer tests (tests/test_scene_kat.py).
+ * Formulation: dense 6x6 spatial algebra in WORLD coordinates about the world origin, double precision. */
+#define NFMAX (NBMAX + 1 + MPPI_MAX_FREE)
+
+typedef struct {
+    real R[9], p[3];   /* pose */
+    real v[6];         /* spatial velocity (w, vO) */
+    real f[6];         /* external wrench accumulator */
+    real C[36];        /* implicit damping accumulator */
+    real mass;         /* mass of the owning actor (contact scaling) */
+} frame_t;
+
+typedef struct {
+    int is_scene, floating, n_free, free_actor[MPPI_MAX_FREE];
+    real robot_mass;
+} scene_info_t;
+
+static void scene_info(const mppi_model_t *m, scene_info_t *si) {
+    si->floating = !m->actors[m->robot_actor].fixed;
+    si->n_free = 0;
+    for (int a = 0; a < m->n_actors; a++)
+        if (a != m->robot_actor && !m->actors[a].fixed && si->n_free < MPPI_MAX_FREE) si->free_actor[si->n_free++] = a;
+    si->robot_mass = (real)m->base_mass;
+    for (int i = 0; i < m->n_bodies; i++) si->robot_mass += (real)m->bodies[i].mass;
+    si->is_scene = si->floating || si->n_free > 0 || m->n_pairs > 0;
+}
+int orc_is_scene(const mppi_model_t *m) { scene_info_t si; scene_info(m, &si); return si.is_scene; }
+
+/* C6 += J^T (b 1 + (a-b) n n^T) J with J = [-[p]x 1]: viscous element acting at point p */
+static void damping_add(real *C, const real *p, const real *n, real a, real b) {
+    real J[18]; /* 3x6 */
+    real px[9];
+    skew3(p, px);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { J[6 * i + j] = -px[3 * i + j]; J[6 * i + 3 + j] = (i == j) ? 1 : 0; }
+    real Cl[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Cl[3 * i + j] = (i == j ? b : 0) + (a - b) * n[i] * n[j];
+    real T[18]; /* Cl J */
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 6; j++) { real t = 0; for (int k = 0; k < 3; k++) t += Cl[3 * i + k] * J[6 * k + j]; T[6 * i + j] = t; }
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) { real t = 0; for (int k = 0; k < 3; k++) t += J[6 * k + i] * T[6 * k + j]; C[6 * i + j] += t; }
+}
+static void wrench_add(real *f6, const real *p, const real *f, real sign) {
+    real m3[3];
+    cross3(p, f, m3);
+    for (int j = 0; j < 3; j++) { f6[j] += sign * m3[j]; f6[3 + j] += sign * f[j]; }
+}
+static void vel_at(const real *v6, const real *p, real *out) {
+    real t[3];
+    cross3(v6, p, t);
+    for (int j = 0; j < 3; j++) out[j] = v6[3 + j] + t[j];
+}
+
+typedef struct { real R[9], p[3]; const real *v; int ent; } shape_w_t;
+static const real ZERO6[6] = {0, 0, 0, 0, 0, 0};
+
+typedef struct { real f[6]; real C[36]; real rep[3]; int any; } pair_acc_t;
+
+/* one contact point: normal n from B to A, penetration depth > 0 (same law as csrc/mppi_scene.hpp::contact_point,
+ * written from DESIGN.md section 3) */
+static void contact_point(int mode, real mu, real k, real cn, real ct, real kh, const real *p, const real *n, real depth,
+                          const real *vA, const real *vB, pair_acc_t *acc) {
+    real va[3], vb[3], vr[3], vt[3];
+    vel_at(vA, p, va); vel_at(vB, p, vb);
+    for (int j = 0; j < 3; j++) vr[j] = va[j] - vb[j];
+    real vn = vr[0] * n[0] + vr[1] * n[1] + vr[2] * n[2];
+    for (int j = 0; j < 3; j++) vt[j] = vr[j] - vn * n[j];
+    real vtn = (real)sqrt((double)(vt[0] * vt[0] + vt[1] * vt[1] + vt[2] * vt[2]));
+    acc->any = 1;
+    if (mode == 0) {
+        real fn = k * depth - cn * vn; if (fn < 0) fn = 0;
+        real sc = mu * fn / (vtn + (real)1e-9); if (ct < sc) sc = ct;
+        real f[3];
+        for (int j = 0; j < 3; j++) { f[j] = fn * n[j] - sc * vt[j]; acc->rep[j] += f[j]; }
+        wrench_add(acc->f, p, f, 1);
+        return;
+    }
+    real a = (vn < 0 ? cn : 0) + kh;
+    real fn = k * depth - a * vn; if (fn < 0) fn = 0;
+    real b = mu * fn / (vtn + (real)1e-9); if (ct < b) b = ct;
+    real f[3];
+    for (int j = 0; j < 3; j++) f[j] = k * depth * n[j];
+    wrench_add(acc->f, p, f, 1);
+    damping_add(acc->C, p, n, a, b);
+    for (int j = 0; j < 3; j++) acc->rep[j] += f[j] - (a - b) * vn * n[j] - b * vr[j];
+}
+
+static void shape_world(const mppi_model_t *m, const mppi_shape_t *S, int ent, const frame_t *fr, const real *root, shape_w_t *w) {
+    real Rf[9], pf[3];
+    if (ent >= 0) { memcpy(Rf, fr[ent].R, sizeof Rf); memcpy(pf, fr[ent].p, sizeof pf); w->v = fr[ent].v; }
+    else { const real *rs = root + 13 * S->actor; quat_to_R(rs + 3, Rf); pf[0] = rs[0]; pf[1] = rs[1]; pf[2] = rs[2]; w->v = ZERO6; }
+    real Rs[9], ps[3], t[3];
+    for (int j = 0; j < 9; j++) Rs[j] = (real)S->R[j];
+    for (int j = 0; j < 3; j++) ps[j] = (real)S->p[j];
+    m3_mul(Rf, Rs, w->R);
+    m3_vec(Rf, ps, t);
+    for (int j = 0; j < 3; j++) w->p[j] = pf[j] + t[j];
+    w->ent = ent;
+    (void)m;
+}
+
+static void corners_in_box(int mode, real mu, real k, real cn, real ct, real kh, const shape_w_t *X, const double *hx, const shape_w_t *Y,
+                           const double *hy, real sign, const real *vA, const real *vB, pair_acc_t *acc) {
+    /* feature points of X: 8 corners, 12 edge midpoints, 6 face centres (26 = 3^3 - centre) */
+    for (int c = 0; c < 27; c++) {
+        if (c == 13) continue;
+        real loc[3] = {(real)((c % 3 - 1) * hx[0]), (real)(((c / 3) % 3 - 1) * hx[1]), (real)((c / 9 - 1) * hx[2])};
+        real pw[3], t[3], d[3], y[3];
+        m3_vec(X->R, loc, t);
+        for (int j = 0; j < 3; j++) { pw[j] = X->p[j] + t[j]; d[j] = pw[j] - Y->p[j]; }
+        m3_tvec(Y->R, d, y);
+        real dx = (real)hy[0] - (real)fabs((double)y[0]), dy = (real)hy[1] - (real)fabs((double)y[1]), dz = (real)hy[2] - (real)fabs((double)y[2]);
+        if (dx > 0 && dy > 0 && dz > 0) {
+            real nl[3] = {0, 0, 0}, depth;
+            if (dx <= dy && dx <= dz) { nl[0] = y[0] > 0 ? 1 : -1; depth = dx; }
+            else if (dy <= dz) { nl[1] = y[1] > 0 ? 1 : -1; depth = dy; }
+            else { nl[2] = y[2] > 0 ? 1 : -1; depth = dz; }
+            real n[3];
+            m3_vec(Y->R, nl, n);
+            for (int j = 0; j < 3; j++) n[j] *= sign;
+            contact_point(mode, mu, k, cn, ct, kh, pw, n, depth, vA, vB, acc);
+        }
+    }
+}
+
+/* dynamic frame index of a shape (-1: static), and the mass that scales its contact gains */
+static int shape_entity(const mppi_model_t *m, const scene_info_t *si, const mppi_shape_t *S, real *mass) {
+    *mass = -1;
+    if (S->actor == m->robot_actor) {
+        if (S->body >= 0) { *mass = si->robot_mass; return S->body; }
+        if (si->floating) { *mass = si->robot_mass; return m->n_bodies; }
+        return -1;
+    }
+    for (int f = 0; f < si->n_free; f++)
+        if (si->free_actor[f] == S->actor) { *mass = (real)m->actors[S->actor].mass; return m->n_bodies + 1 + f; }
+    return -1;
+}
+
+static void scene_contacts(const mppi_model_t *m, const scene_info_t *si, frame_t *fr, const real *root, real *cf) {
+    real h = (real)(m->dt / m->substeps);
+    int nf = m->n_bodies + 1 + MPPI_MAX_FREE;
+    for (int e = 0; e < nf; e++) { memset(fr[e].f, 0, sizeof fr[e].f); memset(fr[e].C, 0, sizeof fr[e].C); }
+    for (int j = 0; j < 3 * m->n_rb; j++) cf[j] = 0;
+    for (int ip = 0; ip < m->n_pairs; ip++) {
+        const mppi_shape_t *A = &m->shapes[m->pairs[ip].a];
+        const mppi_shape_t *B = m->pairs[ip].b >= 0 ? &m->shapes[m->pairs[ip].b] : NULL;
+        real ma, mb = -1;
+        int ea = shape_entity(m, si, A, &ma), eb = -1;
+        if (B) eb = shape_entity(m, si, B, &mb);
+        real mua = (real)A->friction, mub = B ? (real)B->friction : (real)m->ground_friction;
+        real mu = mua < mub ? mua : mub;
+        int mode; real meff;
+        if (ma > 0 && mb > 0) { mode = 0; meff = ma * mb / (ma + mb); }
+        else if (ma > 0) { mode = 1; meff = ma; }
+        else { mode = 2; meff = mb; }
+        int tb = B ? B->type : -1;
+        real npts = (A->type == MPPI_SHAPE_BOX && (tb == MPPI_SHAPE_BOX || tb == -1)) ? 4 : 1;
+        real k = (real)m->contact_alpha * meff / (h * h) / npts, cn = (real)m->contact_beta * meff / h / npts;
+        real ct = (real)m->friction_beta * meff / h / npts, kh = (real)m->contact_alpha * meff / h / npts;
+        shape_w_t wa, wb;
+        shape_world(m, A, ea, fr, root, &wa);
+        pair_acc_t acc;
+        memset(&acc, 0, sizeof acc);
+        if (!B) {
+            real ez[3] = {0, 0, 1};
+            if (A->type == MPPI_SHAPE_BOX) {
+                for (int c = 0; c < 8; c++) {
+                    real loc[3] = {(real)((c & 1) ? A->size[0] : -A->size[0]), (real)((c & 2) ? A->size[1] : -A->size[1]), (real)((c & 4) ? A->size[2] : -A->size[2])};
+                    real t[3], pw[3];
+                    m3_vec(wa.R, loc, t);
+                    for (int j = 0; j < 3; j++) pw[j] = wa.p[j] + t[j];
+                    if (pw[2] < 0) contact_point(mode, mu, k, cn, ct, kh, pw, ez, -pw[2], wa.v, ZERO6, &acc);
+                }
+            } else if (A->type == MPPI_SHAPE_SPHERE) {
+                real pw[3] = {wa.p[0], wa.p[1], wa.p[2] - (real)A->size[0]};
+                if (pw[2] < 0) contact_point(mode, mu, k, cn, ct, kh, pw, ez, -pw[2], wa.v, ZERO6, &acc);
+            } else { /* disc: lowest rim point; axis = local z of the shape frame */
+                real ax[3] = {wa.R[2], wa.R[5], wa.R[8]};
+                real d[3] = {ax[2] * ax[0], ax[2] * ax[1], ax[2] * ax[2] - 1};
+                real l2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+                if (l2 > (real)1e-8) {
+                    real sc = (real)A->size[0] / (real)sqrt((double)l2), pw[3];
+                    for (int j = 0; j < 3; j++) pw[j] = wa.p[j] + sc * d[j];
+                    if (pw[2] < 0) contact_point(mode, mu, k, cn, ct, kh, pw, ez, -pw[2], wa.v, ZERO6, &acc);
+                }
+            }
+        } else {
+            shape_world(m, B, eb, fr, root, &wb);
+            if (A->type == MPPI_SHAPE_BOX && B->type == MPPI_SHAPE_BOX) {
+                corners_in_box(mode, mu, k, cn, ct, kh, &wa, A->size, &wb, B->size, 1, wa.v, wb.v, &acc);
+                corners_in_box(mode, mu, k, cn, ct, kh, &wb, B->size, &wa, A->size, -1, wa.v, wb.v, &acc);
+            }
+        }
+        if (!acc.any) continue;
+        if (mode == 0) {
+            for (int j = 0; j < 6; j++) { fr[ea].f[j] += acc.f[j]; fr[eb].f[j] -= acc.f[j]; }
+        } else if (mode == 1) {
+            for (int j = 0; j < 6; j++) fr[ea].f[j] += acc.f[j];
+            for (int j = 0; j < 36; j++) fr[ea].C[j] += acc.C[j];
+        } else {
+            for (int j = 0; j < 6; j++) fr[eb].f[j] -= acc.f[j];
+            for (int j = 0; j < 36; j++) fr[eb].C[j] += acc.C[j];
+        }
+        for (int j = 0; j < 3; j++) { cf[3 * A->rb + j] += acc.rep[j]; if (B) cf[3 * B->rb + j] -= acc.rep[j]; }
+    }
+}
+
+/* rigid inertia about the world origin, world axes, from body-frame (m, h = m c, Io about the body origin) */
+static void world_inertia(const real *R, const real *p, real mass, const double *h_b, const double *Io6, real *I6, real *hw) {
+    real c[3] = {0, 0, 0}, hb[3] = {(real)h_b[0], (real)h_b[1], (real)h_b[2]};
+    if (mass > 0) for (int j = 0; j < 3; j++) c[j] = hb[j] / mass;
+    real cc = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+    real Ic[9];
+    real Io[9] = {(real)Io6[0], (real)Io6[1], (real)Io6[2], (real)Io6[1], (real)Io6[3], (real)Io6[4], (real)Io6[2], (real)Io6[4], (real)Io6[5]};
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Ic[3 * i + j] = Io[3 * i + j] - mass * ((i == j ? cc : 0) - c[i] * c[j]);
+    real T[9], Rt[9], Iw[9], cw[3], t[3];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rt[3 * i + j] = R[3 * j + i];
+    m3_mul(R, Ic, T); m3_mul(T, Rt, Iw);
+    m3_vec(R, c, t);
+    for (int j = 0; j < 3; j++) { cw[j] = p[j] + t[j]; hw[j] = mass * cw[j]; }
+    real cw2 = cw[0] * cw[0] + cw[1] * cw[1] + cw[2] * cw[2];
+    real Iow[6] = {Iw[0] + mass * (cw2 - cw[0] * cw[0]), Iw[1] - mass * cw[0] * cw[1], Iw[2] - mass * cw[0] * cw[2],
+                   Iw[4] + mass * (cw2 - cw[1] * cw[1]), Iw[5] - mass * cw[1] * cw[2], Iw[8] + mass * (cw2 - cw[2] * cw[2])};
+    rigid_inertia(mass, hw, Iow, I6);
+}
+
+static int solve6(real *A, real *b) { /* Gaussian elimination with partial pivoting, in place */
+    for (int c = 0; c < 6; c++) {
+        int piv = c;
+        for (int r = c + 1; r < 6; r++) if (fabs((double)A[6 * r + c]) > fabs((double)A[6 * piv + c])) piv = r;
+        if (A[6 * piv + c] == 0) return -1;
+        if (piv != c) { for (int j = 0; j < 6; j++) { real t = A[6 * c + j]; A[6 * c + j] = A[6 * piv + j]; A[6 * piv + j] = t; } real t = b[c]; b[c] = b[piv]; b[piv] = t; }
+        for (int r = c + 1; r < 6; r++) {
+            real f = A[6 * r + c] / A[6 * c + c];
+            for (int j = c; j < 6; j++) A[6 * r + j] -= f * A[6 * c + j];
+            b[r] -= f * b[c];
+        }
+    }
+    for (int r = 5; r >= 0; r--) { real t = b[r]; for (int j = r + 1; j < 6; j++) t -= A[6 * r + j] * b[j]; b[r] = t / A[6 * r + r]; }
+    return 0;
+}
+
+static void quat_integrate(real *q, const real *w, real h) {
+    real x = q[0], y = q[1], z = q[2], s = q[3], k = h / 2;
+    real nx = x + k * (w[0] * s + w[1] * z - w[2] * y), ny = y + k * (w[1] * s + w[2] * x - w[0] * z);
+    real nz = z + k * (w[2] * s + w[0] * y - w[1] * x), ns = s - k * (w[0] * x + w[1] * y + w[2] * z);
+    real n = (real)sqrt((double)(nx * nx + ny * ny + nz * nz + ns * ns));
+    q[0] = nx / n; q[1] = ny / n; q[2] = nz / n; q[3] = ns / n;
+}
+static void root_integrate(real *rs, const real *a6, real h) {
+    real *p = rs, *v = rs + 7, *w = rs + 10, t1[3], t2[3], vd[3];
+    cross3(a6, p, t1); cross3(w, v, t2);
+    for (int j = 0; j < 3; j++) vd[j] = a6[3 + j] + t1[j] + t2[j];
+    for (int j = 0; j < 3; j++) w[j] += h * a6[j];
+    for (int j = 0; j < 3; j++) v[j] += h * vd[j];
+    for (int j = 0; j < 3; j++) p[j] += h * v[j];
+    quat_integrate(rs + 3, w, h);
+}
+static void root_frame(const real *rs, frame_t *f) {
+    quat_to_R(rs + 3, f->R);
+    real t[3];
+    cross3(rs + 10, rs, t);
+    for (int j = 0; j < 3; j++) { f->p[j] = rs[j]; f->v[j] = rs[10 + j]; f->v[3 + j] = rs[7 + j] - t[j]; }
+}
+
+/* World-frame dense ABA of the robot with external wrenches / implicit dampings per frame. */
+static void scene_aba(const mppi_model_t *m, const scene_info_t *si, frame_t *fr, const real *qd, const real *tau_exp, const real *kdh,
+                      real *qdd, real *abase) {
+    int n = m->n_bodies;
+    real h = (real)(m->dt / m->substeps);
+    real g[3] = {0, 0, 0};
+    if (m->actors[m->robot_actor].gravity) for (int j = 0; j < 3; j++) g[j] = (real)m->gravity[j];
+    real S[NBMAX][6], c[NBMAX][6], IA[NBMAX + 1][36], pA[NBMAX + 1][6], U[NBMAX][6], d[NBMAX], u[NBMAX], a[NBMAX][6];
+    const real *vb = fr[n].v;
+    for (int i = 0; i <= n; i++) {
+        const frame_t *F = &fr[i];
+        real hw[3];
+        if (i < n) world_inertia(F->R, F->p, (real)m->bodies[i].mass, m->bodies[i].h, m->bodies[i].Io, IA[i], hw);
+        else world_inertia(F->R, F->p, (real)m->base_mass, m->base_h, m->base_Io, IA[i], hw);
+        real mass = i < n ? (real)m->bodies[i].mass : (real)m->base_mass;
+        real Iv[6], Cv[6], fg[6], t3[3];
+        m6_vec(IA[i], F->v, Iv);
+        crf(F->v, Iv, pA[i]);
+        m6_vec(F->C, F->v, Cv);
+        cross3(hw, g, t3);
+        for (int j = 0; j < 3; j++) { fg[j] = t3[j]; fg[3 + j] = mass * g[j]; }
+        for (int j = 0; j < 6; j++) pA[i][j] += Cv[j] - F->f[j] - fg[j];
+        for (int j = 0; j < 36; j++) IA[i][j] += h * F->C[j];
+        if (i < n) {
+            const mppi_body_t *b = &m->bodies[i];
+            real ax[3] = {(real)b->axis[0], (real)b->axis[1], (real)b->axis[2]}, aw[3], t[3];
+            m3_vec(F->R, ax, aw);
+            if (b->jtype == MPPI_JOINT_REVOLUTE) { cross3(F->p, aw, t); for (int j = 0; j < 3; j++) { S[i][j] = aw[j]; S[i][3 + j] = t[j]; } }
+            else for (int j = 0; j < 3; j++) { S[i][j] = 0; S[i][3 + j] = aw[j]; }
+            const real *vp = b->parent < 0 ? vb : fr[b->parent].v;
+            real sj[6];
+            for (int j = 0; j < 6; j++) sj[j] = S[i][j] * qd[i];
+            crm(vp, sj, c[i]);
+        }
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        m6_vec(IA[i], S[i], U[i]);
+        real sd = 0, sp = 0;
+        for (int j = 0; j < 6; j++) { sd += S[i][j] * U[i][j]; sp += S[i][j] * pA[i][j]; }
+        d[i] = sd + kdh[i];
+        u[i] = tau_exp[i] - sp;
+        int par = m->bodies[i].parent < 0 ? n : m->bodies[i].parent;
+        real Ia[36], t6[6];
+        for (int r = 0; r < 6; r++) for (int cc = 0; cc < 6; cc++) Ia[6 * r + cc] = IA[i][6 * r + cc] - U[i][r] * U[i][cc] / d[i];
+        m6_vec(Ia, c[i], t6);
+        for (int j = 0; j < 6; j++) pA[par][j] += pA[i][j] + t6[j] + U[i][j] * (u[i] / d[i]);
+        for (int j = 0; j < 36; j++) IA[par][j] += Ia[j];
+    }
+    for (int j = 0; j < 6; j++) abase[j] = 0;
+    if (si->floating) {
+        real A[36], b6[6];
+        memcpy(A, IA[n], sizeof A);
+        for (int j = 0; j < 6; j++) b6[j] = -pA[n][j];
+        solve6(A, b6);
+        memcpy(abase, b6, sizeof b6);
+    }
+    for (int i = 0; i < n; i++) {
+        int par = m->bodies[i].parent;
+        real ap[6], ua = 0;
+        for (int j = 0; j < 6; j++) ap[j] = (par < 0 ? abase[j] : a[par][j]) + c[i][j];
+        for (int j = 0; j < 6; j++) ua += U[i][j] * ap[j];
+        qdd[i] = (u[i] - ua) / d[i];
+        for (int j = 0; j < 6; j++) a[i][j] = ap[j] + S[i][j] * qdd[i];
+    }
+}
+
+/* frames of the current scene state: robot bodies (world poses + velocities), base, free actors */
+static void scene_frames(const mppi_model_t *m, const scene_info_t *si, const real *root, const real *q, const real *qd, frame_t *fr) {
+    int n = m->n_bodies;
+    kin_t k;
+    kinematics(m, root, q, qd, &k);  /* poses only are taken from the body-frame kinematics */
+    root_frame(root + 13 * m->robot_actor, &fr[n]);
+    if (!si->floating) memset(fr[n].v, 0, sizeof fr[n].v);
+    for (int i = 0; i < n; i++) {
+        const mppi_body_t *b = &m->bodies[i];
+        memcpy(fr[i].R, k.Rw[i], sizeof fr[i].R);
+        memcpy(fr[i].p, k.pw[i], sizeof fr[i].p);
+        real ax[3] = {(real)b->axis[0], (real)b->axis[1], (real)b->axis[2]}, aw[3], t[3], Sw[6];
+        m3_vec(fr[i].R, ax, aw);
+        if (b->jtype == MPPI_JOINT_REVOLUTE) { cross3(fr[i].p, aw, t); for (int j = 0; j < 3; j++) { Sw[j] = aw[j]; Sw[3 + j] = t[j]; } }
+        else for (int j = 0; j < 3; j++) { Sw[j] = 0; Sw[3 + j] = aw[j]; }
+        const real *vp = b->parent < 0 ? fr[n].v : fr[b->parent].v;
+        for (int j = 0; j < 6; j++) fr[i].v[j] = vp[j] + Sw[j] * qd[i];
+    }
+    for (int f = 0; f < si->n_free; f++) root_frame(root + 13 * si->free_actor[f], &fr[n + 1 + f]);
+}
+
+/* One simulator step of a contact scene; root [A][13] (robot base + free actors) is updated in place.
+ * cf (optional) receives the net contact force per rigid body of the last substep. */
+void orc_scene_step(const mppi_model_t *m, real *root, real *q, real *qd, const real *target, real *cf_out) {
+    scene_info_t si;
+    scene_info(m, &si);
+    int n = m->n_bodies;
+    real h = (real)(m->dt / m->substeps), kd = (real)m->drive_kd;
+    frame_t *fr = (frame_t *)calloc(NFMAX, sizeof(frame_t));
+    real *cf = (real *)calloc(3 * (size_t)m->n_rb + 3, sizeof(real));
+    for (int s = 0; s < m->substeps; s++) {
+        scene_frames(m, &si, root, q, qd, fr);
+        scene_contacts(m, &si, fr, root, cf);
+        real ff[NBMAX], vs[NBMAX], tau[NBMAX], kdh[NBMAX], qdd[NBMAX], abase[6];
+        for (int i = 0; i < n; i++) {
+            ff[i] = m->drive_mode == MPPI_DRIVE_EFFORT ? target[i] : 0;
+            vs[i] = m->drive_mode == MPPI_DRIVE_VELOCITY ? target[i] : 0;
+            tau[i] = ff[i] + kd * (vs[i] - qd[i]);
+            kdh[i] = kd * h;
+        }
+        scene_aba(m, &si, fr, qd, tau, kdh, qdd, abase);
+        int any = 0;
+        for (int i = 0; i < n; i++) {
+            real lim = (real)m->bodies[i].effort;
+            real tt = ff[i] + kd * (vs[i] - qd[i] - h * qdd[i]);
+            if (lim > 0 && (real)fabs((double)tt) > lim) { any = 1; tau[i] = tt > 0 ? lim : -lim; kdh[i] = 0; }
+        }
+        if (any) scene_aba(m, &si, fr, qd, tau, kdh, qdd, abase);
+        for (int i = 0; i < n; i++) {
+            const mppi_body_t *b = &m->bodies[i];
+            real vmax = (real)b->velocity;
+            qd[i] += h * qdd[i];
+            if (vmax > 0) { if (qd[i] > vmax) qd[i] = vmax; if (qd[i] < -vmax) qd[i] = -vmax; }
+            q[i] += h * qd[i];
+            if (b->limited) {
+                if (q[i] < (real)b->lower) { q[i] = (real)b->lower; if (qd[i] < 0) qd[i] = 0; }
+                if (q[i] > (real)b->upper) { q[i] = (real)b->upper; if (qd[i] > 0) qd[i] = 0; }
+            }
+        }
+        if (si.floating) root_integrate(root + 13 * m->robot_actor, abase, h);
+        for (int f = 0; f < si.n_free; f++) {
+            int a = si.free_actor[f];
+            const mppi_actor_t *A = &m->actors[a];
+            const frame_t *F = &fr[n + 1 + f];
+            double Io6[6] = {0, 0, 0, 0, 0, 0}, h0[3] = {0, 0, 0};
+            if (A->type == MPPI_ACTOR_BOX) {
+                double x = A->size[0], y = A->size[1], z = A->size[2];
+                Io6[0] = A->mass / 12 * (y * y + z * z); Io6[3] = A->mass / 12 * (x * x + z * z); Io6[5] = A->mass / 12 * (x * x + y * y);
+            } else Io6[0] = Io6[3] = Io6[5] = 0.4 * A->mass * A->size[0] * A->size[0];
+            real I6[36], hw[3], Iv[6], pA6[6], Cv[6], t3[3], g[3] = {0, 0, 0};
+            if (A->gravity) for (int j = 0; j < 3; j++) g[j] = (real)m->gravity[j];
+            world_inertia(F->R, F->p, (real)A->mass, h0, Io6, I6, hw);
+            m6_vec(I6, F->v, Iv);
+            crf(F->v, Iv, pA6);
+            m6_vec(F->C, F->v, Cv);
+            cross3(hw, g, t3);
+            real b6[6];
+            for (int j = 0; j < 3; j++) { b6[j] = -(pA6[j] + Cv[j] - F->f[j] - t3[j]); b6[3 + j] = -(pA6[3 + j] + Cv[3 + j] - F->f[3 + j] - (real)A->mass * g[j]); }
+            for (int j = 0; j < 36; j++) I6[j] += h * F->C[j];
+            solve6(I6, b6);
+            root_integrate(root + 13 * a, b6, h);
+        }
+    }
+    if (cf_out) memcpy(cf_out, cf, sizeof(real) * 3 * m->n_rb);
+    free(fr); free(cf);
+}
+
 /* ------------------------------------------------------------------ stage costs */
 static real clamp1(real x) { return x > 1 ? 1 : (x < -1 ? -1 : x); }
 
-real orc_cost(const mppi_model_t *m, const mppi_cost_t *c, const real *root, const real *q, const real *qd, const real *rb) {
+real orc_cost(const mppi_model_t *m, const mppi_cost_t *c, const real *root, const real *q, const real *qd, const real *rb, const real *cf) {
     (void)m; (void)qd;
     switch (c->kind) {
     case MPPI_COST_POINT_REACH: {
@@ -386,6 +810,23 @@ real orc_cost(const mppi_model_t *m, const mppi_cost_t *c, const real *root, con
         real a1 = (real)asin((double)clamp1(-M20));
         real ori = (real)sqrt((double)(a0 * a0 + a1 * a1));
         return (real)c->w[0] * dist + (real)c->w[1] * ori;
+    }
+    case MPPI_COST_BOXER_PUSH: {
+        /* examples/boxer_push/planner.py:26-67.  link[0] = ee_link, actor[0] = block, actor[1] = goal,
+         * link[1], link[2] = rigid bodies of paper_obst1 / paper_obst2; w = {robot_to_block, block_to_goal,
+         * block_to_goal_ort, push_align, velocity, collision, goal_yaw} */
+        const real *r = rb + 13 * c->link[0];
+        const real *blk = root + 13 * c->actor[0], *goal = root + 13 * c->actor[1];
+        real rbx = r[0] - blk[0], rby = r[1] - blk[1], bgx = goal[0] - blk[0], bgy = goal[1] - blk[1];
+        real d_rb = (real)sqrt((double)(rbx * rbx + rby * rby)), d_bg = (real)sqrt((double)(bgx * bgx + bgy * bgy));
+        const real *qq = blk + 3; /* quaternion_to_yaw, mppiisaac/utils/conversions.py:4-11 */
+        real yaw = (real)atan2((double)(2 * (qq[3] * qq[2] + qq[0] * qq[1])), (double)(qq[3] * qq[3] + qq[0] * qq[0] - qq[1] * qq[1] - qq[2] * qq[2]));
+        real ort = (real)fabs((double)(yaw - (real)c->w[6]));
+        real align = (rbx * bgx + rby * bgy) / (d_rb * d_bg) + 1;
+        real coll = 0;
+        if (cf) coll = (real)(fabs((double)cf[3 * c->link[1]]) + fabs((double)cf[3 * c->link[1] + 1]) + fabs((double)cf[3 * c->link[2]]) + fabs((double)cf[3 * c->link[2] + 1]));
+        real vel = (real)sqrt((double)(blk[7] * blk[7] + blk[8] * blk[8]));
+        return (real)c->w[0] * d_rb + (real)c->w[1] * d_bg + (real)c->w[2] * ort + (real)c->w[3] * align + (real)c->w[4] * vel + (real)c->w[5] * coll;
     }
     default:
         return 0;
@@ -468,6 +909,10 @@ static real rollout_one(const mppi_model_t *m, const mppi_config_t *cfg, const m
     int g = cfg->k_offset + k;
     real q[NBMAX], qd[NBMAX], target[NBMAX], u[MPPI_MAX_NU];
     real *rb = (real *)malloc(sizeof(real) * 13 * m->n_rb);
+    real *cf = (real *)calloc(3 * (size_t)m->n_rb + 3, sizeof(real));
+    real root[13 * MPPI_MAX_ACTORS]; /* per-sample root rows (robot base and free actors move in contact scenes) */
+    memcpy(root, root0, sizeof(real) * 13 * m->n_actors);
+    const int scene = orc_is_scene(m);
     for (int i = 0; i < n; i++) { q[i] = dof0[2 * i]; qd[i] = dof0[2 * i + 1]; }
     real S = 0, ctrl = 0, disc = 1;
     for (int t = 0; t < H; t++) {
@@ -484,9 +929,10 @@ static real rollout_one(const mppi_model_t *m, const mppi_config_t *cfg, const m
             ctrl += (real)cfg->lambda_ * (cfg->noise_abs_cost ? (real)fabs((double)term) : term);
         }
         orc_cmd_map(m, u, target);
-        orc_step(m, root0, q, qd, target);
-        orc_rigid_body_state(m, root0, q, qd, rb, NULL);
-        real ct = orc_cost(m, cost, root0, q, qd, rb);
+        if (scene) orc_scene_step(m, root, q, qd, target, cf);
+        else orc_step(m, root, q, qd, target);
+        orc_rigid_body_state(m, root, q, qd, rb, NULL);
+        real ct = orc_cost(m, cost, root, q, qd, rb, cf);
         S += disc * ct;
         disc *= (real)cfg->rollout_var_discount;
         if (viz && cfg->want_rollouts) {
@@ -494,7 +940,7 @@ static real rollout_one(const mppi_model_t *m, const mppi_config_t *cfg, const m
             for (int j = 0; j < 3; j++) viz[((size_t)t * K + k) * 3 + j] = o[j];
         }
     }
-    free(rb);
+    free(rb); free(cf);
     return S + ctrl;
 }
 

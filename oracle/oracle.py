@@ -67,9 +67,21 @@ class Oracle:
         self.lib.orc_rigid_body_state(C.byref(model), self.p(root), self.p(q), self.p(qd), self.p(rb), self.p(cf))
         return rb, cf
 
-    def cost(self, model, cost, root, q, qd, rb):
+    def cost(self, model, cost, root, q, qd, rb, cf=None):
         root, q, qd, rb = map(self.arr, (root, q, qd, rb))
-        return float(self.lib.orc_cost(C.byref(model), C.byref(cost), self.p(root), self.p(q), self.p(qd), self.p(rb)))
+        cf = self.arr(cf) if cf is not None else None
+        return float(self.lib.orc_cost(C.byref(model), C.byref(cost), self.p(root), self.p(q), self.p(qd), self.p(rb), self.p(cf)))
+
+    def is_scene(self, model):
+        return bool(self.lib.orc_is_scene(C.byref(model)))
+
+    def scene_step(self, model, root, q, qd, target):
+        """one dt step of a contact scene -> (root [A,13], q, qd, cf [n_rb,3])"""
+        root, q, qd = self.arr(root).copy(), self.arr(q).copy(), self.arr(qd).copy()
+        target = self.arr(target)
+        cf = np.zeros((model.n_rb, 3), self.dtype)
+        self.lib.orc_scene_step(C.byref(model), self.p(root), self.p(q), self.p(qd), self.p(target), self.p(cf))
+        return root, q, qd, cf
 
     def sample(self, cfg, index_base=0):
         eps = np.zeros((cfg.horizon, cfg.nu, cfg.num_samples), self.dtype)

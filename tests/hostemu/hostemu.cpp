@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../mppi-isaac_amd/csrc/mppi_pack.hpp"
+#include "../../mppi-isaac_amd/csrc/mppi_scene.hpp"
 
 using namespace mppi;
 
@@ -21,6 +22,11 @@ int emu_rollout(const mppi_model_t *model, const mppi_config_t *cfg, const mppi_
     bool ok = dispatch_topology(m.nb, parents, [&](auto topo) {
         using T = decltype(topo);
         std::vector<float> v(viz ? (size_t)c.H * 3 * c.K : 0);
+        if (is_scene(m)) {
+            std::vector<float> lmem(SceneLayout<T>::floats(m.n_rb));
+            LMem L{lmem.data(), 1};
+            for (int s = 0; s < c.K; s++) S[s] = rollout_scene<T>(m, c, k, dof0, root0, U, eps, prior, du, viz ? v.data() : nullptr, s, L);
+        } else
         for (int s = 0; s < c.K; s++) S[s] = rollout_sample<T>(m, c, k, dof0, root0, U, eps, prior, du, viz ? v.data() : nullptr, s);
         if (viz)  // device layout [H][3][K] -> reference layout [H][K][3]
             for (int t = 0; t < c.H; t++)
@@ -53,6 +59,30 @@ int emu_rigid_body_state(const mppi_model_t *model, const float *root, const flo
     bool ok = dispatch_topology(m.nb, parents, [&](auto topo) {
         using T = decltype(topo);
         rigid_body_state<T>(m, root, q, qd, rb, cf);
+    });
+    return ok ? 0 : -3;
+}
+
+// one dt step of a contact scene: dof [2n] and root [A][13] are updated in place; rb/cf = reference-layout rows
+int emu_scene_step(const mppi_model_t *model, float *dof, float *root, const float *u, float *rb, float *cf) {
+    DevModel m; std::string err;
+    if (!pack_model(*model, m, err)) return -1;
+    int parents[MPPI_MAX_BODIES];
+    for (int i = 0; i < m.nb; i++) parents[i] = m.b[i].parent;
+    bool ok = dispatch_topology(m.nb, parents, [&](auto topo) {
+        using T = decltype(topo);
+        std::vector<float> lmem(SceneLayout<T>::floats(m.n_rb));
+        LMem L{lmem.data(), 1};
+        SceneState<T> s;
+        scene_init<T>(m, dof, root, s);
+        float target[MPPI_MAX_BODIES + 1], uu[kMaxNu] = {0};
+        for (int c = 0; c < m.nu; c++) uu[c] = u[c];
+        cmd_map<T>(m, uu, target);
+        step_scene<T>(m, root, s, target, L);
+        for (int i = 0; i < T::NB; i++) { dof[2 * i] = s.q[i]; dof[2 * i + 1] = s.qd[i]; }
+        std::vector<float> rootn(13 * m.n_actors);
+        scene_materialise<T>(m, root, s, lmem.data() + SceneLayout<T>::kCf, rootn.data(), rb, cf);
+        for (int j = 0; j < 13 * m.n_actors; j++) root[j] = rootn[j];
     });
     return ok ? 0 : -3;
 }

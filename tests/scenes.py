@@ -54,3 +54,24 @@ def point_reach(K=64, H=10, goal=(4.5, 0.2), **mppi_over):
     cost.actor[0] = scene.actor_index("goal")
     cost.w[0] = 2.0
     return scene, scene.to_c(), cfg, cost, dof, root
+
+
+def boxer_push(K=64, H=12, **mppi_over):
+    """BASELINE config 4: boxer + block + two obstacles + goal (reference examples/boxer_push/config_boxer_push.yaml:9-10),
+    conf/mppi/boxer_push.yaml with K/H overridden; size/mass/friction noise off."""
+    scene = build_scene(["boxer", "block", "paper_obst1", "paper_obst2", "goal"], [[0.0, 2.5, 0.05]])
+    ex = load_config({"defaults": [{"mppi": "boxer_push"}, {"isaacgym": "normal"}]})
+    ex.mppi.num_samples, ex.mppi.horizon = K, H
+    for k, v in mppi_over.items():
+        setattr(ex.mppi, k, v)
+    cfg = make_config(ex.mppi, viz_link=scene.viz_link_index())
+    dof, root = scene.initial_state()
+    cost = capi.Cost()
+    cost.kind = capi.COST_BOXER_PUSH
+    cost.link[0] = scene.rigid_body_index("boxer", "ee_link")
+    cost.link[1] = scene.rigid_body_index("paper_obst1", "box")
+    cost.link[2] = scene.rigid_body_index("paper_obst2", "box")
+    cost.actor[0], cost.actor[1] = scene.actor_index("block"), scene.actor_index("goal")
+    for i, w in enumerate((0.1, 2.0, 3.0, 0.6, 0.0, 100.0, 0.0)):
+        cost.w[i] = w
+    return scene, scene.to_c(), cfg, cost, dof, root

@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from mppiisaac.backend import capi
-from scenes import panda_reach, point_reach
+from scenes import boxer_push, panda_reach, point_reach
 
 pytestmark = pytest.mark.gpu
 
@@ -245,12 +245,87 @@ def test_error_paths(lib):
     assert lib.mppi_rollout(c.ctx) == -4 and b"no fused cost" in lib.mppi_last_error()      # MPPI_ESTATE
     assert lib.mppi_set_cost(c.ctx, C.byref(bad)) == -3                                       # MPPI_EUNSUPPORTED
     c.close()
-    from scenes import build_scene
-    boxer = build_scene(["boxer", "block", "goal"]).to_c()
-    from mppiisaac.planner.mppi import make_config
-    from mppiisaac.utils.config_store import load_config
-    bc = make_config(load_config({"defaults": [{"mppi": "boxer_push"}]}).mppi)
-    assert lib.mppi_create(C.byref(boxer), C.byref(bc), 0, C.byref(ctx)) == -1
-    assert b"floating-base" in lib.mppi_last_error()
+    m.drive_mode = capi.DRIVE_POSITION
+    assert lib.mppi_create(C.byref(m), C.byref(cfg), 0, C.byref(ctx)) == -1
+    assert b"position" in lib.mppi_last_error()
+    m.drive_mode = capi.DRIVE_VELOCITY
     cfg.lambda_ = 0.0
     assert lib.mppi_create(C.byref(m), C.byref(cfg), 0, C.byref(ctx)) == -1
+
+
+def test_boxer_push_rollout_matches_oracle(lib, oracle64):
+    """BASELINE config 4 scene (floating diff-drive base + free block + obstacles + ground, penalty contact).
+    Open-floor rollouts are smooth -> strict parity; the full-interaction case is checked through
+    properties, because contact switching makes fp32/fp64 trajectories diverge chaotically."""
+    K, H = 256, 12
+    scene, m, cfg, cost, dof, root = boxer_push(K=K, H=H)
+    root[0, 2] = 0.019
+    root[scene.actor_index("block"), 0:3] = [2.5, 1.8, 0.0923]
+    c = Ctx(m, cfg, cost)
+    c.call("mppi_sample", C.c_uint32(0))
+    eps = c.get("mppi_get_noise", (H, 2, K))
+    np.testing.assert_allclose(eps, oracle64.sample(cfg), atol=2e-6)
+    ext = torch.tensor(eps * 0.3, device="cuda").contiguous()       # gentle commands: stay on the open floor
+    c.call("mppi_set_noise_dev", C.c_void_p(ext.data_ptr()))
+    c.set_state(dof, root)
+    c.call("mppi_rollout")
+    S = c.get("mppi_get_costs", (K,))
+    So, duo, vizo = oracle64.rollout(m, cfg, cost, dof, root, np.zeros((H, 2)), eps * 0.3, want_viz=True)
+    np.testing.assert_allclose(S, So, rtol=1e-3)
+    np.testing.assert_allclose(c.get("mppi_get_rollouts", (H, K, 3)), vizo, atol=2e-3)
+    a = np.zeros(2, np.float32)
+    c.call("mppi_reduce", None); c.call("mppi_update", None, 1)
+    Uo, ao, _ = oracle64.update(cfg, oracle64.record(cfg, So, duo), np.zeros((H, 2)))
+    np.testing.assert_allclose(c.get("mppi_get_action", (2,)), ao, atol=5e-3)
+    # full noise, block in front of the robot: properties
+    root[scene.actor_index("block"), 0:3] = [0.0, 1.9, 0.0923]
+    c.call("mppi_set_noise_dev", None)
+    c.set_state(dof, root); c.set_U(np.zeros((H, 2)))
+    c.call("mppi_rollout")
+    S = c.get("mppi_get_costs", (K,))
+    assert np.isfinite(S).all()
+    So, _, _ = oracle64.rollout(m, cfg, cost, dof, root, np.zeros((H, 2)), eps)
+    # same cost distribution: medians within 2 %, and at least 80 % of the samples agree to 1 %
+    assert np.median(S) == pytest.approx(np.median(So), rel=2e-2)
+    assert (np.abs(S - So) <= 1e-2 * np.abs(So)).mean() > 0.8
+    c.close()
+
+
+def test_boxer_generic_mode_and_world(lib, oracle64):
+    """Objective callback path and the K=1 world simulator on the contact scene: reference-layout tensors
+    (root states of the moving base and block, net contact forces) against the oracle."""
+    from mppiisaac.objectives import BoxerPushObjective
+    from mppiisaac.planner.isaacgym_wrapper import IsaacGymWrapper
+    from mppiisaac.planner.mppi_isaac import MPPIisaacPlanner
+    from mppiisaac.utils.config_store import load_config
+    actors = ["boxer", "block", "paper_obst1", "paper_obst2", "goal"]
+    cfg = load_config({"defaults": [{"mppi": "boxer_push"}, {"isaacgym": "normal"}], "actors": actors,
+                       "initial_actor_positions": [[0.0, 2.5, 0.05]], "nx": 4},
+                      overrides={"mppi.num_samples": 128, "mppi.horizon": 12, "mppi.filter_u": False})
+    world = IsaacGymWrapper(cfg.isaacgym, actors=actors, init_positions=cfg.initial_actor_positions, num_envs=1)
+    m = world._c_model
+    dof, root = world.scene.initial_state()
+    q, qd, ro = dof[0::2].astype(np.float64), dof[1::2].astype(np.float64), root.astype(np.float64)
+    u = torch.tensor([0.4, 0.5])
+    for _ in range(15):
+        world.apply_robot_cmd(u)
+        world.step()
+        ro, q, qd, cfo = oracle64.scene_step(m, ro, q, qd, oracle64.cmd_map(m, u.numpy()))
+    np.testing.assert_allclose(world._root_state[0].cpu().numpy(), ro, atol=2e-3)
+    np.testing.assert_allclose(world._net_contact_force[0].cpu().numpy(), cfo, rtol=2e-2, atol=2.0)
+    rbo, _ = oracle64.rigid_body_state(m, ro, q, qd)
+    np.testing.assert_allclose(world._rigid_body_state[0].cpu().numpy()[:, 0:7], rbo[:, 0:7], atol=2e-3)
+    assert world.get_actor_contact_forces_by_name("paper_obst1", "box").shape == (1, 3)
+
+    class Generic(BoxerPushObjective):
+        fused_spec = None
+    fused = MPPIisaacPlanner(cfg, BoxerPushObjective(cfg))
+    generic = MPPIisaacPlanner(cfg, Generic(cfg))
+    # the world state (settled robot) goes in through the reference's RPC entry (bytes of dof/root tensors)
+    from mppiisaac.utils.transport import bytes_to_torch, torch_to_bytes
+    db, rbts = torch_to_bytes(world._dof_state.cpu()), torch_to_bytes(world._root_state.cpu())
+    af = bytes_to_torch(fused.compute_action_tensor(db, rbts)).numpy()
+    ag = bytes_to_torch(generic.compute_action_tensor(db, rbts)).numpy()
+    Sf, Sg = fused.mppi.get_costs().numpy(), generic.mppi.get_costs().numpy()
+    assert (np.abs(Sf - Sg) <= 2e-3 * np.abs(Sf)).mean() > 0.9     # same kernels, same arithmetic; contact chaos aside
+    np.testing.assert_allclose(ag, af, atol=5e-2)

@@ -1,0 +1,154 @@
+"""Contact scenes (floating base, free bodies, penalty contact): physics known-answer tests of the oracle,
+and the device arithmetic (host build, tests/hostemu) against the oracle.  There is nothing in the
+reference to pin these against (PhysX is absent); the numbers below are physics, not fixtures."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from scenes import boxer_push, build_scene
+
+f32 = lambda a: np.ascontiguousarray(a, np.float32)
+fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def yaw_of(q):
+    return np.arctan2(2 * (q[3] * q[2] + q[0] * q[1]), q[3] ** 2 + q[0] ** 2 - q[1] ** 2 - q[2] ** 2)
+
+
+def settle(o, m, root, q, qd, steps=20, u=(0.0, 0.0)):
+    cf = None
+    for _ in range(steps):
+        root, q, qd, cf = o.scene_step(m, root, q, qd, o.cmd_map(m, u))
+    return root, q, qd, cf
+
+
+@pytest.fixture(scope="module")
+def open_floor():
+    scene = build_scene(["boxer", "block", "goal"], [[0.0, 2.5, 0.05]])
+    dof, root = scene.initial_state()
+    return scene, scene.to_c(), dof[0::2].astype(float), dof[1::2].astype(float), root.astype(float)
+
+
+def test_free_fall_without_contacts(oracle64, open_floor):
+    scene, m, q, qd, root = open_floor
+    m2 = scene.to_c()
+    m2.n_pairs = 0
+    r, _, _, _ = oracle64.scene_step(m2, root, q, qd, [0, 0])
+    # two substeps of h = 0.025 under g = 9.8: v = -0.49, z drops by h^2 g (1 + 2)
+    assert r[0, 9] == pytest.approx(-0.49, abs=1e-9) and r[1, 9] == pytest.approx(-0.49, abs=1e-9)
+    assert r[0, 2] == pytest.approx(0.05 - 9.8 * 0.025 ** 2 * 3, abs=1e-9)
+    assert np.abs(r[0, 10:13]).max() < 1e-9  # no spurious rotation
+
+
+def test_resting_contact_carries_the_weight(oracle64, open_floor):
+    scene, m, q, qd, root = open_floor
+    root, q, qd, cf = settle(oracle64, m, root, q, qd, 40)
+    assert np.abs(root[:, 7:13]).max() < 1e-3                      # everything at rest
+    total = 254.0 + 20.0                                           # base cluster (mass override) + two wheels
+    robot_rows = [scene.rigid_body_index("boxer", n) for n in scene.link_names]
+    assert cf[robot_rows, 2].sum() == pytest.approx(total * 9.8, rel=1e-3)
+    assert cf[scene.rigid_body_index("block", "box"), 2] == pytest.approx(1.0 * 9.8, rel=1e-3)
+    # wheels (r = 0.08 at z = 0.058 in the chassis) carry the robot a few mm into the penalty layer
+    assert 0.015 < root[0, 2] < 0.022
+    assert 0.09 < root[1, 2] < 0.1                                 # block half height 0.1 minus the penalty sink
+
+
+def test_differential_drive_kinematics(oracle64, open_floor):
+    """v = r * mean(wheel speed), yaw rate = r (w_R - w_L) / L - the inverse of the reference's _ik
+    (isaacgym_wrapper.py:510-522) must come out of wheel-ground traction."""
+    scene, m, q, qd, root = open_floor
+    root, q, qd, _ = settle(oracle64, m, root, q, qd, 20)
+    r1, q1, qd1, _ = settle(oracle64, m, root, q, qd, 40, u=(0.5, 0.0))
+    heading = np.array([np.sin(yaw_of(r1[0, 3:7])), -np.cos(yaw_of(r1[0, 3:7]))])   # forward is -y at yaw 0
+    assert r1[0, 7:9] @ heading == pytest.approx(0.5, rel=2e-2)
+    np.testing.assert_allclose(qd1, [6.25, 6.25], rtol=1e-2)
+    r2, q2, qd2, _ = settle(oracle64, m, root, q, qd, 40, u=(0.0, 1.0))
+    assert r2[0, 12] == pytest.approx(1.0, rel=2e-2)
+    assert yaw_of(r2[0, 3:7]) == pytest.approx(2.0, rel=3e-2)
+    np.testing.assert_allclose(np.abs(qd2), [3.0875, 3.0875], rtol=2e-2)
+
+
+def test_pushing_moves_the_block_and_reports_contact(oracle64):
+    scene, m, cfg, cost, dof, root = boxer_push()
+    root = root.astype(float)
+    root[scene.actor_index("block"), 0:3] = [0.0, 1.9, 0.1]          # straight ahead of the robot (heading -y)
+    q, qd = dof[0::2].astype(float), dof[1::2].astype(float)
+    root, q, qd, _ = settle(oracle64, m, root, q, qd, 10)
+    y0 = root[1, 1]
+    root, q, qd, cf = settle(oracle64, m, root, q, qd, 20, u=(0.5, 0.0))
+    assert root[1, 1] < y0 - 0.15                                     # the block was pushed along -y
+    assert abs(root[1, 0]) < 0.05
+    # Newton's third law in the reported forces: chassis and block see opposite pushes
+    fb, fc = cf[scene.rigid_body_index("block", "box")], cf[scene.rigid_body_index("boxer", "chassis_link")]
+    assert fb[1] < 0 < fc[1]
+    # driving on pushes the block into paper_obst2 (y in [0.6, 1.4]): the obstacle must then report a contact force
+    root, q, qd, cf = settle(oracle64, m, root, q, qd, 30, u=(0.5, 0.0))
+    assert np.abs(cf[scene.rigid_body_index("paper_obst2", "box"), 0:2]).sum() > 1.0
+
+
+def test_device_arithmetic_matches_oracle_stepwise(hostemu, oracle64):
+    """fp32 world-frame structured code (LDS-indexed frames, Cholesky) vs fp64 dense oracle, re-synchronised
+    every step (contact switching makes long open-loop comparisons chaotic)."""
+    scene, m, cfg, cost, dof, root = boxer_push()
+    root = root.astype(float)
+    root[scene.actor_index("block"), 0:3] = [0.05, 1.9, 0.1]
+    q, qd = dof[0::2].astype(float), dof[1::2].astype(float)
+    rb = np.zeros((m.n_rb, 13), np.float32)
+    cf = np.zeros((m.n_rb, 3), np.float32)
+    seq = [((0.0, 0.0), 8), ((0.6, 0.0), 20), ((0.4, 0.9), 12), ((-0.3, -1.5), 10)]
+    worst = 0.0
+    for u, n in seq:
+        for _ in range(n):
+            de = np.zeros(2 * scene.n_dof, np.float32)
+            de[0::2], de[1::2] = q, qd
+            re = f32(root).copy()
+            assert hostemu.emu_scene_step(C.byref(m), fp(de), fp(re.reshape(-1)), fp(f32(u)), fp(rb), fp(cf)) == 0
+            root, q, qd, cfo = oracle64.scene_step(m, root, q, qd, oracle64.cmd_map(m, u))
+            np.testing.assert_allclose(re[:, 0:7], root[:, 0:7], atol=2e-5)       # poses
+            np.testing.assert_allclose(re[:, 7:13], root[:, 7:13], atol=2e-3)     # velocities
+            np.testing.assert_allclose(de[1::2], qd, atol=2e-3)
+            scale = max(1.0, np.abs(cfo).max())
+            worst = max(worst, np.abs(cf - cfo).max() / scale)
+            rbo, _ = oracle64.rigid_body_state(m, root, q, qd)
+            np.testing.assert_allclose(rb[:, 0:7], rbo[:, 0:7], atol=1e-4)        # link poses incl. ee_link on the base
+    assert worst < 5e-3  # net contact forces, relative to the largest force in the scene
+
+
+def test_boxer_push_cost_matches_reference_expression(oracle64):
+    """oracle BOXER_PUSH cost == the reference Objective's torch expression (examples/boxer_push/planner.py:26-67)."""
+    import torch
+    from mppiisaac.objectives import BoxerPushObjective
+    scene, m, cfg, cost, dof, root = boxer_push()
+    root = root.astype(float)
+    root[scene.actor_index("block"), 0:3] = [0.05, 1.9, 0.1]
+    q, qd = dof[0::2].astype(float), dof[1::2].astype(float)
+    root, q, qd, cf = settle(oracle64, m, root, q, qd, 25, u=(0.6, 0.3))
+    rb, _ = oracle64.rigid_body_state(m, root, q, qd)
+
+    class FakeSim:  # the getters an Objective uses, on one env
+        device = "cpu"
+        def get_actor_link_by_name(self, actor_name, link_name): return torch.tensor(rb[scene.rigid_body_index(actor_name, link_name)])[None]
+        def get_actor_position_by_name(self, n): return torch.tensor(root[scene.actor_index(n), 0:3])[None]
+        def get_actor_velocity_by_name(self, n): return torch.tensor(root[scene.actor_index(n), 7:10])[None]
+        def get_actor_orientation_by_name(self, n): return torch.tensor(root[scene.actor_index(n), 3:7])[None]
+        def get_actor_contact_forces_by_name(self, actor_name, link_name): return torch.tensor(cf[scene.rigid_body_index(actor_name, link_name)])[None]
+    want = float(BoxerPushObjective().compute_cost(FakeSim()))
+    assert oracle64.cost(m, cost, root, q, qd, rb, cf) == pytest.approx(want, rel=1e-10)
+
+
+def test_rollout_costs_match_oracle_on_open_floor(hostemu, oracle64):
+    """whole-horizon rollouts without block/obstacle interaction are smooth: strict cost parity."""
+    scene, m, cfg, cost, dof, root = boxer_push(K=32, H=12)
+    root[scene.actor_index("block"), 0:3] = [2.5, 1.8, 0.0923]
+    root[0, 2] = 0.019                                              # start settled on the wheels
+    eps = oracle64.sample(cfg) * 0.3
+    U = np.zeros((12, 2))
+    S, du, viz = oracle64.rollout(m, cfg, cost, dof, root, U, eps, want_viz=True)
+    Se = np.zeros(32, np.float32)
+    due = np.zeros((12, 2, 32), np.float32)
+    vize = np.zeros((12, 32, 3), np.float32)
+    assert hostemu.emu_rollout(C.byref(m), C.byref(cfg), C.byref(cost), fp(f32(dof)), fp(f32(root)), fp(f32(U)), fp(f32(eps)), None,
+                               fp(Se), fp(due), fp(vize)) == 0
+    np.testing.assert_allclose(Se, S, rtol=5e-4)
+    np.testing.assert_allclose(vize, viz, atol=1e-3)
