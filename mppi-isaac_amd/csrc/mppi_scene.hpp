@@ -600,6 +600,26 @@ MPPI_HD float stage_cost_scene(CModel &m, CCost &c, const float *root, const Sce
         const float vel = sqrtf(bvx * bvx + bvy * bvy);
         return c.w[0] * d_rb + c.w[1] * d_bg + c.w[2] * ort + c.w[3] * align + c.w[4] * vel + c.w[5] * coll;
     }
+    if (c.kind == kCostPandaPick) {
+        // examples/panda_pick/planner.py:24-53: link[0] = panda_ee, link[1] = table rigid body, actor[0] = block,
+        // actor[1] = goal; w = {robot_to_block, block_to_goal, collision, robot_ori}
+        Pose<T> P;
+        P.pb = loadv(s.base);
+        P.Rb = quat_to_R(s.base + 3);
+        forward_kinematics_base<T>(m, s.q, P);
+        M3 R;
+        V3 r;
+        link_pose<T>(m, P, c.link[0], R, r);
+        V3 b = {0.f, 0.f, 0.f};
+        for (int f = 0; f < kMaxFree; f++)
+            if (f < m.n_free && m.fr[f].actor == c.actor[0]) b = loadv(s.fr[f]);
+        const V3 g = loadv(root + 13 * c.actor[1]);
+        const V3 drb = r - b, dbg = b - g;
+        const int ot = Lay::kCf + 3 * c.link[1];
+        const float forces = fabsf(L[ot]) + fabsf(L[ot + 1]) + fabsf(L[ot + 2]);
+        const float a0 = atan2f(R.a[7], -R.a[8]), a1 = asinf(clamp1(R.a[6]));  // see PANDA_REACH
+        return c.w[0] * sqrtf(dot(drb, drb)) + c.w[1] * sqrtf(dot(dbg, dbg)) + c.w[2] * forces + c.w[3] * sqrtf(a0 * a0 + a1 * a1);
+    }
     // fixed-base costs: the robot row of `root` is the (constant) base
     return stage_cost<T>(m, c, root, s.q, s.qd);
 }

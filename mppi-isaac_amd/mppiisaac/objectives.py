@@ -121,3 +121,42 @@ class BoxerPushObjective(object):
             c.w[i] = float(w[k])
         c.w[6] = float(self.goal_yaw)
         return c
+
+
+class PandaPickObjective(object):
+    """reference examples/panda_pick/planner.py:9-53: reach the block, bring it to the goal, stay off the table."""
+
+    def __init__(self, cfg=None, robot="panda", link="panda_ee", block="panda_pick_block", goal="goal", table="table"):
+        self.weights = {"robot_to_block": 40.0, "block_to_goal": 10.0, "collision": 26.0, "robot_ori": 2.0}
+        self.robot, self.link, self.block, self.goal, self.table = robot, link, block, goal, table
+        self.reset()
+
+    def reset(self):
+        self.prev_block_to_goal_dist = 1
+        self.prev_robot_to_block_dist = 1
+
+    def compute_cost(self, sim):
+        r_pos = sim.get_actor_link_by_name(self.robot, self.link)
+        block_pos = sim.get_actor_position_by_name(self.block)
+        goal_pos = sim.get_actor_position_by_name(self.goal)
+        table_forces = sim.get_actor_contact_forces_by_name(self.table, "box")
+        robot_to_block_dist = torch.linalg.norm(r_pos[:, 0:3] - block_pos[:, 0:3], axis=1)
+        block_to_goal_dist = torch.linalg.norm(block_pos[:, 0:3] - goal_pos[:, 0:3], axis=1)
+        robot_rpy = matrix_to_euler_angles(quaternion_to_matrix(r_pos[:, 3:7]), "ZYX")[:, 0:2]
+        robot_rpy_dist = torch.linalg.norm(robot_rpy, axis=1)
+        forces = torch.sum(torch.abs(table_forces[:, 0:3]), axis=1)
+        w = self.weights
+        self.prev_block_to_goal_dist = block_to_goal_dist
+        return (w["robot_to_block"] * robot_to_block_dist + w["block_to_goal"] * block_to_goal_dist
+                + w["collision"] * forces + w["robot_ori"] * robot_rpy_dist)
+
+    def fused_spec(self, sim) -> capi.Cost:
+        c = capi.Cost()
+        c.kind = capi.COST_PANDA_PICK
+        c.link[0] = sim.scene.rigid_body_index(self.robot, self.link)
+        c.link[1] = sim.scene.rigid_body_index(self.table, "box")
+        c.actor[0] = sim.scene.actor_index(self.block)
+        c.actor[1] = sim.scene.actor_index(self.goal)
+        for i, k in enumerate(("robot_to_block", "block_to_goal", "collision", "robot_ori")):
+            c.w[i] = float(self.weights[k])
+        return c

@@ -828,6 +828,22 @@ real orc_cost(const mppi_model_t *m, const mppi_cost_t *c, const real *root, con
         real vel = (real)sqrt((double)(blk[7] * blk[7] + blk[8] * blk[8]));
         return (real)c->w[0] * d_rb + (real)c->w[1] * d_bg + (real)c->w[2] * ort + (real)c->w[3] * align + (real)c->w[4] * vel + (real)c->w[5] * coll;
     }
+    case MPPI_COST_PANDA_PICK: {
+        /* examples/panda_pick/planner.py:24-53.  link[0] = panda_ee, link[1] = table body, actor[0] = block,
+         * actor[1] = goal; w = {robot_to_block, block_to_goal, collision, robot_ori} */
+        const real *ee = rb + 13 * c->link[0];
+        const real *blk = root + 13 * c->actor[0], *goal = root + 13 * c->actor[1];
+        real d1 = 0, d2 = 0;
+        for (int j = 0; j < 3; j++) { d1 += (ee[j] - blk[j]) * (ee[j] - blk[j]); d2 += (blk[j] - goal[j]) * (blk[j] - goal[j]); }
+        real forces = 0;
+        if (cf) for (int j = 0; j < 3; j++) forces += (real)fabs((double)cf[3 * c->link[1] + j]);
+        real r = ee[3], i = ee[4], j = ee[5], kk = ee[6];
+        real two_s = 2 / (r * r + i * i + j * j + kk * kk);
+        real M00 = 1 - two_s * (j * j + kk * kk), M10 = two_s * (i * j + kk * r), M20 = two_s * (i * kk - j * r);
+        real a0 = (real)atan2((double)M10, (double)M00), a1 = (real)asin((double)clamp1(-M20));
+        return (real)c->w[0] * (real)sqrt((double)d1) + (real)c->w[1] * (real)sqrt((double)d2) + (real)c->w[2] * forces
+               + (real)c->w[3] * (real)sqrt((double)(a0 * a0 + a1 * a1));
+    }
     default:
         return 0;
     }

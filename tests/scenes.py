@@ -75,3 +75,23 @@ def boxer_push(K=64, H=12, **mppi_over):
     for i, w in enumerate((0.1, 2.0, 3.0, 0.6, 0.0, 100.0, 0.0)):
         cost.w[i] = w
     return scene, scene.to_c(), cfg, cost, dof, root
+
+
+def panda_pick(K=64, H=12, **mppi_over):
+    """BASELINE config 5 scene: gripper panda + axes + pick block + table + goal (reference
+    examples/panda_pick/panda_pick.yaml:6), conf/mppi/panda_pick.yaml with K/H overridden."""
+    scene = build_scene(["panda_gripper", "xaxis", "yaxis", "panda_pick_block", "table", "goal"], [[0.0, 0.0, 0.0]])
+    ex = load_config({"defaults": [{"mppi": "panda_pick"}, {"isaacgym": "normal"}]})
+    ex.mppi.num_samples, ex.mppi.horizon = K, H
+    for k, v in mppi_over.items():
+        setattr(ex.mppi, k, v)
+    cfg = make_config(ex.mppi, viz_link=scene.viz_link_index())
+    dof, root = scene.initial_state()
+    cost = capi.Cost()
+    cost.kind = capi.COST_PANDA_PICK
+    cost.link[0] = scene.rigid_body_index("panda", "panda_ee")
+    cost.link[1] = scene.rigid_body_index("table", "box")
+    cost.actor[0], cost.actor[1] = scene.actor_index("panda_pick_block"), scene.actor_index("goal")
+    for i, w in enumerate((40.0, 10.0, 26.0, 2.0)):
+        cost.w[i] = w
+    return scene, scene.to_c(), cfg, cost, dof, root

@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from mppiisaac.backend import capi
-from scenes import boxer_push, panda_reach, point_reach
+from scenes import boxer_push, panda_pick, panda_reach, point_reach
 
 pytestmark = pytest.mark.gpu
 
@@ -336,3 +336,22 @@ def test_boxer_generic_mode_and_world(lib, oracle64):
     Sf, Sg = fused.mppi.get_costs().numpy(), generic.mppi.get_costs().numpy()
     assert (np.abs(Sf - Sg) <= 2e-3 * np.abs(Sf)).mean() > 0.9     # same kernels, same arithmetic; contact chaos aside
     np.testing.assert_allclose(ag, af, atol=5e-2)
+
+
+def test_panda_pick_rollout_matches_oracle(lib, oracle64):
+    """BASELINE config 5 scene on one GPU shard (K=512 of the 8192-per-GPU workload), H=30."""
+    K, H = 512, 30
+    scene, m, cfg, cost, dof, root = panda_pick(K=K, H=H)
+    c = Ctx(m, cfg, cost)
+    c.call("mppi_sample", C.c_uint32(0))
+    eps = c.get("mppi_get_noise", (H, 9, K))
+    c.set_state(dof, root)
+    a = np.zeros(9, np.float32)
+    c.call("mppi_command", capi.fptr(a))
+    S = c.get("mppi_get_costs", (K,))
+    So, duo, _ = oracle64.rollout(m, cfg, cost, dof, root, np.zeros((H, 9)), eps)
+    assert (np.abs(S - So) <= 1e-3 * np.abs(So)).mean() > 0.95     # contact switching can split a few samples
+    assert np.median(np.abs(S - So) / np.abs(So)) < 1e-5
+    Uo, ao, _ = oracle64.update(cfg, oracle64.record(cfg, So, duo), np.zeros((H, 9)))
+    np.testing.assert_allclose(a, ao, atol=2e-3)
+    c.close()

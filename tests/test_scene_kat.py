@@ -6,7 +6,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from scenes import boxer_push, build_scene
+from scenes import boxer_push, build_scene, panda_pick
 
 f32 = lambda a: np.ascontiguousarray(a, np.float32)
 fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
@@ -152,3 +152,25 @@ def test_rollout_costs_match_oracle_on_open_floor(hostemu, oracle64):
                                fp(Se), fp(due), fp(vize)) == 0
     np.testing.assert_allclose(Se, S, rtol=5e-4)
     np.testing.assert_allclose(vize, viz, atol=1e-3)
+
+
+def test_panda_pick_scene(hostemu, oracle64):
+    """BASELINE config 5 scene: fixed-base gripper arm, 1-gram block on a static table (implicit contact),
+    goal marker; rollouts through the device arithmetic match the oracle."""
+    scene, m, cfg, cost, dof, root = panda_pick(K=32, H=12)
+    assert scene.nu == 9 and m.n_pairs == len(scene.pairs) and oracle64.is_scene(m)
+    q, qd, ro = dof[0::2].astype(float), dof[1::2].astype(float), root.astype(float)
+    for _ in range(30):
+        ro, q, qd, cf = oracle64.scene_step(m, ro, q, qd, np.zeros(9))
+    blk, tab = scene.actor_index("panda_pick_block"), scene.rigid_body_index("table", "box")
+    assert 0.155 < ro[blk, 2] < 0.16 and np.abs(ro[blk, 7:13]).max() < 1e-6      # resting on the table top (z = 0.14 + 0.02)
+    assert cf[tab, 2] == pytest.approx(-0.001 * 9.8, rel=1e-3)                     # the table carries the block's weight
+    np.testing.assert_allclose(q, dof[0::2], atol=1e-6)                            # gravity is off for the arm: it holds its pose
+    eps = oracle64.sample(cfg)
+    U = np.zeros((12, 9))
+    S, du, _ = oracle64.rollout(m, cfg, cost, dof, root, U, eps)
+    Se = np.zeros(32, np.float32)
+    due = np.zeros((12, 9, 32), np.float32)
+    assert hostemu.emu_rollout(C.byref(m), C.byref(cfg), C.byref(cost), fp(f32(dof)), fp(f32(root)), fp(f32(U)), fp(f32(eps)), None,
+                               fp(Se), fp(due), None) == 0
+    np.testing.assert_allclose(Se, S, rtol=1e-4)
