@@ -23,20 +23,34 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "mppi-isaac_amd"))
 sys.path.insert(0, ROOT)
 
-K_PER_GPU, HORIZON = 4096, 20
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
-Q0 = [0.0, -0.94, 0.0, -2.8, 0.0, 1.8675, 0.0]  # conf/actors/panda_stick.yaml init_joint_pose
-GOAL = [0.5, -0.4, 0.3]                          # reference benchmarks/panda_arm/setup/exp.yaml:21-24
+# BASELINE.json configs.  The default - and the only one the driver's bench line uses - is panda_reach.
+WORKLOADS = {
+    "panda_reach": dict(desc="panda_stick reach (BASELINE configs[2]): ABA from URDF, no contact, fused reach cost",
+                        actors=["panda_stick", "goal"], mppi="panda", nx=14, K=4096, H=20, init=[[0.0, 0.0, 0.0]],
+                        q0=[0.0, -0.94, 0.0, -2.8, 0.0, 1.8675, 0.0],   # conf/actors/panda_stick.yaml init_joint_pose
+                        goal=[0.5, -0.4, 0.3], objective="PandaReachObjective"),  # reference benchmarks/panda_arm/setup/exp.yaml:21-24
+    "point_reach": dict(desc="point_robot reach (BASELINE configs[1]): 3-DoF velocity-driven base",
+                        actors=["point_robot", "goal"], mppi="pointbot", nx=6, K=1024, H=15, init=[[0.0, 0.0, 0.05]],
+                        q0=[0.1, 0.0, 0.0], goal=[4.5, 0.2, 0.0], objective="PointReachObjective"),
+    "boxer_push": dict(desc="boxer_push (BASELINE configs[3]): floating diff-drive base + block + obstacles, penalty contact",
+                       actors=["boxer", "block", "paper_obst1", "paper_obst2", "goal"], mppi="boxer_push", nx=4, K=8192, H=25,
+                       init=[[0.0, 2.5, 0.05]], q0=None, goal=None, objective="BoxerPushObjective"),
+    "panda_pick": dict(desc="panda_pick (BASELINE configs[4], 8192 samples per GPU): gripper arm + block + table contact",
+                       actors=["panda_gripper", "xaxis", "yaxis", "panda_pick_block", "table", "goal"], mppi="panda_pick", nx=18,
+                       K=8192, H=30, init=[[0.0, 0.0, 0.0]], q0=None, goal=None, objective="PandaPickObjective"),
+}
 
 
-def make_cfg(k_total):
+def make_cfg(w, k_total):
     from mppiisaac.utils.config_store import load_config
-    return load_config({"defaults": [{"mppi": "panda"}, {"isaacgym": "normal"}], "actors": ["panda_stick", "goal"],
-                        "initial_actor_positions": [[0.0, 0.0, 0.0]], "nx": 14},
-                       overrides={"mppi.num_samples": k_total, "mppi.horizon": HORIZON, "mppi.filter_u": False})
+    return load_config({"defaults": [{"mppi": w["mppi"]}, {"isaacgym": "normal"}], "actors": w["actors"],
+                        "initial_actor_positions": w["init"], "nx": w["nx"]},
+                       overrides={"mppi.num_samples": k_total, "mppi.horizon": w["H"], "mppi.filter_u": False,
+                                  "mppi.use_priors": False})
 
 
-def cpu_baseline(planner, seconds_budget=20.0):
+def cpu_baseline(planner, dof, K_PER_GPU, HORIZON, seconds_budget=20.0):
     """The oracle (C restatement, fp32, OpenMP over samples) timed on this box's host cores on the same
     K=4096 x H=20 control iteration.  Bounded sample: as many iterations as fit ~seconds_budget."""
     from mppiisaac.backend import capi
@@ -45,12 +59,11 @@ def cpu_baseline(planner, seconds_budget=20.0):
     cores = os.cpu_count() or 1
     os.environ["OMP_NUM_THREADS"] = str(cores)
     o = Oracle("f32")
-    eps = np.zeros((HORIZON, 7, K_PER_GPU), np.float32)
+    nu = sim.scene.nu
+    eps = np.zeros((HORIZON, nu, K_PER_GPU), np.float32)
     capi.check(sim._lib, sim._lib.mppi_get_noise(sim._ctx, capi.fptr(eps)))
-    dof = np.zeros(14, np.float32)
-    dof[0::2] = Q0
     root = sim._root_state[0].cpu().numpy()
-    U = np.zeros((HORIZON, 7), np.float32)
+    U = np.zeros((HORIZON, nu), np.float32)
     cost = planner.objective.fused_spec(sim)
     t0 = time.perf_counter()
     U, a, S = o.command(sim._c_model, sim._mppi_config, cost, dof, root, U, eps)
@@ -60,8 +73,8 @@ def cpu_baseline(planner, seconds_budget=20.0):
     for _ in range(n):
         U, a, S = o.command(sim._c_model, sim._mppi_config, cost, dof, root, U, eps)
     dt = (time.perf_counter() - t0) / n
-    return {"value": 1.0 / dt, "unit": "Hz (K=4096,H=20 control iterations/s)", "cores": cores, "kind": "port",
-            "sample": f"{n} open-loop control iterations of the same K=4096xH=20 panda workload, oracle/mppi_oracle.c fp32, "
+    return {"value": 1.0 / dt, "unit": f"Hz (K={K_PER_GPU},H={HORIZON} control iterations/s)", "cores": cores, "kind": "port",
+            "sample": f"{n} open-loop control iterations of the same K={K_PER_GPU}xH={HORIZON} workload, oracle/mppi_oracle.c fp32, "
                       f"OpenMP over samples on {cores} host threads ({dt * 1e3:.1f} ms/iteration)"}
 
 
@@ -72,12 +85,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--async-loop", action="store_true", help="do not copy the action to the host every iteration")
+    ap.add_argument("--workload", default="panda_reach", choices=sorted(WORKLOADS), help="BASELINE config (default: the metric's)")
     args = ap.parse_args()
+    wl = WORKLOADS[args.workload]
+    K_PER_GPU, HORIZON = wl["K"], wl["H"]
 
     import torch
     import torch.distributed as dist
     from mppiisaac.backend import capi
-    from mppiisaac.objectives import PandaReachObjective
+    import mppiisaac.objectives as objectives
     from mppiisaac.planner.isaacgym_wrapper import IsaacGymWrapper
     from mppiisaac.planner.mppi_isaac import MPPIisaacPlanner
 
@@ -91,23 +107,27 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", local_rank))
 
-    cfg = make_cfg(K_PER_GPU * world_size)
+    cfg = make_cfg(wl, K_PER_GPU * world_size)
     cfg.mppi.device = f"cuda:{local_rank}"
-    objective = PandaReachObjective(cfg)
+    objective = getattr(objectives, wl["objective"])(cfg)
     planner = MPPIisaacPlanner(cfg, objective, shard=world_size > 1)
     world = IsaacGymWrapper(cfg.isaacgym, actors=cfg.actors, init_positions=cfg.initial_actor_positions, num_envs=1,
                             device=cfg.mppi.device)
     lib, P, W = planner.sim._lib, planner.sim._ctx, world._ctx
-    for sim in (planner.sim, world):
-        sim.set_actor_position_by_name(GOAL, "goal")
-    dof0 = np.zeros(14, np.float32)
-    dof0[0::2] = Q0
+    GOAL = wl["goal"]
+    if GOAL is not None:
+        for sim in (planner.sim, world):
+            sim.set_actor_position_by_name(GOAL, "goal")
+    dof0 = world._dof_state[0].cpu().numpy().copy()
+    if wl["q0"] is not None:
+        dof0[0::2] = wl["q0"]
     root0 = world._root_state[0].cpu().numpy()
     for sim in (planner.sim, world):
         sim._push_single_state(dof0, root0)
     planner._bind_objective()
     records = planner.mppi._records
-    action = np.zeros(7, np.float32)
+    nu = planner.sim.scene.nu
+    action = np.zeros(nu, np.float32)
     ap_ = capi.fptr(action)
 
     def iterate(sync):
@@ -150,14 +170,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # final state sanity: the closed loop must have moved the end effector towards the goal
+    # final state sanity (default workload): the closed loop must have moved the end effector to the goal
     world._materialise()
-    ee = world.get_actor_link_by_name("panda", "panda_ee_tip")[0, 0:3].cpu().numpy()
-    dist_to_goal = float(np.linalg.norm(ee - np.asarray(GOAL)))
+    dist_to_goal = None
+    if args.workload == "panda_reach":
+        ee = world.get_actor_link_by_name("panda", "panda_ee_tip")[0, 0:3].cpu().numpy()
+        dist_to_goal = float(np.linalg.norm(ee - np.asarray(GOAL)))
 
     if rank == 0:
         loop_hz = args.steps / elapsed
-        nu, K, H = 7, K_PER_GPU, HORIZON
+        K, H = K_PER_GPU, HORIZON
         bytes_alg = 4 * (3 * K * H * nu + 2 * K + H * nu)  # SURVEY.md 8d, per GPU per control iteration
         achieved = bytes_alg / (kms[0] * 1e-3) / 1e9
         traffic, traffic_src = None, None  # HBM bytes/launch from the last committed rocprofv3 PMC passes
@@ -167,14 +189,15 @@ def main():
             traffic = pmc.get("k_rollout", {}).get("hbm_traffic_bytes_per_launch")
             traffic_src = f"profiles/{pmc.get('tag')}_pmc_summary.json (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes of this command)"
         out = {
-            "metric": "MPPI control-loop Hz (K samples x H horizon), Panda 7-DoF K=4096 H=20",
+            "metric": "MPPI control-loop Hz (K samples x H horizon), Panda 7-DoF K=4096 H=20" if args.workload == "panda_reach"
+                      else f"MPPI control-loop Hz, {args.workload} K={K} H={H} (not the BASELINE metric)",
             "value": loop_hz * world_size,
-            "unit": "Hz (4096-sample x 20-step control iterations per second, summed over GPUs)",
+            "unit": f"Hz ({K}-sample x {H}-step control iterations per second, summed over GPUs)",
             "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "panda_stick reach (BASELINE configs[2]): ABA from URDF, no contact, fused reach cost",
+            "config": {"workload": wl["desc"],
                        "K_per_gpu": K, "K_total": K * world_size, "H": H, "nu": nu, "dt": cfg.isaacgym.dt,
                        "substeps": cfg.isaacgym.substeps, "closed_loop": True, "action_to_host_every_step": sync,
                        "parallelism": f"sample-shard x{world_size}" if world_size > 1 else "single GPU",
@@ -187,7 +210,7 @@ def main():
             "kernels_ms": {"k_rollout(+record tail)": kms[0], "k_reduce(generic mode only)": kms[1], "k_combine_update": kms[2]},
         }
         if world_size == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(planner)
+            out["cpu_baseline"] = cpu_baseline(planner, dof0, K_PER_GPU, HORIZON)
         print(json.dumps(out))
     if world_size > 1:
         dist.destroy_process_group()
