@@ -42,16 +42,27 @@ constexpr int kMaxPairs = 48;
 constexpr int kMaxFree = 2;
 
 // ---- device-side model (fp32, z-framed) ------------------------------------------------
-struct DevBody {
-    int parent, jtype, limited, pad;
+// Three 64-byte blocks, each fetched with ONE s_load_dwordx16 where it is used (load_block below):
+// block 0 = kinematics, block 1 = inertia + limits, block 2 = command map row.
+struct BodyK0 {
     float Rt[9];  // joint frame in parent body frame (child->parent), q = 0
     float pt[3];
+    int jtype, parent, pad0[2];
+};
+struct BodyK1 {
     float m;
     float hb[3];  // m * com, body frame
     float Ic[6];  // inertia about the COM, body axes: xx xy xz yy yz zz
     float lower, upper, effort, vmax;
-    float cmd[kMaxNu];  // dense row of the command map: target_i = sum_c cmd[c] * u[c]
+    int limited, pad1;
 };
+struct alignas(64) DevBody {
+    BodyK0 k0;
+    BodyK1 k1;
+    float cmd[kMaxNu];  // dense row of the command map: target_i = sum_c cmd[c] * u[c]
+    float pad2[16 - kMaxNu];
+};
+static_assert(sizeof(BodyK0) == 64 && sizeof(BodyK1) == 64 && sizeof(DevBody) == 192, "DevBody block layout");
 struct DevLink {
     int body, pad[3];
     float R[9];
@@ -120,6 +131,21 @@ typedef const MPPI_CONST_AS DevFree CFree;
 typedef const MPPI_CONST_AS DevCfg CCfg;
 typedef const MPPI_CONST_AS DevCost CCost;
 typedef const MPPI_CONST_AS float cfloat;
+
+// one 64-byte block of a uniform struct -> 16 SGPRs with a single scalar load
+#if defined(__clang__)
+typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
+#else
+typedef unsigned u32x16 __attribute__((vector_size(64)));
+#endif
+template <class B, class S>
+MPPI_HD B load_block(S &src) {
+    static_assert(sizeof(B) == 64 && sizeof(S) == 64, "64-byte blocks only");
+    const u32x16 v = *reinterpret_cast<const MPPI_CONST_AS u32x16 *>(&src);
+    B out;
+    __builtin_memcpy(&out, &v, 64);
+    return out;
+}
 
 template <class P>
 MPPI_HD P *launder(P *p) {
@@ -269,6 +295,7 @@ template <class T>
 struct Pose {
     M3 R[T::NB ? T::NB : 1];
     V3 p[T::NB ? T::NB : 1];
+    int jt[T::NB ? T::NB : 1];  // joint types (wave-uniform), cached with the pose
     M3 Rb;
     V3 pb;
 };
@@ -310,7 +337,8 @@ MPPI_HD void forward_kinematics_base(CModel &m, const float *q, Pose<T> &P) {
     static_for<0, T::NB>([&](auto ic) MPPI_LAMBDA {
         constexpr int i = ic;
         constexpr int par = T::par[i];
-        CBody &b = m.b[i];
+        const BodyK0 b = load_block<BodyK0>(m.b[i].k0);
+        P.jt[i] = b.jtype;
         const M3 &Rp = par < 0 ? P.Rb : P.R[par < 0 ? 0 : par];
         const V3 pp = par < 0 ? P.pb : P.p[par < 0 ? 0 : par];
         M3 RT = mul(Rp, load3(b.Rt));
@@ -338,7 +366,7 @@ MPPI_HD void forward_kinematics_base(CModel &m, const float *q, Pose<T> &P) {
 template <class T, int i>
 MPPI_HD SV joint_subspace(CModel &m, const Pose<T> &P) {
     V3 az = {P.R[i].a[2], P.R[i].a[5], P.R[i].a[8]};
-    if (m.b[i].jtype == 0) return {az, cross(P.p[i], az)};
+    if (P.jt[i] == 0) return {az, cross(P.p[i], az)};
     return {{0.f, 0.f, 0.f}, az};
 }
 
@@ -368,7 +396,7 @@ MPPI_HD void aba_world(CModel &m, const Pose<T> &P, const float *qd, const float
     static_rfor<0, NB>([&](auto ic) MPPI_LAMBDA {
         constexpr int i = ic;
         constexpr int par = T::par[i];
-        CBody &b = m.b[i];
+        const BodyK1 b = load_block<BodyK1>(m.b[i].k1);
         const M3 &R = P.R[i];
         SV S = joint_subspace<T, i>(m, P);
         // rigid inertia about the world origin: I_O = R Ic R^T + m(|cw|^2 1 - cw cw^T), h = m cw
@@ -484,7 +512,7 @@ MPPI_HD void step(CModel &m0, const float *root, float *q, float *qd, const floa
         bool any = false;
         static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
             constexpr int i = ic;
-            float lim = m.b[i].effort;
+            float lim = m.b[i].k1.effort;
             float tt = ff[i] + kd * (vs[i] - qd[i] - h * qdd[i]);
             if (lim > 0.f && fabsf(tt) > lim) {
                 any = true;
@@ -495,7 +523,7 @@ MPPI_HD void step(CModel &m0, const float *root, float *q, float *qd, const floa
         if (any) aba_world<T>(*launder(mp), P, qd, tau, kdh, qdd);
         static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
             constexpr int i = ic;
-            CBody &b = m.b[i];
+            const BodyK1 b = load_block<BodyK1>(m.b[i].k1);
             float v = qd[i] + h * qdd[i];
             if (b.vmax > 0.f) v = fminf(fmaxf(v, -b.vmax), b.vmax);
             float x = q[i] + h * v;

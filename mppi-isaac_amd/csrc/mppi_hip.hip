@@ -15,12 +15,14 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "mppi_pack.hpp"
 #include "mppi_scene.hpp"
+#include "mppi_quad.hpp"
 
 using namespace mppi;
 
@@ -120,6 +122,28 @@ __global__ __launch_bounds__(kWave) void k_rollout(const DevModel *__restrict__ 
     }
     // fused tail: this wave's partial record (its own du writes are visible to its own lanes)
     wave_record(*(CCfg *)cfg, s, live, du, k, partials + (size_t)blockIdx.x * (2 + cfg->H * cfg->nu));
+}
+
+// Quad-parallel rollout (mppi_quad.hpp): 4 lanes per sample, 16 samples per wavefront.
+template <class T>
+__global__ __launch_bounds__(kWave) void k_rollout_quad(const DevModel *__restrict__ m, const DevCfg *__restrict__ cfg,
+                                                        const DevCost *__restrict__ cost, const float *__restrict__ x0_dof,
+                                                        const float *__restrict__ x0_root, const float *__restrict__ U,
+                                                        const float *__restrict__ eps, const float *__restrict__ prior,
+                                                        float *__restrict__ du, float *__restrict__ S, float *__restrict__ viz,
+                                                        float *__restrict__ partials) {
+#if defined(__HIP_DEVICE_COMPILE__)  // (the host pass sees the 4-float emulation type of mppi_quad.hpp)
+    const int k = (blockIdx.x * kWave + threadIdx.x) >> 2;
+    const int lane4 = threadIdx.x & 3;
+    const bool live = k < cfg->K;        // the four lanes of a quad share k
+    const bool leader = lane4 == 0;
+    float s = INFINITY;
+    if (live) {
+        s = quad_rollout<T>(*(CModel *)m, *(CCfg *)cfg, *(CCost *)cost, x0_dof, x0_root, U, eps, prior, du, viz, k, leader, quad_row(), lane4 < 3);
+        if (leader) S[k] = s;
+    }
+    wave_record(*(CCfg *)cfg, s, live && leader, du, k, partials + (size_t)blockIdx.x * (2 + cfg->H * cfg->nu));
+#endif
 }
 
 // Combine n records; mode 0: write the combined record to `out`; mode 1: U += N/eta, action, shift.
@@ -481,6 +505,9 @@ struct mppi_ctx {
     DevCfg hc;
     DevCost hk;
     int n = 0, A = 0, B = 0, K = 0, H = 0, nu = 0, HN = 0, RF = 0, n_waves = 0;
+    int n_quads = 0;      // wavefronts of the quad-parallel rollout (16 samples each)
+    int n_partials = 0;   // records currently held by d_partials
+    bool quad = false;
     DevModel *d_model = nullptr;
     DevCfg *d_cfg = nullptr;
     DevCost *d_cost = nullptr;
@@ -527,6 +554,11 @@ hipError_t raise_lds_limit(size_t bytes) {
     return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sim_step_scene<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
+template <class T>
+void launch_rollout_quad_t(mppi_ctx *c) {
+    hipLaunchKernelGGL(k_rollout_quad<T>, dim3(c->n_quads), dim3(kWave), 0, c->stream, c->d_model, c->d_cfg, c->d_cost, c->d_x0_dof, c->d_x0_root,
+                       c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_S, c->cfg.want_rollouts ? c->d_viz : nullptr, c->d_partials);
+}
 template <class T>
 void launch_rollout_t(mppi_ctx *c) {
     hipLaunchKernelGGL(k_rollout<T>, dim3(c->n_waves), dim3(kWave), 0, c->stream, c->d_model, c->d_cfg, c->d_cost, c->d_x0_dof, c->d_x0_root,
@@ -622,7 +654,7 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
     }
     std::memset(&c->hk, 0, sizeof c->hk);
     int parents[MPPI_MAX_BODIES];
-    for (int i = 0; i < c->hm.nb; i++) parents[i] = c->hm.b[i].parent;
+    for (int i = 0; i < c->hm.nb; i++) parents[i] = c->hm.b[i].k0.parent;
     c->topo = topology_string(c->hm.nb, parents);
     c->scene = is_scene(c->hm);
     hipError_t lds_err = hipSuccess;
@@ -635,7 +667,11 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
             c->launch_materialise = &launch_materialise_scene_t<T>;
             if (hipSetDevice(device) == hipSuccess) lds_err = raise_lds_limit<T>(c->lds_bytes);
         } else {
-            c->launch_rollout = &launch_rollout_t<T>;
+            // fixed-base contact-free scenes: one sample per 4-lane quad unless MPPI_ROLLOUT=lane asks for the
+            // one-lane-per-sample kernel (kept for A/B measurements and as the reference arithmetic)
+            const char *mode = std::getenv("MPPI_ROLLOUT");
+            c->quad = !(mode && std::string(mode) == "lane");
+            c->launch_rollout = c->quad ? &launch_rollout_quad_t<T> : &launch_rollout_t<T>;
             c->launch_sim_step = &launch_sim_step_t<T>;
             c->launch_materialise = &launch_materialise_t<T>;
         }
@@ -663,6 +699,7 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
     }
     c->n = c->hm.nb; c->A = c->hm.n_actors; c->B = c->hm.n_rb; c->K = cfg->num_samples; c->H = cfg->horizon; c->nu = cfg->nu;
     c->HN = c->H * c->nu; c->RF = 2 + c->HN; c->n_waves = (c->K + kWave - 1) / kWave;
+    c->n_quads = (c->K + 15) / 16;
     const size_t K = c->K;
     ALLOC_TRY(c->d_model, sizeof(DevModel));
     ALLOC_TRY(c->d_cfg, sizeof(DevCfg));
@@ -675,7 +712,7 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
     ALLOC_TRY(c->d_S, sizeof(float) * K);
     ALLOC_TRY(c->d_prior, sizeof(float) * c->HN);
     ALLOC_TRY(c->d_viz, sizeof(float) * (cfg->want_rollouts ? (size_t)c->H * K * 3 : 1));
-    ALLOC_TRY(c->d_partials, sizeof(float) * (size_t)c->n_waves * c->RF);
+    ALLOC_TRY(c->d_partials, sizeof(float) * (size_t)c->n_quads * c->RF);
     ALLOC_TRY(c->d_record, sizeof(float) * c->RF);
     ALLOC_TRY(c->d_action, sizeof(float) * c->nu);
     ALLOC_TRY(c->d_beta_eta, sizeof(float) * 2);
@@ -806,6 +843,7 @@ int mppi_rollout(mppi_ctx_t *c) {
         c->launch_rollout(c);
     }
     c->partials_valid = true;
+    c->n_partials = c->quad ? c->n_quads : c->n_waves;
     return launch_check();
 }
 int mppi_reduce(mppi_ctx_t *c, float *record_out_dev) {
@@ -814,23 +852,24 @@ int mppi_reduce(mppi_ctx_t *c, float *record_out_dev) {
         EvScope ev(c, 1);
         hipLaunchKernelGGL(k_reduce, dim3(c->n_waves), dim3(kWave), 0, c->stream, c->d_cfg, c->d_S, c->d_du, c->d_partials);
         c->partials_valid = true;
+        c->n_partials = c->n_waves;
     }
     if (record_out_dev)  // one shard record for the cross-GPU all-gather
-        hipLaunchKernelGGL(k_combine, dim3(1), dim3(256), 0, c->stream, c->d_cfg, c->d_partials, c->n_waves, 0, record_out_dev, c->d_U, c->d_action,
+        hipLaunchKernelGGL(k_combine, dim3(1), dim3(256), 0, c->stream, c->d_cfg, c->d_partials, c->n_partials, 0, record_out_dev, c->d_U, c->d_action,
                            c->d_beta_eta);
     return launch_check();
 }
 int mppi_record_floats(const mppi_ctx_t *c) { return c ? c->RF : 0; }
 int mppi_record_dev(mppi_ctx_t *c, float **record_dev) {
     CTX_TRY(c);
-    hipLaunchKernelGGL(k_combine, dim3(1), dim3(256), 0, c->stream, c->d_cfg, c->d_partials, c->n_waves, 0, c->d_record, c->d_U, c->d_action, c->d_beta_eta);
+    hipLaunchKernelGGL(k_combine, dim3(1), dim3(256), 0, c->stream, c->d_cfg, c->d_partials, c->n_partials, 0, c->d_record, c->d_U, c->d_action, c->d_beta_eta);
     *record_dev = c->d_record;
     return launch_check();
 }
 int mppi_update(mppi_ctx_t *c, const float *records_dev, int n_records) {
     CTX_TRY(c);
     const float *recs = records_dev ? records_dev : c->d_partials;
-    int n = records_dev ? n_records : c->n_waves;
+    int n = records_dev ? n_records : c->n_partials;
     if (n < 1) return fail(MPPI_EINVAL, "n_records < 1");
     {
         EvScope ev(c, 2);
@@ -960,7 +999,7 @@ int mppi_kernel_ms(mppi_ctx_t *c, int which, float *ms) {
 }
 int mppi_kernel_info(mppi_ctx_t *c, char *buf, int buflen) {
     CTX_TRY(c);
-    std::snprintf(buf, buflen, "topology=%s K=%d H=%d nu=%d waves=%d block=%d bytes_alg=%zu", c->topo.c_str(), c->K, c->H, c->nu, c->n_waves, kWave,
+    std::snprintf(buf, buflen, "topology=%s rollout=%s K=%d H=%d nu=%d waves=%d block=%d bytes_alg=%zu", c->topo.c_str(), c->scene ? "scene" : (c->quad ? "quad" : "lane"), c->K, c->H, c->nu, c->quad ? c->n_quads : c->n_waves, kWave,
                   (size_t)4 * (3 * (size_t)c->K * c->HN + 2 * (size_t)c->K + c->HN));
     return MPPI_OK;
 }

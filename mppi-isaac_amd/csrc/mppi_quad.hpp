@@ -1,0 +1,433 @@
+// mppi_quad.hpp - quad-parallel rollout: ONE SAMPLE PER 4-LANE QUAD (fixed-base, contact-free scenes).
+//
+// Why: at K = 4096 the one-lane-per-sample kernel is 64 wavefronts on a 1024-SIMD chip, and a lone
+// wavefront issues one instruction per ~4 cycles whatever its ILP (measured: SQ_ACTIVE_INST_ANY =
+// 73 % of wave cycles at 1.04 instructions per quad-cycle) - the kernel is bound by ITS OWN
+// instruction count.  Splitting a sample over the x/y/z components of its 3-vectors cuts the per-lane
+// instruction stream ~3x and quadruples the wavefronts in flight.
+//
+// Layout inside a quad: lanes 0,1,2 own component (matrix row) r = 0,1,2; lane 3 is an exact replica of
+// lane 0 (same data, same permutation sources) so wave-uniform branches and replicated scalars never
+// diverge and nothing undefined is ever read.  Cross-lane traffic is DPP quad_perm only (a VALU operand
+// modifier - no LDS, no extra latency):
+//   rot1/rot2   lane r reads component (r+1)%3 / (r+2)%3        cross products, rotated-row matvecs
+//   bc<k>       every lane reads component k                    standard-row products
+// 3x3 pose matrices are stored as STANDARD rows (row r = R[r][0..2]) because they multiply uniform
+// constant matrices; the four 3x3 blocks of an articulated inertia are stored as ROTATED rows
+// (a[j] = A[r][(r+j)%3]) because they only ever meet distributed vectors, and skew(h) is natural there.
+// H^T is kept alongside H (column access is the one thing a row distribution cannot do cheaply).
+//
+// The same templates compile for the host (tests/hostemu): QF is then a 4-float struct and the
+// permutations are array shuffles, so the arithmetic is checked against the oracle without a GPU.
+#pragma once
+#include "mppi_device.hpp"
+
+namespace mppi {
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float QF;
+template <int CTRL>
+__device__ __forceinline__ float quad_dpp(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ QF rot1(QF x) { return quad_dpp<0x49>(x); }  // quad_perm [1,2,0,1]
+__device__ __forceinline__ QF rot2(QF x) { return quad_dpp<0x92>(x); }  // quad_perm [2,0,1,2]
+template <int K>
+__device__ __forceinline__ QF bc(QF x) { return quad_dpp<K * 0x55>(x); }  // quad_perm [k,k,k,k]
+__device__ __forceinline__ int quad_row() { int l = threadIdx.x & 3; return l == 3 ? 0 : l; }
+__device__ __forceinline__ QF qsel(float x0, float x1, float x2) { int r = quad_row(); return r == 0 ? x0 : (r == 1 ? x1 : x2); }
+__device__ __forceinline__ QF qrep(float x) { return x; }
+__device__ __forceinline__ float qlane0(QF x) { return x; }  // value as seen by the calling lane
+__device__ __forceinline__ QF qsqrt(QF x) { return sqrtf(x); }
+__device__ __forceinline__ QF qrcp(QF x) { return 1.f / x; }
+__device__ __forceinline__ QF qabs(QF x) { return fabsf(x); }
+__device__ __forceinline__ QF qmin(QF a, QF b) { return fminf(a, b); }
+__device__ __forceinline__ QF qmax(QF a, QF b) { return fmaxf(a, b); }
+__device__ __forceinline__ QF qatan2(QF a, QF b) { return atan2f(a, b); }
+__device__ __forceinline__ QF qasin(QF a) { return asinf(a); }
+__device__ __forceinline__ void qsincos(QF x, QF &s, QF &c) { fast_sincos(x, s, c); }
+__device__ __forceinline__ bool qany_gt(QF a, QF b) { return a > b; }     // replicated scalars: same in every lane of the quad
+__device__ __forceinline__ QF qwhere_gt(QF a, QF b, QF x, QF y) { return a > b ? x : y; }
+__device__ __forceinline__ QF qwhere_lt(QF a, QF b, QF x, QF y) { return a < b ? x : y; }
+#else
+struct QF {
+    float v[4];
+};
+inline QF operator+(QF a, QF b) { QF o; for (int i = 0; i < 4; i++) o.v[i] = a.v[i] + b.v[i]; return o; }
+inline QF operator-(QF a, QF b) { QF o; for (int i = 0; i < 4; i++) o.v[i] = a.v[i] - b.v[i]; return o; }
+inline QF operator*(QF a, QF b) { QF o; for (int i = 0; i < 4; i++) o.v[i] = a.v[i] * b.v[i]; return o; }
+inline QF operator*(float a, QF b) { QF o; for (int i = 0; i < 4; i++) o.v[i] = a * b.v[i]; return o; }
+inline QF operator*(QF b, float a) { return a * b; }
+inline QF operator+(QF b, float a) { QF o; for (int i = 0; i < 4; i++) o.v[i] = b.v[i] + a; return o; }
+inline QF operator+(float a, QF b) { return b + a; }
+inline QF operator-(QF b, float a) { return b + (-a); }
+inline QF operator-(float a, QF b) { QF o; for (int i = 0; i < 4; i++) o.v[i] = a - b.v[i]; return o; }
+inline QF operator-(QF a) { QF o; for (int i = 0; i < 4; i++) o.v[i] = -a.v[i]; return o; }
+inline QF &operator+=(QF &a, QF b) { a = a + b; return a; }
+inline QF &operator-=(QF &a, QF b) { a = a - b; return a; }
+inline QF rot1(QF x) { return QF{{x.v[1], x.v[2], x.v[0], x.v[1]}}; }
+inline QF rot2(QF x) { return QF{{x.v[2], x.v[0], x.v[1], x.v[2]}}; }
+template <int K>
+inline QF bc(QF x) { return QF{{x.v[K], x.v[K], x.v[K], x.v[K]}}; }
+inline int quad_row() { return 0; }
+inline QF qsel(float x0, float x1, float x2) { return QF{{x0, x1, x2, x0}}; }
+inline QF qrep(float x) { return QF{{x, x, x, x}}; }
+inline float qlane0(QF x) { return x.v[0]; }
+inline QF qsqrt(QF x) { QF o; for (int i = 0; i < 4; i++) o.v[i] = sqrtf(x.v[i]); return o; }
+inline QF qrcp(QF x) { QF o; for (int i = 0; i < 4; i++) o.v[i] = 1.f / x.v[i]; return o; }
+inline QF qabs(QF x) { QF o; for (int i = 0; i < 4; i++) o.v[i] = fabsf(x.v[i]); return o; }
+inline QF qmin(QF a, QF b) { QF o; for (int i = 0; i < 4; i++) o.v[i] = fminf(a.v[i], b.v[i]); return o; }
+inline QF qmax(QF a, QF b) { QF o; for (int i = 0; i < 4; i++) o.v[i] = fmaxf(a.v[i], b.v[i]); return o; }
+inline QF qatan2(QF a, QF b) { QF o; for (int i = 0; i < 4; i++) o.v[i] = atan2f(a.v[i], b.v[i]); return o; }
+inline QF qasin(QF a) { QF o; for (int i = 0; i < 4; i++) o.v[i] = asinf(a.v[i]); return o; }
+inline void qsincos(QF x, QF &s, QF &c) { for (int i = 0; i < 4; i++) fast_sincos(x.v[i], s.v[i], c.v[i]); }
+inline bool qany_gt(QF a, QF b) { return a.v[0] > b.v[0]; }
+inline QF qwhere_gt(QF a, QF b, QF x, QF y) { QF o; for (int i = 0; i < 4; i++) o.v[i] = a.v[i] > b.v[i] ? x.v[i] : y.v[i]; return o; }
+inline QF qwhere_lt(QF a, QF b, QF x, QF y) { QF o; for (int i = 0; i < 4; i++) o.v[i] = a.v[i] < b.v[i] ? x.v[i] : y.v[i]; return o; }
+#endif
+
+// sum over the three components, taken from lane 0 so that replicated scalars (d, u, qdd, costs) are
+// bit-identical across the quad whatever the summation order of each lane would have been
+MPPI_HD QF qsum(QF x) { return bc<0>(x + rot1(x) + rot2(x)); }
+MPPI_HD QF qcross(QF a, QF b) { return rot1(a) * rot2(b) - rot2(a) * rot1(b); }
+
+struct QSV {  // spatial vector (world axes, about the world origin), one component per lane
+    QF a, l;
+};
+struct QM3 {  // 3x3, STANDARD row r per lane
+    QF c[3];
+};
+struct QAI {  // symmetric 6x6 [[I,H],[H^T,M]], ROTATED rows: x[j] = X[r][(r+j)%3]
+    QF I[3], H[3], Ht[3], M[3];
+};
+
+// y = A x for the 6x6: rotated rows meet rotated copies of the distributed vector
+MPPI_HD QSV qmul(const QAI &A, const QSV &x) {
+    const QF a1 = rot1(x.a), a2 = rot2(x.a), l1 = rot1(x.l), l2 = rot2(x.l);
+    QSV y;
+    y.a = A.I[0] * x.a + A.I[1] * a1 + A.I[2] * a2 + A.H[0] * x.l + A.H[1] * l1 + A.H[2] * l2;
+    y.l = A.Ht[0] * x.a + A.Ht[1] * a1 + A.Ht[2] * a2 + A.M[0] * x.l + A.M[1] * l1 + A.M[2] * l2;
+    return y;
+}
+MPPI_HD QF qdot6(const QSV &p, const QSV &q) { return qsum(p.a * q.a + p.l * q.l); }
+
+template <class T>
+struct QPose {
+    QM3 R[T::NB ? T::NB : 1];
+    QF p[T::NB ? T::NB : 1];
+    int jt[T::NB ? T::NB : 1];
+    QM3 Rb;
+    QF pb;
+};
+
+template <class T>
+MPPI_HD void quad_fk(CModel &m, const QF *q, QPose<T> &P) {
+    static_for<0, T::NB>([&](auto ic) MPPI_LAMBDA {
+        constexpr int i = ic;
+        constexpr int par = T::par[i];
+        const BodyK0 b = load_block<BodyK0>(m.b[i].k0);
+        P.jt[i] = b.jtype;
+        const QM3 &Rp = par < 0 ? P.Rb : P.R[par < 0 ? 0 : par];
+        const QF pp = par < 0 ? P.pb : P.p[par < 0 ? 0 : par];
+        QM3 RT;
+        for (int c = 0; c < 3; c++) RT.c[c] = Rp.c[0] * b.Rt[c] + Rp.c[1] * b.Rt[3 + c] + Rp.c[2] * b.Rt[6 + c];
+        const QF pw = pp + Rp.c[0] * b.pt[0] + Rp.c[1] * b.pt[1] + Rp.c[2] * b.pt[2];
+        if (b.jtype == 0) {
+            QF s, c;
+            qsincos(q[i], s, c);
+            P.R[i].c[0] = c * RT.c[0] + s * RT.c[1];
+            P.R[i].c[1] = c * RT.c[1] - s * RT.c[0];
+            P.R[i].c[2] = RT.c[2];
+            P.p[i] = pw;
+        } else {
+            P.R[i] = RT;
+            P.p[i] = pw + q[i] * RT.c[2];
+        }
+    });
+}
+
+template <class T, int i>
+MPPI_HD QSV quad_subspace(const QPose<T> &P) {
+    const QF az = P.R[i].c[2];  // third column of R: component r lives in lane r's row
+    if (P.jt[i] == 0) return {az, qcross(P.p[i], az)};
+    return {qrep(0.f), az};
+}
+
+// Articulated-body solve, quad-parallel.  tau/kdh/qd/qdd are replicated scalars (same in all lanes of a quad).
+template <class T>
+MPPI_HD void quad_aba(CModel &m, const QPose<T> &P, const QF *qd, const QF *tau_exp, const QF *kdh, QF *qdd) {
+    constexpr int NB = T::NB;
+    QSV v[NB], U[NB], pacc[NB];
+    QAI acc[NB];
+    QF invd[NB], u[NB];
+    bool has_acc[NB];
+    static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
+        constexpr int i = ic;
+        constexpr int par = T::par[i];
+        const QSV S = quad_subspace<T, i>(P);
+        const QSV sj = {qd[i] * S.a, qd[i] * S.l};
+        if constexpr (par < 0) v[i] = sj;
+        else v[i] = {v[par < 0 ? 0 : par].a + sj.a, v[par < 0 ? 0 : par].l + sj.l};
+        has_acc[i] = false;
+    });
+    static_rfor<0, NB>([&](auto ic) MPPI_LAMBDA {
+        constexpr int i = ic;
+        constexpr int par = T::par[i];
+        const BodyK1 b = load_block<BodyK1>(m.b[i].k1);
+        const QM3 &R = P.R[i];
+        const QSV S = quad_subspace<T, i>(P);
+        // rigid inertia about the world origin: I_O = R Ic R^T + m(|cw|^2 1 - cw cw^T), h = m cw
+        const QF h = R.c[0] * b.hb[0] + R.c[1] * b.hb[1] + R.c[2] * b.hb[2] + b.m * P.p[i];
+        QF Tr[3];
+        Tr[0] = R.c[0] * b.Ic[0] + R.c[1] * b.Ic[1] + R.c[2] * b.Ic[2];
+        Tr[1] = R.c[0] * b.Ic[1] + R.c[1] * b.Ic[3] + R.c[2] * b.Ic[4];
+        Tr[2] = R.c[0] * b.Ic[2] + R.c[1] * b.Ic[4] + R.c[2] * b.Ic[5];
+        const float invm = b.m > 0.f ? 1.f / b.m : 0.f;
+        const QF cw = invm * h;
+        const QF hh = qsum(h * cw);
+        const QF h1 = rot1(h), h2 = rot2(h);
+        QAI A;
+        A.I[0] = Tr[0] * R.c[0] + Tr[1] * R.c[1] + Tr[2] * R.c[2] + hh - h * cw;
+        A.I[1] = Tr[0] * rot1(R.c[0]) + Tr[1] * rot1(R.c[1]) + Tr[2] * rot1(R.c[2]) - h * rot1(cw);
+        A.I[2] = Tr[0] * rot2(R.c[0]) + Tr[1] * rot2(R.c[1]) + Tr[2] * rot2(R.c[2]) - h * rot2(cw);
+        A.H[0] = qrep(0.f); A.H[1] = -h2;       A.H[2] = h1;        // skew(h), rotated rows
+        A.Ht[0] = A.H[0];  A.Ht[1] = h2;       A.Ht[2] = -h1;      // skew(h)^T = -skew(h)
+        A.M[0] = qrep(b.m); A.M[1] = A.H[0];   A.M[2] = A.H[0];
+        // bias force v x* (I v)
+        const QF w = v[i].a, vl = v[i].l;
+        const QF n = A.I[0] * w + A.I[1] * rot1(w) + A.I[2] * rot2(w) + qcross(h, vl);
+        const QF f = b.m * vl + qcross(w, h);
+        QSV pA = {qcross(w, n) + qcross(vl, f), qcross(w, f)};
+        if (has_acc[i]) {
+            for (int j = 0; j < 3; j++) { A.I[j] += acc[i].I[j]; A.H[j] += acc[i].H[j]; A.Ht[j] += acc[i].Ht[j]; A.M[j] += acc[i].M[j]; }
+            pA = {pA.a + pacc[i].a, pA.l + pacc[i].l};
+        }
+        U[i] = qmul(A, S);
+        const QF d = qdot6(S, U[i]) + kdh[i];
+        invd[i] = qrcp(d);
+        u[i] = tau_exp[i] - qdot6(S, pA);
+        if constexpr (par >= 0) {
+            const QSV vp = v[par < 0 ? 0 : par];
+            const QSV sj = {qd[i] * S.a, qd[i] * S.l};
+            const QSV c = {qcross(vp.a, sj.a), qcross(vp.a, sj.l) + qcross(vp.l, sj.a)};
+            const QSV Ac = qmul(A, c);
+            const QF k = (u[i] - qdot6(U[i], c)) * invd[i];
+            const QSV pa = {pA.a + Ac.a + k * U[i].a, pA.l + Ac.l + k * U[i].l};
+            // Ia = IA - U U^T / d  (rotated rows: X[r][(r+j)%3] -= x_r * rot_j(y))
+            const QF un = U[i].a * invd[i], uf = U[i].l * invd[i];
+            const QF n1 = rot1(U[i].a), n2 = rot2(U[i].a), f1 = rot1(U[i].l), f2 = rot2(U[i].l);
+            A.I[0] -= un * U[i].a; A.I[1] -= un * n1; A.I[2] -= un * n2;
+            A.H[0] -= un * U[i].l; A.H[1] -= un * f1; A.H[2] -= un * f2;
+            A.Ht[0] -= uf * U[i].a; A.Ht[1] -= uf * n1; A.Ht[2] -= uf * n2;
+            A.M[0] -= uf * U[i].l; A.M[1] -= uf * f1; A.M[2] -= uf * f2;
+            constexpr int pj = par < 0 ? 0 : par;
+            if (has_acc[pj]) {
+                for (int j = 0; j < 3; j++) { acc[pj].I[j] += A.I[j]; acc[pj].H[j] += A.H[j]; acc[pj].Ht[j] += A.Ht[j]; acc[pj].M[j] += A.M[j]; }
+                pacc[pj] = {pacc[pj].a + pa.a, pacc[pj].l + pa.l};
+            } else {
+                acc[pj] = A;
+                pacc[pj] = pa;
+                has_acc[pj] = true;
+            }
+        }
+    });
+    QSV a[NB];
+    const QF zero = qrep(0.f);
+    QSV a0 = {zero, zero};
+    if (m.gravity_on) a0.l = qsel(-m.g[0], -m.g[1], -m.g[2]);
+    static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
+        constexpr int i = ic;
+        constexpr int par = T::par[i];
+        const QSV S = quad_subspace<T, i>(P);
+        QSV ap = a0;
+        if constexpr (par >= 0) {
+            const QSV vp = v[par < 0 ? 0 : par];
+            const QSV sj = {qd[i] * S.a, qd[i] * S.l};
+            ap = {a[par < 0 ? 0 : par].a + qcross(vp.a, sj.a), a[par < 0 ? 0 : par].l + qcross(vp.a, sj.l) + qcross(vp.l, sj.a)};
+        }
+        const QF dd = (u[i] - qdot6(U[i], ap)) * invd[i];
+        qdd[i] = dd;
+        a[i] = {ap.a + dd * S.a, ap.l + dd * S.l};
+    });
+}
+
+// base pose of the (fixed) robot from its root row, distributed over the quad
+template <class T>
+MPPI_HD void quad_base(CModel &m, const float *root, QPose<T> &P) {
+    const float *rs = root + 13 * m.robot_actor;
+    const M3 R = quat_to_R(rs + 3);
+    P.pb = qsel(rs[0], rs[1], rs[2]);
+    for (int c = 0; c < 3; c++) P.Rb.c[c] = qsel(R.a[c], R.a[3 + c], R.a[6 + c]);
+}
+
+template <class T>
+MPPI_HD void quad_step(CModel &m0, const float *root, QF *q, QF *qd, const QF *target) {
+    constexpr int NB = T::NB;
+    CModel *mp = &m0;
+    for (int s = 0; s < m0.substeps; s++) {
+        CModel &m = *launder(mp);
+        const float h = m.h, kd = m.kd;
+        QPose<T> P;
+        quad_base<T>(m, root, P);
+        quad_fk<T>(m, q, P);
+        QF tau[NB], kdh[NB], qdd[NB], ff[NB], vs[NB], eff[NB];
+        static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
+            constexpr int i = ic;
+            ff[i] = m.drive_mode == kDriveEffort ? target[i] : qrep(0.f);
+            vs[i] = m.drive_mode == kDriveVelocity ? target[i] : qrep(0.f);
+            tau[i] = ff[i] + kd * (vs[i] - qd[i]);
+            kdh[i] = qrep(kd * h);
+            eff[i] = qrep(m.b[i].k1.effort);
+        });
+        quad_aba<T>(m, P, qd, tau, kdh, qdd);
+        bool any = false;
+        static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
+            constexpr int i = ic;
+            const QF tt = ff[i] + kd * (vs[i] - qd[i] - h * qdd[i]);
+            const bool lim_on = m.b[i].k1.effort > 0.f;
+            if (lim_on && qany_gt(qabs(tt), eff[i])) {
+                any = true;
+                tau[i] = qwhere_gt(tt, qrep(0.f), eff[i], -eff[i]);
+                kdh[i] = qrep(0.f);
+            }
+        });
+        if (any) quad_aba<T>(*launder(mp), P, qd, tau, kdh, qdd);
+        static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
+            constexpr int i = ic;
+            const BodyK1 b = load_block<BodyK1>(m.b[i].k1);
+            QF v = qd[i] + h * qdd[i];
+            if (b.vmax > 0.f) v = qmin(qmax(v, qrep(-b.vmax)), qrep(b.vmax));
+            QF x = q[i] + h * v;
+            if (b.limited) {
+                const QF lo = qrep(b.lower), hi = qrep(b.upper), z = qrep(0.f);
+                v = qwhere_lt(x, lo, qmax(v, z), v);
+                x = qmax(x, lo);
+                v = qwhere_gt(x, hi, qmin(v, z), v);
+                x = qmin(x, hi);
+            }
+            q[i] = x;
+            qd[i] = v;
+        });
+    }
+}
+
+// world pose of link l: row r of R (standard) and component r of p
+template <class T>
+MPPI_HD void quad_link_pose(CModel &m, const QPose<T> &P, int l, QM3 &R, QF &p) {
+    CLink &L = m.l[l];
+    const int body = L.body;
+    const float wb = body < 0 ? 1.f : 0.f;
+    QM3 Rb;
+    for (int c = 0; c < 3; c++) Rb.c[c] = wb * P.Rb.c[c];
+    QF pb = wb * P.pb;
+    static_for<0, T::NB>([&](auto ic) MPPI_LAMBDA {
+        constexpr int i = ic;
+        const float w = body == i ? 1.f : 0.f;
+        for (int c = 0; c < 3; c++) Rb.c[c] += w * P.R[i].c[c];
+        pb += w * P.p[i];
+    });
+    for (int c = 0; c < 3; c++) R.c[c] = Rb.c[0] * L.R[c] + Rb.c[1] * L.R[3 + c] + Rb.c[2] * L.R[6 + c];
+    p = pb + Rb.c[0] * L.p[0] + Rb.c[1] * L.p[1] + Rb.c[2] * L.p[2];
+}
+
+template <class T>
+MPPI_HD QF quad_stage_cost(CModel &m, CCost &c, const float *root, const QF *q) {
+    if (c.kind == kCostPointReach) {
+        const float gx = c.actor[0] >= 0 ? root[13 * c.actor[0]] : c.w[1];
+        const float gy = c.actor[0] >= 0 ? root[13 * c.actor[0] + 1] : c.w[2];
+        const QF dx = q[0] - gx, dy = q[T::NB > 1 ? 1 : 0] - gy;
+        return c.w[0] * qsqrt(dx * dx + dy * dy);
+    }
+    if (c.kind == kCostPandaReach) {
+        QPose<T> P;
+        quad_base<T>(m, root, P);
+        quad_fk<T>(m, q, P);
+        QM3 R;
+        QF p;
+        quad_link_pose<T>(m, P, c.link[0], R, p);
+        const float *g = root + 13 * c.actor[0];
+        const QF d = p - qsel(g[0], g[1], g[2]);
+        const QF dist = qsqrt(qsum(d * d));
+        // row 2 of R lives in lane 2: R20, R21, R22 -> replicated (see stage_cost in mppi_device.hpp)
+        const QF r20 = bc<2>(R.c[0]), r21 = bc<2>(R.c[1]), r22 = bc<2>(R.c[2]);
+        const QF a0 = qatan2(r21, -r22);
+        const QF a1 = qasin(qmin(qmax(r20, qrep(-1.f)), qrep(1.f)));
+        return c.w[0] * dist + c.w[1] * qsqrt(a0 * a0 + a1 * a1);
+    }
+    return qrep(0.f);
+}
+
+// Whole-horizon rollout of the sample owned by this quad.  Every lane of the quad returns the same S.
+// `leader` is true in exactly one lane of the quad (it performs the du store); lanes 0..2 store viz.
+template <class T>
+MPPI_HD QF quad_rollout(CModel &m0, CCfg &cfg0, CCost &cost0, const float *dof0, const float *root, const float *U, const float *eps,
+                        const float *prior, float *du, float *viz, int k, bool leader, int row, bool viz_lane) {
+    constexpr int NB = T::NB;
+    const int K = cfg0.K, nu = cfg0.nu, H = cfg0.H;
+    const int g = cfg0.k_offset + k;
+    const bool is_null = cfg0.sample_null_action && g == cfg0.k_total - 1;
+    const bool is_prior = cfg0.use_priors && prior != nullptr && g == cfg0.k_total - 2;
+    QF q[NB], qd[NB], target[NB];
+    static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
+        constexpr int i = ic;
+        q[i] = qrep(dof0[2 * i]);
+        qd[i] = qrep(dof0[2 * i + 1]);
+    });
+    QF S = qrep(0.f);
+    float ctrl = 0.f, disc = 1.f;
+    CModel *mp = &m0;
+    CCfg *cp = &cfg0;
+    CCost *kp = &cost0;
+    for (int t = 0; t < H; t++) {
+        CCfg &cfg = *launder(cp);
+        float u[kMaxNu];
+#pragma unroll
+        for (int c = 0; c < kMaxNu; c++) {
+            if (c < nu) {
+                float Ut = U[t * nu + c];
+                float v = Ut + eps[(size_t)(t * nu + c) * K + k];
+                if (is_null) v = 0.f;
+                if (is_prior) v = prior[t * nu + c];
+                v = fminf(fmaxf(v, cfg.u_min[c]), cfg.u_max[c]);
+                u[c] = v;
+                float d = v - Ut;
+                if (leader) du[(size_t)(t * nu + c) * K + k] = d;
+                float term = Ut * d * cfg.inv_sigma[c];
+                ctrl += cfg.lambda * (cfg.noise_abs_cost ? fabsf(term) : term);
+            } else {
+                u[c] = 0.f;
+            }
+        }
+        {
+            CModel &m = *launder(mp);
+            static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
+                constexpr int i = ic;
+                float tg = 0.f;
+#pragma unroll
+                for (int c = 0; c < kMaxNu; c++)
+                    if (c < m.nu) tg += m.b[i].cmd[c] * u[c];
+                target[i] = qrep(tg);
+            });
+        }
+        quad_step<T>(*mp, root, q, qd, target);
+        S += disc * quad_stage_cost<T>(*launder(mp), *launder(kp), root, q);
+        disc *= cfg.gamma;
+        if (cfg.want_rollouts && viz != nullptr) {
+            CModel &m = *launder(mp);
+            QPose<T> P;
+            quad_base<T>(m, root, P);
+            quad_fk<T>(m, q, P);
+            QM3 R;
+            QF p;
+            quad_link_pose<T>(m, P, cfg.viz_link, R, p);
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (viz_lane) viz[((size_t)t * 3 + row) * K + k] = p;  // lane r stores component r
+#else
+            for (int r = 0; r < 3; r++) viz[((size_t)t * 3 + r) * K + k] = p.v[r];
+#endif
+        }
+    }
+    return S + ctrl;
+}
+
+}  // namespace mppi

@@ -369,7 +369,7 @@ MPPI_HD void aba_scene(CModel &m, const Pose<T> &P, const SV &vbase, const float
     static_rfor<0, NB>([&](auto ic) MPPI_LAMBDA {
         constexpr int i = ic;
         constexpr int par = T::par[i];
-        CBody &b = m.b[i];
+        const BodyK1 b = load_block<BodyK1>(m.b[i].k1);
         SV S = joint_subspace<T, i>(m, P);
         AI A;
         SV pA;
@@ -499,7 +499,7 @@ MPPI_HD void step_scene(CModel &m0, const float *root, SceneState<T> &s, const f
         bool any = false;
         static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
             constexpr int i = ic;
-            float lim = m.b[i].effort;
+            float lim = m.b[i].k1.effort;
             float tt = ff[i] + kd * (vs[i] - s.qd[i] - h * qdd[i]);
             if (lim > 0.f && fabsf(tt) > lim) {
                 any = true;
@@ -510,7 +510,7 @@ MPPI_HD void step_scene(CModel &m0, const float *root, SceneState<T> &s, const f
         if (any) aba_scene<T>(*launder(mp), P, vbase, s.qd, tau, kdh, L, qdd, abase);
         static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
             constexpr int i = ic;
-            CBody &b = m.b[i];
+            const BodyK1 b = load_block<BodyK1>(m.b[i].k1);
             float v = s.qd[i] + h * qdd[i];
             if (b.vmax > 0.f) v = fminf(fmaxf(v, -b.vmax), b.vmax);
             float x = s.q[i] + h * v;

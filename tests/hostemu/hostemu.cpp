@@ -8,6 +8,7 @@
 
 #include "../../mppi-isaac_amd/csrc/mppi_pack.hpp"
 #include "../../mppi-isaac_amd/csrc/mppi_scene.hpp"
+#include "../../mppi-isaac_amd/csrc/mppi_quad.hpp"
 
 using namespace mppi;
 
@@ -18,7 +19,7 @@ int emu_rollout(const mppi_model_t *model, const mppi_config_t *cfg, const mppi_
     DevModel m; DevCfg c; DevCost k; std::string err;
     if (!pack_model(*model, m, err) || !pack_config(*cfg, c, err) || !pack_cost(*cost, m, k, err)) return -1;
     int parents[MPPI_MAX_BODIES];
-    for (int i = 0; i < m.nb; i++) parents[i] = m.b[i].parent;
+    for (int i = 0; i < m.nb; i++) parents[i] = m.b[i].k0.parent;
     bool ok = dispatch_topology(m.nb, parents, [&](auto topo) {
         using T = decltype(topo);
         std::vector<float> v(viz ? (size_t)c.H * 3 * c.K : 0);
@@ -36,11 +37,35 @@ int emu_rollout(const mppi_model_t *model, const mppi_config_t *cfg, const mppi_
     return ok ? 0 : -3;
 }
 
+// quad-parallel rollout (csrc/mppi_quad.hpp) with the 4-lane quad emulated as a 4-float struct
+int emu_rollout_quad(const mppi_model_t *model, const mppi_config_t *cfg, const mppi_cost_t *cost, const float *dof0, const float *root0,
+                     const float *U, const float *eps, const float *prior, float *S, float *du, float *viz) {
+    DevModel m; DevCfg c; DevCost k; std::string err;
+    if (!pack_model(*model, m, err) || !pack_config(*cfg, c, err) || !pack_cost(*cost, m, k, err)) return -1;
+    if (is_scene(m)) return -4;
+    int parents[MPPI_MAX_BODIES];
+    for (int i = 0; i < m.nb; i++) parents[i] = m.b[i].k0.parent;
+    bool ok = dispatch_topology(m.nb, parents, [&](auto topo) {
+        using T = decltype(topo);
+        std::vector<float> v(viz ? (size_t)c.H * 3 * c.K : 0);
+        for (int s = 0; s < c.K; s++) {
+            QF r = quad_rollout<T>(m, c, k, dof0, root0, U, eps, prior, du, viz ? v.data() : nullptr, s, true, 0, true);
+            S[s] = r.v[0];
+            if (r.v[1] != r.v[0] || r.v[2] != r.v[0] || r.v[3] != r.v[0]) S[s] = NAN;  // replicated scalars must agree across the quad
+        }
+        if (viz)
+            for (int t = 0; t < c.H; t++)
+                for (int j = 0; j < 3; j++)
+                    for (int s = 0; s < c.K; s++) viz[((size_t)t * c.K + s) * 3 + j] = v[((size_t)t * 3 + j) * c.K + s];
+    });
+    return ok ? 0 : -3;
+}
+
 int emu_step(const mppi_model_t *model, const float *root, float *q, float *qd, const float *u) {
     DevModel m; std::string err;
     if (!pack_model(*model, m, err)) return -1;
     int parents[MPPI_MAX_BODIES];
-    for (int i = 0; i < m.nb; i++) parents[i] = m.b[i].parent;
+    for (int i = 0; i < m.nb; i++) parents[i] = m.b[i].k0.parent;
     bool ok = dispatch_topology(m.nb, parents, [&](auto topo) {
         using T = decltype(topo);
         float target[MPPI_MAX_BODIES], uu[kMaxNu] = {0};
@@ -55,7 +80,7 @@ int emu_rigid_body_state(const mppi_model_t *model, const float *root, const flo
     DevModel m; std::string err;
     if (!pack_model(*model, m, err)) return -1;
     int parents[MPPI_MAX_BODIES];
-    for (int i = 0; i < m.nb; i++) parents[i] = m.b[i].parent;
+    for (int i = 0; i < m.nb; i++) parents[i] = m.b[i].k0.parent;
     bool ok = dispatch_topology(m.nb, parents, [&](auto topo) {
         using T = decltype(topo);
         rigid_body_state<T>(m, root, q, qd, rb, cf);
@@ -68,7 +93,7 @@ int emu_scene_step(const mppi_model_t *model, float *dof, float *root, const flo
     DevModel m; std::string err;
     if (!pack_model(*model, m, err)) return -1;
     int parents[MPPI_MAX_BODIES];
-    for (int i = 0; i < m.nb; i++) parents[i] = m.b[i].parent;
+    for (int i = 0; i < m.nb; i++) parents[i] = m.b[i].k0.parent;
     bool ok = dispatch_topology(m.nb, parents, [&](auto topo) {
         using T = decltype(topo);
         std::vector<float> lmem(SceneLayout<T>::floats(m.n_rb));
@@ -91,7 +116,7 @@ float emu_cost(const mppi_model_t *model, const mppi_cost_t *cost, const float *
     DevModel m; DevCost k; std::string err;
     if (!pack_model(*model, m, err) || !pack_cost(*cost, m, k, err)) return -1e30f;
     int parents[MPPI_MAX_BODIES];
-    for (int i = 0; i < m.nb; i++) parents[i] = m.b[i].parent;
+    for (int i = 0; i < m.nb; i++) parents[i] = m.b[i].k0.parent;
     float out = -1e30f;
     dispatch_topology(m.nb, parents, [&](auto topo) {
         using T = decltype(topo);

@@ -78,3 +78,25 @@ def test_cross_sample_determinism(hostemu, oracle64):
     eps = np.repeat(oracle64.sample(cfg)[:, :, :1], 64, axis=2)
     S, du, _ = emu_rollout(hostemu, m, cfg, cost, dof, root, np.zeros((cfg.horizon, 7)), eps)
     assert np.all(S == S[0]) and np.all(du == du[:, :, :1])
+
+
+@pytest.mark.parametrize("make", [panda_reach, point_reach])
+def test_quad_parallel_rollout_matches_oracle(make, hostemu, oracle64):
+    """csrc/mppi_quad.hpp (one sample per 4-lane quad, DPP permutations emulated by array shuffles): same
+    trajectory costs as the oracle, and every replicated scalar identical across the four lanes."""
+    scene, m, cfg, cost, dof, root = make(K=96)
+    eps = oracle64.sample(cfg)
+    rng = np.random.default_rng(1)
+    U = 0.05 * rng.normal(size=(cfg.horizon, cfg.nu))
+    S, du, viz = oracle64.rollout(m, cfg, cost, dof, root, U, eps, want_viz=True)
+    Se = np.zeros(cfg.num_samples, np.float32)
+    due = np.zeros_like(f32(eps))
+    vize = np.zeros((cfg.horizon, cfg.num_samples, 3), np.float32) if cfg.want_rollouts else None
+    rc = hostemu.emu_rollout_quad(C.byref(m), C.byref(cfg), C.byref(cost), fp(f32(dof)), fp(f32(root)), fp(f32(U)), fp(f32(eps)), None,
+                                  fp(Se), fp(due), fp(vize))
+    assert rc == 0
+    assert not np.isnan(Se).any()                       # NaN marks a quad whose lanes disagreed
+    np.testing.assert_allclose(Se, S, rtol=2e-5)
+    np.testing.assert_allclose(due, du, atol=1e-6)
+    if vize is not None:
+        np.testing.assert_allclose(vize, viz, atol=2e-5)
