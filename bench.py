@@ -135,12 +135,10 @@ def main():
         if world_size > 1:
             capi.check(lib, lib.mppi_reduce(P, ctypes.c_void_p(records[rank].data_ptr())))
             dist.all_gather_into_tensor(records.view(-1), records[rank].clone())
-            capi.check(lib, lib.mppi_update(P, ctypes.c_void_p(records.data_ptr()), world_size))
+            capi.check(lib, lib.mppi_update_step_world(P, ctypes.c_void_p(records.data_ptr()), world_size, W))
         else:
             capi.check(lib, lib.mppi_reduce(P, None))
-            capi.check(lib, lib.mppi_update(P, None, 1))
-        capi.check(lib, lib.mppi_world_step_from(W, P))
-        capi.check(lib, lib.mppi_set_state_from_world(P, W))
+            capi.check(lib, lib.mppi_update_step_world(P, None, 1, W))  # update + world step + state feedback
         if sync:
             capi.check(lib, lib.mppi_get_action(P, ap_))  # D2H + stream sync: the controller output
 

@@ -238,6 +238,8 @@ int mppi_sim_finish(mppi_ctx_t *ctx);                      /* S += control cost 
 /* device-resident closed loop: step a K=1 world with the planner's action, feed its state back */
 int mppi_world_step_from(mppi_ctx_t *world, mppi_ctx_t *planner);
 int mppi_set_state_from_world(mppi_ctx_t *planner, mppi_ctx_t *world);
+/* mppi_update + mppi_world_step_from + mppi_set_state_from_world; one kernel for fixed-base contact-free scenes */
+int mppi_update_step_world(mppi_ctx_t *planner, const float *records_dev, int n_records, mppi_ctx_t *world);
 
 /* ---- instrumentation (reference has only print(FPS), examples/panda/world.py:53-59) */
 int mppi_set_profiling(mppi_ctx_t *ctx, int on);            /* bracket every launch with hipEvents on the context's stream */

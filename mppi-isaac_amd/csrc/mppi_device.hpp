@@ -42,6 +42,9 @@ constexpr int kMaxPairs = 48;
 constexpr int kMaxFree = 2;
 
 // ---- device-side model (fp32, z-framed) ------------------------------------------------
+struct CmdBlock {
+    float v[16];
+};
 // Three 64-byte blocks, each fetched with ONE s_load_dwordx16 where it is used (load_block below):
 // block 0 = kinematics, block 1 = inertia + limits, block 2 = command map row.
 struct BodyK0 {
@@ -59,8 +62,7 @@ struct BodyK1 {
 struct alignas(64) DevBody {
     BodyK0 k0;
     BodyK1 k1;
-    float cmd[kMaxNu];  // dense row of the command map: target_i = sum_c cmd[c] * u[c]
-    float pad2[16 - kMaxNu];
+    CmdBlock cmd;  // dense row of the command map: target_i = sum_c cmd[c] * u[c]  (zero beyond nu)
 };
 static_assert(sizeof(BodyK0) == 64 && sizeof(BodyK1) == 64 && sizeof(DevBody) == 192, "DevBody block layout");
 struct DevLink {
@@ -102,11 +104,15 @@ struct DevModel {
     DevShape sh[kMaxShapes];
     DevPair pr[kMaxPairs];
 };
-struct DevCfg {
+struct CtrlBlock {  // one 64-byte block per quantity: fetched with a single s_load_dwordx16
+    float v[16];
+};
+struct alignas(64) DevCfg {
     int K, H, nu, k_offset, k_total, sample_null_action, use_priors, noise_abs_cost, want_rollouts, viz_link, pad[2];
     float lambda, inv_lambda, gamma, u_init;
-    float u_min[kMaxNu], u_max[kMaxNu], inv_sigma[kMaxNu];  // inv_sigma = 1 / noise_sigma[c][c]
+    CtrlBlock u_min, u_max, inv_sigma;  // per control dimension, zero beyond nu; inv_sigma = 1 / noise_sigma[c][c]
 };
+
 struct DevCost {
     int kind, link[4], actor[6], pad;
     float w[16];
@@ -139,13 +145,31 @@ typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x16 __attribute__((vector_size(64)));
 #endif
 template <class B, class S>
-MPPI_HD B load_block(S &src) {
+MPPI_HD B load_block(const MPPI_CONST_AS S &src) {
     static_assert(sizeof(B) == 64 && sizeof(S) == 64, "64-byte blocks only");
     const u32x16 v = *reinterpret_cast<const MPPI_CONST_AS u32x16 *>(&src);
     B out;
     __builtin_memcpy(&out, &v, 64);
     return out;
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+// the same block from an LDS copy of the model: four ds_read_b128 (every lane reads the same address ->
+// broadcast), in-order returns, VGPR operands (no SGPR constant-bus limit, no SGPR spills)
+#define MPPI_LDS_AS __attribute__((address_space(3)))
+template <class B, class S>
+__device__ __forceinline__ B load_block(const MPPI_LDS_AS S &src) {
+    static_assert(sizeof(B) == 64 && sizeof(S) == 64, "64-byte blocks only");
+    const u32x16 v = *reinterpret_cast<const MPPI_LDS_AS u32x16 *>(&src);
+    B out;
+    __builtin_memcpy(&out, &v, 64);
+    return out;
+}
+typedef const MPPI_LDS_AS DevModel LModel;
+__device__ __forceinline__ LModel *launder(LModel *p) {
+    asm volatile("" : "+v"(p));
+    return p;
+}
+#endif
 
 template <class P>
 MPPI_HD P *launder(P *p) {
@@ -288,6 +312,38 @@ MPPI_HD void rank1_sub(AI &A, SV U, float s) {
     A.H[3] -= U.a.y * f.x; A.H[4] -= U.a.y * f.y; A.H[5] -= U.a.y * f.z;
     A.H[6] -= U.a.z * f.x; A.H[7] -= U.a.z * f.y; A.H[8] -= U.a.z * f.z;
     A.M.xx -= U.l.x * f.x; A.M.xy -= U.l.x * f.y; A.M.xz -= U.l.x * f.z; A.M.yy -= U.l.y * f.y; A.M.yz -= U.l.y * f.z; A.M.zz -= U.l.z * f.z;
+}
+
+// Controls of horizon step t for sample k: u = clamp(U_t + eps), effective perturbation du = u - U_t
+// (stored by `leader` lanes), control-cost increment.  All loads are issued before the first use so the
+// wave waits once, not once per control dimension; everything is branch-free over the padded kMaxNu.
+MPPI_HD float sample_controls(CCfg &cfg, const float *U, const float *eps, const float *prior, int t, int k, bool is_null, bool is_prior,
+                              bool leader, float *du, float *u) {
+    const int K = cfg.K, nu = cfg.nu;
+    float Ut[kMaxNu], e[kMaxNu], pr[kMaxNu];
+#pragma unroll
+    for (int c = 0; c < kMaxNu; c++) {
+        const int cc = c < nu ? c : nu - 1;  // keep the address valid; the lane is masked below
+        Ut[c] = U[t * nu + cc];
+        e[c] = eps[(size_t)(t * nu + cc) * K + k];
+        pr[c] = is_prior ? prior[t * nu + cc] : 0.f;
+    }
+    const CtrlBlock lo = load_block<CtrlBlock>(cfg.u_min), hi = load_block<CtrlBlock>(cfg.u_max), is = load_block<CtrlBlock>(cfg.inv_sigma);
+    float ctrl = 0.f;
+#pragma unroll
+    for (int c = 0; c < kMaxNu; c++) {
+        float v = Ut[c] + e[c];
+        if (is_null) v = 0.f;
+        if (is_prior) v = pr[c];
+        v = fminf(fmaxf(v, lo.v[c]), hi.v[c]);
+        const bool on = c < nu;
+        u[c] = on ? v : 0.f;
+        const float d = v - Ut[c];
+        if (on && leader) du[(size_t)(t * nu + c) * K + k] = d;
+        const float term = Ut[c] * d * is.v[c];  // inv_sigma is zero beyond nu
+        ctrl += cfg.lambda * (cfg.noise_abs_cost ? fabsf(term) : term);
+    }
+    return ctrl;
 }
 
 // World pose of every moving body for joint positions q (z-framed joints).
@@ -480,11 +536,10 @@ template <class T>
 MPPI_HD void cmd_map(CModel &m, const float *u, float *target) {
     static_for<0, T::NB>([&](auto ic) MPPI_LAMBDA {
         constexpr int i = ic;
-        CBody &b = m.b[i];
+        const CmdBlock b = load_block<CmdBlock>(m.b[i].cmd);
         float t = 0.f;
 #pragma unroll
-        for (int c = 0; c < kMaxNu; c++)
-            if (c < m.nu) t += b.cmd[c] * u[c];
+        for (int c = 0; c < kMaxNu; c++) t += b.v[c] * u[c];  // rows and u are zero beyond nu
         target[i] = t;
     });
 }
@@ -610,23 +665,7 @@ MPPI_HD float rollout_sample(CModel &m0, CCfg &cfg0, CCost &cost0, const float *
     CCost *kp = &cost0;
     for (int t = 0; t < H; t++) {
         CCfg &cfg = *launder(cp);
-#pragma unroll
-        for (int c = 0; c < kMaxNu; c++) {
-            if (c < nu) {
-                float Ut = U[t * nu + c];
-                float v = Ut + eps[(size_t)(t * nu + c) * K + k];
-                if (is_null) v = 0.f;
-                if (is_prior) v = prior[t * nu + c];
-                v = fminf(fmaxf(v, cfg.u_min[c]), cfg.u_max[c]);
-                u[c] = v;
-                float d = v - Ut;
-                du[(size_t)(t * nu + c) * K + k] = d;
-                float term = Ut * d * cfg.inv_sigma[c];
-                ctrl += cfg.lambda * (cfg.noise_abs_cost ? fabsf(term) : term);
-            } else {
-                u[c] = 0.f;
-            }
-        }
+        ctrl += sample_controls(cfg, U, eps, prior, t, k, is_null, is_prior, true, du, u);
         cmd_map<T>(*launder(mp), u, target);
         step<T>(*mp, root, q, qd, target);
         S += disc * stage_cost<T>(*launder(mp), *launder(kp), root, q, qd);

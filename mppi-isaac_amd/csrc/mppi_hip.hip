@@ -14,6 +14,7 @@
 // Buffers are sample-minor so every per-sample access of a wave is one coalesced 256-B request.
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -133,72 +134,88 @@ __global__ __launch_bounds__(kWave) void k_rollout_quad(const DevModel *__restri
                                                         float *__restrict__ du, float *__restrict__ S, float *__restrict__ viz,
                                                         float *__restrict__ partials) {
 #if defined(__HIP_DEVICE_COMPILE__)  // (the host pass sees the 4-float emulation type of mppi_quad.hpp)
+    // Stage the robot model (header + body + link blocks, ~4 KB) in LDS once per wavefront: constants are then
+    // fetched with in-order ds_read_b128 broadcasts into VGPRs - no SMEM round trip (s_waitcnt lgkmcnt(0) on
+    // every block), no SGPR spills, no constant-bus moves.
+    constexpr int kModelBytes = (int)((offsetof(DevModel, fr) + 15) / 16 * 16);
+    __shared__ __attribute__((aligned(64))) uint4 s_model[kModelBytes / 16];
+    for (int i = threadIdx.x; i < kModelBytes / 16; i += kWave) s_model[i] = reinterpret_cast<const uint4 *>(m)[i];
+    __syncthreads();
+    LModel &lm = *(LModel *)s_model;
     const int k = (blockIdx.x * kWave + threadIdx.x) >> 2;
     const int lane4 = threadIdx.x & 3;
     const bool live = k < cfg->K;        // the four lanes of a quad share k
     const bool leader = lane4 == 0;
     float s = INFINITY;
     if (live) {
-        s = quad_rollout<T>(*(CModel *)m, *(CCfg *)cfg, *(CCost *)cost, x0_dof, x0_root, U, eps, prior, du, viz, k, leader, quad_row(), lane4 < 3);
+        s = quad_rollout<T>(lm, *(CCfg *)cfg, *(CCost *)cost, x0_dof, x0_root, U, eps, prior, du, viz, k, leader, quad_row(), lane4 < 3);
         if (leader) S[k] = s;
     }
     wave_record(*(CCfg *)cfg, s, live && leader, du, k, partials + (size_t)blockIdx.x * (2 + cfg->H * cfg->nu));
 #endif
 }
 
-// Combine n records; mode 0: write the combined record to `out`; mode 1: U += N/eta, action, shift.
-__global__ __launch_bounds__(256) void k_combine(const DevCfg *__restrict__ cfg, const float *__restrict__ recs, int nrec, int mode,
-                                                 float *__restrict__ out, float *__restrict__ U, float *__restrict__ action,
-                                                 float *__restrict__ beta_eta) {
-    __shared__ float s_red[256];
-    __shared__ float s_U[MPPI_MAX_H * MPPI_MAX_NU];
-    constexpr int kMaxScale = 2048;
+// Combine n records (1024 threads): beta = min, eta and N rescaled by e^{-(beta_r-beta)/lambda}.
+// mode 0: write the combined record to `out`; mode 1: U += N/eta, action = U[0], shift U, append u_init.
+// The record sum over r is split over four 256-thread groups (r mod 4) with two accumulators each.
+constexpr int kCombineThreads = 1024;
+__device__ __forceinline__ void combine_update(CCfg &cfg, const float *__restrict__ recs, int nrec, int mode, float *__restrict__ out,
+                                               float *__restrict__ U, float *__restrict__ action, float *__restrict__ beta_eta, float *s_act) {
+    __shared__ float s_red[kCombineThreads];
+    __shared__ float s_part[4][MPPI_MAX_H * MPPI_MAX_NU];
+    constexpr int kMaxScale = 4096;
     __shared__ float s_scale[kMaxScale];
-    const int HN = cfg->H * cfg->nu, RF = 2 + HN, nu = cfg->nu;
+    const int HN = cfg.H * cfg.nu, RF = 2 + HN, nu = cfg.nu;
     const int tid = threadIdx.x;
     float b = INFINITY;
-    for (int r = tid; r < nrec; r += 256)
+    for (int r = tid; r < nrec; r += kCombineThreads)
         if (recs[(size_t)r * RF + 1] > 0.f) b = fminf(b, recs[(size_t)r * RF]);
     s_red[tid] = b;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
+    for (int o = kCombineThreads / 2; o > 0; o >>= 1) {
         if (tid < o) s_red[tid] = fminf(s_red[tid], s_red[tid + o]);
         __syncthreads();
     }
     const float beta = s_red[0];
     __syncthreads();
-    // scale factor of every record: e^{-(beta_r - beta)/lambda} (0 for empty records), staged in LDS
     float e = 0.f;
-    for (int r = tid; r < nrec; r += 256) {
-        float er = recs[(size_t)r * RF + 1];
-        float sc = er > 0.f ? __expf(-(recs[(size_t)r * RF] - beta) * cfg->inv_lambda) : 0.f;
+    for (int r = tid; r < nrec; r += kCombineThreads) {
+        const float er = recs[(size_t)r * RF + 1];
+        const float sc = er > 0.f ? __expf(-(recs[(size_t)r * RF] - beta) * cfg.inv_lambda) : 0.f;
         if (r < kMaxScale) s_scale[r] = sc;
         e += er * sc;
     }
     s_red[tid] = e;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
+    for (int o = kCombineThreads / 2; o > 0; o >>= 1) {
         if (tid < o) s_red[tid] += s_red[tid + o];
         __syncthreads();
     }
     const float eta = s_red[0];
-    for (int j = tid; j < HN; j += 256) {
+    const int g = tid >> 8, jj = tid & 255;
+    for (int j = jj; j < HN; j += 256) {
         float N0 = 0.f, N1 = 0.f;
-        int r = 0;
-        const int nfast = nrec < kMaxScale ? nrec : kMaxScale;
-        for (; r + 2 <= nfast; r += 2) {
-            N0 += recs[(size_t)r * RF + 2 + j] * s_scale[r];
-            N1 += recs[(size_t)(r + 1) * RF + 2 + j] * s_scale[r + 1];
+        int r = g;
+        for (; r + 4 < nrec; r += 8) {
+            const float s0 = r < kMaxScale ? s_scale[r] : 0.f, s1 = r + 4 < kMaxScale ? s_scale[r + 4] : 0.f;
+            N0 += recs[(size_t)r * RF + 2 + j] * s0;
+            N1 += recs[(size_t)(r + 4) * RF + 2 + j] * s1;
         }
-        for (; r < nrec; r++) {
-            float er = recs[(size_t)r * RF + 1];
-            float sc = r < kMaxScale ? s_scale[r] : (er > 0.f ? __expf(-(recs[(size_t)r * RF] - beta) * cfg->inv_lambda) : 0.f);
-            N0 += recs[(size_t)r * RF + 2 + j] * sc;
-        }
-        const float N = N0 + N1;
-        if (mode == 0) out[2 + j] = N;
-        else s_U[j] = U[j] + (eta > 0.f ? N / eta : 0.f);
+        for (; r < nrec; r += 4) N0 += recs[(size_t)r * RF + 2 + j] * (r < kMaxScale ? s_scale[r] : 0.f);
+        s_part[g][j] = N0 + N1;
     }
+    __syncthreads();
+    float *s_U = s_part[0];  // reused for the updated nominal after the group sums are consumed
+    float Unew = 0.f;
+    if (tid < 256)
+        for (int j = tid; j < HN; j += 256) {
+            const float N = (s_part[0][j] + s_part[1][j]) + (s_part[2][j] + s_part[3][j]);
+            if (mode == 0) out[2 + j] = N;
+            else {
+                Unew = U[j] + (eta > 0.f ? N / eta : 0.f);
+                s_part[1][j] = Unew;  // staging row distinct from the one read above
+            }
+        }
     if (mode == 0) {
         if (tid == 0) {
             out[0] = beta;
@@ -207,12 +224,61 @@ __global__ __launch_bounds__(256) void k_combine(const DevCfg *__restrict__ cfg,
         return;
     }
     __syncthreads();
-    if (tid < nu) action[tid] = s_U[tid];
+    s_U = s_part[1];
+    if (tid < nu) {
+        action[tid] = s_U[tid];
+        if (s_act != nullptr) s_act[tid] = s_U[tid];
+    }
     if (tid == 0) {
         beta_eta[0] = beta;
         beta_eta[1] = eta;
     }
-    for (int j = tid; j < HN; j += 256) U[j] = (j + nu < HN) ? s_U[j + nu] : cfg->u_init;  // shift, append u_init
+    for (int j = tid; j < HN; j += kCombineThreads) U[j] = (j + nu < HN) ? s_U[j + nu] : cfg.u_init;  // shift, append u_init
+}
+
+__global__ __launch_bounds__(kCombineThreads) void k_combine(const DevCfg *__restrict__ cfg, const float *__restrict__ recs, int nrec, int mode,
+                                                             float *__restrict__ out, float *__restrict__ U, float *__restrict__ action,
+                                                             float *__restrict__ beta_eta) {
+    combine_update(*(CCfg *)cfg, recs, nrec, mode, out, U, action, beta_eta, nullptr);
+}
+
+// Closed-loop tail in ONE launch: combine + nominal update, then the K = 1 world is stepped with the new
+// action by one quad of the same workgroup and its state becomes the planner's next x0
+// (replaces k_combine + k_sim_step + k_state_from_world; fixed-base contact-free scenes only).
+template <class T>
+__global__ __launch_bounds__(kCombineThreads) void k_combine_world(const DevCfg *__restrict__ cfg, const float *__restrict__ recs, int nrec,
+                                                                   float *__restrict__ U, float *__restrict__ action, float *__restrict__ beta_eta,
+                                                                   const DevModel *__restrict__ wm, const float *__restrict__ w_root,
+                                                                   float *__restrict__ wq, float *__restrict__ wqd, float *__restrict__ x0_dof) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ float s_act[MPPI_MAX_NU];
+    combine_update(*(CCfg *)cfg, recs, nrec, 1, nullptr, U, action, beta_eta, s_act);
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        constexpr int NB = T::NB;
+        CModel &M = *(CModel *)wm;
+        QF q[NB ? NB : 1], qd[NB ? NB : 1], target[NB ? NB : 1];
+        static_for<0, NB>([&](auto ic) {
+            constexpr int i = ic;
+            q[i] = wq[i];
+            qd[i] = wqd[i];
+            const CmdBlock b = load_block<CmdBlock>(M.b[i].cmd);
+            float tg = 0.f;
+#pragma unroll
+            for (int c = 0; c < kMaxNu; c++) tg += b.v[c] * (c < M.nu ? s_act[c] : 0.f);
+            target[i] = tg;
+        });
+        quad_step<T>(M, w_root, q, qd, target);
+        if (threadIdx.x == 0)
+            static_for<0, NB>([&](auto ic) {
+                constexpr int i = ic;
+                wq[i] = q[i];
+                wqd[i] = qd[i];
+                x0_dof[2 * i] = q[i];
+                x0_dof[2 * i + 1] = qd[i];
+            });
+    }
+#endif
 }
 
 // ---- contact scenes (floating base, free bodies, penalty contact): per-lane working set in LDS ----
@@ -272,10 +338,10 @@ __global__ __launch_bounds__(kWave) void k_sim_step_scene(const DevModel *__rest
                 v = Ut + eps[(size_t)(t * nu + c) * K + k];
                 if (cfg->sample_null_action && g == cfg->k_total - 1) v = 0.f;
                 if (cfg->use_priors && prior != nullptr && g == cfg->k_total - 2) v = prior[t * nu + c];
-                v = fminf(fmaxf(v, cfg->u_min[c]), cfg->u_max[c]);
+                v = fminf(fmaxf(v, cfg->u_min.v[c]), cfg->u_max.v[c]);
                 float d = v - Ut;
                 du[(size_t)(t * nu + c) * K + k] = d;
-                float term = Ut * d * cfg->inv_sigma[c];
+                float term = Ut * d * cfg->inv_sigma.v[c];
                 cc += cfg->lambda * (cfg->noise_abs_cost ? fabsf(term) : term);
             }
         }
@@ -431,10 +497,10 @@ __global__ __launch_bounds__(kWave) void k_sim_step(const DevModel *__restrict__
                 v = Ut + eps[(size_t)(t * nu + c) * K + k];
                 if (cfg->sample_null_action && g == cfg->k_total - 1) v = 0.f;
                 if (cfg->use_priors && prior != nullptr && g == cfg->k_total - 2) v = prior[t * nu + c];
-                v = fminf(fmaxf(v, cfg->u_min[c]), cfg->u_max[c]);
+                v = fminf(fmaxf(v, cfg->u_min.v[c]), cfg->u_max.v[c]);
                 float d = v - Ut;
                 du[(size_t)(t * nu + c) * K + k] = d;
-                float term = Ut * d * cfg->inv_sigma[c];
+                float term = Ut * d * cfg->inv_sigma.v[c];
                 cc += cfg->lambda * (cfg->noise_abs_cost ? fabsf(term) : term);
             }
         }
@@ -526,6 +592,7 @@ struct mppi_ctx {
     void (*launch_rollout)(mppi_ctx *) = nullptr;
     void (*launch_sim_step)(mppi_ctx *, int, int, const float *) = nullptr;
     void (*launch_materialise)(mppi_ctx *, float *, float *, float *, float *) = nullptr;
+    void (*launch_combine_world)(mppi_ctx *, const float *, int, mppi_ctx *) = nullptr;  // fused closed-loop tail (quad scenes)
     std::string topo;
 };
 
@@ -558,6 +625,11 @@ template <class T>
 void launch_rollout_quad_t(mppi_ctx *c) {
     hipLaunchKernelGGL(k_rollout_quad<T>, dim3(c->n_quads), dim3(kWave), 0, c->stream, c->d_model, c->d_cfg, c->d_cost, c->d_x0_dof, c->d_x0_root,
                        c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_S, c->cfg.want_rollouts ? c->d_viz : nullptr, c->d_partials);
+}
+template <class T>
+void launch_combine_world_t(mppi_ctx *p, const float *recs, int n, mppi_ctx *w) {
+    hipLaunchKernelGGL(k_combine_world<T>, dim3(1), dim3(kCombineThreads), 0, p->stream, p->d_cfg, recs, n, p->d_U, p->d_action, p->d_beta_eta,
+                       w->d_model, w->d_x0_root, w->d_q, w->d_qd, p->d_x0_dof);
 }
 template <class T>
 void launch_rollout_t(mppi_ctx *c) {
@@ -672,6 +744,7 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
             const char *mode = std::getenv("MPPI_ROLLOUT");
             c->quad = !(mode && std::string(mode) == "lane");
             c->launch_rollout = c->quad ? &launch_rollout_quad_t<T> : &launch_rollout_t<T>;
+            c->launch_combine_world = &launch_combine_world_t<T>;
             c->launch_sim_step = &launch_sim_step_t<T>;
             c->launch_materialise = &launch_materialise_t<T>;
         }
@@ -855,14 +928,14 @@ int mppi_reduce(mppi_ctx_t *c, float *record_out_dev) {
         c->n_partials = c->n_waves;
     }
     if (record_out_dev)  // one shard record for the cross-GPU all-gather
-        hipLaunchKernelGGL(k_combine, dim3(1), dim3(256), 0, c->stream, c->d_cfg, c->d_partials, c->n_partials, 0, record_out_dev, c->d_U, c->d_action,
+        hipLaunchKernelGGL(k_combine, dim3(1), dim3(kCombineThreads), 0, c->stream, c->d_cfg, c->d_partials, c->n_partials, 0, record_out_dev, c->d_U, c->d_action,
                            c->d_beta_eta);
     return launch_check();
 }
 int mppi_record_floats(const mppi_ctx_t *c) { return c ? c->RF : 0; }
 int mppi_record_dev(mppi_ctx_t *c, float **record_dev) {
     CTX_TRY(c);
-    hipLaunchKernelGGL(k_combine, dim3(1), dim3(256), 0, c->stream, c->d_cfg, c->d_partials, c->n_partials, 0, c->d_record, c->d_U, c->d_action, c->d_beta_eta);
+    hipLaunchKernelGGL(k_combine, dim3(1), dim3(kCombineThreads), 0, c->stream, c->d_cfg, c->d_partials, c->n_partials, 0, c->d_record, c->d_U, c->d_action, c->d_beta_eta);
     *record_dev = c->d_record;
     return launch_check();
 }
@@ -873,7 +946,27 @@ int mppi_update(mppi_ctx_t *c, const float *records_dev, int n_records) {
     if (n < 1) return fail(MPPI_EINVAL, "n_records < 1");
     {
         EvScope ev(c, 2);
-        hipLaunchKernelGGL(k_combine, dim3(1), dim3(256), 0, c->stream, c->d_cfg, recs, n, 1, (float *)nullptr, c->d_U, c->d_action, c->d_beta_eta);
+        hipLaunchKernelGGL(k_combine, dim3(1), dim3(kCombineThreads), 0, c->stream, c->d_cfg, recs, n, 1, (float *)nullptr, c->d_U, c->d_action, c->d_beta_eta);
+    }
+    return launch_check();
+}
+/* closed-loop tail: mppi_update + mppi_world_step_from + mppi_set_state_from_world, one launch where possible */
+int mppi_update_step_world(mppi_ctx_t *c, const float *records_dev, int n_records, mppi_ctx_t *world) {
+    CTX_TRY(c);
+    if (!world || world->K != 1 || world->n != c->n || world->A != c->A || world->device != c->device)
+        return fail(MPPI_EINVAL, "world must be a K=1 context of the same scene on the same device");
+    if (c->launch_combine_world == nullptr || c->scene || world->scene) {  // contact scenes: three launches
+        int rc;
+        if ((rc = mppi_update(c, records_dev, n_records))) return rc;
+        if ((rc = mppi_world_step_from(world, c))) return rc;
+        return mppi_set_state_from_world(c, world);
+    }
+    const float *recs = records_dev ? records_dev : c->d_partials;
+    const int n = records_dev ? n_records : c->n_partials;
+    if (n < 1) return fail(MPPI_EINVAL, "n_records < 1");
+    {
+        EvScope ev(c, 2);
+        c->launch_combine_world(c, recs, n, world);
     }
     return launch_check();
 }

@@ -89,7 +89,9 @@ inline QF qwhere_lt(QF a, QF b, QF x, QF y) { QF o; for (int i = 0; i < 4; i++) 
 // sum over the three components, taken from lane 0 so that replicated scalars (d, u, qdd, costs) are
 // bit-identical across the quad whatever the summation order of each lane would have been
 MPPI_HD QF qsum(QF x) { return bc<0>(x + rot1(x) + rot2(x)); }
-MPPI_HD QF qcross(QF a, QF b) { return rot1(a) * rot2(b) - rot2(a) * rot1(b); }
+// (a x b)_r = t_{r+1} with t_r = a_r b_{r+1} - a_{r+1} b_r: three permutations instead of four, two of
+// them foldable into the multiply as DPP source modifiers
+MPPI_HD QF qcross(QF a, QF b) { return rot1(a * rot1(b) - rot1(a) * b); }
 
 struct QSV {  // spatial vector (world axes, about the world origin), one component per lane
     QF a, l;
@@ -120,12 +122,17 @@ struct QPose {
     QF pb;
 };
 
-template <class T>
-MPPI_HD void quad_fk(CModel &m, const QF *q, QPose<T> &P) {
+template <class T, class M>
+MPPI_HD void quad_fk(M &m, const QF *q, QPose<T> &P) {
+    // the 64-byte constant block of body i+1 is requested before body i is computed, so its scalar-load
+    // latency hides under ~100 VALU instructions instead of stalling the (only) wave of this SIMD
+    BodyK0 blk[2];
+    if constexpr (T::NB > 0) blk[0] = load_block<BodyK0>(m.b[0].k0);
     static_for<0, T::NB>([&](auto ic) MPPI_LAMBDA {
         constexpr int i = ic;
         constexpr int par = T::par[i];
-        const BodyK0 b = load_block<BodyK0>(m.b[i].k0);
+        if constexpr (i + 1 < T::NB) blk[(i + 1) & 1] = load_block<BodyK0>(m.b[i + 1].k0);
+        const BodyK0 &b = blk[i & 1];
         P.jt[i] = b.jtype;
         const QM3 &Rp = par < 0 ? P.Rb : P.R[par < 0 ? 0 : par];
         const QF pp = par < 0 ? P.pb : P.p[par < 0 ? 0 : par];
@@ -154,8 +161,13 @@ MPPI_HD QSV quad_subspace(const QPose<T> &P) {
 }
 
 // Articulated-body solve, quad-parallel.  tau/kdh/qd/qdd are replicated scalars (same in all lanes of a quad).
-template <class T>
-MPPI_HD void quad_aba(CModel &m, const QPose<T> &P, const QF *qd, const QF *tau_exp, const QF *kdh, QF *qdd) {
+struct JointLimits {  // wave-uniform per-joint limits, cached from block 1 while the ABA has it in SGPRs
+    float effort, lower, upper, vmax;
+    int limited;
+};
+
+template <class T, class M>
+MPPI_HD void quad_aba(M &m, const QPose<T> &P, const QF *qd, const QF *tau_exp, const QF *kdh, QF *qdd, JointLimits *lim) {
     constexpr int NB = T::NB;
     QSV v[NB], U[NB], pacc[NB];
     QAI acc[NB];
@@ -170,10 +182,14 @@ MPPI_HD void quad_aba(CModel &m, const QPose<T> &P, const QF *qd, const QF *tau_
         else v[i] = {v[par < 0 ? 0 : par].a + sj.a, v[par < 0 ? 0 : par].l + sj.l};
         has_acc[i] = false;
     });
+    BodyK1 blk[2];
+    if constexpr (NB > 0) blk[(NB - 1) & 1] = load_block<BodyK1>(m.b[NB - 1].k1);
     static_rfor<0, NB>([&](auto ic) MPPI_LAMBDA {
         constexpr int i = ic;
         constexpr int par = T::par[i];
-        const BodyK1 b = load_block<BodyK1>(m.b[i].k1);
+        if constexpr (i > 0) blk[(i - 1) & 1] = load_block<BodyK1>(m.b[i - 1].k1);  // prefetch the next body's block
+        const BodyK1 &b = blk[i & 1];
+        lim[i] = {b.effort, b.lower, b.upper, b.vmax, b.limited};
         const QM3 &R = P.R[i];
         const QSV S = quad_subspace<T, i>(P);
         // rigid inertia about the world origin: I_O = R Ic R^T + m(|cw|^2 1 - cw cw^T), h = m cw
@@ -252,49 +268,50 @@ MPPI_HD void quad_aba(CModel &m, const QPose<T> &P, const QF *qd, const QF *tau_
 }
 
 // base pose of the (fixed) robot from its root row, distributed over the quad
-template <class T>
-MPPI_HD void quad_base(CModel &m, const float *root, QPose<T> &P) {
+template <class T, class M>
+MPPI_HD void quad_base(M &m, const float *root, QPose<T> &P) {
     const float *rs = root + 13 * m.robot_actor;
     const M3 R = quat_to_R(rs + 3);
     P.pb = qsel(rs[0], rs[1], rs[2]);
     for (int c = 0; c < 3; c++) P.Rb.c[c] = qsel(R.a[c], R.a[3 + c], R.a[6 + c]);
 }
 
-template <class T>
-MPPI_HD void quad_step(CModel &m0, const float *root, QF *q, QF *qd, const QF *target) {
+template <class T, class M>
+MPPI_HD void quad_step(M &m0, const float *root, QF *q, QF *qd, const QF *target) {
     constexpr int NB = T::NB;
-    CModel *mp = &m0;
+    M *mp = &m0;
     for (int s = 0; s < m0.substeps; s++) {
-        CModel &m = *launder(mp);
+        M &m = *launder(mp);
         const float h = m.h, kd = m.kd;
         QPose<T> P;
         quad_base<T>(m, root, P);
         quad_fk<T>(m, q, P);
-        QF tau[NB], kdh[NB], qdd[NB], ff[NB], vs[NB], eff[NB];
+        QF tau[NB], kdh[NB], qdd[NB], ff[NB], vs[NB];
+        JointLimits lim[NB];
+        const int drive_mode = m.drive_mode;
         static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
             constexpr int i = ic;
-            ff[i] = m.drive_mode == kDriveEffort ? target[i] : qrep(0.f);
-            vs[i] = m.drive_mode == kDriveVelocity ? target[i] : qrep(0.f);
+            ff[i] = drive_mode == kDriveEffort ? target[i] : qrep(0.f);
+            vs[i] = drive_mode == kDriveVelocity ? target[i] : qrep(0.f);
             tau[i] = ff[i] + kd * (vs[i] - qd[i]);
             kdh[i] = qrep(kd * h);
-            eff[i] = qrep(m.b[i].k1.effort);
         });
-        quad_aba<T>(m, P, qd, tau, kdh, qdd);
+        quad_aba<T>(m, P, qd, tau, kdh, qdd, lim);
         bool any = false;
         static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
             constexpr int i = ic;
             const QF tt = ff[i] + kd * (vs[i] - qd[i] - h * qdd[i]);
-            const bool lim_on = m.b[i].k1.effort > 0.f;
-            if (lim_on && qany_gt(qabs(tt), eff[i])) {
+            const QF eff = qrep(lim[i].effort);
+            if (lim[i].effort > 0.f && qany_gt(qabs(tt), eff)) {
                 any = true;
-                tau[i] = qwhere_gt(tt, qrep(0.f), eff[i], -eff[i]);
+                tau[i] = qwhere_gt(tt, qrep(0.f), eff, -eff);
                 kdh[i] = qrep(0.f);
             }
         });
-        if (any) quad_aba<T>(*launder(mp), P, qd, tau, kdh, qdd);
+        if (any) quad_aba<T>(*launder(mp), P, qd, tau, kdh, qdd, lim);
         static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
             constexpr int i = ic;
-            const BodyK1 b = load_block<BodyK1>(m.b[i].k1);
+            const JointLimits b = lim[i];
             QF v = qd[i] + h * qdd[i];
             if (b.vmax > 0.f) v = qmin(qmax(v, qrep(-b.vmax)), qrep(b.vmax));
             QF x = q[i] + h * v;
@@ -312,9 +329,9 @@ MPPI_HD void quad_step(CModel &m0, const float *root, QF *q, QF *qd, const QF *t
 }
 
 // world pose of link l: row r of R (standard) and component r of p
-template <class T>
-MPPI_HD void quad_link_pose(CModel &m, const QPose<T> &P, int l, QM3 &R, QF &p) {
-    CLink &L = m.l[l];
+template <class T, class M>
+MPPI_HD void quad_link_pose(M &m, const QPose<T> &P, int l, QM3 &R, QF &p) {
+    auto &L = m.l[l];
     const int body = L.body;
     const float wb = body < 0 ? 1.f : 0.f;
     QM3 Rb;
@@ -330,8 +347,8 @@ MPPI_HD void quad_link_pose(CModel &m, const QPose<T> &P, int l, QM3 &R, QF &p) 
     p = pb + Rb.c[0] * L.p[0] + Rb.c[1] * L.p[1] + Rb.c[2] * L.p[2];
 }
 
-template <class T>
-MPPI_HD QF quad_stage_cost(CModel &m, CCost &c, const float *root, const QF *q) {
+template <class T, class M>
+MPPI_HD QF quad_stage_cost(M &m, CCost &c, const float *root, const QF *q) {
     if (c.kind == kCostPointReach) {
         const float gx = c.actor[0] >= 0 ? root[13 * c.actor[0]] : c.w[1];
         const float gy = c.actor[0] >= 0 ? root[13 * c.actor[0] + 1] : c.w[2];
@@ -359,8 +376,8 @@ MPPI_HD QF quad_stage_cost(CModel &m, CCost &c, const float *root, const QF *q) 
 
 // Whole-horizon rollout of the sample owned by this quad.  Every lane of the quad returns the same S.
 // `leader` is true in exactly one lane of the quad (it performs the du store); lanes 0..2 store viz.
-template <class T>
-MPPI_HD QF quad_rollout(CModel &m0, CCfg &cfg0, CCost &cost0, const float *dof0, const float *root, const float *U, const float *eps,
+template <class T, class M>
+MPPI_HD QF quad_rollout(M &m0, CCfg &cfg0, CCost &cost0, const float *dof0, const float *root, const float *U, const float *eps,
                         const float *prior, float *du, float *viz, int k, bool leader, int row, bool viz_lane) {
     constexpr int NB = T::NB;
     const int K = cfg0.K, nu = cfg0.nu, H = cfg0.H;
@@ -375,37 +392,21 @@ MPPI_HD QF quad_rollout(CModel &m0, CCfg &cfg0, CCost &cost0, const float *dof0,
     });
     QF S = qrep(0.f);
     float ctrl = 0.f, disc = 1.f;
-    CModel *mp = &m0;
+    M *mp = &m0;
     CCfg *cp = &cfg0;
     CCost *kp = &cost0;
     for (int t = 0; t < H; t++) {
         CCfg &cfg = *launder(cp);
         float u[kMaxNu];
-#pragma unroll
-        for (int c = 0; c < kMaxNu; c++) {
-            if (c < nu) {
-                float Ut = U[t * nu + c];
-                float v = Ut + eps[(size_t)(t * nu + c) * K + k];
-                if (is_null) v = 0.f;
-                if (is_prior) v = prior[t * nu + c];
-                v = fminf(fmaxf(v, cfg.u_min[c]), cfg.u_max[c]);
-                u[c] = v;
-                float d = v - Ut;
-                if (leader) du[(size_t)(t * nu + c) * K + k] = d;
-                float term = Ut * d * cfg.inv_sigma[c];
-                ctrl += cfg.lambda * (cfg.noise_abs_cost ? fabsf(term) : term);
-            } else {
-                u[c] = 0.f;
-            }
-        }
+        ctrl += sample_controls(cfg, U, eps, prior, t, k, is_null, is_prior, leader, du, u);
         {
-            CModel &m = *launder(mp);
+            M &m = *launder(mp);
             static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
                 constexpr int i = ic;
+                const CmdBlock b = load_block<CmdBlock>(m.b[i].cmd);
                 float tg = 0.f;
 #pragma unroll
-                for (int c = 0; c < kMaxNu; c++)
-                    if (c < m.nu) tg += m.b[i].cmd[c] * u[c];
+                for (int c = 0; c < kMaxNu; c++) tg += b.v[c] * u[c];
                 target[i] = qrep(tg);
             });
         }
@@ -413,7 +414,7 @@ MPPI_HD QF quad_rollout(CModel &m0, CCfg &cfg0, CCost &cost0, const float *dof0,
         S += disc * quad_stage_cost<T>(*launder(mp), *launder(kp), root, q);
         disc *= cfg.gamma;
         if (cfg.want_rollouts && viz != nullptr) {
-            CModel &m = *launder(mp);
+            M &m = *launder(mp);
             QPose<T> P;
             quad_base<T>(m, root, P);
             quad_fk<T>(m, q, P);

@@ -641,23 +641,7 @@ MPPI_HD float rollout_scene(CModel &m0, CCfg &cfg0, CCost &cost0, const float *d
     CCost *kp = &cost0;
     for (int t = 0; t < H; t++) {
         CCfg &cfg = *launder(cp);
-#pragma unroll
-        for (int c = 0; c < kMaxNu; c++) {
-            if (c < nu) {
-                float Ut = U[t * nu + c];
-                float v = Ut + eps[(size_t)(t * nu + c) * K + k];
-                if (is_null) v = 0.f;
-                if (is_prior) v = prior[t * nu + c];
-                v = fminf(fmaxf(v, cfg.u_min[c]), cfg.u_max[c]);
-                u[c] = v;
-                float d = v - Ut;
-                du[(size_t)(t * nu + c) * K + k] = d;
-                float term = Ut * d * cfg.inv_sigma[c];
-                ctrl += cfg.lambda * (cfg.noise_abs_cost ? fabsf(term) : term);
-            } else {
-                u[c] = 0.f;
-            }
-        }
+        ctrl += sample_controls(cfg, U, eps, prior, t, k, is_null, is_prior, true, du, u);
         cmd_map<T>(*launder(mp), u, target);
         step_scene<T>(*mp, root, s, target, L);
         S += disc * stage_cost_scene<T>(*launder(mp), *launder(kp), root, s, L);

@@ -113,6 +113,7 @@ _SIGNATURES = {
     "mppi_sim_finish": (C.c_int, [_vp]),
     "mppi_world_step_from": (C.c_int, [_vp, _vp]),
     "mppi_set_state_from_world": (C.c_int, [_vp, _vp]),
+    "mppi_update_step_world": (C.c_int, [_vp, _vp, C.c_int, _vp]),
     "mppi_set_profiling": (C.c_int, [_vp, C.c_int]),
     "mppi_kernel_ms": (C.c_int, [_vp, C.c_int, _fp]),
     "mppi_kernel_info": (C.c_int, [_vp, C.c_char_p, C.c_int]),

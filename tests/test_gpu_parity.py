@@ -112,7 +112,21 @@ def test_closed_loop_matches_oracle(lib, oracle64):
     p.call("mppi_get_state", capi.fptr(dev_dof), None)
     np.testing.assert_allclose(dev_dof[0::2], q, atol=1e-4)
     np.testing.assert_allclose(dev_dof[1::2], qd, atol=1e-3)
-    p.close(); w.close()
+    # the fused closed-loop tail (update + world step + state feedback in one launch) gives the same loop
+    p2, w2 = Ctx(m, cfg, cost), Ctx(m, wcfg)
+    p2.call("mppi_sample", C.c_uint32(0))
+    for c in (p2, w2):
+        c.set_state(dof, root)
+    w2.call("mppi_sim_reset")
+    for it in range(5):
+        p2.call("mppi_rollout")
+        p2.call("mppi_reduce", None)
+        capi.check(lib, lib.mppi_update_step_world(p2.ctx, None, 1, w2.ctx))
+    dof2 = np.zeros(14, np.float32)
+    p2.call("mppi_get_state", capi.fptr(dof2), None)
+    np.testing.assert_allclose(dof2, dev_dof, atol=2e-5)
+    np.testing.assert_allclose(p2.get("mppi_get_action", (7,)), action, atol=2e-6)
+    p.close(); w.close(); p2.close(); w2.close()
 
 
 def test_two_shards_combine_to_single_context(lib, oracle64):

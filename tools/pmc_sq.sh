@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CMD="python $REPO/bench.py --steps 100 --warmup 10 --no-cpu-baseline"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq -- $CMD > $OUT/pmc_sq_bench.json 2> $OUT/pmc_sq.err
-rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq2 -- $CMD > $OUT/pmc_sq2_bench.json 2> $OUT/pmc_sq2.err
+rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq2 -- $CMD > $OUT/pmc_sq2_bench.json 2> $OUT/pmc_sq2.err
 python - <<PY
 import csv, glob, collections
 for d in ("pmc_sq", "pmc_sq2"):
@@ -18,7 +18,9 @@ for d in ("pmc_sq", "pmc_sq2"):
     for r in csv.DictReader(open(fs[0])):
         k = r["Kernel_Name"]
         if "k_rollout" in k or "k_combine" in k or "k_sim_step" in k:
-            agg[k.split("(")[0][-40:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            import re
+            name = re.sub(r"\(anonymous namespace\)::|void ", "", k).split("<")[0].split("(")[0] + ("/K1" if r["Grid_Size"] in ("64",) else "")
+            agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         print(k, {c: round(sum(x)/len(x), 1) for c, x in v.items()})
 PY
