@@ -57,7 +57,8 @@ struct BodyK1 {
     float hb[3];  // m * com, body frame
     float Ic[6];  // inertia about the COM, body axes: xx xy xz yy yz zz
     float lower, upper, effort, vmax;
-    int limited, pad1;
+    int limited;
+    float invm;   // 1/m (0 for massless bodies)
 };
 struct alignas(64) DevBody {
     BodyK0 k0;

@@ -268,7 +268,10 @@ __global__ __launch_bounds__(kCombineThreads) void k_combine_world(const DevCfg 
             for (int c = 0; c < kMaxNu; c++) tg += b.v[c] * (c < M.nu ? s_act[c] : 0.f);
             target[i] = tg;
         });
-        quad_step<T>(M, w_root, q, qd, target);
+        QPose<T> P;
+        quad_base<T>(M, w_root, P);
+        quad_fk<T>(M, q, P);
+        quad_step<T>(M, P, q, qd, target);
         if (threadIdx.x == 0)
             static_for<0, NB>([&](auto ic) {
                 constexpr int i = ic;

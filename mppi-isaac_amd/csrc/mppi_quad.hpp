@@ -39,13 +39,16 @@ __device__ __forceinline__ QF qsel(float x0, float x1, float x2) { int r = quad_
 __device__ __forceinline__ QF qrep(float x) { return x; }
 __device__ __forceinline__ float qlane0(QF x) { return x; }  // value as seen by the calling lane
 __device__ __forceinline__ QF qsqrt(QF x) { return sqrtf(x); }
-__device__ __forceinline__ QF qrcp(QF x) { return 1.f / x; }
+// reciprocal: v_rcp_f32 (1 ulp) + one Newton step (3 instructions instead of the ~10 of an IEEE division)
+__device__ __forceinline__ QF qrcp(QF x) { float r = __builtin_amdgcn_rcpf(x); return r * (2.f - x * r); }
 __device__ __forceinline__ QF qabs(QF x) { return fabsf(x); }
 __device__ __forceinline__ QF qmin(QF a, QF b) { return fminf(a, b); }
 __device__ __forceinline__ QF qmax(QF a, QF b) { return fmaxf(a, b); }
 __device__ __forceinline__ QF qatan2(QF a, QF b) { return atan2f(a, b); }
 __device__ __forceinline__ QF qasin(QF a) { return asinf(a); }
-__device__ __forceinline__ void qsincos(QF x, QF &s, QF &c) { fast_sincos(x, s, c); }
+// hardware v_sin_f32 / v_cos_f32: measured max abs error 6.6e-7 / 4.4e-7 on [-6.4, 6.4] (tools/exp/sin_acc.hip),
+// 3 instructions instead of ~28 for the polynomial version the host build keeps
+__device__ __forceinline__ void qsincos(QF x, QF &s, QF &c) { s = __sinf(x); c = __cosf(x); }
 __device__ __forceinline__ bool qany_gt(QF a, QF b) { return a > b; }     // replicated scalars: same in every lane of the quad
 __device__ __forceinline__ QF qwhere_gt(QF a, QF b, QF x, QF y) { return a > b ? x : y; }
 __device__ __forceinline__ QF qwhere_lt(QF a, QF b, QF x, QF y) { return a < b ? x : y; }
@@ -169,17 +172,27 @@ struct JointLimits {  // wave-uniform per-joint limits, cached from block 1 whil
 template <class T, class M>
 MPPI_HD void quad_aba(M &m, const QPose<T> &P, const QF *qd, const QF *tau_exp, const QF *kdh, QF *qdd, JointLimits *lim) {
     constexpr int NB = T::NB;
-    QSV v[NB], U[NB], pacc[NB];
+    QSV v[NB], U[NB], pacc[NB], cb[NB];
+    QF Sl[NB];  // linear part of the joint subspace (the angular part is the third column of R)
     QAI acc[NB];
     QF invd[NB], u[NB];
     bool has_acc[NB];
+    const QF zero = qrep(0.f);
+    // pass 1: velocities, and the two quantities both later sweeps need: S_i and c_i = v_parent x (S_i qd_i)
     static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
         constexpr int i = ic;
         constexpr int par = T::par[i];
         const QSV S = quad_subspace<T, i>(P);
+        Sl[i] = S.l;
         const QSV sj = {qd[i] * S.a, qd[i] * S.l};
-        if constexpr (par < 0) v[i] = sj;
-        else v[i] = {v[par < 0 ? 0 : par].a + sj.a, v[par < 0 ? 0 : par].l + sj.l};
+        if constexpr (par < 0) {
+            v[i] = sj;
+            cb[i] = {zero, zero};
+        } else {
+            const QSV vp = v[par < 0 ? 0 : par];
+            v[i] = {vp.a + sj.a, vp.l + sj.l};
+            cb[i] = {qcross(vp.a, sj.a), qcross(vp.a, sj.l) + qcross(vp.l, sj.a)};
+        }
         has_acc[i] = false;
     });
     BodyK1 blk[2];
@@ -191,15 +204,14 @@ MPPI_HD void quad_aba(M &m, const QPose<T> &P, const QF *qd, const QF *tau_exp, 
         const BodyK1 &b = blk[i & 1];
         lim[i] = {b.effort, b.lower, b.upper, b.vmax, b.limited};
         const QM3 &R = P.R[i];
-        const QSV S = quad_subspace<T, i>(P);
+        const QSV S = {P.jt[i] == 0 ? R.c[2] : zero, Sl[i]};
         // rigid inertia about the world origin: I_O = R Ic R^T + m(|cw|^2 1 - cw cw^T), h = m cw
         const QF h = R.c[0] * b.hb[0] + R.c[1] * b.hb[1] + R.c[2] * b.hb[2] + b.m * P.p[i];
         QF Tr[3];
         Tr[0] = R.c[0] * b.Ic[0] + R.c[1] * b.Ic[1] + R.c[2] * b.Ic[2];
         Tr[1] = R.c[0] * b.Ic[1] + R.c[1] * b.Ic[3] + R.c[2] * b.Ic[4];
         Tr[2] = R.c[0] * b.Ic[2] + R.c[1] * b.Ic[4] + R.c[2] * b.Ic[5];
-        const float invm = b.m > 0.f ? 1.f / b.m : 0.f;
-        const QF cw = invm * h;
+        const QF cw = b.invm * h;
         const QF hh = qsum(h * cw);
         const QF h1 = rot1(h), h2 = rot2(h);
         QAI A;
@@ -223,9 +235,7 @@ MPPI_HD void quad_aba(M &m, const QPose<T> &P, const QF *qd, const QF *tau_exp, 
         invd[i] = qrcp(d);
         u[i] = tau_exp[i] - qdot6(S, pA);
         if constexpr (par >= 0) {
-            const QSV vp = v[par < 0 ? 0 : par];
-            const QSV sj = {qd[i] * S.a, qd[i] * S.l};
-            const QSV c = {qcross(vp.a, sj.a), qcross(vp.a, sj.l) + qcross(vp.l, sj.a)};
+            const QSV c = cb[i];
             const QSV Ac = qmul(A, c);
             const QF k = (u[i] - qdot6(U[i], c)) * invd[i];
             const QSV pa = {pA.a + Ac.a + k * U[i].a, pA.l + Ac.l + k * U[i].l};
@@ -248,19 +258,14 @@ MPPI_HD void quad_aba(M &m, const QPose<T> &P, const QF *qd, const QF *tau_exp, 
         }
     });
     QSV a[NB];
-    const QF zero = qrep(0.f);
     QSV a0 = {zero, zero};
     if (m.gravity_on) a0.l = qsel(-m.g[0], -m.g[1], -m.g[2]);
     static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
         constexpr int i = ic;
         constexpr int par = T::par[i];
-        const QSV S = quad_subspace<T, i>(P);
+        const QSV S = {P.jt[i] == 0 ? P.R[i].c[2] : zero, Sl[i]};
         QSV ap = a0;
-        if constexpr (par >= 0) {
-            const QSV vp = v[par < 0 ? 0 : par];
-            const QSV sj = {qd[i] * S.a, qd[i] * S.l};
-            ap = {a[par < 0 ? 0 : par].a + qcross(vp.a, sj.a), a[par < 0 ? 0 : par].l + qcross(vp.a, sj.l) + qcross(vp.l, sj.a)};
-        }
+        if constexpr (par >= 0) ap = {a[par < 0 ? 0 : par].a + cb[i].a, a[par < 0 ? 0 : par].l + cb[i].l};
         const QF dd = (u[i] - qdot6(U[i], ap)) * invd[i];
         qdd[i] = dd;
         a[i] = {ap.a + dd * S.a, ap.l + dd * S.l};
@@ -276,16 +281,15 @@ MPPI_HD void quad_base(M &m, const float *root, QPose<T> &P) {
     for (int c = 0; c < 3; c++) P.Rb.c[c] = qsel(R.a[c], R.a[3 + c], R.a[6 + c]);
 }
 
+// One simulator step.  P must hold the forward kinematics of q on entry (base pose included) and holds the
+// forward kinematics of the NEW q on exit: the pose computed for the cost / next step is never recomputed.
 template <class T, class M>
-MPPI_HD void quad_step(M &m0, const float *root, QF *q, QF *qd, const QF *target) {
+MPPI_HD void quad_step(M &m0, QPose<T> &P, QF *q, QF *qd, const QF *target) {
     constexpr int NB = T::NB;
     M *mp = &m0;
     for (int s = 0; s < m0.substeps; s++) {
         M &m = *launder(mp);
         const float h = m.h, kd = m.kd;
-        QPose<T> P;
-        quad_base<T>(m, root, P);
-        quad_fk<T>(m, q, P);
         QF tau[NB], kdh[NB], qdd[NB], ff[NB], vs[NB];
         JointLimits lim[NB];
         const int drive_mode = m.drive_mode;
@@ -325,6 +329,7 @@ MPPI_HD void quad_step(M &m0, const float *root, QF *q, QF *qd, const QF *target
             q[i] = x;
             qd[i] = v;
         });
+        quad_fk<T>(*launder(mp), q, P);
     }
 }
 
@@ -348,7 +353,7 @@ MPPI_HD void quad_link_pose(M &m, const QPose<T> &P, int l, QM3 &R, QF &p) {
 }
 
 template <class T, class M>
-MPPI_HD QF quad_stage_cost(M &m, CCost &c, const float *root, const QF *q) {
+MPPI_HD QF quad_stage_cost(M &m, CCost &c, const float *root, const QF *q, const QPose<T> &P) {
     if (c.kind == kCostPointReach) {
         const float gx = c.actor[0] >= 0 ? root[13 * c.actor[0]] : c.w[1];
         const float gy = c.actor[0] >= 0 ? root[13 * c.actor[0] + 1] : c.w[2];
@@ -356,9 +361,6 @@ MPPI_HD QF quad_stage_cost(M &m, CCost &c, const float *root, const QF *q) {
         return c.w[0] * qsqrt(dx * dx + dy * dy);
     }
     if (c.kind == kCostPandaReach) {
-        QPose<T> P;
-        quad_base<T>(m, root, P);
-        quad_fk<T>(m, q, P);
         QM3 R;
         QF p;
         quad_link_pose<T>(m, P, c.link[0], R, p);
@@ -392,6 +394,9 @@ MPPI_HD QF quad_rollout(M &m0, CCfg &cfg0, CCost &cost0, const float *dof0, cons
     });
     QF S = qrep(0.f);
     float ctrl = 0.f, disc = 1.f;
+    QPose<T> P;  // forward kinematics of the current q, carried across the whole horizon
+    quad_base<T>(m0, root, P);
+    quad_fk<T>(m0, q, P);
     M *mp = &m0;
     CCfg *cp = &cfg0;
     CCost *kp = &cost0;
@@ -410,14 +415,11 @@ MPPI_HD QF quad_rollout(M &m0, CCfg &cfg0, CCost &cost0, const float *dof0, cons
                 target[i] = qrep(tg);
             });
         }
-        quad_step<T>(*mp, root, q, qd, target);
-        S += disc * quad_stage_cost<T>(*launder(mp), *launder(kp), root, q);
+        quad_step<T>(*mp, P, q, qd, target);
+        S += disc * quad_stage_cost<T>(*launder(mp), *launder(kp), root, q, P);
         disc *= cfg.gamma;
         if (cfg.want_rollouts && viz != nullptr) {
             M &m = *launder(mp);
-            QPose<T> P;
-            quad_base<T>(m, root, P);
-            quad_fk<T>(m, q, P);
             QM3 R;
             QF p;
             quad_link_pose<T>(m, P, cfg.viz_link, R, p);
