@@ -102,10 +102,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world_size:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    # one process per GPU over RCCL.  MPPI_BENCH_BACKEND=gloo (ranks may then share a GPU, records staged
+    # through the host) exists only to smoke-test the sharded loop on a single-GPU box.
+    backend = os.environ.get("MPPI_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world_size > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world_size)
 
     cfg = make_cfg(wl, K_PER_GPU * world_size)
     cfg.mppi.device = f"cuda:{local_rank}"
@@ -134,7 +141,12 @@ def main():
         capi.check(lib, lib.mppi_rollout(P))
         if world_size > 1:
             capi.check(lib, lib.mppi_reduce(P, ctypes.c_void_p(records[rank].data_ptr())))
-            dist.all_gather_into_tensor(records.view(-1), records[rank].clone())
+            if backend == "nccl":
+                dist.all_gather_into_tensor(records.view(-1), records[rank].clone())
+            else:
+                host = records.cpu()
+                dist.all_gather_into_tensor(host.view(-1), host[rank].clone())
+                records.copy_(host)
             capi.check(lib, lib.mppi_update_step_world(P, ctypes.c_void_p(records.data_ptr()), world_size, W))
         else:
             capi.check(lib, lib.mppi_reduce(P, None))
@@ -164,7 +176,7 @@ def main():
         kms.append(ms.value if rc == 0 else 0.0)
     capi.check(lib, lib.mppi_set_profiling(P, 0))
     if world_size > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -129,13 +129,14 @@ template <class T, class M>
 MPPI_HD void quad_fk(M &m, const QF *q, QPose<T> &P) {
     // the 64-byte constant block of body i+1 is requested before body i is computed, so its scalar-load
     // latency hides under ~100 VALU instructions instead of stalling the (only) wave of this SIMD
-    BodyK0 blk[2];
-    if constexpr (T::NB > 0) blk[0] = load_block<BodyK0>(m.b[0].k0);
+    // all kinematic blocks are requested up front (LDS returns in order, so body i only waits for its own
+    // block while the later ones stream in behind the arithmetic)
+    BodyK0 blk[T::NB ? T::NB : 1];
+    static_for<0, T::NB>([&](auto ic) MPPI_LAMBDA { blk[ic] = load_block<BodyK0>(m.b[ic].k0); });
     static_for<0, T::NB>([&](auto ic) MPPI_LAMBDA {
         constexpr int i = ic;
         constexpr int par = T::par[i];
-        if constexpr (i + 1 < T::NB) blk[(i + 1) & 1] = load_block<BodyK0>(m.b[i + 1].k0);
-        const BodyK0 &b = blk[i & 1];
+        const BodyK0 &b = blk[i];
         P.jt[i] = b.jtype;
         const QM3 &Rp = par < 0 ? P.Rb : P.R[par < 0 ? 0 : par];
         const QF pp = par < 0 ? P.pb : P.p[par < 0 ? 0 : par];
@@ -195,13 +196,12 @@ MPPI_HD void quad_aba(M &m, const QPose<T> &P, const QF *qd, const QF *tau_exp, 
         }
         has_acc[i] = false;
     });
-    BodyK1 blk[2];
-    if constexpr (NB > 0) blk[(NB - 1) & 1] = load_block<BodyK1>(m.b[NB - 1].k1);
+    BodyK1 blk[NB];  // requested leaf-first, in the order the backward sweep consumes them
+    static_rfor<0, NB>([&](auto ic) MPPI_LAMBDA { blk[ic] = load_block<BodyK1>(m.b[ic].k1); });
     static_rfor<0, NB>([&](auto ic) MPPI_LAMBDA {
         constexpr int i = ic;
         constexpr int par = T::par[i];
-        if constexpr (i > 0) blk[(i - 1) & 1] = load_block<BodyK1>(m.b[i - 1].k1);  // prefetch the next body's block
-        const BodyK1 &b = blk[i & 1];
+        const BodyK1 &b = blk[i];
         lim[i] = {b.effort, b.lower, b.upper, b.vmax, b.limited};
         const QM3 &R = P.R[i];
         const QSV S = {P.jt[i] == 0 ? R.c[2] : zero, Sl[i]};
