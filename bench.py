@@ -214,9 +214,9 @@ def main():
                        "loop_hz": loop_hz, "env_steps_per_s": loop_hz * K * H * world_size,
                        "final_ee_to_goal_m": dist_to_goal},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_rollout",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_rollout_quad" if os.environ.get("MPPI_ROLLOUT") != "lane" and args.workload in ("panda_reach", "point_reach") else "k_rollout",
                          "kernel_ms": kms[0], "bytes_alg_per_launch": bytes_alg,
-                         "note": "latency/occupancy-bound path (SURVEY 8d): 64 waves on 256 CUs; see DESIGN.md for the fp32-VALU view"},
+                         "note": "instruction-issue-bound path (SURVEY 8d; DESIGN.md 6): one sample per 4-lane quad = K/16 wavefronts, one per CU at K=4096"},
             "kernels_ms": {"k_rollout(+record tail)": kms[0], "k_reduce(generic mode only)": kms[1], "k_combine_update": kms[2]},
         }
         if world_size == 1 and not args.no_cpu_baseline:

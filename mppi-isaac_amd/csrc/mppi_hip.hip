@@ -142,7 +142,13 @@ __global__ __launch_bounds__(kWave) void k_rollout_quad(const DevModel *__restri
     for (int i = threadIdx.x; i < kModelBytes / 16; i += kWave) s_model[i] = reinterpret_cast<const uint4 *>(m)[i];
     __syncthreads();
     LModel &lm = *(LModel *)s_model;
-    const int k = (blockIdx.x * kWave + threadIdx.x) >> 2;
+    // XCD-aware chunk mapping: a wavefront owns 16 consecutive samples = 64 B of every sample-minor row, i.e.
+    // half a 128-B line.  Workgroup b runs on XCD b % 8 and the XCD L2s are private, so with the identity
+    // mapping the two halves of each line are fetched by two different L2s (measured: 2x the algorithmic
+    // read traffic).  Chunks are therefore dealt so that chunks 2i and 2i+1 land on the same XCD.
+    const int nb = gridDim.x;
+    const int chunk = (nb % 16 == 0) ? (int)(blockIdx.x % 8) * (nb / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    const int k = chunk * 16 + (threadIdx.x >> 2);
     const int lane4 = threadIdx.x & 3;
     const bool live = k < cfg->K;        // the four lanes of a quad share k
     const bool leader = lane4 == 0;
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(kWave) void k_rollout_quad(const DevModel *__restri
         s = quad_rollout<T>(lm, *(CCfg *)cfg, *(CCost *)cost, x0_dof, x0_root, U, eps, prior, du, viz, k, leader, quad_row(), lane4 < 3);
         if (leader) S[k] = s;
     }
-    wave_record(*(CCfg *)cfg, s, live && leader, du, k, partials + (size_t)blockIdx.x * (2 + cfg->H * cfg->nu));
+    wave_record(*(CCfg *)cfg, s, live && leader, du, k, partials + (size_t)chunk * (2 + cfg->H * cfg->nu));
 #endif
 }
 

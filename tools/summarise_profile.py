@@ -29,6 +29,7 @@ for k, v in out.items():
     if "FETCH_SIZE_KB_mean" in v and "WRITE_SIZE_KB_mean" in v:
         v["hbm_traffic_bytes_per_launch"] = int(1024 * (2 * v["FETCH_SIZE_KB_mean"] + v["WRITE_SIZE_KB_mean"]))
 json.dump(out, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1, sort_keys=True)
-json.dump({"tag": tag, "k_rollout": out.get("k_rollout", {})}, open(os.path.join(dst, "pmc_latest.json"), "w"), indent=1)
+main = out.get("k_rollout_quad") or out.get("k_rollout", {})
+json.dump({"tag": tag, "k_rollout": main}, open(os.path.join(dst, "pmc_latest.json"), "w"), indent=1)
 print(open(os.path.join(dst, f"{tag}_kernel_stats.csv")).read()[:1200])
-print(json.dumps(out.get("k_rollout"), indent=1))
+print(json.dumps(main, indent=1))
