@@ -369,3 +369,60 @@ def test_panda_pick_rollout_matches_oracle(lib, oracle64):
     Uo, ao, _ = oracle64.update(cfg, oracle64.record(cfg, So, duo), np.zeros((H, 9)))
     np.testing.assert_allclose(a, ao, atol=2e-3)
     c.close()
+
+
+@pytest.mark.parametrize("K,H", [(1, 12), (7, 13), (100, 16), (1000, 12)])
+def test_ragged_sizes(K, H, lib, oracle64):
+    """sample counts that do not fill a quad-wave (16), a wavefront (64) or the XCD chunk mapping."""
+    scene, m, cfg, cost, dof, root = panda_reach(K=K, H=H, sample_null_action=(K > 1))
+    c = Ctx(m, cfg, cost)
+    c.call("mppi_sample", C.c_uint32(3))
+    eps = c.get("mppi_get_noise", (H, 7, K))
+    np.testing.assert_allclose(eps, oracle64.sample(cfg, 3), atol=1e-6)
+    c.set_state(dof, root)
+    a = np.zeros(7, np.float32)
+    c.call("mppi_command", capi.fptr(a))
+    S = c.get("mppi_get_costs", (K,))
+    So, duo, _ = oracle64.rollout(m, cfg, cost, dof, root, np.zeros((H, 7)), eps)
+    np.testing.assert_allclose(S, So, rtol=1e-4)
+    _, ao, _ = oracle64.update(cfg, oracle64.record(cfg, So, duo), np.zeros((H, 7)))
+    np.testing.assert_allclose(a, ao, atol=2e-4)
+    c.close()
+
+
+def test_random_sampling_priors_and_param_update(lib, oracle64):
+    """mppi_mode 'simple' / sampling_method 'random' (torch noise on the device), a prior in sample K-2
+    (reference mppi_isaac.py:38-41) and update_mppi_params (:129-138) through the planner facade."""
+    from mppiisaac.objectives import PandaReachObjective
+    from mppiisaac.planner.mppi_isaac import MPPIisaacPlanner
+    from mppiisaac.utils.config_store import load_config
+    cfg = load_config({"defaults": [{"mppi": "panda"}, {"isaacgym": "normal"}], "actors": ["panda_stick", "goal"],
+                       "initial_actor_positions": [[0.0, 0.0, 0.0]], "nx": 14},
+                      overrides={"mppi.num_samples": 128, "mppi.horizon": 8, "mppi.mppi_mode": "simple",
+                                 "mppi.sampling_method": "random", "mppi.use_priors": True, "mppi.filter_u": False})
+
+    class Prior:
+        def compute_command(self, sim):
+            return torch.full((7,), 0.05)
+    pl = MPPIisaacPlanner(cfg, PandaReachObjective(cfg), prior=Prior())
+    q = [0.0, -0.94, 0.0, -2.8, 0.0, 1.8675, 0.0]
+    a = pl.compute_action(q, [0.0] * 7).numpy()
+    sim = pl.sim
+    eps = np.zeros((8, 7, 128), np.float32)
+    capi.check(sim._lib, sim._lib.mppi_get_noise(sim._ctx, capi.fptr(eps)))
+    assert eps.std() == pytest.approx(np.sqrt(0.1), rel=0.1)                   # N(0, noise_sigma)
+    du = np.zeros((8, 7, 128), np.float32)
+    capi.check(sim._lib, sim._lib.mppi_get_perturbations(sim._ctx, capi.fptr(du)))
+    np.testing.assert_allclose(du[:, :, 126], 0.05, atol=1e-7)                # prior sequence in sample K-2 (U = 0)
+    np.testing.assert_array_equal(du[:, :, 127], 0.0)                         # null action in sample K-1
+    dof = np.zeros(14); dof[0::2] = q
+    root = sim._root_state[0].cpu().numpy()
+    So, duo, _ = oracle64.rollout(sim._c_model, sim._mppi_config, pl.objective.fused_spec(sim), dof, root, np.zeros((8, 7)), eps,
+                                  prior=np.full((8, 7), 0.05))
+    np.testing.assert_allclose(pl.mppi.get_costs().numpy(), So, rtol=1e-4)
+    _, ao, _ = oracle64.update(sim._mppi_config, oracle64.record(sim._mppi_config, So, duo), np.zeros((8, 7)))
+    np.testing.assert_allclose(a, ao, atol=2e-4)
+    pl.update_mppi_params({"noise_sigma": (0.4 * np.eye(7)).tolist()})      # rebuilds the MPPI core with the new covariance
+    pl.compute_action(q, [0.0] * 7)
+    capi.check(pl.sim._lib, pl.sim._lib.mppi_get_noise(pl.sim._ctx, capi.fptr(eps)))
+    assert eps.std() == pytest.approx(np.sqrt(0.4), rel=0.1)
