@@ -617,9 +617,9 @@ MPPI_HD void link_pose(CModel &m, const Pose<T> &P, int l, M3 &R, V3 &p) {
 
 MPPI_HD float clamp1(float x) { return fminf(fmaxf(x, -1.f), 1.f); }
 
-// Fused stage cost (DevCost.kind).  See include/mppi_hip.h for the reference Objective each restates.
+// Fused stage cost (DevCost.kind) for a given pose.  See include/mppi_hip.h for the reference Objective each restates.
 template <class T>
-MPPI_HD float stage_cost(CModel &m, CCost &c, const float *root, const float *q, const float *qd) {
+MPPI_HD float stage_cost_pose(CModel &m, CCost &c, const float *root, const float *q, const Pose<T> &P) {
     if (c.kind == kCostPointReach) {
         float gx = c.actor[0] >= 0 ? root[13 * c.actor[0]] : c.w[1];
         float gy = c.actor[0] >= 0 ? root[13 * c.actor[0] + 1] : c.w[2];
@@ -627,8 +627,6 @@ MPPI_HD float stage_cost(CModel &m, CCost &c, const float *root, const float *q,
         return c.w[0] * sqrtf(dx * dx + dy * dy);
     }
     if (c.kind == kCostPandaReach) {
-        Pose<T> P;
-        forward_kinematics<T>(m, root, q, P);
         M3 R;
         V3 p;
         link_pose<T>(m, P, c.link[0], R, p);
@@ -642,6 +640,17 @@ MPPI_HD float stage_cost(CModel &m, CCost &c, const float *root, const float *q,
         return c.w[0] * dist + c.w[1] * sqrtf(a0 * a0 + a1 * a1);
     }
     return 0.f;
+}
+
+template <class T>
+MPPI_HD float stage_cost(CModel &m, CCost &c, const float *root, const float *q, const float *qd) {
+    if (c.kind != kCostPandaReach) {
+        Pose<T> none;  // not read by the pose-free costs
+        return stage_cost_pose<T>(m, c, root, q, none);
+    }
+    Pose<T> P;
+    forward_kinematics<T>(m, root, q, P);
+    return stage_cost_pose<T>(m, c, root, q, P);
 }
 
 // Whole-horizon rollout of ONE sample (lane).  eps/du are sample-minor: [(t*nu+c)*K + k].

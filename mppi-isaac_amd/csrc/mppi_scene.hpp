@@ -620,8 +620,12 @@ MPPI_HD float stage_cost_scene(CModel &m, CCost &c, const float *root, const Sce
         const float a0 = atan2f(R.a[7], -R.a[8]), a1 = asinf(clamp1(R.a[6]));  // see PANDA_REACH
         return c.w[0] * sqrtf(dot(drb, drb)) + c.w[1] * sqrtf(dot(dbg, dbg)) + c.w[2] * forces + c.w[3] * sqrtf(a0 * a0 + a1 * a1);
     }
-    // fixed-base costs: the robot row of `root` is the (constant) base
-    return stage_cost<T>(m, c, root, s.q, s.qd);
+    // reach costs: the link pose comes from the sample's own (possibly floating) base
+    Pose<T> P;
+    P.pb = loadv(s.base);
+    P.Rb = quat_to_R(s.base + 3);
+    if (c.kind == kCostPandaReach) forward_kinematics_base<T>(m, s.q, P);
+    return stage_cost_pose<T>(m, c, root, s.q, P);
 }
 
 template <class T>

@@ -130,6 +130,10 @@ class Scene:
         a = self.robot
         idx, terms = 0, []
         if a.differential_drive:
+            if not a.left_wheel_joints or not a.right_wheel_joints:
+                # e.g. the shipped conf/actors/jackal.yaml: the reference evaluates `name in None` here and raises
+                # TypeError (isaacgym_wrapper.py:552-555); fail with a message instead
+                raise ValueError(f"actor '{a.name}': differential_drive needs left_wheel_joints and right_wheel_joints")
             idx = 2
         for name in self.dof_names:
             if a.differential_drive and name in (a.left_wheel_joints or []):
@@ -169,8 +173,8 @@ class Scene:
                             kind, size = capi.SHAPE_BOX, [0.5 * v for v in c["size"]]
                         elif t == "sphere":
                             kind, size = capi.SHAPE_SPHERE, [c["radius"], 0.0, 0.0]
-                        elif t == "cylinder" and c["length"] < 0.25 * c["radius"]:
-                            kind, size = capi.SHAPE_DISC, [c["radius"], 0.0, 0.0]      # wheel / caster
+                        elif t == "cylinder" and (c["length"] < 0.25 * c["radius"] or self._is_wheel(l, Rl @ Rc)):
+                            kind, size = capi.SHAPE_DISC, [c["radius"], 0.0, 0.0]      # wheel / caster: rim contact
                         elif t == "cylinder":
                             kind, size = capi.SHAPE_BOX, [c["radius"], c["radius"], 0.5 * c["length"]]
                         elif t == "mesh":
@@ -210,6 +214,13 @@ class Scene:
         if len(shapes) > capi.MAX_SHAPES or len(pairs) > capi.MAX_PAIRS:
             raise ValueError(f"contact scene too large: {len(shapes)} shapes, {len(pairs)} pairs")
         return shapes, pairs
+
+    def _is_wheel(self, link: dict, R_shape: np.ndarray) -> bool:
+        """a cylinder that spins about its own axis: welded to a moving body whose joint axis is the cylinder axis"""
+        if link["body"] < 0:
+            return False
+        b = self.robot_model["bodies"][link["body"]]
+        return b["jtype"] == "revolute" and abs(float(np.dot(R_shape[:, 2], np.asarray(b["axis"])))) > 0.99
 
     def viz_link_index(self) -> int:
         """link index (within the robot) of ActorWrapper.visualize_link, -1 if unset."""

@@ -8,9 +8,11 @@ from mppiisaac.utils.config_store import load_config
 from mppiisaac.utils.isaacgym_utils import load_actor_cfgs, load_asset
 
 
-def build_scene(actors, init_positions=None, isaacgym="normal", overrides=None):
+def build_scene(actors, init_positions=None, isaacgym="normal", overrides=None, robot_overrides=None):
     env_cfg = load_actor_cfgs(actors)
     robots = [a for a in env_cfg if a.type == "robot"]
+    for k, v in (robot_overrides or {}).items():
+        setattr(robots[0], k, v)
     if init_positions:
         for p, a in zip(init_positions, robots):
             a.init_pos = list(p)

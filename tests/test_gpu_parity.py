@@ -426,3 +426,40 @@ def test_random_sampling_priors_and_param_update(lib, oracle64):
     pl.compute_action(q, [0.0] * 7)
     capi.check(pl.sim._lib, pl.sim._lib.mppi_get_noise(pl.sim._ctx, capi.fptr(eps)))
     assert eps.std() == pytest.approx(np.sqrt(0.4), rel=0.1)
+
+
+@pytest.mark.parametrize("actors,init,link,nu,sigma,umax", [
+    (["omnipanda_effort", "goal"], [[0.0, 0.0, 0.0]], "panda_hand", 12, 4.0, 10.0),   # effort mode, 12-DoF tree, quad kernel
+    (["heijn", "goal"], [[0.0, 0.0, 0.0]], "front_link", 3, 1.0, 1.5),                 # holonomic base
+    (["albert", "goal"], [[0.0, 0.0, 0.2]], "mmrobot_link7", 9, 0.2, 0.5),            # diff-drive base + arm: contact scene
+])
+def test_more_robots_rollout(actors, init, link, nu, sigma, umax, lib, oracle64):
+    """SURVEY 8f rank 1 robots through the HIP path: reach cost on one of their links, rollouts vs the oracle."""
+    from mppiisaac.planner.mppi import MPPIConfig, make_config
+    from scenes import build_scene
+    scene = build_scene(actors, init)
+    assert scene.nu == nu
+    m = scene.to_c()
+    K, H = 128, 12
+    cfg = make_config(MPPIConfig(num_samples=K, horizon=H, noise_sigma=(sigma * np.eye(nu)).tolist(), lambda_=0.1, u_min=[-umax], u_max=[umax],
+                                 sample_null_action=True), viz_link=scene.viz_link_index())
+    cost = capi.Cost()
+    cost.kind = capi.COST_PANDA_REACH
+    cost.link[0] = scene.rigid_body_index(scene.robot.name, link)
+    cost.actor[0] = scene.actor_index("goal")
+    cost.w[0], cost.w[1] = 1.0, 0.1
+    dof, root = scene.initial_state()
+    root[scene.actor_index("goal"), 0:3] = [0.6, 0.3, 0.5]
+    c = Ctx(m, cfg, cost)
+    c.call("mppi_sample", C.c_uint32(0))
+    eps = c.get("mppi_get_noise", (H, nu, K))
+    c.set_state(dof, root)
+    c.call("mppi_rollout")
+    S = c.get("mppi_get_costs", (K,))
+    So, duo, _ = oracle64.rollout(m, cfg, cost, dof, root, np.zeros((H, nu)), eps)
+    assert np.isfinite(S).all()
+    if oracle64.is_scene(m):   # contact switching: distribution-level agreement
+        assert (np.abs(S - So) <= 2e-3 * np.abs(So)).mean() > 0.9
+    else:
+        np.testing.assert_allclose(S, So, rtol=2e-4)
+    c.close()

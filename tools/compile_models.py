@@ -15,7 +15,10 @@ URDFS = {
     "panda_isaac/robots/franka_panda_gripper.urdf": "franka_panda_gripper",
     "panda_isaac/robots/franka_panda.urdf": "franka_panda",
     "boxer/boxer.urdf": "boxer",
-    "heijn.urdf": "heijn",
+    "heijn/heijn.urdf": "heijn",
+    "jackal/jackal.urdf": "jackal",
+    "albert/albert.urdf": "albert",
+    "omni_panda/omniPandaWithGripper.urdf": "omni_panda_gripper",
 }
 out_dir = os.path.join(ROOT, "mppi-isaac_amd", "assets", "compiled")
 os.makedirs(out_dir, exist_ok=True)
