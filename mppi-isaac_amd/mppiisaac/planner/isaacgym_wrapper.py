@@ -225,7 +225,8 @@ class Scene:
     def viz_link_index(self) -> int:
         """link index (within the robot) of ActorWrapper.visualize_link, -1 if unset."""
         v = self.robot.visualize_link
-        return self.link_names.index(v) if v else -1
+        # e.g. conf/actors/omnipanda_effort.yaml names a link its URDF does not have (Isaac Gym then reports -1)
+        return self.link_names.index(v) if v and v in self.link_names else -1
 
     def actor_index(self, name: str) -> int:
         return [a.name for a in self.env_cfg].index(name)
@@ -397,7 +398,7 @@ class IsaacGymWrapper:
         self._root_state = torch.zeros((K, A, 13), **f32)
         self._rigid_body_state = torch.zeros((K, B, 13), **f32)
         self._net_contact_force = torch.zeros((K, B, 3), **f32)
-        self._visualize_link_present = any([a.visualize_link for a in self.env_cfg])
+        self._visualize_link_present = sc.viz_link_index() >= 0
         self.visualize_link_buffer = []
         if self._visualize_link_present:
             self.robot_rigid_body_viz_idx = sc.rigid_body_index(sc.robot.name, sc.robot.visualize_link)
