@@ -1,0 +1,689 @@
+// mppi_kernels.hpp - every gfx950 kernel of the backend, the context they run on and the per-topology
+// launch table.  Included by the main translation unit (mppi_hip.hip: C-ABI) and by one generated
+// translation unit per kinematic tree (topo_<i>.hip, written by __graft_entry__.build()), so the
+// compile-time-tree instantiations build in parallel.
+//
+// Launch structure of one control iteration (replaces the reference's Python horizon loop with
+// ~H x (gym set + simulate + fetch + 4 refresh + 15-40 torch kernels), reference
+// mppiisaac/planner/mppi_isaac.py:57-69 / SURVEY.md 3.1):
+//   k_rollout_quad<Topo>  one sample per 4-lane quad, persistent over the whole horizon: perturb/clamp the
+//                         nominal controls, H x substeps articulated-body steps, fused stage cost, discounted
+//                         sum, and - in its tail - the per-wave softmax record (beta, eta, sum w du).
+//                         k_rollout<Topo> (one lane per sample) and k_rollout_scene<Topo> (contact scenes,
+//                         LDS-staged frames) are the other two rollout kernels.
+//   k_combine[_world]     rescales and sums per-wave / per-GPU records (the same formula joins waves, and
+//                         GPUs after the RCCL all-gather), updates and shifts the nominal U, emits the
+//                         action; the _world variant also steps the K = 1 world and feeds its state back.
+// Buffers are sample-minor so every per-sample access of a wave is one coalesced request.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mppi_pack.hpp"
+#include "mppi_scene.hpp"
+#include "mppi_quad.hpp"
+
+using namespace mppi;
+
+struct mppi_ctx;
+
+namespace {
+
+constexpr int kWave = 64;
+
+// ------------------------------------------------------------------------------ wave helpers
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, kWave));
+    return v;
+}
+
+// ------------------------------------------------------------------------------ kernels
+template <class T>
+__global__ __launch_bounds__(kWave) void k_rollout(const DevModel *__restrict__ m, const DevCfg *__restrict__ cfg,
+                                                   const DevCost *__restrict__ cost, const float *__restrict__ x0_dof,
+                                                   const float *__restrict__ x0_root, const float *__restrict__ U,
+                                                   const float *__restrict__ eps, const float *__restrict__ prior,
+                                                   float *__restrict__ du, float *__restrict__ S, float *__restrict__ viz,
+                                                   float *__restrict__ partials);
+
+// Partial record [beta, eta, N[HN]] of the 64 samples of one wave (all 64 lanes must be active):
+// beta = min S, w = exp(-(S-beta)/lambda), eta = sum w, N[j] = sum_k w_k du[j][k].  The du rows are
+// read back 4 at a time so the shuffle reductions of one row overlap the loads of the next.
+__device__ __forceinline__ void wave_record(CCfg &cfg, float s, bool live, const float *__restrict__ du, int k, float *__restrict__ rec) {
+    const int K = cfg.K, HN = cfg.H * cfg.nu;
+    const bool fin = live && isfinite(s);  // NaN / Inf trajectory cost -> weight 0
+    const float beta = wave_min(fin ? s : INFINITY);
+    const float w = fin ? __expf(-(s - beta) * cfg.inv_lambda) : 0.f;
+    const float eta = wave_sum(w);
+    const int lane = threadIdx.x & (kWave - 1);
+    if (lane == 0) {
+        rec[0] = beta;
+        rec[1] = eta;
+    }
+    const size_t kk = live ? (size_t)k : 0;
+    int j = 0;
+    for (; j + 4 <= HN; j += 4) {
+        float x0 = w * du[(size_t)(j + 0) * K + kk], x1 = w * du[(size_t)(j + 1) * K + kk];
+        float x2 = w * du[(size_t)(j + 2) * K + kk], x3 = w * du[(size_t)(j + 3) * K + kk];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            x0 += __shfl_xor(x0, o, kWave);
+            x1 += __shfl_xor(x1, o, kWave);
+            x2 += __shfl_xor(x2, o, kWave);
+            x3 += __shfl_xor(x3, o, kWave);
+        }
+        if (lane == 0) {
+            rec[2 + j] = x0; rec[3 + j] = x1; rec[4 + j] = x2; rec[5 + j] = x3;
+        }
+    }
+    for (; j < HN; j++) {
+        float x = wave_sum(w * du[(size_t)j * K + kk]);
+        if (lane == 0) rec[2 + j] = x;
+    }
+}
+
+__global__ __launch_bounds__(kWave) void k_reduce(const DevCfg *__restrict__ cfg, const float *__restrict__ S,
+                                                  const float *__restrict__ du, float *__restrict__ partials) {
+    const int k = blockIdx.x * kWave + threadIdx.x;
+    const bool live = k < cfg->K;
+    wave_record(*(CCfg *)cfg, live ? S[k] : INFINITY, live, du, k, partials + (size_t)blockIdx.x * (2 + cfg->H * cfg->nu));
+}
+
+template <class T>
+__global__ __launch_bounds__(kWave) void k_rollout(const DevModel *__restrict__ m, const DevCfg *__restrict__ cfg,
+                                                   const DevCost *__restrict__ cost, const float *__restrict__ x0_dof,
+                                                   const float *__restrict__ x0_root, const float *__restrict__ U,
+                                                   const float *__restrict__ eps, const float *__restrict__ prior,
+                                                   float *__restrict__ du, float *__restrict__ S, float *__restrict__ viz,
+                                                   float *__restrict__ partials) {
+    const int k = blockIdx.x * kWave + threadIdx.x;
+    const bool live = k < cfg->K;
+    float s = INFINITY;
+    if (live) {
+        s = rollout_sample<T>(*(CModel *)m, *(CCfg *)cfg, *(CCost *)cost, x0_dof, x0_root, U, eps, prior, du, viz, k);
+        S[k] = s;
+    }
+    // fused tail: this wave's partial record (its own du writes are visible to its own lanes)
+    wave_record(*(CCfg *)cfg, s, live, du, k, partials + (size_t)blockIdx.x * (2 + cfg->H * cfg->nu));
+}
+
+// Quad-parallel rollout (mppi_quad.hpp): 4 lanes per sample, 16 samples per wavefront.
+template <class T>
+__global__ __launch_bounds__(kWave) void k_rollout_quad(const DevModel *__restrict__ m, const DevCfg *__restrict__ cfg,
+                                                        const DevCost *__restrict__ cost, const float *__restrict__ x0_dof,
+                                                        const float *__restrict__ x0_root, const float *__restrict__ U,
+                                                        const float *__restrict__ eps, const float *__restrict__ prior,
+                                                        float *__restrict__ du, float *__restrict__ S, float *__restrict__ viz,
+                                                        float *__restrict__ partials) {
+#if defined(__HIP_DEVICE_COMPILE__)  // (the host pass sees the 4-float emulation type of mppi_quad.hpp)
+    // Stage the robot model (header + body + link blocks, ~4 KB) in LDS once per wavefront: constants are then
+    // fetched with in-order ds_read_b128 broadcasts into VGPRs - no SMEM round trip (s_waitcnt lgkmcnt(0) on
+    // every block), no SGPR spills, no constant-bus moves.
+    constexpr int kModelBytes = (int)((offsetof(DevModel, fr) + 15) / 16 * 16);
+    __shared__ __attribute__((aligned(64))) uint4 s_model[kModelBytes / 16];
+    for (int i = threadIdx.x; i < kModelBytes / 16; i += kWave) s_model[i] = reinterpret_cast<const uint4 *>(m)[i];
+    __syncthreads();
+    LModel &lm = *(LModel *)s_model;
+    // XCD-aware chunk mapping: a wavefront owns 16 consecutive samples = 64 B of every sample-minor row, i.e.
+    // half a 128-B line.  Workgroup b runs on XCD b % 8 and the XCD L2s are private, so with the identity
+    // mapping the two halves of each line are fetched by two different L2s (measured: 2x the algorithmic
+    // read traffic).  Chunks are therefore dealt so that chunks 2i and 2i+1 land on the same XCD.
+    const int nb = gridDim.x;
+    const int chunk = (nb % 16 == 0) ? (int)(blockIdx.x % 8) * (nb / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    const int k = chunk * 16 + (threadIdx.x >> 2);
+    const int lane4 = threadIdx.x & 3;
+    const bool live = k < cfg->K;        // the four lanes of a quad share k
+    const bool leader = lane4 == 0;
+    float s = INFINITY;
+    if (live) {
+        s = quad_rollout<T>(lm, *(CCfg *)cfg, *(CCost *)cost, x0_dof, x0_root, U, eps, prior, du, viz, k, leader, quad_row(), lane4 < 3);
+        if (leader) S[k] = s;
+    }
+    wave_record(*(CCfg *)cfg, s, live && leader, du, k, partials + (size_t)chunk * (2 + cfg->H * cfg->nu));
+#endif
+}
+
+// Combine n records (1024 threads): beta = min, eta and N rescaled by e^{-(beta_r-beta)/lambda}.
+// mode 0: write the combined record to `out`; mode 1: U += N/eta, action = U[0], shift U, append u_init.
+// The record sum over r is split over four 256-thread groups (r mod 4) with two accumulators each.
+constexpr int kCombineThreads = 1024;
+__device__ __forceinline__ void combine_update(CCfg &cfg, const float *__restrict__ recs, int nrec, int mode, float *__restrict__ out,
+                                               float *__restrict__ U, float *__restrict__ action, float *__restrict__ beta_eta, float *s_act) {
+    __shared__ float s_red[kCombineThreads];
+    __shared__ float s_part[4][MPPI_MAX_H * MPPI_MAX_NU];
+    constexpr int kMaxScale = 4096;
+    __shared__ float s_scale[kMaxScale];
+    const int HN = cfg.H * cfg.nu, RF = 2 + HN, nu = cfg.nu;
+    const int tid = threadIdx.x;
+    float b = INFINITY;
+    for (int r = tid; r < nrec; r += kCombineThreads)
+        if (recs[(size_t)r * RF + 1] > 0.f) b = fminf(b, recs[(size_t)r * RF]);
+    s_red[tid] = b;
+    __syncthreads();
+    for (int o = kCombineThreads / 2; o > 0; o >>= 1) {
+        if (tid < o) s_red[tid] = fminf(s_red[tid], s_red[tid + o]);
+        __syncthreads();
+    }
+    const float beta = s_red[0];
+    __syncthreads();
+    float e = 0.f;
+    for (int r = tid; r < nrec; r += kCombineThreads) {
+        const float er = recs[(size_t)r * RF + 1];
+        const float sc = er > 0.f ? __expf(-(recs[(size_t)r * RF] - beta) * cfg.inv_lambda) : 0.f;
+        if (r < kMaxScale) s_scale[r] = sc;
+        e += er * sc;
+    }
+    s_red[tid] = e;
+    __syncthreads();
+    for (int o = kCombineThreads / 2; o > 0; o >>= 1) {
+        if (tid < o) s_red[tid] += s_red[tid + o];
+        __syncthreads();
+    }
+    const float eta = s_red[0];
+    const int g = tid >> 8, jj = tid & 255;
+    for (int j = jj; j < HN; j += 256) {
+        float N0 = 0.f, N1 = 0.f;
+        int r = g;
+        for (; r + 4 < nrec; r += 8) {
+            const float s0 = r < kMaxScale ? s_scale[r] : 0.f, s1 = r + 4 < kMaxScale ? s_scale[r + 4] : 0.f;
+            N0 += recs[(size_t)r * RF + 2 + j] * s0;
+            N1 += recs[(size_t)(r + 4) * RF + 2 + j] * s1;
+        }
+        for (; r < nrec; r += 4) N0 += recs[(size_t)r * RF + 2 + j] * (r < kMaxScale ? s_scale[r] : 0.f);
+        s_part[g][j] = N0 + N1;
+    }
+    __syncthreads();
+    float *s_U = s_part[0];  // reused for the updated nominal after the group sums are consumed
+    float Unew = 0.f;
+    if (tid < 256)
+        for (int j = tid; j < HN; j += 256) {
+            const float N = (s_part[0][j] + s_part[1][j]) + (s_part[2][j] + s_part[3][j]);
+            if (mode == 0) out[2 + j] = N;
+            else {
+                Unew = U[j] + (eta > 0.f ? N / eta : 0.f);
+                s_part[1][j] = Unew;  // staging row distinct from the one read above
+            }
+        }
+    if (mode == 0) {
+        if (tid == 0) {
+            out[0] = beta;
+            out[1] = eta;
+        }
+        return;
+    }
+    __syncthreads();
+    s_U = s_part[1];
+    if (tid < nu) {
+        action[tid] = s_U[tid];
+        if (s_act != nullptr) s_act[tid] = s_U[tid];
+    }
+    if (tid == 0) {
+        beta_eta[0] = beta;
+        beta_eta[1] = eta;
+    }
+    for (int j = tid; j < HN; j += kCombineThreads) U[j] = (j + nu < HN) ? s_U[j + nu] : cfg.u_init;  // shift, append u_init
+}
+
+__global__ __launch_bounds__(kCombineThreads) void k_combine(const DevCfg *__restrict__ cfg, const float *__restrict__ recs, int nrec, int mode,
+                                                             float *__restrict__ out, float *__restrict__ U, float *__restrict__ action,
+                                                             float *__restrict__ beta_eta) {
+    combine_update(*(CCfg *)cfg, recs, nrec, mode, out, U, action, beta_eta, nullptr);
+}
+
+// Closed-loop tail in ONE launch: combine + nominal update, then the K = 1 world is stepped with the new
+// action by one quad of the same workgroup and its state becomes the planner's next x0
+// (replaces k_combine + k_sim_step + k_state_from_world; fixed-base contact-free scenes only).
+template <class T>
+__global__ __launch_bounds__(kCombineThreads) void k_combine_world(const DevCfg *__restrict__ cfg, const float *__restrict__ recs, int nrec,
+                                                                   float *__restrict__ U, float *__restrict__ action, float *__restrict__ beta_eta,
+                                                                   const DevModel *__restrict__ wm, const float *__restrict__ w_root,
+                                                                   float *__restrict__ wq, float *__restrict__ wqd, float *__restrict__ x0_dof) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ float s_act[MPPI_MAX_NU];
+    combine_update(*(CCfg *)cfg, recs, nrec, 1, nullptr, U, action, beta_eta, s_act);
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        constexpr int NB = T::NB;
+        CModel &M = *(CModel *)wm;
+        QF q[NB ? NB : 1], qd[NB ? NB : 1], target[NB ? NB : 1];
+        static_for<0, NB>([&](auto ic) {
+            constexpr int i = ic;
+            q[i] = wq[i];
+            qd[i] = wqd[i];
+            const CmdBlock b = load_block<CmdBlock>(M.b[i].cmd);
+            float tg = 0.f;
+#pragma unroll
+            for (int c = 0; c < kMaxNu; c++) tg += b.v[c] * (c < M.nu ? s_act[c] : 0.f);
+            target[i] = tg;
+        });
+        QPose<T> P;
+        quad_base<T>(M, w_root, P);
+        quad_fk<T>(M, q, P);
+        quad_step<T>(M, P, q, qd, target);
+        if (threadIdx.x == 0)
+            static_for<0, NB>([&](auto ic) {
+                constexpr int i = ic;
+                wq[i] = q[i];
+                wqd[i] = qd[i];
+                x0_dof[2 * i] = q[i];
+                x0_dof[2 * i + 1] = qd[i];
+            });
+    }
+#endif
+}
+
+// ---- contact scenes (floating base, free bodies, penalty contact): per-lane working set in LDS ----
+template <class T>
+__global__ __launch_bounds__(kWave) void k_rollout_scene(const DevModel *__restrict__ m, const DevCfg *__restrict__ cfg,
+                                                         const DevCost *__restrict__ cost, const float *__restrict__ x0_dof,
+                                                         const float *__restrict__ x0_root, const float *__restrict__ U,
+                                                         const float *__restrict__ eps, const float *__restrict__ prior,
+                                                         float *__restrict__ du, float *__restrict__ S, float *__restrict__ viz,
+                                                         float *__restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int k = blockIdx.x * kWave + threadIdx.x;
+    const bool live = k < cfg->K;
+    const LMem L{lds + threadIdx.x, kWave};  // lane-minor rows: conflict-free ds_read/ds_write
+    float s = INFINITY;
+    if (live) {
+        s = rollout_scene<T>(*(CModel *)m, *(CCfg *)cfg, *(CCost *)cost, x0_dof, x0_root, U, eps, prior, du, viz, k, L);
+        S[k] = s;
+    }
+    wave_record(*(CCfg *)cfg, s, live, du, k, partials + (size_t)blockIdx.x * (2 + cfg->H * cfg->nu));
+}
+
+// env state of contact scenes in HBM (sample-minor): base [13][K], free [kMaxFree*13][K], cf [n_rb*3][K]
+template <class T>
+__global__ __launch_bounds__(kWave) void k_sim_step_scene(const DevModel *__restrict__ m, const DevCfg *__restrict__ cfg, int mode, int t,
+                                                          const float *__restrict__ u_ext, const float *__restrict__ x0_root,
+                                                          const float *__restrict__ U, const float *__restrict__ eps, const float *__restrict__ prior,
+                                                          float *__restrict__ du, float *__restrict__ ctrl, float *__restrict__ q_, float *__restrict__ qd_,
+                                                          float *__restrict__ base_, float *__restrict__ fr_, float *__restrict__ cf_) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NB = T::NB;
+    const int K = cfg->K, nu = cfg->nu;
+    const int k = blockIdx.x * kWave + threadIdx.x;
+    if (k >= K) return;
+    const LMem L{lds + threadIdx.x, kWave};
+    CModel &M = *(CModel *)m;
+    SceneState<T> s;
+    static_for<0, NB>([&](auto ic) {
+        constexpr int i = ic;
+        s.q[i] = q_[(size_t)i * K + k];
+        s.qd[i] = qd_[(size_t)i * K + k];
+    });
+    for (int j = 0; j < 13; j++) s.base[j] = base_[(size_t)j * K + k];
+    for (int f = 0; f < kMaxFree; f++)
+        for (int j = 0; j < 13; j++) s.fr[f][j] = fr_[(size_t)(f * 13 + j) * K + k];
+    float target[NB ? NB : 1], u[kMaxNu];
+    const int g = cfg->k_offset + k;
+    float cc = 0.f;
+#pragma unroll
+    for (int c = 0; c < kMaxNu; c++) {
+        float v = 0.f;
+        if (c < nu) {
+            if (mode == 0) v = u_ext[(size_t)k * nu + c];
+            else if (mode == 1) v = u_ext[c];
+            else {
+                float Ut = U[t * nu + c];
+                v = Ut + eps[(size_t)(t * nu + c) * K + k];
+                if (cfg->sample_null_action && g == cfg->k_total - 1) v = 0.f;
+                if (cfg->use_priors && prior != nullptr && g == cfg->k_total - 2) v = prior[t * nu + c];
+                v = fminf(fmaxf(v, cfg->u_min.v[c]), cfg->u_max.v[c]);
+                float d = v - Ut;
+                du[(size_t)(t * nu + c) * K + k] = d;
+                float term = Ut * d * cfg->inv_sigma.v[c];
+                cc += cfg->lambda * (cfg->noise_abs_cost ? fabsf(term) : term);
+            }
+        }
+        u[c] = v;
+    }
+    if (mode == 2) ctrl[k] += cc;
+    cmd_map<T>(M, u, target);
+    step_scene<T>(M, x0_root, s, target, L);
+    static_for<0, NB>([&](auto ic) {
+        constexpr int i = ic;
+        q_[(size_t)i * K + k] = s.q[i];
+        qd_[(size_t)i * K + k] = s.qd[i];
+    });
+    for (int j = 0; j < 13; j++) base_[(size_t)j * K + k] = s.base[j];
+    for (int f = 0; f < kMaxFree; f++)
+        for (int j = 0; j < 13; j++) fr_[(size_t)(f * 13 + j) * K + k] = s.fr[f][j];
+    for (int j = 0; j < 3 * M.n_rb; j++) cf_[(size_t)j * K + k] = L[SceneLayout<T>::kCf + j];
+}
+
+template <class T>
+__global__ __launch_bounds__(kWave) void k_materialise_scene(const DevModel *__restrict__ m, int K, const float *__restrict__ x0_root,
+                                                             const float *__restrict__ q_, const float *__restrict__ qd_, const float *__restrict__ base_,
+                                                             const float *__restrict__ fr_, const float *__restrict__ cf_, float *__restrict__ dof,
+                                                             float *__restrict__ root, float *__restrict__ rb, float *__restrict__ cf) {
+    constexpr int NB = T::NB;
+    const int k = blockIdx.x * kWave + threadIdx.x;
+    if (k >= K) return;
+    CModel &M = *(CModel *)m;
+    SceneState<T> s;
+    static_for<0, NB>([&](auto ic) {
+        constexpr int i = ic;
+        s.q[i] = q_[(size_t)i * K + k];
+        s.qd[i] = qd_[(size_t)i * K + k];
+        if (dof != nullptr) {
+            dof[(size_t)k * 2 * NB + 2 * i] = s.q[i];
+            dof[(size_t)k * 2 * NB + 2 * i + 1] = s.qd[i];
+        }
+    });
+    for (int j = 0; j < 13; j++) s.base[j] = base_[(size_t)j * K + k];
+    for (int f = 0; f < kMaxFree; f++)
+        for (int j = 0; j < 13; j++) s.fr[f][j] = fr_[(size_t)(f * 13 + j) * K + k];
+    const int A = M.n_actors, B = M.n_rb;
+    scene_materialise<T>(M, x0_root, s, nullptr, root != nullptr ? root + (size_t)k * 13 * A : nullptr,
+                         rb != nullptr ? rb + (size_t)k * 13 * B : nullptr, nullptr);
+    if (cf != nullptr)
+        for (int j = 0; j < 3 * B; j++) cf[(size_t)k * 3 * B + j] = cf_[(size_t)j * K + k];
+}
+
+// all envs <- x0 (root rows of the robot base and the free actors)
+__global__ void k_sim_reset_scene(const DevModel *__restrict__ m, int K, const float *__restrict__ x0_root, float *__restrict__ base_,
+                                  float *__restrict__ fr_, float *__restrict__ cf_) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    for (int j = 0; j < 13; j++) base_[(size_t)j * K + k] = x0_root[13 * m->robot_actor + j];
+    for (int f = 0; f < kMaxFree; f++)
+        for (int j = 0; j < 13; j++) fr_[(size_t)(f * 13 + j) * K + k] = f < m->n_free ? x0_root[13 * m->fr[f].actor + j] : 0.f;
+    for (int j = 0; j < 3 * m->n_rb; j++) cf_[(size_t)j * K + k] = 0.f;
+}
+// planner.x0_root rows of the robot base / free actors <- world env 0
+__global__ void k_root_from_world(const DevModel *__restrict__ m, const float *__restrict__ wbase, const float *__restrict__ wfr, float *__restrict__ x0_root) {
+    const int j = threadIdx.x;
+    if (j < 13) {
+        x0_root[13 * m->robot_actor + j] = wbase[j];
+        for (int f = 0; f < kMaxFree; f++)
+            if (f < m->n_free) x0_root[13 * m->fr[f].actor + j] = wfr[f * 13 + j];
+    }
+}
+
+// ---- halton-spline sampler -------------------------------------------------------------------
+__constant__ int c_primes[MPPI_MAX_KNOTS * MPPI_MAX_NU] = {
+    2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37, 41, 43, 47, 53, 59, 61, 67, 71, 73, 79, 83, 89, 97, 101, 103, 107, 109, 113,
+    127, 131, 137, 139, 149, 151, 157, 163, 167, 173, 179, 181, 191, 193, 197, 199, 211, 223, 227, 229, 233, 239, 241, 251,
+    257, 263, 269, 271, 277, 281, 283, 293, 307, 311, 313, 317, 331, 337, 347, 349, 353, 359, 367, 373, 379, 383, 389, 397,
+    401, 409, 419, 421, 431, 433, 439, 443, 449, 457, 461, 463, 467, 479, 487, 491, 499, 503, 509, 521, 523, 541, 547, 557,
+    563, 569, 571, 577, 587, 593, 599, 601, 607, 613, 617, 619, 631, 641, 643, 647, 653, 659, 661, 673, 677, 683, 691, 701,
+    709, 719, 727, 733, 739, 743, 751, 757, 761, 769, 773, 787, 797, 809, 811, 821, 823, 827, 829, 839, 853, 857, 859, 863,
+    877, 881, 883, 887, 907, 911, 919, 929, 937, 941, 947, 953, 967, 971, 977, 983, 991, 997, 1009, 1013, 1019, 1021, 1031,
+    1033, 1039, 1049, 1051, 1061, 1063, 1069, 1087, 1091, 1093, 1097, 1103, 1109, 1117, 1123, 1129, 1151, 1153, 1163};
+
+// linearly digit-scrambled radical inverse in double (digit -> digit*mult mod p, mult = round(0.618 p))
+__device__ double halton_scrambled(uint32_t n, int dim) {
+    const uint32_t p = (uint32_t)c_primes[dim];
+    uint32_t mult = (uint32_t)(0.6180339887498949 * (double)p + 0.5);
+    if (mult < 1u) mult = 1u;
+    double f = 1.0 / (double)p, r = 0.0;
+    const double invp = f;
+    while (n > 0u) {
+        uint32_t dgt = n % p;
+        r += f * (double)((dgt * mult) % p);
+        n /= p;
+        f *= invp;
+    }
+    return r;
+}
+
+// eps[(t*nu+c)*K + k] = sigma_c * sum_i B[t][i] * Phi^-1(halton(g+1+base, i*nu+c))
+__global__ __launch_bounds__(kWave) void k_sample(const DevCfg *__restrict__ cfg, const double *__restrict__ basis, const double *__restrict__ sigma,
+                                                  int n_knots, uint32_t index_base, float *__restrict__ eps) {
+    const int K = cfg->K, H = cfg->H, nu = cfg->nu;
+    const int k = blockIdx.x * kWave + threadIdx.x;
+    if (k >= K) return;
+    const uint32_t n = (uint32_t)(cfg->k_offset + k) + 1u + index_base;
+    for (int c = 0; c < nu; c++) {
+        double z[MPPI_MAX_KNOTS];
+        for (int i = 0; i < n_knots; i++) z[i] = normcdfinv(halton_scrambled(n, i * nu + c));
+        for (int t = 0; t < H; t++) {
+            double s = 0.0;
+            for (int i = 0; i < n_knots; i++) s += basis[t * n_knots + i] * z[i];
+            eps[(size_t)(t * nu + c) * K + k] = (float)(sigma[c] * s);
+        }
+    }
+}
+
+// ---- batched simulator (generic Objective mode, K=1 world) -------------------------------------
+__global__ void k_sim_reset(int K, int n, const float *__restrict__ x0_dof, float *__restrict__ q, float *__restrict__ qd,
+                            float *__restrict__ S, float *__restrict__ ctrl) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    for (int i = 0; i < n; i++) {
+        q[(size_t)i * K + k] = x0_dof[2 * i];
+        qd[(size_t)i * K + k] = x0_dof[2 * i + 1];
+    }
+    S[k] = 0.f;
+    ctrl[k] = 0.f;
+}
+
+// mode 0: u_ext is [K][nu] (reference layout), mode 1: u_ext is one shared [nu], mode 2: horizon step t
+template <class T>
+__global__ __launch_bounds__(kWave) void k_sim_step(const DevModel *__restrict__ m, const DevCfg *__restrict__ cfg, int mode, int t,
+                                                    const float *__restrict__ u_ext, const float *__restrict__ x0_root,
+                                                    const float *__restrict__ U, const float *__restrict__ eps, const float *__restrict__ prior,
+                                                    float *__restrict__ du, float *__restrict__ ctrl, float *__restrict__ q_, float *__restrict__ qd_) {
+    constexpr int NB = T::NB;
+    const int K = cfg->K, nu = cfg->nu;
+    const int k = blockIdx.x * kWave + threadIdx.x;
+    if (k >= K) return;
+    float q[NB], qd[NB], target[NB], u[kMaxNu];
+    static_for<0, NB>([&](auto ic) {
+        constexpr int i = ic;
+        q[i] = q_[(size_t)i * K + k];
+        qd[i] = qd_[(size_t)i * K + k];
+    });
+    const int g = cfg->k_offset + k;
+    float cc = 0.f;
+#pragma unroll
+    for (int c = 0; c < kMaxNu; c++) {
+        float v = 0.f;
+        if (c < nu) {
+            if (mode == 0) v = u_ext[(size_t)k * nu + c];
+            else if (mode == 1) v = u_ext[c];
+            else {
+                float Ut = U[t * nu + c];
+                v = Ut + eps[(size_t)(t * nu + c) * K + k];
+                if (cfg->sample_null_action && g == cfg->k_total - 1) v = 0.f;
+                if (cfg->use_priors && prior != nullptr && g == cfg->k_total - 2) v = prior[t * nu + c];
+                v = fminf(fmaxf(v, cfg->u_min.v[c]), cfg->u_max.v[c]);
+                float d = v - Ut;
+                du[(size_t)(t * nu + c) * K + k] = d;
+                float term = Ut * d * cfg->inv_sigma.v[c];
+                cc += cfg->lambda * (cfg->noise_abs_cost ? fabsf(term) : term);
+            }
+        }
+        u[c] = v;
+    }
+    if (mode == 2) ctrl[k] += cc;
+    cmd_map<T>(*(CModel *)m, u, target);
+    step<T>(*(CModel *)m, x0_root, q, qd, target);
+    static_for<0, NB>([&](auto ic) {
+        constexpr int i = ic;
+        q_[(size_t)i * K + k] = q[i];
+        qd_[(size_t)i * K + k] = qd[i];
+    });
+}
+
+// sample-minor sim state -> reference-layout tensors (isaacgym_wrapper.py:186-199)
+template <class T>
+__global__ __launch_bounds__(kWave) void k_materialise(const DevModel *__restrict__ m, int K, const float *__restrict__ x0_root,
+                                                       const float *__restrict__ q_, const float *__restrict__ qd_, float *__restrict__ dof,
+                                                       float *__restrict__ root, float *__restrict__ rb, float *__restrict__ cf) {
+    constexpr int NB = T::NB;
+    const int k = blockIdx.x * kWave + threadIdx.x;
+    if (k >= K) return;
+    float q[NB ? NB : 1], qd[NB ? NB : 1];
+    static_for<0, NB>([&](auto ic) {
+        constexpr int i = ic;
+        q[i] = q_[(size_t)i * K + k];
+        qd[i] = qd_[(size_t)i * K + k];
+        if (dof != nullptr) {
+            dof[(size_t)k * 2 * NB + 2 * i] = q[i];
+            dof[(size_t)k * 2 * NB + 2 * i + 1] = qd[i];
+        }
+    });
+    const int A = m->n_actors, B = m->n_rb;
+    if (root != nullptr)
+        for (int j = 0; j < 13 * A; j++) root[(size_t)k * 13 * A + j] = x0_root[j];
+    if (rb != nullptr) rigid_body_state<T>(*(CModel *)m, x0_root, q, qd, rb + (size_t)k * 13 * B, cf != nullptr ? cf + (size_t)k * 3 * B : nullptr);
+    else if (cf != nullptr)
+        for (int j = 0; j < 3 * B; j++) cf[(size_t)k * 3 * B + j] = 0.f;
+}
+
+__global__ void k_accumulate_cost(int K, float disc, const float *__restrict__ c, float *__restrict__ S) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < K) S[k] += disc * c[k];
+}
+__global__ void k_sim_finish(int K, const float *__restrict__ ctrl, float *__restrict__ S) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < K) S[k] += ctrl[k];
+}
+// planner.x0_dof <- world env 0 (K_world = 1: sample-minor == plain arrays)
+__global__ void k_state_from_world(int n, const float *__restrict__ wq, const float *__restrict__ wqd, float *__restrict__ x0_dof) {
+    const int i = threadIdx.x;
+    if (i < n) {
+        x0_dof[2 * i] = wq[i];
+        x0_dof[2 * i + 1] = wqd[i];
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------ context
+struct mppi_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    mppi_model_t model;
+    mppi_config_t cfg;
+    DevModel hm;
+    DevCfg hc;
+    DevCost hk;
+    int n = 0, A = 0, B = 0, K = 0, H = 0, nu = 0, HN = 0, RF = 0, n_waves = 0;
+    int n_quads = 0;      // wavefronts of the quad-parallel rollout (16 samples each)
+    int n_partials = 0;   // records currently held by d_partials
+    bool quad = false;
+    DevModel *d_model = nullptr;
+    DevCfg *d_cfg = nullptr;
+    DevCost *d_cost = nullptr;
+    float *d_x0_dof = nullptr, *d_x0_root = nullptr, *d_U = nullptr, *d_eps = nullptr, *d_du = nullptr, *d_S = nullptr;
+    float *d_prior = nullptr, *d_viz = nullptr, *d_partials = nullptr, *d_record = nullptr, *d_action = nullptr, *d_beta_eta = nullptr;
+    float *d_q = nullptr, *d_qd = nullptr, *d_ctrl = nullptr;
+    float *d_base = nullptr, *d_fr = nullptr, *d_cf = nullptr;  // contact scenes: env root rows and contact forces
+    bool scene = false;
+    size_t lds_bytes = 0;
+    double *d_basis = nullptr, *d_sigma = nullptr;
+    const float *eps_in = nullptr;  // d_eps or an external noise buffer
+    bool has_prior = false, has_cost = false, profiling = false;
+    bool partials_valid = false;  // d_partials holds the records of the current S (written by the fused rollout tail)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[3];
+    size_t ev_used[3] = {0, 0, 0};
+    void (*launch_rollout)(mppi_ctx *) = nullptr;
+    void (*launch_sim_step)(mppi_ctx *, int, int, const float *) = nullptr;
+    void (*launch_materialise)(mppi_ctx *, float *, float *, float *, float *) = nullptr;
+    void (*launch_combine_world)(mppi_ctx *, const float *, int, mppi_ctx *) = nullptr;  // fused closed-loop tail (quad scenes)
+    std::string topo;
+};
+
+// one row of the launch table: the kinematic tree and its kernel launchers
+namespace mppi {
+struct TopoEntry {
+    int nb;
+    int parents[MPPI_MAX_BODIES];
+    size_t scene_lds_floats;  // per-lane LDS floats of the contact-scene kernels, excluding 3 * n_rb
+    void (*rollout)(mppi_ctx *);
+    void (*rollout_quad)(mppi_ctx *);
+    void (*rollout_scene)(mppi_ctx *);
+    void (*sim_step)(mppi_ctx *, int, int, const float *);
+    void (*sim_step_scene)(mppi_ctx *, int, int, const float *);
+    void (*materialise)(mppi_ctx *, float *, float *, float *, float *);
+    void (*materialise_scene)(mppi_ctx *, float *, float *, float *, float *);
+    void (*combine_world)(mppi_ctx *, const float *, int, mppi_ctx *);
+    hipError_t (*raise_lds)(size_t);
+};
+}  // namespace mppi
+
+namespace {
+
+template <class T>
+void launch_rollout_scene_t(mppi_ctx *c) {
+    hipLaunchKernelGGL(k_rollout_scene<T>, dim3(c->n_waves), dim3(kWave), c->lds_bytes, c->stream, c->d_model, c->d_cfg, c->d_cost, c->d_x0_dof,
+                       c->d_x0_root, c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_S, c->cfg.want_rollouts ? c->d_viz : nullptr,
+                       c->d_partials);
+}
+template <class T>
+void launch_sim_step_scene_t(mppi_ctx *c, int mode, int t, const float *u_ext) {
+    hipLaunchKernelGGL(k_sim_step_scene<T>, dim3(c->n_waves), dim3(kWave), c->lds_bytes, c->stream, c->d_model, c->d_cfg, mode, t, u_ext, c->d_x0_root,
+                       c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_ctrl, c->d_q, c->d_qd, c->d_base, c->d_fr, c->d_cf);
+}
+template <class T>
+void launch_materialise_scene_t(mppi_ctx *c, float *dof, float *root, float *rb, float *cf) {
+    hipLaunchKernelGGL(k_materialise_scene<T>, dim3(c->n_waves), dim3(kWave), 0, c->stream, c->d_model, c->K, c->d_x0_root, c->d_q, c->d_qd, c->d_base,
+                       c->d_fr, c->d_cf, dof, root, rb, cf);
+}
+template <class T>
+hipError_t raise_lds_limit(size_t bytes) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rollout_scene<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sim_step_scene<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+template <class T>
+void launch_rollout_quad_t(mppi_ctx *c) {
+    hipLaunchKernelGGL(k_rollout_quad<T>, dim3(c->n_quads), dim3(kWave), 0, c->stream, c->d_model, c->d_cfg, c->d_cost, c->d_x0_dof, c->d_x0_root,
+                       c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_S, c->cfg.want_rollouts ? c->d_viz : nullptr, c->d_partials);
+}
+template <class T>
+void launch_combine_world_t(mppi_ctx *p, const float *recs, int n, mppi_ctx *w) {
+    hipLaunchKernelGGL(k_combine_world<T>, dim3(1), dim3(kCombineThreads), 0, p->stream, p->d_cfg, recs, n, p->d_U, p->d_action, p->d_beta_eta,
+                       w->d_model, w->d_x0_root, w->d_q, w->d_qd, p->d_x0_dof);
+}
+template <class T>
+void launch_rollout_t(mppi_ctx *c) {
+    hipLaunchKernelGGL(k_rollout<T>, dim3(c->n_waves), dim3(kWave), 0, c->stream, c->d_model, c->d_cfg, c->d_cost, c->d_x0_dof, c->d_x0_root,
+                       c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_S, c->cfg.want_rollouts ? c->d_viz : nullptr, c->d_partials);
+}
+template <class T>
+void launch_sim_step_t(mppi_ctx *c, int mode, int t, const float *u_ext) {
+    hipLaunchKernelGGL(k_sim_step<T>, dim3(c->n_waves), dim3(kWave), 0, c->stream, c->d_model, c->d_cfg, mode, t, u_ext, c->d_x0_root, c->d_U,
+                       c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_ctrl, c->d_q, c->d_qd);
+}
+template <class T>
+void launch_materialise_t(mppi_ctx *c, float *dof, float *root, float *rb, float *cf) {
+    hipLaunchKernelGGL(k_materialise<T>, dim3(c->n_waves), dim3(kWave), 0, c->stream, c->d_model, c->K, c->d_x0_root, c->d_q, c->d_qd, dof, root,
+                       rb, cf);
+}
+
+template <class T>
+TopoEntry make_topo_entry() {
+    TopoEntry e{};
+    e.nb = T::NB;
+    for (int i = 0; i < T::NB; i++) e.parents[i] = T::par[i];
+    e.scene_lds_floats = (size_t)SceneLayout<T>::kCf;
+    e.rollout = &launch_rollout_t<T>;
+    e.rollout_quad = &launch_rollout_quad_t<T>;
+    e.rollout_scene = &launch_rollout_scene_t<T>;
+    e.sim_step = &launch_sim_step_t<T>;
+    e.sim_step_scene = &launch_sim_step_scene_t<T>;
+    e.materialise = &launch_materialise_t<T>;
+    e.materialise_scene = &launch_materialise_scene_t<T>;
+    e.combine_world = &launch_combine_world_t<T>;
+    e.raise_lds = &raise_lds_limit<T>;
+    return e;
+}
+
+}  // namespace
