@@ -210,6 +210,9 @@ int mppi_set_noise_dev(mppi_ctx_t *ctx, const float *eps_dev); /* external eps [
 int mppi_set_prior(mppi_ctx_t *ctx, const float *prior_host);  /* [H][nu] for sample k_total-2   */
 int mppi_set_nominal(mppi_ctx_t *ctx, const float *U_host);    /* [H][nu]                        */
 int mppi_get_nominal(mppi_ctx_t *ctx, float *U_host);
+/* filter_u: linear smoothing operator F [H][H] applied to the updated nominal (U <- F U) before the action is taken;
+ * NULL switches it off.  The host builds F as a Savitzky-Golay filter (mppiisaac/planner/mppi.py:savgol_matrix). */
+int mppi_set_filter(mppi_ctx_t *ctx, const float *F_host);
 int mppi_rollout(mppi_ctx_t *ctx);   /* persistent kernel: K samples x H steps, fused cost -> S[K], du */
 int mppi_reduce(mppi_ctx_t *ctx, float *record_out_dev); /* shard record (beta, eta, N[H*nu]); NULL = internal buffer */
 int mppi_record_floats(const mppi_ctx_t *ctx);               /* 2 + H*nu                             */

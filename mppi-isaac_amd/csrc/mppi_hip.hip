@@ -173,6 +173,7 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
     ALLOC_TRY(c->d_base, sizeof(float) * 13 * K);
     ALLOC_TRY(c->d_fr, sizeof(float) * kMaxFree * 13 * K);
     ALLOC_TRY(c->d_cf, sizeof(float) * 3 * c->B * K);
+    ALLOC_TRY(c->d_filter, sizeof(float) * c->H * c->H);
     ALLOC_TRY(c->d_basis, sizeof(double) * MPPI_MAX_H * MPPI_MAX_KNOTS);
     ALLOC_TRY(c->d_sigma, sizeof(double) * MPPI_MAX_NU);
     c->eps_in = c->d_eps;
@@ -194,7 +195,7 @@ int mppi_destroy(mppi_ctx_t *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     void *bufs[] = {c->d_model, c->d_cfg, c->d_cost, c->d_x0_dof, c->d_x0_root, c->d_U, c->d_eps, c->d_du, c->d_S, c->d_prior, c->d_viz,
-                    c->d_partials, c->d_record, c->d_action, c->d_beta_eta, c->d_q, c->d_qd, c->d_ctrl, c->d_basis, c->d_sigma, c->d_base, c->d_fr, c->d_cf};
+                    c->d_partials, c->d_record, c->d_action, c->d_beta_eta, c->d_q, c->d_qd, c->d_ctrl, c->d_basis, c->d_sigma, c->d_base, c->d_fr, c->d_cf, c->d_filter};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (auto &v : c->ev)
@@ -279,6 +280,15 @@ int mppi_set_nominal(mppi_ctx_t *c, const float *U) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     return MPPI_OK;
 }
+int mppi_set_filter(mppi_ctx_t *c, const float *F) {
+    CTX_TRY(c);
+    c->use_filter = F != nullptr;
+    if (F) {
+        HIP_TRY(hipMemcpyAsync(c->d_filter, F, sizeof(float) * c->H * c->H, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return MPPI_OK;
+}
 int mppi_get_nominal(mppi_ctx_t *c, float *U) {
     CTX_TRY(c);
     HIP_TRY(hipMemcpyAsync(U, c->d_U, sizeof(float) * c->HN, hipMemcpyDeviceToHost, c->stream));
@@ -307,13 +317,13 @@ int mppi_reduce(mppi_ctx_t *c, float *record_out_dev) {
     }
     if (record_out_dev)  // one shard record for the cross-GPU all-gather
         hipLaunchKernelGGL(k_combine, dim3(1), dim3(kCombineThreads), 0, c->stream, c->d_cfg, c->d_partials, c->n_partials, 0, record_out_dev, c->d_U, c->d_action,
-                           c->d_beta_eta);
+                           c->d_beta_eta, (const float *)nullptr);
     return launch_check();
 }
 int mppi_record_floats(const mppi_ctx_t *c) { return c ? c->RF : 0; }
 int mppi_record_dev(mppi_ctx_t *c, float **record_dev) {
     CTX_TRY(c);
-    hipLaunchKernelGGL(k_combine, dim3(1), dim3(kCombineThreads), 0, c->stream, c->d_cfg, c->d_partials, c->n_partials, 0, c->d_record, c->d_U, c->d_action, c->d_beta_eta);
+    hipLaunchKernelGGL(k_combine, dim3(1), dim3(kCombineThreads), 0, c->stream, c->d_cfg, c->d_partials, c->n_partials, 0, c->d_record, c->d_U, c->d_action, c->d_beta_eta, (const float *)nullptr);
     *record_dev = c->d_record;
     return launch_check();
 }
@@ -324,7 +334,8 @@ int mppi_update(mppi_ctx_t *c, const float *records_dev, int n_records) {
     if (n < 1) return fail(MPPI_EINVAL, "n_records < 1");
     {
         EvScope ev(c, 2);
-        hipLaunchKernelGGL(k_combine, dim3(1), dim3(kCombineThreads), 0, c->stream, c->d_cfg, recs, n, 1, (float *)nullptr, c->d_U, c->d_action, c->d_beta_eta);
+        hipLaunchKernelGGL(k_combine, dim3(1), dim3(kCombineThreads), 0, c->stream, c->d_cfg, recs, n, 1, (float *)nullptr, c->d_U, c->d_action, c->d_beta_eta,
+                           c->use_filter ? (const float *)c->d_filter : (const float *)nullptr);
     }
     return launch_check();
 }

@@ -160,7 +160,8 @@ __global__ __launch_bounds__(kWave) void k_rollout_quad(const DevModel *__restri
 // The record sum over r is split over four 256-thread groups (r mod 4) with two accumulators each.
 constexpr int kCombineThreads = 1024;
 __device__ __forceinline__ void combine_update(CCfg &cfg, const float *__restrict__ recs, int nrec, int mode, float *__restrict__ out,
-                                               float *__restrict__ U, float *__restrict__ action, float *__restrict__ beta_eta, float *s_act) {
+                                               float *__restrict__ U, float *__restrict__ action, float *__restrict__ beta_eta, float *s_act,
+                                               const float *__restrict__ filt) {
     __shared__ float s_red[kCombineThreads];
     __shared__ float s_part[4][MPPI_MAX_H * MPPI_MAX_NU];
     constexpr int kMaxScale = 4096;
@@ -225,6 +226,17 @@ __device__ __forceinline__ void combine_update(CCfg &cfg, const float *__restric
     }
     __syncthreads();
     s_U = s_part[1];
+    if (filt != nullptr) {  // filter_u: U <- F U over the horizon, per control dimension
+        const int H = cfg.H;
+        for (int j = tid; j < HN; j += kCombineThreads) {
+            const int t = j / nu, c = j - t * nu;
+            float acc = 0.f;
+            for (int s2 = 0; s2 < H; s2++) acc += filt[t * H + s2] * s_part[1][s2 * nu + c];
+            s_part[2][j] = acc;
+        }
+        __syncthreads();
+        s_U = s_part[2];
+    }
     if (tid < nu) {
         action[tid] = s_U[tid];
         if (s_act != nullptr) s_act[tid] = s_U[tid];
@@ -238,8 +250,8 @@ __device__ __forceinline__ void combine_update(CCfg &cfg, const float *__restric
 
 __global__ __launch_bounds__(kCombineThreads) void k_combine(const DevCfg *__restrict__ cfg, const float *__restrict__ recs, int nrec, int mode,
                                                              float *__restrict__ out, float *__restrict__ U, float *__restrict__ action,
-                                                             float *__restrict__ beta_eta) {
-    combine_update(*(CCfg *)cfg, recs, nrec, mode, out, U, action, beta_eta, nullptr);
+                                                             float *__restrict__ beta_eta, const float *__restrict__ filt) {
+    combine_update(*(CCfg *)cfg, recs, nrec, mode, out, U, action, beta_eta, nullptr, filt);
 }
 
 // Closed-loop tail in ONE launch: combine + nominal update, then the K = 1 world is stepped with the new
@@ -249,10 +261,11 @@ template <class T>
 __global__ __launch_bounds__(kCombineThreads) void k_combine_world(const DevCfg *__restrict__ cfg, const float *__restrict__ recs, int nrec,
                                                                    float *__restrict__ U, float *__restrict__ action, float *__restrict__ beta_eta,
                                                                    const DevModel *__restrict__ wm, const float *__restrict__ w_root,
-                                                                   float *__restrict__ wq, float *__restrict__ wqd, float *__restrict__ x0_dof) {
+                                                                   float *__restrict__ wq, float *__restrict__ wqd, float *__restrict__ x0_dof,
+                                                                   const float *__restrict__ filt) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ float s_act[MPPI_MAX_NU];
-    combine_update(*(CCfg *)cfg, recs, nrec, 1, nullptr, U, action, beta_eta, s_act);
+    combine_update(*(CCfg *)cfg, recs, nrec, 1, nullptr, U, action, beta_eta, s_act, filt);
     __syncthreads();
     if (threadIdx.x < 4) {
         constexpr int NB = T::NB;
@@ -584,6 +597,8 @@ struct mppi_ctx {
     float *d_prior = nullptr, *d_viz = nullptr, *d_partials = nullptr, *d_record = nullptr, *d_action = nullptr, *d_beta_eta = nullptr;
     float *d_q = nullptr, *d_qd = nullptr, *d_ctrl = nullptr;
     float *d_base = nullptr, *d_fr = nullptr, *d_cf = nullptr;  // contact scenes: env root rows and contact forces
+    float *d_filter = nullptr;  // filter_u operator [H][H]
+    bool use_filter = false;
     bool scene = false;
     size_t lds_bytes = 0;
     double *d_basis = nullptr, *d_sigma = nullptr;
@@ -650,7 +665,7 @@ void launch_rollout_quad_t(mppi_ctx *c) {
 template <class T>
 void launch_combine_world_t(mppi_ctx *p, const float *recs, int n, mppi_ctx *w) {
     hipLaunchKernelGGL(k_combine_world<T>, dim3(1), dim3(kCombineThreads), 0, p->stream, p->d_cfg, recs, n, p->d_U, p->d_action, p->d_beta_eta,
-                       w->d_model, w->d_x0_root, w->d_q, w->d_qd, p->d_x0_dof);
+                       w->d_model, w->d_x0_root, w->d_q, w->d_qd, p->d_x0_dof, p->use_filter ? p->d_filter : nullptr);
 }
 template <class T>
 void launch_rollout_t(mppi_ctx *c) {

@@ -92,6 +92,7 @@ _SIGNATURES = {
     "mppi_set_prior": (C.c_int, [_vp, _fp]),
     "mppi_set_nominal": (C.c_int, [_vp, _fp]),
     "mppi_get_nominal": (C.c_int, [_vp, _fp]),
+    "mppi_set_filter": (C.c_int, [_vp, _fp]),
     "mppi_rollout": (C.c_int, [_vp]),
     "mppi_reduce": (C.c_int, [_vp, _vp]),
     "mppi_record_floats": (C.c_int, [_vp]),

@@ -73,6 +73,26 @@ def bspline_basis(horizon: int, n_knots: int, degree: int = 2) -> np.ndarray:
     return B
 
 
+def savgol_matrix(horizon: int, window: int = 9, order: int = 3) -> np.ndarray:
+    """[H, H] Savitzky-Golay smoothing operator with polynomial edge handling (the behaviour of
+    scipy.signal.savgol_filter(..., mode="interp")): row t fits a degree-`order` polynomial to the `window`
+    samples nearest to t (clamped inside the horizon) and evaluates it at t.  `filter_u: True` applies it to
+    the nominal control sequence after every update.  mppi_torch's own window/order are not visible from
+    the reference tree: window 9 / order 3 are this build's choice (PARITY UNPINNED)."""
+    H = horizon
+    w = min(window, H if H % 2 == 1 else H - 1)
+    if w < 3:
+        return np.eye(H)
+    p = min(order, w - 1)
+    F = np.zeros((H, H))
+    for t in range(H):
+        a = int(np.clip(t - w // 2, 0, H - w))
+        x = np.arange(a, a + w, dtype=float) - t
+        V = np.vander(x, p + 1, increasing=True)       # [w, p+1]
+        F[t, a:a + w] = np.linalg.pinv(V)[0]            # value of the fitted polynomial at x = 0
+    return F
+
+
 def knots_for_horizon(horizon: int) -> int:
     """halton-spline: n_knots = H // 4; below 3 knots sample every step directly (SURVEY.md A)."""
     nk = horizon // 4
@@ -170,6 +190,9 @@ class MPPIPlanner:
         if cfg.U_init is not None:
             U = np.ascontiguousarray(np.asarray(cfg.U_init, np.float32).reshape(self.T, self.nu))
             capi.check(self._lib, self._lib.mppi_set_nominal(self._ctx, capi.fptr(U)))
+        if cfg.filter_u:
+            F = np.ascontiguousarray(savgol_matrix(self.T), np.float32)
+            capi.check(self._lib, self._lib.mppi_set_filter(self._ctx, capi.fptr(F)))
         self._external_noise = None
         if sim._mppi_config.sampling == capi.SAMPLE_HALTON_SPLINE:
             capi.check(self._lib, self._lib.mppi_sample(self._ctx, np.uint32(cfg.seed_val)))

@@ -463,3 +463,32 @@ def test_more_robots_rollout(actors, init, link, nu, sigma, umax, lib, oracle64)
     else:
         np.testing.assert_allclose(S, So, rtol=2e-4)
     c.close()
+
+
+def test_filter_u_smooths_the_nominal(lib, oracle64):
+    """filter_u (conf/mppi/panda.yaml: True): the updated nominal is U <- F (U + sum w du), then action / shift."""
+    from mppiisaac.planner.mppi import savgol_matrix
+    K, H = 256, 12
+    scene, m, cfg, cost, dof, root = panda_reach(K=K, H=H)
+    c = Ctx(m, cfg, cost)
+    c.call("mppi_sample", C.c_uint32(0))
+    eps = c.get("mppi_get_noise", (H, 7, K))
+    F = np.ascontiguousarray(savgol_matrix(H), np.float32)
+    c.call("mppi_set_filter", capi.fptr(F))
+    rng = np.random.default_rng(2)
+    U0 = (0.05 * rng.normal(size=(H, 7))).astype(np.float32)
+    c.set_state(dof, root); c.set_U(U0)
+    a = np.zeros(7, np.float32)
+    c.call("mppi_command", capi.fptr(a))
+    U1 = c.get("mppi_get_nominal", (H, 7))
+    So, duo, _ = oracle64.rollout(m, cfg, cost, dof, root, U0, eps)
+    rec = oracle64.record(cfg, So, duo)
+    Unew = U0 + rec[2:].reshape(H, 7) / rec[1]
+    Uf = F.astype(np.float64) @ Unew
+    np.testing.assert_allclose(a, Uf[0], atol=2e-4)
+    np.testing.assert_allclose(U1[:-1], Uf[1:], atol=2e-4)
+    c.call("mppi_set_filter", None)
+    c.set_U(U0)
+    c.call("mppi_command", capi.fptr(a))
+    np.testing.assert_allclose(a, Unew[0], atol=2e-4)
+    c.close()

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from mppiisaac.backend import capi
-from mppiisaac.planner.mppi import MPPIConfig, bspline_basis, knots_for_horizon, make_config
+from mppiisaac.planner.mppi import MPPIConfig, bspline_basis, knots_for_horizon, make_config, savgol_matrix
 from mppiisaac.utils.config_store import ExampleConfig, load_config
 from scenes import build_scene
 
@@ -95,3 +95,17 @@ def test_product_path_fails_loudly_without_gpu():
     cfg.mppi.device = "cpu"
     with pytest.raises(capi.MppiHipError):
         MPPIisaacPlanner(cfg, PandaReachObjective(cfg))
+
+
+def test_savgol_matrix_matches_scipy():
+    """filter_u operator == scipy.signal.savgol_filter(mode='interp') applied along the horizon."""
+    from scipy.signal import savgol_filter
+    rng = np.random.default_rng(0)
+    for H in (12, 20, 30):
+        F = savgol_matrix(H, 9, 3)
+        U = rng.normal(size=(H, 4))
+        np.testing.assert_allclose(F @ U, savgol_filter(U, 9, 3, axis=0, mode="interp"), atol=1e-10)
+        np.testing.assert_allclose(F.sum(1), 1.0, atol=1e-10)      # constants pass through
+        t = np.arange(H, dtype=float)
+        np.testing.assert_allclose(F @ (t ** 3), t ** 3, atol=1e-6)   # cubics are reproduced exactly
+    assert np.array_equal(savgol_matrix(2), np.eye(2))
