@@ -253,6 +253,32 @@ MPPI_HD void box_corners_in_box(CPair &P, const ShapeW &X, cfloat *hx, const Sha
     }
 }
 
+// sphere (centre ps, radius r) against box Y: closest point of the box to the centre; sign = +1 when the
+// sphere is shape A (normal from B = box to A = sphere)
+MPPI_HD void sphere_in_box(CPair &P, V3 ps, float r, const ShapeW &Y, cfloat *hy, float sign, const SV &vA, const SV &vB, PairAcc &acc) {
+    const V3 d = ps - Y.p;
+    const V3 y = {Y.R.a[0] * d.x + Y.R.a[3] * d.y + Y.R.a[6] * d.z, Y.R.a[1] * d.x + Y.R.a[4] * d.y + Y.R.a[7] * d.z,
+                  Y.R.a[2] * d.x + Y.R.a[5] * d.y + Y.R.a[8] * d.z};
+    const V3 cl = {fminf(fmaxf(y.x, -hy[0]), hy[0]), fminf(fmaxf(y.y, -hy[1]), hy[1]), fminf(fmaxf(y.z, -hy[2]), hy[2])};
+    const V3 e = y - cl;
+    const float dist2 = dot(e, e);
+    if (dist2 >= r * r) return;
+    V3 nl;
+    float depth;
+    if (dist2 > 1e-12f) {  // centre outside the box: normal along the shortest connection
+        const float dist = sqrtf(dist2);
+        nl = (1.f / dist) * e;
+        depth = r - dist;
+    } else {  // centre inside: push out through the nearest face
+        const float dx = hy[0] - fabsf(y.x), dy = hy[1] - fabsf(y.y), dz = hy[2] - fabsf(y.z);
+        if (dx <= dy && dx <= dz) { nl = {y.x > 0.f ? 1.f : -1.f, 0.f, 0.f}; depth = dx + r; }
+        else if (dy <= dz) { nl = {0.f, y.y > 0.f ? 1.f : -1.f, 0.f}; depth = dy + r; }
+        else { nl = {0.f, 0.f, y.z > 0.f ? 1.f : -1.f}; depth = dz + r; }
+    }
+    const V3 pw = Y.p + mul(Y.R, cl);
+    contact_point(P, pw, sign * mul(Y.R, nl), depth, vA, vB, acc);
+}
+
 // All candidate pairs of the scene -> per-frame wrench / damping accumulators and net contact forces.
 template <class T>
 MPPI_HD void contact_forces(CModel &m, const float *root, const LMem &L) {
@@ -294,6 +320,10 @@ MPPI_HD void contact_forces(CModel &m, const float *root, const LMem &L) {
             if (A.type == 0 && B.type == 0) {
                 box_corners_in_box(P, wa, A.half, wb, B.half, 1.f, wa.v, wb.v, acc);
                 box_corners_in_box(P, wb, B.half, wa, A.half, -1.f, wa.v, wb.v, acc);
+            } else if (A.type == 1 && B.type == 0) {
+                sphere_in_box(P, wa.p, A.half[0], wb, B.half, 1.f, wa.v, wb.v, acc);
+            } else if (A.type == 0 && B.type == 1) {
+                sphere_in_box(P, wb.p, B.half[0], wa, A.half, -1.f, wa.v, wb.v, acc);
             }
         }
         if (acc.any) {

@@ -209,18 +209,19 @@ class Scene:
                 if capi.SHAPE_DISC in kinds:
                     continue
                 if kinds == {capi.SHAPE_SPHERE}:
-                    continue  # no sphere-sphere contacts in the shipped scenes
+                    continue  # sphere-sphere is not implemented (no such pair in the shipped scenes)
                 pairs.append((i, j))
         if len(shapes) > capi.MAX_SHAPES or len(pairs) > capi.MAX_PAIRS:
             raise ValueError(f"contact scene too large: {len(shapes)} shapes, {len(pairs)} pairs")
         return shapes, pairs
 
     def _is_wheel(self, link: dict, R_shape: np.ndarray) -> bool:
-        """a cylinder that spins about its own axis: welded to a moving body whose joint axis is the cylinder axis"""
+        """a cylinder that spins about its own axis on one of the actor's declared wheel joints"""
         if link["body"] < 0:
             return False
         b = self.robot_model["bodies"][link["body"]]
-        return b["jtype"] == "revolute" and abs(float(np.dot(R_shape[:, 2], np.asarray(b["axis"])))) > 0.99
+        wheels = (self.robot.left_wheel_joints or []) + (self.robot.right_wheel_joints or [])
+        return b["joint"] in wheels and abs(float(np.dot(R_shape[:, 2], np.asarray(b["axis"])))) > 0.99
 
     def viz_link_index(self) -> int:
         """link index (within the robot) of ActorWrapper.visualize_link, -1 if unset."""
@@ -361,6 +362,8 @@ class IsaacGymWrapper:
         self.viewer = None
         self.saved_root_state = None
         self._mppi_config = mppi_config
+        self._mppi_config_factory = mppi_config  # kept to rebuild the C config when the actor list changes
+        self.generation = 0
         self.scene = Scene(self.env_cfg, cfg, load_asset(robots[0]) if robots else None)
         self.start_sim()
 
@@ -537,6 +540,71 @@ class IsaacGymWrapper:
 
     def get_dof_state(self):
         return self._dof_state
+
+    # ------------------------------------------------------------------ env mutation (reference :423-427, :695-758)
+    def _restart(self):
+        """reference add_to_envs / obstacle-size change: stop_sim(); start_sim() (there broken by a misspelled
+        attribute).  The HIP context is rebuilt for the new actor list; `generation` lets owners of
+        the old context (the MPPI driver) notice."""
+        from mppiisaac.utils.isaacgym_utils import load_asset
+        keep_root = self._root_state[0].clone() if hasattr(self, "_root_state") else None
+        keep_dof = self._dof_state[0].clone() if hasattr(self, "_dof_state") else None
+        n_old = keep_root.shape[0] if keep_root is not None else 0
+        self.stop_sim()
+        for i, a in enumerate(self.env_cfg):
+            a.handle = i
+        robots = [a for a in self.env_cfg if a.type == "robot"]
+        self.scene = Scene(self.env_cfg, self.cfg, load_asset(robots[0]))
+        self._mppi_config = self._mppi_config_factory
+        self.generation += 1
+        self.start_sim()
+        if keep_root is not None:  # carry the state of the actors that already existed
+            root = self._root_state[0].clone()
+            root[:n_old] = keep_root
+            self._push_single_state(keep_dof.cpu().numpy(), root.cpu().numpy())
+
+    def add_to_envs(self, additions):
+        for a in additions:
+            self.env_cfg.append(ActorWrapper(**a))
+        self._restart()
+
+    def update_root_state_tensor_by_obstacles(self, obstacles):
+        """obstacles: dict name -> {position, velocity, size[, type]} (urdfenvs FullSensor layout, reference
+        :695-742).  Obstacle i is the fixed sphere actor 'sphere<i>'; unknown ones are added (simulator restart),
+        a changed radius restarts too, otherwise only the root rows move."""
+        changed = False
+        updates = []
+        for i, obst in enumerate(list(obstacles.values())):
+            name = f"sphere{i}"
+            size = list(np.atleast_1d(obst["size"]).astype(float))
+            idx = [k for k, a in enumerate(self.env_cfg) if a.name == name]
+            if not idx:
+                self.env_cfg.append(ActorWrapper(**{"type": "sphere", "name": name, "handle": None, "size": size, "fixed": True,
+                                                    "init_pos": [float(v) for v in obst["position"]]}))
+                changed = True
+                continue
+            if not all(a == b for a, b in zip(size, self.env_cfg[idx[0]].size)):
+                self.env_cfg[idx[0]].size = size
+                changed = True
+            updates.append((idx[0], obst))
+        if changed:
+            self._restart()
+        root = self._root_state[0].clone()
+        for k, obst in updates:
+            root[k] = torch.tensor([*obst["position"], 0, 0, 0, 1, *obst["velocity"], 0, 0, 0], dtype=torch.float32, device=self.device)
+        self._push_single_state(self._dof_state[0].cpu().numpy(), root.cpu().numpy())
+        return changed
+
+    def update_root_state_tensor_by_obstacles_tensor(self, obst_tensor):
+        """reference :744-758: each row of obst_tensor [n,13] overwrites the root state of the first
+        non-robot, non-fixed actor."""
+        idx = [k for k, a in enumerate(self.env_cfg) if (a.type != "robot" and not a.fixed)]
+        if not idx:
+            raise ValueError("no free (non-robot, non-fixed) actor to place")
+        root = self._root_state[0].clone()
+        for o in torch.as_tensor(obst_tensor, dtype=torch.float32, device=self.device).reshape(-1, 13):
+            root[idx[0]] = o
+        self._push_single_state(self._dof_state[0].cpu().numpy(), root.cpu().numpy())
 
     def set_actor_position_by_name(self, position, name: str) -> None:
         """Move an actor (e.g. the goal) in every env; takes effect for the next rollout/step."""

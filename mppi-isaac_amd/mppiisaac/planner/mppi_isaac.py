@@ -61,11 +61,28 @@ class MPPIisaacPlanner(object):
     def running_cost(self, _):
         return self.objective.compute_cost(self.sim)
 
+    def _rebind_after_restart(self):
+        """the simulator was rebuilt with a new actor list (new HIP context): rebuild the MPPI driver on it and
+        carry the nominal control sequence over (in the reference the mppi object simply survives the restart)."""
+        U = self.mppi.U
+        self.mppi = MPPIPlanner(self.cfg.mppi, self.cfg.nx, dynamics=self.dynamics, running_cost=self.running_cost,
+                                prior=self.prior, sim=self.sim, shard=self._shard, process_group=self._pg)
+        import numpy as np
+        from mppiisaac.backend import capi
+        Uh = np.ascontiguousarray(U.numpy(), np.float32)
+        capi.check(self.sim._lib, self.sim._lib.mppi_set_nominal(self.sim._ctx, capi.fptr(Uh)))
+        self._generation = self.sim.generation
+
     def compute_action(self, q, qdot, obst=None, obst_tensor=None):
-        if obst or obst_tensor is not None:
-            raise NotImplementedError("dynamic obstacles (SURVEY.md 8f rank 3) are not part of this scope row yet")
         self.sim.reset_root_state()
         self.sim.reset_robot_state(q, qdot)
+        # two ways of placing obstacles, as in the reference (mppi_isaac.py:75-81)
+        if obst:
+            self.sim.update_root_state_tensor_by_obstacles(obst)
+        if obst_tensor is not None:
+            self.sim.update_root_state_tensor_by_obstacles_tensor(obst_tensor)
+        if self.sim.generation != getattr(self, "_generation", 0):
+            self._rebind_after_restart()
         self.sim.save_root_state()
         self._bind_objective()
         return self.mppi.command(self.state_place_holder).cpu()
@@ -84,7 +101,8 @@ class MPPIisaacPlanner(object):
         return torch_to_bytes(self.mppi.command(self.state_place_holder))
 
     def add_to_env(self, env_cfg_additions):
-        raise NotImplementedError("add_to_env (SURVEY.md 8f rank 3) is not part of this scope row yet")
+        self.sim.add_to_envs(env_cfg_additions)
+        self._rebind_after_restart()
 
     def get_rollouts(self):
         if not self.sim._visualize_link_present:

@@ -488,6 +488,36 @@ static void corners_in_box(int mode, real mu, real k, real cn, real ct, real kh,
     }
 }
 
+/* sphere (centre ps, radius r) against box Y; sign = +1 when the sphere is shape A */
+static void sphere_in_box(int mode, real mu, real k, real cn, real ct, real kh, const real *ps, real r, const shape_w_t *Y, const double *hy,
+                          real sign, const real *vA, const real *vB, pair_acc_t *acc) {
+    real d[3], y[3], cl[3], e[3], nl[3] = {0, 0, 0}, depth, dist2 = 0;
+    for (int j = 0; j < 3; j++) d[j] = ps[j] - Y->p[j];
+    m3_tvec(Y->R, d, y);
+    for (int j = 0; j < 3; j++) {
+        cl[j] = y[j] < -(real)hy[j] ? -(real)hy[j] : (y[j] > (real)hy[j] ? (real)hy[j] : y[j]);
+        e[j] = y[j] - cl[j];
+        dist2 += e[j] * e[j];
+    }
+    if (dist2 >= r * r) return;
+    if (dist2 > (real)1e-12) {
+        real dist = (real)sqrt((double)dist2);
+        for (int j = 0; j < 3; j++) nl[j] = e[j] / dist;
+        depth = r - dist;
+    } else {
+        real dx = (real)hy[0] - (real)fabs((double)y[0]), dy = (real)hy[1] - (real)fabs((double)y[1]), dz = (real)hy[2] - (real)fabs((double)y[2]);
+        if (dx <= dy && dx <= dz) { nl[0] = y[0] > 0 ? 1 : -1; depth = dx + r; }
+        else if (dy <= dz) { nl[1] = y[1] > 0 ? 1 : -1; depth = dy + r; }
+        else { nl[2] = y[2] > 0 ? 1 : -1; depth = dz + r; }
+    }
+    real pw[3], n[3], t[3];
+    m3_vec(Y->R, cl, t);
+    for (int j = 0; j < 3; j++) pw[j] = Y->p[j] + t[j];
+    m3_vec(Y->R, nl, n);
+    for (int j = 0; j < 3; j++) n[j] *= sign;
+    contact_point(mode, mu, k, cn, ct, kh, pw, n, depth, vA, vB, acc);
+}
+
 /* dynamic frame index of a shape (-1: static), and the mass that scales its contact gains */
 static int shape_entity(const mppi_model_t *m, const scene_info_t *si, const mppi_shape_t *S, real *mass) {
     *mass = -1;
@@ -554,6 +584,10 @@ static void scene_contacts(const mppi_model_t *m, const scene_info_t *si, frame_
             if (A->type == MPPI_SHAPE_BOX && B->type == MPPI_SHAPE_BOX) {
                 corners_in_box(mode, mu, k, cn, ct, kh, &wa, A->size, &wb, B->size, 1, wa.v, wb.v, &acc);
                 corners_in_box(mode, mu, k, cn, ct, kh, &wb, B->size, &wa, A->size, -1, wa.v, wb.v, &acc);
+            } else if (A->type == MPPI_SHAPE_SPHERE && B->type == MPPI_SHAPE_BOX) {
+                sphere_in_box(mode, mu, k, cn, ct, kh, wa.p, (real)A->size[0], &wb, B->size, 1, wa.v, wb.v, &acc);
+            } else if (A->type == MPPI_SHAPE_BOX && B->type == MPPI_SHAPE_SPHERE) {
+                sphere_in_box(mode, mu, k, cn, ct, kh, wb.p, (real)B->size[0], &wa, A->size, -1, wa.v, wb.v, &acc);
             }
         }
         if (!acc.any) continue;

@@ -492,3 +492,56 @@ def test_filter_u_smooths_the_nominal(lib, oracle64):
     c.call("mppi_command", capi.fptr(a))
     np.testing.assert_allclose(a, Unew[0], atol=2e-4)
     c.close()
+
+
+def test_dynamic_obstacles_through_compute_action(lib):
+    """compute_action(q, qdot, obst=...) (reference mppi_isaac.py:71-85, isaacgym_wrapper.py:695-742): unknown
+    obstacles are added as fixed spheres (simulator restart), known ones only move; an Objective that reads
+    sim.obstacle_positions (as the reference's benchmark planner does) steers around them."""
+    from mppiisaac.planner.mppi_isaac import MPPIisaacPlanner
+    from mppiisaac.utils.config_store import load_config
+    cfg = load_config({"defaults": [{"mppi": "pointbot"}, {"isaacgym": "normal"}], "actors": ["point_robot"],
+                       "initial_actor_positions": [[0.0, 0.0, 0.05]], "nx": 6},
+                      overrides={"mppi.num_samples": 256, "mppi.horizon": 12, "mppi.use_priors": False, "mppi.filter_u": False})
+
+    class Objective:  # navigation + inverse-distance obstacle term (benchmarks/point_robot/.../mppi_planner_wrapper.py:17-35)
+        def __init__(self):
+            self.goal = torch.tensor([2.0, 0.0], device="cuda")
+        def reset(self):
+            pass
+        def compute_cost(self, sim):
+            dof = sim.get_dof_state()
+            pos = torch.stack((dof[:, 0], dof[:, 2]), 1)
+            nav = torch.linalg.norm(pos - self.goal, axis=1)
+            obs = sim.obstacle_positions
+            near = torch.sum(1 / torch.linalg.norm(obs[:, :, :2] - pos.unsqueeze(1), axis=2), axis=1) if obs.shape[1] else 0.0
+            return 2.0 * nav + 1.0 * near
+    pl = MPPIisaacPlanner(cfg, Objective())
+    n_actors0 = len(pl.sim.env_cfg)
+    obst = {"o0": {"position": [1.0, 0.05, 0.1], "velocity": [0, 0, 0], "size": [0.3]},
+            "o1": {"position": [1.0, -1.5, 0.1], "velocity": [0, 0, 0], "size": [0.2]}}
+    # the reference needs one call to create the actors and restart; the next call places them (:709-722)
+    pl.compute_action([0.1, 0.0, 0.0], [0.0, 0.0, 0.0], obst=obst)
+    assert len(pl.sim.env_cfg) == n_actors0 + 2 and pl.sim.generation == 1
+    a = pl.compute_action([0.1, 0.0, 0.0], [0.0, 0.0, 0.0], obst=obst).numpy()
+    assert pl.sim.generation == 1                                   # no second restart
+    np.testing.assert_allclose(pl.sim.get_actor_position_by_name("sphere0")[0].cpu().numpy(), [1.0, 0.05, 0.1], atol=1e-6)
+    assert pl.sim.obstacle_positions.shape == (256, 2, 3)
+    assert a[0] > 0.0                                                # heads for the goal ...
+    q, traj = np.array([0.1, 0.0, 0.0]), []
+    qd = np.zeros(3)
+    world_model = pl.sim._c_model
+    from oracle.oracle import Oracle
+    o = Oracle("f64")
+    root = pl.sim._root_state[0].cpu().numpy().astype(np.float64)
+    for _ in range(60):                                              # closed loop on the oracle's world
+        a = pl.compute_action(list(q), list(qd), obst=obst).numpy()
+        if o.is_scene(world_model):
+            root, q, qd, _ = o.scene_step(world_model, root, q, qd, o.cmd_map(world_model, a))
+        else:
+            q, qd = o.step(world_model, root, q, qd, o.cmd_map(world_model, a))
+        traj.append(q[:2].copy())
+    traj = np.asarray(traj)
+    d = np.linalg.norm(traj - np.array([1.0, 0.05]), axis=1)
+    assert d.min() > 0.3 + 0.2 - 0.05                                # ... around the obstacle (radius 0.3, robot radius 0.2)
+    assert np.linalg.norm(traj[-1] - np.array([2.0, 0.0])) < 0.6
