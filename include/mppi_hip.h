@@ -113,6 +113,10 @@ typedef struct mppi_actor {
     double friction;
     int32_t first_rb;  /* first rigid-body row of this actor in rigid_body_state         */
     int32_t n_rb;      /* robot: n_links, box/sphere: 1                                  */
+    /* per-env randomisation of box/sphere actors (isaacgym_wrapper.py:430-475, isaacgym_utils.py:30-52) */
+    double noise_sigma_size[3];    /* size += N(0, sigma)                                */
+    double noise_percentage_mass;  /* mass += U(-p, p) * mass                            */
+    double noise_percentage_friction; /* friction += U(-p, p) * friction                 */
 } mppi_actor_t;
 
 /* Scene of one env: one articulated robot + simple actors, in env_cfg (= root_state) order. */
@@ -149,6 +153,11 @@ typedef struct mppi_model {
     double contact_alpha;     /* penalty stiffness  k = alpha * m_eff / h^2 per contact patch */
     double contact_beta;      /* normal damping     c = beta  * m_eff / h                     */
     double friction_beta;     /* stick damping      c_t = friction_beta * m_eff / h           */
+    /* >= 0: every sample (global id g) draws its own box sizes / masses / frictions from a counter-based
+     * hash of (seed, g, actor) - the seeded counterpart of the reference's unseeded np.random draws per env;
+     * < 0: nominal values in every sample */
+    int32_t randomize_seed;
+    int32_t pad2_;
 } mppi_model_t;
 
 /* mppi_torch.MPPIConfig fields (reference conf/mppi/ + benchmarks/point_robot/setup/mppi.yaml:5-37) */

@@ -85,20 +85,24 @@ struct DevShape {
 struct DevPair {
     int a, b;       // shapes; b = -1: ground plane
     int mode;       // 0: both dynamic (explicit penalty), 1: a dynamic / b static (implicit), 2: b dynamic / a static
-    int pad;
+    int rnd;        // a noisy actor takes part: friction / mass scale are per sample
     float mu, k, cn, ct;  // combined friction, stiffness and damping per contact point
-    float kh, pad2[3];    // k * h (implicit spring term of static contacts)
+    float kh;             // k * h (implicit spring term of static contacts)
+    float ma, mb, mub;    // nominal masses of the reacting actors (-1: static) and the ground friction for b = -1
 };
 struct DevFree {
-    int actor, rb, gravity, pad;
+    int actor, rb, gravity, type;
     float m, Ic[3];  // box / sphere principal inertia about the centre
+    float size[3], pad;
 };
 struct DevModel {
     int nb, nl, n_actors, robot_actor, n_rb, robot_first_rb, drive_mode, substeps, gravity_on, nu, floating, n_free;
     float kd, h, g[3], base_m, pad2[2];
     float base_hb[3], base_Ic[6], pad3[3];
     int actor_first_rb[kMaxActors];
-    int n_shapes, n_pairs, pad4[2];
+    int n_shapes, n_pairs, rnd_seed, pad4;
+    float noise[kMaxActors][5];  // per actor: sigma_size xyz, mass percentage, friction percentage
+    float actor_mu[kMaxActors], actor_mass[kMaxActors];
     DevBody b[kMaxBodies];
     DevLink l[kMaxLinks];
     DevFree fr[kMaxFree];

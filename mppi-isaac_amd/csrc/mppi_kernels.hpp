@@ -342,6 +342,7 @@ __global__ __launch_bounds__(kWave) void k_sim_step_scene(const DevModel *__rest
         for (int j = 0; j < 13; j++) s.fr[f][j] = fr_[(size_t)(f * 13 + j) * K + k];
     float target[NB ? NB : 1], u[kMaxNu];
     const int g = cfg->k_offset + k;
+    scene_randomise<T>(M, g, L);  // LDS does not persist across launches: redraw this sample's actor noise
     float cc = 0.f;
 #pragma unroll
     for (int c = 0; c < kMaxNu; c++) {

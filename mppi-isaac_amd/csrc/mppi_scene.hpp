@@ -31,9 +31,52 @@ struct SceneLayout {
     static constexpr int NF = T::NB + 1 + kMaxFree;  // dynamic frames
     static constexpr int kFrame = 0;                 // [NF][18]: R(9) p(3) w(3) vO(3)
     static constexpr int kAcc = NF * 18;             // [NF][27]: f(6) C(21)
-    static constexpr int kCf = kAcc + NF * 27;       // [n_rb][3] net contact force
+    static constexpr int kRnd = kAcc + NF * 27;      // [kMaxActors][5] this sample's size deltas xyz, mass scale, friction
+    static constexpr int kCf = kRnd + kMaxActors * 5;  // [n_rb][3] net contact force
     MPPI_HD static constexpr int floats(int n_rb) { return kCf + 3 * n_rb; }
 };
+
+// counter-based uniform in (0,1): the seeded stand-in for the reference's unseeded np.random draws per env
+MPPI_HD float hash_uniform(int seed, int g, int actor, int k) {
+    uint32_t h = (uint32_t)seed * 0x9E3779B1u ^ (uint32_t)(g + 1) * 0x85EBCA77u ^ (uint32_t)(actor + 1) * 0xC2B2AE3Du ^ (uint32_t)(k + 1) * 0x27D4EB2Fu;
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    return ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
+}
+MPPI_HD float std_normal_from_uniform(float u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return normcdfinvf(u);
+#else
+    // Acklam's rational approximation (|error| < 1.2e-9 relative) - host build only
+    const double a[] = {-3.969683028665376e+01, 2.209460984245205e+02, -2.759285104469687e+02, 1.383577518672690e+02, -3.066479806614716e+01, 2.506628277459239e+00};
+    const double b[] = {-5.447609879822406e+01, 1.615858368580409e+02, -1.556989798598866e+02, 6.680131188771972e+01, -1.328068155288572e+01};
+    const double c[] = {-7.784894002430293e-03, -3.223964580411365e-01, -2.400758277161838e+00, -2.549732539343734e+00, 4.374664141464968e+00, 2.938163982698783e+00};
+    const double d[] = {7.784695709041462e-03, 3.224671290700398e-01, 2.445134137142996e+00, 3.754408661907416e+00};
+    double p = u, x;
+    if (p < 0.02425) { double q = sqrt(-2 * log(p)); x = (((((c[0]*q+c[1])*q+c[2])*q+c[3])*q+c[4])*q+c[5]) / ((((d[0]*q+d[1])*q+d[2])*q+d[3])*q+1); }
+    else if (p <= 1 - 0.02425) { double q = p - 0.5, r = q*q; x = (((((a[0]*r+a[1])*r+a[2])*r+a[3])*r+a[4])*r+a[5])*q / (((((b[0]*r+b[1])*r+b[2])*r+b[3])*r+b[4])*r+1); }
+    else { double q = sqrt(-2 * log(1 - p)); x = -(((((c[0]*q+c[1])*q+c[2])*q+c[3])*q+c[4])*q+c[5]) / ((((d[0]*q+d[1])*q+d[2])*q+d[3])*q+1); }
+    return (float)x;
+#endif
+}
+
+// this sample's draws for every actor: size deltas, mass scale, friction (nominal when randomisation is off)
+template <class T>
+MPPI_HD void scene_randomise(CModel &m, int g, const LMem &L) {
+    using Lay = SceneLayout<T>;
+    for (int a = 0; a < kMaxActors; a++) {
+        const int o = Lay::kRnd + 5 * a;
+        const bool on = m.rnd_seed >= 0 && a < m.n_actors && a != m.robot_actor;
+        for (int j = 0; j < 3; j++) {
+            const float sg = on ? m.noise[a][j] : 0.f;
+            L[o + j] = sg != 0.f ? sg * std_normal_from_uniform(hash_uniform(m.rnd_seed, g, a, j)) : 0.f;
+        }
+        const float pm = on ? m.noise[a][3] : 0.f, pf = on ? m.noise[a][4] : 0.f;
+        L[o + 3] = pm != 0.f ? 1.f + pm * (2.f * hash_uniform(m.rnd_seed, g, a, 3) - 1.f) : 1.f;
+        const float mu0 = a < m.n_actors ? m.actor_mu[a] : 0.f;
+        L[o + 4] = pf != 0.f ? mu0 * (1.f + pf * (2.f * hash_uniform(m.rnd_seed, g, a, 4) - 1.f)) : mu0;
+    }
+}
+
 constexpr int scene_floats_max(int nb) { return (nb + 1 + kMaxFree) * 45 + 3 * (kMaxLinks + kMaxActors); }
 
 template <class T>
@@ -165,7 +208,11 @@ MPPI_HD void pair_zero(PairAcc &a) {
 }
 
 // One contact point p (world), unit normal n pointing from B to A, penetration depth > 0.
-MPPI_HD void contact_point(CPair &P, V3 p, V3 n, float depth, const SV &vA, const SV &vB, PairAcc &acc) {
+struct Gains {  // per-pair contact parameters of THIS sample (equal to the packed nominal ones without randomisation)
+    int mode;
+    float mu, k, cn, ct, kh;
+};
+MPPI_HD void contact_point(const Gains &P, V3 p, V3 n, float depth, const SV &vA, const SV &vB, PairAcc &acc) {
     const V3 vr = vel_at(vA, p) - vel_at(vB, p);
     const float vn = dot(vr, n);
     const V3 vt = vr - vn * n;
@@ -232,7 +279,7 @@ MPPI_HD ShapeW shape_world(CShape &S, const float *root, const LMem &L) {
 // Feature points of box X (8 corners, 12 edge midpoints, 6 face centres) that lie inside box Y; a pure
 // vertex test misses boxes that cross like a plus sign (a tall block against a wide chassis face).
 // sign = +1 when X is shape A (normal from B=Y to A=X)
-MPPI_HD void box_corners_in_box(CPair &P, const ShapeW &X, cfloat *hx, const ShapeW &Y, cfloat *hy, float sign, const SV &vA, const SV &vB, PairAcc &acc) {
+MPPI_HD void box_corners_in_box(const Gains &P, const ShapeW &X, const float *hx, const ShapeW &Y, const float *hy, float sign, const SV &vA, const SV &vB, PairAcc &acc) {
     for (int c = 0; c < 27; c++) {
         if (c == 13) continue;  // the centre is not a surface feature
         V3 loc = {(float)(c % 3 - 1) * hx[0], (float)((c / 3) % 3 - 1) * hx[1], (float)(c / 9 - 1) * hx[2]};
@@ -255,7 +302,7 @@ MPPI_HD void box_corners_in_box(CPair &P, const ShapeW &X, cfloat *hx, const Sha
 
 // sphere (centre ps, radius r) against box Y: closest point of the box to the centre; sign = +1 when the
 // sphere is shape A (normal from B = box to A = sphere)
-MPPI_HD void sphere_in_box(CPair &P, V3 ps, float r, const ShapeW &Y, cfloat *hy, float sign, const SV &vA, const SV &vB, PairAcc &acc) {
+MPPI_HD void sphere_in_box(const Gains &P, V3 ps, float r, const ShapeW &Y, const float *hy, float sign, const SV &vA, const SV &vB, PairAcc &acc) {
     const V3 d = ps - Y.p;
     const V3 y = {Y.R.a[0] * d.x + Y.R.a[3] * d.y + Y.R.a[6] * d.z, Y.R.a[1] * d.x + Y.R.a[4] * d.y + Y.R.a[7] * d.z,
                   Y.R.a[2] * d.x + Y.R.a[5] * d.y + Y.R.a[8] * d.z};
@@ -283,61 +330,92 @@ MPPI_HD void sphere_in_box(CPair &P, V3 ps, float r, const ShapeW &Y, cfloat *hy
 template <class T>
 MPPI_HD void contact_forces(CModel &m, const float *root, const LMem &L) {
     using Lay = SceneLayout<T>;
-    for (int j = Lay::kAcc; j < Lay::floats(m.n_rb); j++) L[j] = 0.f;
+    for (int j = Lay::kAcc; j < Lay::kRnd; j++) L[j] = 0.f;
+    for (int j = Lay::kCf; j < Lay::floats(m.n_rb); j++) L[j] = 0.f;
     const SV zero = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
     for (int ip = 0; ip < m.n_pairs; ip++) {
-        CPair &P = m.pr[ip];
-        CShape &A = m.sh[P.a];
+        CPair &Pm = m.pr[ip];
+        CShape &A = m.sh[Pm.a];
         const ShapeW wa = shape_world(A, root, L);
+        Gains P = {Pm.mode, Pm.mu, Pm.k, Pm.cn, Pm.ct, Pm.kh};
+        float hA[3] = {A.half[0], A.half[1], A.half[2]}, hB[3] = {0.f, 0.f, 0.f};
+        const int oa = Lay::kRnd + 5 * A.src_actor;
+        if (Pm.rnd) {  // this sample's own box size / friction / mass of the noisy actors in the pair
+            if (A.src_actor != m.robot_actor) {
+                if (A.type == 0) for (int j = 0; j < 3; j++) hA[j] += 0.5f * L[oa + j];
+                else if (A.type == 1) hA[0] += L[oa];
+            }
+            const float mua = A.src_actor != m.robot_actor ? L[oa + 4] : A.mu;
+            float mub = Pm.mub, sb = 1.f;
+            const float sa = A.src_actor != m.robot_actor ? L[oa + 3] : 1.f;
+            if (Pm.b >= 0) {
+                CShape &Bs = m.sh[Pm.b];
+                const int ob = Lay::kRnd + 5 * Bs.src_actor;
+                mub = Bs.src_actor != m.robot_actor ? L[ob + 4] : Bs.mu;
+                sb = Bs.src_actor != m.robot_actor ? L[ob + 3] : 1.f;
+            }
+            P.mu = fminf(mua, mub);
+            const float ma = Pm.ma * sa, mb = Pm.mb * sb;
+            const float meff0 = Pm.mode == 0 ? Pm.ma * Pm.mb / (Pm.ma + Pm.mb) : (Pm.mode == 1 ? Pm.ma : Pm.mb);
+            const float meff = Pm.mode == 0 ? ma * mb / (ma + mb) : (Pm.mode == 1 ? ma : mb);
+            const float sc = meff / meff0;
+            P.k *= sc; P.cn *= sc; P.ct *= sc; P.kh *= sc;
+        }
         PairAcc acc;
         pair_zero(acc);
         int rbB = -1, entB = -1;
-        if (P.b < 0) {  // ground plane z = 0, normal +z (from ground to A)
+        if (Pm.b < 0) {  // ground plane z = 0, normal +z (from ground to A)
             const V3 ez = {0.f, 0.f, 1.f};
             if (A.type == 0) {
                 for (int c = 0; c < 8; c++) {
-                    V3 loc = {(c & 1) ? A.half[0] : -A.half[0], (c & 2) ? A.half[1] : -A.half[1], (c & 4) ? A.half[2] : -A.half[2]};
+                    V3 loc = {(c & 1) ? hA[0] : -hA[0], (c & 2) ? hA[1] : -hA[1], (c & 4) ? hA[2] : -hA[2]};
                     V3 pw = wa.p + mul(wa.R, loc);
                     if (pw.z < 0.f) contact_point(P, pw, ez, -pw.z, wa.v, zero, acc);
                 }
             } else if (A.type == 1) {
-                V3 pw = {wa.p.x, wa.p.y, wa.p.z - A.half[0]};
+                V3 pw = {wa.p.x, wa.p.y, wa.p.z - hA[0]};
                 if (pw.z < 0.f) contact_point(P, pw, ez, -pw.z, wa.v, zero, acc);
             } else {  // disc: lowest point of the rim, axis = local z
                 V3 ax = {wa.R.a[2], wa.R.a[5], wa.R.a[8]};
                 V3 d = {ax.z * ax.x, ax.z * ax.y, ax.z * ax.z - 1.f};
                 float l2 = dot(d, d);
                 if (l2 > 1e-8f) {
-                    V3 pw = wa.p + (A.half[0] / sqrtf(l2)) * d;
+                    V3 pw = wa.p + (hA[0] / sqrtf(l2)) * d;
                     if (pw.z < 0.f) contact_point(P, pw, ez, -pw.z, wa.v, zero, acc);
                 }
             }
         } else {
-            CShape &B = m.sh[P.b];
+            CShape &B = m.sh[Pm.b];
             const ShapeW wb = shape_world(B, root, L);
             rbB = B.rb;
             entB = B.ent;
+            for (int j = 0; j < 3; j++) hB[j] = B.half[j];
+            if (Pm.rnd && B.src_actor != m.robot_actor) {
+                const int ob = Lay::kRnd + 5 * B.src_actor;
+                if (B.type == 0) for (int j = 0; j < 3; j++) hB[j] += 0.5f * L[ob + j];
+                else if (B.type == 1) hB[0] += L[ob];
+            }
             if (A.type == 0 && B.type == 0) {
-                box_corners_in_box(P, wa, A.half, wb, B.half, 1.f, wa.v, wb.v, acc);
-                box_corners_in_box(P, wb, B.half, wa, A.half, -1.f, wa.v, wb.v, acc);
+                box_corners_in_box(P, wa, hA, wb, hB, 1.f, wa.v, wb.v, acc);
+                box_corners_in_box(P, wb, hB, wa, hA, -1.f, wa.v, wb.v, acc);
             } else if (A.type == 1 && B.type == 0) {
-                sphere_in_box(P, wa.p, A.half[0], wb, B.half, 1.f, wa.v, wb.v, acc);
+                sphere_in_box(P, wa.p, hA[0], wb, hB, 1.f, wa.v, wb.v, acc);
             } else if (A.type == 0 && B.type == 1) {
-                sphere_in_box(P, wb.p, B.half[0], wa, A.half, -1.f, wa.v, wb.v, acc);
+                sphere_in_box(P, wb.p, hB[0], wa, hA, -1.f, wa.v, wb.v, acc);
             }
         }
         if (acc.any) {
             const SV neg = {{-acc.f.a.x, -acc.f.a.y, -acc.f.a.z}, {-acc.f.l.x, -acc.f.l.y, -acc.f.l.z}};
-            if (P.mode == 0) {
+            if (Pm.mode == 0) {
                 acc_add(L, Lay::kAcc, A.ent, acc.f, nullptr);
                 acc_add(L, Lay::kAcc, entB, neg, nullptr);
-            } else if (P.mode == 1) {
+            } else if (Pm.mode == 1) {
                 acc_add(L, Lay::kAcc, A.ent, acc.f, &acc.C);
             } else {
                 acc_add(L, Lay::kAcc, entB, neg, &acc.C);
             }
-            const int oa = Lay::kCf + 3 * A.rb;
-            L[oa] += acc.rep.x; L[oa + 1] += acc.rep.y; L[oa + 2] += acc.rep.z;
+            const int ocf = Lay::kCf + 3 * A.rb;
+            L[ocf] += acc.rep.x; L[ocf + 1] += acc.rep.y; L[ocf + 2] += acc.rep.z;
             if (rbB >= 0) {
                 const int ob = Lay::kCf + 3 * rbB;
                 L[ob] -= acc.rep.x; L[ob + 1] -= acc.rep.y; L[ob + 2] -= acc.rep.z;
@@ -561,17 +639,28 @@ MPPI_HD void step_scene(CModel &m0, const float *root, SceneState<T> &s, const f
                 V3 p;
                 SV v;
                 frame_load(L, NB + 1 + f, R, p, v);
-                const float Ic6[6] = {F.Ic[0], 0.f, 0.f, F.Ic[1], 0.f, F.Ic[2]};
+                float fm = F.m, Ic6[6] = {F.Ic[0], 0.f, 0.f, F.Ic[1], 0.f, F.Ic[2]};
+                if (m.rnd_seed >= 0) {  // this sample's own mass and box size
+                    const int orn = SceneLayout<T>::kRnd + 5 * F.actor;
+                    fm *= L[orn + 3];
+                    if (F.type == 1) {  // MPPI_ACTOR_BOX
+                        const float x = F.size[0] + L[orn], y = F.size[1] + L[orn + 1], z = F.size[2] + L[orn + 2];
+                        Ic6[0] = fm / 12.f * (y * y + z * z); Ic6[3] = fm / 12.f * (x * x + z * z); Ic6[5] = fm / 12.f * (x * x + y * y);
+                    } else {  // sphere
+                        const float r = F.size[0] + L[orn];
+                        Ic6[0] = Ic6[3] = Ic6[5] = 0.4f * fm * r * r;
+                    }
+                }
                 AI A;
                 SV pA;
                 V3 hw;
-                rigid_world(R, p, F.m, V3{0.f, 0.f, 0.f}, Ic6, v, A, pA, hw);
+                rigid_world(R, p, fm, V3{0.f, 0.f, 0.f}, Ic6, v, A, pA, hw);
                 SV fe;
                 AI C;
                 acc_load(L, SceneLayout<T>::kAcc, NB + 1 + f, fe, C);
                 const V3 g = F.gravity ? V3{m.g[0], m.g[1], m.g[2]} : V3{0.f, 0.f, 0.f};
                 SV Cv = mul(C, v);
-                pA = {pA.a + Cv.a - fe.a - cross(hw, g), pA.l + Cv.l - fe.l - F.m * g};
+                pA = {pA.a + Cv.a - fe.a - cross(hw, g), pA.l + Cv.l - fe.l - fm * g};
                 A.I.xx += h * C.I.xx; A.I.xy += h * C.I.xy; A.I.xz += h * C.I.xz; A.I.yy += h * C.I.yy; A.I.yz += h * C.I.yz; A.I.zz += h * C.I.zz;
                 for (int j = 0; j < 9; j++) A.H[j] += h * C.H[j];
                 A.M.xx += h * C.M.xx; A.M.xy += h * C.M.xy; A.M.xz += h * C.M.xz; A.M.yy += h * C.M.yy; A.M.yz += h * C.M.yz; A.M.zz += h * C.M.zz;
@@ -583,7 +672,8 @@ MPPI_HD void step_scene(CModel &m0, const float *root, SceneState<T> &s, const f
 
 // ---- scene rollouts -----------------------------------------------------------------------------
 template <class T>
-MPPI_HD void scene_init(CModel &m, const float *dof0, const float *root, SceneState<T> &s) {
+MPPI_HD void scene_init(CModel &m, const float *dof0, const float *root, SceneState<T> &s, int g, const LMem &L) {
+    scene_randomise<T>(m, g, L);
     static_for<0, T::NB>([&](auto ic) MPPI_LAMBDA {
         constexpr int i = ic;
         s.q[i] = dof0[2 * i];
@@ -667,7 +757,7 @@ MPPI_HD float rollout_scene(CModel &m0, CCfg &cfg0, CCost &cost0, const float *d
     const bool is_null = cfg0.sample_null_action && g == cfg0.k_total - 1;
     const bool is_prior = cfg0.use_priors && prior != nullptr && g == cfg0.k_total - 2;
     SceneState<T> s;
-    scene_init<T>(m0, dof0, root, s);
+    scene_init<T>(m0, dof0, root, s, g, L);
     float target[NB ? NB : 1], u[kMaxNu];
     float S = 0.f, ctrl = 0.f, disc = 1.f;
     CModel *mp = &m0;

@@ -35,7 +35,8 @@ class Link(C.Structure):
 
 class Actor(C.Structure):
     _fields_ = [("type", _i), ("fixed", _i), ("collision", _i), ("gravity", _i), ("size", _d * 3),
-                ("mass", _d), ("friction", _d), ("first_rb", _i), ("n_rb", _i)]
+                ("mass", _d), ("friction", _d), ("first_rb", _i), ("n_rb", _i),
+                ("noise_sigma_size", _d * 3), ("noise_percentage_mass", _d), ("noise_percentage_friction", _d)]
 
 
 class Shape(C.Structure):
@@ -54,7 +55,8 @@ class Model(C.Structure):
                 ("drive_mode", _i), ("substeps", _i), ("drive_kd", _d), ("dt", _d), ("gravity", _d * 3),
                 ("nu", _i), ("cmd_col", (_i * 2) * MAX_BODIES), ("cmd_coef", (_d * 2) * MAX_BODIES),
                 ("n_shapes", _i), ("n_pairs", _i), ("shapes", Shape * MAX_SHAPES), ("pairs", Pair * MAX_PAIRS),
-                ("ground_friction", _d), ("contact_alpha", _d), ("contact_beta", _d), ("friction_beta", _d)]
+                ("ground_friction", _d), ("contact_alpha", _d), ("contact_beta", _d), ("friction_beta", _d),
+                ("randomize_seed", _i), ("pad2_", _i)]
 
 
 class Config(C.Structure):

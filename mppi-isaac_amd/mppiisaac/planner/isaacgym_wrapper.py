@@ -124,6 +124,7 @@ class Scene:
         self.n_rb = len(self.rb_names)
         self.cmd_terms, self.nu = self._command_map()
         self.shapes, self.pairs = self._contact_scene()
+        self.randomize_seed = -1  # >= 0: per-sample size/mass/friction draws of the noisy box/sphere actors
 
     def _command_map(self):
         """apply_robot_cmd's scatter (reference :524-559) as <=2 (column, coefficient) terms per DOF."""
@@ -263,6 +264,12 @@ class Scene:
             for j in range(3):
                 ca.size[j] = float(size[j])
             ca.mass, ca.friction = float(a.mass), float(a.friction)
+            if a.type != "robot":
+                ns = list(a.noise_sigma_size or []) + [0.0] * 3
+                for j in range(3):
+                    ca.noise_sigma_size[j] = float(ns[j])
+                ca.noise_percentage_mass = float(a.noise_percentage_mass)
+                ca.noise_percentage_friction = float(a.noise_percentage_friction)
             ca.first_rb = self.first_rb[i]
             ca.n_rb = len(self.link_names) if a.type == "robot" else 1
         m.robot_actor = self.robot_idx
@@ -321,6 +328,7 @@ class Scene:
             m.pairs[i].a, m.pairs[i].b = a, b
         m.ground_friction = self.GROUND_FRICTION
         m.contact_alpha, m.contact_beta, m.friction_beta = self.CONTACT_ALPHA, self.CONTACT_BETA, self.FRICTION_BETA
+        m.randomize_seed = int(self.randomize_seed)
         if self.robot.dof_mode not in DRIVE_GAINS:
             raise ValueError("Invalid dof_mode")
         m.drive_mode, m.drive_kd = DRIVE_GAINS[self.robot.dof_mode]
@@ -339,7 +347,7 @@ def _dev_ptr(t: Optional[torch.Tensor]):
 class IsaacGymWrapper:
     def __init__(self, cfg: IsaacGymConfig, actors: List[str], init_positions: List[List[float]] = None,
                  num_envs: int = 1, viewer: bool = False, device: str = "cuda:0", interactive_goal=True,
-                 mppi_config=None):
+                 mppi_config=None, randomize_seed: Optional[int] = None):
         from mppiisaac.utils.isaacgym_utils import load_actor_cfgs, load_asset
 
         if viewer or getattr(cfg, "viewer", False):
@@ -365,6 +373,11 @@ class IsaacGymWrapper:
         self._mppi_config_factory = mppi_config  # kept to rebuild the C config when the actor list changes
         self.generation = 0
         self.scene = Scene(self.env_cfg, cfg, load_asset(robots[0]) if robots else None)
+        # The reference draws a different size/mass/friction for every env of noisy box actors (unseeded
+        # np.random, :430-475).  Here the K rollout envs draw from a seeded hash of the global sample id; a
+        # single env (the K=1 "world") keeps the nominal values unless a seed is passed explicitly.
+        self._randomize_seed = randomize_seed if randomize_seed is not None else (0 if self.num_envs > 1 else -1)
+        self.scene.randomize_seed = self._randomize_seed
         self.start_sim()
 
     # ------------------------------------------------------------------ lifetime
@@ -555,6 +568,7 @@ class IsaacGymWrapper:
             a.handle = i
         robots = [a for a in self.env_cfg if a.type == "robot"]
         self.scene = Scene(self.env_cfg, self.cfg, load_asset(robots[0]))
+        self.scene.randomize_seed = self._randomize_seed
         self._mppi_config = self._mppi_config_factory
         self.generation += 1
         self.start_sim()

@@ -951,12 +951,67 @@ void orc_sample(const mppi_config_t *cfg, uint32_t index_base, real *eps) {
     free(z);
 }
 
+/* ------------------------------------------------------------------ per-sample actor randomisation */
+/* The reference draws, per env and per noisy actor, a size (normal), a mass and a friction (uniform +-percentage)
+ * from numpy's unseeded global generator (isaacgym_wrapper.py:430-475, isaacgym_utils.py:30-52). Here the draws
+ * are a counter-based hash of (seed, global sample index, actor, component) so that every GPU shard, the host
+ * emulation and this oracle see the same per-sample world. fp32 arithmetic on purpose: the draws are inputs. */
+static float hash_uniform(int seed, int g, int actor, int k) {
+    uint32_t h = (uint32_t)seed * 0x9E3779B1u ^ (uint32_t)(g + 1) * 0x85EBCA77u ^ (uint32_t)(actor + 1) * 0xC2B2AE3Du ^ (uint32_t)(k + 1) * 0x27D4EB2Fu;
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    return ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
+}
+/* [actor][5]: size deltas xyz, mass scale, friction of sample g */
+void orc_randomise_draws(const mppi_model_t *m, int g, double *out) {
+    for (int a = 0; a < m->n_actors; a++) {
+        const mppi_actor_t *A = &m->actors[a];
+        int on = m->randomize_seed >= 0 && a != m->robot_actor;
+        for (int j = 0; j < 3; j++) {
+            double sg = on ? A->noise_sigma_size[j] : 0;
+            out[5 * a + j] = sg != 0 ? sg * orc_norminv((double)hash_uniform(m->randomize_seed, g, a, j)) : 0;
+        }
+        double pm = on ? A->noise_percentage_mass : 0, pf = on ? A->noise_percentage_friction : 0;
+        out[5 * a + 3] = pm != 0 ? 1 + pm * (2 * (double)hash_uniform(m->randomize_seed, g, a, 3) - 1) : 1;
+        out[5 * a + 4] = pf != 0 ? A->friction * (1 + pf * (2 * (double)hash_uniform(m->randomize_seed, g, a, 4) - 1)) : A->friction;
+    }
+}
+/* the model sample g simulates: noisy actors and their shapes take this sample's size / mass / friction */
+void orc_randomise_model(const mppi_model_t *m, int g, mppi_model_t *out) {
+    *out = *m;
+    if (m->randomize_seed < 0) return;
+    double dr[5 * MPPI_MAX_ACTORS];
+    orc_randomise_draws(m, g, dr);
+    for (int a = 0; a < m->n_actors; a++) {
+        if (a == m->robot_actor) continue;
+        mppi_actor_t *A = &out->actors[a];
+        if (A->type == MPPI_ACTOR_BOX) for (int j = 0; j < 3; j++) A->size[j] += dr[5 * a + j];
+        else A->size[0] += dr[5 * a];
+        A->mass *= dr[5 * a + 3];
+        A->friction = dr[5 * a + 4];
+    }
+    for (int i = 0; i < m->n_shapes; i++) {
+        mppi_shape_t *S = &out->shapes[i];
+        if (S->actor == m->robot_actor) continue;
+        if (S->type == MPPI_SHAPE_BOX) for (int j = 0; j < 3; j++) S->size[j] += 0.5 * dr[5 * S->actor + j];
+        else if (S->type == MPPI_SHAPE_SPHERE) S->size[0] += dr[5 * S->actor];
+        S->friction = dr[5 * S->actor + 4];
+    }
+    out->randomize_seed = -1;
+}
+
 /* ------------------------------------------------------------------ rollout + update */
 /* One sample: returns total cost S: sum_t gamma^t c_t + lambda * sum_t U_t^T Sigma^-1 du_t */
-static real rollout_one(const mppi_model_t *m, const mppi_config_t *cfg, const mppi_cost_t *cost, const real *dof0,
+static real rollout_one(const mppi_model_t *m_nominal, const mppi_config_t *cfg, const mppi_cost_t *cost, const real *dof0,
                         const real *root0, const real *U, const real *eps, const real *prior, int k, real *du, real *viz) {
-    int K = cfg->num_samples, H = cfg->horizon, nu = cfg->nu, n = m->n_bodies;
+    int K = cfg->num_samples, H = cfg->horizon, nu = cfg->nu, n = m_nominal->n_bodies;
     int g = cfg->k_offset + k;
+    const mppi_model_t *m = m_nominal;
+    mppi_model_t *mine = NULL;
+    if (m_nominal->randomize_seed >= 0) {
+        mine = (mppi_model_t *)malloc(sizeof(mppi_model_t));
+        orc_randomise_model(m_nominal, g, mine);
+        m = mine;
+    }
     real q[NBMAX], qd[NBMAX], target[NBMAX], u[MPPI_MAX_NU];
     real *rb = (real *)malloc(sizeof(real) * 13 * m->n_rb);
     real *cf = (real *)calloc(3 * (size_t)m->n_rb + 3, sizeof(real));
@@ -990,7 +1045,7 @@ static real rollout_one(const mppi_model_t *m, const mppi_config_t *cfg, const m
             for (int j = 0; j < 3; j++) viz[((size_t)t * K + k) * 3 + j] = o[j];
         }
     }
-    free(rb); free(cf);
+    free(rb); free(cf); free(mine);
     return S + ctrl;
 }
 

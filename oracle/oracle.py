@@ -83,6 +83,18 @@ class Oracle:
         self.lib.orc_scene_step(C.byref(model), self.p(root), self.p(q), self.p(qd), self.p(target), self.p(cf))
         return root, q, qd, cf
 
+    def randomise_draws(self, model, g):
+        """[n_actors, 5] size deltas xyz, mass scale, friction that sample g simulates"""
+        out = np.zeros((model.n_actors, 5), np.float64)
+        self.lib.orc_randomise_draws(C.byref(model), C.c_int(g), out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def randomise_model(self, model, g):
+        """the model sample g simulates (noisy actors take their per-sample size / mass / friction)"""
+        out = type(model)()
+        self.lib.orc_randomise_model(C.byref(model), C.c_int(g), C.byref(out))
+        return out
+
     def sample(self, cfg, index_base=0):
         eps = np.zeros((cfg.horizon, cfg.nu, cfg.num_samples), self.dtype)
         self.lib.orc_sample(C.byref(cfg), C.c_uint32(index_base), self.p(eps))

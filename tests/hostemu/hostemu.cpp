@@ -89,7 +89,7 @@ int emu_rigid_body_state(const mppi_model_t *model, const float *root, const flo
 }
 
 // one dt step of a contact scene: dof [2n] and root [A][13] are updated in place; rb/cf = reference-layout rows
-int emu_scene_step(const mppi_model_t *model, float *dof, float *root, const float *u, float *rb, float *cf) {
+int emu_scene_step_g(const mppi_model_t *model, float *dof, float *root, const float *u, float *rb, float *cf, int sample_id) {
     DevModel m; std::string err;
     if (!pack_model(*model, m, err)) return -1;
     int parents[MPPI_MAX_BODIES];
@@ -99,7 +99,7 @@ int emu_scene_step(const mppi_model_t *model, float *dof, float *root, const flo
         std::vector<float> lmem(SceneLayout<T>::floats(m.n_rb));
         LMem L{lmem.data(), 1};
         SceneState<T> s;
-        scene_init<T>(m, dof, root, s);
+        scene_init<T>(m, dof, root, s, sample_id, L);
         float target[MPPI_MAX_BODIES + 1], uu[kMaxNu] = {0};
         for (int c = 0; c < m.nu; c++) uu[c] = u[c];
         cmd_map<T>(m, uu, target);
@@ -110,6 +110,10 @@ int emu_scene_step(const mppi_model_t *model, float *dof, float *root, const flo
         for (int j = 0; j < 13 * m.n_actors; j++) root[j] = rootn[j];
     });
     return ok ? 0 : -3;
+}
+
+int emu_scene_step(const mppi_model_t *model, float *dof, float *root, const float *u, float *rb, float *cf) {
+    return emu_scene_step_g(model, dof, root, u, rb, cf, 0);
 }
 
 float emu_cost(const mppi_model_t *model, const mppi_cost_t *cost, const float *root, const float *q, const float *qd) {

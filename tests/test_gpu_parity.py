@@ -305,6 +305,41 @@ def test_boxer_push_rollout_matches_oracle(lib, oracle64):
     c.close()
 
 
+def test_randomised_actors_per_sample(lib, oracle64):
+    """every sample simulates its own block size / mass / friction (reference isaacgym_wrapper.py:430-475,
+    seeded here). The draws are a function of the GLOBAL sample index: a shard reproduces its slice of the single-context
+    costs bit for bit, and the costs follow the oracle run on the same explicitly perturbed models."""
+    from mppiisaac.planner.mppi import make_config
+    from mppiisaac.utils.config_store import load_config
+    K, H = 256, 12
+    scene, m0, cfg, cost, dof, root = boxer_push(K=K, H=H)
+    root[0, 2] = 0.019
+    root[scene.actor_index("block"), 0:3] = [0.0, 1.9, 0.0923]      # in front of the robot: pushed in most samples
+    scene.randomize_seed = 3
+    m = scene.to_c()
+    eps = oracle64.sample(cfg)
+
+    def costs(model, config):
+        c = Ctx(model, config, cost)
+        c.call("mppi_sample", C.c_uint32(0)); c.set_state(dof, root); c.call("mppi_rollout")
+        S = c.get("mppi_get_costs", (config.num_samples,))
+        c.close()
+        return S
+    S_nom, S = costs(m0, cfg), costs(m, cfg)
+    assert np.isfinite(S).all()
+    assert (np.abs(S - S_nom) > 1e-3 * np.abs(S_nom)).mean() > 0.3         # the perturbed worlds differ from the nominal one
+    So, _, _ = oracle64.rollout(m, cfg, cost, dof, root, np.zeros((H, 2)), eps)
+    So_nom, _, _ = oracle64.rollout(m0, cfg, cost, dof, root, np.zeros((H, 2)), eps)
+    agree = (np.abs(S - So) <= 1e-2 * np.abs(So)).mean()
+    assert np.median(S) == pytest.approx(np.median(So), rel=2e-2)
+    assert agree > 0.8
+    assert agree > (np.abs(S - So_nom) <= 1e-2 * np.abs(So_nom)).mean() + 0.1   # and it is THIS seed's worlds that it follows
+    ex = load_config({"defaults": [{"mppi": "boxer_push"}, {"isaacgym": "normal"}]}, overrides={"mppi.num_samples": K, "mppi.horizon": H})
+    for r in range(2):
+        sc = make_config(ex.mppi, k_offset=r * K // 2, k_local=K // 2, viz_link=scene.viz_link_index())
+        np.testing.assert_array_equal(costs(m, sc), S[r * K // 2:(r + 1) * K // 2])
+
+
 def test_boxer_generic_mode_and_world(lib, oracle64):
     """Objective callback path and the K=1 world simulator on the contact scene: reference-layout tensors
     (root states of the moving base and block, net contact forces) against the oracle."""

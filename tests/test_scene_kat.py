@@ -174,3 +174,66 @@ def test_panda_pick_scene(hostemu, oracle64):
     assert hostemu.emu_rollout(C.byref(m), C.byref(cfg), C.byref(cost), fp(f32(dof)), fp(f32(root)), fp(f32(U)), fp(f32(eps)), None,
                                fp(Se), fp(due), None) == 0
     np.testing.assert_allclose(Se, S, rtol=1e-4)
+
+
+# ---------------------------------------------------------------- per-sample actor randomisation
+def test_randomisation_draws_are_seeded_per_sample_and_bounded(oracle64):
+    """reference isaacgym_wrapper.py:430-475 / isaacgym_utils.py:30-52: size ~ N(0, sigma), mass and friction
+    uniform within +-percentage - here a counter-based hash of (seed, sample, actor) instead of np.random"""
+    scene, m, cfg, cost, dof, root = boxer_push()
+    a = scene.actor_index("block")
+    scene.randomize_seed = -1
+    off = oracle64.randomise_draws(scene.to_c(), 3)
+    np.testing.assert_array_equal(off[:, 0:4], np.tile([0.0, 0.0, 0.0, 1.0], (m.n_actors, 1)))
+    scene.randomize_seed = 11
+    m = scene.to_c()
+    d = np.stack([oracle64.randomise_draws(m, g) for g in range(4096)])
+    np.testing.assert_array_equal(d, np.stack([oracle64.randomise_draws(m, g) for g in range(4096)]))
+    assert np.all(d[:, scene.actor_index("boxer")] == [0, 0, 0, 1, m.actors[scene.actor_index("boxer")].friction])
+    blk = d[:, a]
+    assert abs(blk[:, 0].mean()) < 4e-4 and abs(blk[:, 0].std() - 0.005) < 3e-4   # block.yaml noise_sigma_size
+    assert np.all(blk[:, 2] == 0.0)
+    assert 0.7 <= blk[:, 3].min() < 0.71 and 1.29 < blk[:, 3].max() <= 1.3
+    f0 = m.actors[a].friction
+    assert 0.7 * f0 <= blk[:, 4].min() and blk[:, 4].max() <= 1.3 * f0 and blk[:, 4].std() > 0.1 * f0
+    assert abs(np.corrcoef(blk[:, 0], blk[:, 1])[0, 1]) < 0.05
+    scene.randomize_seed = 12
+    assert not np.allclose(oracle64.randomise_draws(scene.to_c(), 0)[a], d[0, a])
+
+
+def test_randomised_samples_device_arithmetic_matches_oracle(hostemu, oracle64):
+    """every sample simulates its own block (size / mass / friction): device code with per-sample draws in LDS vs the
+    oracle stepping an explicitly perturbed model, re-synchronised every step"""
+    hostemu.emu_scene_step_g.restype = C.c_int
+    scene, m, cfg, cost, dof, root0 = boxer_push()
+    scene.randomize_seed = 5
+    m = scene.to_c()
+    differs = steps = switched = 0
+    for g in (0, 1, 77, 4095):
+        mg = oracle64.randomise_model(m, g)
+        root = root0.astype(float)
+        root[scene.actor_index("block"), 0:3] = [0.05, 1.9, 0.1]       # right in front of the robot: pushed within a few steps
+        q, qd = dof[0::2].astype(float), dof[1::2].astype(float)
+        rb = np.zeros((m.n_rb, 13), np.float32)
+        cf = np.zeros((m.n_rb, 3), np.float32)
+        worst = 0.0
+        for u, n in [((0.0, 0.0), 8), ((0.6, 0.0), 20), ((0.4, 0.9), 12), ((-0.3, -1.5), 10)]:
+            for _ in range(n):
+                de = np.zeros(2 * scene.n_dof, np.float32)
+                de[0::2], de[1::2] = q, qd
+                re = f32(root).copy()
+                assert hostemu.emu_scene_step_g(C.byref(m), fp(de), fp(re.reshape(-1)), fp(f32(u)), fp(rb), fp(cf), C.c_int(g)) == 0
+                nominal = oracle64.scene_step(m, root, q, qd, oracle64.cmd_map(m, u))[0]
+                root, q, qd, cfo = oracle64.scene_step(mg, root, q, qd, oracle64.cmd_map(m, u))
+                differs += int(np.abs(nominal[:, 7:13] - root[:, 7:13]).max() > 1e-4)
+                steps += 1
+                # a support point touching down inside a substep switches its approach damper on (a velocity jump of
+                # beta * v_n): fp32 and fp64 can take that event one substep apart. Such steps are counted, not hidden.
+                if np.abs(re[:, 0:7] - root[:, 0:7]).max() > 2e-5 or np.abs(re[:, 7:13] - root[:, 7:13]).max() > 2e-3:
+                    switched += 1
+                    np.testing.assert_allclose(re[:, 0:7], root[:, 0:7], atol=5e-3)
+                    continue
+                worst = max(worst, np.abs(cf - cfo).max() / max(1.0, np.abs(cfo).max()))
+        assert worst < 5e-3
+    assert switched <= 0.02 * steps, (switched, steps)
+    assert differs > 20      # the perturbed worlds really do evolve differently from the nominal one
