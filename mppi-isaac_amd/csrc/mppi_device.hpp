@@ -100,7 +100,8 @@ struct DevModel {
     float kd, h, g[3], base_m, pad2[2];
     float base_hb[3], base_Ic[6], pad3[3];
     int actor_first_rb[kMaxActors];
-    int n_shapes, n_pairs, rnd_seed, pad4;
+    int n_shapes, n_pairs, rnd_seed, n_rnd;
+    int rnd_slot[kMaxActors];    // LDS slot of a noisy actor's per-sample draws (-1: nominal)
     float noise[kMaxActors][5];  // per actor: sigma_size xyz, mass percentage, friction percentage
     float actor_mu[kMaxActors], actor_mass[kMaxActors];
     DevBody b[kMaxBodies];

@@ -110,8 +110,11 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
         if (!same) continue;
         ok = true;
         if (c->scene) {
-            c->lds_bytes = sizeof(float) * kWave * (e->scene_lds_floats + 3 * (size_t)c->hm.n_rb);
-            c->launch_rollout = e->rollout_scene;
+            c->lds_bytes = sizeof(float) * kWave * (e->scene_lds_floats + 3 * (size_t)c->hm.n_rb + 5 * (size_t)c->hm.n_rnd);
+            // rollouts: 4 lanes per sample (contact points dealt over the quad) unless MPPI_ROLLOUT=lane
+            const char *mode = std::getenv("MPPI_ROLLOUT");
+            c->quad = !(mode && std::string(mode) == "lane");
+            c->launch_rollout = c->quad ? e->rollout_scene_quad : e->rollout_scene;
             c->launch_sim_step = e->sim_step_scene;
             c->launch_materialise = e->materialise_scene;
             if (hipSetDevice(device) == hipSuccess) lds_err = e->raise_lds(c->lds_bytes);
@@ -481,7 +484,7 @@ int mppi_kernel_ms(mppi_ctx_t *c, int which, float *ms) {
 }
 int mppi_kernel_info(mppi_ctx_t *c, char *buf, int buflen) {
     CTX_TRY(c);
-    std::snprintf(buf, buflen, "topology=%s rollout=%s K=%d H=%d nu=%d waves=%d block=%d bytes_alg=%zu", c->topo.c_str(), c->scene ? "scene" : (c->quad ? "quad" : "lane"), c->K, c->H, c->nu, c->quad ? c->n_quads : c->n_waves, kWave,
+    std::snprintf(buf, buflen, "topology=%s rollout=%s K=%d H=%d nu=%d waves=%d block=%d bytes_alg=%zu", c->topo.c_str(), c->scene ? (c->quad ? "scene-quad" : "scene") : (c->quad ? "quad" : "lane"), c->K, c->H, c->nu, c->quad ? c->n_quads : c->n_waves, kWave,
                   (size_t)4 * (3 * (size_t)c->K * c->HN + 2 * (size_t)c->K + c->HN));
     return MPPI_OK;
 }

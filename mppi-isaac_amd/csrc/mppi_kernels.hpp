@@ -317,6 +317,34 @@ __global__ __launch_bounds__(kWave) void k_rollout_scene(const DevModel *__restr
     wave_record(*(CCfg *)cfg, s, live, du, k, partials + (size_t)blockIdx.x * (2 + cfg->H * cfg->nu));
 }
 
+// Contact scene, 4 lanes per sample: the quad replicates the sample's state arithmetic (idle lanes cost nothing -
+// at K=8192 one lane per sample is only 128 wavefronts on 1024 SIMDs) and deals the contact feature points of
+// every pair over its four lanes (mppi_scene.hpp: kSplitQuad).  The sample's LDS rows are shared by the quad:
+// element i of the wave's s-th sample lives at lds[i*16 + s] (16 banks per row, 4-lane broadcast reads).
+template <class T>
+__global__ __launch_bounds__(kWave) void k_rollout_scene_quad(const DevModel *__restrict__ m, const DevCfg *__restrict__ cfg,
+                                                              const DevCost *__restrict__ cost, const float *__restrict__ x0_dof,
+                                                              const float *__restrict__ x0_root, const float *__restrict__ U,
+                                                              const float *__restrict__ eps, const float *__restrict__ prior,
+                                                              float *__restrict__ du, float *__restrict__ S, float *__restrict__ viz,
+                                                              float *__restrict__ partials) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int nb = gridDim.x;  // XCD-aware chunk mapping as in k_rollout_quad
+    const int chunk = (nb % 16 == 0) ? (int)(blockIdx.x % 8) * (nb / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    const int k = chunk * 16 + (threadIdx.x >> 2);
+    const int lane4 = threadIdx.x & 3;
+    const bool live = k < cfg->K;
+    const LMem L{lds + (threadIdx.x >> 2), 16};
+    float s = INFINITY;
+    if (live) {
+        s = rollout_scene<T, kSplitQuad>(*(CModel *)m, *(CCfg *)cfg, *(CCost *)cost, x0_dof, x0_root, U, eps, prior, du, viz, k, L, Split{lane4, 4});
+        if (lane4 == 0) S[k] = s;
+    }
+    wave_record(*(CCfg *)cfg, s, live && lane4 == 0, du, k, partials + (size_t)chunk * (2 + cfg->H * cfg->nu));
+#endif
+}
+
 // env state of contact scenes in HBM (sample-minor): base [13][K], free [kMaxFree*13][K], cf [n_rb*3][K]
 template <class T>
 __global__ __launch_bounds__(kWave) void k_sim_step_scene(const DevModel *__restrict__ m, const DevCfg *__restrict__ cfg, int mode, int t,
@@ -624,6 +652,7 @@ struct TopoEntry {
     void (*rollout)(mppi_ctx *);
     void (*rollout_quad)(mppi_ctx *);
     void (*rollout_scene)(mppi_ctx *);
+    void (*rollout_scene_quad)(mppi_ctx *);
     void (*sim_step)(mppi_ctx *, int, int, const float *);
     void (*sim_step_scene)(mppi_ctx *, int, int, const float *);
     void (*materialise)(mppi_ctx *, float *, float *, float *, float *);
@@ -638,6 +667,12 @@ namespace {
 template <class T>
 void launch_rollout_scene_t(mppi_ctx *c) {
     hipLaunchKernelGGL(k_rollout_scene<T>, dim3(c->n_waves), dim3(kWave), c->lds_bytes, c->stream, c->d_model, c->d_cfg, c->d_cost, c->d_x0_dof,
+                       c->d_x0_root, c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_S, c->cfg.want_rollouts ? c->d_viz : nullptr,
+                       c->d_partials);
+}
+template <class T>
+void launch_rollout_scene_quad_t(mppi_ctx *c) {
+    hipLaunchKernelGGL(k_rollout_scene_quad<T>, dim3(c->n_quads), dim3(kWave), c->lds_bytes / 4, c->stream, c->d_model, c->d_cfg, c->d_cost, c->d_x0_dof,
                        c->d_x0_root, c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_S, c->cfg.want_rollouts ? c->d_viz : nullptr,
                        c->d_partials);
 }
@@ -693,6 +728,7 @@ TopoEntry make_topo_entry() {
     e.rollout = &launch_rollout_t<T>;
     e.rollout_quad = &launch_rollout_quad_t<T>;
     e.rollout_scene = &launch_rollout_scene_t<T>;
+    e.rollout_scene_quad = &launch_rollout_scene_quad_t<T>;
     e.sim_step = &launch_sim_step_t<T>;
     e.sim_step_scene = &launch_sim_step_scene_t<T>;
     e.materialise = &launch_materialise_t<T>;

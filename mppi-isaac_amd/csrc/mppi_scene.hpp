@@ -31,9 +31,9 @@ struct SceneLayout {
     static constexpr int NF = T::NB + 1 + kMaxFree;  // dynamic frames
     static constexpr int kFrame = 0;                 // [NF][18]: R(9) p(3) w(3) vO(3)
     static constexpr int kAcc = NF * 18;             // [NF][27]: f(6) C(21)
-    static constexpr int kRnd = kAcc + NF * 27;      // [kMaxActors][5] this sample's size deltas xyz, mass scale, friction
-    static constexpr int kCf = kRnd + kMaxActors * 5;  // [n_rb][3] net contact force
-    MPPI_HD static constexpr int floats(int n_rb) { return kCf + 3 * n_rb; }
+    static constexpr int kCf = kAcc + NF * 27;       // [n_rb][3] net contact force
+    // then [n_rnd][5]: this sample's size deltas xyz, mass scale, friction of the noisy actors (m.rnd_slot)
+    MPPI_HD static constexpr int floats(int n_rb, int n_rnd) { return kCf + 3 * n_rb + 5 * n_rnd; }
 };
 
 // counter-based uniform in (0,1): the seeded stand-in for the reference's unseeded np.random draws per env
@@ -59,22 +59,33 @@ MPPI_HD float std_normal_from_uniform(float u) {
 #endif
 }
 
-// this sample's draws for every actor: size deltas, mass scale, friction (nominal when randomisation is off)
+// this sample's draws for the noisy actors: size deltas, mass scale, friction
 template <class T>
 MPPI_HD void scene_randomise(CModel &m, int g, const LMem &L) {
     using Lay = SceneLayout<T>;
-    for (int a = 0; a < kMaxActors; a++) {
-        const int o = Lay::kRnd + 5 * a;
-        const bool on = m.rnd_seed >= 0 && a < m.n_actors && a != m.robot_actor;
+    if (m.n_rnd == 0) return;
+    for (int a = 0; a < m.n_actors; a++) {
+        const int slot = m.rnd_slot[a];
+        if (slot < 0) continue;
+        const int o = Lay::kCf + 3 * m.n_rb + 5 * slot;
         for (int j = 0; j < 3; j++) {
-            const float sg = on ? m.noise[a][j] : 0.f;
+            const float sg = m.noise[a][j];
             L[o + j] = sg != 0.f ? sg * std_normal_from_uniform(hash_uniform(m.rnd_seed, g, a, j)) : 0.f;
         }
-        const float pm = on ? m.noise[a][3] : 0.f, pf = on ? m.noise[a][4] : 0.f;
+        const float pm = m.noise[a][3], pf = m.noise[a][4], mu0 = m.actor_mu[a];
         L[o + 3] = pm != 0.f ? 1.f + pm * (2.f * hash_uniform(m.rnd_seed, g, a, 3) - 1.f) : 1.f;
-        const float mu0 = a < m.n_actors ? m.actor_mu[a] : 0.f;
         L[o + 4] = pf != 0.f ? mu0 * (1.f + pf * (2.f * hash_uniform(m.rnd_seed, g, a, 4) - 1.f)) : mu0;
     }
+}
+struct ActorDraw {
+    float d[3], ms, mu;
+};
+template <class T>
+MPPI_HD ActorDraw actor_draw(CModel &m, int a, const LMem &L) {
+    const int slot = m.rnd_slot[a];
+    if (slot < 0) return ActorDraw{{0.f, 0.f, 0.f}, 1.f, m.actor_mu[a]};
+    const int o = SceneLayout<T>::kCf + 3 * m.n_rb + 5 * slot;
+    return ActorDraw{{L[o], L[o + 1], L[o + 2]}, L[o + 3], L[o + 4]};
 }
 
 constexpr int scene_floats_max(int nb) { return (nb + 1 + kMaxFree) * 45 + 3 * (kMaxLinks + kMaxActors); }
@@ -207,6 +218,44 @@ MPPI_HD void pair_zero(PairAcc &a) {
     a.any = false;
 }
 
+MPPI_HD void pair_add(PairAcc &a, const PairAcc &b) {
+    a.f = a.f + b.f;
+    add_to(a.C, b.C);
+    a.rep = a.rep + b.rep;
+    a.any = a.any || b.any;
+}
+
+// How the feature points of one pair are dealt over the lanes that share a sample: lane `sub` of `n` takes the
+// points sub, sub + n, ...  kSplitNone: one lane per sample.  kSplitQuad: the 4 lanes of a quad hold the same
+// sample state (replicated arithmetic) and share the sample's LDS rows; the partial pair sums are combined with
+// a DPP butterfly so that all four lanes see bit-identical totals.  kSplitEmulate: host restatement of
+// kSplitQuad (the four partial sums are formed one after the other).
+enum { kSplitNone = 0, kSplitQuad = 1, kSplitEmulate = 2 };
+struct Split {
+    int sub, n;
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int CTRL>
+__device__ __forceinline__ float scene_dpp(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+// sum over the quad, identical in all four lanes: (x0+x1)+(x2+x3) in every lane (fp addition commutes)
+__device__ __forceinline__ float quad_allsum(float x) {
+    x += scene_dpp<0xB1>(x);  // quad_perm [1,0,3,2]
+    x += scene_dpp<0x4E>(x);  // quad_perm [2,3,0,1]
+    return x;
+}
+__device__ __forceinline__ void quad_reduce(PairAcc &a) {
+    a.any = quad_allsum(a.any ? 1.f : 0.f) > 0.f;
+    a.f.a = {quad_allsum(a.f.a.x), quad_allsum(a.f.a.y), quad_allsum(a.f.a.z)};
+    a.f.l = {quad_allsum(a.f.l.x), quad_allsum(a.f.l.y), quad_allsum(a.f.l.z)};
+    a.rep = {quad_allsum(a.rep.x), quad_allsum(a.rep.y), quad_allsum(a.rep.z)};
+    a.C.I = {quad_allsum(a.C.I.xx), quad_allsum(a.C.I.xy), quad_allsum(a.C.I.xz), quad_allsum(a.C.I.yy), quad_allsum(a.C.I.yz), quad_allsum(a.C.I.zz)};
+    for (int j = 0; j < 9; j++) a.C.H[j] = quad_allsum(a.C.H[j]);
+    a.C.M = {quad_allsum(a.C.M.xx), quad_allsum(a.C.M.xy), quad_allsum(a.C.M.xz), quad_allsum(a.C.M.yy), quad_allsum(a.C.M.yz), quad_allsum(a.C.M.zz)};
+}
+#endif
+
 // One contact point p (world), unit normal n pointing from B to A, penetration depth > 0.
 struct Gains {  // per-pair contact parameters of THIS sample (equal to the packed nominal ones without randomisation)
     int mode;
@@ -279,8 +328,9 @@ MPPI_HD ShapeW shape_world(CShape &S, const float *root, const LMem &L) {
 // Feature points of box X (8 corners, 12 edge midpoints, 6 face centres) that lie inside box Y; a pure
 // vertex test misses boxes that cross like a plus sign (a tall block against a wide chassis face).
 // sign = +1 when X is shape A (normal from B=Y to A=X)
-MPPI_HD void box_corners_in_box(const Gains &P, const ShapeW &X, const float *hx, const ShapeW &Y, const float *hy, float sign, const SV &vA, const SV &vB, PairAcc &acc) {
-    for (int c = 0; c < 27; c++) {
+MPPI_HD void box_corners_in_box(const Gains &P, const ShapeW &X, const float *hx, const ShapeW &Y, const float *hy, float sign, const SV &vA, const SV &vB,
+                                Split sp, PairAcc &acc) {
+    for (int c = sp.sub; c < 27; c += sp.n) {
         if (c == 13) continue;  // the centre is not a surface feature
         V3 loc = {(float)(c % 3 - 1) * hx[0], (float)((c / 3) % 3 - 1) * hx[1], (float)(c / 9 - 1) * hx[2]};
         V3 pw = X.p + mul(X.R, loc);
@@ -327,11 +377,10 @@ MPPI_HD void sphere_in_box(const Gains &P, V3 ps, float r, const ShapeW &Y, cons
 }
 
 // All candidate pairs of the scene -> per-frame wrench / damping accumulators and net contact forces.
-template <class T>
-MPPI_HD void contact_forces(CModel &m, const float *root, const LMem &L) {
+template <class T, int SPLIT = kSplitNone>
+MPPI_HD void contact_forces(CModel &m, const float *root, const LMem &L, Split split = Split{0, 1}) {
     using Lay = SceneLayout<T>;
-    for (int j = Lay::kAcc; j < Lay::kRnd; j++) L[j] = 0.f;
-    for (int j = Lay::kCf; j < Lay::floats(m.n_rb); j++) L[j] = 0.f;
+    for (int j = Lay::kAcc; j < Lay::kCf + 3 * m.n_rb; j++) L[j] = 0.f;
     const SV zero = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
     for (int ip = 0; ip < m.n_pairs; ip++) {
         CPair &Pm = m.pr[ip];
@@ -339,23 +388,28 @@ MPPI_HD void contact_forces(CModel &m, const float *root, const LMem &L) {
         const ShapeW wa = shape_world(A, root, L);
         Gains P = {Pm.mode, Pm.mu, Pm.k, Pm.cn, Pm.ct, Pm.kh};
         float hA[3] = {A.half[0], A.half[1], A.half[2]}, hB[3] = {0.f, 0.f, 0.f};
-        const int oa = Lay::kRnd + 5 * A.src_actor;
-        if (Pm.rnd) {  // this sample's own box size / friction / mass of the noisy actors in the pair
-            if (A.src_actor != m.robot_actor) {
-                if (A.type == 0) for (int j = 0; j < 3; j++) hA[j] += 0.5f * L[oa + j];
-                else if (A.type == 1) hA[0] += L[oa];
+        if (Pm.rnd) {  // this sample's own size / friction / mass of the noisy actors in the pair
+            const bool ra = A.src_actor == m.robot_actor;
+            const ActorDraw da = actor_draw<T>(m, A.src_actor, L);
+            if (!ra) {
+                if (A.type == 0) for (int j = 0; j < 3; j++) hA[j] += 0.5f * da.d[j];
+                else if (A.type == 1) hA[0] += da.d[0];
             }
-            const float mua = A.src_actor != m.robot_actor ? L[oa + 4] : A.mu;
+            const float mua = ra ? A.mu : da.mu;
             float mub = Pm.mub, sb = 1.f;
-            const float sa = A.src_actor != m.robot_actor ? L[oa + 3] : 1.f;
             if (Pm.b >= 0) {
                 CShape &Bs = m.sh[Pm.b];
-                const int ob = Lay::kRnd + 5 * Bs.src_actor;
-                mub = Bs.src_actor != m.robot_actor ? L[ob + 4] : Bs.mu;
-                sb = Bs.src_actor != m.robot_actor ? L[ob + 3] : 1.f;
+                const bool rbt = Bs.src_actor == m.robot_actor;
+                const ActorDraw db = actor_draw<T>(m, Bs.src_actor, L);
+                mub = rbt ? Bs.mu : db.mu;
+                sb = db.ms;
+                if (!rbt) {
+                    if (Bs.type == 0) for (int j = 0; j < 3; j++) hB[j] = 0.5f * db.d[j];
+                    else if (Bs.type == 1) hB[0] = db.d[0];
+                }
             }
             P.mu = fminf(mua, mub);
-            const float ma = Pm.ma * sa, mb = Pm.mb * sb;
+            const float ma = Pm.ma * da.ms, mb = Pm.mb * sb;
             const float meff0 = Pm.mode == 0 ? Pm.ma * Pm.mb / (Pm.ma + Pm.mb) : (Pm.mode == 1 ? Pm.ma : Pm.mb);
             const float meff = Pm.mode == 0 ? ma * mb / (ma + mb) : (Pm.mode == 1 ? ma : mb);
             const float sc = meff / meff0;
@@ -364,45 +418,60 @@ MPPI_HD void contact_forces(CModel &m, const float *root, const LMem &L) {
         PairAcc acc;
         pair_zero(acc);
         int rbB = -1, entB = -1;
-        if (Pm.b < 0) {  // ground plane z = 0, normal +z (from ground to A)
-            const V3 ez = {0.f, 0.f, 1.f};
-            if (A.type == 0) {
-                for (int c = 0; c < 8; c++) {
-                    V3 loc = {(c & 1) ? hA[0] : -hA[0], (c & 2) ? hA[1] : -hA[1], (c & 4) ? hA[2] : -hA[2]};
-                    V3 pw = wa.p + mul(wa.R, loc);
-                    if (pw.z < 0.f) contact_point(P, pw, ez, -pw.z, wa.v, zero, acc);
-                }
-            } else if (A.type == 1) {
-                V3 pw = {wa.p.x, wa.p.y, wa.p.z - hA[0]};
-                if (pw.z < 0.f) contact_point(P, pw, ez, -pw.z, wa.v, zero, acc);
-            } else {  // disc: lowest point of the rim, axis = local z
-                V3 ax = {wa.R.a[2], wa.R.a[5], wa.R.a[8]};
-                V3 d = {ax.z * ax.x, ax.z * ax.y, ax.z * ax.z - 1.f};
-                float l2 = dot(d, d);
-                if (l2 > 1e-8f) {
-                    V3 pw = wa.p + (hA[0] / sqrtf(l2)) * d;
-                    if (pw.z < 0.f) contact_point(P, pw, ez, -pw.z, wa.v, zero, acc);
-                }
-            }
-        } else {
+        ShapeW wb;
+        if (Pm.b >= 0) {
             CShape &B = m.sh[Pm.b];
-            const ShapeW wb = shape_world(B, root, L);
+            wb = shape_world(B, root, L);
             rbB = B.rb;
             entB = B.ent;
-            for (int j = 0; j < 3; j++) hB[j] = B.half[j];
-            if (Pm.rnd && B.src_actor != m.robot_actor) {
-                const int ob = Lay::kRnd + 5 * B.src_actor;
-                if (B.type == 0) for (int j = 0; j < 3; j++) hB[j] += 0.5f * L[ob + j];
-                else if (B.type == 1) hB[0] += L[ob];
+            for (int j = 0; j < 3; j++) hB[j] += B.half[j];  // (+ this sample's delta from above)
+        }
+        const int typeB = Pm.b >= 0 ? m.sh[Pm.b].type : -1;
+        auto points = [&](Split sp, PairAcc &out) MPPI_LAMBDA {
+            if (Pm.b < 0) {  // ground plane z = 0, normal +z (from ground to A)
+                const V3 ez = {0.f, 0.f, 1.f};
+                if (A.type == 0) {
+                    for (int c = sp.sub; c < 8; c += sp.n) {
+                        V3 loc = {(c & 1) ? hA[0] : -hA[0], (c & 2) ? hA[1] : -hA[1], (c & 4) ? hA[2] : -hA[2]};
+                        V3 pw = wa.p + mul(wa.R, loc);
+                        if (pw.z < 0.f) contact_point(P, pw, ez, -pw.z, wa.v, zero, out);
+                    }
+                } else if (sp.sub == 0) {
+                    if (A.type == 1) {
+                        V3 pw = {wa.p.x, wa.p.y, wa.p.z - hA[0]};
+                        if (pw.z < 0.f) contact_point(P, pw, ez, -pw.z, wa.v, zero, out);
+                    } else {  // disc: lowest point of the rim, axis = local z
+                        V3 ax = {wa.R.a[2], wa.R.a[5], wa.R.a[8]};
+                        V3 d = {ax.z * ax.x, ax.z * ax.y, ax.z * ax.z - 1.f};
+                        float l2 = dot(d, d);
+                        if (l2 > 1e-8f) {
+                            V3 pw = wa.p + (hA[0] / sqrtf(l2)) * d;
+                            if (pw.z < 0.f) contact_point(P, pw, ez, -pw.z, wa.v, zero, out);
+                        }
+                    }
+                }
+            } else if (A.type == 0 && typeB == 0) {
+                box_corners_in_box(P, wa, hA, wb, hB, 1.f, wa.v, wb.v, sp, out);
+                box_corners_in_box(P, wb, hB, wa, hA, -1.f, wa.v, wb.v, sp, out);
+            } else if (sp.sub == 0) {
+                if (A.type == 1 && typeB == 0) sphere_in_box(P, wa.p, hA[0], wb, hB, 1.f, wa.v, wb.v, out);
+                else if (A.type == 0 && typeB == 1) sphere_in_box(P, wb.p, hB[0], wa, hA, -1.f, wa.v, wb.v, out);
             }
-            if (A.type == 0 && B.type == 0) {
-                box_corners_in_box(P, wa, hA, wb, hB, 1.f, wa.v, wb.v, acc);
-                box_corners_in_box(P, wb, hB, wa, hA, -1.f, wa.v, wb.v, acc);
-            } else if (A.type == 1 && B.type == 0) {
-                sphere_in_box(P, wa.p, hA[0], wb, hB, 1.f, wa.v, wb.v, acc);
-            } else if (A.type == 0 && B.type == 1) {
-                sphere_in_box(P, wb.p, hB[0], wa, hA, -1.f, wa.v, wb.v, acc);
+        };
+        if constexpr (SPLIT == kSplitEmulate) {
+            for (int sb = 0; sb < split.n; sb++) {
+                PairAcc part;
+                pair_zero(part);
+                points(Split{sb, split.n}, part);
+                pair_add(acc, part);
             }
+        } else {
+            points(split, acc);
+#if defined(__HIP_DEVICE_COMPILE__)
+            // (wave-uniform skip: most pairs are apart in most samples)
+            if constexpr (SPLIT == kSplitQuad)
+                if (__builtin_amdgcn_ballot_w64(acc.any) != 0) quad_reduce(acc);
+#endif
         }
         if (acc.any) {
             const SV neg = {{-acc.f.a.x, -acc.f.a.y, -acc.f.a.z}, {-acc.f.l.x, -acc.f.l.y, -acc.f.l.z}};
@@ -583,8 +652,8 @@ MPPI_HD void scene_frames(CModel &m, const float *root, const SceneState<T> &s, 
 }
 
 // One simulator step of a contact scene (dt = substeps * h).  `root` carries the static actors.
-template <class T>
-MPPI_HD void step_scene(CModel &m0, const float *root, SceneState<T> &s, const float *target, const LMem &L) {
+template <class T, int SPLIT = kSplitNone>
+MPPI_HD void step_scene(CModel &m0, const float *root, SceneState<T> &s, const float *target, const LMem &L, Split split = Split{0, 1}) {
     constexpr int NB = T::NB;
     CModel *mp = &m0;
     for (int sub = 0; sub < m0.substeps; sub++) {
@@ -593,7 +662,7 @@ MPPI_HD void step_scene(CModel &m0, const float *root, SceneState<T> &s, const f
         Pose<T> P;
         SV vbase;
         scene_frames<T>(m, root, s, P, vbase, L);
-        contact_forces<T>(m, root, L);
+        contact_forces<T, SPLIT>(m, root, L, split);
         float tau[NB ? NB : 1], kdh[NB ? NB : 1], qdd[NB ? NB : 1], ff[NB ? NB : 1], vs[NB ? NB : 1];
         static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
             constexpr int i = ic;
@@ -640,14 +709,14 @@ MPPI_HD void step_scene(CModel &m0, const float *root, SceneState<T> &s, const f
                 SV v;
                 frame_load(L, NB + 1 + f, R, p, v);
                 float fm = F.m, Ic6[6] = {F.Ic[0], 0.f, 0.f, F.Ic[1], 0.f, F.Ic[2]};
-                if (m.rnd_seed >= 0) {  // this sample's own mass and box size
-                    const int orn = SceneLayout<T>::kRnd + 5 * F.actor;
-                    fm *= L[orn + 3];
+                if (m.rnd_slot[F.actor] >= 0) {  // this sample's own mass and size
+                    const ActorDraw dr = actor_draw<T>(m, F.actor, L);
+                    fm *= dr.ms;
                     if (F.type == 1) {  // MPPI_ACTOR_BOX
-                        const float x = F.size[0] + L[orn], y = F.size[1] + L[orn + 1], z = F.size[2] + L[orn + 2];
+                        const float x = F.size[0] + dr.d[0], y = F.size[1] + dr.d[1], z = F.size[2] + dr.d[2];
                         Ic6[0] = fm / 12.f * (y * y + z * z); Ic6[3] = fm / 12.f * (x * x + z * z); Ic6[5] = fm / 12.f * (x * x + y * y);
                     } else {  // sphere
-                        const float r = F.size[0] + L[orn];
+                        const float r = F.size[0] + dr.d[0];
                         Ic6[0] = Ic6[3] = Ic6[5] = 0.4f * fm * r * r;
                     }
                 }
@@ -748,9 +817,10 @@ MPPI_HD float stage_cost_scene(CModel &m, CCost &c, const float *root, const Sce
     return stage_cost_pose<T>(m, c, root, s.q, P);
 }
 
-template <class T>
+template <class T, int SPLIT = kSplitNone>
 MPPI_HD float rollout_scene(CModel &m0, CCfg &cfg0, CCost &cost0, const float *dof0, const float *root, const float *U, const float *eps,
-                            const float *prior, float *du, float *viz, int k, const LMem &L) {
+                            const float *prior, float *du, float *viz, int k, const LMem &L, Split split = Split{0, 1}) {
+    const bool leader = split.sub == 0;  // lanes sharing a sample hold identical values: one of them writes
     constexpr int NB = T::NB;
     const int K = cfg0.K, nu = cfg0.nu, H = cfg0.H;
     const int g = cfg0.k_offset + k;
@@ -765,12 +835,12 @@ MPPI_HD float rollout_scene(CModel &m0, CCfg &cfg0, CCost &cost0, const float *d
     CCost *kp = &cost0;
     for (int t = 0; t < H; t++) {
         CCfg &cfg = *launder(cp);
-        ctrl += sample_controls(cfg, U, eps, prior, t, k, is_null, is_prior, true, du, u);
+        ctrl += sample_controls(cfg, U, eps, prior, t, k, is_null, is_prior, leader, du, u);
         cmd_map<T>(*launder(mp), u, target);
-        step_scene<T>(*mp, root, s, target, L);
+        step_scene<T, SPLIT>(*mp, root, s, target, L, split);
         S += disc * stage_cost_scene<T>(*launder(mp), *launder(kp), root, s, L);
         disc *= cfg.gamma;
-        if (cfg.want_rollouts && viz != nullptr) {
+        if (cfg.want_rollouts && viz != nullptr && leader) {
             CModel &m = *launder(mp);
             Pose<T> P;
             P.pb = loadv(s.base);

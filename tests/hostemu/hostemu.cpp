@@ -12,7 +12,11 @@
 
 using namespace mppi;
 
+static int g_scene_split = 1;  // 4: contact feature points dealt over an emulated quad (kSplitEmulate)
+
 extern "C" {
+
+void emu_set_scene_split(int n) { g_scene_split = n; }
 
 int emu_rollout(const mppi_model_t *model, const mppi_config_t *cfg, const mppi_cost_t *cost, const float *dof0, const float *root0,
                 const float *U, const float *eps, const float *prior, float *S, float *du, float *viz) {
@@ -24,9 +28,11 @@ int emu_rollout(const mppi_model_t *model, const mppi_config_t *cfg, const mppi_
         using T = decltype(topo);
         std::vector<float> v(viz ? (size_t)c.H * 3 * c.K : 0);
         if (is_scene(m)) {
-            std::vector<float> lmem(SceneLayout<T>::floats(m.n_rb));
+            std::vector<float> lmem(SceneLayout<T>::floats(m.n_rb, m.n_rnd));
             LMem L{lmem.data(), 1};
-            for (int s = 0; s < c.K; s++) S[s] = rollout_scene<T>(m, c, k, dof0, root0, U, eps, prior, du, viz ? v.data() : nullptr, s, L);
+            for (int s = 0; s < c.K; s++)
+                S[s] = g_scene_split > 1 ? rollout_scene<T, kSplitEmulate>(m, c, k, dof0, root0, U, eps, prior, du, viz ? v.data() : nullptr, s, L, Split{0, g_scene_split})
+                                         : rollout_scene<T>(m, c, k, dof0, root0, U, eps, prior, du, viz ? v.data() : nullptr, s, L);
         } else
         for (int s = 0; s < c.K; s++) S[s] = rollout_sample<T>(m, c, k, dof0, root0, U, eps, prior, du, viz ? v.data() : nullptr, s);
         if (viz)  // device layout [H][3][K] -> reference layout [H][K][3]
@@ -96,14 +102,15 @@ int emu_scene_step_g(const mppi_model_t *model, float *dof, float *root, const f
     for (int i = 0; i < m.nb; i++) parents[i] = m.b[i].k0.parent;
     bool ok = dispatch_topology(m.nb, parents, [&](auto topo) {
         using T = decltype(topo);
-        std::vector<float> lmem(SceneLayout<T>::floats(m.n_rb));
+        std::vector<float> lmem(SceneLayout<T>::floats(m.n_rb, m.n_rnd));
         LMem L{lmem.data(), 1};
         SceneState<T> s;
         scene_init<T>(m, dof, root, s, sample_id, L);
         float target[MPPI_MAX_BODIES + 1], uu[kMaxNu] = {0};
         for (int c = 0; c < m.nu; c++) uu[c] = u[c];
         cmd_map<T>(m, uu, target);
-        step_scene<T>(m, root, s, target, L);
+        if (g_scene_split > 1) step_scene<T, kSplitEmulate>(m, root, s, target, L, Split{0, g_scene_split});
+        else step_scene<T>(m, root, s, target, L);
         for (int i = 0; i < T::NB; i++) { dof[2 * i] = s.q[i]; dof[2 * i + 1] = s.qd[i]; }
         std::vector<float> rootn(13 * m.n_actors);
         scene_materialise<T>(m, root, s, lmem.data() + SceneLayout<T>::kCf, rootn.data(), rb, cf);

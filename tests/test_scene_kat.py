@@ -237,3 +237,44 @@ def test_randomised_samples_device_arithmetic_matches_oracle(hostemu, oracle64):
         assert worst < 5e-3
     assert switched <= 0.02 * steps, (switched, steps)
     assert differs > 20      # the perturbed worlds really do evolve differently from the nominal one
+
+
+def test_quad_split_of_contact_points_is_the_same_contact_model(hostemu, oracle64):
+    """k_rollout_scene_quad deals the feature points of every pair over the 4 lanes of a quad and sums the partial
+    wrenches / dampings: emulated on the host (kSplitEmulate), same steps as the one-lane arithmetic up to fp32
+    summation order, and the same parity with the oracle."""
+    scene, m, cfg, cost, dof, root0 = boxer_push()
+    q, qd = dof[0::2].astype(float), dof[1::2].astype(float)
+    root = root0.astype(float)
+    root[scene.actor_index("block"), 0:3] = [0.05, 1.9, 0.1]
+    rb = np.zeros((m.n_rb, 13), np.float32)
+    cf1, cf4 = np.zeros((m.n_rb, 3), np.float32), np.zeros((m.n_rb, 3), np.float32)
+    try:
+        for u, n in [((0.0, 0.0), 8), ((0.6, 0.0), 20), ((0.4, 0.9), 12)]:
+            for _ in range(n):
+                out = []
+                for split, cf in ((1, cf1), (4, cf4)):
+                    hostemu.emu_set_scene_split(split)
+                    de = np.zeros(2 * scene.n_dof, np.float32)
+                    de[0::2], de[1::2] = q, qd
+                    re = f32(root).copy()
+                    assert hostemu.emu_scene_step(C.byref(m), fp(de), fp(re.reshape(-1)), fp(f32(u)), fp(rb), fp(cf)) == 0
+                    out.append((de, re))
+                np.testing.assert_allclose(out[1][1][:, 0:7], out[0][1][:, 0:7], atol=1e-5)     # poses
+                np.testing.assert_allclose(out[1][1][:, 7:13], out[0][1][:, 7:13], atol=1e-3)   # velocities (summation order)
+                np.testing.assert_allclose(out[1][0], out[0][0], atol=1e-3)
+                np.testing.assert_allclose(cf4, cf1, atol=2e-3 * max(1.0, np.abs(cf1).max()))
+                root, q, qd, cfo = oracle64.scene_step(m, root, q, qd, oracle64.cmd_map(m, u))
+                np.testing.assert_allclose(out[1][1][:, 0:7], root[:, 0:7], atol=2e-5)
+        hostemu.emu_set_scene_split(4)
+        scene, m, cfg, cost, dof, root = panda_pick(K=16, H=10)
+        eps = oracle64.sample(cfg)
+        U = np.zeros((10, cfg.nu))
+        S, du, _ = oracle64.rollout(m, cfg, cost, dof, root, U, eps)
+        Se = np.zeros(16, np.float32)
+        due = np.zeros((10, cfg.nu, 16), np.float32)
+        assert hostemu.emu_rollout(C.byref(m), C.byref(cfg), C.byref(cost), fp(f32(dof)), fp(f32(root)), fp(f32(U)), fp(f32(eps)), None,
+                                   fp(Se), fp(due), None) == 0
+        np.testing.assert_allclose(Se, S, rtol=2e-3)
+    finally:
+        hostemu.emu_set_scene_split(1)
