@@ -427,6 +427,33 @@ MPPI_HD void contact_forces(CModel &m, const float *root, const LMem &L, Split s
             for (int j = 0; j < 3; j++) hB[j] += B.half[j];  // (+ this sample's delta from above)
         }
         const int typeB = Pm.b >= 0 ? m.sh[Pm.b].type : -1;
+        // Broad phase: bounding sphere of one shape against the other shape's box grown by that radius (both ways).
+        // Conservative by construction (a margin covers rounding), so skipping changes no result; it removes the
+        // 2 x 26 feature-point tests of the many link-vs-table / link-vs-block pairs that are nowhere near each other.
+        bool apart = false;
+        {
+            constexpr float kMargin = 1e-4f;
+            const float rA = A.type == 0 ? sqrtf(hA[0] * hA[0] + hA[1] * hA[1] + hA[2] * hA[2]) : hA[0];
+            if (Pm.b < 0) {
+                apart = A.type != 2 && wa.p.z > rA + kMargin;
+            } else if (A.type != 2 && typeB != 2) {
+                const float rB = typeB == 0 ? sqrtf(hB[0] * hB[0] + hB[1] * hB[1] + hB[2] * hB[2]) : hB[0];
+                const V3 d = wa.p - wb.p;
+                if (typeB == 0) {
+                    const V3 y = {wb.R.a[0] * d.x + wb.R.a[3] * d.y + wb.R.a[6] * d.z, wb.R.a[1] * d.x + wb.R.a[4] * d.y + wb.R.a[7] * d.z,
+                                  wb.R.a[2] * d.x + wb.R.a[5] * d.y + wb.R.a[8] * d.z};
+                    apart = fabsf(y.x) > hB[0] + rA + kMargin || fabsf(y.y) > hB[1] + rA + kMargin || fabsf(y.z) > hB[2] + rA + kMargin;
+                } else {
+                    apart = dot(d, d) > (rA + rB + kMargin) * (rA + rB + kMargin);
+                }
+                if (A.type == 0) {
+                    const V3 x = {wa.R.a[0] * d.x + wa.R.a[3] * d.y + wa.R.a[6] * d.z, wa.R.a[1] * d.x + wa.R.a[4] * d.y + wa.R.a[7] * d.z,
+                                  wa.R.a[2] * d.x + wa.R.a[5] * d.y + wa.R.a[8] * d.z};
+                    apart = apart || fabsf(x.x) > hA[0] + rB + kMargin || fabsf(x.y) > hA[1] + rB + kMargin || fabsf(x.z) > hA[2] + rB + kMargin;
+                }
+            }
+        }
+        if (apart) continue;
         auto points = [&](Split sp, PairAcc &out) MPPI_LAMBDA {
             if (Pm.b < 0) {  // ground plane z = 0, normal +z (from ground to A)
                 const V3 ez = {0.f, 0.f, 1.f};
