@@ -1,6 +1,9 @@
 // mppi_hip.hip - C-ABI (include/mppi_hip.h) of the MPPI rollout backend.  Kernels, context and the
 // per-topology launch table live in mppi_kernels.hpp; the compile-time kinematic trees are instantiated in
 // the generated topo_<i>.hip units and found through topo_table.inc.
+#include <mutex>
+#include <unordered_set>
+
 #include "mppi_kernels.hpp"
 #include "topo_table.inc"  // generated: extern "C" const TopoEntry *mppi_topo_entry_<i>(); kTopoEntries[]
 
@@ -52,7 +55,15 @@ int dev_alloc(P **p, size_t bytes) {
         if (rc_) return rc_;                \
     } while (0)
 
-int check_ctx(const mppi_ctx *c) { return c ? MPPI_OK : fail(MPPI_EINVAL, "null context"); }
+// live handles: a destroyed (stale) or foreign pointer is reported instead of dereferenced
+std::mutex g_live_mu;
+std::unordered_set<const mppi_ctx *> g_live;
+int check_ctx(const mppi_ctx *c) {
+    if (!c) return fail(MPPI_EINVAL, "null context");
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    if (g_live.find(c) == g_live.end()) return fail(MPPI_EINVAL, "stale or foreign context handle (destroyed by mppi_destroy?)");
+    return MPPI_OK;
+}
 #define CTX_TRY(c)            \
     do {                      \
         int rc_ = check_ctx(c); \
@@ -189,12 +200,20 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
     HIP_TRY(hipMemcpy(c->d_sigma, sig, sizeof sig, hipMemcpyHostToDevice));
     std::vector<float> U0(c->HN, (float)cfg->u_init);
     HIP_TRY(hipMemcpy(c->d_U, U0.data(), sizeof(float) * c->HN, hipMemcpyHostToDevice));
+    {
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        g_live.insert(c);
+    }
     *out = c;
     return MPPI_OK;
 }
 
 int mppi_destroy(mppi_ctx_t *c) {
     if (!c) return MPPI_OK;
+    {
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        if (g_live.erase(c) == 0) return fail(MPPI_EINVAL, "mppi_destroy: stale or foreign context handle");
+    }
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     void *bufs[] = {c->d_model, c->d_cfg, c->d_cost, c->d_x0_dof, c->d_x0_root, c->d_U, c->d_eps, c->d_du, c->d_S, c->d_prior, c->d_viz,
@@ -323,7 +342,7 @@ int mppi_reduce(mppi_ctx_t *c, float *record_out_dev) {
                            c->d_beta_eta, (const float *)nullptr);
     return launch_check();
 }
-int mppi_record_floats(const mppi_ctx_t *c) { return c ? c->RF : 0; }
+int mppi_record_floats(const mppi_ctx_t *c) { return check_ctx(c) == MPPI_OK ? c->RF : 0; }
 int mppi_record_dev(mppi_ctx_t *c, float **record_dev) {
     CTX_TRY(c);
     hipLaunchKernelGGL(k_combine, dim3(1), dim3(kCombineThreads), 0, c->stream, c->d_cfg, c->d_partials, c->n_partials, 0, c->d_record, c->d_U, c->d_action, c->d_beta_eta, (const float *)nullptr);
@@ -345,7 +364,8 @@ int mppi_update(mppi_ctx_t *c, const float *records_dev, int n_records) {
 /* closed-loop tail: mppi_update + mppi_world_step_from + mppi_set_state_from_world, one launch where possible */
 int mppi_update_step_world(mppi_ctx_t *c, const float *records_dev, int n_records, mppi_ctx_t *world) {
     CTX_TRY(c);
-    if (!world || world->K != 1 || world->n != c->n || world->A != c->A || world->device != c->device)
+    CTX_TRY(world);
+    if (world->K != 1 || world->n != c->n || world->A != c->A || world->device != c->device)
         return fail(MPPI_EINVAL, "world must be a K=1 context of the same scene on the same device");
     if (c->launch_combine_world == nullptr || c->scene || world->scene) {  // contact scenes: three launches
         int rc;
@@ -445,13 +465,15 @@ int mppi_sim_finish(mppi_ctx_t *c) {
 }
 int mppi_world_step_from(mppi_ctx_t *world, mppi_ctx_t *planner) {
     CTX_TRY(world);
-    if (!planner || world->nu != planner->nu || world->device != planner->device) return fail(MPPI_EINVAL, "world/planner mismatch");
+    CTX_TRY(planner);
+    if (world->nu != planner->nu || world->device != planner->device) return fail(MPPI_EINVAL, "world/planner mismatch");
     world->launch_sim_step(world, 1, 0, planner->d_action);
     return launch_check();
 }
 int mppi_set_state_from_world(mppi_ctx_t *planner, mppi_ctx_t *world) {
     CTX_TRY(planner);
-    if (!world || world->K != 1 || world->n != planner->n || world->A != planner->A) return fail(MPPI_EINVAL, "world must be a K=1 context of the same scene");
+    CTX_TRY(world);
+    if (world->K != 1 || world->n != planner->n || world->A != planner->A) return fail(MPPI_EINVAL, "world must be a K=1 context of the same scene");
     hipLaunchKernelGGL(k_state_from_world, dim3(1), dim3(64), 0, planner->stream, planner->n, world->d_q, world->d_qd, planner->d_x0_dof);
     HIP_TRY(hipMemcpyAsync(planner->d_x0_root, world->d_x0_root, sizeof(float) * 13 * planner->A, hipMemcpyDeviceToDevice, planner->stream));
     if (world->scene)  // the world's robot base and free actors have moved: K = 1, so sample-minor rows are plain arrays

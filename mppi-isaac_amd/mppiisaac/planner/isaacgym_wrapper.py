@@ -563,6 +563,12 @@ class IsaacGymWrapper:
         keep_root = self._root_state[0].clone() if hasattr(self, "_root_state") else None
         keep_dof = self._dof_state[0].clone() if hasattr(self, "_dof_state") else None
         n_old = keep_root.shape[0] if keep_root is not None else 0
+        # the nominal control sequence lives in the context that is about to be destroyed: carry it over here
+        # (nobody may touch the old handle afterwards - in the reference the mppi object simply survives)
+        keep_U = None
+        if getattr(self, "_ctx", None) and not callable(self._mppi_config) and self._mppi_config is not None:
+            keep_U = np.zeros((self._mppi_config.horizon, self._mppi_config.nu), np.float32)
+            capi.check(self._lib, self._lib.mppi_get_nominal(self._ctx, capi.fptr(keep_U)))
         self.stop_sim()
         for i, a in enumerate(self.env_cfg):
             a.handle = i
@@ -572,6 +578,8 @@ class IsaacGymWrapper:
         self._mppi_config = self._mppi_config_factory
         self.generation += 1
         self.start_sim()
+        if keep_U is not None and keep_U.shape == (self._mppi_config.horizon, self._mppi_config.nu):
+            capi.check(self._lib, self._lib.mppi_set_nominal(self._ctx, capi.fptr(keep_U)))
         if keep_root is not None:  # carry the state of the actors that already existed
             root = self._root_state[0].clone()
             root[:n_old] = keep_root

@@ -62,15 +62,11 @@ class MPPIisaacPlanner(object):
         return self.objective.compute_cost(self.sim)
 
     def _rebind_after_restart(self):
-        """the simulator was rebuilt with a new actor list (new HIP context): rebuild the MPPI driver on it and
-        carry the nominal control sequence over (in the reference the mppi object simply survives the restart)."""
-        U = self.mppi.U
+        """the simulator was rebuilt with a new actor list (new HIP context; IsaacGymWrapper._restart carried the
+        nominal control sequence over): rebuild the MPPI driver on it.  The old context is gone - its handle must
+        not be used again (in the reference the mppi object simply survives the restart)."""
         self.mppi = MPPIPlanner(self.cfg.mppi, self.cfg.nx, dynamics=self.dynamics, running_cost=self.running_cost,
                                 prior=self.prior, sim=self.sim, shard=self._shard, process_group=self._pg)
-        import numpy as np
-        from mppiisaac.backend import capi
-        Uh = np.ascontiguousarray(U.numpy(), np.float32)
-        capi.check(self.sim._lib, self.sim._lib.mppi_set_nominal(self.sim._ctx, capi.fptr(Uh)))
         self._generation = self.sim.generation
 
     def compute_action(self, q, qdot, obst=None, obst_tensor=None):

@@ -82,6 +82,21 @@ def test_library_exports_every_declared_symbol():
     assert lib.mppi_abi_version() == capi.ABI_VERSION
 
 
+def test_stale_or_foreign_handles_are_reported_not_dereferenced():
+    """the C-ABI keeps a registry of live contexts: a handle that was destroyed (or never created) yields
+    MPPI_EINVAL instead of a use-after-free (no compute, runs without a GPU)."""
+    lib = capi.load_library()
+    junk = (C.c_char * 4096)()
+    bogus = C.cast(junk, C.c_void_p)
+    out = np.zeros(8, np.float32)
+    assert lib.mppi_get_nominal(bogus, capi.fptr(out)) != 0
+    assert b"stale or foreign" in lib.mppi_last_error()
+    assert lib.mppi_rollout(bogus) != 0
+    assert lib.mppi_destroy(bogus) != 0
+    assert lib.mppi_record_floats(bogus) == 0
+    assert lib.mppi_destroy(None) == 0
+
+
 def test_product_path_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():
