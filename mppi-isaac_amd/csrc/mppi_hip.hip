@@ -122,13 +122,14 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
         ok = true;
         if (c->scene) {
             c->lds_bytes = sizeof(float) * kWave * (e->scene_lds_floats + 3 * (size_t)c->hm.n_rb + 5 * (size_t)c->hm.n_rnd);
+            c->lds_bytes_quad = sizeof(float) * 16 * (e->scene_lds_floats + 3 * (size_t)c->hm.n_rb + 5 * (size_t)c->hm.n_rnd + 12 * (size_t)c->hm.n_shapes);
             // rollouts: 4 lanes per sample (contact points dealt over the quad) unless MPPI_ROLLOUT=lane
             const char *mode = std::getenv("MPPI_ROLLOUT");
             c->quad = !(mode && std::string(mode) == "lane");
             c->launch_rollout = c->quad ? e->rollout_scene_quad : e->rollout_scene;
             c->launch_sim_step = e->sim_step_scene;
             c->launch_materialise = e->materialise_scene;
-            if (hipSetDevice(device) == hipSuccess) lds_err = e->raise_lds(c->lds_bytes);
+            if (hipSetDevice(device) == hipSuccess) lds_err = e->raise_lds(c->lds_bytes, c->lds_bytes_quad);
         } else {
             // fixed-base contact-free scenes: one sample per 4-lane quad unless MPPI_ROLLOUT=lane asks for the
             // one-lane-per-sample kernel (kept for A/B measurements and as the reference arithmetic)
@@ -141,7 +142,7 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
         }
         break;
     }
-    if (ok && c->lds_bytes > 160 * 1024) {
+    if (ok && (c->lds_bytes > 160 * 1024 || c->lds_bytes_quad > 160 * 1024)) {
         delete c;
         return fail(MPPI_EUNSUPPORTED, "contact scene needs more than 160 KiB of LDS per wavefront");
     }

@@ -629,7 +629,7 @@ struct mppi_ctx {
     float *d_filter = nullptr;  // filter_u operator [H][H]
     bool use_filter = false;
     bool scene = false;
-    size_t lds_bytes = 0;
+    size_t lds_bytes = 0, lds_bytes_quad = 0;  // dynamic LDS of the lane-per-sample / quad-per-sample scene kernels
     double *d_basis = nullptr, *d_sigma = nullptr;
     const float *eps_in = nullptr;  // d_eps or an external noise buffer
     bool has_prior = false, has_cost = false, profiling = false;
@@ -658,7 +658,7 @@ struct TopoEntry {
     void (*materialise)(mppi_ctx *, float *, float *, float *, float *);
     void (*materialise_scene)(mppi_ctx *, float *, float *, float *, float *);
     void (*combine_world)(mppi_ctx *, const float *, int, mppi_ctx *);
-    hipError_t (*raise_lds)(size_t);
+    hipError_t (*raise_lds)(size_t, size_t);
 };
 }  // namespace mppi
 
@@ -672,7 +672,7 @@ void launch_rollout_scene_t(mppi_ctx *c) {
 }
 template <class T>
 void launch_rollout_scene_quad_t(mppi_ctx *c) {
-    hipLaunchKernelGGL(k_rollout_scene_quad<T>, dim3(c->n_quads), dim3(kWave), c->lds_bytes / 4, c->stream, c->d_model, c->d_cfg, c->d_cost, c->d_x0_dof,
+    hipLaunchKernelGGL(k_rollout_scene_quad<T>, dim3(c->n_quads), dim3(kWave), c->lds_bytes_quad, c->stream, c->d_model, c->d_cfg, c->d_cost, c->d_x0_dof,
                        c->d_x0_root, c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_S, c->cfg.want_rollouts ? c->d_viz : nullptr,
                        c->d_partials);
 }
@@ -687,10 +687,12 @@ void launch_materialise_scene_t(mppi_ctx *c, float *dof, float *root, float *rb,
                        c->d_fr, c->d_cf, dof, root, rb, cf);
 }
 template <class T>
-hipError_t raise_lds_limit(size_t bytes) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rollout_scene<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+hipError_t raise_lds_limit(size_t lane_bytes, size_t quad_bytes) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rollout_scene<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lane_bytes);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sim_step_scene<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rollout_scene_quad<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)quad_bytes);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sim_step_scene<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lane_bytes);
 }
 
 template <class T>

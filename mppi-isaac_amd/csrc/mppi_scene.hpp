@@ -33,7 +33,9 @@ struct SceneLayout {
     static constexpr int kAcc = NF * 18;             // [NF][27]: f(6) C(21)
     static constexpr int kCf = kAcc + NF * 27;       // [n_rb][3] net contact force
     // then [n_rnd][5]: this sample's size deltas xyz, mass scale, friction of the noisy actors (m.rnd_slot)
-    MPPI_HD static constexpr int floats(int n_rb, int n_rnd) { return kCf + 3 * n_rb + 5 * n_rnd; }
+    // then (shared-sample kernels only) [n_shapes][12]: world pose R(9) p(3) of every collision shape, refreshed once per
+    // substep instead of once per candidate pair
+    MPPI_HD static constexpr int floats(int n_rb, int n_rnd, int n_cached_shapes = 0) { return kCf + 3 * n_rb + 5 * n_rnd + 12 * n_cached_shapes; }
 };
 
 // counter-based uniform in (0,1): the seeded stand-in for the reference's unseeded np.random draws per env
@@ -325,28 +327,83 @@ MPPI_HD ShapeW shape_world(CShape &S, const float *root, const LMem &L) {
     return w;
 }
 
+// World poses of the collision shapes in the sample's LDS rows (kernels whose lanes share a sample): the shapes are
+// dealt over the lanes; static shapes are posed once per rollout, the others once per substep.
+template <class T>
+MPPI_HD int shape_cache_base(CModel &m) { return SceneLayout<T>::kCf + 3 * m.n_rb + 5 * m.n_rnd; }
+template <class T>
+MPPI_HD void shape_cache_update(CModel &m, const float *root, const LMem &L, Split sp, bool statics) {
+    const int base = shape_cache_base<T>(m);
+    for (int i = sp.sub; i < m.n_shapes; i += sp.n) {
+        CShape &S = m.sh[i];
+        if ((S.ent < 0) != statics) continue;
+        const ShapeW w = shape_world(S, root, L);
+        const int o = base + 12 * i;
+        for (int j = 0; j < 9; j++) L[o + j] = w.R.a[j];
+        L[o + 9] = w.p.x; L[o + 10] = w.p.y; L[o + 11] = w.p.z;
+    }
+}
+template <class T>
+MPPI_HD ShapeW shape_cached(CModel &m, int i, const LMem &L) {
+    const int o = shape_cache_base<T>(m) + 12 * i;
+    ShapeW w;
+    for (int j = 0; j < 9; j++) w.R.a[j] = L[o + j];
+    w.p = {L[o + 9], L[o + 10], L[o + 11]};
+    w.v = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    return w;
+}
+MPPI_HD SV frame_velocity(const LMem &L, int ent) {
+    if (ent < 0) return SV{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    const int o = ent * 18;
+    return SV{{L[o + 12], L[o + 13], L[o + 14]}, {L[o + 15], L[o + 16], L[o + 17]}};
+}
+
 // Feature points of box X (8 corners, 12 edge midpoints, 6 face centres) that lie inside box Y; a pure
 // vertex test misses boxes that cross like a plus sign (a tall block against a wide chassis face).
 // sign = +1 when X is shape A (normal from B=Y to A=X)
 MPPI_HD void box_corners_in_box(const Gains &P, const ShapeW &X, const float *hx, const ShapeW &Y, const float *hy, float sign, const SV &vA, const SV &vB,
                                 Split sp, PairAcc &acc) {
-    for (int c = sp.sub; c < 27; c += sp.n) {
-        if (c == 13) continue;  // the centre is not a surface feature
-        V3 loc = {(float)(c % 3 - 1) * hx[0], (float)((c / 3) % 3 - 1) * hx[1], (float)(c / 9 - 1) * hx[2]};
-        V3 pw = X.p + mul(X.R, loc);
-        V3 d = pw - Y.p;
-        V3 y = {Y.R.a[0] * d.x + Y.R.a[3] * d.y + Y.R.a[6] * d.z, Y.R.a[1] * d.x + Y.R.a[4] * d.y + Y.R.a[7] * d.z,
-                Y.R.a[2] * d.x + Y.R.a[5] * d.y + Y.R.a[8] * d.z};  // R_Y^T d
-        float dx = hy[0] - fabsf(y.x), dy = hy[1] - fabsf(y.y), dz = hy[2] - fabsf(y.z);
-        if (dx > 0.f && dy > 0.f && dz > 0.f) {
-            V3 nl;
-            float depth;
-            if (dx <= dy && dx <= dz) { nl = {y.x > 0.f ? 1.f : -1.f, 0.f, 0.f}; depth = dx; }
-            else if (dy <= dz) { nl = {0.f, y.y > 0.f ? 1.f : -1.f, 0.f}; depth = dy; }
-            else { nl = {0.f, 0.f, y.z > 0.f ? 1.f : -1.f}; depth = dz; }
-            V3 n = sign * mul(Y.R, nl);  // outward normal of Y, oriented from B to A
-            contact_point(P, pw, n, depth, vA, vB, acc);
-        }
+    // feature point c of X in Y's frame: y = R_Y^T (p_X - p_Y) + sum_j s_j (R_Y^T R_X)_j hx_j with s_j in {-1, 0, 1}
+    const V3 d = X.p - Y.p;
+    const V3 yc = {Y.R.a[0] * d.x + Y.R.a[3] * d.y + Y.R.a[6] * d.z, Y.R.a[1] * d.x + Y.R.a[4] * d.y + Y.R.a[7] * d.z,
+                   Y.R.a[2] * d.x + Y.R.a[5] * d.y + Y.R.a[8] * d.z};
+    V3 col[3];  // columns of R_Y^T R_X scaled by the half extents of X
+    for (int j = 0; j < 3; j++) {
+        const V3 xj = {X.R.a[j], X.R.a[3 + j], X.R.a[6 + j]};  // column j of R_X
+        col[j] = {hx[j] * (Y.R.a[0] * xj.x + Y.R.a[3] * xj.y + Y.R.a[6] * xj.z), hx[j] * (Y.R.a[1] * xj.x + Y.R.a[4] * xj.y + Y.R.a[7] * xj.z),
+                  hx[j] * (Y.R.a[2] * xj.x + Y.R.a[5] * xj.y + Y.R.a[8] * xj.z)};
+    }
+    auto point = [&](int c, V3 &y, float &dx, float &dy, float &dz) MPPI_LAMBDA {
+        const int c3 = c / 3, c9 = c / 9;
+        const float s0 = (float)(c - 3 * c3 - 1), s1 = (float)(c3 - 3 * c9 - 1), s2 = (float)(c9 - 1);
+        y = yc + s0 * col[0] + s1 * col[1] + s2 * col[2];
+        dx = hy[0] - fabsf(y.x); dy = hy[1] - fabsf(y.y); dz = hy[2] - fabsf(y.z);
+        return c != 13 && dx > 0.f && dy > 0.f && dz > 0.f;  // the centre (13) is not a surface feature
+    };
+    // phase 1: inside tests only (cheap, branch-free); phase 2: the contact arithmetic for the hits.  Lanes that
+    // share a wavefront diverge on WHICH points hit - compacting the hits makes the wavefront pay for the
+    // largest hit count of a lane instead of for every point that hits in any lane.
+    unsigned hits = 0;
+    int it = 0;
+    for (int c = sp.sub; c < 27; c += sp.n, it++) {
+        V3 y;
+        float dx, dy, dz;
+        if (point(c, y, dx, dy, dz)) hits |= 1u << it;
+    }
+    while (hits != 0) {
+        const int j = __builtin_ctz(hits);
+        hits &= hits - 1;
+        V3 y;
+        float dx, dy, dz;
+        point(sp.sub + j * sp.n, y, dx, dy, dz);
+        V3 nl;
+        float depth;
+        if (dx <= dy && dx <= dz) { nl = {y.x > 0.f ? 1.f : -1.f, 0.f, 0.f}; depth = dx; }
+        else if (dy <= dz) { nl = {0.f, y.y > 0.f ? 1.f : -1.f, 0.f}; depth = dy; }
+        else { nl = {0.f, 0.f, y.z > 0.f ? 1.f : -1.f}; depth = dz; }
+        const V3 pw = Y.p + mul(Y.R, y);
+        const V3 n = sign * mul(Y.R, nl);  // outward normal of Y, oriented from B to A
+        contact_point(P, pw, n, depth, vA, vB, acc);
     }
 }
 
@@ -382,10 +439,14 @@ MPPI_HD void contact_forces(CModel &m, const float *root, const LMem &L, Split s
     using Lay = SceneLayout<T>;
     for (int j = Lay::kAcc; j < Lay::kCf + 3 * m.n_rb; j++) L[j] = 0.f;
     const SV zero = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    constexpr bool kCached = SPLIT != kSplitNone;
+    if constexpr (kCached) shape_cache_update<T>(m, root, L, SPLIT == kSplitEmulate ? Split{0, 1} : split, false);
     for (int ip = 0; ip < m.n_pairs; ip++) {
         CPair &Pm = m.pr[ip];
         CShape &A = m.sh[Pm.a];
-        const ShapeW wa = shape_world(A, root, L);
+        ShapeW wa;
+        if constexpr (kCached) wa = shape_cached<T>(m, Pm.a, L);
+        else wa = shape_world(A, root, L);
         Gains P = {Pm.mode, Pm.mu, Pm.k, Pm.cn, Pm.ct, Pm.kh};
         float hA[3] = {A.half[0], A.half[1], A.half[2]}, hB[3] = {0.f, 0.f, 0.f};
         if (Pm.rnd) {  // this sample's own size / friction / mass of the noisy actors in the pair
@@ -421,7 +482,8 @@ MPPI_HD void contact_forces(CModel &m, const float *root, const LMem &L, Split s
         ShapeW wb;
         if (Pm.b >= 0) {
             CShape &B = m.sh[Pm.b];
-            wb = shape_world(B, root, L);
+            if constexpr (kCached) wb = shape_cached<T>(m, Pm.b, L);
+            else wb = shape_world(B, root, L);
             rbB = B.rb;
             entB = B.ent;
             for (int j = 0; j < 3; j++) hB[j] += B.half[j];  // (+ this sample's delta from above)
@@ -454,6 +516,10 @@ MPPI_HD void contact_forces(CModel &m, const float *root, const LMem &L, Split s
             }
         }
         if (apart) continue;
+        if constexpr (kCached) {  // the cache holds poses only: velocities of the few pairs that get here
+            wa.v = frame_velocity(L, A.ent);
+            if (Pm.b >= 0) wb.v = frame_velocity(L, entB);
+        }
         auto points = [&](Split sp, PairAcc &out) MPPI_LAMBDA {
             if (Pm.b < 0) {  // ground plane z = 0, normal +z (from ground to A)
                 const V3 ez = {0.f, 0.f, 1.f};
@@ -855,6 +921,7 @@ MPPI_HD float rollout_scene(CModel &m0, CCfg &cfg0, CCost &cost0, const float *d
     const bool is_prior = cfg0.use_priors && prior != nullptr && g == cfg0.k_total - 2;
     SceneState<T> s;
     scene_init<T>(m0, dof0, root, s, g, L);
+    if constexpr (SPLIT != kSplitNone) shape_cache_update<T>(m0, root, L, SPLIT == kSplitEmulate ? Split{0, 1} : split, true);
     float target[NB ? NB : 1], u[kMaxNu];
     float S = 0.f, ctrl = 0.f, disc = 1.f;
     CModel *mp = &m0;

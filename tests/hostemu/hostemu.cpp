@@ -28,7 +28,7 @@ int emu_rollout(const mppi_model_t *model, const mppi_config_t *cfg, const mppi_
         using T = decltype(topo);
         std::vector<float> v(viz ? (size_t)c.H * 3 * c.K : 0);
         if (is_scene(m)) {
-            std::vector<float> lmem(SceneLayout<T>::floats(m.n_rb, m.n_rnd));
+            std::vector<float> lmem(SceneLayout<T>::floats(m.n_rb, m.n_rnd, m.n_shapes));
             LMem L{lmem.data(), 1};
             for (int s = 0; s < c.K; s++)
                 S[s] = g_scene_split > 1 ? rollout_scene<T, kSplitEmulate>(m, c, k, dof0, root0, U, eps, prior, du, viz ? v.data() : nullptr, s, L, Split{0, g_scene_split})
@@ -102,14 +102,17 @@ int emu_scene_step_g(const mppi_model_t *model, float *dof, float *root, const f
     for (int i = 0; i < m.nb; i++) parents[i] = m.b[i].k0.parent;
     bool ok = dispatch_topology(m.nb, parents, [&](auto topo) {
         using T = decltype(topo);
-        std::vector<float> lmem(SceneLayout<T>::floats(m.n_rb, m.n_rnd));
+        std::vector<float> lmem(SceneLayout<T>::floats(m.n_rb, m.n_rnd, m.n_shapes));
         LMem L{lmem.data(), 1};
         SceneState<T> s;
         scene_init<T>(m, dof, root, s, sample_id, L);
         float target[MPPI_MAX_BODIES + 1], uu[kMaxNu] = {0};
         for (int c = 0; c < m.nu; c++) uu[c] = u[c];
         cmd_map<T>(m, uu, target);
-        if (g_scene_split > 1) step_scene<T, kSplitEmulate>(m, root, s, target, L, Split{0, g_scene_split});
+        if (g_scene_split > 1) {
+            shape_cache_update<T>(m, root, L, Split{0, 1}, true);
+            step_scene<T, kSplitEmulate>(m, root, s, target, L, Split{0, g_scene_split});
+        }
         else step_scene<T>(m, root, s, target, L);
         for (int i = 0; i < T::NB; i++) { dof[2 * i] = s.q[i]; dof[2 * i + 1] = s.qd[i]; }
         std::vector<float> rootn(13 * m.n_actors);

@@ -37,3 +37,61 @@ for make, K, H in ((boxer_push, 8192, 25), (panda_pick, 8192, 30)):
     run(make.__name__ + " full", make, K, H)
     run(make.__name__ + " no pairs", make, K, H, no_pairs)
 run("panda_pick block pairs only (ground+table)", panda_pick, 8192, 30, only([21, 22]))
+
+
+def closed_loop_variants(workload, steps=150):
+    """reach the steady closed-loop state with the bench loop, then time the rollout kernel on variants of the scene"""
+    import copy
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
+    import bench
+    import mppiisaac.objectives as objectives
+    from mppiisaac.planner.isaacgym_wrapper import IsaacGymWrapper
+    from mppiisaac.planner.mppi_isaac import MPPIisaacPlanner
+    wl = bench.WORKLOADS[workload]
+    cfg = bench.make_cfg(wl, wl["K"])
+    cfg.mppi.device = "cuda:0"
+    planner = MPPIisaacPlanner(cfg, getattr(objectives, wl["objective"])(cfg))
+    world = IsaacGymWrapper(cfg.isaacgym, actors=cfg.actors, init_positions=cfg.initial_actor_positions, num_envs=1, device="cuda:0")
+    P, W = planner.sim._ctx, world._ctx
+    cost = planner.objective.fused_spec(planner.sim)
+    capi.check(lib, lib.mppi_set_cost(P, C.byref(cost)))
+    capi.check(lib, lib.mppi_set_state_from_world(P, W))
+    for _ in range(steps):
+        capi.check(lib, lib.mppi_rollout(P))
+        capi.check(lib, lib.mppi_update_step_world(P, None, 1, W))
+    n, A = planner.sim.scene.n_dof, len(planner.sim.env_cfg)
+    dof, root = np.zeros(2 * n, np.float32), np.zeros((A, 13), np.float32)
+    capi.check(lib, lib.mppi_get_state(P, capi.fptr(dof), capi.fptr(root)))
+    U = np.zeros((wl["H"], planner.sim.scene.nu), np.float32)
+    capi.check(lib, lib.mppi_get_nominal(P, capi.fptr(U)))
+    print(workload, "closed-loop state after", steps, "steps: q =", np.round(dof[0::2], 2), flush=True)
+    model0 = planner.sim._c_model
+
+    def timed(name, edit):
+        m = type(model0).from_buffer_copy(model0)
+        if edit: edit(m)
+        ctx = C.c_void_p()
+        capi.check(lib, lib.mppi_create(C.byref(m), C.byref(planner.sim._mppi_config), 0, C.byref(ctx)))
+        capi.check(lib, lib.mppi_set_cost(ctx, C.byref(cost)))
+        capi.check(lib, lib.mppi_set_state(ctx, capi.fptr(dof), capi.fptr(root)))
+        capi.check(lib, lib.mppi_set_nominal(ctx, capi.fptr(U)))
+        capi.check(lib, lib.mppi_sample(ctx, C.c_uint32(0)))
+        for _ in range(3): capi.check(lib, lib.mppi_rollout(ctx))
+        capi.check(lib, lib.mppi_synchronize(ctx))
+        t = time.perf_counter()
+        for _ in range(20): capi.check(lib, lib.mppi_rollout(ctx))
+        capi.check(lib, lib.mppi_synchronize(ctx))
+        print(f"  {name:44s} {1e3 * (time.perf_counter() - t) / 20:8.3f} ms", flush=True)
+        lib.mppi_destroy(ctx)
+    def no_rnd(m): m.randomize_seed = -1
+    timed("full (seeded noise)", None)
+    timed("full, noise off", no_rnd)
+    timed("no pairs", no_pairs)
+    if workload == "panda_pick":
+        timed("block pairs only", only([21, 22]))
+        timed("block + finger/hand-block pairs", only([13, 15, 17, 19, 21, 22]))
+        timed("no link-table pairs", only([0, 1, 3, 5, 7, 9, 11, 13, 15, 17, 19, 21, 22]))
+
+
+closed_loop_variants("panda_pick")
+closed_loop_variants("boxer_push")
