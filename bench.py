@@ -107,8 +107,14 @@ def main():
     backend = os.environ.get("MPPI_BENCH_BACKEND", "nccl")
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    if world_size > 1:
+    # MPPI_BENCH_FORCE_DIST=1: run the sharded code path (process group, record all-gather) even with one rank, so
+    # that the RCCL path can be exercised and its per-iteration overhead measured on a single-GPU box
+    sharded = world_size > 1 or bool(os.environ.get("MPPI_BENCH_FORCE_DIST"))
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world_size))
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", local_rank))
         else:
@@ -117,7 +123,7 @@ def main():
     cfg = make_cfg(wl, K_PER_GPU * world_size)
     cfg.mppi.device = f"cuda:{local_rank}"
     objective = getattr(objectives, wl["objective"])(cfg)
-    planner = MPPIisaacPlanner(cfg, objective, shard=world_size > 1)
+    planner = MPPIisaacPlanner(cfg, objective, shard=sharded)
     world = IsaacGymWrapper(cfg.isaacgym, actors=cfg.actors, init_positions=cfg.initial_actor_positions, num_envs=1,
                             device=cfg.mppi.device)
     lib, P, W = planner.sim._lib, planner.sim._ctx, world._ctx
@@ -133,19 +139,20 @@ def main():
         sim._push_single_state(dof0, root0)
     planner._bind_objective()
     records = planner.mppi._records
+    send = torch.zeros_like(records[0])  # this rank's shard record (written by mppi_reduce, gathered into `records`)
     nu = planner.sim.scene.nu
     action = np.zeros(nu, np.float32)
     ap_ = capi.fptr(action)
 
     def iterate(sync):
         capi.check(lib, lib.mppi_rollout(P))
-        if world_size > 1:
-            capi.check(lib, lib.mppi_reduce(P, ctypes.c_void_p(records[rank].data_ptr())))
+        if sharded:
+            capi.check(lib, lib.mppi_reduce(P, ctypes.c_void_p(send.data_ptr())))
             if backend == "nccl":
-                dist.all_gather_into_tensor(records.view(-1), records[rank].clone())
+                dist.all_gather_into_tensor(records.view(-1), send)
             else:
-                host = records.cpu()
-                dist.all_gather_into_tensor(host.view(-1), host[rank].clone())
+                host = torch.empty(records.shape, dtype=records.dtype)
+                dist.all_gather_into_tensor(host.view(-1), send.cpu())
                 records.copy_(host)
             capi.check(lib, lib.mppi_update_step_world(P, ctypes.c_void_p(records.data_ptr()), world_size, W))
         else:
@@ -155,7 +162,7 @@ def main():
             capi.check(lib, lib.mppi_get_action(P, ap_))  # D2H + stream sync: the controller output
 
     def barrier():
-        if world_size > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -175,7 +182,7 @@ def main():
         rc = lib.mppi_kernel_ms(P, which, ctypes.byref(ms))  # rc != 0: that kernel was not launched (fused tail)
         kms.append(ms.value if rc == 0 else 0.0)
     capi.check(lib, lib.mppi_set_profiling(P, 0))
-    if world_size > 1:
+    if sharded:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -210,7 +217,7 @@ def main():
             "config": {"workload": wl["desc"],
                        "K_per_gpu": K, "K_total": K * world_size, "H": H, "nu": nu, "dt": cfg.isaacgym.dt,
                        "substeps": cfg.isaacgym.substeps, "closed_loop": True, "action_to_host_every_step": sync,
-                       "parallelism": f"sample-shard x{world_size}" if world_size > 1 else "single GPU",
+                       "parallelism": f"sample-shard x{world_size} ({backend} all-gather of the shard records)" if sharded else "single GPU",
                        "loop_hz": loop_hz, "env_steps_per_s": loop_hz * K * H * world_size,
                        "final_ee_to_goal_m": dist_to_goal},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -221,8 +228,9 @@ def main():
         }
         if world_size == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(planner, dof0, K_PER_GPU, HORIZON)
-        print(json.dumps(out))
-    if world_size > 1:
+        ctypes.CDLL(None).fflush(None)  # RCCL's version banner (C stdio) goes out before the result line, not after it
+        print(json.dumps(out), flush=True)
+    if sharded:
         dist.destroy_process_group()
 
 
