@@ -114,7 +114,8 @@ struct CtrlBlock {  // one 64-byte block per quantity: fetched with a single s_l
     float v[16];
 };
 struct alignas(64) DevCfg {
-    int K, H, nu, k_offset, k_total, sample_null_action, use_priors, noise_abs_cost, want_rollouts, viz_link, pad[2];
+    int K, H, nu, k_offset, k_total, sample_null_action, use_priors, noise_abs_cost, want_rollouts, viz_link;
+    float *action_mirror;  // host-mapped pinned copy of the action (written by the update kernels: no D2H copy op), or null
     float lambda, inv_lambda, gamma, u_init;
     CtrlBlock u_min, u_max, inv_sigma;  // per control dimension, zero beyond nu; inv_sigma = 1 / noise_sigma[c][c]
 };

@@ -195,6 +195,11 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
     double sig[MPPI_MAX_NU] = {0};
     for (int j = 0; j < c->nu; j++) sig[j] = std::sqrt(cfg->noise_sigma_diag[j]);
     HIP_TRY(hipMemcpy(c->d_model, &c->hm, sizeof(DevModel), hipMemcpyHostToDevice));
+    // the update kernels also store the action into mapped pinned host memory: mppi_get_action is then a stream
+    // synchronise + a host read instead of a D2H copy operation
+    HIP_TRY(hipHostMalloc((void **)&c->h_action, sizeof(float) * MPPI_MAX_NU, hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(c->h_action, 0, sizeof(float) * MPPI_MAX_NU);
+    HIP_TRY(hipHostGetDevicePointer((void **)&c->hc.action_mirror, c->h_action, 0));
     HIP_TRY(hipMemcpy(c->d_cfg, &c->hc, sizeof(DevCfg), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_cost, &c->hk, sizeof(DevCost), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_basis, cfg->spline_basis, sizeof(double) * MPPI_MAX_H * MPPI_MAX_KNOTS, hipMemcpyHostToDevice));
@@ -221,6 +226,7 @@ int mppi_destroy(mppi_ctx_t *c) {
                     c->d_partials, c->d_record, c->d_action, c->d_beta_eta, c->d_q, c->d_qd, c->d_ctrl, c->d_basis, c->d_sigma, c->d_base, c->d_fr, c->d_cf, c->d_filter};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
+    if (c->h_action) (void)hipHostFree(c->h_action);
     for (auto &v : c->ev)
         for (auto &p : v) {
             (void)hipEventDestroy(p.first);
@@ -385,8 +391,8 @@ int mppi_update_step_world(mppi_ctx_t *c, const float *records_dev, int n_record
 }
 int mppi_get_action(mppi_ctx_t *c, float *action) {
     CTX_TRY(c);
-    HIP_TRY(hipMemcpyAsync(action, c->d_action, sizeof(float) * c->nu, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    std::memcpy(action, c->h_action, sizeof(float) * c->nu);
     return MPPI_OK;
 }
 int mppi_action_dev(mppi_ctx_t *c, float **action_dev) {

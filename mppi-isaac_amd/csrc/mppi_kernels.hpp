@@ -240,6 +240,8 @@ __device__ __forceinline__ void combine_update(CCfg &cfg, const float *__restric
     if (tid < nu) {
         action[tid] = s_U[tid];
         if (s_act != nullptr) s_act[tid] = s_U[tid];
+        float *mirror = cfg.action_mirror;
+        if (mirror != nullptr) mirror[tid] = s_U[tid];
     }
     if (tid == 0) {
         beta_eta[0] = beta;
@@ -627,6 +629,7 @@ struct mppi_ctx {
     float *d_q = nullptr, *d_qd = nullptr, *d_ctrl = nullptr;
     float *d_base = nullptr, *d_fr = nullptr, *d_cf = nullptr;  // contact scenes: env root rows and contact forces
     float *d_filter = nullptr;  // filter_u operator [H][H]
+    float *h_action = nullptr;  // pinned, host-mapped mirror of d_action
     bool use_filter = false;
     bool scene = false;
     size_t lds_bytes = 0, lds_bytes_quad = 0;  // dynamic LDS of the lane-per-sample / quad-per-sample scene kernels
