@@ -193,6 +193,9 @@ class MPPIPlanner:
         if cfg.filter_u:
             F = np.ascontiguousarray(savgol_matrix(self.T), np.float32)
             capi.check(self._lib, self._lib.mppi_set_filter(self._ctx, capi.fptr(F)))
+        import os
+        self._graph, self._graph_sig, self._graph_viz = None, None, []
+        self._graph_state = "off" if os.environ.get("MPPI_GENERIC_GRAPH", "1") == "0" else "on"
         self._external_noise = None
         if sim._mppi_config.sampling == capi.SAMPLE_HALTON_SPLINE:
             capi.check(self._lib, self._lib.mppi_sample(self._ctx, np.uint32(cfg.seed_val)))
@@ -235,17 +238,8 @@ class MPPIPlanner:
             capi.check(lib, lib.mppi_rollout(ctx))
         else:
             capi.check(lib, lib.mppi_sim_reset(ctx))
-            for t in range(self.T):
-                # dynamics(): apply the perturbed command of step t and step the simulator
-                capi.check(lib, lib.mppi_sim_step_horizon(ctx, t))
-                self.sim._materialise()
-                if self.sim._visualize_link_present:
-                    self.sim.visualize_link_buffer.append(self.sim.visualize_link_pos.clone())
-                c = self._running_cost(state)
-                c = c.to(dtype=torch.float32, device=self.sim.device).contiguous()
-                if c.shape != (self.K,):
-                    raise ValueError(f"compute_cost must return a [{self.K}] tensor, got {tuple(c.shape)}")
-                capi.check(lib, lib.mppi_sim_accumulate_cost(ctx, t, C_void(c)))
+            if not self._replay_horizon(state):
+                self._horizon_eager(state)
             capi.check(lib, lib.mppi_sim_finish(ctx))
         if self._world > 1:
             rank = _dist_rank(self._pg)
@@ -257,6 +251,73 @@ class MPPIPlanner:
             capi.check(lib, lib.mppi_update(ctx, None, 1))
         capi.check(lib, lib.mppi_get_action(ctx, capi.fptr(self._action)))
         return torch.from_numpy(self._action.copy()).unsqueeze(0) if self.cfg.u_per_command > 1 else torch.from_numpy(self._action.copy())
+
+    # -- generic Objective mode: the horizon loop ---------------------------------------------------
+    def _horizon_eager(self, state):
+        """reference loop shape (mppi_isaac.py:57-69): per horizon step dynamics() = apply + step, then running_cost()"""
+        lib, ctx = self._lib, self._ctx
+        for t in range(self.T):
+            capi.check(lib, lib.mppi_sim_step_horizon(ctx, t))
+            self.sim._materialise()
+            if self.sim._visualize_link_present:
+                self.sim.visualize_link_buffer.append(self.sim.visualize_link_pos.clone())
+            c = self._running_cost(state)
+            c = c.to(dtype=torch.float32, device=self.sim.device).contiguous()
+            if c.shape != (self.K,):
+                raise ValueError(f"compute_cost must return a [{self.K}] tensor, got {tuple(c.shape)}")
+            capi.check(lib, lib.mppi_sim_accumulate_cost(ctx, t, C_void(c)))
+
+    def _objective_signature(self):
+        """what a captured horizon bakes in from the Python side: the objective object and its weights"""
+        obj = getattr(self._running_cost, "__self__", None)
+        obj = getattr(obj, "objective", obj)
+        w = getattr(obj, "weights", None)
+        return (id(obj), repr(sorted(w.items())) if isinstance(w, dict) else repr(w))
+
+    def _replay_horizon(self, state) -> bool:
+        """The generic horizon is launch-bound: H x (step kernel, materialise, ~20 small torch kernels of the Python
+        Objective, accumulate).  It is therefore captured ONCE into a HIP graph (torch.cuda.CUDAGraph) and replayed:
+        the Objective's Python code runs at capture time only, its tensor program runs every iteration.  Anything
+        the Objective reads through `sim` tensors (goal, obstacles, states) stays live; Python-side numbers are
+        baked in, so the capture is redone when the objective object or its `.weights` change.  Objectives that
+        cannot be captured (host synchronisation such as .item()/.cpu() inside compute_cost) fall back to the
+        eager loop for good.  MPPI_GENERIC_GRAPH=0 switches the capture off."""
+        if self._graph_state == "off":
+            return False
+        sig = self._objective_signature()
+        if self._graph is not None and sig != self._graph_sig:
+            self._graph = None                         # objective or weights changed: capture again
+        lib, ctx = self._lib, self._ctx
+        if self._graph is None:
+            try:
+                self._horizon_eager(state)             # warm-up: lazy initialisation must not happen under capture
+                self.sim.visualize_link_buffer = []
+                capi.check(lib, lib.mppi_sim_reset(ctx))
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                main = torch.cuda.current_stream()
+                try:
+                    with torch.cuda.graph(g):
+                        capi.check(lib, lib.mppi_set_stream(ctx, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+                        self._horizon_eager(state)
+                finally:
+                    capi.check(lib, lib.mppi_set_stream(ctx, C.c_void_p(main.cuda_stream)))
+                self._graph, self._graph_sig = g, sig
+                self._graph_viz = list(self.sim.visualize_link_buffer)
+                self.sim.visualize_link_buffer = []
+                capi.check(lib, lib.mppi_sim_reset(ctx))
+            except Exception as e:  # not capturable: keep the reference loop shape
+                import warnings
+                warnings.warn(f"generic Objective horizon is not graph-capturable ({type(e).__name__}: {e}); running it eagerly")
+                self._graph, self._graph_state = None, "off"
+                torch.cuda.synchronize()
+                self.sim.visualize_link_buffer = []
+                capi.check(lib, lib.mppi_sim_reset(ctx))
+                return False
+        self._graph.replay()
+        if self.sim._visualize_link_present:
+            self.sim.visualize_link_buffer = list(self._graph_viz)
+        return True
 
     def get_costs(self) -> torch.Tensor:
         S = np.zeros(self.K, np.float32)

@@ -223,6 +223,57 @@ def test_generic_objective_mode_equals_fused(lib):
             np.testing.assert_allclose(rg.numpy(), rf.numpy(), atol=1e-4)
 
 
+def test_generic_horizon_graph_replay_equals_eager_loop(lib, monkeypatch):
+    """the generic Objective horizon is captured into a HIP graph and replayed; it must give what the reference-shaped
+    eager loop gives, follow state / goal changes (they flow through sim tensors), re-capture when the weights
+    change, and fall back to the eager loop for an Objective that synchronises with the host."""
+    from mppiisaac.objectives import PandaReachObjective
+    from mppiisaac.planner.mppi_isaac import MPPIisaacPlanner
+    from mppiisaac.utils.config_store import load_config
+    from mppiisaac.utils.transport import bytes_to_torch
+    cfg = load_config({"defaults": [{"mppi": "panda"}, {"isaacgym": "normal"}], "actors": ["panda_stick", "goal"],
+                       "initial_actor_positions": [[0.0, 0.0, 0.0]], "nx": 14},
+                      overrides={"mppi.num_samples": 256, "mppi.horizon": 12, "mppi.use_priors": False, "mppi.filter_u": False})
+
+    class Generic(PandaReachObjective):
+        fused_spec = None
+    graph = MPPIisaacPlanner(cfg, Generic(cfg))
+    monkeypatch.setenv("MPPI_GENERIC_GRAPH", "0")
+    eager = MPPIisaacPlanner(cfg, Generic(cfg))
+    monkeypatch.delenv("MPPI_GENERIC_GRAPH")
+    assert eager.mppi._graph_state == "off" and graph.mppi._graph_state == "on"
+    q = np.array([0.0, -0.94, 0.0, -2.8, 0.0, 1.8675, 0.0])
+    goals = [[0.5, -0.4, 0.3], [0.5, -0.4, 0.3], [0.3, 0.4, 0.5], [0.3, 0.4, 0.5]]
+    for i, goal in enumerate(goals):                       # iteration 0 captures, 1.. replay; the goal moves at 2
+        for pl in (graph, eager):
+            pl.sim.set_actor_position_by_name(goal, "goal")
+        qi = q + 0.05 * i
+        ag, ae = graph.compute_action(list(qi), [0.0] * 7).numpy(), eager.compute_action(list(qi), [0.0] * 7).numpy()
+        np.testing.assert_allclose(graph.mppi.get_costs().numpy(), eager.mppi.get_costs().numpy(), rtol=1e-5)
+        np.testing.assert_allclose(ag, ae, atol=1e-5)
+        np.testing.assert_allclose(bytes_to_torch(graph.get_rollouts()).cpu().numpy(), bytes_to_torch(eager.get_rollouts()).cpu().numpy(), atol=1e-6)
+    assert graph.mppi._graph is not None and eager.mppi._graph is None
+    g0 = graph.mppi._graph
+    for pl in (graph, eager):                              # python-side numbers are baked in: a weight change re-captures
+        pl.objective.weights["robot_ori"] = 1.5            # mutated in place, as reference examples do
+    ag, ae = graph.compute_action(list(q), [0.0] * 7).numpy(), eager.compute_action(list(q), [0.0] * 7).numpy()
+    assert graph.mppi._graph is not g0
+    np.testing.assert_allclose(graph.mppi.get_costs().numpy(), eager.mppi.get_costs().numpy(), rtol=1e-5)
+
+    class Syncing(PandaReachObjective):                   # .item() inside compute_cost cannot be captured
+        fused_spec = None
+        def compute_cost(self, sim):
+            c = super().compute_cost(sim)
+            return c + 0.0 * float(c[0].item())
+    with pytest.warns(UserWarning, match="not graph-capturable"):
+        s = MPPIisaacPlanner(cfg, Syncing(cfg))
+        s.sim.set_actor_position_by_name(goals[0], "goal")
+        a1 = s.compute_action(list(q), [0.0] * 7).numpy()
+    assert s.mppi._graph_state == "off" and np.isfinite(a1).all()
+    a2 = s.compute_action(list(q), [0.0] * 7).numpy()     # and keeps working eagerly
+    assert np.isfinite(a2).all()
+
+
 def test_world_sim_matches_oracle_and_reference_layouts(lib, oracle64):
     """IsaacGymWrapper(num_envs=1): apply_robot_cmd + step and the four reference-layout tensors."""
     from mppiisaac.planner.isaacgym_wrapper import IsaacGymWrapper
