@@ -137,7 +137,8 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
             c->quad = !(mode && std::string(mode) == "lane");
             c->launch_rollout = c->quad ? e->rollout_quad : e->rollout;
             c->launch_combine_world = e->combine_world;
-            c->launch_sim_step = e->sim_step;
+            // many envs: quad step kernel; the K = 1 world (and tiny K) keeps the one-lane kernel
+            c->launch_sim_step = (c->quad && cfg->num_samples >= 64) ? e->sim_step_quad : e->sim_step;
             c->launch_materialise = e->materialise;
         }
         break;

@@ -563,6 +563,73 @@ __global__ __launch_bounds__(kWave) void k_sim_step(const DevModel *__restrict__
     });
 }
 
+// the same step with one sample per 4-lane quad (generic Objective mode of the planner: K/16 wavefronts instead of K/64)
+template <class T>
+__global__ __launch_bounds__(kWave) void k_sim_step_quad(const DevModel *__restrict__ m, const DevCfg *__restrict__ cfg, int mode, int t,
+                                                         const float *__restrict__ u_ext, const float *__restrict__ x0_root,
+                                                         const float *__restrict__ U, const float *__restrict__ eps, const float *__restrict__ prior,
+                                                         float *__restrict__ du, float *__restrict__ ctrl, float *__restrict__ q_, float *__restrict__ qd_) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NB = T::NB;
+    constexpr int kModelBytes = (int)((offsetof(DevModel, fr) + 15) / 16 * 16);
+    __shared__ __attribute__((aligned(64))) uint4 s_model[kModelBytes / 16];
+    for (int i = threadIdx.x; i < kModelBytes / 16; i += kWave) s_model[i] = reinterpret_cast<const uint4 *>(m)[i];
+    __syncthreads();
+    LModel &lm = *(LModel *)s_model;
+    const int K = cfg->K, nu = cfg->nu;
+    const int k = blockIdx.x * 16 + (threadIdx.x >> 2);
+    if (k >= K) return;
+    const bool leader = (threadIdx.x & 3) == 0;
+    QF q[NB], qd[NB], target[NB];
+    static_for<0, NB>([&](auto ic) {
+        constexpr int i = ic;
+        q[i] = q_[(size_t)i * K + k];
+        qd[i] = qd_[(size_t)i * K + k];
+    });
+    const int g = cfg->k_offset + k;
+    float u[kMaxNu], cc = 0.f;
+#pragma unroll
+    for (int c = 0; c < kMaxNu; c++) {
+        float v = 0.f;
+        if (c < nu) {
+            if (mode == 0) v = u_ext[(size_t)k * nu + c];
+            else if (mode == 1) v = u_ext[c];
+            else {
+                float Ut = U[t * nu + c];
+                v = Ut + eps[(size_t)(t * nu + c) * K + k];
+                if (cfg->sample_null_action && g == cfg->k_total - 1) v = 0.f;
+                if (cfg->use_priors && prior != nullptr && g == cfg->k_total - 2) v = prior[t * nu + c];
+                v = fminf(fmaxf(v, cfg->u_min.v[c]), cfg->u_max.v[c]);
+                float d = v - Ut;
+                if (leader) du[(size_t)(t * nu + c) * K + k] = d;
+                float term = Ut * d * cfg->inv_sigma.v[c];
+                cc += cfg->lambda * (cfg->noise_abs_cost ? fabsf(term) : term);
+            }
+        }
+        u[c] = v;
+    }
+    if (mode == 2 && leader) ctrl[k] += cc;
+    static_for<0, NB>([&](auto ic) {
+        constexpr int i = ic;
+        const CmdBlock b = load_block<CmdBlock>(lm.b[i].cmd);
+        float tg = 0.f;
+#pragma unroll
+        for (int c = 0; c < kMaxNu; c++) tg += b.v[c] * u[c];
+        target[i] = tg;
+    });
+    QPose<T> P;
+    quad_base<T>(lm, x0_root, P);
+    quad_fk<T>(lm, q, P);
+    quad_step<T>(lm, P, q, qd, target);
+    if (leader)
+        static_for<0, NB>([&](auto ic) {
+            constexpr int i = ic;
+            q_[(size_t)i * K + k] = q[i];
+            qd_[(size_t)i * K + k] = qd[i];
+        });
+#endif
+}
+
 // sample-minor sim state -> reference-layout tensors (isaacgym_wrapper.py:186-199)
 template <class T>
 __global__ __launch_bounds__(kWave) void k_materialise(const DevModel *__restrict__ m, int K, const float *__restrict__ x0_root,
@@ -657,6 +724,7 @@ struct TopoEntry {
     void (*rollout_scene)(mppi_ctx *);
     void (*rollout_scene_quad)(mppi_ctx *);
     void (*sim_step)(mppi_ctx *, int, int, const float *);
+    void (*sim_step_quad)(mppi_ctx *, int, int, const float *);
     void (*sim_step_scene)(mppi_ctx *, int, int, const float *);
     void (*materialise)(mppi_ctx *, float *, float *, float *, float *);
     void (*materialise_scene)(mppi_ctx *, float *, float *, float *, float *);
@@ -719,6 +787,11 @@ void launch_sim_step_t(mppi_ctx *c, int mode, int t, const float *u_ext) {
                        c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_ctrl, c->d_q, c->d_qd);
 }
 template <class T>
+void launch_sim_step_quad_t(mppi_ctx *c, int mode, int t, const float *u_ext) {
+    hipLaunchKernelGGL(k_sim_step_quad<T>, dim3(c->n_quads), dim3(kWave), 0, c->stream, c->d_model, c->d_cfg, mode, t, u_ext, c->d_x0_root, c->d_U,
+                       c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_ctrl, c->d_q, c->d_qd);
+}
+template <class T>
 void launch_materialise_t(mppi_ctx *c, float *dof, float *root, float *rb, float *cf) {
     hipLaunchKernelGGL(k_materialise<T>, dim3(c->n_waves), dim3(kWave), 0, c->stream, c->d_model, c->K, c->d_x0_root, c->d_q, c->d_qd, dof, root,
                        rb, cf);
@@ -735,6 +808,7 @@ TopoEntry make_topo_entry() {
     e.rollout_scene = &launch_rollout_scene_t<T>;
     e.rollout_scene_quad = &launch_rollout_scene_quad_t<T>;
     e.sim_step = &launch_sim_step_t<T>;
+    e.sim_step_quad = &launch_sim_step_quad_t<T>;
     e.sim_step_scene = &launch_sim_step_scene_t<T>;
     e.materialise = &launch_materialise_t<T>;
     e.materialise_scene = &launch_materialise_scene_t<T>;
