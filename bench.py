@@ -202,9 +202,25 @@ def main():
         traffic, traffic_src = None, None  # HBM bytes/launch from the last committed rocprofv3 PMC passes
         pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc_path):
-            pmc = json.load(open(pmc_path))
-            traffic = pmc.get("k_rollout", {}).get("hbm_traffic_bytes_per_launch")
-            traffic_src = f"profiles/{pmc.get('tag')}_pmc_summary.json (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes of this command)"
+            pmc = json.load(open(pmc_path)).get("by_workload", {}).get(wl["desc"].split(" ")[0])
+            if pmc:
+                traffic = pmc.get("k_rollout", {}).get("hbm_traffic_bytes_per_launch")
+                traffic_src = f"profiles/{pmc.get('tag')}_pmc_summary.json (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes of this command)"
+        lane = os.environ.get("MPPI_ROLLOUT") == "lane"
+        scene = args.workload in ("boxer_push", "panda_pick")
+        kernel_name = ("k_rollout_scene" if scene else "k_rollout") + ("" if lane else "_quad")
+        # measured HBM ceiling next to the 8 TB/s spec: read + write of a 256 MiB device-to-device copy
+        a = torch.empty(64 << 20, dtype=torch.float32, device="cuda")
+        b = torch.empty_like(a)
+        b.copy_(a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        hbm_measured = 10 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del a, b
         out = {
             "metric": "MPPI control-loop Hz (K samples x H horizon), Panda 7-DoF K=4096 H=20" if args.workload == "panda_reach"
                       else f"MPPI control-loop Hz, {args.workload} K={K} H={H} (not the BASELINE metric)",
@@ -221,9 +237,10 @@ def main():
                        "loop_hz": loop_hz, "env_steps_per_s": loop_hz * K * H * world_size,
                        "final_ee_to_goal_m": dist_to_goal},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_rollout_quad" if os.environ.get("MPPI_ROLLOUT") != "lane" and args.workload in ("panda_reach", "point_reach") else "k_rollout",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": kernel_name, "peak_measured": hbm_measured,
                          "kernel_ms": kms[0], "bytes_alg_per_launch": bytes_alg,
-                         "note": "instruction-issue-bound path (SURVEY 8d; DESIGN.md 6): one sample per 4-lane quad = K/16 wavefronts, one per CU at K=4096"},
+                         "note": "instruction-issue-bound path (SURVEY 8d; DESIGN.md 6): one sample per 4-lane quad = K/16 wavefronts, one per CU at K=4096; "
+                                 "peak_measured = device-to-device copy of 256 MiB (read + write bytes / time) on this GPU"},
             "kernels_ms": {"k_rollout(+record tail)": kms[0], "k_reduce(generic mode only)": kms[1], "k_combine_update": kms[2]},
         }
         if world_size == 1 and not args.no_cpu_baseline:

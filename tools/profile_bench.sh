@@ -10,9 +10,13 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps 300 --warmup 30 --no-cpu-baseline"
+WORKLOAD=${WORKLOAD:-panda_reach}
+STEPS=${STEPS:-300}
+CMD="python $REPO/bench.py --workload $WORKLOAD --steps $STEPS --warmup 30 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace_bench.json 2> $OUT/trace.err
+if [ -z "${STATS_ONLY:-}" ]; then
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $CMD > $OUT/pmc_fetch_bench.json 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- $CMD > $OUT/pmc_write_bench.json 2> $OUT/pmc_write.err
+fi
 find $OUT -name "*.csv" | head -30
 for f in $(find $OUT/trace -name "*kernel_stats.csv"); do echo "== $f"; cat $f; done

@@ -17,6 +17,10 @@ def short(n):
     n = n.replace("(anonymous namespace)::", "").replace("void ", "")
     return n.split("<")[0].split("(")[0]
 out = collections.defaultdict(dict)
+workload = json.load(open(os.path.join(src, "trace_bench.json")))["config"]["workload"].split(" ")[0]
+if not glob.glob(os.path.join(src, "pmc_fetch", "*", "*_counter_collection.csv")):  # STATS_ONLY run
+    print(open(os.path.join(dst, f"{tag}_kernel_stats.csv")).read()[:1500])
+    sys.exit(0)
 for name, key in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     f = glob.glob(os.path.join(src, name, "*", "*_counter_collection.csv"))[0]
     agg = collections.defaultdict(list)
@@ -29,7 +33,12 @@ for k, v in out.items():
     if "FETCH_SIZE_KB_mean" in v and "WRITE_SIZE_KB_mean" in v:
         v["hbm_traffic_bytes_per_launch"] = int(1024 * (2 * v["FETCH_SIZE_KB_mean"] + v["WRITE_SIZE_KB_mean"]))
 json.dump(out, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1, sort_keys=True)
-main = out.get("k_rollout_quad") or out.get("k_rollout", {})
-json.dump({"tag": tag, "k_rollout": main}, open(os.path.join(dst, "pmc_latest.json"), "w"), indent=1)
+main = out.get("k_rollout_quad") or out.get("k_rollout_scene_quad") or out.get("k_rollout", {})
+latest_path = os.path.join(dst, "pmc_latest.json")
+latest = json.load(open(latest_path)) if os.path.exists(latest_path) else {}
+if "by_workload" not in latest:
+    latest = {"by_workload": {}}
+latest["by_workload"][workload] = {"tag": tag, "k_rollout": main}   # bench.py reads the entry of ITS workload only
+json.dump(latest, open(latest_path, "w"), indent=1, sort_keys=True)
 print(open(os.path.join(dst, f"{tag}_kernel_stats.csv")).read()[:1200])
 print(json.dumps(main, indent=1))
