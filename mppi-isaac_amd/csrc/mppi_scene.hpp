@@ -358,21 +358,42 @@ MPPI_HD SV frame_velocity(const LMem &L, int ent) {
     return SV{{L[o + 12], L[o + 13], L[o + 14]}, {L[o + 15], L[o + 16], L[o + 17]}};
 }
 
+// Relative pose of two boxes, computed once per pair: Rrel = R_Y^T R_X (Rrel[3*i+j] = y_i . x_j) and t = R_Y^T (p_X - p_Y)
+struct BoxRel {
+    float R[9];
+    V3 t;
+};
+MPPI_HD BoxRel box_relative(const ShapeW &X, const ShapeW &Y) {
+    BoxRel r;
+    const V3 d = X.p - Y.p;
+    for (int i = 0; i < 3; i++) {
+        const V3 yi = {Y.R.a[i], Y.R.a[3 + i], Y.R.a[6 + i]};  // column i of R_Y
+        for (int j = 0; j < 3; j++) r.R[3 * i + j] = yi.x * X.R.a[j] + yi.y * X.R.a[3 + j] + yi.z * X.R.a[6 + j];
+        const float ti = yi.x * d.x + yi.y * d.y + yi.z * d.z;
+        if (i == 0) r.t.x = ti; else if (i == 1) r.t.y = ti; else r.t.z = ti;
+    }
+    return r;
+}
+// Separating-axis test on the six face normals (conservative: never separates two boxes that intersect; the edge-edge
+// axes are left out, so some disjoint pairs pass - they then simply find no feature point inside)
+MPPI_HD bool boxes_apart(const BoxRel &r, const float *hx, const float *hy, float margin) {
+    float a[9];
+    for (int j = 0; j < 9; j++) a[j] = fabsf(r.R[j]);
+    const float t[3] = {r.t.x, r.t.y, r.t.z};
+    bool apart = false;
+    for (int i = 0; i < 3; i++)  // face normals of Y
+        apart = apart || fabsf(t[i]) > hy[i] + a[3 * i] * hx[0] + a[3 * i + 1] * hx[1] + a[3 * i + 2] * hx[2] + margin;
+    for (int j = 0; j < 3; j++)  // face normals of X
+        apart = apart || fabsf(t[0] * r.R[j] + t[1] * r.R[3 + j] + t[2] * r.R[6 + j]) > hx[j] + a[j] * hy[0] + a[3 + j] * hy[1] + a[6 + j] * hy[2] + margin;
+    return apart;
+}
+
 // Feature points of box X (8 corners, 12 edge midpoints, 6 face centres) that lie inside box Y; a pure
 // vertex test misses boxes that cross like a plus sign (a tall block against a wide chassis face).
+// yc = centre of X in Y's frame, col[j] = column j of R_Y^T R_X scaled by the half extent hx[j];
 // sign = +1 when X is shape A (normal from B=Y to A=X)
-MPPI_HD void box_corners_in_box(const Gains &P, const ShapeW &X, const float *hx, const ShapeW &Y, const float *hy, float sign, const SV &vA, const SV &vB,
-                                Split sp, PairAcc &acc) {
-    // feature point c of X in Y's frame: y = R_Y^T (p_X - p_Y) + sum_j s_j (R_Y^T R_X)_j hx_j with s_j in {-1, 0, 1}
-    const V3 d = X.p - Y.p;
-    const V3 yc = {Y.R.a[0] * d.x + Y.R.a[3] * d.y + Y.R.a[6] * d.z, Y.R.a[1] * d.x + Y.R.a[4] * d.y + Y.R.a[7] * d.z,
-                   Y.R.a[2] * d.x + Y.R.a[5] * d.y + Y.R.a[8] * d.z};
-    V3 col[3];  // columns of R_Y^T R_X scaled by the half extents of X
-    for (int j = 0; j < 3; j++) {
-        const V3 xj = {X.R.a[j], X.R.a[3 + j], X.R.a[6 + j]};  // column j of R_X
-        col[j] = {hx[j] * (Y.R.a[0] * xj.x + Y.R.a[3] * xj.y + Y.R.a[6] * xj.z), hx[j] * (Y.R.a[1] * xj.x + Y.R.a[4] * xj.y + Y.R.a[7] * xj.z),
-                  hx[j] * (Y.R.a[2] * xj.x + Y.R.a[5] * xj.y + Y.R.a[8] * xj.z)};
-    }
+MPPI_HD void box_points_in_box(const Gains &P, V3 yc, const V3 *col, const ShapeW &Y, const float *hy, float sign, const SV &vA, const SV &vB,
+                               Split sp, PairAcc &acc) {
     auto point = [&](int c, V3 &y, float &dx, float &dy, float &dz) MPPI_LAMBDA {
         const int c3 = c / 3, c9 = c / 9;
         const float s0 = (float)(c - 3 * c3 - 1), s1 = (float)(c3 - 3 * c9 - 1), s2 = (float)(c9 - 1);
@@ -493,7 +514,11 @@ MPPI_HD void contact_forces(CModel &m, const float *root, const LMem &L, Split s
         // Conservative by construction (a margin covers rounding), so skipping changes no result; it removes the
         // 2 x 26 feature-point tests of the many link-vs-table / link-vs-block pairs that are nowhere near each other.
         bool apart = false;
-        {
+        BoxRel rel;
+        if (Pm.b >= 0 && A.type == 0 && typeB == 0) {
+            rel = box_relative(wa, wb);
+            apart = boxes_apart(rel, hA, hB, 1e-4f);
+        } else {
             constexpr float kMargin = 1e-4f;
             const float rA = A.type == 0 ? sqrtf(hA[0] * hA[0] + hA[1] * hA[1] + hA[2] * hA[2]) : hA[0];
             if (Pm.b < 0) {
@@ -544,8 +569,15 @@ MPPI_HD void contact_forces(CModel &m, const float *root, const LMem &L, Split s
                     }
                 }
             } else if (A.type == 0 && typeB == 0) {
-                box_corners_in_box(P, wa, hA, wb, hB, 1.f, wa.v, wb.v, sp, out);
-                box_corners_in_box(P, wb, hB, wa, hA, -1.f, wa.v, wb.v, sp, out);
+                // A's points in B: centre t, columns of Rrel; B's points in A: centre -Rrel^T t, columns = rows of Rrel
+                const V3 colA[3] = {{hA[0] * rel.R[0], hA[0] * rel.R[3], hA[0] * rel.R[6]}, {hA[1] * rel.R[1], hA[1] * rel.R[4], hA[1] * rel.R[7]},
+                                    {hA[2] * rel.R[2], hA[2] * rel.R[5], hA[2] * rel.R[8]}};
+                box_points_in_box(P, rel.t, colA, wb, hB, 1.f, wa.v, wb.v, sp, out);
+                const V3 tb = {-(rel.R[0] * rel.t.x + rel.R[3] * rel.t.y + rel.R[6] * rel.t.z), -(rel.R[1] * rel.t.x + rel.R[4] * rel.t.y + rel.R[7] * rel.t.z),
+                               -(rel.R[2] * rel.t.x + rel.R[5] * rel.t.y + rel.R[8] * rel.t.z)};
+                const V3 colB[3] = {{hB[0] * rel.R[0], hB[0] * rel.R[1], hB[0] * rel.R[2]}, {hB[1] * rel.R[3], hB[1] * rel.R[4], hB[1] * rel.R[5]},
+                                    {hB[2] * rel.R[6], hB[2] * rel.R[7], hB[2] * rel.R[8]}};
+                box_points_in_box(P, tb, colB, wa, hA, -1.f, wa.v, wb.v, sp, out);
             } else if (sp.sub == 0) {
                 if (A.type == 1 && typeB == 0) sphere_in_box(P, wa.p, hA[0], wb, hB, 1.f, wa.v, wb.v, out);
                 else if (A.type == 0 && typeB == 1) sphere_in_box(P, wb.p, hB[0], wa, hA, -1.f, wa.v, wb.v, out);
