@@ -306,7 +306,7 @@ MPPI_HD void quad_step(M &m0, QPose<T> &P, QF *q, QF *qd, const QF *target) {
             constexpr int i = ic;
             const QF tt = ff[i] + kd * (vs[i] - qd[i] - h * qdd[i]);
             const QF eff = qrep(lim[i].effort);
-            if (lim[i].effort > 0.f && qany_gt(qabs(tt), eff)) {
+            if (qany_gt(qabs(tt), eff)) {  // (no limit: eff = +inf)
                 any = true;
                 tau[i] = qwhere_gt(tt, qrep(0.f), eff, -eff);
                 kdh[i] = qrep(0.f);
@@ -317,9 +317,9 @@ MPPI_HD void quad_step(M &m0, QPose<T> &P, QF *q, QF *qd, const QF *target) {
             constexpr int i = ic;
             const JointLimits b = lim[i];
             QF v = qd[i] + h * qdd[i];
-            if (b.vmax > 0.f) v = qmin(qmax(v, qrep(-b.vmax)), qrep(b.vmax));
+            v = qmin(qmax(v, qrep(-b.vmax)), qrep(b.vmax));  // absent limits are +-inf (mppi_pack.hpp): no branches
             QF x = q[i] + h * v;
-            if (b.limited) {
+            {
                 const QF lo = qrep(b.lower), hi = qrep(b.upper), z = qrep(0.f);
                 v = qwhere_lt(x, lo, qmax(v, z), v);
                 x = qmax(x, lo);
