@@ -324,6 +324,15 @@ MPPI_HD void rank1_sub(AI &A, SV U, float s) {
 // Controls of horizon step t for sample k: u = clamp(U_t + eps), effective perturbation du = u - U_t
 // (stored by `leader` lanes), control-cost increment.  All loads are issued before the first use so the
 // wave waits once, not once per control dimension; everything is branch-free over the padded kMaxNu.
+// clamp to [lo, hi]: one v_med3_f32 on the device (fminf(fmaxf()) costs two operations plus a canonicalisation each)
+MPPI_HD float clampf(float v, float lo, float hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_fmed3f(v, lo, hi);
+#else
+    return fminf(fmaxf(v, lo), hi);
+#endif
+}
+
 MPPI_HD float sample_controls(CCfg &cfg, const float *U, const float *eps, const float *prior, int t, int k, bool is_null, bool is_prior,
                               bool leader, float *du, float *u) {
     const int K = cfg.K, nu = cfg.nu;
@@ -342,7 +351,7 @@ MPPI_HD float sample_controls(CCfg &cfg, const float *U, const float *eps, const
         float v = Ut[c] + e[c];
         if (is_null) v = 0.f;
         if (is_prior) v = pr[c];
-        v = fminf(fmaxf(v, lo.v[c]), hi.v[c]);
+        v = clampf(v, lo.v[c], hi.v[c]);
         const bool on = c < nu;
         u[c] = on ? v : 0.f;
         const float d = v - Ut[c];

@@ -42,6 +42,7 @@ __device__ __forceinline__ QF qsqrt(QF x) { return sqrtf(x); }
 // reciprocal: v_rcp_f32 (1 ulp) + one Newton step (3 instructions instead of the ~10 of an IEEE division)
 __device__ __forceinline__ QF qrcp(QF x) { float r = __builtin_amdgcn_rcpf(x); return r * (2.f - x * r); }
 __device__ __forceinline__ QF qabs(QF x) { return fabsf(x); }
+__device__ __forceinline__ QF qclamp(QF v, QF lo, QF hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
 __device__ __forceinline__ QF qmin(QF a, QF b) { return fminf(a, b); }
 __device__ __forceinline__ QF qmax(QF a, QF b) { return fmaxf(a, b); }
 __device__ __forceinline__ QF qatan2(QF a, QF b) { return atan2f(a, b); }
@@ -79,6 +80,7 @@ inline float qlane0(QF x) { return x.v[0]; }
 inline QF qsqrt(QF x) { QF o; for (int i = 0; i < 4; i++) o.v[i] = sqrtf(x.v[i]); return o; }
 inline QF qrcp(QF x) { QF o; for (int i = 0; i < 4; i++) o.v[i] = 1.f / x.v[i]; return o; }
 inline QF qabs(QF x) { QF o; for (int i = 0; i < 4; i++) o.v[i] = fabsf(x.v[i]); return o; }
+inline QF qclamp(QF v, QF lo, QF hi) { QF o; for (int i = 0; i < 4; i++) o.v[i] = fminf(fmaxf(v.v[i], lo.v[i]), hi.v[i]); return o; }
 inline QF qmin(QF a, QF b) { QF o; for (int i = 0; i < 4; i++) o.v[i] = fminf(a.v[i], b.v[i]); return o; }
 inline QF qmax(QF a, QF b) { QF o; for (int i = 0; i < 4; i++) o.v[i] = fmaxf(a.v[i], b.v[i]); return o; }
 inline QF qatan2(QF a, QF b) { QF o; for (int i = 0; i < 4; i++) o.v[i] = atan2f(a.v[i], b.v[i]); return o; }
@@ -317,14 +319,13 @@ MPPI_HD void quad_step(M &m0, QPose<T> &P, QF *q, QF *qd, const QF *target) {
             constexpr int i = ic;
             const JointLimits b = lim[i];
             QF v = qd[i] + h * qdd[i];
-            v = qmin(qmax(v, qrep(-b.vmax)), qrep(b.vmax));  // absent limits are +-inf (mppi_pack.hpp): no branches
+            v = qclamp(v, qrep(-b.vmax), qrep(b.vmax));  // absent limits are +-inf (mppi_pack.hpp): no branches
             QF x = q[i] + h * v;
             {
                 const QF lo = qrep(b.lower), hi = qrep(b.upper), z = qrep(0.f);
                 v = qwhere_lt(x, lo, qmax(v, z), v);
-                x = qmax(x, lo);
                 v = qwhere_gt(x, hi, qmin(v, z), v);
-                x = qmin(x, hi);
+                x = qclamp(x, lo, hi);
             }
             q[i] = x;
             qd[i] = v;
@@ -370,7 +371,7 @@ MPPI_HD QF quad_stage_cost(M &m, CCost &c, const float *root, const QF *q, const
         // row 2 of R lives in lane 2: R20, R21, R22 -> replicated (see stage_cost in mppi_device.hpp)
         const QF r20 = bc<2>(R.c[0]), r21 = bc<2>(R.c[1]), r22 = bc<2>(R.c[2]);
         const QF a0 = qatan2(r21, -r22);
-        const QF a1 = qasin(qmin(qmax(r20, qrep(-1.f)), qrep(1.f)));
+        const QF a1 = qasin(qclamp(r20, qrep(-1.f), qrep(1.f)));
         return c.w[0] * dist + c.w[1] * qsqrt(a0 * a0 + a1 * a1);
     }
     return qrep(0.f);
