@@ -476,6 +476,33 @@ def test_ragged_sizes(K, H, lib, oracle64):
     c.close()
 
 
+@pytest.mark.parametrize("K", [1, 7, 100, 272])
+def test_ragged_sizes_contact_scene(K, lib, oracle64, monkeypatch):
+    """the quad-per-sample contact kernel with sample counts that leave quads / wavefronts partly empty (and 272 = 17
+    wavefronts: the XCD chunk mapping falls back to the identity), and the one-lane kernel on the same inputs"""
+    H = 10
+    scene, m, cfg, cost, dof, root = boxer_push(K=K, H=H, sample_null_action=(K > 1))
+    root[0, 2] = 0.019
+    root[scene.actor_index("block"), 0:3] = [2.5, 1.8, 0.0923]          # open floor: smooth, strict parity
+    eps = oracle64.sample(cfg) * 0.3
+    So, duo, _ = oracle64.rollout(m, cfg, cost, dof, root, np.zeros((H, 2)), eps)
+    _, ao, _ = oracle64.update(cfg, oracle64.record(cfg, So, duo), np.zeros((H, 2)))
+    for mode in ("quad", "lane"):
+        monkeypatch.setenv("MPPI_ROLLOUT", mode)
+        c = Ctx(m, cfg, cost)
+        ext = torch.tensor(eps, dtype=torch.float32, device="cuda").contiguous()
+        c.call("mppi_set_noise_dev", C.c_void_p(ext.data_ptr()))
+        c.set_state(dof, root)
+        a = np.zeros(2, np.float32)
+        c.call("mppi_command", capi.fptr(a))
+        np.testing.assert_allclose(c.get("mppi_get_costs", (K,)), So, rtol=1e-3)
+        np.testing.assert_allclose(a, ao, atol=5e-3)
+        info = C.create_string_buffer(256)
+        c.call("mppi_kernel_info", info, 256)
+        assert (b"rollout=scene-quad" if mode == "quad" else b"rollout=scene ") in info.value
+        c.close()
+
+
 def test_random_sampling_priors_and_param_update(lib, oracle64):
     """mppi_mode 'simple' / sampling_method 'random' (torch noise on the device), a prior in sample K-2
     (reference mppi_isaac.py:38-41) and update_mppi_params (:129-138) through the planner facade."""
