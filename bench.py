@@ -144,6 +144,8 @@ def main():
     action = np.zeros(nu, np.float32)
     ap_ = capi.fptr(action)
 
+    action_sync = os.environ.get("MPPI_BENCH_ACTION") == "sync"
+
     def iterate(sync):
         capi.check(lib, lib.mppi_rollout(P))
         if sharded:
@@ -159,7 +161,9 @@ def main():
             capi.check(lib, lib.mppi_reduce(P, None))
             capi.check(lib, lib.mppi_update_step_world(P, None, 1, W))  # update + world step + state feedback
         if sync:
-            capi.check(lib, lib.mppi_get_action(P, ap_))  # D2H + stream sync: the controller output
+            # the controller output reaches the host as soon as the update kernel has published it (polled sequence
+            # number in mapped host memory); MPPI_BENCH_ACTION=sync waits for the whole stream instead
+            capi.check(lib, (lib.mppi_get_action if action_sync else lib.mppi_wait_action)(P, ap_))
 
     def barrier():
         if sharded:

@@ -229,6 +229,11 @@ int mppi_record_dev(mppi_ctx_t *ctx, float **record_dev);    /* device pointer o
 /* combine n shard records (device, [n][2+H*nu]; NULL = own record), update U, emit action, shift */
 int mppi_update(mppi_ctx_t *ctx, const float *records_dev, int n_records);
 int mppi_get_action(mppi_ctx_t *ctx, float *action_host);     /* [nu]; synchronises the stream        */
+/* The action of the LAST update as soon as the update kernel has published it (the kernel mirrors the action and a
+ * sequence number into mapped pinned host memory; this call polls the number): returns before the stream is idle,
+ * e.g. while the fused K=1 world step of mppi_update_step_world still runs.  Work enqueued afterwards stays ordered
+ * behind it on the stream.  Same role as the `.cpu()` of the action in mppi_isaac.py:84. */
+int mppi_wait_action(mppi_ctx_t *ctx, float *action_host);
 int mppi_action_dev(mppi_ctx_t *ctx, float **action_dev);
 int mppi_command(mppi_ctx_t *ctx, float *action_host);        /* rollout+reduce+update+get_action     */
 int mppi_get_costs(mppi_ctx_t *ctx, float *S_host);           /* [K] total trajectory costs           */

@@ -117,6 +117,7 @@ struct alignas(64) DevCfg {
     int K, H, nu, k_offset, k_total, sample_null_action, use_priors, noise_abs_cost, want_rollouts, viz_link;
     float *action_mirror;  // host-mapped pinned copy of the action (written by the update kernels: no D2H copy op), or null
     float lambda, inv_lambda, gamma, u_init;
+    unsigned *seq_dev, *seq_host;  // update counter (device) and its host-mapped mirror, published after the action
     CtrlBlock u_min, u_max, inv_sigma;  // per control dimension, zero beyond nu; inv_sigma = 1 / noise_sigma[c][c]
 };
 

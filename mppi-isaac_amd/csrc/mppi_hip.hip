@@ -1,6 +1,8 @@
 // mppi_hip.hip - C-ABI (include/mppi_hip.h) of the MPPI rollout backend.  Kernels, context and the
 // per-topology launch table live in mppi_kernels.hpp; the compile-time kinematic trees are instantiated in
 // the generated topo_<i>.hip units and found through topo_table.inc.
+#include <atomic>
+#include <chrono>
 #include <mutex>
 #include <unordered_set>
 
@@ -198,9 +200,12 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
     HIP_TRY(hipMemcpy(c->d_model, &c->hm, sizeof(DevModel), hipMemcpyHostToDevice));
     // the update kernels also store the action into mapped pinned host memory: mppi_get_action is then a stream
     // synchronise + a host read instead of a D2H copy operation
-    HIP_TRY(hipHostMalloc((void **)&c->h_action, sizeof(float) * MPPI_MAX_NU, hipHostMallocMapped | hipHostMallocCoherent));
-    std::memset(c->h_action, 0, sizeof(float) * MPPI_MAX_NU);
+    HIP_TRY(hipHostMalloc((void **)&c->h_action, sizeof(float) * 32, hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(c->h_action, 0, sizeof(float) * 32);
     HIP_TRY(hipHostGetDevicePointer((void **)&c->hc.action_mirror, c->h_action, 0));
+    c->hc.seq_host = reinterpret_cast<unsigned *>(c->hc.action_mirror + 16);
+    ALLOC_TRY(c->d_seq, sizeof(unsigned));
+    c->hc.seq_dev = c->d_seq;
     HIP_TRY(hipMemcpy(c->d_cfg, &c->hc, sizeof(DevCfg), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_cost, &c->hk, sizeof(DevCost), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_basis, cfg->spline_basis, sizeof(double) * MPPI_MAX_H * MPPI_MAX_KNOTS, hipMemcpyHostToDevice));
@@ -228,6 +233,7 @@ int mppi_destroy(mppi_ctx_t *c) {
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->h_action) (void)hipHostFree(c->h_action);
+    if (c->d_seq) (void)hipFree(c->d_seq);
     for (auto &v : c->ev)
         for (auto &p : v) {
             (void)hipEventDestroy(p.first);
@@ -367,6 +373,7 @@ int mppi_update(mppi_ctx_t *c, const float *records_dev, int n_records) {
         hipLaunchKernelGGL(k_combine, dim3(1), dim3(kCombineThreads), 0, c->stream, c->d_cfg, recs, n, 1, (float *)nullptr, c->d_U, c->d_action, c->d_beta_eta,
                            c->use_filter ? (const float *)c->d_filter : (const float *)nullptr);
     }
+    c->seq_expected++;  // the kernel publishes this number next to the action (mppi_wait_action)
     return launch_check();
 }
 /* closed-loop tail: mppi_update + mppi_world_step_from + mppi_set_state_from_world, one launch where possible */
@@ -388,7 +395,24 @@ int mppi_update_step_world(mppi_ctx_t *c, const float *records_dev, int n_record
         EvScope ev(c, 2);
         c->launch_combine_world(c, recs, n, world);
     }
+    c->seq_expected++;
     return launch_check();
+}
+int mppi_wait_action(mppi_ctx_t *c, float *action) {
+    CTX_TRY(c);
+    if (!action) return fail(MPPI_EINVAL, "null action");
+    const volatile unsigned *seq = reinterpret_cast<const volatile unsigned *>(c->h_action + 16);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0; *seq != c->seq_expected; spins++) {
+        if ((spins & 0xFFFF) == 0xFFFF && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) {
+            hipError_t e = hipStreamSynchronize(c->stream);  // a kernel fault surfaces here
+            if (e != hipSuccess) return fail(MPPI_EHIP, std::string("mppi_wait_action: ") + hipGetErrorString(e));
+            if (*seq != c->seq_expected) return fail(MPPI_ESTATE, "mppi_wait_action: the update kernel never published its action");
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    std::memcpy(action, c->h_action, sizeof(float) * c->nu);
+    return MPPI_OK;
 }
 int mppi_get_action(mppi_ctx_t *c, float *action) {
     CTX_TRY(c);

@@ -243,6 +243,14 @@ __device__ __forceinline__ void combine_update(CCfg &cfg, const float *__restric
         float *mirror = cfg.action_mirror;
         if (mirror != nullptr) mirror[tid] = s_U[tid];
     }
+    // publish: the action stores above come from this same wavefront (nu <= 64), so the fence of lane 0 covers them
+    if (tid == 0 && cfg.seq_host != nullptr) {
+        __threadfence_system();
+        unsigned *sd = cfg.seq_dev;
+        const unsigned sq = *sd + 1u;
+        *sd = sq;
+        __hip_atomic_store(cfg.seq_host, sq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (tid == 0) {
         beta_eta[0] = beta;
         beta_eta[1] = eta;
@@ -696,7 +704,9 @@ struct mppi_ctx {
     float *d_q = nullptr, *d_qd = nullptr, *d_ctrl = nullptr;
     float *d_base = nullptr, *d_fr = nullptr, *d_cf = nullptr;  // contact scenes: env root rows and contact forces
     float *d_filter = nullptr;  // filter_u operator [H][H]
-    float *h_action = nullptr;  // pinned, host-mapped mirror of d_action
+    float *h_action = nullptr;  // pinned, host-mapped mirror of d_action; word 16 = sequence number of the last update
+    unsigned *d_seq = nullptr;
+    unsigned seq_expected = 0;  // updates launched so far
     bool use_filter = false;
     bool scene = false;
     size_t lds_bytes = 0, lds_bytes_quad = 0;  // dynamic LDS of the lane-per-sample / quad-per-sample scene kernels

@@ -101,6 +101,7 @@ _SIGNATURES = {
     "mppi_record_dev": (C.c_int, [_vp, C.POINTER(_vp)]),
     "mppi_update": (C.c_int, [_vp, _vp, C.c_int]),
     "mppi_get_action": (C.c_int, [_vp, _fp]),
+    "mppi_wait_action": (C.c_int, [_vp, _fp]),
     "mppi_action_dev": (C.c_int, [_vp, C.POINTER(_vp)]),
     "mppi_command": (C.c_int, [_vp, _fp]),
     "mppi_get_costs": (C.c_int, [_vp, _fp]),

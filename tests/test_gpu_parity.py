@@ -129,6 +129,27 @@ def test_closed_loop_matches_oracle(lib, oracle64):
     p.close(); w.close(); p2.close(); w2.close()
 
 
+def test_wait_action_sees_every_update(lib, oracle64):
+    """mppi_wait_action polls the sequence number the update kernel publishes next to the action in mapped host memory:
+    it must return the action of the LAST update, iteration after iteration, and agree with the stream-synchronising
+    mppi_get_action."""
+    scene, m, cfg, cost, dof, root = panda_reach(K=256, H=12)
+    c = Ctx(m, cfg, cost)
+    c.call("mppi_sample", C.c_uint32(0)); c.set_state(dof, root)
+    early, late = np.zeros(7, np.float32), np.zeros(7, np.float32)
+    seen = []
+    for _ in range(50):
+        c.call("mppi_rollout"); c.call("mppi_reduce", None); c.call("mppi_update", None, 1)
+        c.call("mppi_wait_action", capi.fptr(early))
+        c.call("mppi_get_action", capi.fptr(late))
+        np.testing.assert_array_equal(early, late)
+        seen.append(early.copy())
+    assert len({a.tobytes() for a in seen}) > 40          # the nominal shifts every iteration: the actions differ
+    c.call("mppi_wait_action", capi.fptr(early))          # no new update: returns at once with the same action
+    np.testing.assert_array_equal(early, late)
+    c.close()
+
+
 def test_two_shards_combine_to_single_context(lib, oracle64):
     """the N-GPU arithmetic on one GPU: two contexts own samples [0,K/2) and [K/2,K); their shard records
     combined by mppi_update must reproduce the single-context action."""
