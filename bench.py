@@ -173,7 +173,7 @@ def main():
     sync = not args.async_loop
     for _ in range(args.warmup):
         iterate(sync)
-    capi.check(lib, lib.mppi_set_profiling(P, 1))
+    capi.check(lib, lib.mppi_set_profiling(P, 4))  # hipEvent brackets around every 4th launch of each kernel
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):

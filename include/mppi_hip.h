@@ -259,7 +259,7 @@ int mppi_set_state_from_world(mppi_ctx_t *planner, mppi_ctx_t *world);
 int mppi_update_step_world(mppi_ctx_t *planner, const float *records_dev, int n_records, mppi_ctx_t *world);
 
 /* ---- instrumentation (reference has only print(FPS), examples/panda/world.py:53-59) */
-int mppi_set_profiling(mppi_ctx_t *ctx, int on);            /* bracket every launch with hipEvents on the context's stream */
+int mppi_set_profiling(mppi_ctx_t *ctx, int on);            /* hipEvent brackets on the context's stream: 0 off, n >= 1 every n-th launch */
 int mppi_kernel_ms(mppi_ctx_t *ctx, int which, float *ms); /* mean launch duration since profiling was enabled: 0 rollout 1 reduce 2 update */
 int mppi_kernel_info(mppi_ctx_t *ctx, char *buf, int buflen);
 

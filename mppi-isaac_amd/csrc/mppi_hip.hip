@@ -29,6 +29,7 @@ struct EvScope {  // optional hipEvent bracket around one launch (profiling mode
     hipEvent_t stop = nullptr;
     EvScope(mppi_ctx *c_, int w) : c(c_), which(w) {
         if (!c->profiling) return;
+        if (c->ev_seen[which]++ % (size_t)c->profile_period != 0) return;  // every n-th launch of this kernel
         auto &v = c->ev[which];
         if (c->ev_used[which] == v.size()) {
             hipEvent_t a, b;
@@ -516,7 +517,8 @@ int mppi_set_state_from_world(mppi_ctx_t *planner, mppi_ctx_t *world) {
 int mppi_set_profiling(mppi_ctx_t *c, int on) {
     CTX_TRY(c);
     c->profiling = on != 0;
-    for (int w = 0; w < 3; w++) c->ev_used[w] = 0;
+    c->profile_period = on > 1 ? on : 1;
+    for (int w = 0; w < 3; w++) c->ev_used[w] = c->ev_seen[w] = 0;
     return MPPI_OK;
 }
 /* average hipEvent duration (ms) of the launches of kernel `which` since mppi_set_profiling(ctx,1) */

@@ -715,7 +715,8 @@ struct mppi_ctx {
     bool has_prior = false, has_cost = false, profiling = false;
     bool partials_valid = false;  // d_partials holds the records of the current S (written by the fused rollout tail)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[3];
-    size_t ev_used[3] = {0, 0, 0};
+    size_t ev_used[3] = {0, 0, 0}, ev_seen[3] = {0, 0, 0};
+    int profile_period = 1;  // hipEvent brackets on every n-th launch
     void (*launch_rollout)(mppi_ctx *) = nullptr;
     void (*launch_sim_step)(mppi_ctx *, int, int, const float *) = nullptr;
     void (*launch_materialise)(mppi_ctx *, float *, float *, float *, float *) = nullptr;
