@@ -334,12 +334,17 @@ MPPI_HD float clampf(float v, float lo, float hi) {
 #endif
 }
 
+// MAXC: compile-time bound of the control dimension (nu <= number of driven bodies of the kinematic tree), so the
+// unrolled loops stop at 7 for the Panda instead of kMaxNu = 12; u[] is still written up to kMaxNu
+template <int MAXC = kMaxNu>
 MPPI_HD float sample_controls(CCfg &cfg, const float *U, const float *eps, const float *prior, int t, int k, bool is_null, bool is_prior,
                               bool leader, float *du, float *u) {
     const int K = cfg.K, nu = cfg.nu;
-    float Ut[kMaxNu], e[kMaxNu], pr[kMaxNu];
+    float Ut[MAXC], e[MAXC], pr[MAXC];
 #pragma unroll
-    for (int c = 0; c < kMaxNu; c++) {
+    for (int c = MAXC; c < kMaxNu; c++) u[c] = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; c++) {
         const int cc = c < nu ? c : nu - 1;  // keep the address valid; the lane is masked below
         Ut[c] = U[t * nu + cc];
         e[c] = eps[(size_t)(t * nu + cc) * K + k];
@@ -348,7 +353,7 @@ MPPI_HD float sample_controls(CCfg &cfg, const float *U, const float *eps, const
     const CtrlBlock lo = load_block<CtrlBlock>(cfg.u_min), hi = load_block<CtrlBlock>(cfg.u_max), is = load_block<CtrlBlock>(cfg.inv_sigma);
     float ctrl = 0.f;
 #pragma unroll
-    for (int c = 0; c < kMaxNu; c++) {
+    for (int c = 0; c < MAXC; c++) {
         float v = Ut[c] + e[c];
         if (is_null) v = 0.f;
         if (is_prior) v = pr[c];

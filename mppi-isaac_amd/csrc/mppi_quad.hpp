@@ -323,8 +323,8 @@ MPPI_HD void quad_step(M &m0, QPose<T> &P, QF *q, QF *qd, const QF *target) {
             QF x = q[i] + h * v;
             {
                 const QF lo = qrep(b.lower), hi = qrep(b.upper), z = qrep(0.f);
-                v = qwhere_lt(x, lo, qmax(v, z), v);
-                v = qwhere_gt(x, hi, qmin(v, z), v);
+                // inelastic stop: below the lower limit only v >= 0 survives, above the upper one only v <= 0
+                v = qclamp(v, qwhere_lt(x, lo, z, qrep(-INFINITY)), qwhere_gt(x, hi, z, qrep(INFINITY)));
                 x = qclamp(x, lo, hi);
             }
             q[i] = x;
@@ -404,7 +404,8 @@ MPPI_HD QF quad_rollout(M &m0, CCfg &cfg0, CCost &cost0, const float *dof0, cons
     for (int t = 0; t < H; t++) {
         CCfg &cfg = *launder(cp);
         float u[kMaxNu];
-        ctrl += sample_controls(cfg, U, eps, prior, t, k, is_null, is_prior, leader, du, u);
+        constexpr int MAXC = NB < kMaxNu ? NB : kMaxNu;  // nu <= NB: one command per driven body at most
+        ctrl += sample_controls<MAXC>(cfg, U, eps, prior, t, k, is_null, is_prior, leader, du, u);
         {
             M &m = *launder(mp);
             static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
@@ -412,7 +413,7 @@ MPPI_HD QF quad_rollout(M &m0, CCfg &cfg0, CCost &cost0, const float *dof0, cons
                 const CmdBlock b = load_block<CmdBlock>(m.b[i].cmd);
                 float tg = 0.f;
 #pragma unroll
-                for (int c = 0; c < kMaxNu; c++) tg += b.v[c] * u[c];
+                for (int c = 0; c < MAXC; c++) tg += b.v[c] * u[c];
                 target[i] = qrep(tg);
             });
         }
