@@ -561,7 +561,7 @@ MPPI_HD void cmd_map(CModel &m, const float *u, float *target) {
         const CmdBlock b = load_block<CmdBlock>(m.b[i].cmd);
         float t = 0.f;
 #pragma unroll
-        for (int c = 0; c < kMaxNu; c++) t += b.v[c] * u[c];  // rows and u are zero beyond nu
+        for (int c = 0; c < (T::NB < kMaxNu ? T::NB : kMaxNu); c++) t += b.v[c] * u[c];  // nu <= NB (mppi_pack.hpp); rows and u are zero beyond nu
         target[i] = t;
     });
 }
@@ -696,7 +696,7 @@ MPPI_HD float rollout_sample(CModel &m0, CCfg &cfg0, CCost &cost0, const float *
     CCost *kp = &cost0;
     for (int t = 0; t < H; t++) {
         CCfg &cfg = *launder(cp);
-        ctrl += sample_controls(cfg, U, eps, prior, t, k, is_null, is_prior, true, du, u);
+        ctrl += sample_controls<(T::NB < kMaxNu ? T::NB : kMaxNu)>(cfg, U, eps, prior, t, k, is_null, is_prior, true, du, u);
         cmd_map<T>(*launder(mp), u, target);
         step<T>(*mp, root, q, qd, target);
         S += disc * stage_cost<T>(*launder(mp), *launder(kp), root, q, qd);

@@ -961,7 +961,7 @@ MPPI_HD float rollout_scene(CModel &m0, CCfg &cfg0, CCost &cost0, const float *d
     CCost *kp = &cost0;
     for (int t = 0; t < H; t++) {
         CCfg &cfg = *launder(cp);
-        ctrl += sample_controls(cfg, U, eps, prior, t, k, is_null, is_prior, leader, du, u);
+        ctrl += sample_controls<(NB < kMaxNu ? (NB ? NB : 1) : kMaxNu)>(cfg, U, eps, prior, t, k, is_null, is_prior, leader, du, u);
         cmd_map<T>(*launder(mp), u, target);
         step_scene<T, SPLIT>(*mp, root, s, target, L, split);
         S += disc * stage_cost_scene<T>(*launder(mp), *launder(kp), root, s, L);
