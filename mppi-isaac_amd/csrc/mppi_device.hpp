@@ -343,12 +343,17 @@ MPPI_HD float sample_controls(CCfg &cfg, const float *U, const float *eps, const
     float Ut[MAXC], e[MAXC], pr[MAXC];
 #pragma unroll
     for (int c = MAXC; c < kMaxNu; c++) u[c] = 0.f;
+    // 32-bit element indices (H * nu * K < 2^31 is checked by pack_config): no 64-bit scalar multiplies per load.
+    // The prior row is loaded by every lane when there is one (uniform address, uniform condition) and selected per
+    // lane below - a per-lane `is_prior ? prior[..] : 0` would put each load under its own exec-mask branch.
+    const bool has_prior = prior != nullptr;
 #pragma unroll
     for (int c = 0; c < MAXC; c++) {
         const int cc = c < nu ? c : nu - 1;  // keep the address valid; the lane is masked below
-        Ut[c] = U[t * nu + cc];
-        e[c] = eps[(size_t)(t * nu + cc) * K + k];
-        pr[c] = is_prior ? prior[t * nu + cc] : 0.f;
+        const unsigned row = (unsigned)(t * nu + cc);
+        Ut[c] = U[row];
+        e[c] = eps[row * (unsigned)K + (unsigned)k];
+        pr[c] = has_prior ? prior[row] : 0.f;
     }
     const CtrlBlock lo = load_block<CtrlBlock>(cfg.u_min), hi = load_block<CtrlBlock>(cfg.u_max), is = load_block<CtrlBlock>(cfg.inv_sigma);
     float ctrl = 0.f;
@@ -361,7 +366,7 @@ MPPI_HD float sample_controls(CCfg &cfg, const float *U, const float *eps, const
         const bool on = c < nu;
         u[c] = on ? v : 0.f;
         const float d = v - Ut[c];
-        if (on && leader) du[(size_t)(t * nu + c) * K + k] = d;
+        if (on && leader) du[(unsigned)(t * nu + c) * (unsigned)K + (unsigned)k] = d;
         const float term = Ut[c] * d * is.v[c];  // inv_sigma is zero beyond nu
         ctrl += cfg.lambda * (cfg.noise_abs_cost ? fabsf(term) : term);
     }
