@@ -31,6 +31,7 @@ struct EvScope {  // optional hipEvent bracket around one launch (profiling mode
         if (!c->profiling) return;
         if (c->ev_seen[which]++ % (size_t)c->profile_period != 0) return;  // every n-th launch of this kernel
         auto &v = c->ev[which];
+        if (c->ev_used[which] >= 8192) return;  // bounded: a long profiled run keeps its first 8192 brackets per kernel
         if (c->ev_used[which] == v.size()) {
             hipEvent_t a, b;
             (void)hipEventCreate(&a);
@@ -74,6 +75,76 @@ int check_ctx(const mppi_ctx *c) {
         hipError_t e_ = hipSetDevice((c)->device); \
         if (e_ != hipSuccess) return fail(MPPI_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(e_)); \
     } while (0)
+
+// device / pinned allocations and initial uploads of a new context; any failure leaves a partially filled context that
+// release_ctx() disposes of
+int create_buffers(mppi_ctx *c, const mppi_config_t *cfg) {
+    c->n = c->hm.nb; c->A = c->hm.n_actors; c->B = c->hm.n_rb; c->K = cfg->num_samples; c->H = cfg->horizon; c->nu = cfg->nu;
+    c->HN = c->H * c->nu; c->RF = 2 + c->HN; c->n_waves = (c->K + kWave - 1) / kWave;
+    c->n_quads = (c->K + 15) / 16;
+    const size_t K = c->K;
+    ALLOC_TRY(c->d_model, sizeof(DevModel));
+    ALLOC_TRY(c->d_cfg, sizeof(DevCfg));
+    ALLOC_TRY(c->d_cost, sizeof(DevCost));
+    ALLOC_TRY(c->d_x0_dof, sizeof(float) * 2 * c->n);
+    ALLOC_TRY(c->d_x0_root, sizeof(float) * 13 * c->A);
+    ALLOC_TRY(c->d_U, sizeof(float) * c->HN);
+    ALLOC_TRY(c->d_eps, sizeof(float) * c->HN * K);
+    ALLOC_TRY(c->d_du, sizeof(float) * c->HN * K);
+    ALLOC_TRY(c->d_S, sizeof(float) * K);
+    ALLOC_TRY(c->d_prior, sizeof(float) * c->HN);
+    ALLOC_TRY(c->d_viz, sizeof(float) * (cfg->want_rollouts ? (size_t)c->H * K * 3 : 1));
+    ALLOC_TRY(c->d_partials, sizeof(float) * (size_t)c->n_quads * c->RF);
+    ALLOC_TRY(c->d_record, sizeof(float) * c->RF);
+    ALLOC_TRY(c->d_action, sizeof(float) * c->nu);
+    ALLOC_TRY(c->d_beta_eta, sizeof(float) * 2);
+    ALLOC_TRY(c->d_q, sizeof(float) * c->n * K);
+    ALLOC_TRY(c->d_qd, sizeof(float) * c->n * K);
+    ALLOC_TRY(c->d_ctrl, sizeof(float) * K);
+    ALLOC_TRY(c->d_base, sizeof(float) * 13 * K);
+    ALLOC_TRY(c->d_fr, sizeof(float) * kMaxFree * 13 * K);
+    ALLOC_TRY(c->d_cf, sizeof(float) * 3 * c->B * K);
+    ALLOC_TRY(c->d_filter, sizeof(float) * c->H * c->H);
+    ALLOC_TRY(c->d_basis, sizeof(double) * MPPI_MAX_H * MPPI_MAX_KNOTS);
+    ALLOC_TRY(c->d_sigma, sizeof(double) * MPPI_MAX_NU);
+    c->eps_in = c->d_eps;
+    double sig[MPPI_MAX_NU] = {0};
+    for (int j = 0; j < c->nu; j++) sig[j] = std::sqrt(cfg->noise_sigma_diag[j]);
+    HIP_TRY(hipMemcpy(c->d_model, &c->hm, sizeof(DevModel), hipMemcpyHostToDevice));
+    // the update kernels also store the action into mapped pinned host memory: mppi_get_action is then a stream
+    // synchronise + a host read instead of a D2H copy operation
+    HIP_TRY(hipHostMalloc((void **)&c->h_action, sizeof(float) * 32, hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(c->h_action, 0, sizeof(float) * 32);
+    HIP_TRY(hipHostGetDevicePointer((void **)&c->hc.action_mirror, c->h_action, 0));
+    c->hc.seq_host = reinterpret_cast<unsigned *>(c->hc.action_mirror + 16);
+    ALLOC_TRY(c->d_seq, sizeof(unsigned));
+    c->hc.seq_dev = c->d_seq;
+    HIP_TRY(hipMemcpy(c->d_cfg, &c->hc, sizeof(DevCfg), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_cost, &c->hk, sizeof(DevCost), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_basis, cfg->spline_basis, sizeof(double) * MPPI_MAX_H * MPPI_MAX_KNOTS, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_sigma, sig, sizeof sig, hipMemcpyHostToDevice));
+    std::vector<float> U0(c->HN, (float)cfg->u_init);
+    HIP_TRY(hipMemcpy(c->d_U, U0.data(), sizeof(float) * c->HN, hipMemcpyHostToDevice));
+    return MPPI_OK;
+}
+
+// frees everything a context owns (null-safe: also used for a context whose creation failed half way)
+void release_ctx(mppi_ctx *c) {
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void *bufs[] = {c->d_model, c->d_cfg, c->d_cost, c->d_x0_dof, c->d_x0_root, c->d_U, c->d_eps, c->d_du, c->d_S, c->d_prior, c->d_viz,
+                    c->d_partials, c->d_record, c->d_action, c->d_beta_eta, c->d_q, c->d_qd, c->d_ctrl, c->d_basis, c->d_sigma, c->d_base, c->d_fr, c->d_cf, c->d_filter,
+                    c->d_seq};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    if (c->h_action) (void)hipHostFree(c->h_action);
+    for (auto &v : c->ev)
+        for (auto &p : v) {
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+        }
+    delete c;
+}
 
 int launch_check() {
     hipError_t e = hipGetLastError();
@@ -167,52 +238,11 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
         delete c;
         return fail(MPPI_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
     }
-    c->n = c->hm.nb; c->A = c->hm.n_actors; c->B = c->hm.n_rb; c->K = cfg->num_samples; c->H = cfg->horizon; c->nu = cfg->nu;
-    c->HN = c->H * c->nu; c->RF = 2 + c->HN; c->n_waves = (c->K + kWave - 1) / kWave;
-    c->n_quads = (c->K + 15) / 16;
-    const size_t K = c->K;
-    ALLOC_TRY(c->d_model, sizeof(DevModel));
-    ALLOC_TRY(c->d_cfg, sizeof(DevCfg));
-    ALLOC_TRY(c->d_cost, sizeof(DevCost));
-    ALLOC_TRY(c->d_x0_dof, sizeof(float) * 2 * c->n);
-    ALLOC_TRY(c->d_x0_root, sizeof(float) * 13 * c->A);
-    ALLOC_TRY(c->d_U, sizeof(float) * c->HN);
-    ALLOC_TRY(c->d_eps, sizeof(float) * c->HN * K);
-    ALLOC_TRY(c->d_du, sizeof(float) * c->HN * K);
-    ALLOC_TRY(c->d_S, sizeof(float) * K);
-    ALLOC_TRY(c->d_prior, sizeof(float) * c->HN);
-    ALLOC_TRY(c->d_viz, sizeof(float) * (cfg->want_rollouts ? (size_t)c->H * K * 3 : 1));
-    ALLOC_TRY(c->d_partials, sizeof(float) * (size_t)c->n_quads * c->RF);
-    ALLOC_TRY(c->d_record, sizeof(float) * c->RF);
-    ALLOC_TRY(c->d_action, sizeof(float) * c->nu);
-    ALLOC_TRY(c->d_beta_eta, sizeof(float) * 2);
-    ALLOC_TRY(c->d_q, sizeof(float) * c->n * K);
-    ALLOC_TRY(c->d_qd, sizeof(float) * c->n * K);
-    ALLOC_TRY(c->d_ctrl, sizeof(float) * K);
-    ALLOC_TRY(c->d_base, sizeof(float) * 13 * K);
-    ALLOC_TRY(c->d_fr, sizeof(float) * kMaxFree * 13 * K);
-    ALLOC_TRY(c->d_cf, sizeof(float) * 3 * c->B * K);
-    ALLOC_TRY(c->d_filter, sizeof(float) * c->H * c->H);
-    ALLOC_TRY(c->d_basis, sizeof(double) * MPPI_MAX_H * MPPI_MAX_KNOTS);
-    ALLOC_TRY(c->d_sigma, sizeof(double) * MPPI_MAX_NU);
-    c->eps_in = c->d_eps;
-    double sig[MPPI_MAX_NU] = {0};
-    for (int j = 0; j < c->nu; j++) sig[j] = std::sqrt(cfg->noise_sigma_diag[j]);
-    HIP_TRY(hipMemcpy(c->d_model, &c->hm, sizeof(DevModel), hipMemcpyHostToDevice));
-    // the update kernels also store the action into mapped pinned host memory: mppi_get_action is then a stream
-    // synchronise + a host read instead of a D2H copy operation
-    HIP_TRY(hipHostMalloc((void **)&c->h_action, sizeof(float) * 32, hipHostMallocMapped | hipHostMallocCoherent));
-    std::memset(c->h_action, 0, sizeof(float) * 32);
-    HIP_TRY(hipHostGetDevicePointer((void **)&c->hc.action_mirror, c->h_action, 0));
-    c->hc.seq_host = reinterpret_cast<unsigned *>(c->hc.action_mirror + 16);
-    ALLOC_TRY(c->d_seq, sizeof(unsigned));
-    c->hc.seq_dev = c->d_seq;
-    HIP_TRY(hipMemcpy(c->d_cfg, &c->hc, sizeof(DevCfg), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->d_cost, &c->hk, sizeof(DevCost), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->d_basis, cfg->spline_basis, sizeof(double) * MPPI_MAX_H * MPPI_MAX_KNOTS, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->d_sigma, sig, sizeof sig, hipMemcpyHostToDevice));
-    std::vector<float> U0(c->HN, (float)cfg->u_init);
-    HIP_TRY(hipMemcpy(c->d_U, U0.data(), sizeof(float) * c->HN, hipMemcpyHostToDevice));
+    const int rc = create_buffers(c, cfg);
+    if (rc != MPPI_OK) {  // (the error text is already set) nothing allocated so far may leak
+        release_ctx(c);
+        return rc;
+    }
     {
         std::lock_guard<std::mutex> lk(g_live_mu);
         g_live.insert(c);
@@ -227,20 +257,7 @@ int mppi_destroy(mppi_ctx_t *c) {
         std::lock_guard<std::mutex> lk(g_live_mu);
         if (g_live.erase(c) == 0) return fail(MPPI_EINVAL, "mppi_destroy: stale or foreign context handle");
     }
-    (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
-    void *bufs[] = {c->d_model, c->d_cfg, c->d_cost, c->d_x0_dof, c->d_x0_root, c->d_U, c->d_eps, c->d_du, c->d_S, c->d_prior, c->d_viz,
-                    c->d_partials, c->d_record, c->d_action, c->d_beta_eta, c->d_q, c->d_qd, c->d_ctrl, c->d_basis, c->d_sigma, c->d_base, c->d_fr, c->d_cf, c->d_filter};
-    for (void *b : bufs)
-        if (b) (void)hipFree(b);
-    if (c->h_action) (void)hipHostFree(c->h_action);
-    if (c->d_seq) (void)hipFree(c->d_seq);
-    for (auto &v : c->ev)
-        for (auto &p : v) {
-            (void)hipEventDestroy(p.first);
-            (void)hipEventDestroy(p.second);
-        }
-    delete c;
+    release_ctx(c);
     return MPPI_OK;
 }
 
