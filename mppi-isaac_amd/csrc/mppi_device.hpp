@@ -335,42 +335,58 @@ MPPI_HD float clampf(float v, float lo, float hi) {
 }
 
 // MAXC: compile-time bound of the control dimension (nu <= number of driven bodies of the kinematic tree), so the
-// unrolled loops stop at 7 for the Panda instead of kMaxNu = 12; u[] is still written up to kMaxNu
-template <int MAXC = kMaxNu>
-MPPI_HD float sample_controls(CCfg &cfg, const float *U, const float *eps, const float *prior, int t, int k, bool is_null, bool is_prior,
-                              bool leader, float *du, float *u) {
-    const int K = cfg.K, nu = cfg.nu;
+// unrolled loops stop at 7 for the Panda instead of kMaxNu = 12; u[] is still written up to kMaxNu.
+// The work is split in a LOAD half (nominal row, this sample's noise, prior row of step t) and an APPLY half, so that a
+// rollout can request step t+1's rows before it simulates step t: the ~1 us HBM latency of the streamed noise then
+// hides under the step instead of stalling the (only) wavefront of the SIMD once per horizon step.
+template <int MAXC>
+struct ControlRows {
     float Ut[MAXC], e[MAXC], pr[MAXC];
-#pragma unroll
-    for (int c = MAXC; c < kMaxNu; c++) u[c] = 0.f;
+};
+template <int MAXC = kMaxNu>
+MPPI_HD void load_controls(CCfg &cfg, const float *U, const float *eps, const float *prior, int t, int k, ControlRows<MAXC> &r) {
+    const int K = cfg.K, nu = cfg.nu;
     // 32-bit element indices (H * nu * K < 2^31 is checked by pack_config): no 64-bit scalar multiplies per load.
     // The prior row is loaded by every lane when there is one (uniform address, uniform condition) and selected per
-    // lane below - a per-lane `is_prior ? prior[..] : 0` would put each load under its own exec-mask branch.
+    // lane in apply_controls - a per-lane `is_prior ? prior[..] : 0` would put each load under its own exec-mask branch.
     const bool has_prior = prior != nullptr;
 #pragma unroll
     for (int c = 0; c < MAXC; c++) {
-        const int cc = c < nu ? c : nu - 1;  // keep the address valid; the lane is masked below
+        const int cc = c < nu ? c : nu - 1;  // keep the address valid; the lane is masked in apply_controls
         const unsigned row = (unsigned)(t * nu + cc);
-        Ut[c] = U[row];
-        e[c] = eps[row * (unsigned)K + (unsigned)k];
-        pr[c] = has_prior ? prior[row] : 0.f;
+        r.Ut[c] = U[row];
+        r.e[c] = eps[row * (unsigned)K + (unsigned)k];
+        r.pr[c] = has_prior ? prior[row] : 0.f;
     }
+}
+template <int MAXC = kMaxNu>
+MPPI_HD float apply_controls(CCfg &cfg, const ControlRows<MAXC> &r, int t, int k, bool is_null, bool is_prior, bool leader, float *du, float *u) {
+    const int K = cfg.K, nu = cfg.nu;
+#pragma unroll
+    for (int c = MAXC; c < kMaxNu; c++) u[c] = 0.f;
     const CtrlBlock lo = load_block<CtrlBlock>(cfg.u_min), hi = load_block<CtrlBlock>(cfg.u_max), is = load_block<CtrlBlock>(cfg.inv_sigma);
     float ctrl = 0.f;
 #pragma unroll
     for (int c = 0; c < MAXC; c++) {
-        float v = Ut[c] + e[c];
+        float v = r.Ut[c] + r.e[c];
         if (is_null) v = 0.f;
-        if (is_prior) v = pr[c];
+        if (is_prior) v = r.pr[c];
         v = clampf(v, lo.v[c], hi.v[c]);
         const bool on = c < nu;
         u[c] = on ? v : 0.f;
-        const float d = v - Ut[c];
+        const float d = v - r.Ut[c];
         if (on && leader) du[(unsigned)(t * nu + c) * (unsigned)K + (unsigned)k] = d;
-        const float term = Ut[c] * d * is.v[c];  // inv_sigma is zero beyond nu
+        const float term = r.Ut[c] * d * is.v[c];  // inv_sigma is zero beyond nu
         ctrl += cfg.lambda * (cfg.noise_abs_cost ? fabsf(term) : term);
     }
     return ctrl;
+}
+template <int MAXC = kMaxNu>
+MPPI_HD float sample_controls(CCfg &cfg, const float *U, const float *eps, const float *prior, int t, int k, bool is_null, bool is_prior,
+                              bool leader, float *du, float *u) {
+    ControlRows<MAXC> r;
+    load_controls<MAXC>(cfg, U, eps, prior, t, k, r);
+    return apply_controls<MAXC>(cfg, r, t, k, is_null, is_prior, leader, du, u);
 }
 
 // World pose of every moving body for joint positions q (z-framed joints).

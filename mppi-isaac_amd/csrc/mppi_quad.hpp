@@ -401,11 +401,15 @@ MPPI_HD QF quad_rollout(M &m0, CCfg &cfg0, CCost &cost0, const float *dof0, cons
     M *mp = &m0;
     CCfg *cp = &cfg0;
     CCost *kp = &cost0;
+    constexpr int MAXC = NB < kMaxNu ? NB : kMaxNu;  // nu <= NB: one command per driven body at most
+    ControlRows<MAXC> rows;
+    load_controls<MAXC>(cfg0, U, eps, prior, 0, k, rows);
     for (int t = 0; t < H; t++) {
         CCfg &cfg = *launder(cp);
         float u[kMaxNu];
-        constexpr int MAXC = NB < kMaxNu ? NB : kMaxNu;  // nu <= NB: one command per driven body at most
-        ctrl += sample_controls<MAXC>(cfg, U, eps, prior, t, k, is_null, is_prior, leader, du, u);
+        ctrl += apply_controls<MAXC>(cfg, rows, t, k, is_null, is_prior, leader, du, u);
+        // next step's rows are requested now and consumed after this step's dynamics (the last request re-reads row H-1)
+        load_controls<MAXC>(cfg, U, eps, prior, t + 1 < H ? t + 1 : t, k, rows);
         {
             M &m = *launder(mp);
             static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
