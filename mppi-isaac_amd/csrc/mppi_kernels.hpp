@@ -134,8 +134,15 @@ __global__ __launch_bounds__(kWave) void k_rollout_quad(const DevModel *__restri
     constexpr int kModelBytes = (int)((offsetof(DevModel, fr) + 15) / 16 * 16);
     __shared__ __attribute__((aligned(64))) uint4 s_model[kModelBytes / 16];
     for (int i = threadIdx.x; i < kModelBytes / 16; i += kWave) s_model[i] = reinterpret_cast<const uint4 *>(m)[i];
+    // ... and the step loop's own constants (control limits, nominal rows, cost target and weights)
+    __shared__ __attribute__((aligned(64))) float s_step[sizeof(StepConsts) / sizeof(float)];
+    {
+        const int n = step_const_count(*(CCfg *)cfg);
+        for (int j = threadIdx.x; j < n; j += kWave) s_step[j] = step_const_entry(*(CCfg *)cfg, *(CCost *)cost, x0_root, U, j);
+    }
     __syncthreads();
     LModel &lm = *(LModel *)s_model;
+    LStep &sc = *(LStep *)s_step;
     // XCD-aware chunk mapping: a wavefront owns 16 consecutive samples = 64 B of every sample-minor row, i.e.
     // half a 128-B line.  Workgroup b runs on XCD b % 8 and the XCD L2s are private, so with the identity
     // mapping the two halves of each line are fetched by two different L2s (measured: 2x the algorithmic
@@ -148,7 +155,7 @@ __global__ __launch_bounds__(kWave) void k_rollout_quad(const DevModel *__restri
     const bool leader = lane4 == 0;
     float s = INFINITY;
     if (live) {
-        s = quad_rollout<T>(lm, *(CCfg *)cfg, *(CCost *)cost, x0_dof, x0_root, U, eps, prior, du, viz, k, leader, quad_row(), lane4 < 3);
+        s = quad_rollout<T>(lm, *(CCfg *)cfg, *(CCost *)cost, sc, x0_dof, x0_root, eps, prior, du, viz, k, leader, quad_row(), lane4 < 3);
         if (leader) S[k] = s;
     }
     wave_record(*(CCfg *)cfg, s, live && leader, du, k, partials + (size_t)chunk * (2 + cfg->H * cfg->nu));

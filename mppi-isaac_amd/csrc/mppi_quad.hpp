@@ -20,6 +20,8 @@
 // The same templates compile for the host (tests/hostemu): QF is then a 4-float struct and the
 // permutations are array shuffles, so the arithmetic is checked against the oracle without a GPU.
 #pragma once
+#include <cstddef>
+
 #include "mppi_device.hpp"
 
 namespace mppi {
@@ -353,37 +355,105 @@ MPPI_HD void quad_link_pose(M &m, const QPose<T> &P, int l, QM3 &R, QF &p) {
     p = pb + Rb.c[0] * L.p[0] + Rb.c[1] * L.p[1] + Rb.c[2] * L.p[2];
 }
 
-template <class T, class M>
-MPPI_HD QF quad_stage_cost(M &m, CCost &c, const float *root, const QF *q, const QPose<T> &P) {
-    if (c.kind == kCostPointReach) {
-        const float gx = c.actor[0] >= 0 ? root[13 * c.actor[0]] : c.w[1];
-        const float gy = c.actor[0] >= 0 ? root[13 * c.actor[0] + 1] : c.w[2];
-        const QF dx = q[0] - gx, dy = q[T::NB > 1 ? 1 : 0] - gy;
-        return c.w[0] * qsqrt(dx * dx + dy * dy);
+// Per-rollout constants of the step loop, staged next to the robot model (LDS on the device).  Through the scalar cache
+// every one of them was a reload per horizon step - ~11 dependent round trips of a few hundred cycles each that the
+// single wavefront of a SIMD cannot hide (lgkmcnt is shared with the LDS traffic, so scalar loads cannot be left in
+// flight either).  From LDS they arrive in order a few dozen cycles after the request.
+struct StepConsts {
+    CtrlBlock u_min, u_max, inv_sigma;
+    float goal[4];                       // cost target (actor position, or the fixed goal of POINT_REACH)
+    float w[4];                          // cost weights
+    float U[MPPI_MAX_H * MPPI_MAX_NU];   // nominal control rows
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const MPPI_LDS_AS StepConsts LStep;
+#else
+typedef const StepConsts LStep;
+#endif
+// entry j of the staging copy (cooperative: lane j of the wavefront fills entries j, j + 64, ...)
+MPPI_HD float step_const_entry(CCfg &cfg, CCost &c, const float *root, const float *U, int j) {
+    constexpr int kU = (int)(offsetof(StepConsts, U) / sizeof(float));
+    if (j < 16) return cfg.u_min.v[j];
+    if (j < 32) return cfg.u_max.v[j - 16];
+    if (j < 48) return cfg.inv_sigma.v[j - 32];
+    if (j < 52) {
+        const int a = c.actor[0], i = j - 48;
+        if (i == 3) return 0.f;
+        if (a >= 0) return root[13 * a + i];
+        return i < 2 ? c.w[1 + i] : 0.f;  // POINT_REACH without a goal actor: (w1, w2) is the target
     }
-    if (c.kind == kCostPandaReach) {
+    if (j < 56) return c.w[j - 52];
+    return j - kU < cfg.H * cfg.nu ? U[j - kU] : 0.f;
+}
+MPPI_HD int step_const_count(CCfg &cfg) { return (int)(offsetof(StepConsts, U) / sizeof(float)) + cfg.H * cfg.nu; }
+
+template <class T, class M>
+MPPI_HD QF quad_stage_cost(M &m, int kind, int link, LStep &sc, const QF *q, const QPose<T> &P) {
+    if (kind == kCostPointReach) {
+        const QF dx = q[0] - sc.goal[0], dy = q[T::NB > 1 ? 1 : 0] - sc.goal[1];
+        return sc.w[0] * qsqrt(dx * dx + dy * dy);
+    }
+    if (kind == kCostPandaReach) {
         QM3 R;
         QF p;
-        quad_link_pose<T>(m, P, c.link[0], R, p);
-        const float *g = root + 13 * c.actor[0];
-        const QF d = p - qsel(g[0], g[1], g[2]);
+        quad_link_pose<T>(m, P, link, R, p);
+        const QF d = p - qsel(sc.goal[0], sc.goal[1], sc.goal[2]);
         const QF dist = qsqrt(qsum(d * d));
         // row 2 of R lives in lane 2: R20, R21, R22 -> replicated (see stage_cost in mppi_device.hpp)
         const QF r20 = bc<2>(R.c[0]), r21 = bc<2>(R.c[1]), r22 = bc<2>(R.c[2]);
         const QF a0 = qatan2(r21, -r22);
         const QF a1 = qasin(qclamp(r20, qrep(-1.f), qrep(1.f)));
-        return c.w[0] * dist + c.w[1] * qsqrt(a0 * a0 + a1 * a1);
+        return sc.w[0] * dist + sc.w[1] * qsqrt(a0 * a0 + a1 * a1);
     }
     return qrep(0.f);
+}
+
+// control rows of step t: the nominal row from the staged copy, this sample's noise from HBM (requested one step ahead)
+template <int MAXC>
+MPPI_HD void load_controls_q(LStep &sc, const float *eps, const float *prior, int nu, int K, int t, int k, ControlRows<MAXC> &r) {
+    const bool has_prior = prior != nullptr;
+#pragma unroll
+    for (int c = 0; c < MAXC; c++) {
+        const int cc = c < nu ? c : nu - 1;
+        const unsigned row = (unsigned)(t * nu + cc);
+        r.Ut[c] = sc.U[row];
+        r.e[c] = eps[row * (unsigned)K + (unsigned)k];
+        r.pr[c] = has_prior ? prior[row] : 0.f;
+    }
+}
+template <int MAXC>
+MPPI_HD float apply_controls_q(LStep &sc, float lambda, bool abs_cost, int nu, int K, const ControlRows<MAXC> &r, int t, int k, bool is_null,
+                               bool is_prior, bool leader, float *du, float *u) {
+#pragma unroll
+    for (int c = MAXC; c < kMaxNu; c++) u[c] = 0.f;
+    const CtrlBlock lo = load_block<CtrlBlock>(sc.u_min), hi = load_block<CtrlBlock>(sc.u_max), is = load_block<CtrlBlock>(sc.inv_sigma);
+    float ctrl = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; c++) {
+        float v = r.Ut[c] + r.e[c];
+        if (is_null) v = 0.f;
+        if (is_prior) v = r.pr[c];
+        v = clampf(v, lo.v[c], hi.v[c]);
+        const bool on = c < nu;
+        u[c] = on ? v : 0.f;
+        const float d = v - r.Ut[c];
+        if (on && leader) du[(unsigned)(t * nu + c) * (unsigned)K + (unsigned)k] = d;
+        const float term = r.Ut[c] * d * is.v[c];  // inv_sigma is zero beyond nu
+        ctrl += lambda * (abs_cost ? fabsf(term) : term);
+    }
+    return ctrl;
 }
 
 // Whole-horizon rollout of the sample owned by this quad.  Every lane of the quad returns the same S.
 // `leader` is true in exactly one lane of the quad (it performs the du store); lanes 0..2 store viz.
 template <class T, class M>
-MPPI_HD QF quad_rollout(M &m0, CCfg &cfg0, CCost &cost0, const float *dof0, const float *root, const float *U, const float *eps,
+MPPI_HD QF quad_rollout(M &m0, CCfg &cfg0, CCost &cost0, LStep &sc, const float *dof0, const float *root, const float *eps,
                         const float *prior, float *du, float *viz, int k, bool leader, int row, bool viz_lane) {
     constexpr int NB = T::NB;
-    const int K = cfg0.K, nu = cfg0.nu, H = cfg0.H;
+    // read once, kept in SGPRs across the horizon (not laundered)
+    const int K = cfg0.K, nu = cfg0.nu, H = cfg0.H, kind = cost0.kind, link = cost0.link[0], viz_link = cfg0.viz_link;
+    const float lambda = cfg0.lambda, gamma = cfg0.gamma;
+    const bool abs_cost = cfg0.noise_abs_cost != 0, want_viz = cfg0.want_rollouts && viz != nullptr;
     const int g = cfg0.k_offset + k;
     const bool is_null = cfg0.sample_null_action && g == cfg0.k_total - 1;
     const bool is_prior = cfg0.use_priors && prior != nullptr && g == cfg0.k_total - 2;
@@ -399,17 +469,14 @@ MPPI_HD QF quad_rollout(M &m0, CCfg &cfg0, CCost &cost0, const float *dof0, cons
     quad_base<T>(m0, root, P);
     quad_fk<T>(m0, q, P);
     M *mp = &m0;
-    CCfg *cp = &cfg0;
-    CCost *kp = &cost0;
     constexpr int MAXC = NB < kMaxNu ? NB : kMaxNu;  // nu <= NB: one command per driven body at most
     ControlRows<MAXC> rows;
-    load_controls<MAXC>(cfg0, U, eps, prior, 0, k, rows);
+    load_controls_q<MAXC>(sc, eps, prior, nu, K, 0, k, rows);
     for (int t = 0; t < H; t++) {
-        CCfg &cfg = *launder(cp);
         float u[kMaxNu];
-        ctrl += apply_controls<MAXC>(cfg, rows, t, k, is_null, is_prior, leader, du, u);
+        ctrl += apply_controls_q<MAXC>(sc, lambda, abs_cost, nu, K, rows, t, k, is_null, is_prior, leader, du, u);
         // next step's rows are requested now and consumed after this step's dynamics (the last request re-reads row H-1)
-        load_controls<MAXC>(cfg, U, eps, prior, t + 1 < H ? t + 1 : t, k, rows);
+        load_controls_q<MAXC>(sc, eps, prior, nu, K, t + 1 < H ? t + 1 : t, k, rows);
         {
             M &m = *launder(mp);
             static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
@@ -422,13 +489,13 @@ MPPI_HD QF quad_rollout(M &m0, CCfg &cfg0, CCost &cost0, const float *dof0, cons
             });
         }
         quad_step<T>(*mp, P, q, qd, target);
-        S += disc * quad_stage_cost<T>(*launder(mp), *launder(kp), root, q, P);
-        disc *= cfg.gamma;
-        if (cfg.want_rollouts && viz != nullptr) {
+        S += disc * quad_stage_cost<T>(*launder(mp), kind, link, sc, q, P);
+        disc *= gamma;
+        if (want_viz) {
             M &m = *launder(mp);
             QM3 R;
             QF p;
-            quad_link_pose<T>(m, P, cfg.viz_link, R, p);
+            quad_link_pose<T>(m, P, viz_link, R, p);
 #if defined(__HIP_DEVICE_COMPILE__)
             if (viz_lane) viz[((size_t)t * 3 + row) * K + k] = p;  // lane r stores component r
 #else
