@@ -419,11 +419,11 @@ MPPI_HD void fast_sincos(float x, float &s, float &c) {
     c = ((ki + 1) & 2) ? -cc : cc;
 }
 
-template <class T>
-MPPI_HD void forward_kinematics_base(CModel &m, const float *q, Pose<T> &P);
+template <class T, class M>
+MPPI_HD void forward_kinematics_base(M &m, const float *q, Pose<T> &P);
 
-template <class T>
-MPPI_HD void forward_kinematics(CModel &m, const float *root, const float *q, Pose<T> &P) {
+template <class T, class M>
+MPPI_HD void forward_kinematics(M &m, const float *root, const float *q, Pose<T> &P) {
     const float *rs = root + 13 * m.robot_actor;
     P.pb = loadv(rs);
     P.Rb = quat_to_R(rs + 3);
@@ -431,8 +431,8 @@ MPPI_HD void forward_kinematics(CModel &m, const float *root, const float *q, Po
 }
 
 // body poses from the base pose already stored in P.Rb / P.pb
-template <class T>
-MPPI_HD void forward_kinematics_base(CModel &m, const float *q, Pose<T> &P) {
+template <class T, class M>
+MPPI_HD void forward_kinematics_base(M &m, const float *q, Pose<T> &P) {
     static_for<0, T::NB>([&](auto ic) MPPI_LAMBDA {
         constexpr int i = ic;
         constexpr int par = T::par[i];
@@ -462,8 +462,8 @@ MPPI_HD void forward_kinematics_base(CModel &m, const float *q, Pose<T> &P) {
 }
 
 // joint motion subspace (world axes, about the world origin) of body i
-template <class T, int i>
-MPPI_HD SV joint_subspace(CModel &m, const Pose<T> &P) {
+template <class T, int i, class M>
+MPPI_HD SV joint_subspace(M &m, const Pose<T> &P) {
     V3 az = {P.R[i].a[2], P.R[i].a[5], P.R[i].a[8]};
     if (P.jt[i] == 0) return {az, cross(P.p[i], az)};
     return {{0.f, 0.f, 0.f}, az};
@@ -575,8 +575,8 @@ MPPI_HD void aba_world(CModel &m, const Pose<T> &P, const float *qd, const float
 }
 
 // apply_robot_cmd: control u[nu] -> per-DOF drive target (reference isaacgym_wrapper.py:524-572)
-template <class T>
-MPPI_HD void cmd_map(CModel &m, const float *u, float *target) {
+template <class T, class M>
+MPPI_HD void cmd_map(M &m, const float *u, float *target) {
     static_for<0, T::NB>([&](auto ic) MPPI_LAMBDA {
         constexpr int i = ic;
         const CmdBlock b = load_block<CmdBlock>(m.b[i].cmd);
@@ -639,9 +639,9 @@ MPPI_HD void step(CModel &m0, const float *root, float *q, float *qd, const floa
 // (wave-uniform) index; it is resolved by a 0/1-weighted blend over the compile-time body list
 // instead of a select chain, because the optimiser turns "select between array elements" into an
 // indexed load and then keeps the whole Pose in scratch memory.
-template <class T>
-MPPI_HD void link_pose(CModel &m, const Pose<T> &P, int l, M3 &R, V3 &p) {
-    CLink &L = m.l[l];
+template <class T, class M>
+MPPI_HD void link_pose(M &m, const Pose<T> &P, int l, M3 &R, V3 &p) {
+    auto &L = m.l[l];
     const int body = L.body;
     float wb = body < 0 ? 1.f : 0.f;
     M3 Rb;
@@ -660,8 +660,8 @@ MPPI_HD void link_pose(CModel &m, const Pose<T> &P, int l, M3 &R, V3 &p) {
 MPPI_HD float clamp1(float x) { return fminf(fmaxf(x, -1.f), 1.f); }
 
 // Fused stage cost (DevCost.kind) for a given pose.  See include/mppi_hip.h for the reference Objective each restates.
-template <class T>
-MPPI_HD float stage_cost_pose(CModel &m, CCost &c, const float *root, const float *q, const Pose<T> &P) {
+template <class T, class M>
+MPPI_HD float stage_cost_pose(M &m, CCost &c, const float *root, const float *q, const Pose<T> &P) {
     if (c.kind == kCostPointReach) {
         float gx = c.actor[0] >= 0 ? root[13 * c.actor[0]] : c.w[1];
         float gy = c.actor[0] >= 0 ? root[13 * c.actor[0] + 1] : c.w[2];

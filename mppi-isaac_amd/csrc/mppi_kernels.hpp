@@ -347,6 +347,8 @@ __global__ __launch_bounds__(kWave) void k_rollout_scene_quad(const DevModel *__
                                                               float *__restrict__ partials) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    // (staging the model in LDS as k_rollout_quad does was measured slower here: the constants then occupy VGPRs of a
+    // kernel that already spills - boxer 1.63 -> 1.73 ms, gripper scene 5.09 -> 6.39 ms, scratch 404 -> 972 B/lane)
     const int nb = gridDim.x;  // XCD-aware chunk mapping as in k_rollout_quad
     const int chunk = (nb % 16 == 0) ? (int)(blockIdx.x % 8) * (nb / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
     const int k = chunk * 16 + (threadIdx.x >> 2);

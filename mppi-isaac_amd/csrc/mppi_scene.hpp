@@ -62,8 +62,8 @@ MPPI_HD float std_normal_from_uniform(float u) {
 }
 
 // this sample's draws for the noisy actors: size deltas, mass scale, friction
-template <class T>
-MPPI_HD void scene_randomise(CModel &m, int g, const LMem &L) {
+template <class T, class M>
+MPPI_HD void scene_randomise(M &m, int g, const LMem &L) {
     using Lay = SceneLayout<T>;
     if (m.n_rnd == 0) return;
     for (int a = 0; a < m.n_actors; a++) {
@@ -82,8 +82,8 @@ MPPI_HD void scene_randomise(CModel &m, int g, const LMem &L) {
 struct ActorDraw {
     float d[3], ms, mu;
 };
-template <class T>
-MPPI_HD ActorDraw actor_draw(CModel &m, int a, const LMem &L) {
+template <class T, class M>
+MPPI_HD ActorDraw actor_draw(M &m, int a, const LMem &L) {
     const int slot = m.rnd_slot[a];
     if (slot < 0) return ActorDraw{{0.f, 0.f, 0.f}, 1.f, m.actor_mu[a]};
     const int o = SceneLayout<T>::kCf + 3 * m.n_rb + 5 * slot;
@@ -309,7 +309,8 @@ struct ShapeW {
     V3 p;
     SV v;
 };
-MPPI_HD ShapeW shape_world(CShape &S, const float *root, const LMem &L) {
+template <class SH>
+MPPI_HD ShapeW shape_world(SH &S, const float *root, const LMem &L) {
     M3 Rf;
     V3 pf;
     SV vf = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
@@ -329,13 +330,13 @@ MPPI_HD ShapeW shape_world(CShape &S, const float *root, const LMem &L) {
 
 // World poses of the collision shapes in the sample's LDS rows (kernels whose lanes share a sample): the shapes are
 // dealt over the lanes; static shapes are posed once per rollout, the others once per substep.
-template <class T>
-MPPI_HD int shape_cache_base(CModel &m) { return SceneLayout<T>::kCf + 3 * m.n_rb + 5 * m.n_rnd; }
-template <class T>
-MPPI_HD void shape_cache_update(CModel &m, const float *root, const LMem &L, Split sp, bool statics) {
+template <class T, class M>
+MPPI_HD int shape_cache_base(M &m) { return SceneLayout<T>::kCf + 3 * m.n_rb + 5 * m.n_rnd; }
+template <class T, class M>
+MPPI_HD void shape_cache_update(M &m, const float *root, const LMem &L, Split sp, bool statics) {
     const int base = shape_cache_base<T>(m);
     for (int i = sp.sub; i < m.n_shapes; i += sp.n) {
-        CShape &S = m.sh[i];
+        auto &S = m.sh[i];
         if ((S.ent < 0) != statics) continue;
         const ShapeW w = shape_world(S, root, L);
         const int o = base + 12 * i;
@@ -343,8 +344,8 @@ MPPI_HD void shape_cache_update(CModel &m, const float *root, const LMem &L, Spl
         L[o + 9] = w.p.x; L[o + 10] = w.p.y; L[o + 11] = w.p.z;
     }
 }
-template <class T>
-MPPI_HD ShapeW shape_cached(CModel &m, int i, const LMem &L) {
+template <class T, class M>
+MPPI_HD ShapeW shape_cached(M &m, int i, const LMem &L) {
     const int o = shape_cache_base<T>(m) + 12 * i;
     ShapeW w;
     for (int j = 0; j < 9; j++) w.R.a[j] = L[o + j];
@@ -455,16 +456,16 @@ MPPI_HD void sphere_in_box(const Gains &P, V3 ps, float r, const ShapeW &Y, cons
 }
 
 // All candidate pairs of the scene -> per-frame wrench / damping accumulators and net contact forces.
-template <class T, int SPLIT = kSplitNone>
-MPPI_HD void contact_forces(CModel &m, const float *root, const LMem &L, Split split = Split{0, 1}) {
+template <class T, int SPLIT = kSplitNone, class M = CModel>
+MPPI_HD void contact_forces(M &m, const float *root, const LMem &L, Split split = Split{0, 1}) {
     using Lay = SceneLayout<T>;
     for (int j = Lay::kAcc; j < Lay::kCf + 3 * m.n_rb; j++) L[j] = 0.f;
     const SV zero = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
     constexpr bool kCached = SPLIT != kSplitNone;
     if constexpr (kCached) shape_cache_update<T>(m, root, L, SPLIT == kSplitEmulate ? Split{0, 1} : split, false);
     for (int ip = 0; ip < m.n_pairs; ip++) {
-        CPair &Pm = m.pr[ip];
-        CShape &A = m.sh[Pm.a];
+        auto &Pm = m.pr[ip];
+        auto &A = m.sh[Pm.a];
         ShapeW wa;
         if constexpr (kCached) wa = shape_cached<T>(m, Pm.a, L);
         else wa = shape_world(A, root, L);
@@ -480,7 +481,7 @@ MPPI_HD void contact_forces(CModel &m, const float *root, const LMem &L, Split s
             const float mua = ra ? A.mu : da.mu;
             float mub = Pm.mub, sb = 1.f;
             if (Pm.b >= 0) {
-                CShape &Bs = m.sh[Pm.b];
+                auto &Bs = m.sh[Pm.b];
                 const bool rbt = Bs.src_actor == m.robot_actor;
                 const ActorDraw db = actor_draw<T>(m, Bs.src_actor, L);
                 mub = rbt ? Bs.mu : db.mu;
@@ -502,7 +503,7 @@ MPPI_HD void contact_forces(CModel &m, const float *root, const LMem &L, Split s
         int rbB = -1, entB = -1;
         ShapeW wb;
         if (Pm.b >= 0) {
-            CShape &B = m.sh[Pm.b];
+            auto &B = m.sh[Pm.b];
             if constexpr (kCached) wb = shape_cached<T>(m, Pm.b, L);
             else wb = shape_world(B, root, L);
             rbB = B.rb;
@@ -646,8 +647,8 @@ MPPI_HD void root_integrate(float *rs, const SV &a, float h) {
 
 // Articulated-body solve of the robot with external wrenches f_i and implicit dampings C_i per frame
 // (from contact_forces), explicit gravity, optional floating base.  Returns qdd and the base acceleration.
-template <class T>
-MPPI_HD void aba_scene(CModel &m, const Pose<T> &P, const SV &vbase, const float *qd, const float *tau_exp, const float *kdh,
+template <class T, class M>
+MPPI_HD void aba_scene(M &m, const Pose<T> &P, const SV &vbase, const float *qd, const float *tau_exp, const float *kdh,
                        const LMem &L, float *qdd, SV &abase) {
     constexpr int NB = T::NB;
     using Lay = SceneLayout<T>;
@@ -748,8 +749,8 @@ MPPI_HD void aba_scene(CModel &m, const Pose<T> &P, const SV &vbase, const float
 }
 
 // kinematics of the whole scene for the current state: robot poses + dynamic frames into L
-template <class T>
-MPPI_HD void scene_frames(CModel &m, const float *root, const SceneState<T> &s, Pose<T> &P, SV &vbase, const LMem &L) {
+template <class T, class M>
+MPPI_HD void scene_frames(M &m, const float *root, const SceneState<T> &s, Pose<T> &P, SV &vbase, const LMem &L) {
     constexpr int NB = T::NB;
     // the robot row of `root` is replaced by the sample's own base state
     P.pb = loadv(s.base);
@@ -777,12 +778,12 @@ MPPI_HD void scene_frames(CModel &m, const float *root, const SceneState<T> &s, 
 }
 
 // One simulator step of a contact scene (dt = substeps * h).  `root` carries the static actors.
-template <class T, int SPLIT = kSplitNone>
-MPPI_HD void step_scene(CModel &m0, const float *root, SceneState<T> &s, const float *target, const LMem &L, Split split = Split{0, 1}) {
+template <class T, int SPLIT = kSplitNone, class M = CModel>
+MPPI_HD void step_scene(M &m0, const float *root, SceneState<T> &s, const float *target, const LMem &L, Split split = Split{0, 1}) {
     constexpr int NB = T::NB;
-    CModel *mp = &m0;
+    M *mp = &m0;
     for (int sub = 0; sub < m0.substeps; sub++) {
-        CModel &m = *launder(mp);
+        M &m = *launder(mp);
         const float h = m.h, kd = m.kd;
         Pose<T> P;
         SV vbase;
@@ -827,7 +828,7 @@ MPPI_HD void step_scene(CModel &m0, const float *root, SceneState<T> &s, const f
         // free rigid bodies: (I + h C) a = -(v x* I v + C v - f - f_g)
         for (int f = 0; f < kMaxFree; f++)
             if (f < m.n_free) {
-                CFree &F = m.fr[f];
+                auto &F = m.fr[f];
                 float *rs = s.fr[f];
                 M3 R;
                 V3 p;
@@ -865,8 +866,8 @@ MPPI_HD void step_scene(CModel &m0, const float *root, SceneState<T> &s, const f
 }
 
 // ---- scene rollouts -----------------------------------------------------------------------------
-template <class T>
-MPPI_HD void scene_init(CModel &m, const float *dof0, const float *root, SceneState<T> &s, int g, const LMem &L) {
+template <class T, class M>
+MPPI_HD void scene_init(M &m, const float *dof0, const float *root, SceneState<T> &s, int g, const LMem &L) {
     scene_randomise<T>(m, g, L);
     static_for<0, T::NB>([&](auto ic) MPPI_LAMBDA {
         constexpr int i = ic;
@@ -886,8 +887,8 @@ MPPI_HD float quat_yaw(const float *q) {
 // Stage cost of a contact scene.  BOXER_PUSH restates examples/boxer_push/planner.py:26-67:
 // link[0] = robot link (ee_link), actor[0] = block, actor[1] = goal, link[1], link[2] = rigid bodies of the
 // two obstacles; w = {robot_to_block, block_to_goal, block_to_goal_ort, push_align, velocity, collision, goal_yaw}.
-template <class T>
-MPPI_HD float stage_cost_scene(CModel &m, CCost &c, const float *root, const SceneState<T> &s, const LMem &L) {
+template <class T, class M>
+MPPI_HD float stage_cost_scene(M &m, CCost &c, const float *root, const SceneState<T> &s, const LMem &L) {
     using Lay = SceneLayout<T>;
     if (c.kind == kCostBoxerPush) {
         Pose<T> P;
@@ -942,8 +943,8 @@ MPPI_HD float stage_cost_scene(CModel &m, CCost &c, const float *root, const Sce
     return stage_cost_pose<T>(m, c, root, s.q, P);
 }
 
-template <class T, int SPLIT = kSplitNone>
-MPPI_HD float rollout_scene(CModel &m0, CCfg &cfg0, CCost &cost0, const float *dof0, const float *root, const float *U, const float *eps,
+template <class T, int SPLIT = kSplitNone, class M = CModel>
+MPPI_HD float rollout_scene(M &m0, CCfg &cfg0, CCost &cost0, const float *dof0, const float *root, const float *U, const float *eps,
                             const float *prior, float *du, float *viz, int k, const LMem &L, Split split = Split{0, 1}) {
     const bool leader = split.sub == 0;  // lanes sharing a sample hold identical values: one of them writes
     constexpr int NB = T::NB;
@@ -956,7 +957,7 @@ MPPI_HD float rollout_scene(CModel &m0, CCfg &cfg0, CCost &cost0, const float *d
     if constexpr (SPLIT != kSplitNone) shape_cache_update<T>(m0, root, L, SPLIT == kSplitEmulate ? Split{0, 1} : split, true);
     float target[NB ? NB : 1], u[kMaxNu];
     float S = 0.f, ctrl = 0.f, disc = 1.f;
-    CModel *mp = &m0;
+    M *mp = &m0;
     CCfg *cp = &cfg0;
     CCost *kp = &cost0;
     for (int t = 0; t < H; t++) {
@@ -967,7 +968,7 @@ MPPI_HD float rollout_scene(CModel &m0, CCfg &cfg0, CCost &cost0, const float *d
         S += disc * stage_cost_scene<T>(*launder(mp), *launder(kp), root, s, L);
         disc *= cfg.gamma;
         if (cfg.want_rollouts && viz != nullptr && leader) {
-            CModel &m = *launder(mp);
+            M &m = *launder(mp);
             Pose<T> P;
             P.pb = loadv(s.base);
             P.Rb = quat_to_R(s.base + 3);
@@ -984,8 +985,8 @@ MPPI_HD float rollout_scene(CModel &m0, CCfg &cfg0, CCost &cost0, const float *d
 }
 
 // reference-layout rows of ONE env of a contact scene: root [A][13], rigid bodies [n_rb][13], contact forces [n_rb][3]
-template <class T>
-MPPI_HD void scene_materialise(CModel &m, const float *root, const SceneState<T> &s, const float *cf_in /* [n_rb*3] or null */,
+template <class T, class M>
+MPPI_HD void scene_materialise(M &m, const float *root, const SceneState<T> &s, const float *cf_in /* [n_rb*3] or null */,
                                float *root_out, float *rb, float *cf) {
     constexpr int NB = T::NB;
     // root rows: static actors from x0, robot and free actors from the env state
