@@ -457,7 +457,8 @@ MPPI_HD void sphere_in_box(const Gains &P, V3 ps, float r, const ShapeW &Y, cons
 
 // All candidate pairs of the scene -> per-frame wrench / damping accumulators and net contact forces.
 template <class T, int SPLIT = kSplitNone, class M = CModel>
-MPPI_HD void contact_forces(M &m, const float *root, const LMem &L, Split split = Split{0, 1}) {
+MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, Split split = Split{0, 1}) {
+    unsigned touched = 0;  // entities (dynamic frames) whose accumulator rows are non-zero after this call
     using Lay = SceneLayout<T>;
     for (int j = Lay::kAcc; j < Lay::kCf + 3 * m.n_rb; j++) L[j] = 0.f;
     const SV zero = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
@@ -602,11 +603,14 @@ MPPI_HD void contact_forces(M &m, const float *root, const LMem &L, Split split 
         if (acc.any) {
             const SV neg = {{-acc.f.a.x, -acc.f.a.y, -acc.f.a.z}, {-acc.f.l.x, -acc.f.l.y, -acc.f.l.z}};
             if (Pm.mode == 0) {
+                touched |= (1u << A.ent) | (1u << entB);
                 acc_add(L, Lay::kAcc, A.ent, acc.f, nullptr);
                 acc_add(L, Lay::kAcc, entB, neg, nullptr);
             } else if (Pm.mode == 1) {
+                touched |= 1u << A.ent;
                 acc_add(L, Lay::kAcc, A.ent, acc.f, &acc.C);
             } else {
+                touched |= 1u << entB;
                 acc_add(L, Lay::kAcc, entB, neg, &acc.C);
             }
             const int ocf = Lay::kCf + 3 * A.rb;
@@ -617,6 +621,7 @@ MPPI_HD void contact_forces(M &m, const float *root, const LMem &L, Split split 
             }
         }
     }
+    return touched;
 }
 
 // quaternion (xyzw) integration q <- normalize(q + h/2 (w,0) * q), world-frame angular velocity
@@ -777,6 +782,48 @@ MPPI_HD void scene_frames(M &m, const float *root, const SceneState<T> &s, Pose<
         }
 }
 
+// free rigid bodies (frames and accumulators of this substep in L): (I + h C) a = -(v x* I v + C v - f - f_g)
+template <class T, class M>
+MPPI_HD void step_free_bodies(M &m, SceneState<T> &s, const LMem &L, float h) {
+    constexpr int NB = T::NB;
+    for (int f = 0; f < kMaxFree; f++)
+        if (f < m.n_free) {
+            auto &F = m.fr[f];
+            float *rs = s.fr[f];
+            M3 R;
+            V3 p;
+            SV v;
+            frame_load(L, NB + 1 + f, R, p, v);
+            float fm = F.m, Ic6[6] = {F.Ic[0], 0.f, 0.f, F.Ic[1], 0.f, F.Ic[2]};
+            if (m.rnd_slot[F.actor] >= 0) {  // this sample's own mass and size
+                const ActorDraw dr = actor_draw<T>(m, F.actor, L);
+                fm *= dr.ms;
+                if (F.type == 1) {  // MPPI_ACTOR_BOX
+                    const float x = F.size[0] + dr.d[0], y = F.size[1] + dr.d[1], z = F.size[2] + dr.d[2];
+                    Ic6[0] = fm / 12.f * (y * y + z * z); Ic6[3] = fm / 12.f * (x * x + z * z); Ic6[5] = fm / 12.f * (x * x + y * y);
+                } else {  // sphere
+                    const float r = F.size[0] + dr.d[0];
+                    Ic6[0] = Ic6[3] = Ic6[5] = 0.4f * fm * r * r;
+                }
+            }
+            AI A;
+            SV pA;
+            V3 hw;
+            rigid_world(R, p, fm, V3{0.f, 0.f, 0.f}, Ic6, v, A, pA, hw);
+            SV fe;
+            AI C;
+            acc_load(L, SceneLayout<T>::kAcc, NB + 1 + f, fe, C);
+            const V3 g = F.gravity ? V3{m.g[0], m.g[1], m.g[2]} : V3{0.f, 0.f, 0.f};
+            SV Cv = mul(C, v);
+            pA = {pA.a + Cv.a - fe.a - cross(hw, g), pA.l + Cv.l - fe.l - fm * g};
+            A.I.xx += h * C.I.xx; A.I.xy += h * C.I.xy; A.I.xz += h * C.I.xz; A.I.yy += h * C.I.yy; A.I.yz += h * C.I.yz; A.I.zz += h * C.I.zz;
+            for (int j = 0; j < 9; j++) A.H[j] += h * C.H[j];
+            A.M.xx += h * C.M.xx; A.M.xy += h * C.M.xy; A.M.xz += h * C.M.xz; A.M.yy += h * C.M.yy; A.M.yz += h * C.M.yz; A.M.zz += h * C.M.zz;
+            SV rhs = {{-pA.a.x, -pA.a.y, -pA.a.z}, {-pA.l.x, -pA.l.y, -pA.l.z}};
+            root_integrate(rs, solve6(A, rhs), h);
+        }
+}
+
 // One simulator step of a contact scene (dt = substeps * h).  `root` carries the static actors.
 template <class T, int SPLIT = kSplitNone, class M = CModel>
 MPPI_HD void step_scene(M &m0, const float *root, SceneState<T> &s, const float *target, const LMem &L, Split split = Split{0, 1}) {
@@ -825,43 +872,7 @@ MPPI_HD void step_scene(M &m0, const float *root, SceneState<T> &s, const float 
             s.qd[i] = v;
         });
         if (m.floating) root_integrate(s.base, abase, h);
-        // free rigid bodies: (I + h C) a = -(v x* I v + C v - f - f_g)
-        for (int f = 0; f < kMaxFree; f++)
-            if (f < m.n_free) {
-                auto &F = m.fr[f];
-                float *rs = s.fr[f];
-                M3 R;
-                V3 p;
-                SV v;
-                frame_load(L, NB + 1 + f, R, p, v);
-                float fm = F.m, Ic6[6] = {F.Ic[0], 0.f, 0.f, F.Ic[1], 0.f, F.Ic[2]};
-                if (m.rnd_slot[F.actor] >= 0) {  // this sample's own mass and size
-                    const ActorDraw dr = actor_draw<T>(m, F.actor, L);
-                    fm *= dr.ms;
-                    if (F.type == 1) {  // MPPI_ACTOR_BOX
-                        const float x = F.size[0] + dr.d[0], y = F.size[1] + dr.d[1], z = F.size[2] + dr.d[2];
-                        Ic6[0] = fm / 12.f * (y * y + z * z); Ic6[3] = fm / 12.f * (x * x + z * z); Ic6[5] = fm / 12.f * (x * x + y * y);
-                    } else {  // sphere
-                        const float r = F.size[0] + dr.d[0];
-                        Ic6[0] = Ic6[3] = Ic6[5] = 0.4f * fm * r * r;
-                    }
-                }
-                AI A;
-                SV pA;
-                V3 hw;
-                rigid_world(R, p, fm, V3{0.f, 0.f, 0.f}, Ic6, v, A, pA, hw);
-                SV fe;
-                AI C;
-                acc_load(L, SceneLayout<T>::kAcc, NB + 1 + f, fe, C);
-                const V3 g = F.gravity ? V3{m.g[0], m.g[1], m.g[2]} : V3{0.f, 0.f, 0.f};
-                SV Cv = mul(C, v);
-                pA = {pA.a + Cv.a - fe.a - cross(hw, g), pA.l + Cv.l - fe.l - fm * g};
-                A.I.xx += h * C.I.xx; A.I.xy += h * C.I.xy; A.I.xz += h * C.I.xz; A.I.yy += h * C.I.yy; A.I.yz += h * C.I.yz; A.I.zz += h * C.I.zz;
-                for (int j = 0; j < 9; j++) A.H[j] += h * C.H[j];
-                A.M.xx += h * C.M.xx; A.M.xy += h * C.M.xy; A.M.xz += h * C.M.xz; A.M.yy += h * C.M.yy; A.M.yz += h * C.M.yz; A.M.zz += h * C.M.zz;
-                SV rhs = {{-pA.a.x, -pA.a.y, -pA.a.z}, {-pA.l.x, -pA.l.y, -pA.l.z}};
-                root_integrate(rs, solve6(A, rhs), h);
-            }
+        step_free_bodies<T>(m, s, L, h);
     }
 }
 
@@ -887,17 +898,11 @@ MPPI_HD float quat_yaw(const float *q) {
 // Stage cost of a contact scene.  BOXER_PUSH restates examples/boxer_push/planner.py:26-67:
 // link[0] = robot link (ee_link), actor[0] = block, actor[1] = goal, link[1], link[2] = rigid bodies of the
 // two obstacles; w = {robot_to_block, block_to_goal, block_to_goal_ort, push_align, velocity, collision, goal_yaw}.
+// core: R, r = world pose of link[0] (callers obtain it from their own kinematics)
 template <class T, class M>
-MPPI_HD float stage_cost_scene(M &m, CCost &c, const float *root, const SceneState<T> &s, const LMem &L) {
+MPPI_HD float stage_cost_scene_link(M &m, CCost &c, const float *root, const SceneState<T> &s, const LMem &L, const M3 &R, V3 r) {
     using Lay = SceneLayout<T>;
     if (c.kind == kCostBoxerPush) {
-        Pose<T> P;
-        P.pb = loadv(s.base);
-        P.Rb = quat_to_R(s.base + 3);
-        forward_kinematics_base<T>(m, s.q, P);
-        M3 R;
-        V3 r;
-        link_pose<T>(m, P, c.link[0], R, r);
         // block = free actor (looked up by actor id), goal = static actor
         float bx = 0.f, by = 0.f, bvx = 0.f, bvy = 0.f, byaw = 0.f;
         for (int f = 0; f < kMaxFree; f++)
@@ -915,30 +920,32 @@ MPPI_HD float stage_cost_scene(M &m, CCost &c, const float *root, const SceneSta
         const float vel = sqrtf(bvx * bvx + bvy * bvy);
         return c.w[0] * d_rb + c.w[1] * d_bg + c.w[2] * ort + c.w[3] * align + c.w[4] * vel + c.w[5] * coll;
     }
-    if (c.kind == kCostPandaPick) {
-        // examples/panda_pick/planner.py:24-53: link[0] = panda_ee, link[1] = table rigid body, actor[0] = block,
-        // actor[1] = goal; w = {robot_to_block, block_to_goal, collision, robot_ori}
-        Pose<T> P;
-        P.pb = loadv(s.base);
-        P.Rb = quat_to_R(s.base + 3);
+    // PANDA_PICK, examples/panda_pick/planner.py:24-53: link[0] = panda_ee, link[1] = table rigid body, actor[0] = block,
+    // actor[1] = goal; w = {robot_to_block, block_to_goal, collision, robot_ori}
+    V3 b = {0.f, 0.f, 0.f};
+    for (int f = 0; f < kMaxFree; f++)
+        if (f < m.n_free && m.fr[f].actor == c.actor[0]) b = loadv(s.fr[f]);
+    const V3 g = loadv(root + 13 * c.actor[1]);
+    const V3 drb = r - b, dbg = b - g;
+    const int ot = Lay::kCf + 3 * c.link[1];
+    const float forces = fabsf(L[ot]) + fabsf(L[ot + 1]) + fabsf(L[ot + 2]);
+    const float a0 = atan2f(R.a[7], -R.a[8]), a1 = asinf(clamp1(R.a[6]));  // see PANDA_REACH
+    return c.w[0] * sqrtf(dot(drb, drb)) + c.w[1] * sqrtf(dot(dbg, dbg)) + c.w[2] * forces + c.w[3] * sqrtf(a0 * a0 + a1 * a1);
+}
+
+template <class T, class M>
+MPPI_HD float stage_cost_scene(M &m, CCost &c, const float *root, const SceneState<T> &s, const LMem &L) {
+    Pose<T> P;
+    P.pb = loadv(s.base);
+    P.Rb = quat_to_R(s.base + 3);
+    if (c.kind == kCostBoxerPush || c.kind == kCostPandaPick) {
         forward_kinematics_base<T>(m, s.q, P);
         M3 R;
         V3 r;
         link_pose<T>(m, P, c.link[0], R, r);
-        V3 b = {0.f, 0.f, 0.f};
-        for (int f = 0; f < kMaxFree; f++)
-            if (f < m.n_free && m.fr[f].actor == c.actor[0]) b = loadv(s.fr[f]);
-        const V3 g = loadv(root + 13 * c.actor[1]);
-        const V3 drb = r - b, dbg = b - g;
-        const int ot = Lay::kCf + 3 * c.link[1];
-        const float forces = fabsf(L[ot]) + fabsf(L[ot + 1]) + fabsf(L[ot + 2]);
-        const float a0 = atan2f(R.a[7], -R.a[8]), a1 = asinf(clamp1(R.a[6]));  // see PANDA_REACH
-        return c.w[0] * sqrtf(dot(drb, drb)) + c.w[1] * sqrtf(dot(dbg, dbg)) + c.w[2] * forces + c.w[3] * sqrtf(a0 * a0 + a1 * a1);
+        return stage_cost_scene_link<T>(m, c, root, s, L, R, r);
     }
     // reach costs: the link pose comes from the sample's own (possibly floating) base
-    Pose<T> P;
-    P.pb = loadv(s.base);
-    P.Rb = quat_to_R(s.base + 3);
     if (c.kind == kCostPandaReach) forward_kinematics_base<T>(m, s.q, P);
     return stage_cost_pose<T>(m, c, root, s.q, P);
 }
