@@ -194,6 +194,7 @@ def main():
     # final state sanity (default workload): the closed loop must have moved the end effector to the goal
     world._materialise()
     dist_to_goal = None
+    final_root = [round(float(v), 4) for v in world._root_state[0, :, 0:3].reshape(-1).cpu().numpy()]  # actor positions: run-to-run sanity
     if args.workload == "panda_reach":
         ee = world.get_actor_link_by_name("panda", "panda_ee_tip")[0, 0:3].cpu().numpy()
         dist_to_goal = float(np.linalg.norm(ee - np.asarray(GOAL)))
@@ -239,7 +240,7 @@ def main():
                        "substeps": cfg.isaacgym.substeps, "closed_loop": True, "action_to_host_every_step": sync,
                        "parallelism": f"sample-shard x{world_size} ({backend} all-gather of the shard records)" if sharded else "single GPU",
                        "loop_hz": loop_hz, "env_steps_per_s": loop_hz * K * H * world_size,
-                       "final_ee_to_goal_m": dist_to_goal},
+                       "final_ee_to_goal_m": dist_to_goal, "final_actor_positions": final_root},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": kernel_name, "peak_measured": hbm_measured,
                          "kernel_ms": kms[0], "bytes_alg_per_launch": bytes_alg,

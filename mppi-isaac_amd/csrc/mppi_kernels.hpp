@@ -28,6 +28,7 @@
 #include "mppi_pack.hpp"
 #include "mppi_scene.hpp"
 #include "mppi_quad.hpp"
+#include "mppi_scene_quad.hpp"
 
 using namespace mppi;
 

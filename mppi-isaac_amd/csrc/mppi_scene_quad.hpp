@@ -1,0 +1,337 @@
+// mppi_scene_quad.hpp - contact-scene step with the articulated-body algebra split over the quad.
+//
+// k_rollout_scene_quad gives every sample a 4-lane quad.  The contact work was already dealt over the lanes
+// (mppi_scene.hpp, kSplitQuad); the robot's kinematics and articulated-body solve were still computed four times,
+// once per lane.  Here they use the quad layout of mppi_quad.hpp instead - lane r owns component (matrix row) r of
+// every 3-vector / 3x3 block, DPP quad_perm for the cross-lane traffic - which cuts their per-lane instruction
+// stream ~3x and their register footprint with it (the one-lane version spills: 256 VGPR + 256 AGPR + scratch).
+//
+// What changes against quad_aba (fixed base, no contact): per-frame external wrenches and implicit contact
+// dampings from the sample's LDS accumulators (lane r gathers ITS rows), explicit gravity, and a floating base
+// (the base's 6x6 system is gathered to all lanes and solved by the replicated Cholesky of mppi_scene.hpp).
+// Sample state (q, qd, base and free-body rows) stays replicated across the quad, as do the free-body solves.
+#pragma once
+#include "mppi_quad.hpp"
+#include "mppi_scene.hpp"
+
+namespace mppi {
+
+// ---- quad <-> per-sample LDS rows -----------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int R>
+__device__ __forceinline__ float qget(QF x) { return bc<R>(x); }
+// lane r reads / writes L[base + o_r]
+__device__ __forceinline__ QF qgather(const LMem &L, int base, int o0, int o1, int o2) {
+    const int r = quad_row();
+    return L[base + (r == 0 ? o0 : (r == 1 ? o1 : o2))];
+}
+__device__ __forceinline__ void qscatter(const LMem &L, int base, int o0, int o1, int o2, QF x) {
+    const int r = quad_row();
+    L[base + (r == 0 ? o0 : (r == 1 ? o1 : o2))] = x;
+}
+#else
+template <int R>
+inline float qget(QF x) { return x.v[R]; }
+inline QF qgather(const LMem &L, int base, int o0, int o1, int o2) { return QF{{L[base + o0], L[base + o1], L[base + o2], L[base + o0]}}; }
+inline void qscatter(const LMem &L, int base, int o0, int o1, int o2, QF x) {
+    L[base + o0] = x.v[0];
+    L[base + o1] = x.v[1];
+    L[base + o2] = x.v[2];
+}
+#endif
+
+// frame row block of mppi_scene.hpp: R[9] row-major, p[3], w[3], vO[3]
+MPPI_HD void qframe_store(const LMem &L, int ent, const QM3 &R, QF p, const QSV &v) {
+    const int o = ent * 18;
+    for (int c = 0; c < 3; c++) qscatter(L, o + c, 0, 3, 6, R.c[c]);  // lane r: R[r][c] -> o + 3r + c
+    qscatter(L, o + 9, 0, 1, 2, p);
+    qscatter(L, o + 12, 0, 1, 2, v.a);
+    qscatter(L, o + 15, 0, 1, 2, v.l);
+}
+
+constexpr int sym_index(int r, int c) {  // position of (r, c) in (xx, xy, xz, yy, yz, zz)
+    const int lo = r < c ? r : c, hi = r < c ? c : r;
+    return lo * 3 - lo * (lo - 1) / 2 + (hi - lo);
+}
+// external wrench and implicit damping of frame `ent` (accumulator rows of contact_forces) in the quad layout
+MPPI_HD void qacc_load(const LMem &L, int base, int ent, QSV &fe, QAI &C) {
+    const int o = base + ent * 27;
+    fe.a = qgather(L, o, 0, 1, 2);
+    fe.l = qgather(L, o + 3, 0, 1, 2);
+    for (int j = 0; j < 3; j++) {  // rotated rows: X[j] of lane r = X[r][(r + j) % 3]
+        const int c0 = j % 3, c1 = (1 + j) % 3, c2 = (2 + j) % 3;
+        C.I[j] = qgather(L, o + 6, sym_index(0, c0), sym_index(1, c1), sym_index(2, c2));
+        C.M[j] = qgather(L, o + 21, sym_index(0, c0), sym_index(1, c1), sym_index(2, c2));
+        C.H[j] = qgather(L, o + 12, 0 * 3 + c0, 1 * 3 + c1, 2 * 3 + c2);
+        C.Ht[j] = qgather(L, o + 12, c0 * 3 + 0, c1 * 3 + 1, c2 * 3 + 2);  // H^T[r][c] = H[c][r]
+    }
+}
+
+// replicated (one-lane layout) copy of a 6x6 kept in rotated rows, and of a distributed spatial vector
+MPPI_HD AI qai_gather(const QAI &X) {
+    AI A;
+    // entry (r, c) sits in lane r at rotation j = (c - r + 3) % 3
+    A.I = {qget<0>(X.I[0]), qget<0>(X.I[1]), qget<0>(X.I[2]), qget<1>(X.I[0]), qget<1>(X.I[1]), qget<2>(X.I[0])};
+    A.M = {qget<0>(X.M[0]), qget<0>(X.M[1]), qget<0>(X.M[2]), qget<1>(X.M[0]), qget<1>(X.M[1]), qget<2>(X.M[0])};
+    A.H[0] = qget<0>(X.H[0]); A.H[1] = qget<0>(X.H[1]); A.H[2] = qget<0>(X.H[2]);
+    A.H[3] = qget<1>(X.H[2]); A.H[4] = qget<1>(X.H[0]); A.H[5] = qget<1>(X.H[1]);
+    A.H[6] = qget<2>(X.H[1]); A.H[7] = qget<2>(X.H[2]); A.H[8] = qget<2>(X.H[0]);
+    return A;
+}
+MPPI_HD V3 qv3_gather(QF x) { return V3{qget<0>(x), qget<1>(x), qget<2>(x)}; }
+
+// rigid inertia about the world origin and velocity-product force of a body posed at (R, p) moving with v:
+// the block of quad_aba, shared by the bodies and the floating base
+template <class F>
+MPPI_HD void qrigid_world(const QM3 &R, QF p, float mass, const F *hb, const F *Ic, const QSV &v, QAI &A, QSV &pA, QF &h) {
+    h = R.c[0] * hb[0] + R.c[1] * hb[1] + R.c[2] * hb[2] + mass * p;
+    QF Tr[3];
+    Tr[0] = R.c[0] * Ic[0] + R.c[1] * Ic[1] + R.c[2] * Ic[2];
+    Tr[1] = R.c[0] * Ic[1] + R.c[1] * Ic[3] + R.c[2] * Ic[4];
+    Tr[2] = R.c[0] * Ic[2] + R.c[1] * Ic[4] + R.c[2] * Ic[5];
+    const float invm = mass > 0.f ? 1.f / mass : 0.f;
+    const QF cw = invm * h;
+    const QF hh = qsum(h * cw);
+    const QF h1 = rot1(h), h2 = rot2(h);
+    A.I[0] = Tr[0] * R.c[0] + Tr[1] * R.c[1] + Tr[2] * R.c[2] + hh - h * cw;
+    A.I[1] = Tr[0] * rot1(R.c[0]) + Tr[1] * rot1(R.c[1]) + Tr[2] * rot1(R.c[2]) - h * rot1(cw);
+    A.I[2] = Tr[0] * rot2(R.c[0]) + Tr[1] * rot2(R.c[1]) + Tr[2] * rot2(R.c[2]) - h * rot2(cw);
+    A.H[0] = qrep(0.f); A.H[1] = -h2;     A.H[2] = h1;   // skew(h), rotated rows
+    A.Ht[0] = A.H[0];  A.Ht[1] = h2;      A.Ht[2] = -h1;
+    A.M[0] = qrep(mass); A.M[1] = A.H[0]; A.M[2] = A.H[0];
+    const QF w = v.a, vl = v.l;
+    const QF n = A.I[0] * w + A.I[1] * rot1(w) + A.I[2] * rot2(w) + qcross(h, vl);
+    const QF f = mass * vl + qcross(w, h);
+    pA = {qcross(w, n) + qcross(vl, f), qcross(w, f)};
+}
+
+// gravity, contact wrench and implicit contact damping of one frame: (IA + h C) a + (pA + C v - f - f_g) = 0
+MPPI_HD void qexternal(const LMem &L, int acc_base, int ent, bool touched, float hstep, QF hmom, float mass, QF gq, const QSV &v, QAI &A,
+                       QSV &pA) {
+    pA.a = pA.a - qcross(hmom, gq);
+    pA.l = pA.l - mass * gq;
+    if (touched) {
+        QSV fe;
+        QAI C;
+        qacc_load(L, acc_base, ent, fe, C);
+        const QSV Cv = qmul(C, v);
+        pA = {pA.a + Cv.a - fe.a, pA.l + Cv.l - fe.l};
+        for (int j = 0; j < 3; j++) {
+            A.I[j] += hstep * C.I[j];
+            A.H[j] += hstep * C.H[j];
+            A.Ht[j] += hstep * C.Ht[j];
+            A.M[j] += hstep * C.M[j];
+        }
+    }
+}
+
+// Articulated-body solve of the robot inside a contact scene.  vbase / abase: spatial velocity / acceleration of the base
+// about the world origin (zero / unused for a fixed base).  `touched`: frames with non-zero accumulators.
+template <class T, class M>
+MPPI_HD void quad_aba_scene(M &m, const QPose<T> &P, const QSV &vbase, const QF *qd, const QF *tau_exp, const QF *kdh, const LMem &L,
+                            unsigned touched, QF *qdd, SV &abase, JointLimits *lim) {
+    constexpr int NB = T::NB;
+    constexpr int NBs = NB ? NB : 1;
+    using Lay = SceneLayout<T>;
+    QSV v[NBs], U[NBs], pacc[NBs + 1], cb[NBs];
+    QF Sl[NBs];
+    QAI acc[NBs + 1];
+    QF invd[NBs], u[NBs];
+    bool has_acc[NBs + 1];
+    const QF zero = qrep(0.f);
+    const float hstep = m.h;
+    const bool floating = m.floating != 0;
+    const QF gq = m.gravity_on ? qsel(m.g[0], m.g[1], m.g[2]) : zero;
+    static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
+        constexpr int i = ic;
+        constexpr int par = T::par[i];
+        const QSV S = quad_subspace<T, i>(P);
+        Sl[i] = S.l;
+        const QSV sj = {qd[i] * S.a, qd[i] * S.l};
+        const QSV vp = par < 0 ? vbase : v[par < 0 ? 0 : par];
+        v[i] = {vp.a + sj.a, vp.l + sj.l};
+        cb[i] = {qcross(vp.a, sj.a), qcross(vp.a, sj.l) + qcross(vp.l, sj.a)};
+        has_acc[i] = false;
+    });
+    has_acc[NB] = false;
+    BodyK1 blk[NBs];
+    static_rfor<0, NB>([&](auto ic) MPPI_LAMBDA { blk[ic] = load_block<BodyK1>(m.b[ic].k1); });
+    static_rfor<0, NB>([&](auto ic) MPPI_LAMBDA {
+        constexpr int i = ic;
+        constexpr int par = T::par[i];
+        const BodyK1 &b = blk[i];
+        lim[i] = {b.effort, b.lower, b.upper, b.vmax, b.limited};
+        const QSV S = {P.jt[i] == 0 ? P.R[i].c[2] : zero, Sl[i]};
+        QAI A;
+        QSV pA;
+        QF h;
+        qrigid_world(P.R[i], P.p[i], b.m, b.hb, b.Ic, v[i], A, pA, h);
+        qexternal(L, Lay::kAcc, i, (touched >> i) & 1u, hstep, h, b.m, gq, v[i], A, pA);
+        if (has_acc[i]) {
+            for (int j = 0; j < 3; j++) { A.I[j] += acc[i].I[j]; A.H[j] += acc[i].H[j]; A.Ht[j] += acc[i].Ht[j]; A.M[j] += acc[i].M[j]; }
+            pA = {pA.a + pacc[i].a, pA.l + pacc[i].l};
+        }
+        U[i] = qmul(A, S);
+        const QF d = qdot6(S, U[i]) + kdh[i];
+        invd[i] = qrcp(d);
+        u[i] = tau_exp[i] - qdot6(S, pA);
+        constexpr int pj = par < 0 ? NB : par;  // the base accumulator lives at index NB
+        if (par >= 0 || floating) {
+            const QSV c = cb[i];
+            const QSV Ac = qmul(A, c);
+            const QF k = (u[i] - qdot6(U[i], c)) * invd[i];
+            const QSV pa = {pA.a + Ac.a + k * U[i].a, pA.l + Ac.l + k * U[i].l};
+            const QF un = U[i].a * invd[i], uf = U[i].l * invd[i];
+            const QF n1 = rot1(U[i].a), n2 = rot2(U[i].a), f1 = rot1(U[i].l), f2 = rot2(U[i].l);
+            A.I[0] -= un * U[i].a; A.I[1] -= un * n1; A.I[2] -= un * n2;
+            A.H[0] -= un * U[i].l; A.H[1] -= un * f1; A.H[2] -= un * f2;
+            A.Ht[0] -= uf * U[i].a; A.Ht[1] -= uf * n1; A.Ht[2] -= uf * n2;
+            A.M[0] -= uf * U[i].l; A.M[1] -= uf * f1; A.M[2] -= uf * f2;
+            if (has_acc[pj]) {
+                for (int j = 0; j < 3; j++) { acc[pj].I[j] += A.I[j]; acc[pj].H[j] += A.H[j]; acc[pj].Ht[j] += A.Ht[j]; acc[pj].M[j] += A.M[j]; }
+                pacc[pj] = {pacc[pj].a + pa.a, pacc[pj].l + pa.l};
+            } else {
+                acc[pj] = A;
+                pacc[pj] = pa;
+                has_acc[pj] = true;
+            }
+        }
+    });
+    abase = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    QSV a0 = {zero, zero};
+    if (floating) {
+        QAI A;
+        QSV pA;
+        QF h;
+        qrigid_world(P.Rb, P.pb, m.base_m, m.base_hb, m.base_Ic, vbase, A, pA, h);
+        qexternal(L, Lay::kAcc, NB, (touched >> NB) & 1u, hstep, h, m.base_m, gq, vbase, A, pA);
+        if (has_acc[NB]) {
+            for (int j = 0; j < 3; j++) { A.I[j] += acc[NB].I[j]; A.H[j] += acc[NB].H[j]; A.Ht[j] += acc[NB].Ht[j]; A.M[j] += acc[NB].M[j]; }
+            pA = {pA.a + pacc[NB].a, pA.l + pacc[NB].l};
+        }
+        // the base's 6x6 system, gathered to every lane and solved by the replicated Cholesky
+        const V3 na = qv3_gather(pA.a), nl = qv3_gather(pA.l);
+        abase = solve6(qai_gather(A), SV{{-na.x, -na.y, -na.z}, {-nl.x, -nl.y, -nl.z}});
+        a0 = {qsel(abase.a.x, abase.a.y, abase.a.z), qsel(abase.l.x, abase.l.y, abase.l.z)};
+    }
+    QSV a[NBs];
+    static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
+        constexpr int i = ic;
+        constexpr int par = T::par[i];
+        const QSV S = {P.jt[i] == 0 ? P.R[i].c[2] : zero, Sl[i]};
+        const QSV apar = par < 0 ? a0 : a[par < 0 ? 0 : par];
+        const QSV ap = {apar.a + cb[i].a, apar.l + cb[i].l};
+        const QF dd = (u[i] - qdot6(U[i], ap)) * invd[i];
+        qdd[i] = dd;
+        a[i] = {ap.a + dd * S.a, ap.l + dd * S.l};
+    });
+}
+
+// base pose of the sample (its own root row) and the robot's kinematics, distributed over the quad
+template <class T, class M>
+MPPI_HD void quad_scene_pose(M &m, const SceneState<T> &s, QPose<T> &P) {
+    const M3 Rb = quat_to_R(s.base + 3);
+    P.pb = qsel(s.base[0], s.base[1], s.base[2]);
+    for (int c = 0; c < 3; c++) P.Rb.c[c] = qsel(Rb.a[c], Rb.a[3 + c], Rb.a[6 + c]);
+    QF q[T::NB ? T::NB : 1];
+    static_for<0, T::NB>([&](auto ic) MPPI_LAMBDA { q[ic] = qrep(s.q[ic]); });
+    quad_fk<T>(m, q, P);
+}
+
+// One simulator step of a contact scene, quad layout for the robot (same physics as step_scene).
+template <class T, int SPLIT, class M>
+MPPI_HD void step_scene_quad(M &m0, const float *root, SceneState<T> &s, const float *target, const LMem &L, Split split) {
+    constexpr int NB = T::NB;
+    constexpr int NBs = NB ? NB : 1;
+    M *mp = &m0;
+    for (int sub = 0; sub < m0.substeps; sub++) {
+        M &m = *launder(mp);
+        const float h = m.h, kd = m.kd;
+        QPose<T> P;
+        quad_scene_pose<T>(m, s, P);
+        QSV vbase = {qrep(0.f), qrep(0.f)};
+        if (m.floating) {
+            const QF wb = qsel(s.base[10], s.base[11], s.base[12]), vb = qsel(s.base[7], s.base[8], s.base[9]);
+            vbase = {wb, vb - qcross(wb, P.pb)};
+        }
+        QF qd[NBs];
+        static_for<0, NB>([&](auto ic) MPPI_LAMBDA { qd[ic] = qrep(s.qd[ic]); });
+        {  // dynamic frames into the sample's LDS rows: each lane writes its own matrix rows / vector components
+            QSV v[NBs];
+            static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
+                constexpr int i = ic;
+                constexpr int par = T::par[i];
+                const QSV S = quad_subspace<T, i>(P);
+                const QSV vp = par < 0 ? vbase : v[par < 0 ? 0 : par];
+                v[i] = {vp.a + qd[i] * S.a, vp.l + qd[i] * S.l};
+                qframe_store(L, i, P.R[i], P.p[i], v[i]);
+            });
+            qframe_store(L, NB, P.Rb, P.pb, vbase);
+            for (int f = 0; f < kMaxFree; f++)
+                if (f < m.n_free) {
+                    const float *rs = s.fr[f];
+                    V3 p = loadv(rs), w = loadv(rs + 10), vl = loadv(rs + 7);
+                    frame_store(L, NB + 1 + f, quat_to_R(rs + 3), p, SV{w, vl - cross(w, p)});
+                }
+        }
+        const unsigned touched = contact_forces<T, SPLIT>(m, root, L, split);
+        QF tau[NBs], kdh[NBs], qdd[NBs], ff[NBs], vs[NBs];
+        JointLimits lim[NBs];
+        const int drive_mode = m.drive_mode;
+        static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
+            constexpr int i = ic;
+            ff[i] = qrep(drive_mode == kDriveEffort ? target[i] : 0.f);
+            vs[i] = qrep(drive_mode == kDriveVelocity ? target[i] : 0.f);
+            tau[i] = ff[i] + kd * (vs[i] - qd[i]);
+            kdh[i] = qrep(kd * h);
+        });
+        SV abase;
+        quad_aba_scene<T>(m, P, vbase, qd, tau, kdh, L, touched, qdd, abase, lim);
+        bool any = false;
+        static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
+            constexpr int i = ic;
+            const QF tt = ff[i] + kd * (vs[i] - qd[i] - h * qdd[i]);
+            const QF eff = qrep(lim[i].effort);
+            if (qany_gt(qabs(tt), eff)) {  // (no limit: eff = +inf)
+                any = true;
+                tau[i] = qwhere_gt(tt, qrep(0.f), eff, -eff);
+                kdh[i] = qrep(0.f);
+            }
+        });
+        if (any) quad_aba_scene<T>(*launder(mp), P, vbase, qd, tau, kdh, L, touched, qdd, abase, lim);
+        static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
+            constexpr int i = ic;
+            const JointLimits b = lim[i];
+            QF v = qd[i] + h * qdd[i];
+            v = qclamp(v, qrep(-b.vmax), qrep(b.vmax));
+            QF x = qrep(s.q[i]) + h * v;
+            const QF lo = qrep(b.lower), hi = qrep(b.upper), z = qrep(0.f);
+            v = qclamp(v, qwhere_lt(x, lo, z, qrep(-INFINITY)), qwhere_gt(x, hi, z, qrep(INFINITY)));
+            x = qclamp(x, lo, hi);
+            s.q[i] = qlane0(x);
+            s.qd[i] = qlane0(v);
+        });
+        if (m.floating) root_integrate(s.base, abase, h);
+        step_free_bodies<T>(m, s, L, h);
+    }
+}
+
+// stage cost of a contact scene with the link pose taken from the quad kinematics
+template <class T, class M>
+MPPI_HD float stage_cost_scene_quad(M &m, CCost &c, const float *root, const SceneState<T> &s, const LMem &L) {
+    if (c.kind != kCostBoxerPush && c.kind != kCostPandaPick) return stage_cost_scene<T>(m, c, root, s, L);
+    QPose<T> P;
+    quad_scene_pose<T>(m, s, P);
+    QM3 Rq;
+    QF pq;
+    quad_link_pose<T>(m, P, c.link[0], Rq, pq);
+    M3 R;
+    for (int cc = 0; cc < 3; cc++) {
+        R.a[cc] = qget<0>(Rq.c[cc]);
+        R.a[3 + cc] = qget<1>(Rq.c[cc]);
+        R.a[6 + cc] = qget<2>(Rq.c[cc]);
+    }
+    return stage_cost_scene_link<T>(m, c, root, s, L, R, qv3_gather(pq));
+}
+
+}  // namespace mppi

@@ -9,6 +9,7 @@
 #include "../../mppi-isaac_amd/csrc/mppi_pack.hpp"
 #include "../../mppi-isaac_amd/csrc/mppi_scene.hpp"
 #include "../../mppi-isaac_amd/csrc/mppi_quad.hpp"
+#include "../../mppi-isaac_amd/csrc/mppi_scene_quad.hpp"
 
 using namespace mppi;
 
@@ -114,7 +115,7 @@ int emu_scene_step_g(const mppi_model_t *model, float *dof, float *root, const f
         cmd_map<T>(m, uu, target);
         if (g_scene_split > 1) {
             shape_cache_update<T>(m, root, L, Split{0, 1}, true);
-            step_scene<T, kSplitEmulate>(m, root, s, target, L, Split{0, g_scene_split});
+            step_scene_quad<T, kSplitEmulate>(m, root, s, target, L, Split{0, g_scene_split});
         }
         else step_scene<T>(m, root, s, target, L);
         for (int i = 0; i < T::NB; i++) { dof[2 * i] = s.q[i]; dof[2 * i + 1] = s.qd[i]; }
