@@ -30,9 +30,13 @@ def test_jackal_yaml_as_shipped_is_rejected():
         build_scene(["jackal", "goal"], [[0.0, 0.0, 0.1]])
 
 
+@pytest.mark.parametrize("split", [1, 4])
 @pytest.mark.parametrize("name", sorted(CASES))
-def test_step_parity(name, hostemu, oracle64):
+def test_step_parity(name, split, hostemu, oracle64):
+    """split = 4: the arithmetic of k_rollout_scene_quad on the host (contact points dealt over an emulated quad, robot
+    kinematics and articulated-body solve in the quad layout incl. the gathered floating-base system for albert)"""
     actors, init, nu, umax = CASES[name]
+    hostemu.emu_set_scene_split(split)
     scene = build_scene(actors, init, robot_overrides=JACKAL_WHEELS if name == "jackal" else None)
     m = scene.to_c()
     assert scene.nu == nu
@@ -65,6 +69,7 @@ def test_step_parity(name, hostemu, oracle64):
         lim = np.array([bool(m.bodies[i].limited) for i in range(scene.n_dof)])
         free = ~(lim & ((np.abs(q - lo) < 1e-5) | (np.abs(q - hi) < 1e-5)))
         np.testing.assert_allclose(de[1::2][free], qd[free], atol=5e-3)
+    hostemu.emu_set_scene_split(1)
     assert np.isfinite(q).all() and np.isfinite(ro).all()
 
 
