@@ -9,6 +9,9 @@ Semantics: SURVEY.md section A (build-normative; mppi_torch itself is not in the
 """
 from __future__ import annotations
 
+import ctypes as C
+import os
+import warnings
 from dataclasses import dataclass, field
 from typing import Callable, List, Optional
 
@@ -193,7 +196,6 @@ class MPPIPlanner:
         if cfg.filter_u:
             F = np.ascontiguousarray(savgol_matrix(self.T), np.float32)
             capi.check(self._lib, self._lib.mppi_set_filter(self._ctx, capi.fptr(F)))
-        import os
         self._graph, self._graph_sig, self._graph_viz = None, None, []
         self._graph_state = "off" if os.environ.get("MPPI_GENERIC_GRAPH", "1") == "0" else "on"
         self._external_noise = None
@@ -307,7 +309,6 @@ class MPPIPlanner:
                 self.sim.visualize_link_buffer = []
                 capi.check(lib, lib.mppi_sim_reset(ctx))
             except Exception as e:  # not capturable: keep the reference loop shape
-                import warnings
                 warnings.warn(f"generic Objective horizon is not graph-capturable ({type(e).__name__}: {e}); running it eagerly")
                 self._graph, self._graph_state = None, "off"
                 torch.cuda.synchronize()
@@ -323,9 +324,6 @@ class MPPIPlanner:
         S = np.zeros(self.K, np.float32)
         capi.check(self._lib, self._lib.mppi_get_costs(self._ctx, capi.fptr(S)))
         return torch.from_numpy(S)
-
-
-import ctypes as C  # noqa: E402
 
 
 def C_void(t: torch.Tensor):
