@@ -13,10 +13,9 @@ listeners and line drawing are graphics and out of scope.
 from __future__ import annotations
 
 import ctypes
-import os
 from dataclasses import dataclass, field
 from enum import Enum
-from typing import Dict, List, Optional
+from typing import List, Optional
 
 import numpy as np
 import torch

@@ -12,7 +12,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import warnings
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Callable, List, Optional
 
 import numpy as np
