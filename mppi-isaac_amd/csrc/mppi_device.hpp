@@ -82,13 +82,29 @@ struct DevShape {
     float mu;
     float R[9], p[3];
 };
-struct DevPair {
-    int a, b;       // shapes; b = -1: ground plane
-    int mode;       // 0: both dynamic (explicit penalty), 1: a dynamic / b static (implicit), 2: b dynamic / a static
-    int rnd;        // a noisy actor takes part: friction / mass scale are per sample
+// One candidate pair = two 64-byte blocks.  The broad phase needs block g only (one s_load_dwordx16: shape ids for the
+// pose cache, types, half extents - no dependent loads of the two shape records); block c (contact law, noise lookup)
+// is fetched for the pairs that survive it.
+struct PairGeom {
+    int a, b;        // shapes; b = -1: ground plane
+    int mode;        // 0: both dynamic (explicit penalty), 1: a dynamic / b static (implicit), 2: b dynamic / a static
+    int rnd;         // a noisy actor takes part: size / friction / mass scale are per sample
+    int typeA, typeB, entA, entB;  // MPPI_SHAPE_* (typeB = -1: ground), dynamic frame (-1: static)
+    float hA[3], hB[3];            // nominal half extents | radius in [0]
+    int rbA, rbB;                  // rigid-body rows for net_contact_force
+};
+struct PairGain {
     float mu, k, cn, ct;  // combined friction, stiffness and damping per contact point
     float kh;             // k * h (implicit spring term of static contacts)
     float ma, mb, mub;    // nominal masses of the reacting actors (-1: static) and the ground friction for b = -1
+    int actorA, actorB;   // actors of the two shapes (rows of the per-sample noise draws)
+    int robotA, robotB;   // the shape belongs to the robot (never noisy; keeps its own per-shape friction)
+    float muA, muB;       // per-shape friction
+    int pad[2];
+};
+struct DevPair {
+    PairGeom g;
+    PairGain c;
 };
 struct DevFree {
     int actor, rb, gravity, type;

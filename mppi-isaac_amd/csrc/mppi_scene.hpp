@@ -465,67 +465,51 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, Split sp
     constexpr bool kCached = SPLIT != kSplitNone;
     if constexpr (kCached) shape_cache_update<T>(m, root, L, SPLIT == kSplitEmulate ? Split{0, 1} : split, false);
     for (int ip = 0; ip < m.n_pairs; ip++) {
-        auto &Pm = m.pr[ip];
-        auto &A = m.sh[Pm.a];
-        ShapeW wa;
-        if constexpr (kCached) wa = shape_cached<T>(m, Pm.a, L);
-        else wa = shape_world(A, root, L);
-        Gains P = {Pm.mode, Pm.mu, Pm.k, Pm.cn, Pm.ct, Pm.kh};
-        float hA[3] = {A.half[0], A.half[1], A.half[2]}, hB[3] = {0.f, 0.f, 0.f};
-        if (Pm.rnd) {  // this sample's own size / friction / mass of the noisy actors in the pair
-            const bool ra = A.src_actor == m.robot_actor;
-            const ActorDraw da = actor_draw<T>(m, A.src_actor, L);
-            if (!ra) {
-                if (A.type == 0) for (int j = 0; j < 3; j++) hA[j] += 0.5f * da.d[j];
-                else if (A.type == 1) hA[0] += da.d[0];
-            }
-            const float mua = ra ? A.mu : da.mu;
-            float mub = Pm.mub, sb = 1.f;
-            if (Pm.b >= 0) {
-                auto &Bs = m.sh[Pm.b];
-                const bool rbt = Bs.src_actor == m.robot_actor;
-                const ActorDraw db = actor_draw<T>(m, Bs.src_actor, L);
-                mub = rbt ? Bs.mu : db.mu;
-                sb = db.ms;
-                if (!rbt) {
-                    if (Bs.type == 0) for (int j = 0; j < 3; j++) hB[j] = 0.5f * db.d[j];
-                    else if (Bs.type == 1) hB[0] = db.d[0];
-                }
-            }
-            P.mu = fminf(mua, mub);
-            const float ma = Pm.ma * da.ms, mb = Pm.mb * sb;
-            const float meff0 = Pm.mode == 0 ? Pm.ma * Pm.mb / (Pm.ma + Pm.mb) : (Pm.mode == 1 ? Pm.ma : Pm.mb);
-            const float meff = Pm.mode == 0 ? ma * mb / (ma + mb) : (Pm.mode == 1 ? ma : mb);
-            const float sc = meff / meff0;
-            P.k *= sc; P.cn *= sc; P.ct *= sc; P.kh *= sc;
+        // geometry block of the pair: all the broad phase needs (no dependent loads of the two shape records)
+        const PairGeom G = load_block<PairGeom>(m.pr[ip].g);
+        const bool has_b = G.b >= 0;
+        ShapeW wa, wb;
+        if constexpr (kCached) {
+            wa = shape_cached<T>(m, G.a, L);
+            if (has_b) wb = shape_cached<T>(m, G.b, L);
+        } else {
+            wa = shape_world(m.sh[G.a], root, L);
+            if (has_b) wb = shape_world(m.sh[G.b], root, L);
         }
-        PairAcc acc;
-        pair_zero(acc);
-        int rbB = -1, entB = -1;
-        ShapeW wb;
-        if (Pm.b >= 0) {
-            auto &B = m.sh[Pm.b];
-            if constexpr (kCached) wb = shape_cached<T>(m, Pm.b, L);
-            else wb = shape_world(B, root, L);
-            rbB = B.rb;
-            entB = B.ent;
-            for (int j = 0; j < 3; j++) hB[j] += B.half[j];  // (+ this sample's delta from above)
+        float hA[3] = {G.hA[0], G.hA[1], G.hA[2]}, hB[3] = {G.hB[0], G.hB[1], G.hB[2]};
+        ActorDraw da = {{0.f, 0.f, 0.f}, 1.f, 0.f}, db = {{0.f, 0.f, 0.f}, 1.f, 0.f};
+        bool robotA = true, robotB = true;
+        if (G.rnd) {  // this sample's own size of the noisy actors in the pair (friction and mass scale: see below)
+            auto &Cn = m.pr[ip].c;
+            robotA = Cn.robotA != 0;
+            robotB = Cn.robotB != 0 || !has_b;
+            if (!robotA) {
+                da = actor_draw<T>(m, Cn.actorA, L);
+                if (G.typeA == 0) for (int j = 0; j < 3; j++) hA[j] += 0.5f * da.d[j];
+                else if (G.typeA == 1) hA[0] += da.d[0];
+            }
+            if (!robotB) {
+                db = actor_draw<T>(m, Cn.actorB, L);
+                if (G.typeB == 0) for (int j = 0; j < 3; j++) hB[j] += 0.5f * db.d[j];
+                else if (G.typeB == 1) hB[0] += db.d[0];
+            }
         }
-        const int typeB = Pm.b >= 0 ? m.sh[Pm.b].type : -1;
-        // Broad phase: bounding sphere of one shape against the other shape's box grown by that radius (both ways).
-        // Conservative by construction (a margin covers rounding), so skipping changes no result; it removes the
-        // 2 x 26 feature-point tests of the many link-vs-table / link-vs-block pairs that are nowhere near each other.
+        const int typeA = G.typeA, typeB = G.typeB, rbB = G.rbB, entB = G.entB;
+        // Broad phase: six-axis SAT for two boxes, otherwise the bounding sphere of one shape against the other shape's
+        // box grown by that radius (both ways).  Conservative by construction (a margin covers rounding), so skipping
+        // changes no result; it removes the 2 x 26 feature-point tests of the many link-vs-table / link-vs-block
+        // pairs that are nowhere near each other.
         bool apart = false;
         BoxRel rel;
-        if (Pm.b >= 0 && A.type == 0 && typeB == 0) {
+        if (has_b && typeA == 0 && typeB == 0) {
             rel = box_relative(wa, wb);
             apart = boxes_apart(rel, hA, hB, 1e-4f);
         } else {
             constexpr float kMargin = 1e-4f;
-            const float rA = A.type == 0 ? sqrtf(hA[0] * hA[0] + hA[1] * hA[1] + hA[2] * hA[2]) : hA[0];
-            if (Pm.b < 0) {
-                apart = A.type != 2 && wa.p.z > rA + kMargin;
-            } else if (A.type != 2 && typeB != 2) {
+            const float rA = typeA == 0 ? sqrtf(hA[0] * hA[0] + hA[1] * hA[1] + hA[2] * hA[2]) : hA[0];
+            if (!has_b) {
+                apart = typeA != 2 && wa.p.z > rA + kMargin;
+            } else if (typeA != 2 && typeB != 2) {
                 const float rB = typeB == 0 ? sqrtf(hB[0] * hB[0] + hB[1] * hB[1] + hB[2] * hB[2]) : hB[0];
                 const V3 d = wa.p - wb.p;
                 if (typeB == 0) {
@@ -535,7 +519,7 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, Split sp
                 } else {
                     apart = dot(d, d) > (rA + rB + kMargin) * (rA + rB + kMargin);
                 }
-                if (A.type == 0) {
+                if (typeA == 0) {
                     const V3 x = {wa.R.a[0] * d.x + wa.R.a[3] * d.y + wa.R.a[6] * d.z, wa.R.a[1] * d.x + wa.R.a[4] * d.y + wa.R.a[7] * d.z,
                                   wa.R.a[2] * d.x + wa.R.a[5] * d.y + wa.R.a[8] * d.z};
                     apart = apart || fabsf(x.x) > hA[0] + rB + kMargin || fabsf(x.y) > hA[1] + rB + kMargin || fabsf(x.z) > hA[2] + rB + kMargin;
@@ -543,21 +527,36 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, Split sp
             }
         }
         if (apart) continue;
+        // contact law of the survivors: second block of the pair
+        const PairGain Cg = load_block<PairGain>(m.pr[ip].c);
+        Gains P = {G.mode, Cg.mu, Cg.k, Cg.cn, Cg.ct, Cg.kh};
+        if (G.rnd) {  // per-sample friction (min of the two) and contact gains scaled with the per-sample reacting mass
+            const float mua = robotA ? Cg.muA : da.mu;
+            const float mub = !has_b ? Cg.mub : (robotB ? Cg.muB : db.mu);
+            P.mu = fminf(mua, mub);
+            const float ma = Cg.ma * da.ms, mb = Cg.mb * db.ms;
+            const float meff0 = G.mode == 0 ? Cg.ma * Cg.mb / (Cg.ma + Cg.mb) : (G.mode == 1 ? Cg.ma : Cg.mb);
+            const float meff = G.mode == 0 ? ma * mb / (ma + mb) : (G.mode == 1 ? ma : mb);
+            const float sc = meff / meff0;
+            P.k *= sc; P.cn *= sc; P.ct *= sc; P.kh *= sc;
+        }
+        PairAcc acc;
+        pair_zero(acc);
         if constexpr (kCached) {  // the cache holds poses only: velocities of the few pairs that get here
-            wa.v = frame_velocity(L, A.ent);
-            if (Pm.b >= 0) wb.v = frame_velocity(L, entB);
+            wa.v = frame_velocity(L, G.entA);
+            if (has_b) wb.v = frame_velocity(L, entB);
         }
         auto points = [&](Split sp, PairAcc &out) MPPI_LAMBDA {
-            if (Pm.b < 0) {  // ground plane z = 0, normal +z (from ground to A)
+            if (!has_b) {  // ground plane z = 0, normal +z (from ground to A)
                 const V3 ez = {0.f, 0.f, 1.f};
-                if (A.type == 0) {
+                if (typeA == 0) {
                     for (int c = sp.sub; c < 8; c += sp.n) {
                         V3 loc = {(c & 1) ? hA[0] : -hA[0], (c & 2) ? hA[1] : -hA[1], (c & 4) ? hA[2] : -hA[2]};
                         V3 pw = wa.p + mul(wa.R, loc);
                         if (pw.z < 0.f) contact_point(P, pw, ez, -pw.z, wa.v, zero, out);
                     }
                 } else if (sp.sub == 0) {
-                    if (A.type == 1) {
+                    if (typeA == 1) {
                         V3 pw = {wa.p.x, wa.p.y, wa.p.z - hA[0]};
                         if (pw.z < 0.f) contact_point(P, pw, ez, -pw.z, wa.v, zero, out);
                     } else {  // disc: lowest point of the rim, axis = local z
@@ -570,7 +569,7 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, Split sp
                         }
                     }
                 }
-            } else if (A.type == 0 && typeB == 0) {
+            } else if (typeA == 0 && typeB == 0) {
                 // A's points in B: centre t, columns of Rrel; B's points in A: centre -Rrel^T t, columns = rows of Rrel
                 const V3 colA[3] = {{hA[0] * rel.R[0], hA[0] * rel.R[3], hA[0] * rel.R[6]}, {hA[1] * rel.R[1], hA[1] * rel.R[4], hA[1] * rel.R[7]},
                                     {hA[2] * rel.R[2], hA[2] * rel.R[5], hA[2] * rel.R[8]}};
@@ -581,8 +580,8 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, Split sp
                                     {hB[2] * rel.R[6], hB[2] * rel.R[7], hB[2] * rel.R[8]}};
                 box_points_in_box(P, tb, colB, wa, hA, -1.f, wa.v, wb.v, sp, out);
             } else if (sp.sub == 0) {
-                if (A.type == 1 && typeB == 0) sphere_in_box(P, wa.p, hA[0], wb, hB, 1.f, wa.v, wb.v, out);
-                else if (A.type == 0 && typeB == 1) sphere_in_box(P, wb.p, hB[0], wa, hA, -1.f, wa.v, wb.v, out);
+                if (typeA == 1 && typeB == 0) sphere_in_box(P, wa.p, hA[0], wb, hB, 1.f, wa.v, wb.v, out);
+                else if (typeA == 0 && typeB == 1) sphere_in_box(P, wb.p, hB[0], wa, hA, -1.f, wa.v, wb.v, out);
             }
         };
         if constexpr (SPLIT == kSplitEmulate) {
@@ -602,18 +601,18 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, Split sp
         }
         if (acc.any) {
             const SV neg = {{-acc.f.a.x, -acc.f.a.y, -acc.f.a.z}, {-acc.f.l.x, -acc.f.l.y, -acc.f.l.z}};
-            if (Pm.mode == 0) {
-                touched |= (1u << A.ent) | (1u << entB);
-                acc_add(L, Lay::kAcc, A.ent, acc.f, nullptr);
+            if (G.mode == 0) {
+                touched |= (1u << G.entA) | (1u << entB);
+                acc_add(L, Lay::kAcc, G.entA, acc.f, nullptr);
                 acc_add(L, Lay::kAcc, entB, neg, nullptr);
-            } else if (Pm.mode == 1) {
-                touched |= 1u << A.ent;
-                acc_add(L, Lay::kAcc, A.ent, acc.f, &acc.C);
+            } else if (G.mode == 1) {
+                touched |= 1u << G.entA;
+                acc_add(L, Lay::kAcc, G.entA, acc.f, &acc.C);
             } else {
                 touched |= 1u << entB;
                 acc_add(L, Lay::kAcc, entB, neg, &acc.C);
             }
-            const int ocf = Lay::kCf + 3 * A.rb;
+            const int ocf = Lay::kCf + 3 * G.rbA;
             L[ocf] += acc.rep.x; L[ocf + 1] += acc.rep.y; L[ocf + 2] += acc.rep.z;
             if (rbB >= 0) {
                 const int ob = Lay::kCf + 3 * rbB;
