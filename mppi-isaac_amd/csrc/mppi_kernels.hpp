@@ -329,7 +329,7 @@ __global__ __launch_bounds__(kWave) void k_rollout_scene(const DevModel *__restr
     const LMem L{lds + threadIdx.x, kWave};  // lane-minor rows: conflict-free ds_read/ds_write
     float s = INFINITY;
     if (live) {
-        s = rollout_scene<T>(*(CModel *)m, *(CCfg *)cfg, *(CCost *)cost, x0_dof, x0_root, U, eps, prior, du, viz, k, L);
+        s = rollout_scene<T>(*(CModel *)m, *(CModel *)m, *(CCfg *)cfg, *(CCost *)cost, x0_dof, x0_root, U, eps, prior, du, viz, k, L);
         S[k] = s;
     }
     wave_record(*(CCfg *)cfg, s, live, du, k, partials + (size_t)blockIdx.x * (2 + cfg->H * cfg->nu));
@@ -348,8 +348,14 @@ __global__ __launch_bounds__(kWave) void k_rollout_scene_quad(const DevModel *__
                                                               float *__restrict__ partials) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    // (staging the model in LDS as k_rollout_quad does was measured slower here: the constants then occupy VGPRs of a
-    // kernel that already spills - boxer 1.63 -> 1.73 ms, gripper scene 5.09 -> 6.39 ms, scratch 404 -> 972 B/lane)
+    // The robot part of the model (header, bodies, links: 4.3 KB) is staged in LDS for the quad-layout kinematics and
+    // articulated-body solve; shapes, pairs and free bodies stay behind the scalar cache (staging the WHOLE model was
+    // measured slower: the contact loop's constants then occupy VGPRs of code that already spills)
+    constexpr int kModelBytes = (int)((offsetof(DevModel, fr) + 15) / 16 * 16);
+    __shared__ __attribute__((aligned(64))) uint4 s_model[kModelBytes / 16];
+    for (int i = threadIdx.x; i < kModelBytes / 16; i += kWave) s_model[i] = reinterpret_cast<const uint4 *>(m)[i];
+    __syncthreads();
+    LModel &lm = *(LModel *)s_model;
     const int nb = gridDim.x;  // XCD-aware chunk mapping as in k_rollout_quad
     const int chunk = (nb % 16 == 0) ? (int)(blockIdx.x % 8) * (nb / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
     const int k = chunk * 16 + (threadIdx.x >> 2);
@@ -358,7 +364,7 @@ __global__ __launch_bounds__(kWave) void k_rollout_scene_quad(const DevModel *__
     const LMem L{lds + (threadIdx.x >> 2), 16};
     float s = INFINITY;
     if (live) {
-        s = rollout_scene<T, kSplitQuad>(*(CModel *)m, *(CCfg *)cfg, *(CCost *)cost, x0_dof, x0_root, U, eps, prior, du, viz, k, L, Split{lane4, 4});
+        s = rollout_scene<T, kSplitQuad>(*(CModel *)m, lm, *(CCfg *)cfg, *(CCost *)cost, x0_dof, x0_root, U, eps, prior, du, viz, k, L, Split{lane4, 4});
         if (lane4 == 0) S[k] = s;
     }
     wave_record(*(CCfg *)cfg, s, live && lane4 == 0, du, k, partials + (size_t)chunk * (2 + cfg->H * cfg->nu));

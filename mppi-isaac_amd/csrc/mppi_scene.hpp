@@ -97,6 +97,10 @@ struct SceneState {
     float q[T::NB ? T::NB : 1], qd[T::NB ? T::NB : 1];
     float base[13];           // robot root row: pos, quat xyzw, linvel, angvel
     float fr[kMaxFree][13];   // free actors' root rows
+    // accumulator rows (per dynamic frame) and net-contact-force rows (per rigid body, when there are <= 32 of them)
+    // that the previous contact pass wrote: only those are cleared by the next pass.  All ones = "clear everything"
+    // (fresh LDS: start of a rollout, every launch of the step kernels).
+    unsigned acc_dirty = ~0u, cf_dirty = ~0u;
 };
 
 MPPI_HD V3 vel_at(const SV &v, V3 p) { return v.l + cross(v.a, p); }
@@ -457,10 +461,19 @@ MPPI_HD void sphere_in_box(const Gains &P, V3 ps, float r, const ShapeW &Y, cons
 
 // All candidate pairs of the scene -> per-frame wrench / damping accumulators and net contact forces.
 template <class T, int SPLIT = kSplitNone, class M = CModel>
-MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, Split split = Split{0, 1}) {
+MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned &acc_dirty, unsigned &cf_dirty, Split split = Split{0, 1}) {
     unsigned touched = 0;  // entities (dynamic frames) whose accumulator rows are non-zero after this call
     using Lay = SceneLayout<T>;
-    for (int j = Lay::kAcc; j < Lay::kCf + 3 * m.n_rb; j++) L[j] = 0.f;
+    // contacts are sparse: clear only what the previous pass wrote (375 LDS rows per substep in the gripper scene otherwise)
+    for (int e = 0; e < Lay::NF; e++)
+        if ((acc_dirty >> e) & 1u)
+            for (int j = 0; j < 27; j++) L[Lay::kAcc + 27 * e + j] = 0.f;
+    const bool cf_all = m.n_rb > 32;
+    for (int r = 0; r < m.n_rb; r++)
+        if (cf_all || ((cf_dirty >> r) & 1u)) {
+            L[Lay::kCf + 3 * r] = 0.f; L[Lay::kCf + 3 * r + 1] = 0.f; L[Lay::kCf + 3 * r + 2] = 0.f;
+        }
+    unsigned cf_touched = 0;
     const SV zero = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
     constexpr bool kCached = SPLIT != kSplitNone;
     if constexpr (kCached) shape_cache_update<T>(m, root, L, SPLIT == kSplitEmulate ? Split{0, 1} : split, false);
@@ -614,12 +627,15 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, Split sp
             }
             const int ocf = Lay::kCf + 3 * G.rbA;
             L[ocf] += acc.rep.x; L[ocf + 1] += acc.rep.y; L[ocf + 2] += acc.rep.z;
+            cf_touched |= (1u << (G.rbA & 31)) | (rbB >= 0 ? 1u << (rbB & 31) : 0u);
             if (rbB >= 0) {
                 const int ob = Lay::kCf + 3 * rbB;
                 L[ob] -= acc.rep.x; L[ob + 1] -= acc.rep.y; L[ob + 2] -= acc.rep.z;
             }
         }
     }
+    acc_dirty = touched;
+    cf_dirty = cf_touched;
     return touched;
 }
 
@@ -834,7 +850,7 @@ MPPI_HD void step_scene(M &m0, const float *root, SceneState<T> &s, const float 
         Pose<T> P;
         SV vbase;
         scene_frames<T>(m, root, s, P, vbase, L);
-        contact_forces<T, SPLIT>(m, root, L, split);
+        contact_forces<T, SPLIT>(m, root, L, s.acc_dirty, s.cf_dirty, split);
         float tau[NB ? NB : 1], kdh[NB ? NB : 1], qdd[NB ? NB : 1], ff[NB ? NB : 1], vs[NB ? NB : 1];
         static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
             constexpr int i = ic;
@@ -951,13 +967,14 @@ MPPI_HD float stage_cost_scene(M &m, CCost &c, const float *root, const SceneSta
 
 // quad layout of the robot's kinematics / articulated-body solve (mppi_scene_quad.hpp; used by the kernels whose lanes
 // share a sample)
-template <class T, int SPLIT, class M>
-MPPI_HD void step_scene_quad(M &m0, const float *root, SceneState<T> &s, const float *target, const LMem &L, Split split);
-template <class T, class M>
-MPPI_HD float stage_cost_scene_quad(M &m, CCost &c, const float *root, const SceneState<T> &s, const LMem &L);
+template <class T, int SPLIT, class M, class MR>
+MPPI_HD void step_scene_quad(M &m0, MR &mr0, const float *root, SceneState<T> &s, const float *target, const LMem &L, Split split);
+template <class T, class M, class MR>
+MPPI_HD float stage_cost_scene_quad(M &m, MR &mr, CCost &c, const float *root, const SceneState<T> &s, const LMem &L);
 
-template <class T, int SPLIT = kSplitNone, class M = CModel>
-MPPI_HD float rollout_scene(M &m0, CCfg &cfg0, CCost &cost0, const float *dof0, const float *root, const float *U, const float *eps,
+// mr0: view of the same model for the robot algebra of the quad path (an LDS copy of the model prefix in the kernel)
+template <class T, int SPLIT = kSplitNone, class M = CModel, class MR = CModel>
+MPPI_HD float rollout_scene(M &m0, MR &mr0, CCfg &cfg0, CCost &cost0, const float *dof0, const float *root, const float *U, const float *eps,
                             const float *prior, float *du, float *viz, int k, const LMem &L, Split split = Split{0, 1}) {
     const bool leader = split.sub == 0;  // lanes sharing a sample hold identical values: one of them writes
     constexpr int NB = T::NB;
@@ -983,8 +1000,8 @@ MPPI_HD float rollout_scene(M &m0, CCfg &cfg0, CCost &cost0, const float *dof0, 
             step_scene<T, SPLIT>(*mp, root, s, target, L, split);
             S += disc * stage_cost_scene<T>(*launder(mp), *launder(kp), root, s, L);
         } else {
-            step_scene_quad<T, SPLIT>(*mp, root, s, target, L, split);
-            S += disc * stage_cost_scene_quad<T>(*launder(mp), *launder(kp), root, s, L);
+            step_scene_quad<T, SPLIT>(*mp, mr0, root, s, target, L, split);
+            S += disc * stage_cost_scene_quad<T>(*launder(mp), mr0, *launder(kp), root, s, L);
         }
         disc *= cfg.gamma;
         if (cfg.want_rollouts && viz != nullptr && leader) {

@@ -239,16 +239,20 @@ MPPI_HD void quad_scene_pose(M &m, const SceneState<T> &s, QPose<T> &P) {
 }
 
 // One simulator step of a contact scene, quad layout for the robot (same physics as step_scene).
-template <class T, int SPLIT, class M>
-MPPI_HD void step_scene_quad(M &m0, const float *root, SceneState<T> &s, const float *target, const LMem &L, Split split) {
+// `mr0`: the same model as seen by the robot algebra (bodies, links, header) - the kernel passes an LDS copy of that prefix,
+// whose blocks arrive in order as VGPRs; shapes, pairs and free bodies keep going through the scalar cache (`m0`).
+template <class T, int SPLIT, class M, class MR>
+MPPI_HD void step_scene_quad(M &m0, MR &mr0, const float *root, SceneState<T> &s, const float *target, const LMem &L, Split split) {
     constexpr int NB = T::NB;
     constexpr int NBs = NB ? NB : 1;
     M *mp = &m0;
+    MR *mrp = &mr0;
     for (int sub = 0; sub < m0.substeps; sub++) {
         M &m = *launder(mp);
+        MR &mr = *launder(mrp);
         const float h = m.h, kd = m.kd;
         QPose<T> P;
-        quad_scene_pose<T>(m, s, P);
+        quad_scene_pose<T>(mr, s, P);
         QSV vbase = {qrep(0.f), qrep(0.f)};
         if (m.floating) {
             const QF wb = qsel(s.base[10], s.base[11], s.base[12]), vb = qsel(s.base[7], s.base[8], s.base[9]);
@@ -274,7 +278,7 @@ MPPI_HD void step_scene_quad(M &m0, const float *root, SceneState<T> &s, const f
                     frame_store(L, NB + 1 + f, quat_to_R(rs + 3), p, SV{w, vl - cross(w, p)});
                 }
         }
-        const unsigned touched = contact_forces<T, SPLIT>(m, root, L, split);
+        const unsigned touched = contact_forces<T, SPLIT>(m, root, L, s.acc_dirty, s.cf_dirty, split);
         QF tau[NBs], kdh[NBs], qdd[NBs], ff[NBs], vs[NBs];
         JointLimits lim[NBs];
         const int drive_mode = m.drive_mode;
@@ -286,7 +290,7 @@ MPPI_HD void step_scene_quad(M &m0, const float *root, SceneState<T> &s, const f
             kdh[i] = qrep(kd * h);
         });
         SV abase;
-        quad_aba_scene<T>(m, P, vbase, qd, tau, kdh, L, touched, qdd, abase, lim);
+        quad_aba_scene<T>(mr, P, vbase, qd, tau, kdh, L, touched, qdd, abase, lim);
         bool any = false;
         static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
             constexpr int i = ic;
@@ -298,7 +302,7 @@ MPPI_HD void step_scene_quad(M &m0, const float *root, SceneState<T> &s, const f
                 kdh[i] = qrep(0.f);
             }
         });
-        if (any) quad_aba_scene<T>(*launder(mp), P, vbase, qd, tau, kdh, L, touched, qdd, abase, lim);
+        if (any) quad_aba_scene<T>(*launder(mrp), P, vbase, qd, tau, kdh, L, touched, qdd, abase, lim);
         static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
             constexpr int i = ic;
             const JointLimits b = lim[i];
@@ -317,14 +321,14 @@ MPPI_HD void step_scene_quad(M &m0, const float *root, SceneState<T> &s, const f
 }
 
 // stage cost of a contact scene with the link pose taken from the quad kinematics
-template <class T, class M>
-MPPI_HD float stage_cost_scene_quad(M &m, CCost &c, const float *root, const SceneState<T> &s, const LMem &L) {
+template <class T, class M, class MR>
+MPPI_HD float stage_cost_scene_quad(M &m, MR &mr, CCost &c, const float *root, const SceneState<T> &s, const LMem &L) {
     if (c.kind != kCostBoxerPush && c.kind != kCostPandaPick) return stage_cost_scene<T>(m, c, root, s, L);
     QPose<T> P;
-    quad_scene_pose<T>(m, s, P);
+    quad_scene_pose<T>(mr, s, P);
     QM3 Rq;
     QF pq;
-    quad_link_pose<T>(m, P, c.link[0], Rq, pq);
+    quad_link_pose<T>(mr, P, c.link[0], Rq, pq);
     M3 R;
     for (int cc = 0; cc < 3; cc++) {
         R.a[cc] = qget<0>(Rq.c[cc]);

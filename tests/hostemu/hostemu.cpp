@@ -32,8 +32,8 @@ int emu_rollout(const mppi_model_t *model, const mppi_config_t *cfg, const mppi_
             std::vector<float> lmem(SceneLayout<T>::floats(m.n_rb, m.n_rnd, m.n_shapes));
             LMem L{lmem.data(), 1};
             for (int s = 0; s < c.K; s++)
-                S[s] = g_scene_split > 1 ? rollout_scene<T, kSplitEmulate>(m, c, k, dof0, root0, U, eps, prior, du, viz ? v.data() : nullptr, s, L, Split{0, g_scene_split})
-                                         : rollout_scene<T>(m, c, k, dof0, root0, U, eps, prior, du, viz ? v.data() : nullptr, s, L);
+                S[s] = g_scene_split > 1 ? rollout_scene<T, kSplitEmulate>(m, m, c, k, dof0, root0, U, eps, prior, du, viz ? v.data() : nullptr, s, L, Split{0, g_scene_split})
+                                         : rollout_scene<T>(m, m, c, k, dof0, root0, U, eps, prior, du, viz ? v.data() : nullptr, s, L);
         } else
         for (int s = 0; s < c.K; s++) S[s] = rollout_sample<T>(m, c, k, dof0, root0, U, eps, prior, du, viz ? v.data() : nullptr, s);
         if (viz)  // device layout [H][3][K] -> reference layout [H][K][3]
@@ -115,7 +115,7 @@ int emu_scene_step_g(const mppi_model_t *model, float *dof, float *root, const f
         cmd_map<T>(m, uu, target);
         if (g_scene_split > 1) {
             shape_cache_update<T>(m, root, L, Split{0, 1}, true);
-            step_scene_quad<T, kSplitEmulate>(m, root, s, target, L, Split{0, g_scene_split});
+            step_scene_quad<T, kSplitEmulate>(m, m, root, s, target, L, Split{0, g_scene_split});
         }
         else step_scene<T>(m, root, s, target, L);
         for (int i = 0; i < T::NB; i++) { dof[2 * i] = s.q[i]; dof[2 * i + 1] = s.qd[i]; }
