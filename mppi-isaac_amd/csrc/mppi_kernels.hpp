@@ -95,6 +95,42 @@ __device__ __forceinline__ void wave_record(CCfg &cfg, float s, bool live, const
     }
 }
 
+// The same record for a wavefront of the quad kernels: 16 samples (chunk * 16 ...), sample s held by lanes 4s..4s+3.
+// Instead of a 64-lane butterfly per row (6 shuffle steps x H*nu rows), lane l sums rows l, l + 64, ... over the 16
+// samples itself: the weights are broadcast through LDS, the 16 du values of a row are one contiguous 64-byte read.
+__device__ __forceinline__ void quad_record(CCfg &cfg, float s, bool live_leader, const float *__restrict__ du, int k0, float *__restrict__ rec) {
+    __shared__ float s_w[16];
+    const int K = cfg.K, HN = cfg.H * cfg.nu;
+    const int lane = threadIdx.x & (kWave - 1);
+    const bool fin = live_leader && isfinite(s);
+    const float beta = wave_min(fin ? s : INFINITY);
+    const float w = fin ? __expf(-(s - beta) * cfg.inv_lambda) : 0.f;
+    const float eta = wave_sum(w);
+    if ((lane & 3) == 0) s_w[lane >> 2] = w;  // non-leader lanes carry w = 0 and are not stored
+    if (lane == 0) {
+        rec[0] = beta;
+        rec[1] = eta;
+    }
+    // this wavefront's own du stores must be visible to its other lanes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const int nlive = K - k0 < 16 ? K - k0 : 16;  // samples of this chunk that exist
+    for (int j = lane; j < HN; j += kWave) {
+        const float *row = du + (size_t)j * K + k0;
+        float acc = 0.f;
+        if (nlive == 16 && (K & 3) == 0) {  // aligned full chunk: four 16-byte loads
+            const float4 a = reinterpret_cast<const float4 *>(row)[0], b = reinterpret_cast<const float4 *>(row)[1];
+            const float4 c = reinterpret_cast<const float4 *>(row)[2], d = reinterpret_cast<const float4 *>(row)[3];
+            acc = a.x * s_w[0] + a.y * s_w[1] + a.z * s_w[2] + a.w * s_w[3] + b.x * s_w[4] + b.y * s_w[5] + b.z * s_w[6] + b.w * s_w[7] +
+                  c.x * s_w[8] + c.y * s_w[9] + c.z * s_w[10] + c.w * s_w[11] + d.x * s_w[12] + d.y * s_w[13] + d.z * s_w[14] + d.w * s_w[15];
+        } else {
+            for (int q = 0; q < nlive; q++) acc += row[q] * s_w[q];
+        }
+        rec[2 + j] = acc;
+    }
+}
+
 __global__ __launch_bounds__(kWave) void k_reduce(const DevCfg *__restrict__ cfg, const float *__restrict__ S,
                                                   const float *__restrict__ du, float *__restrict__ partials) {
     const int k = blockIdx.x * kWave + threadIdx.x;
@@ -159,7 +195,7 @@ __global__ __launch_bounds__(kWave) void k_rollout_quad(const DevModel *__restri
         s = quad_rollout<T>(lm, *(CCfg *)cfg, *(CCost *)cost, sc, x0_dof, x0_root, eps, prior, du, viz, k, leader, quad_row(), lane4 < 3);
         if (leader) S[k] = s;
     }
-    wave_record(*(CCfg *)cfg, s, live && leader, du, k, partials + (size_t)chunk * (2 + cfg->H * cfg->nu));
+    quad_record(*(CCfg *)cfg, s, live && leader, du, chunk * 16, partials + (size_t)chunk * (2 + cfg->H * cfg->nu));
 #endif
 }
 
@@ -367,7 +403,7 @@ __global__ __launch_bounds__(kWave) void k_rollout_scene_quad(const DevModel *__
         s = rollout_scene<T, kSplitQuad>(*(CModel *)m, lm, *(CCfg *)cfg, *(CCost *)cost, x0_dof, x0_root, U, eps, prior, du, viz, k, L, Split{lane4, 4});
         if (lane4 == 0) S[k] = s;
     }
-    wave_record(*(CCfg *)cfg, s, live && lane4 == 0, du, k, partials + (size_t)chunk * (2 + cfg->H * cfg->nu));
+    quad_record(*(CCfg *)cfg, s, live && lane4 == 0, du, chunk * 16, partials + (size_t)chunk * (2 + cfg->H * cfg->nu));
 #endif
 }
 
