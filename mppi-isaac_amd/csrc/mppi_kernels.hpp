@@ -468,6 +468,82 @@ __global__ __launch_bounds__(kWave) void k_sim_step_scene(const DevModel *__rest
     for (int j = 0; j < 3 * M.n_rb; j++) cf_[(size_t)j * K + k] = L[SceneLayout<T>::kCf + j];
 }
 
+// the same step with 4 lanes per env (generic Objective mode of a planner context: K/16 wavefronts, contact work dealt
+// over the quad, quad-layout robot algebra for longer trees).  LDS does not persist across launches: the sample's noise
+// draws and the static shapes' poses are rebuilt here.
+template <class T>
+__global__ __launch_bounds__(kWave) void k_sim_step_scene_quad(const DevModel *__restrict__ m, const DevCfg *__restrict__ cfg, int mode, int t,
+                                                               const float *__restrict__ u_ext, const float *__restrict__ x0_root,
+                                                               const float *__restrict__ U, const float *__restrict__ eps, const float *__restrict__ prior,
+                                                               float *__restrict__ du, float *__restrict__ ctrl, float *__restrict__ q_, float *__restrict__ qd_,
+                                                               float *__restrict__ base_, float *__restrict__ fr_, float *__restrict__ cf_) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NB = T::NB;
+    constexpr int kModelBytes = (int)((offsetof(DevModel, fr) + 15) / 16 * 16);
+    __shared__ __attribute__((aligned(64))) uint4 s_model[kModelBytes / 16];
+    for (int i = threadIdx.x; i < kModelBytes / 16; i += kWave) s_model[i] = reinterpret_cast<const uint4 *>(m)[i];
+    __syncthreads();
+    LModel &lm = *(LModel *)s_model;
+    const int K = cfg->K, nu = cfg->nu;
+    const int k = blockIdx.x * 16 + (threadIdx.x >> 2);
+    if (k >= K) return;
+    const int lane4 = threadIdx.x & 3;
+    const bool leader = lane4 == 0;
+    const Split split{lane4, 4};
+    const LMem L{lds + (threadIdx.x >> 2), 16};
+    CModel &M = *(CModel *)m;
+    SceneState<T> s;
+    static_for<0, NB>([&](auto ic) {
+        constexpr int i = ic;
+        s.q[i] = q_[(size_t)i * K + k];
+        s.qd[i] = qd_[(size_t)i * K + k];
+    });
+    for (int j = 0; j < 13; j++) s.base[j] = base_[(size_t)j * K + k];
+    for (int f = 0; f < kMaxFree; f++)
+        for (int j = 0; j < 13; j++) s.fr[f][j] = fr_[(size_t)(f * 13 + j) * K + k];
+    float target[NB ? NB : 1], u[kMaxNu];
+    const int g = cfg->k_offset + k;
+    scene_randomise<T>(M, g, L);
+    shape_cache_update<T>(M, x0_root, L, split, true);
+    float cc = 0.f;
+#pragma unroll
+    for (int c = 0; c < kMaxNu; c++) {
+        float v = 0.f;
+        if (c < nu) {
+            if (mode == 0) v = u_ext[(size_t)k * nu + c];
+            else if (mode == 1) v = u_ext[c];
+            else {
+                float Ut = U[t * nu + c];
+                v = Ut + eps[(size_t)(t * nu + c) * K + k];
+                if (cfg->sample_null_action && g == cfg->k_total - 1) v = 0.f;
+                if (cfg->use_priors && prior != nullptr && g == cfg->k_total - 2) v = prior[t * nu + c];
+                v = fminf(fmaxf(v, cfg->u_min.v[c]), cfg->u_max.v[c]);
+                float d = v - Ut;
+                if (leader) du[(size_t)(t * nu + c) * K + k] = d;
+                float term = Ut * d * cfg->inv_sigma.v[c];
+                cc += cfg->lambda * (cfg->noise_abs_cost ? fabsf(term) : term);
+            }
+        }
+        u[c] = v;
+    }
+    if (mode == 2 && leader) ctrl[k] += cc;
+    cmd_map<T>(M, u, target);
+    step_scene_any<T, kSplitQuad>(M, lm, x0_root, s, target, L, split);
+    if (leader) {
+        static_for<0, NB>([&](auto ic) {
+            constexpr int i = ic;
+            q_[(size_t)i * K + k] = s.q[i];
+            qd_[(size_t)i * K + k] = s.qd[i];
+        });
+        for (int j = 0; j < 13; j++) base_[(size_t)j * K + k] = s.base[j];
+        for (int f = 0; f < kMaxFree; f++)
+            for (int j = 0; j < 13; j++) fr_[(size_t)(f * 13 + j) * K + k] = s.fr[f][j];
+        for (int j = 0; j < 3 * M.n_rb; j++) cf_[(size_t)j * K + k] = L[SceneLayout<T>::kCf + j];
+    }
+#endif
+}
+
 template <class T>
 __global__ __launch_bounds__(kWave) void k_materialise_scene(const DevModel *__restrict__ m, int K, const float *__restrict__ x0_root,
                                                              const float *__restrict__ q_, const float *__restrict__ qd_, const float *__restrict__ base_,
@@ -789,6 +865,7 @@ struct TopoEntry {
     void (*sim_step)(mppi_ctx *, int, int, const float *);
     void (*sim_step_quad)(mppi_ctx *, int, int, const float *);
     void (*sim_step_scene)(mppi_ctx *, int, int, const float *);
+    void (*sim_step_scene_quad)(mppi_ctx *, int, int, const float *);
     void (*materialise)(mppi_ctx *, float *, float *, float *, float *);
     void (*materialise_scene)(mppi_ctx *, float *, float *, float *, float *);
     void (*combine_world)(mppi_ctx *, const float *, int, mppi_ctx *);
@@ -816,6 +893,11 @@ void launch_sim_step_scene_t(mppi_ctx *c, int mode, int t, const float *u_ext) {
                        c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_ctrl, c->d_q, c->d_qd, c->d_base, c->d_fr, c->d_cf);
 }
 template <class T>
+void launch_sim_step_scene_quad_t(mppi_ctx *c, int mode, int t, const float *u_ext) {
+    hipLaunchKernelGGL(k_sim_step_scene_quad<T>, dim3(c->n_quads), dim3(kWave), c->lds_bytes_quad, c->stream, c->d_model, c->d_cfg, mode, t, u_ext,
+                       c->d_x0_root, c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_ctrl, c->d_q, c->d_qd, c->d_base, c->d_fr, c->d_cf);
+}
+template <class T>
 void launch_materialise_scene_t(mppi_ctx *c, float *dof, float *root, float *rb, float *cf) {
     hipLaunchKernelGGL(k_materialise_scene<T>, dim3(c->n_waves), dim3(kWave), 0, c->stream, c->d_model, c->K, c->d_x0_root, c->d_q, c->d_qd, c->d_base,
                        c->d_fr, c->d_cf, dof, root, rb, cf);
@@ -825,6 +907,8 @@ hipError_t raise_lds_limit(size_t lane_bytes, size_t quad_bytes) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rollout_scene<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lane_bytes);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rollout_scene_quad<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)quad_bytes);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sim_step_scene_quad<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)quad_bytes);
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sim_step_scene<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lane_bytes);
 }
@@ -873,6 +957,7 @@ TopoEntry make_topo_entry() {
     e.sim_step = &launch_sim_step_t<T>;
     e.sim_step_quad = &launch_sim_step_quad_t<T>;
     e.sim_step_scene = &launch_sim_step_scene_t<T>;
+    e.sim_step_scene_quad = &launch_sim_step_scene_quad_t<T>;
     e.materialise = &launch_materialise_t<T>;
     e.materialise_scene = &launch_materialise_scene_t<T>;
     e.combine_world = &launch_combine_world_t<T>;

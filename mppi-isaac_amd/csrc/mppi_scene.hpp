@@ -972,6 +972,15 @@ MPPI_HD void step_scene_quad(M &m0, MR &mr0, const float *root, SceneState<T> &s
 template <class T, class M, class MR>
 MPPI_HD float stage_cost_scene_quad(M &m, MR &mr, CCost &c, const float *root, const SceneState<T> &s, const LMem &L);
 
+// One step of a contact scene in the layout the kernel runs in.  The quad layout of the robot algebra pays from a handful
+// of bodies on (measured: gripper arm, 9 bodies, 5.11 -> 4.43 ms; boxer, 2 wheels on a floating base, 1.64 -> 1.87 ms):
+// short trees keep the replicated one-lane algebra.
+template <class T, int SPLIT, class M, class MR>
+MPPI_HD void step_scene_any(M &m, MR &mr, const float *root, SceneState<T> &s, const float *target, const LMem &L, Split split) {
+    if constexpr (SPLIT == kSplitNone || T::NB <= 4) step_scene<T, SPLIT>(m, root, s, target, L, split);
+    else step_scene_quad<T, SPLIT>(m, mr, root, s, target, L, split);
+}
+
 // mr0: view of the same model for the robot algebra of the quad path (an LDS copy of the model prefix in the kernel)
 template <class T, int SPLIT = kSplitNone, class M = CModel, class MR = CModel>
 MPPI_HD float rollout_scene(M &m0, MR &mr0, CCfg &cfg0, CCost &cost0, const float *dof0, const float *root, const float *U, const float *eps,
@@ -994,15 +1003,9 @@ MPPI_HD float rollout_scene(M &m0, MR &mr0, CCfg &cfg0, CCost &cost0, const floa
         CCfg &cfg = *launder(cp);
         ctrl += sample_controls<(NB < kMaxNu ? (NB ? NB : 1) : kMaxNu)>(cfg, U, eps, prior, t, k, is_null, is_prior, leader, du, u);
         cmd_map<T>(*launder(mp), u, target);
-        // the quad layout of the robot algebra pays from a handful of bodies on (measured: gripper arm, 9 bodies, 5.11 ->
-        // 4.43 ms; boxer, 2 wheels on a floating base, 1.64 -> 1.87 ms): short trees keep the replicated one-lane algebra
-        if constexpr (SPLIT == kSplitNone || T::NB <= 4) {
-            step_scene<T, SPLIT>(*mp, root, s, target, L, split);
-            S += disc * stage_cost_scene<T>(*launder(mp), *launder(kp), root, s, L);
-        } else {
-            step_scene_quad<T, SPLIT>(*mp, mr0, root, s, target, L, split);
-            S += disc * stage_cost_scene_quad<T>(*launder(mp), mr0, *launder(kp), root, s, L);
-        }
+        step_scene_any<T, SPLIT>(*mp, mr0, root, s, target, L, split);
+        if constexpr (SPLIT == kSplitNone || T::NB <= 4) S += disc * stage_cost_scene<T>(*launder(mp), *launder(kp), root, s, L);
+        else S += disc * stage_cost_scene_quad<T>(*launder(mp), mr0, *launder(kp), root, s, L);
         disc *= cfg.gamma;
         if (cfg.want_rollouts && viz != nullptr && leader) {
             M &m = *launder(mp);
