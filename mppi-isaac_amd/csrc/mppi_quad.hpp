@@ -387,16 +387,14 @@ MPPI_HD float step_const_entry(CCfg &cfg, CCost &c, const float *root, const flo
 }
 MPPI_HD int step_const_count(CCfg &cfg) { return (int)(offsetof(StepConsts, U) / sizeof(float)) + cfg.H * cfg.nu; }
 
-template <class T, class M>
-MPPI_HD QF quad_stage_cost(M &m, int kind, int link, LStep &sc, const QF *q, const QPose<T> &P) {
+// R, p: world pose of the cost link (PANDA_REACH; computed by the caller, who may share it with the rollout visualisation)
+template <class T>
+MPPI_HD QF quad_stage_cost(int kind, LStep &sc, const QF *q, const QM3 &R, QF p) {
     if (kind == kCostPointReach) {
         const QF dx = q[0] - sc.goal[0], dy = q[T::NB > 1 ? 1 : 0] - sc.goal[1];
         return sc.w[0] * qsqrt(dx * dx + dy * dy);
     }
     if (kind == kCostPandaReach) {
-        QM3 R;
-        QF p;
-        quad_link_pose<T>(m, P, link, R, p);
         const QF d = p - qsel(sc.goal[0], sc.goal[1], sc.goal[2]);
         const QF dist = qsqrt(qsum(d * d));
         // row 2 of R lives in lane 2: R20, R21, R22 -> replicated (see stage_cost in mppi_device.hpp)
@@ -454,6 +452,7 @@ MPPI_HD QF quad_rollout(M &m0, CCfg &cfg0, CCost &cost0, LStep &sc, const float 
     const int K = cfg0.K, nu = cfg0.nu, H = cfg0.H, kind = cost0.kind, link = cost0.link[0], viz_link = cfg0.viz_link;
     const float lambda = cfg0.lambda, gamma = cfg0.gamma;
     const bool abs_cost = cfg0.noise_abs_cost != 0, want_viz = cfg0.want_rollouts && viz != nullptr;
+    const bool cmd_identity = m0.cmd_identity != 0, need_link = kind == kCostPandaReach;
     const int g = cfg0.k_offset + k;
     const bool is_null = cfg0.sample_null_action && g == cfg0.k_total - 1;
     const bool is_prior = cfg0.use_priors && prior != nullptr && g == cfg0.k_total - 2;
@@ -477,7 +476,9 @@ MPPI_HD QF quad_rollout(M &m0, CCfg &cfg0, CCost &cost0, LStep &sc, const float 
         ctrl += apply_controls_q<MAXC>(sc, lambda, abs_cost, nu, K, rows, t, k, is_null, is_prior, leader, du, u);
         // next step's rows are requested now and consumed after this step's dynamics (the last request re-reads row H-1)
         load_controls_q<MAXC>(sc, eps, prior, nu, K, t + 1 < H ? t + 1 : t, k, rows);
-        {
+        if (cmd_identity) {  // fixed-base arms, the point robot: one unit-gain command per body
+            static_for<0, NB>([&](auto ic) MPPI_LAMBDA { target[ic] = qrep(u[ic < kMaxNu ? (int)ic : 0]); });
+        } else {
             M &m = *launder(mp);
             static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
                 constexpr int i = ic;
@@ -489,13 +490,16 @@ MPPI_HD QF quad_rollout(M &m0, CCfg &cfg0, CCost &cost0, LStep &sc, const float 
             });
         }
         quad_step<T>(*mp, P, q, qd, target);
-        S += disc * quad_stage_cost<T>(*launder(mp), kind, link, sc, q, P);
+        QM3 Rl;  // pose of the cost link, shared with the rollout visualisation when that shows the same link
+        QF pl = qrep(0.f);
+        for (int c = 0; c < 3; c++) Rl.c[c] = qrep(0.f);
+        if (need_link) quad_link_pose<T>(*launder(mp), P, link, Rl, pl);
+        S += disc * quad_stage_cost<T>(kind, sc, q, Rl, pl);
         disc *= gamma;
         if (want_viz) {
-            M &m = *launder(mp);
             QM3 R;
-            QF p;
-            quad_link_pose<T>(m, P, viz_link, R, p);
+            QF p = pl;
+            if (viz_link != link || !need_link) quad_link_pose<T>(*launder(mp), P, viz_link, R, p);
 #if defined(__HIP_DEVICE_COMPILE__)
             if (viz_lane) viz[((size_t)t * 3 + row) * K + k] = p;  // lane r stores component r
 #else
