@@ -214,6 +214,48 @@ def test_full_size_properties(lib, oracle64):
     c.close()
 
 
+@pytest.mark.parametrize("make,K,H,nu", [(boxer_push, 8192, 25, 2), (panda_pick, 8192, 30, 9)])
+def test_full_size_properties_contact_scenes(make, K, H, nu, lib, oracle64, monkeypatch):
+    """BASELINE sizes of the contact scenes (configs 4 and 5, one GPU's shard) through properties that do not need the
+    oracle at full size: finite costs, clamped perturbations, the action as the weighted mean of the perturbations, bitwise
+    determinism, the quad kernel against the one-lane kernel on the same inputs, and a handful of samples against the
+    oracle (chaotic contact switching aside, most of them agree to 1 %)."""
+    scene, m, cfg, cost, dof, root = make(K=K, H=H)
+    c = Ctx(m, cfg, cost)
+    c.call("mppi_sample", C.c_uint32(0)); c.set_state(dof, root)
+    a = np.zeros(nu, np.float32)
+    c.call("mppi_command", capi.fptr(a))
+    S, du = c.get("mppi_get_costs", (K,)), c.get("mppi_get_perturbations", (H, nu, K))
+    eps = c.get("mppi_get_noise", (H, nu, K))
+    assert np.isfinite(S).all() and np.isfinite(a).all()
+    umax = np.array([cfg.u_max[j] for j in range(nu)]); umin = np.array([cfg.u_min[j] for j in range(nu)])
+    assert (du <= umax[None, :, None] + 1e-6).all() and (du >= umin[None, :, None] - 1e-6).all()
+    np.testing.assert_array_equal(du[:, :, -1], 0.0)
+    w = np.exp(-(S.astype(np.float64) - S.min()) / cfg.lambda_)
+    np.testing.assert_allclose(a, (du[0].astype(np.float64) * w).sum(1) / w.sum(), atol=5e-6 * max(1.0, np.abs(umax).max()))
+    c.set_U(np.zeros((H, nu)))
+    c.call("mppi_rollout")
+    np.testing.assert_array_equal(S, c.get("mppi_get_costs", (K,)))
+    c.close()
+    monkeypatch.setenv("MPPI_ROLLOUT", "lane")                      # same physics, one lane per sample
+    l = Ctx(m, cfg, cost)
+    l.call("mppi_sample", C.c_uint32(0)); l.set_state(dof, root); l.call("mppi_rollout")
+    Sl = l.get("mppi_get_costs", (K,))
+    l.close()
+    assert (np.abs(S - Sl) <= 1e-2 * np.abs(Sl)).mean() > 0.9
+    assert np.median(S) == pytest.approx(np.median(Sl), rel=1e-3)
+    from mppiisaac.planner.mppi import make_config
+    from mppiisaac.utils.config_store import load_config
+    name = "boxer_push" if make is boxer_push else "panda_pick"
+    ex = load_config({"defaults": [{"mppi": name}, {"isaacgym": "normal"}]}, overrides={"mppi.num_samples": K, "mppi.horizon": H})
+    ok = 0
+    for k in range(5, K, K // 8):
+        sc = make_config(ex.mppi, k_offset=int(k), k_local=1, viz_link=scene.viz_link_index())
+        So, _, _ = oracle64.rollout(m, sc, cost, dof, root, np.zeros((H, nu)), eps[:, :, k:k + 1])
+        ok += abs(S[k] - So[0]) <= 1e-2 * abs(So[0])
+    assert ok >= 6
+
+
 def test_generic_objective_mode_equals_fused(lib):
     """Objective contract (compute_cost(sim) per horizon step, reference mppi_isaac.py:57-69) == fused kernel."""
     from mppiisaac.objectives import PandaReachObjective, PointReachObjective
