@@ -343,6 +343,32 @@ MPPI_HD void rank1_sub(AI &A, SV U, float s) {
 // Controls of horizon step t for sample k: u = clamp(U_t + eps), effective perturbation du = u - U_t
 // (stored by `leader` lanes), control-cost increment.  All loads are issued before the first use so the
 // wave waits once, not once per control dimension; everything is branch-free over the padded kMaxNu.
+// Hardware square root / reciprocal square root / reciprocal (1 ulp; the reciprocal gets one Newton step).  The IEEE
+// library versions cost 22 (sqrtf), 32 (1/sqrtf) and ~10 (division) instructions each on gfx950 - per contact point, per
+// Cholesky pivot, per cost term - for a last-bit difference that is far inside the tolerances of this path.
+MPPI_HD float fsqrt(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sqrtf(x);
+#else
+    return sqrtf(x);
+#endif
+}
+MPPI_HD float frsqrt(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rsqf(x);
+#else
+    return 1.f / sqrtf(x);
+#endif
+}
+MPPI_HD float frcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r = __builtin_amdgcn_rcpf(x);
+    return r * (2.f - x * r);
+#else
+    return 1.f / x;
+#endif
+}
+
 // clamp to [lo, hi]: one v_med3_f32 on the device (fminf(fmaxf()) costs two operations plus a canonicalisation each)
 MPPI_HD float clampf(float v, float lo, float hi) {
 #if defined(__HIP_DEVICE_COMPILE__)

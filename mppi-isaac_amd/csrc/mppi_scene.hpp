@@ -120,7 +120,7 @@ MPPI_HD SV solve6(const AI &A, SV b) {
         float s = a[j][j];
 #pragma unroll
         for (int k = 0; k < j; k++) s -= a[j][k] * a[j][k];
-        const float inv = 1.f / sqrtf(s);
+        const float inv = frsqrt(s);
         a[j][j] = inv;  // store 1/L_jj
 #pragma unroll
         for (int i = j + 1; i < 6; i++) {
@@ -271,11 +271,11 @@ MPPI_HD void contact_point(const Gains &P, V3 p, V3 n, float depth, const SV &vA
     const V3 vr = vel_at(vA, p) - vel_at(vB, p);
     const float vn = dot(vr, n);
     const V3 vt = vr - vn * n;
-    const float vtn = sqrtf(dot(vt, vt));
+    const float vtn = fsqrt(dot(vt, vt));
     acc.any = true;
     if (P.mode == 0) {  // both dynamic: explicit spring-damper, viscous friction capped by the Coulomb cone
         const float fn = fmaxf(0.f, P.k * depth - P.cn * vn);
-        const float sc = fminf(P.ct, P.mu * fn / (vtn + 1e-9f));
+        const float sc = fminf(P.ct, P.mu * fn * frcp(vtn + 1e-9f));
         const V3 f = fn * n - sc * vt;
         acc.f = {acc.f.a + cross(p, f), acc.f.l + f};
         acc.rep = acc.rep + f;
@@ -289,7 +289,7 @@ MPPI_HD void contact_point(const Gains &P, V3 p, V3 n, float depth, const SV &vA
     // Coulomb friction as an implicit secant viscosity b = min(c_t, mu fn / |v_t|): equals the stick damper
     // at small slip, delivers mu*fn while sliding, and - being implicit - can never reverse the slip
     // velocity (an explicit mu*fn chatters: the yaw inertia seen by a wheel contact is far below the mass)
-    const float b = fminf(P.ct, P.mu * fn / (vtn + 1e-9f));
+    const float b = fminf(P.ct, P.mu * fn * frcp(vtn + 1e-9f));
     const V3 f = (P.k * depth) * n;
     acc.f = {acc.f.a + cross(p, f), acc.f.l + f};
     // C6 = J^T (b 1 + (a-b) n n^T) J,  J = [-[p]x  1]
@@ -446,8 +446,8 @@ MPPI_HD void sphere_in_box(const Gains &P, V3 ps, float r, const ShapeW &Y, cons
     V3 nl;
     float depth;
     if (dist2 > 1e-12f) {  // centre outside the box: normal along the shortest connection
-        const float dist = sqrtf(dist2);
-        nl = (1.f / dist) * e;
+        const float dist = fsqrt(dist2);
+        nl = frcp(dist) * e;
         depth = r - dist;
     } else {  // centre inside: push out through the nearest face
         const float dx = hy[0] - fabsf(y.x), dy = hy[1] - fabsf(y.y), dz = hy[2] - fabsf(y.z);
@@ -519,11 +519,11 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
             apart = boxes_apart(rel, hA, hB, 1e-4f);
         } else {
             constexpr float kMargin = 1e-4f;
-            const float rA = typeA == 0 ? sqrtf(hA[0] * hA[0] + hA[1] * hA[1] + hA[2] * hA[2]) : hA[0];
+            const float rA = typeA == 0 ? fsqrt(hA[0] * hA[0] + hA[1] * hA[1] + hA[2] * hA[2]) * 1.000001f : hA[0];  // (rounded up: conservative)
             if (!has_b) {
                 apart = typeA != 2 && wa.p.z > rA + kMargin;
             } else if (typeA != 2 && typeB != 2) {
-                const float rB = typeB == 0 ? sqrtf(hB[0] * hB[0] + hB[1] * hB[1] + hB[2] * hB[2]) : hB[0];
+                const float rB = typeB == 0 ? fsqrt(hB[0] * hB[0] + hB[1] * hB[1] + hB[2] * hB[2]) * 1.000001f : hB[0];
                 const V3 d = wa.p - wb.p;
                 if (typeB == 0) {
                     const V3 y = {wb.R.a[0] * d.x + wb.R.a[3] * d.y + wb.R.a[6] * d.z, wb.R.a[1] * d.x + wb.R.a[4] * d.y + wb.R.a[7] * d.z,
@@ -577,7 +577,7 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
                         V3 d = {ax.z * ax.x, ax.z * ax.y, ax.z * ax.z - 1.f};
                         float l2 = dot(d, d);
                         if (l2 > 1e-8f) {
-                            V3 pw = wa.p + (hA[0] / sqrtf(l2)) * d;
+                            V3 pw = wa.p + (hA[0] * frsqrt(l2)) * d;
                             if (pw.z < 0.f) contact_point(P, pw, ez, -pw.z, wa.v, zero, out);
                         }
                     }
@@ -647,7 +647,7 @@ MPPI_HD void quat_integrate(float *q, V3 w, float h) {
     float ny = y + k * (w.y * s + w.z * x - w.x * z);
     float nz = z + k * (w.z * s + w.x * y - w.y * x);
     float ns = s - k * (w.x * x + w.y * y + w.z * z);
-    const float inv = 1.f / sqrtf(nx * nx + ny * ny + nz * nz + ns * ns);
+    const float inv = frsqrt(nx * nx + ny * ny + nz * nz + ns * ns);
     q[0] = nx * inv; q[1] = ny * inv; q[2] = nz * inv; q[3] = ns * inv;
 }
 
@@ -713,7 +713,7 @@ MPPI_HD void aba_scene(M &m, const Pose<T> &P, const SV &vbase, const float *qd,
         }
         U[i] = mul(A, S);
         float d = dot(S, U[i]) + kdh[i];
-        invd[i] = 1.f / d;
+        invd[i] = frcp(d);
         u[i] = tau_exp[i] - dot(S, pA);
         const SV vp = par < 0 ? vbase : v[par < 0 ? 0 : par];
         SV sj = {qd[i] * S.a, qd[i] * S.l};
@@ -927,12 +927,12 @@ MPPI_HD float stage_cost_scene_link(M &m, CCost &c, const float *root, const Sce
             }
         const float gx = root[13 * c.actor[1]], gy = root[13 * c.actor[1] + 1];
         const float rbx = r.x - bx, rby = r.y - by, bgx = gx - bx, bgy = gy - by;
-        const float d_rb = sqrtf(rbx * rbx + rby * rby), d_bg = sqrtf(bgx * bgx + bgy * bgy);
+        const float d_rb = fsqrt(rbx * rbx + rby * rby), d_bg = fsqrt(bgx * bgx + bgy * bgy);
         const float ort = fabsf(byaw - c.w[6]);
-        const float align = (rbx * bgx + rby * bgy) / (d_rb * d_bg) + 1.f;
+        const float align = (rbx * bgx + rby * bgy) * frcp(d_rb * d_bg) + 1.f;
         const int o1 = Lay::kCf + 3 * c.link[1], o2 = Lay::kCf + 3 * c.link[2];
         const float coll = fabsf(L[o1]) + fabsf(L[o1 + 1]) + fabsf(L[o2]) + fabsf(L[o2 + 1]);
-        const float vel = sqrtf(bvx * bvx + bvy * bvy);
+        const float vel = fsqrt(bvx * bvx + bvy * bvy);
         return c.w[0] * d_rb + c.w[1] * d_bg + c.w[2] * ort + c.w[3] * align + c.w[4] * vel + c.w[5] * coll;
     }
     // PANDA_PICK, examples/panda_pick/planner.py:24-53: link[0] = panda_ee, link[1] = table rigid body, actor[0] = block,
@@ -945,7 +945,7 @@ MPPI_HD float stage_cost_scene_link(M &m, CCost &c, const float *root, const Sce
     const int ot = Lay::kCf + 3 * c.link[1];
     const float forces = fabsf(L[ot]) + fabsf(L[ot + 1]) + fabsf(L[ot + 2]);
     const float a0 = atan2f(R.a[7], -R.a[8]), a1 = asinf(clamp1(R.a[6]));  // see PANDA_REACH
-    return c.w[0] * sqrtf(dot(drb, drb)) + c.w[1] * sqrtf(dot(dbg, dbg)) + c.w[2] * forces + c.w[3] * sqrtf(a0 * a0 + a1 * a1);
+    return c.w[0] * fsqrt(dot(drb, drb)) + c.w[1] * fsqrt(dot(dbg, dbg)) + c.w[2] * forces + c.w[3] * fsqrt(a0 * a0 + a1 * a1);
 }
 
 template <class T, class M>
