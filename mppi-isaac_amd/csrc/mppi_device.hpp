@@ -551,7 +551,7 @@ MPPI_HD void aba_world(CModel &m, const Pose<T> &P, const float *qd, const float
             T9[3 * r + 1] = r0 * b.Ic[1] + r1 * b.Ic[3] + r2 * b.Ic[4];
             T9[3 * r + 2] = r0 * b.Ic[2] + r1 * b.Ic[4] + r2 * b.Ic[5];
         }
-        float invm = b.m > 0.f ? 1.f / b.m : 0.f;
+        float invm = b.invm;
         V3 cw = invm * h;
         float hh = dot(h, cw);
         AI A;
@@ -575,7 +575,7 @@ MPPI_HD void aba_world(CModel &m, const Pose<T> &P, const float *qd, const float
         }
         U[i] = mul(A, S);
         float d = dot(S, U[i]) + kdh[i];
-        invd[i] = 1.f / d;
+        invd[i] = frcp(d);
         u[i] = tau_exp[i] - dot(S, pA);
         if constexpr (par >= 0) {
             // c = v_parent x (S qd);  pa = pA + IA c + U (u - U.c)/d;  Ia = IA - U U^T / d

@@ -159,7 +159,7 @@ MPPI_HD void rigid_world(const M3 &R, V3 p, float m, V3 hb, F *Ic, const SV &v, 
         T9[3 * r + 1] = r0 * Ic[1] + r1 * Ic[3] + r2 * Ic[4];
         T9[3 * r + 2] = r0 * Ic[2] + r1 * Ic[4] + r2 * Ic[5];
     }
-    float invm = m > 0.f ? 1.f / m : 0.f;
+    float invm = m > 0.f ? frcp(m) : 0.f;
     V3 cw = invm * h;
     float hh = dot(h, cw);
     A.I.xx = T9[0] * R.a[0] + T9[1] * R.a[1] + T9[2] * R.a[2] + hh - h.x * cw.x;
@@ -548,9 +548,9 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
             const float mub = !has_b ? Cg.mub : (robotB ? Cg.muB : db.mu);
             P.mu = fminf(mua, mub);
             const float ma = Cg.ma * da.ms, mb = Cg.mb * db.ms;
-            const float meff0 = G.mode == 0 ? Cg.ma * Cg.mb / (Cg.ma + Cg.mb) : (G.mode == 1 ? Cg.ma : Cg.mb);
-            const float meff = G.mode == 0 ? ma * mb / (ma + mb) : (G.mode == 1 ? ma : mb);
-            const float sc = meff / meff0;
+            const float meff0 = G.mode == 0 ? Cg.ma * Cg.mb * frcp(Cg.ma + Cg.mb) : (G.mode == 1 ? Cg.ma : Cg.mb);
+            const float meff = G.mode == 0 ? ma * mb * frcp(ma + mb) : (G.mode == 1 ? ma : mb);
+            const float sc = meff * frcp(meff0);
             P.k *= sc; P.cn *= sc; P.ct *= sc; P.kh *= sc;
         }
         PairAcc acc;
@@ -815,7 +815,8 @@ MPPI_HD void step_free_bodies(M &m, SceneState<T> &s, const LMem &L, float h) {
                 fm *= dr.ms;
                 if (F.type == 1) {  // MPPI_ACTOR_BOX
                     const float x = F.size[0] + dr.d[0], y = F.size[1] + dr.d[1], z = F.size[2] + dr.d[2];
-                    Ic6[0] = fm / 12.f * (y * y + z * z); Ic6[3] = fm / 12.f * (x * x + z * z); Ic6[5] = fm / 12.f * (x * x + y * y);
+                    const float m12 = fm * (1.f / 12.f);
+                    Ic6[0] = m12 * (y * y + z * z); Ic6[3] = m12 * (x * x + z * z); Ic6[5] = m12 * (x * x + y * y);
                 } else {  // sphere
                     const float r = F.size[0] + dr.d[0];
                     Ic6[0] = Ic6[3] = Ic6[5] = 0.4f * fm * r * r;

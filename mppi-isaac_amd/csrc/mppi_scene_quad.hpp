@@ -89,7 +89,7 @@ MPPI_HD void qrigid_world(const QM3 &R, QF p, float mass, const F *hb, const F *
     Tr[0] = R.c[0] * Ic[0] + R.c[1] * Ic[1] + R.c[2] * Ic[2];
     Tr[1] = R.c[0] * Ic[1] + R.c[1] * Ic[3] + R.c[2] * Ic[4];
     Tr[2] = R.c[0] * Ic[2] + R.c[1] * Ic[4] + R.c[2] * Ic[5];
-    const float invm = mass > 0.f ? 1.f / mass : 0.f;
+    const float invm = mass > 0.f ? frcp(mass) : 0.f;
     const QF cw = invm * h;
     const QF hh = qsum(h * cw);
     const QF h1 = rot1(h), h2 = rot2(h);
