@@ -970,8 +970,10 @@ MPPI_HD float stage_cost_scene(M &m, CCost &c, const float *root, const SceneSta
 // share a sample)
 template <class T, int SPLIT, class M, class MR>
 MPPI_HD void step_scene_quad(M &m0, MR &mr0, const float *root, SceneState<T> &s, const float *target, const LMem &L, Split split);
+// stage cost + rollout-visualisation point of the state after a step, both from ONE quad-layout kinematics pass
 template <class T, class M, class MR>
-MPPI_HD float stage_cost_scene_quad(M &m, MR &mr, CCost &c, const float *root, const SceneState<T> &s, const LMem &L);
+MPPI_HD float step_tail_scene_quad(M &m, MR &mr, CCfg &cfg, CCost &c, const float *root, const SceneState<T> &s, const LMem &L, float *viz, int t, int k,
+                                   bool leader);
 
 // One step of a contact scene in the layout the kernel runs in.  The quad layout of the robot algebra pays from a handful
 // of bodies on (measured: gripper arm, 9 bodies, 5.11 -> 4.43 ms; boxer, 2 wheels on a floating base, 1.64 -> 1.87 ms):
@@ -1003,24 +1005,28 @@ MPPI_HD float rollout_scene(M &m0, MR &mr0, CCfg &cfg0, CCost &cost0, const floa
     for (int t = 0; t < H; t++) {
         CCfg &cfg = *launder(cp);
         ctrl += sample_controls<(NB < kMaxNu ? (NB ? NB : 1) : kMaxNu)>(cfg, U, eps, prior, t, k, is_null, is_prior, leader, du, u);
-        cmd_map<T>(*launder(mp), u, target);
+        if constexpr (SPLIT == kSplitNone) cmd_map<T>(*launder(mp), u, target);
+        else cmd_map<T>(mr0, u, target);  // (the kernel's LDS copy of the robot part: no scalar-cache round trips)
         step_scene_any<T, SPLIT>(*mp, mr0, root, s, target, L, split);
-        if constexpr (SPLIT == kSplitNone || T::NB <= 4) S += disc * stage_cost_scene<T>(*launder(mp), *launder(kp), root, s, L);
-        else S += disc * stage_cost_scene_quad<T>(*launder(mp), mr0, *launder(kp), root, s, L);
-        disc *= cfg.gamma;
-        if (cfg.want_rollouts && viz != nullptr && leader) {
-            M &m = *launder(mp);
-            Pose<T> P;
-            P.pb = loadv(s.base);
-            P.Rb = quat_to_R(s.base + 3);
-            forward_kinematics_base<T>(m, s.q, P);
-            M3 R;
-            V3 p;
-            link_pose<T>(m, P, cfg.viz_link, R, p);
-            viz[((size_t)t * 3 + 0) * K + k] = p.x;
-            viz[((size_t)t * 3 + 1) * K + k] = p.y;
-            viz[((size_t)t * 3 + 2) * K + k] = p.z;
+        if constexpr (SPLIT == kSplitNone || T::NB <= 4) {
+            S += disc * stage_cost_scene<T>(*launder(mp), *launder(kp), root, s, L);
+            if (cfg.want_rollouts && viz != nullptr && leader) {
+                M &m = *launder(mp);
+                Pose<T> P;
+                P.pb = loadv(s.base);
+                P.Rb = quat_to_R(s.base + 3);
+                forward_kinematics_base<T>(m, s.q, P);
+                M3 R;
+                V3 p;
+                link_pose<T>(m, P, cfg.viz_link, R, p);
+                viz[((size_t)t * 3 + 0) * K + k] = p.x;
+                viz[((size_t)t * 3 + 1) * K + k] = p.y;
+                viz[((size_t)t * 3 + 2) * K + k] = p.z;
+            }
+        } else {
+            S += disc * step_tail_scene_quad<T>(*launder(mp), mr0, cfg, *launder(kp), root, s, L, viz, t, k, leader);
         }
+        disc *= cfg.gamma;
     }
     return S + ctrl;
 }

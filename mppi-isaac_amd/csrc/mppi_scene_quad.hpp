@@ -320,22 +320,43 @@ MPPI_HD void step_scene_quad(M &m0, MR &mr0, const float *root, SceneState<T> &s
     }
 }
 
-// stage cost of a contact scene with the link pose taken from the quad kinematics
+// Stage cost of the state after a step and the rollout-visualisation point, both from ONE quad-layout kinematics pass
+// (the one-lane path runs a full forward kinematics for each of them).
 template <class T, class M, class MR>
-MPPI_HD float stage_cost_scene_quad(M &m, MR &mr, CCost &c, const float *root, const SceneState<T> &s, const LMem &L) {
-    if (c.kind != kCostBoxerPush && c.kind != kCostPandaPick) return stage_cost_scene<T>(m, c, root, s, L);
+MPPI_HD float step_tail_scene_quad(M &m, MR &mr, CCfg &cfg, CCost &c, const float *root, const SceneState<T> &s, const LMem &L, float *viz, int t, int k,
+                                   bool leader) {
+    const bool want_viz = cfg.want_rollouts && viz != nullptr;
+    const bool link_cost = c.kind == kCostBoxerPush || c.kind == kCostPandaPick;
+    float cost;
     QPose<T> P;
-    quad_scene_pose<T>(mr, s, P);
-    QM3 Rq;
-    QF pq;
-    quad_link_pose<T>(mr, P, c.link[0], Rq, pq);
-    M3 R;
-    for (int cc = 0; cc < 3; cc++) {
-        R.a[cc] = qget<0>(Rq.c[cc]);
-        R.a[3 + cc] = qget<1>(Rq.c[cc]);
-        R.a[6 + cc] = qget<2>(Rq.c[cc]);
+    if (link_cost || want_viz) quad_scene_pose<T>(mr, s, P);
+    if (link_cost) {
+        QM3 Rq;
+        QF pq;
+        quad_link_pose<T>(mr, P, c.link[0], Rq, pq);
+        M3 R;
+        for (int cc = 0; cc < 3; cc++) {
+            R.a[cc] = qget<0>(Rq.c[cc]);
+            R.a[3 + cc] = qget<1>(Rq.c[cc]);
+            R.a[6 + cc] = qget<2>(Rq.c[cc]);
+        }
+        cost = stage_cost_scene_link<T>(m, c, root, s, L, R, qv3_gather(pq));
+    } else {
+        cost = stage_cost_scene<T>(m, c, root, s, L);
     }
-    return stage_cost_scene_link<T>(m, c, root, s, L, R, qv3_gather(pq));
+    if (want_viz) {
+        QM3 Rq;
+        QF pq;
+        quad_link_pose<T>(mr, P, cfg.viz_link, Rq, pq);
+        const V3 p = qv3_gather(pq);
+        if (leader) {
+            const int K = cfg.K;
+            viz[((size_t)t * 3 + 0) * K + k] = p.x;
+            viz[((size_t)t * 3 + 1) * K + k] = p.y;
+            viz[((size_t)t * 3 + 2) * K + k] = p.z;
+        }
+    }
+    return cost;
 }
 
 }  // namespace mppi
