@@ -1,0 +1,58 @@
+"""bench.py / __graft_entry__ contracts on a real GPU: one JSON line with the agreed keys, smoke() green."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def run_bench(*extra):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "60", "--warmup", "10", *extra],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_prints_one_json_line_with_the_contract_keys():
+    d = run_bench()
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 60 and d["warmup"] == 10 and d["higher_is_better"] is True
+    assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic" and d["scaling"] == "weak"
+    assert "Panda 7-DoF K=4096 H=20" in d["metric"] and "workload" in d["config"]
+    assert d["value"] > 100.0                                   # the BASELINE target (Hz) with a very wide margin
+    assert d["value"] == pytest.approx(1e3 / d["ms_per_step"], rel=1e-6)
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["frac"] == pytest.approx(r["achieved"] / r["peak"])
+    assert 0.05 < r["kernel_ms"] < 5.0
+    c = d["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c, key
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
+    assert d["config"]["final_ee_to_goal_m"] < 0.6              # the closed loop moves towards the goal
+
+
+def test_bench_other_workloads_and_the_sharded_code_path():
+    d = run_bench("--workload", "boxer_push", "--no-cpu-baseline")
+    assert "boxer_push" in d["metric"] and d["roofline"]["kernel"] == "k_rollout_scene_quad" and d["value"] > 10
+    env = dict(os.environ, MPPI_BENCH_FORCE_DIST="1", MASTER_PORT="29547")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "60", "--warmup", "10", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][0])
+    assert "sample-shard x1 (nccl" in d["config"]["parallelism"] and d["value"] > 100.0   # RCCL process group + all-gather, one rank
+
+
+def test_smoke_entry_point():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    g.smoke()
