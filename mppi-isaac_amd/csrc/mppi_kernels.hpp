@@ -244,7 +244,15 @@ __device__ __forceinline__ void combine_update(CCfg &cfg, const float *__restric
     for (int j = jj; j < HN; j += 128) {
         float N0 = 0.f;
 #pragma unroll 8
-        for (int r = g; r < nrec; r += kCombineGroups) N0 += recs[(size_t)r * RF + 2 + j] * (r < kMaxScale ? s_scale[r] : 0.f);
+        for (int r = g; r < nrec; r += kCombineGroups) {
+            float sc;
+            if (r < kMaxScale) sc = s_scale[r];
+            else {  // more records than the LDS table holds (K > 65536 on one GPU): recompute the rescaling factor
+                const float er = recs[(size_t)r * RF + 1];
+                sc = er > 0.f ? __expf(-(recs[(size_t)r * RF] - beta) * cfg.inv_lambda) : 0.f;
+            }
+            N0 += recs[(size_t)r * RF + 2 + j] * sc;
+        }
         s_part[g][j] = N0;
     }
     __syncthreads();

@@ -566,6 +566,22 @@ def test_ragged_sizes_contact_scene(K, lib, oracle64, monkeypatch):
         c.close()
 
 
+def test_more_wave_records_than_the_combine_table_holds(lib, oracle64):
+    """K = 70000 on one GPU = 4375 per-wave records, more than the 4096 rescaling factors the combine kernel caches in
+    LDS: the action must still be the weighted mean over ALL samples."""
+    K, H = 70000, 6
+    scene, m, cfg, cost, dof, root = point_reach(K=K, H=H)
+    c = Ctx(m, cfg, cost)
+    c.call("mppi_sample", C.c_uint32(0)); c.set_state(dof, root)
+    a = np.zeros(3, np.float32)
+    c.call("mppi_command", capi.fptr(a))
+    S, du = c.get("mppi_get_costs", (K,)), c.get("mppi_get_perturbations", (H, 3, K))
+    w = np.exp(-(S.astype(np.float64) - S.min()) / cfg.lambda_)
+    np.testing.assert_allclose(a, (du[0].astype(np.float64) * w).sum(1) / w.sum(), atol=2e-6)
+    assert w[65536:].sum() > 0.01 * w.sum()               # the samples beyond the table carry real weight here
+    c.close()
+
+
 def test_random_sampling_priors_and_param_update(lib, oracle64):
     """mppi_mode 'simple' / sampling_method 'random' (torch noise on the device), a prior in sample K-2
     (reference mppi_isaac.py:38-41) and update_mppi_params (:129-138) through the planner facade."""
