@@ -363,7 +363,7 @@ struct StepConsts {
     CtrlBlock u_min, u_max, inv_sigma;
     float goal[4];                       // cost target (actor position, or the fixed goal of POINT_REACH)
     float w[4];                          // cost weights
-    float U[MPPI_MAX_H * MPPI_MAX_NU];   // nominal control rows
+    CtrlBlock Urow[MPPI_MAX_H];          // nominal control rows, one 64-byte block per horizon step (zero beyond nu)
 };
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef const MPPI_LDS_AS StepConsts LStep;
@@ -372,7 +372,7 @@ typedef const StepConsts LStep;
 #endif
 // entry j of the staging copy (cooperative: lane j of the wavefront fills entries j, j + 64, ...)
 MPPI_HD float step_const_entry(CCfg &cfg, CCost &c, const float *root, const float *U, int j) {
-    constexpr int kU = (int)(offsetof(StepConsts, U) / sizeof(float));
+    constexpr int kU = (int)(offsetof(StepConsts, Urow) / sizeof(float));
     if (j < 16) return cfg.u_min.v[j];
     if (j < 32) return cfg.u_max.v[j - 16];
     if (j < 48) return cfg.inv_sigma.v[j - 32];
@@ -383,9 +383,10 @@ MPPI_HD float step_const_entry(CCfg &cfg, CCost &c, const float *root, const flo
         return i < 2 ? c.w[1 + i] : 0.f;  // POINT_REACH without a goal actor: (w1, w2) is the target
     }
     if (j < 56) return c.w[j - 52];
-    return j - kU < cfg.H * cfg.nu ? U[j - kU] : 0.f;
+    const int t = (j - kU) >> 4, col = (j - kU) & 15;
+    return (t < cfg.H && col < cfg.nu) ? U[t * cfg.nu + col] : 0.f;
 }
-MPPI_HD int step_const_count(CCfg &cfg) { return (int)(offsetof(StepConsts, U) / sizeof(float)) + cfg.H * cfg.nu; }
+MPPI_HD int step_const_count(CCfg &cfg) { return (int)(offsetof(StepConsts, Urow) / sizeof(float)) + cfg.H * 16; }
 
 // R, p: world pose of the cost link (PANDA_REACH; computed by the caller, who may share it with the rollout visualisation)
 template <class T>
@@ -410,11 +411,12 @@ MPPI_HD QF quad_stage_cost(int kind, LStep &sc, const QF *q, const QM3 &R, QF p)
 template <int MAXC>
 MPPI_HD void load_controls_q(LStep &sc, const float *eps, const float *prior, int nu, int K, int t, int k, ControlRows<MAXC> &r) {
     const bool has_prior = prior != nullptr;
+    const CtrlBlock ur = load_block<CtrlBlock>(sc.Urow[t]);  // the whole nominal row in one aligned read
 #pragma unroll
     for (int c = 0; c < MAXC; c++) {
         const int cc = c < nu ? c : nu - 1;
         const unsigned row = (unsigned)(t * nu + cc);
-        r.Ut[c] = sc.U[row];
+        r.Ut[c] = ur.v[c];
         r.e[c] = eps[row * (unsigned)K + (unsigned)k];
         r.pr[c] = has_prior ? prior[row] : 0.f;
     }
