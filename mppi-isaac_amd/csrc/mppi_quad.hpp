@@ -410,20 +410,24 @@ MPPI_HD QF quad_stage_cost(int kind, LStep &sc, const QF *q, const QM3 &R, QF p)
 // control rows of step t: the nominal row from the staged copy, this sample's noise from HBM (requested one step ahead)
 template <int MAXC>
 MPPI_HD void load_controls_q(LStep &sc, const float *eps, const float *prior, int nu, int K, int t, int k, ControlRows<MAXC> &r) {
-    const bool has_prior = prior != nullptr;
     const CtrlBlock ur = load_block<CtrlBlock>(sc.Urow[t]);  // the whole nominal row in one aligned read
 #pragma unroll
     for (int c = 0; c < MAXC; c++) {
         const int cc = c < nu ? c : nu - 1;
-        const unsigned row = (unsigned)(t * nu + cc);
         r.Ut[c] = ur.v[c];
-        r.e[c] = eps[row * (unsigned)K + (unsigned)k];
-        r.pr[c] = has_prior ? prior[row] : 0.f;
+        r.e[c] = eps[(unsigned)(t * nu + cc) * (unsigned)K + (unsigned)k];
+        r.pr[c] = 0.f;
+    }
+    if (prior != nullptr) {  // ONE uniform branch for the whole row (rare: use_priors)
+#pragma unroll
+        for (int c = 0; c < MAXC; c++) r.pr[c] = prior[t * nu + (c < nu ? c : nu - 1)];
     }
 }
+// `leader` is not consulted: the four lanes of a quad hold the same du and store it to the same address (one dword of
+// traffic either way), which replaces seven exec-mask regions per step by plain stores under uniform conditions
 template <int MAXC>
 MPPI_HD float apply_controls_q(LStep &sc, float lambda, bool abs_cost, int nu, int K, const ControlRows<MAXC> &r, int t, int k, bool is_null,
-                               bool is_prior, bool leader, float *du, float *u) {
+                               bool is_prior, bool /*leader*/, float *du, float *u) {
 #pragma unroll
     for (int c = MAXC; c < kMaxNu; c++) u[c] = 0.f;
     const CtrlBlock lo = load_block<CtrlBlock>(sc.u_min), hi = load_block<CtrlBlock>(sc.u_max), is = load_block<CtrlBlock>(sc.inv_sigma);
@@ -437,7 +441,7 @@ MPPI_HD float apply_controls_q(LStep &sc, float lambda, bool abs_cost, int nu, i
         const bool on = c < nu;
         u[c] = on ? v : 0.f;
         const float d = v - r.Ut[c];
-        if (on && leader) du[(unsigned)(t * nu + c) * (unsigned)K + (unsigned)k] = d;
+        if (on) du[(unsigned)(t * nu + c) * (unsigned)K + (unsigned)k] = d;
         const float term = r.Ut[c] * d * is.v[c];  // inv_sigma is zero beyond nu
         ctrl += lambda * (abs_cost ? fabsf(term) : term);
     }
@@ -503,7 +507,8 @@ MPPI_HD QF quad_rollout(M &m0, CCfg &cfg0, CCost &cost0, LStep &sc, const float 
             QF p = pl;
             if (viz_link != link || !need_link) quad_link_pose<T>(*launder(mp), P, viz_link, R, p);
 #if defined(__HIP_DEVICE_COMPILE__)
-            if (viz_lane) viz[((size_t)t * 3 + row) * K + k] = p;  // lane r stores component r
+            (void)viz_lane;  // lane 3 mirrors lane 0 (same component, same address): a plain store, no exec-mask region
+            viz[((unsigned)(t * 3 + row)) * (unsigned)K + (unsigned)k] = p;  // lane r stores component r
 #else
             for (int r = 0; r < 3; r++) viz[((size_t)t * 3 + r) * K + k] = p.v[r];
 #endif
