@@ -115,7 +115,7 @@ struct DevModel {
     int nb, nl, n_actors, robot_actor, n_rb, robot_first_rb, drive_mode, substeps, gravity_on, nu, floating, n_free;
     float kd, h, g[3], base_m;
     int cmd_identity;  // the command map is the identity (nu == nb, one command per body, unit gain): target = u
-    float pad2;
+    int all_revolute;  // every joint is revolute: the quad rollout runs its compile-time specialisation
     float base_hb[3], base_Ic[6], pad3[3];
     int actor_first_rb[kMaxActors];
     int n_shapes, n_pairs, rnd_seed, n_rnd;

@@ -192,7 +192,9 @@ __global__ __launch_bounds__(kWave) void k_rollout_quad(const DevModel *__restri
     const bool leader = lane4 == 0;
     float s = INFINITY;
     if (live) {
-        s = quad_rollout<T>(lm, *(CCfg *)cfg, *(CCost *)cost, sc, x0_dof, x0_root, eps, prior, du, viz, k, leader, quad_row(), lane4 < 3);
+        // one wave-uniform branch picks the instruction stream specialised for an all-revolute tree
+        if (((CModel *)m)->all_revolute) s = quad_rollout<T, 0>(lm, *(CCfg *)cfg, *(CCost *)cost, sc, x0_dof, x0_root, eps, prior, du, viz, k, leader, quad_row(), lane4 < 3);
+        else s = quad_rollout<T, -1>(lm, *(CCfg *)cfg, *(CCost *)cost, sc, x0_dof, x0_root, eps, prior, du, viz, k, leader, quad_row(), lane4 < 3);
         if (leader) S[k] = s;
     }
     quad_record(*(CCfg *)cfg, s, live && leader, du, chunk * 16, partials + (size_t)chunk * (2 + cfg->H * cfg->nu));

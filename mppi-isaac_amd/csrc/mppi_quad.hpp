@@ -120,17 +120,24 @@ MPPI_HD QSV qmul(const QAI &A, const QSV &x) {
 }
 MPPI_HD QF qdot6(const QSV &p, const QSV &q) { return qsum(p.a * q.a + p.l * q.l); }
 
-template <class T>
+// JT: joint types known at compile time (0: every joint is revolute, -1: read per joint from the model).  The kernel picks
+// the instantiation with ONE wave-uniform branch; inside, an all-revolute arm then has no per-joint type test at all
+// (each was a compare on a VGPR-resident uniform value plus an exec-mask region or a select).
+template <class T, int JT = -1>
 struct QPose {
     QM3 R[T::NB ? T::NB : 1];
     QF p[T::NB ? T::NB : 1];
     int jt[T::NB ? T::NB : 1];
     QM3 Rb;
     QF pb;
+    MPPI_HD bool revolute(int i) const {
+        if constexpr (JT == 0) return true;
+        else return jt[i] == 0;
+    }
 };
 
-template <class T, class M>
-MPPI_HD void quad_fk(M &m, const QF *q, QPose<T> &P) {
+template <class T, class M, int JT>
+MPPI_HD void quad_fk(M &m, const QF *q, QPose<T, JT> &P) {
     // the 64-byte constant block of body i+1 is requested before body i is computed, so its scalar-load
     // latency hides under ~100 VALU instructions instead of stalling the (only) wave of this SIMD
     // all kinematic blocks are requested up front (LDS returns in order, so body i only waits for its own
@@ -147,7 +154,7 @@ MPPI_HD void quad_fk(M &m, const QF *q, QPose<T> &P) {
         QM3 RT;
         for (int c = 0; c < 3; c++) RT.c[c] = Rp.c[0] * b.Rt[c] + Rp.c[1] * b.Rt[3 + c] + Rp.c[2] * b.Rt[6 + c];
         const QF pw = pp + Rp.c[0] * b.pt[0] + Rp.c[1] * b.pt[1] + Rp.c[2] * b.pt[2];
-        if (b.jtype == 0) {
+        if (JT == 0 || b.jtype == 0) {
             QF s, c;
             qsincos(q[i], s, c);
             P.R[i].c[0] = c * RT.c[0] + s * RT.c[1];
@@ -161,10 +168,10 @@ MPPI_HD void quad_fk(M &m, const QF *q, QPose<T> &P) {
     });
 }
 
-template <class T, int i>
-MPPI_HD QSV quad_subspace(const QPose<T> &P) {
+template <class T, int i, int JT>
+MPPI_HD QSV quad_subspace(const QPose<T, JT> &P) {
     const QF az = P.R[i].c[2];  // third column of R: component r lives in lane r's row
-    if (P.jt[i] == 0) return {az, qcross(P.p[i], az)};
+    if (P.revolute(i)) return {az, qcross(P.p[i], az)};
     return {qrep(0.f), az};
 }
 
@@ -174,8 +181,8 @@ struct JointLimits {  // wave-uniform per-joint limits, cached from block 1 whil
     int limited;
 };
 
-template <class T, class M>
-MPPI_HD void quad_aba(M &m, const QPose<T> &P, const QF *qd, const QF *tau_exp, const QF *kdh, QF *qdd, JointLimits *lim) {
+template <class T, class M, int JT>
+MPPI_HD void quad_aba(M &m, const QPose<T, JT> &P, const QF *qd, const QF *tau_exp, const QF *kdh, QF *qdd, JointLimits *lim) {
     constexpr int NB = T::NB;
     QSV v[NB], U[NB], pacc[NB], cb[NB];
     QF Sl[NB];  // linear part of the joint subspace (the angular part is the third column of R)
@@ -208,7 +215,7 @@ MPPI_HD void quad_aba(M &m, const QPose<T> &P, const QF *qd, const QF *tau_exp, 
         const BodyK1 &b = blk[i];
         lim[i] = {b.effort, b.lower, b.upper, b.vmax, b.limited};
         const QM3 &R = P.R[i];
-        const QSV S = {P.jt[i] == 0 ? R.c[2] : zero, Sl[i]};
+        const QSV S = {P.revolute(i) ? R.c[2] : zero, Sl[i]};
         // rigid inertia about the world origin: I_O = R Ic R^T + m(|cw|^2 1 - cw cw^T), h = m cw
         const QF h = R.c[0] * b.hb[0] + R.c[1] * b.hb[1] + R.c[2] * b.hb[2] + b.m * P.p[i];
         QF Tr[3];
@@ -267,7 +274,7 @@ MPPI_HD void quad_aba(M &m, const QPose<T> &P, const QF *qd, const QF *tau_exp, 
     static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
         constexpr int i = ic;
         constexpr int par = T::par[i];
-        const QSV S = {P.jt[i] == 0 ? P.R[i].c[2] : zero, Sl[i]};
+        const QSV S = {P.revolute(i) ? P.R[i].c[2] : zero, Sl[i]};
         QSV ap = a0;
         if constexpr (par >= 0) ap = {a[par < 0 ? 0 : par].a + cb[i].a, a[par < 0 ? 0 : par].l + cb[i].l};
         const QF dd = (u[i] - qdot6(U[i], ap)) * invd[i];
@@ -277,8 +284,8 @@ MPPI_HD void quad_aba(M &m, const QPose<T> &P, const QF *qd, const QF *tau_exp, 
 }
 
 // base pose of the (fixed) robot from its root row, distributed over the quad
-template <class T, class M>
-MPPI_HD void quad_base(M &m, const float *root, QPose<T> &P) {
+template <class T, class M, int JT>
+MPPI_HD void quad_base(M &m, const float *root, QPose<T, JT> &P) {
     const float *rs = root + 13 * m.robot_actor;
     const M3 R = quat_to_R(rs + 3);
     P.pb = qsel(rs[0], rs[1], rs[2]);
@@ -287,8 +294,8 @@ MPPI_HD void quad_base(M &m, const float *root, QPose<T> &P) {
 
 // One simulator step.  P must hold the forward kinematics of q on entry (base pose included) and holds the
 // forward kinematics of the NEW q on exit: the pose computed for the cost / next step is never recomputed.
-template <class T, class M>
-MPPI_HD void quad_step(M &m0, QPose<T> &P, QF *q, QF *qd, const QF *target) {
+template <class T, class M, int JT>
+MPPI_HD void quad_step(M &m0, QPose<T, JT> &P, QF *q, QF *qd, const QF *target) {
     constexpr int NB = T::NB;
     M *mp = &m0;
     for (int s = 0; s < m0.substeps; s++) {
@@ -337,8 +344,8 @@ MPPI_HD void quad_step(M &m0, QPose<T> &P, QF *q, QF *qd, const QF *target) {
 }
 
 // world pose of link l: row r of R (standard) and component r of p
-template <class T, class M>
-MPPI_HD void quad_link_pose(M &m, const QPose<T> &P, int l, QM3 &R, QF &p) {
+template <class T, class M, int JT>
+MPPI_HD void quad_link_pose(M &m, const QPose<T, JT> &P, int l, QM3 &R, QF &p) {
     auto &L = m.l[l];
     const int body = L.body;
     const float wb = body < 0 ? 1.f : 0.f;
@@ -450,7 +457,7 @@ MPPI_HD float apply_controls_q(LStep &sc, float lambda, bool abs_cost, int nu, i
 
 // Whole-horizon rollout of the sample owned by this quad.  Every lane of the quad returns the same S.
 // `leader` is true in exactly one lane of the quad (it performs the du store); lanes 0..2 store viz.
-template <class T, class M>
+template <class T, int JT, class M>
 MPPI_HD QF quad_rollout(M &m0, CCfg &cfg0, CCost &cost0, LStep &sc, const float *dof0, const float *root, const float *eps,
                         const float *prior, float *du, float *viz, int k, bool leader, int row, bool viz_lane) {
     constexpr int NB = T::NB;
@@ -470,7 +477,7 @@ MPPI_HD QF quad_rollout(M &m0, CCfg &cfg0, CCost &cost0, LStep &sc, const float 
     });
     QF S = qrep(0.f);
     float ctrl = 0.f, disc = 1.f;
-    QPose<T> P;  // forward kinematics of the current q, carried across the whole horizon
+    QPose<T, JT> P;  // forward kinematics of the current q, carried across the whole horizon
     quad_base<T>(m0, root, P);
     quad_fk<T>(m0, q, P);
     M *mp = &m0;

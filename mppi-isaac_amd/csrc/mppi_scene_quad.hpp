@@ -161,7 +161,7 @@ MPPI_HD void quad_aba_scene(M &m, const QPose<T> &P, const QSV &vbase, const QF 
         constexpr int par = T::par[i];
         const BodyK1 &b = blk[i];
         lim[i] = {b.effort, b.lower, b.upper, b.vmax, b.limited};
-        const QSV S = {P.jt[i] == 0 ? P.R[i].c[2] : zero, Sl[i]};
+        const QSV S = {P.revolute(i) ? P.R[i].c[2] : zero, Sl[i]};
         QAI A;
         QSV pA;
         QF h;
@@ -218,7 +218,7 @@ MPPI_HD void quad_aba_scene(M &m, const QPose<T> &P, const QSV &vbase, const QF 
     static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
         constexpr int i = ic;
         constexpr int par = T::par[i];
-        const QSV S = {P.jt[i] == 0 ? P.R[i].c[2] : zero, Sl[i]};
+        const QSV S = {P.revolute(i) ? P.R[i].c[2] : zero, Sl[i]};
         const QSV apar = par < 0 ? a0 : a[par < 0 ? 0 : par];
         const QSV ap = {apar.a + cb[i].a, apar.l + cb[i].l};
         const QF dd = (u[i] - qdot6(U[i], ap)) * invd[i];

@@ -59,7 +59,8 @@ int emu_rollout_quad(const mppi_model_t *model, const mppi_config_t *cfg, const 
         std::memset(&sc, 0, sizeof sc);
         for (int j = 0; j < step_const_count(c); j++) reinterpret_cast<float *>(&sc)[j] = step_const_entry(c, k, root0, U, j);
         for (int s = 0; s < c.K; s++) {
-            QF r = quad_rollout<T>(m, c, k, sc, dof0, root0, eps, prior, du, viz ? v.data() : nullptr, s, true, 0, true);
+            QF r = m.all_revolute ? quad_rollout<T, 0>(m, c, k, sc, dof0, root0, eps, prior, du, viz ? v.data() : nullptr, s, true, 0, true)
+                                  : quad_rollout<T, -1>(m, c, k, sc, dof0, root0, eps, prior, du, viz ? v.data() : nullptr, s, true, 0, true);
             S[s] = r.v[0];
             if (r.v[1] != r.v[0] || r.v[2] != r.v[0] || r.v[3] != r.v[0]) S[s] = NAN;  // replicated scalars must agree across the quad
         }
