@@ -400,11 +400,15 @@ MPPI_HD void load_controls(CCfg &cfg, const float *U, const float *eps, const fl
         const unsigned row = (unsigned)(t * nu + cc);
         r.Ut[c] = U[row];
         r.e[c] = eps[row * (unsigned)K + (unsigned)k];
-        r.pr[c] = has_prior ? prior[row] : 0.f;
+        r.pr[c] = 0.f;
+    }
+    if (has_prior) {  // ONE uniform branch for the whole row (rare: use_priors)
+#pragma unroll
+        for (int c = 0; c < MAXC; c++) r.pr[c] = prior[t * nu + (c < nu ? c : nu - 1)];
     }
 }
 template <int MAXC = kMaxNu>
-MPPI_HD float apply_controls(CCfg &cfg, const ControlRows<MAXC> &r, int t, int k, bool is_null, bool is_prior, bool leader, float *du, float *u) {
+MPPI_HD float apply_controls(CCfg &cfg, const ControlRows<MAXC> &r, int t, int k, bool is_null, bool is_prior, bool /*leader*/, float *du, float *u) {
     const int K = cfg.K, nu = cfg.nu;
 #pragma unroll
     for (int c = MAXC; c < kMaxNu; c++) u[c] = 0.f;
@@ -419,7 +423,9 @@ MPPI_HD float apply_controls(CCfg &cfg, const ControlRows<MAXC> &r, int t, int k
         const bool on = c < nu;
         u[c] = on ? v : 0.f;
         const float d = v - r.Ut[c];
-        if (on && leader) du[(unsigned)(t * nu + c) * (unsigned)K + (unsigned)k] = d;
+        // (`leader` is not consulted: lanes that share a sample hold the same du and store it to the same address - plain
+        // stores under a uniform condition instead of one exec-mask region per control)
+        if (on) du[(unsigned)(t * nu + c) * (unsigned)K + (unsigned)k] = d;
         const float term = r.Ut[c] * d * is.v[c];  // inv_sigma is zero beyond nu
         ctrl += cfg.lambda * (cfg.noise_abs_cost ? fabsf(term) : term);
     }
