@@ -240,22 +240,27 @@ __device__ __forceinline__ void combine_update(CCfg &cfg, const float *__restric
     float eta = s_red[lane & 15];
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) eta += __shfl_xor(eta, o, kWave);
-    // N[j] = sum_r scale_r * recs[r][2 + j]: eight 128-thread groups take the records r = g, g + 8, ...; the loop is
-    // unrolled so that eight independent (L2-resident) loads are in flight per thread instead of a dependent chain
-    const int g = tid >> 7, jj = tid & 127;
-    for (int j = jj; j < HN; j += 128) {
-        float N0 = 0.f;
+    // N[j] = sum_r scale_r * recs[r][2 + j]: the block is cut into G groups of HN threads (one thread per row j, ONE pass
+    // whatever HN is); group g takes the records r = g, g + G, ...; the loop is unrolled so that eight independent
+    // (L2-resident) loads are in flight per thread instead of a dependent chain
+    const int G = HN <= kCombineThreads ? (kCombineThreads / HN < kCombineGroups ? kCombineThreads / HN : kCombineGroups) : 1;
+    {
+        const int g = tid / HN, j0 = tid - g * HN;
+        if (g < G)
+            for (int j = j0; j < HN; j += kCombineThreads) {  // (more than one trip only if HN > 1024, then G = 1)
+                float N0 = 0.f;
 #pragma unroll 8
-        for (int r = g; r < nrec; r += kCombineGroups) {
-            float sc;
-            if (r < kMaxScale) sc = s_scale[r];
-            else {  // more records than the LDS table holds (K > 65536 on one GPU): recompute the rescaling factor
-                const float er = recs[(size_t)r * RF + 1];
-                sc = er > 0.f ? __expf(-(recs[(size_t)r * RF] - beta) * cfg.inv_lambda) : 0.f;
+                for (int r = g; r < nrec; r += G) {
+                    float sc;
+                    if (r < kMaxScale) sc = s_scale[r];
+                    else {  // more records than the LDS table holds (K > 65536 on one GPU): recompute the rescaling factor
+                        const float er = recs[(size_t)r * RF + 1];
+                        sc = er > 0.f ? __expf(-(recs[(size_t)r * RF] - beta) * cfg.inv_lambda) : 0.f;
+                    }
+                    N0 += recs[(size_t)r * RF + 2 + j] * sc;
+                }
+                s_part[g][j] = N0;
             }
-            N0 += recs[(size_t)r * RF + 2 + j] * sc;
-        }
-        s_part[g][j] = N0;
     }
     __syncthreads();
     float *s_U = s_part[0];  // reused for the updated nominal after the group sums are consumed
@@ -263,8 +268,7 @@ __device__ __forceinline__ void combine_update(CCfg &cfg, const float *__restric
     if (tid < 256)
         for (int j = tid; j < HN; j += 256) {
             float N = 0.f;
-#pragma unroll
-            for (int gg = 0; gg < kCombineGroups; gg++) N += s_part[gg][j];
+            for (int gg = 0; gg < G; gg++) N += s_part[gg][j];
             if (mode == 0) out[2 + j] = N;
             else {
                 Unew = U[j] + (eta > 0.f ? N / eta : 0.f);
