@@ -401,7 +401,7 @@ __global__ __launch_bounds__(kWave) void k_rollout_scene_quad(const DevModel *__
     // The robot part of the model (header, bodies, links: 4.3 KB) is staged in LDS for the quad-layout kinematics and
     // articulated-body solve; shapes, pairs and free bodies stay behind the scalar cache (staging the WHOLE model was
     // measured slower: the contact loop's constants then occupy VGPRs of code that already spills)
-    constexpr int kModelBytes = (int)((offsetof(DevModel, fr) + 15) / 16 * 16);
+    constexpr int kModelBytes = (int)((offsetof(DevModel, sh) + 15) / 16 * 16);  // header, bodies, links, free bodies
     __shared__ __attribute__((aligned(64))) uint4 s_model[kModelBytes / 16];
     for (int i = threadIdx.x; i < kModelBytes / 16; i += kWave) s_model[i] = reinterpret_cast<const uint4 *>(m)[i];
     __syncthreads();
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(kWave) void k_sim_step_scene_quad(const DevModel *_
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NB = T::NB;
-    constexpr int kModelBytes = (int)((offsetof(DevModel, fr) + 15) / 16 * 16);
+    constexpr int kModelBytes = (int)((offsetof(DevModel, sh) + 15) / 16 * 16);  // header, bodies, links, free bodies
     __shared__ __attribute__((aligned(64))) uint4 s_model[kModelBytes / 16];
     for (int i = threadIdx.x; i < kModelBytes / 16; i += kWave) s_model[i] = reinterpret_cast<const uint4 *>(m)[i];
     __syncthreads();
@@ -721,7 +721,7 @@ __global__ __launch_bounds__(kWave) void k_sim_step_quad(const DevModel *__restr
                                                          float *__restrict__ du, float *__restrict__ ctrl, float *__restrict__ q_, float *__restrict__ qd_) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NB = T::NB;
-    constexpr int kModelBytes = (int)((offsetof(DevModel, fr) + 15) / 16 * 16);
+    constexpr int kModelBytes = (int)((offsetof(DevModel, sh) + 15) / 16 * 16);  // header, bodies, links, free bodies
     __shared__ __attribute__((aligned(64))) uint4 s_model[kModelBytes / 16];
     for (int i = threadIdx.x; i < kModelBytes / 16; i += kWave) s_model[i] = reinterpret_cast<const uint4 *>(m)[i];
     __syncthreads();
