@@ -85,7 +85,7 @@ class MPPIisaacPlanner(object):
 
     def reset_rollout_sim(self, dof_state_tensor, root_state_tensor, rigid_body_state_tensor=None):
         self.sim.visualize_link_buffer = []
-        self.sim.set_state_from_env0(bytes_to_torch(dof_state_tensor), bytes_to_torch(root_state_tensor))
+        self.sim.set_state_from_env0(bytes_to_torch(dof_state_tensor, map_location="cpu"), bytes_to_torch(root_state_tensor, map_location="cpu"))
 
     def compute_action_tensor(self, dof_state_tensor, root_state_tensor):
         self.objective.reset()
