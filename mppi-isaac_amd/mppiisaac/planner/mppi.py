@@ -224,9 +224,15 @@ class MPPIPlanner:
         return torch.from_numpy(out)
 
     def set_fused_cost(self, cost: Optional[capi.Cost]):
+        """called before every command (the Objective's weights are mutable): the struct is uploaded only when it changed"""
         self._fused_cost = cost
         if cost is not None:
-            capi.check(self._lib, self._lib.mppi_set_cost(self._ctx, C.byref(cost)))
+            blob = bytes(cost)
+            if blob != getattr(self, "_fused_cost_blob", None):
+                capi.check(self._lib, self._lib.mppi_set_cost(self._ctx, C.byref(cost)))
+                self._fused_cost_blob = blob
+        else:
+            self._fused_cost_blob = None
 
     # -- one control iteration ---------------------------------------------------------------
     def command(self, state=None) -> torch.Tensor:
