@@ -503,6 +503,23 @@ class IsaacGymWrapper:
             raise ValueError(f"command has {u.shape[-1]} entries, expected {self.scene.nu}")
         self._pending_cmd = u.contiguous()
 
+    # per-DOF targets set directly (reference :402-406; used by examples/*/tuning.py and examples/anymal/world.py).  The step
+    # kernels take COMMANDS (nu columns, scattered by the command map), so these are available where one command drives
+    # one DOF with unit gain - every robot but the differential-drive bases.
+    def _latch_dof_targets(self, u, mode: str):
+        if self.scene.robot.dof_mode != mode:
+            raise ValueError(f"the robot is driven in '{self.scene.robot.dof_mode}' mode, not '{mode}'")
+        if self.scene.nu != self.scene.n_dof or any(t[0][1] != 1.0 or t[1][1] != 0.0 for t in self.scene.cmd_terms):
+            raise NotImplementedError("per-DOF targets bypass the differential-drive command map, which the step kernels apply; "
+                                      "use apply_robot_cmd((v, omega, ...))")
+        self.apply_robot_cmd(u)
+
+    def set_dof_velocity_target_tensor(self, u):
+        self._latch_dof_targets(u, "velocity")
+
+    def set_dof_actuation_force_tensor(self, u):
+        self._latch_dof_targets(u, "effort")
+
     def step(self):
         u = self._pending_cmd
         if u is None:

@@ -365,6 +365,29 @@ def test_world_sim_matches_oracle_and_reference_layouts(lib, oracle64):
     assert len(sim.visualize_link_buffer) == 10 and tuple(sim.visualize_link_buffer[0].shape) == (1, 3)
 
 
+def test_direct_dof_targets_equal_commands_for_unit_maps(lib):
+    """set_dof_velocity_target_tensor (reference isaacgym_wrapper.py:402-403) on an arm = apply_robot_cmd; a
+    differential-drive base refuses it (its command map is not the identity)"""
+    from mppiisaac.planner.isaacgym_wrapper import IsaacGymWrapper
+    from mppiisaac.utils.config_store import load_config
+    cfg = load_config({"defaults": [{"mppi": "panda"}, {"isaacgym": "normal"}], "actors": ["panda_stick", "goal"],
+                       "initial_actor_positions": [[0.0, 0.0, 0.0]], "nx": 14})
+    a = IsaacGymWrapper(cfg.isaacgym, actors=cfg.actors, init_positions=cfg.initial_actor_positions, num_envs=1)
+    b = IsaacGymWrapper(cfg.isaacgym, actors=cfg.actors, init_positions=cfg.initial_actor_positions, num_envs=1)
+    u = torch.tensor([[0.1, -0.2, 0.05, 0.3, -0.1, 0.2, 0.0]], device="cuda")
+    for _ in range(5):
+        a.apply_robot_cmd(u); a.step()
+        b.set_dof_velocity_target_tensor(u); b.step()
+    np.testing.assert_array_equal(a._dof_state.cpu().numpy(), b._dof_state.cpu().numpy())
+    with pytest.raises(ValueError):
+        b.set_dof_actuation_force_tensor(u)                 # the arm is velocity-driven
+    cfgb = load_config({"defaults": [{"mppi": "boxer_push"}, {"isaacgym": "normal"}], "actors": ["boxer", "goal"],
+                        "initial_actor_positions": [[0.0, 0.0, 0.05]], "nx": 4})
+    w = IsaacGymWrapper(cfgb.isaacgym, actors=cfgb.actors, init_positions=cfgb.initial_actor_positions, num_envs=1)
+    with pytest.raises(NotImplementedError):
+        w.set_dof_velocity_target_tensor(torch.zeros((1, 2), device="cuda"))
+
+
 def test_error_paths(lib):
     scene, m, cfg, cost, dof, root = panda_reach(K=64, H=12)
     ctx = C.c_void_p()

@@ -97,6 +97,15 @@ def test_stale_or_foreign_handles_are_reported_not_dereferenced():
     assert lib.mppi_destroy(None) == 0
 
 
+def test_direct_dof_target_setters_exist_with_the_reference_names():
+    """reference isaacgym_wrapper.py:402-406 (examples/*/tuning.py, examples/anymal/world.py call them)"""
+    from mppiisaac.planner.isaacgym_wrapper import IsaacGymWrapper
+    for name in ("set_dof_velocity_target_tensor", "set_dof_actuation_force_tensor", "apply_robot_cmd", "step", "reset_to_initial_poses",
+                 "get_actor_link_by_name", "get_actor_position_by_name", "get_actor_velocity_by_name", "get_actor_orientation_by_name",
+                 "get_actor_contact_forces_by_name", "get_dof_state", "stop_sim", "start_sim"):
+        assert callable(getattr(IsaacGymWrapper, name)), name
+
+
 def test_product_path_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():
