@@ -549,8 +549,43 @@ class IsaacGymWrapper:
     def obstacle_positions(self):
         return torch.index_select(self._root_state, 1, self.obstacle_indices)[:, :, 0:3]
 
+    @property
+    def ostacle_velocities(self):  # (sic: the reference's spelling, isaacgym_wrapper.py:288)
+        return torch.index_select(self._root_state, 1, self.obstacle_indices)[:, :, 7:10]
+
+    obstacle_velocities = ostacle_velocities
+
     def _get_actor_index_by_name(self, name: str):
         return self.scene.actor_index(name)
+
+    def _get_actor_index_by_robot_index(self, robot_idx: int):
+        return int(self.robot_indices[robot_idx])
+
+    # by-index getters of the reference (:297-330); indices may be ints or 0-d / 1-element tensors as there
+    @staticmethod
+    def _as_index(idx) -> int:
+        return int(torch.as_tensor(idx).reshape(-1)[0])
+
+    def get_actor_position_by_actor_index(self, actor_idx):
+        return self._root_state[:, self._as_index(actor_idx), 0:3]
+
+    def get_actor_position_by_robot_index(self, robot_idx: int):
+        return self.get_actor_position_by_actor_index(self._get_actor_index_by_robot_index(robot_idx))
+
+    def get_actor_velocity_by_actor_index(self, idx):
+        return self._root_state[:, self._as_index(idx), 7:10]
+
+    def get_actor_velocity_by_robot_index(self, robot_idx: int):
+        return self.get_actor_velocity_by_actor_index(self._get_actor_index_by_robot_index(robot_idx))
+
+    def get_actor_orientation_by_actor_index(self, idx):
+        return self._root_state[:, self._as_index(idx), 3:7]
+
+    def get_actor_orientation_by_robot_index(self, robot_idx: int):
+        return self.get_actor_orientation_by_actor_index(self._get_actor_index_by_robot_index(robot_idx))
+
+    def get_rigid_body_by_rigid_body_index(self, rigid_body_idx):
+        return self._rigid_body_state[:, self._as_index(rigid_body_idx), :]
 
     def get_actor_position_by_name(self, name: str):
         return self._root_state[:, self.scene.actor_index(name), 0:3]
@@ -644,9 +679,39 @@ class IsaacGymWrapper:
             root[idx[0]] = o
         self._push_single_state(self._dof_state[0].cpu().numpy(), root.cpu().numpy())
 
+    # setters of the reference (:359-397): the root row of one actor in every env; takes effect for the next rollout / step
+    def _set_root_columns(self, actor_idx, lo: int, hi: int, value) -> None:
+        root = self._root_state[0].clone()
+        root[self._as_index(actor_idx), lo:hi] = torch.as_tensor(value, dtype=torch.float32, device=self.device).reshape(-1)[: hi - lo]
+        self._push_single_state(self._dof_state[0].cpu().numpy(), root.cpu().numpy())
+
+    def set_actor_position_by_actor_index(self, position, actor_idx) -> None:
+        self._set_root_columns(actor_idx, 0, 3, position)
+
     def set_actor_position_by_name(self, position, name: str) -> None:
         """Move an actor (e.g. the goal) in every env; takes effect for the next rollout/step."""
-        idx = self.scene.actor_index(name)
-        root = self._root_state[0].clone()
-        root[idx, 0:3] = torch.as_tensor(position, dtype=torch.float32, device=self.device).reshape(-1)[:3]
-        self._push_single_state(self._dof_state[0].cpu().numpy(), root.cpu().numpy())
+        self.set_actor_position_by_actor_index(position, self.scene.actor_index(name))
+
+    def set_actor_position_by_robot_index(self, position, robot_idx) -> None:
+        self.set_actor_position_by_actor_index(position, self._get_actor_index_by_robot_index(robot_idx))
+
+    def set_actor_velocity_by_actor_index(self, velocity, actor_idx) -> None:
+        self._set_root_columns(actor_idx, 7, 10, velocity)
+
+    def set_actor_velocity_by_name(self, velocity, name: str) -> None:
+        self.set_actor_velocity_by_actor_index(velocity, self.scene.actor_index(name))
+
+    def set_actor_velocity_by_robot_index(self, velocity, robot_idx) -> None:
+        self.set_actor_velocity_by_actor_index(velocity, self._get_actor_index_by_robot_index(robot_idx))
+
+    def set_root_state_tensor_by_actor_idx(self, state_tensor, idx) -> None:
+        """whole 13-float root row (pos, quat xyzw, linvel, angvel) of one actor (reference :662-667)"""
+        self._set_root_columns(idx, 0, 13, state_tensor)
+
+    def set_actor_dof_state(self, state) -> None:
+        """`dof_mode: position` path of the reference (:399-400): overwrite the interleaved (q, qd) DOF state"""
+        st = torch.as_tensor(state, dtype=torch.float32).reshape(-1)[: 2 * self.scene.n_dof]
+        self._push_single_state(st.cpu().numpy(), self._root_state[0].cpu().numpy())
+
+    def draw_lines(self, lines) -> None:
+        """viewer call of the reference's world scripts: there is no viewer here; accepted and ignored"""

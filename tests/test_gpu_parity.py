@@ -381,6 +381,23 @@ def test_direct_dof_targets_equal_commands_for_unit_maps(lib):
     np.testing.assert_array_equal(a._dof_state.cpu().numpy(), b._dof_state.cpu().numpy())
     with pytest.raises(ValueError):
         b.set_dof_actuation_force_tensor(u)                 # the arm is velocity-driven
+    # by-index getters / setters of the reference (isaacgym_wrapper.py:297-397)
+    g = a.scene.actor_index("goal")
+    a.set_actor_position_by_actor_index([0.3, 0.2, 0.1], torch.tensor(g, device="cuda"))
+    np.testing.assert_allclose(a.get_actor_position_by_name("goal")[0].cpu().numpy(), [0.3, 0.2, 0.1], atol=1e-7)
+    np.testing.assert_allclose(a.get_actor_position_by_actor_index(g)[0].cpu().numpy(), [0.3, 0.2, 0.1], atol=1e-7)
+    a.set_actor_velocity_by_name([0.0, 0.0, 0.5], "goal")
+    assert float(a.get_actor_velocity_by_actor_index(g)[0, 2]) == pytest.approx(0.5)
+    assert a.get_actor_position_by_robot_index(0).shape == (1, 3) and a.get_actor_orientation_by_robot_index(0).shape == (1, 4)
+    ee = a.scene.rigid_body_index("panda", "panda_ee_tip")
+    np.testing.assert_array_equal(a.get_rigid_body_by_rigid_body_index(ee).cpu().numpy(), a.get_actor_link_by_name("panda", "panda_ee_tip").cpu().numpy())
+    row = torch.tensor([0.1, 0.2, 0.3, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0.0])
+    a.set_root_state_tensor_by_actor_idx(row, g)
+    np.testing.assert_allclose(a._root_state[0, g].cpu().numpy(), row.numpy(), atol=1e-7)
+    st = a._dof_state[0].clone(); st[0] = 0.25
+    a.set_actor_dof_state(st.unsqueeze(0))
+    assert float(a.get_dof_state()[0, 0]) == pytest.approx(0.25)
+    assert a.ostacle_velocities.shape[0] == 1 and a.draw_lines([]) is None
     cfgb = load_config({"defaults": [{"mppi": "boxer_push"}, {"isaacgym": "normal"}], "actors": ["boxer", "goal"],
                         "initial_actor_positions": [[0.0, 0.0, 0.05]], "nx": 4})
     w = IsaacGymWrapper(cfgb.isaacgym, actors=cfgb.actors, init_positions=cfgb.initial_actor_positions, num_envs=1)

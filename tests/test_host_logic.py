@@ -100,7 +100,14 @@ def test_stale_or_foreign_handles_are_reported_not_dereferenced():
 def test_direct_dof_target_setters_exist_with_the_reference_names():
     """reference isaacgym_wrapper.py:402-406 (examples/*/tuning.py, examples/anymal/world.py call them)"""
     from mppiisaac.planner.isaacgym_wrapper import IsaacGymWrapper
-    for name in ("set_dof_velocity_target_tensor", "set_dof_actuation_force_tensor", "apply_robot_cmd", "step", "reset_to_initial_poses",
+    for name in ("get_actor_position_by_actor_index", "get_actor_position_by_robot_index", "get_actor_velocity_by_actor_index",
+                 "get_actor_velocity_by_robot_index", "get_actor_orientation_by_actor_index", "get_actor_orientation_by_robot_index",
+                 "get_rigid_body_by_rigid_body_index", "_get_actor_index_by_robot_index", "set_actor_position_by_actor_index",
+                 "set_actor_position_by_robot_index", "set_actor_velocity_by_actor_index", "set_actor_velocity_by_name",
+                 "set_actor_velocity_by_robot_index", "set_root_state_tensor_by_actor_idx", "set_actor_dof_state", "draw_lines",
+                 "save_root_state", "reset_root_state", "get_saved_root_state", "add_to_envs",
+                 "update_root_state_tensor_by_obstacles", "update_root_state_tensor_by_obstacles_tensor",
+                 "set_dof_velocity_target_tensor", "set_dof_actuation_force_tensor", "apply_robot_cmd", "step", "reset_to_initial_poses",
                  "get_actor_link_by_name", "get_actor_position_by_name", "get_actor_velocity_by_name", "get_actor_orientation_by_name",
                  "get_actor_contact_forces_by_name", "get_dof_state", "stop_sim", "start_sim"):
         assert callable(getattr(IsaacGymWrapper, name)), name
