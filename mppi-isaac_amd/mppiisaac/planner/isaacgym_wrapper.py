@@ -480,6 +480,21 @@ class IsaacGymWrapper:
         dof = interleave_dof_state(q, qdot, self.scene.n_dof)
         self._push_single_state(dof, root)
 
+    def set_state_tensor_by_pos_vel(self, handle, pos, vel):
+        """planar pose (x, y, yaw) and velocity of one actor into its root row (reference :677-693, which writes a
+        misspelled attribute and raises; this is its intended behaviour)"""
+        yaw = float(pos[2])
+        root = self._root_state[0].cpu().numpy().copy()
+        i = self._as_index(handle)
+        root[i, 0:2] = [float(pos[0]), float(pos[1])]
+        root[i, 3:7] = [0.0, 0.0, np.sin(yaw / 2), np.cos(yaw / 2)]
+        root[i, 7:10] = [float(v) for v in vel][:3]
+        self._push_single_state(self._dof_state[0].cpu().numpy(), root)
+
+    def _ik(self, actor, u):
+        """(v, omega) -> (left, right) wheel velocities (reference :510-522)"""
+        return diff_drive_ik(actor, u)
+
     def save_root_state(self):
         self.saved_root_state = self._root_state.clone()
 

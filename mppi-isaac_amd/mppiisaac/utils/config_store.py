@@ -82,3 +82,12 @@ try:  # keep the reference's ConfigStore registration when Hydra is installed
     cs.store(group="isaacgym", name="base_isaacgym", node=IsaacGymConfig)
 except ImportError:
     pass
+
+
+def load_isaacgym_config(name):
+    """reference config_store.py:42-46 composes conf/<name>.yaml through hydra; here the same file goes through
+    load_config (hydra / omegaconf are optional in this package)"""
+    import os
+    conf = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "conf")
+    path = os.path.join(conf, name if name.endswith(".yaml") else name + ".yaml")
+    return load_config(path)

@@ -39,3 +39,9 @@ def load_asset(actor_cfg: ActorWrapper) -> dict:
     raise FileNotFoundError(
         f"no compiled model for urdf_file='{actor_cfg.urdf_file}' under {COMPILED_DIR}; compile it with "
         "mppiisaac.backend.urdf_compile.compile_urdf (tools/compile_models.py) and rebuild the HIP library")
+
+
+def add_ground_plane(gym=None, sim=None) -> None:
+    """reference isaacgym_utils.py:61-68 adds a z-up plane with friction 1 to the PhysX scene.  Here the ground is part of
+    every contact scene by construction (Scene._contact_scene: GROUND_FRICTION = 1.0); kept as a no-op for callers."""
+    return None
