@@ -410,11 +410,12 @@ MPPI_HD void box_points_in_box(const Gains &P, V3 yc, const V3 *col, const Shape
     // share a wavefront diverge on WHICH points hit - compacting the hits makes the wavefront pay for the
     // largest hit count of a lane instead of for every point that hits in any lane.
     unsigned hits = 0;
-    int it = 0;
-    for (int c = sp.sub; c < 27; c += sp.n, it++) {
+    const int trips = (27 + sp.n - 1) / sp.n;  // the same trip count in every lane: a scalar loop, no exec-mask back edge
+    for (int it = 0; it < trips; it++) {
+        const int c = sp.sub + it * sp.n;
         V3 y;
         float dx, dy, dz;
-        if (point(c, y, dx, dy, dz)) hits |= 1u << it;
+        if (point(c, y, dx, dy, dz) && c < 27) hits |= 1u << it;
     }
     while (hits != 0) {
         const int j = __builtin_ctz(hits);

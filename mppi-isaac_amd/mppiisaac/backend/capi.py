@@ -136,7 +136,7 @@ def load_library(path: str = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("MPPI_HIP_LIB") or LIB_PATH  # MPPI_HIP_LIB: a variant build for same-box A/B timing (tools/exp/ab_build.sh)
     if not os.path.exists(p):
         raise MppiHipError(
             f"{p} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "

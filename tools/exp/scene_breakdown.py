@@ -6,7 +6,7 @@ import numpy as np, torch
 from mppiisaac.backend import capi
 from scenes import boxer_push, panda_pick
 
-lib = capi.load_library()
+lib = capi.load_library(sys.argv[1] if len(sys.argv) > 1 else None)  # optional: a variant .so (tools/exp/ab_build.sh)
 
 def run(name, make, K, H, edit=None):
     scene, m, cfg, cost, dof, root = make(K=K, H=H)
