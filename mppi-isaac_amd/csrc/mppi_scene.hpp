@@ -16,6 +16,8 @@
 // that shapes can address them with run-time indices; the host harness uses a plain array instead.
 #pragma once
 #include "mppi_device.hpp"
+#include <stdio.h>
+#include <stdlib.h>
 
 namespace mppi {
 
@@ -251,6 +253,11 @@ __device__ __forceinline__ float quad_allsum(float x) {
     x += scene_dpp<0x4E>(x);  // quad_perm [2,3,0,1]
     return x;
 }
+__device__ __forceinline__ unsigned quad_allor(unsigned x) {
+    x |= (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xf, 0xf, true);
+    x |= (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xf, 0xf, true);
+    return x;
+}
 __device__ __forceinline__ void quad_reduce(PairAcc &a) {
     a.any = quad_allsum(a.any ? 1.f : 0.f) > 0.f;
     a.f.a = {quad_allsum(a.f.a.x), quad_allsum(a.f.a.y), quad_allsum(a.f.a.z)};
@@ -460,6 +467,81 @@ MPPI_HD void sphere_in_box(const Gains &P, V3 ps, float r, const ShapeW &Y, cons
     contact_point(P, pw, sign * mul(Y.R, nl), depth, vA, vB, acc);
 }
 
+constexpr int kDealtBroadPhaseMin = 16;  // candidate pairs above which the quad kernels deal the broad phase over the lanes
+// Poses, per-sample sizes and broad-phase verdict of one candidate pair.
+struct PairPose {
+    ShapeW wa, wb;
+    float hA[3], hB[3];
+    ActorDraw da, db;
+    bool robotA, robotB;
+    BoxRel rel;  // (box-box pairs only)
+};
+// Broad phase: six-axis SAT for two boxes, otherwise the bounding sphere of one shape against the other shape's
+// box grown by that radius (both ways).  Conservative by construction (a margin covers rounding), so skipping
+// changes no result; it removes the 2 x 26 feature-point tests of the many link-vs-table / link-vs-block
+// pairs that are nowhere near each other.  Returns true when the two shapes are certainly apart.
+template <class T, bool kCached, class M>
+MPPI_HD bool pair_broad_phase(M &m, int ip, const PairGeom &G, const float *root, const LMem &L, PairPose &o) {
+    const bool has_b = G.b >= 0;
+    if constexpr (kCached) {
+        o.wa = shape_cached<T>(m, G.a, L);
+        if (has_b) o.wb = shape_cached<T>(m, G.b, L);
+    } else {
+        o.wa = shape_world(m.sh[G.a], root, L);
+        if (has_b) o.wb = shape_world(m.sh[G.b], root, L);
+    }
+    const ShapeW &wa = o.wa, &wb = o.wb;
+    float *hA = o.hA, *hB = o.hB;
+    for (int j = 0; j < 3; j++) { hA[j] = G.hA[j]; hB[j] = G.hB[j]; }
+    o.da = {{0.f, 0.f, 0.f}, 1.f, 0.f};
+    o.db = {{0.f, 0.f, 0.f}, 1.f, 0.f};
+    o.robotA = true;
+    o.robotB = true;
+    if (G.rnd) {  // this sample's own size of the noisy actors in the pair (friction and mass scale: see contact_forces)
+        auto &Cn = m.pr[ip].c;
+        o.robotA = Cn.robotA != 0;
+        o.robotB = Cn.robotB != 0 || !has_b;
+        if (!o.robotA) {
+            o.da = actor_draw<T>(m, Cn.actorA, L);
+            if (G.typeA == 0) for (int j = 0; j < 3; j++) hA[j] += 0.5f * o.da.d[j];
+            else if (G.typeA == 1) hA[0] += o.da.d[0];
+        }
+        if (!o.robotB) {
+            o.db = actor_draw<T>(m, Cn.actorB, L);
+            if (G.typeB == 0) for (int j = 0; j < 3; j++) hB[j] += 0.5f * o.db.d[j];
+            else if (G.typeB == 1) hB[0] += o.db.d[0];
+        }
+    }
+    const int typeA = G.typeA, typeB = G.typeB;
+    bool apart = false;
+    if (has_b && typeA == 0 && typeB == 0) {
+        o.rel = box_relative(wa, wb);
+        apart = boxes_apart(o.rel, hA, hB, 1e-4f);
+    } else {
+        constexpr float kMargin = 1e-4f;
+        const float rA = typeA == 0 ? fsqrt(hA[0] * hA[0] + hA[1] * hA[1] + hA[2] * hA[2]) * 1.000001f : hA[0];  // (rounded up: conservative)
+        if (!has_b) {
+            apart = typeA != 2 && wa.p.z > rA + kMargin;
+        } else if (typeA != 2 && typeB != 2) {
+            const float rB = typeB == 0 ? fsqrt(hB[0] * hB[0] + hB[1] * hB[1] + hB[2] * hB[2]) * 1.000001f : hB[0];
+            const V3 d = wa.p - wb.p;
+            if (typeB == 0) {
+                const V3 y = {wb.R.a[0] * d.x + wb.R.a[3] * d.y + wb.R.a[6] * d.z, wb.R.a[1] * d.x + wb.R.a[4] * d.y + wb.R.a[7] * d.z,
+                              wb.R.a[2] * d.x + wb.R.a[5] * d.y + wb.R.a[8] * d.z};
+                apart = fabsf(y.x) > hB[0] + rA + kMargin || fabsf(y.y) > hB[1] + rA + kMargin || fabsf(y.z) > hB[2] + rA + kMargin;
+            } else {
+                apart = dot(d, d) > (rA + rB + kMargin) * (rA + rB + kMargin);
+            }
+            if (typeA == 0) {
+                const V3 x = {wa.R.a[0] * d.x + wa.R.a[3] * d.y + wa.R.a[6] * d.z, wa.R.a[1] * d.x + wa.R.a[4] * d.y + wa.R.a[7] * d.z,
+                              wa.R.a[2] * d.x + wa.R.a[5] * d.y + wa.R.a[8] * d.z};
+                apart = apart || fabsf(x.x) > hA[0] + rB + kMargin || fabsf(x.y) > hA[1] + rB + kMargin || fabsf(x.z) > hA[2] + rB + kMargin;
+            }
+        }
+    }
+    return apart;
+}
+
 // All candidate pairs of the scene -> per-frame wrench / damping accumulators and net contact forces.
 template <class T, int SPLIT = kSplitNone, class M = CModel>
 MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned &acc_dirty, unsigned &cf_dirty, Split split = Split{0, 1}) {
@@ -478,7 +560,35 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
     const SV zero = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
     constexpr bool kCached = SPLIT != kSplitNone;
     if constexpr (kCached) shape_cache_update<T>(m, root, L, SPLIT == kSplitEmulate ? Split{0, 1} : split, false);
+    // Dealt broad phase (quad kernels of the larger trees, whose scenes carry a candidate pair per link and obstacle):
+    // lane r of the quad tests the pairs r, r + 4, ... on its own and the verdicts are OR-ed over the quad; the pair
+    // loop then visits only the survivors.  pair_broad_phase() restates the test of the loop body term by term - the
+    // verdicts must agree bit for bit (tests/test_gpu_parity.py compares contact scenes with the oracle either way).
+    // Pays when most pairs are apart in every sample of a wavefront: 23-pair gripper scene -17 % away from contact.
+    unsigned alive_lo = ~0u, alive_hi = ~0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (SPLIT == kSplitQuad && (T::NB > 4)) {
+        if (m.n_pairs > kDealtBroadPhaseMin) {
+            alive_lo = alive_hi = 0u;
+            const int trips = (m.n_pairs + split.n - 1) / split.n;
+            for (int it = 0; it < trips; it++) {
+                const int ip = it * split.n + split.sub;
+                const int ic = ip < m.n_pairs ? ip : m.n_pairs - 1;
+                const PairGeom G = load_block<PairGeom>(m.pr[ic].g);
+                PairPose pp;
+                const bool apart = pair_broad_phase<T, true>(m, ic, G, root, L, pp);
+                const unsigned bit = (!apart && ip < m.n_pairs) ? 1u << (ip & 31) : 0u;
+                alive_lo |= ip < 32 ? bit : 0u;
+                alive_hi |= ip < 32 ? 0u : bit;
+            }
+            alive_lo = quad_allor(alive_lo);
+            alive_hi = quad_allor(alive_hi);
+        }
+    }
+#endif
     for (int ip = 0; ip < m.n_pairs; ip++) {
+        if constexpr (SPLIT == kSplitQuad && (T::NB > 4))
+            if ((((ip < 32 ? alive_lo : alive_hi) >> (ip & 31)) & 1u) == 0u) continue;
         // geometry block of the pair: all the broad phase needs (no dependent loads of the two shape records)
         const PairGeom G = load_block<PairGeom>(m.pr[ip].g);
         const bool has_b = G.b >= 0;
@@ -540,6 +650,15 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
                 }
             }
         }
+#if !defined(__HIP_DEVICE_COMPILE__)
+        {  // host builds (tests/hostemu): the restated test of the dealt broad phase must give the same verdict
+            PairPose chk;
+            if (pair_broad_phase<T, kCached>(m, ip, G, root, L, chk) != apart) {
+                fprintf(stderr, "mppi_scene.hpp: pair_broad_phase disagrees with contact_forces on pair %d\n", ip);
+                abort();
+            }
+        }
+#endif
         if (apart) continue;
         // contact law of the survivors: second block of the pair
         const PairGain Cg = load_block<PairGain>(m.pr[ip].c);
