@@ -1,0 +1,1 @@
+"""ctypes binding of the C-ABI (include/mppi_hip.h) and the URDF -> packed-model compiler."""

@@ -1,0 +1,1 @@
+"""Host-side mirror of the reference planner interface: MPPIisaacPlanner, MPPIPlanner, IsaacGymWrapper."""

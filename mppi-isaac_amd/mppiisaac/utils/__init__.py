@@ -1,0 +1,1 @@
+"""Config store, tensor transport, planner RPC and actor helpers (reference mppiisaac/utils)."""
