@@ -22,7 +22,9 @@
  * The dynamics follow SURVEY.md section B (Featherstone articulated-body algorithm, implicit
  * velocity-level joint drive, semi-implicit Euler), the MPPI arithmetic SURVEY.md section A.
  * The boundary logic that IS importable from the reference (command scatter, diff-drive IK,
- * state packing, quaternion_to_yaw) is pinned by tests/golden/ (tools/make_golden.py).
+ * state packing, quaternion_to_yaw) is pinned by tests/golden/ (tools/make_golden.py), and so are
+ * the stage costs: orc_cost reproduces Objective.compute_cost of examples/{panda,boxer_push,
+ * panda_pick}/planner.py on recorded simulator answers (tests/golden/objective_costs.json).
  *
  * Formulation: textbook body-coordinate spatial algebra with explicit 6x6 matrices
  * (Featherstone, Rigid Body Dynamics Algorithms, 2008, Table 7.1) - deliberately different

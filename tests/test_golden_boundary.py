@@ -86,3 +86,84 @@ def test_transport_roundtrip():
     b = torch_to_bytes(t)
     assert list(b[:4]) == g["magic"]  # torch.save zip container
     assert bytes_to_torch(b).tolist() == g["roundtrip"]
+
+
+# ---- stage costs against the reference's own example Objectives (tools/make_golden.py section 7) ----
+class ReplaySim:
+    """feeds an Objective the recorded simulator answers of the golden case"""
+    device = "cpu"
+
+    def __init__(self, inputs):
+        self.inputs = {k: torch.tensor(v, dtype=torch.float64) for k, v in inputs.items()}
+
+    def get_actor_link_by_name(self, actor_name, link_name):
+        return self.inputs[f"link:{actor_name}:{link_name}"]
+
+    def get_actor_position_by_name(self, name):
+        return self.inputs[f"position:{name}"]
+
+    def get_actor_velocity_by_name(self, name):
+        return self.inputs[f"velocity:{name}"]
+
+    def get_actor_orientation_by_name(self, name):
+        return self.inputs[f"orientation:{name}"]
+
+    def get_actor_contact_forces_by_name(self, actor_name, link_name):
+        return self.inputs[f"contact:{actor_name}:{link_name}"]
+
+
+OBJECTIVES = {"panda": "PandaReachObjective", "boxer_push": "BoxerPushObjective", "panda_pick": "PandaPickObjective"}
+
+
+@pytest.mark.parametrize("case", sorted(OBJECTIVES))
+def test_objective_compute_cost_matches_reference_objective(case):
+    """generic-mode Objectives (mppiisaac/objectives.py) == the reference example's Objective.compute_cost on the same
+    simulator answers; also the default weights"""
+    import mppiisaac.objectives as objectives
+    g = gold("objective_costs.json")[case]
+    obj = getattr(objectives, OBJECTIVES[case])(None)
+    assert {k: float(v) for k, v in obj.weights.items()} == g["weights"]
+    got = obj.compute_cost(ReplaySim(g["inputs"]))
+    np.testing.assert_allclose(got.numpy(), np.array(g["cost"]), rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("case", sorted(OBJECTIVES))
+def test_oracle_stage_cost_matches_reference_objective(case, oracle64):
+    """the oracle's C stage cost (what the fused HIP cost is checked against) == the reference Objective on the same
+    rigid-body rows, actor rows and contact forces"""
+    from mppiisaac.backend import capi
+    from scenes import panda_reach
+    g = gold("objective_costs.json")[case]
+    inp = {k: np.array(v) for k, v in g["inputs"].items()}
+    _, model, *_ = panda_reach()  # (orc_cost does not read the model)
+    c = capi.Cost()
+    w = g["weights"]
+    K = len(g["cost"])
+    rb, root, cf = np.zeros((K, 3, 13)), np.zeros((K, 2, 13)), np.zeros((K, 3, 3))
+    if case == "panda":
+        c.kind = capi.COST_PANDA_REACH
+        rb[:, 0] = inp["link:panda:panda_ee_tip"]
+        root[:, 0, 0:3] = inp["position:goal"]
+        c.link[0], c.actor[0] = 0, 0
+        c.w[0], c.w[1] = w["robot_to_goal"], w["robot_ori"]
+    elif case == "boxer_push":
+        c.kind = capi.COST_BOXER_PUSH
+        rb[:, 0] = inp["link:boxer:ee_link"]
+        root[:, 0, 0:3], root[:, 0, 3:7], root[:, 0, 7:10] = inp["position:block"], inp["orientation:block"], inp["velocity:block"]
+        root[:, 1, 0:3] = inp["position:goal"]
+        cf[:, 1], cf[:, 2] = inp["contact:paper_obst1:box"], inp["contact:paper_obst2:box"]
+        c.link[0], c.link[1], c.link[2], c.actor[0], c.actor[1] = 0, 1, 2, 0, 1
+        for i, k in enumerate(("robot_to_block", "block_to_goal", "block_to_goal_ort", "push_align", "velocity", "collision")):
+            c.w[i] = w[k]
+        c.w[6] = g["goal_yaw"]
+    else:
+        c.kind = capi.COST_PANDA_PICK
+        rb[:, 0] = inp["link:panda:panda_ee"]
+        root[:, 0, 0:3], root[:, 1, 0:3] = inp["position:panda_pick_block"], inp["position:goal"]
+        cf[:, 1] = inp["contact:table:box"]
+        c.link[0], c.link[1], c.actor[0], c.actor[1] = 0, 1, 0, 1
+        for i, k in enumerate(("robot_to_block", "block_to_goal", "collision", "robot_ori")):
+            c.w[i] = w[k]
+    q = np.zeros(16)
+    got = [oracle64.cost(model, c, root[k], q, q, rb[k], cf[k]) for k in range(K)]
+    np.testing.assert_allclose(got, g["cost"], rtol=1e-6, atol=1e-6)  # (weights travel as fp32 in mppi_cost_t)

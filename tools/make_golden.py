@@ -124,3 +124,72 @@ t = torch.arange(6, dtype=torch.float32).reshape(2, 3)
 b = torch_to_bytes(t)
 dump("transport.json", {"tensor": t.tolist(), "nbytes": len(b), "magic": list(b[:4]),
                         "roundtrip": bytes_to_torch(b).tolist()})
+
+# 7. Objective.compute_cost of the reference's example planners on seeded random simulator states.
+#    hydra / zerorpc / mppi_torch are mocked (absent, unused by compute_cost).  pytorch3d is absent too: the two
+#    functions the panda objectives call are served by scipy.spatial.transform (an independent implementation of
+#    the same conventions: real-first quaternion -> matrix, intrinsic "ZYX" angles); those cases are labelled.
+import importlib.util
+import types
+from scipy.spatial.transform import Rotation
+
+for name in ("hydra", "hydra.core", "hydra.core.config_store", "omegaconf", "zerorpc", "mppi_torch", "mppi_torch.mppi"):
+    sys.modules.setdefault(name, MagicMock())
+
+def _q2m(q):
+    a = q.detach().double().numpy()
+    return torch.tensor(Rotation.from_quat(np.concatenate([a[:, 1:4], a[:, 0:1]], 1)).as_matrix())
+
+def _m2e(M, convention):
+    return torch.tensor(Rotation.from_matrix(M.detach().double().numpy()).as_euler(convention))
+
+p3d = types.ModuleType("pytorch3d")
+p3d.transforms = types.ModuleType("pytorch3d.transforms")
+p3d.transforms.quaternion_to_matrix = _q2m
+p3d.transforms.matrix_to_euler_angles = _m2e
+sys.modules["pytorch3d"] = p3d
+sys.modules["pytorch3d.transforms"] = p3d.transforms
+
+class RecordingSim:
+    """answers every getter with a seeded random tensor of the reference's shape and remembers what it returned"""
+    def __init__(self, K, seed):
+        self.K, self.g, self.calls = K, torch.Generator().manual_seed(seed), {}
+    def _rand(self, n):
+        return torch.randn(self.K, n, generator=self.g, dtype=torch.float64)
+    def _answer(self, key, make):
+        if key not in self.calls:
+            self.calls[key] = make()
+        return self.calls[key]
+    def get_actor_link_by_name(self, actor_name, link_name):
+        def make():
+            x = self._rand(13)
+            x[:, 3:7] = x[:, 3:7] / x[:, 3:7].norm(dim=1, keepdim=True)
+            return x
+        return self._answer(f"link:{actor_name}:{link_name}", make)
+    def get_actor_position_by_name(self, name):
+        return self._answer(f"position:{name}", lambda: self._rand(3))
+    def get_actor_velocity_by_name(self, name):
+        return self._answer(f"velocity:{name}", lambda: self._rand(3))
+    def get_actor_orientation_by_name(self, name):
+        def make():
+            x = self._rand(4)
+            return x / x.norm(dim=1, keepdim=True)
+        return self._answer(f"orientation:{name}", make)
+    def get_actor_contact_forces_by_name(self, actor_name, link_name):
+        # contact is sparse: zero rows in half of the samples
+        return self._answer(f"contact:{actor_name}:{link_name}", lambda: self._rand(3) * (self._rand(1) > 0))
+
+obj_cases = {}
+for case, rel, stand_ins in (("panda", "examples/panda/planner.py", ["pytorch3d.transforms -> scipy"]),
+                             ("boxer_push", "examples/boxer_push/planner.py", []),
+                             ("panda_pick", "examples/panda_pick/planner.py", ["pytorch3d.transforms -> scipy"])):
+    spec = importlib.util.spec_from_file_location(f"ref_example_{case}", os.path.join(REF, rel))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    obj = mod.Objective(None)
+    sim = RecordingSim(K=24, seed=11 + len(obj_cases))
+    cost = obj.compute_cost(sim)
+    obj_cases[case] = {"source": rel, "stand_ins": stand_ins, "weights": {k: float(v) for k, v in obj.weights.items()},
+                       "goal_yaw": float(getattr(obj, "goal_yaw", 0.0)),
+                       "inputs": {k: v.tolist() for k, v in sim.calls.items()}, "cost": cost.tolist()}
+dump("objective_costs.json", obj_cases)
