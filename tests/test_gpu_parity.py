@@ -777,3 +777,37 @@ def test_dynamic_obstacles_through_compute_action(lib):
     d = np.linalg.norm(traj - np.array([1.0, 0.05]), axis=1)
     assert d.min() > 0.3 + 0.2 - 0.05                                # ... around the obstacle (radius 0.3, robot radius 0.2)
     assert np.linalg.norm(traj[-1] - np.array([2.0, 0.0])) < 0.6
+
+
+def test_body_force_reference_test_shape(lib, oracle64):
+    """The reference's only test (mppiisaac/planner/tests/test_isaacgym_wrapper.py:11-35, `test_body_force`): boxer + wall in
+    600 envs, the same (0.2, 0) command everywhere, 200 steps; it asserts the DOF tensor shape and that identical envs
+    report identical contact forces.  (Its `sim.net_cf` / `sim.dof_state` attributes are `_net_contact_force` /
+    `_dof_state` in the wrapper of the same commit.)"""
+    from mppiisaac.planner.isaacgym_wrapper import IsaacGymWrapper
+    from mppiisaac.utils.config_store import load_config
+    cfg = load_config({"defaults": [{"isaacgym": "normal"}]})
+    num_envs = 600
+    sim = IsaacGymWrapper(cfg.isaacgym, actors=["boxer", "wall"], init_positions=[[0.0, 0.0, 0.5]], num_envs=num_envs)
+    assert sim._dof_state.size() == torch.Size([num_envs, 4])
+    cmd = torch.Tensor([0.2, 0.0]).repeat(num_envs, 1)
+    assert cmd.size() == torch.Size([num_envs, 2])
+    sim.apply_robot_cmd(cmd)
+    for _ in range(200):
+        sim.step()
+    cf = sim._net_contact_force.cpu()
+    assert torch.isfinite(cf).all()
+    assert (cf == cf[0:1]).all()                                   # every env identical, bit for bit
+    assert (sim._root_state.cpu() == sim._root_state[0:1].cpu()).all()
+    base = sim._root_state[0, 0].cpu()
+    travelled = float(torch.linalg.norm(base[0:2]))
+    assert base[2] < 0.05 and 1.8 < travelled < 2.05               # dropped onto its wheels, then 0.2 m/s for ~10 s
+    assert cf[0].abs().sum() > 1.0                                 # standing on the ground: wheel / caster forces
+    # the same 200 steps through the oracle
+    m = sim._c_model
+    dof, root = sim.scene.initial_state()
+    q, qd, root = dof[0::2].astype(np.float64), dof[1::2].astype(np.float64), root.astype(np.float64)
+    target = oracle64.cmd_map(m, np.array([0.2, 0.0]))
+    for _ in range(200):
+        root, q, qd, _ = oracle64.scene_step(m, root, q, qd, target)
+    np.testing.assert_allclose(sim._root_state[0, 0, 0:3].cpu().numpy(), root[0, 0:3], atol=2e-2)
