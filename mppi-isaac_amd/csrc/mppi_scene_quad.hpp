@@ -125,48 +125,72 @@ MPPI_HD void qexternal(const LMem &L, int acc_base, int ent, bool touched, float
     }
 }
 
-// Articulated-body solve of the robot inside a contact scene.  vbase / abase: spatial velocity / acceleration of the base
-// about the world origin (zero / unused for a fixed base).  `touched`: frames with non-zero accumulators.
+// Articulated-body solve of the robot inside a contact scene, in two parts so that the second solve of a substep (joint
+// drives saturated at their effort limit: other tau / kdh, everything else the same) reuses what does not depend on the
+// drive: quad_aba_prepare = velocities, bias terms and the world-frame inertia + bias force of every body incl. gravity,
+// contact wrench and implicit contact damping; quad_aba_solve = inward articulated-inertia pass and outward
+// accelerations.  vbase / abase: spatial velocity / acceleration of the base about the world origin (zero / unused
+// for a fixed base).  `touched`: frames with non-zero accumulators.
+template <class T>
+struct QAbaPrep {
+    static constexpr int NBs = T::NB ? T::NB : 1;
+    QSV cb[NBs], pA[NBs + 1];
+    QF Sl[NBs];
+    QAI A[NBs + 1];  // [NB] = the floating base
+};
 template <class T, class M>
-MPPI_HD void quad_aba_scene(M &m, const QPose<T> &P, const QSV &vbase, const QF *qd, const QF *tau_exp, const QF *kdh, const LMem &L,
-                            unsigned touched, QF *qdd, SV &abase, JointLimits *lim) {
+MPPI_HD void quad_aba_prepare(M &m, const QPose<T> &P, const QSV &vbase, const QF *qd, const LMem &L, unsigned touched, QAbaPrep<T> &W,
+                              JointLimits *lim) {
     constexpr int NB = T::NB;
     constexpr int NBs = NB ? NB : 1;
     using Lay = SceneLayout<T>;
-    QSV v[NBs], U[NBs], pacc[NBs + 1], cb[NBs];
-    QF Sl[NBs];
-    QAI acc[NBs + 1];
-    QF invd[NBs], u[NBs];
-    bool has_acc[NBs + 1];
+    QSV v[NBs];
     const QF zero = qrep(0.f);
     const float hstep = m.h;
-    const bool floating = m.floating != 0;
     const QF gq = m.gravity_on ? qsel(m.g[0], m.g[1], m.g[2]) : zero;
     static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
         constexpr int i = ic;
         constexpr int par = T::par[i];
         const QSV S = quad_subspace<T, i>(P);
-        Sl[i] = S.l;
+        W.Sl[i] = S.l;
         const QSV sj = {qd[i] * S.a, qd[i] * S.l};
         const QSV vp = par < 0 ? vbase : v[par < 0 ? 0 : par];
         v[i] = {vp.a + sj.a, vp.l + sj.l};
-        cb[i] = {qcross(vp.a, sj.a), qcross(vp.a, sj.l) + qcross(vp.l, sj.a)};
-        has_acc[i] = false;
+        W.cb[i] = {qcross(vp.a, sj.a), qcross(vp.a, sj.l) + qcross(vp.l, sj.a)};
     });
-    has_acc[NB] = false;
     BodyK1 blk[NBs];
     static_rfor<0, NB>([&](auto ic) MPPI_LAMBDA { blk[ic] = load_block<BodyK1>(m.b[ic].k1); });
     static_rfor<0, NB>([&](auto ic) MPPI_LAMBDA {
         constexpr int i = ic;
-        constexpr int par = T::par[i];
         const BodyK1 &b = blk[i];
         lim[i] = {b.effort, b.lower, b.upper, b.vmax, b.limited};
-        const QSV S = {P.revolute(i) ? P.R[i].c[2] : zero, Sl[i]};
-        QAI A;
-        QSV pA;
         QF h;
-        qrigid_world(P.R[i], P.p[i], b.m, b.hb, b.Ic, v[i], A, pA, h);
-        qexternal(L, Lay::kAcc, i, (touched >> i) & 1u, hstep, h, b.m, gq, v[i], A, pA);
+        qrigid_world(P.R[i], P.p[i], b.m, b.hb, b.Ic, v[i], W.A[i], W.pA[i], h);
+        qexternal(L, Lay::kAcc, i, (touched >> i) & 1u, hstep, h, b.m, gq, v[i], W.A[i], W.pA[i]);
+    });
+    if (m.floating != 0) {
+        QF h;
+        qrigid_world(P.Rb, P.pb, m.base_m, m.base_hb, m.base_Ic, vbase, W.A[NB], W.pA[NB], h);
+        qexternal(L, Lay::kAcc, NB, (touched >> NB) & 1u, hstep, h, m.base_m, gq, vbase, W.A[NB], W.pA[NB]);
+    }
+}
+template <class T, class M>
+MPPI_HD void quad_aba_solve(M &m, const QPose<T> &P, const QAbaPrep<T> &W, const QF *tau_exp, const QF *kdh, QF *qdd, SV &abase) {
+    constexpr int NB = T::NB;
+    constexpr int NBs = NB ? NB : 1;
+    QSV U[NBs], pacc[NBs + 1];
+    QAI acc[NBs + 1];
+    QF invd[NBs], u[NBs];
+    bool has_acc[NBs + 1];
+    const QF zero = qrep(0.f);
+    const bool floating = m.floating != 0;
+    static_for<0, NB + 1>([&](auto ic) MPPI_LAMBDA { has_acc[ic] = false; });
+    static_rfor<0, NB>([&](auto ic) MPPI_LAMBDA {
+        constexpr int i = ic;
+        constexpr int par = T::par[i];
+        const QSV S = {P.revolute(i) ? P.R[i].c[2] : zero, W.Sl[i]};
+        QAI A = W.A[i];
+        QSV pA = W.pA[i];
         if (has_acc[i]) {
             for (int j = 0; j < 3; j++) { A.I[j] += acc[i].I[j]; A.H[j] += acc[i].H[j]; A.Ht[j] += acc[i].Ht[j]; A.M[j] += acc[i].M[j]; }
             pA = {pA.a + pacc[i].a, pA.l + pacc[i].l};
@@ -177,7 +201,7 @@ MPPI_HD void quad_aba_scene(M &m, const QPose<T> &P, const QSV &vbase, const QF 
         u[i] = tau_exp[i] - qdot6(S, pA);
         constexpr int pj = par < 0 ? NB : par;  // the base accumulator lives at index NB
         if (par >= 0 || floating) {
-            const QSV c = cb[i];
+            const QSV c = W.cb[i];
             const QSV Ac = qmul(A, c);
             const QF k = (u[i] - qdot6(U[i], c)) * invd[i];
             const QSV pa = {pA.a + Ac.a + k * U[i].a, pA.l + Ac.l + k * U[i].l};
@@ -200,11 +224,8 @@ MPPI_HD void quad_aba_scene(M &m, const QPose<T> &P, const QSV &vbase, const QF 
     abase = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
     QSV a0 = {zero, zero};
     if (floating) {
-        QAI A;
-        QSV pA;
-        QF h;
-        qrigid_world(P.Rb, P.pb, m.base_m, m.base_hb, m.base_Ic, vbase, A, pA, h);
-        qexternal(L, Lay::kAcc, NB, (touched >> NB) & 1u, hstep, h, m.base_m, gq, vbase, A, pA);
+        QAI A = W.A[NB];
+        QSV pA = W.pA[NB];
         if (has_acc[NB]) {
             for (int j = 0; j < 3; j++) { A.I[j] += acc[NB].I[j]; A.H[j] += acc[NB].H[j]; A.Ht[j] += acc[NB].Ht[j]; A.M[j] += acc[NB].M[j]; }
             pA = {pA.a + pacc[NB].a, pA.l + pacc[NB].l};
@@ -218,9 +239,9 @@ MPPI_HD void quad_aba_scene(M &m, const QPose<T> &P, const QSV &vbase, const QF 
     static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
         constexpr int i = ic;
         constexpr int par = T::par[i];
-        const QSV S = {P.revolute(i) ? P.R[i].c[2] : zero, Sl[i]};
+        const QSV S = {P.revolute(i) ? P.R[i].c[2] : zero, W.Sl[i]};
         const QSV apar = par < 0 ? a0 : a[par < 0 ? 0 : par];
-        const QSV ap = {apar.a + cb[i].a, apar.l + cb[i].l};
+        const QSV ap = {apar.a + W.cb[i].a, apar.l + W.cb[i].l};
         const QF dd = (u[i] - qdot6(U[i], ap)) * invd[i];
         qdd[i] = dd;
         a[i] = {ap.a + dd * S.a, ap.l + dd * S.l};
@@ -290,7 +311,9 @@ MPPI_HD void step_scene_quad(M &m0, MR &mr0, const float *root, SceneState<T> &s
             kdh[i] = qrep(kd * h);
         });
         SV abase;
-        quad_aba_scene<T>(mr, P, vbase, qd, tau, kdh, L, touched, qdd, abase, lim);
+        QAbaPrep<T> prep;
+        quad_aba_prepare<T>(mr, P, vbase, qd, L, touched, prep, lim);
+        quad_aba_solve<T>(mr, P, prep, tau, kdh, qdd, abase);
         bool any = false;
         static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
             constexpr int i = ic;
@@ -302,7 +325,7 @@ MPPI_HD void step_scene_quad(M &m0, MR &mr0, const float *root, SceneState<T> &s
                 kdh[i] = qrep(0.f);
             }
         });
-        if (any) quad_aba_scene<T>(*launder(mrp), P, vbase, qd, tau, kdh, L, touched, qdd, abase, lim);
+        if (any) quad_aba_solve<T>(*launder(mrp), P, prep, tau, kdh, qdd, abase);
         static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
             constexpr int i = ic;
             const JointLimits b = lim[i];
