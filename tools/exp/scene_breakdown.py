@@ -64,6 +64,12 @@ def closed_loop_variants(workload, steps=150):
     capi.check(lib, lib.mppi_get_state(P, capi.fptr(dof), capi.fptr(root)))
     U = np.zeros((wl["H"], planner.sim.scene.nu), np.float32)
     capi.check(lib, lib.mppi_get_nominal(P, capi.fptr(U)))
+    # equal-state A/B of two builds: MPPI_STATE_SAVE=<prefix> records this state, MPPI_STATE_LOAD=<prefix> times at a recorded one
+    if os.environ.get("MPPI_STATE_SAVE"):
+        np.savez(os.environ["MPPI_STATE_SAVE"] + "_" + workload + ".npz", dof=dof, root=root, U=U)
+    if os.environ.get("MPPI_STATE_LOAD"):
+        z = np.load(os.environ["MPPI_STATE_LOAD"] + "_" + workload + ".npz")
+        dof, root, U = np.ascontiguousarray(z["dof"]), np.ascontiguousarray(z["root"]), np.ascontiguousarray(z["U"])
     print(workload, "closed-loop state after", steps, "steps: q =", np.round(dof[0::2], 2), flush=True)
     model0 = planner.sim._c_model
 
