@@ -52,6 +52,24 @@ def test_bench_other_workloads_and_the_sharded_code_path():
     assert "sample-shard x1 (nccl" in d["config"]["parallelism"] and d["value"] > 100.0   # RCCL process group + all-gather, one rank
 
 
+def test_bench_two_ranks_launched_like_the_driver_does():
+    """`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`: env rendezvous on 127.0.0.1, sample shards,
+    record all-gather, max-over-ranks timing, rank 0 prints.  On this one-GPU box the two ranks share the GPU and the
+    exchange goes over gloo (MPPI_BENCH_BACKEND); on the 8-GPU node the same code runs over RCCL."""
+    env = dict(os.environ, MPPI_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29613", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "100", "--warmup", "10"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]                 # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "cpu_baseline" not in d
+    assert d["config"]["K_per_gpu"] == 4096 and d["config"]["K_total"] == 8192
+    assert d["value"] == pytest.approx(2 * d["config"]["loop_hz"], rel=1e-6) and d["value"] > 100.0
+    assert d["config"]["final_ee_to_goal_m"] < 0.6
+
+
 def test_smoke_entry_point():
     sys.path.insert(0, ROOT)
     import __graft_entry__ as g
