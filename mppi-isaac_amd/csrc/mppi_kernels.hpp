@@ -206,10 +206,14 @@ __global__ __launch_bounds__(kWave) void k_rollout_quad(const DevModel *__restri
 // The record sum over r is split over four 256-thread groups (r mod 4) with two accumulators each.
 constexpr int kCombineThreads = 1024;
 constexpr int kCombineGroups = 8;
+// the fused tail also steps the K = 1 world on one quad: 512 threads leave that quad 256 registers (at 1024 threads the
+// step spilled 108 B to scratch)
+constexpr int kCombineWorldThreads = 512;
+template <int NT>
 __device__ __forceinline__ void combine_update(CCfg &cfg, const float *__restrict__ recs, int nrec, int mode, float *__restrict__ out,
                                                float *__restrict__ U, float *__restrict__ action, float *__restrict__ beta_eta, float *s_act,
                                                const float *__restrict__ filt) {
-    __shared__ float s_red[kCombineThreads];
+    __shared__ float s_red[NT];
     __shared__ float s_part[kCombineGroups][MPPI_MAX_H * MPPI_MAX_NU];
     constexpr int kMaxScale = 4096;
     __shared__ float s_scale[kMaxScale];
@@ -217,18 +221,28 @@ __device__ __forceinline__ void combine_update(CCfg &cfg, const float *__restric
     const int tid = threadIdx.x;
     // block reductions: wave shuffles, then one 16-entry pass (two barriers instead of ten per reduction)
     const int wid = tid >> 6, lane = tid & 63;
-    float b = INFINITY;
-    for (int r = tid; r < nrec; r += kCombineThreads)
+    // every load that does not depend on a reduction is issued up front: this kernel is a chain of memory round trips
+    // (records written by the other XCDs come from the fabric, ~2 us each), not bandwidth
+    const float U_old = (mode != 0 && tid < HN) ? U[tid] : 0.f;
+    const bool mine = tid < nrec;  // the first NT records stay in registers between the two passes
+    const float er0 = mine ? recs[(size_t)tid * RF + 1] : 0.f, br0 = mine ? recs[(size_t)tid * RF] : 0.f;
+    float b = er0 > 0.f ? br0 : INFINITY;
+    for (int r = tid + NT; r < nrec; r += NT)
         if (recs[(size_t)r * RF + 1] > 0.f) b = fminf(b, recs[(size_t)r * RF]);
     b = wave_min(b);
     if (lane == 0) s_red[wid] = b;
     __syncthreads();
-    float beta = s_red[lane & 15];
+    float beta = s_red[lane & (NT / kWave - 1)];
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) beta = fminf(beta, __shfl_xor(beta, o, kWave));
+    for (int o = NT / kWave / 2; o > 0; o >>= 1) beta = fminf(beta, __shfl_xor(beta, o, kWave));
     __syncthreads();
     float e = 0.f;
-    for (int r = tid; r < nrec; r += kCombineThreads) {
+    if (mine) {
+        const float sc = er0 > 0.f ? __expf(-(br0 - beta) * cfg.inv_lambda) : 0.f;
+        s_scale[tid] = sc;
+        e = er0 * sc;
+    }
+    for (int r = tid + NT; r < nrec; r += NT) {
         const float er = recs[(size_t)r * RF + 1];
         const float sc = er > 0.f ? __expf(-(recs[(size_t)r * RF] - beta) * cfg.inv_lambda) : 0.f;
         if (r < kMaxScale) s_scale[r] = sc;
@@ -237,19 +251,19 @@ __device__ __forceinline__ void combine_update(CCfg &cfg, const float *__restric
     e = wave_sum(e);
     if (lane == 0) s_red[wid] = e;
     __syncthreads();
-    float eta = s_red[lane & 15];
+    float eta = s_red[lane & (NT / kWave - 1)];
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) eta += __shfl_xor(eta, o, kWave);
+    for (int o = NT / kWave / 2; o > 0; o >>= 1) eta += __shfl_xor(eta, o, kWave);
     // N[j] = sum_r scale_r * recs[r][2 + j]: the block is cut into G groups of HN threads (one thread per row j, ONE pass
-    // whatever HN is); group g takes the records r = g, g + G, ...; the loop is unrolled so that eight independent
-    // (L2-resident) loads are in flight per thread instead of a dependent chain
-    const int G = HN <= kCombineThreads ? (kCombineThreads / HN < kCombineGroups ? kCombineThreads / HN : kCombineGroups) : 1;
+    // whatever HN is); group g takes the records r = g, g + G, ...; the loop is unrolled so that sixteen independent
+    // loads are in flight per thread instead of a dependent chain
+    const int G = HN <= NT ? (NT / HN < kCombineGroups ? NT / HN : kCombineGroups) : 1;
     {
         const int g = tid / HN, j0 = tid - g * HN;
         if (g < G)
-            for (int j = j0; j < HN; j += kCombineThreads) {  // (more than one trip only if HN > 1024, then G = 1)
+            for (int j = j0; j < HN; j += NT) {  // (more than one trip only if HN > 1024, then G = 1)
                 float N0 = 0.f;
-#pragma unroll 8
+#pragma unroll 16
                 for (int r = g; r < nrec; r += G) {
                     float sc;
                     if (r < kMaxScale) sc = s_scale[r];
@@ -271,7 +285,7 @@ __device__ __forceinline__ void combine_update(CCfg &cfg, const float *__restric
             for (int gg = 0; gg < G; gg++) N += s_part[gg][j];
             if (mode == 0) out[2 + j] = N;
             else {
-                Unew = U[j] + (eta > 0.f ? N / eta : 0.f);
+                Unew = (j == tid ? U_old : U[j]) + (eta > 0.f ? N / eta : 0.f);
                 s_part[1][j] = Unew;  // column j is read and written by this thread only
             }
         }
@@ -286,7 +300,7 @@ __device__ __forceinline__ void combine_update(CCfg &cfg, const float *__restric
     s_U = s_part[1];
     if (filt != nullptr) {  // filter_u: U <- F U over the horizon, per control dimension
         const int H = cfg.H;
-        for (int j = tid; j < HN; j += kCombineThreads) {
+        for (int j = tid; j < HN; j += NT) {
             const int t = j / nu, c = j - t * nu;
             float acc = 0.f;
             for (int s2 = 0; s2 < H; s2++) acc += filt[t * H + s2] * s_part[1][s2 * nu + c];
@@ -313,27 +327,27 @@ __device__ __forceinline__ void combine_update(CCfg &cfg, const float *__restric
         beta_eta[0] = beta;
         beta_eta[1] = eta;
     }
-    for (int j = tid; j < HN; j += kCombineThreads) U[j] = (j + nu < HN) ? s_U[j + nu] : cfg.u_init;  // shift, append u_init
+    for (int j = tid; j < HN; j += NT) U[j] = (j + nu < HN) ? s_U[j + nu] : cfg.u_init;  // shift, append u_init
 }
 
 __global__ __launch_bounds__(kCombineThreads) void k_combine(const DevCfg *__restrict__ cfg, const float *__restrict__ recs, int nrec, int mode,
                                                              float *__restrict__ out, float *__restrict__ U, float *__restrict__ action,
                                                              float *__restrict__ beta_eta, const float *__restrict__ filt) {
-    combine_update(*(CCfg *)cfg, recs, nrec, mode, out, U, action, beta_eta, nullptr, filt);
+    combine_update<kCombineThreads>(*(CCfg *)cfg, recs, nrec, mode, out, U, action, beta_eta, nullptr, filt);
 }
 
 // Closed-loop tail in ONE launch: combine + nominal update, then the K = 1 world is stepped with the new
 // action by one quad of the same workgroup and its state becomes the planner's next x0
 // (replaces k_combine + k_sim_step + k_state_from_world; fixed-base contact-free scenes only).
 template <class T>
-__global__ __launch_bounds__(kCombineThreads) void k_combine_world(const DevCfg *__restrict__ cfg, const float *__restrict__ recs, int nrec,
+__global__ __launch_bounds__(kCombineWorldThreads) void k_combine_world(const DevCfg *__restrict__ cfg, const float *__restrict__ recs, int nrec,
                                                                    float *__restrict__ U, float *__restrict__ action, float *__restrict__ beta_eta,
                                                                    const DevModel *__restrict__ wm, const float *__restrict__ w_root,
                                                                    float *__restrict__ wq, float *__restrict__ wqd, float *__restrict__ x0_dof,
                                                                    const float *__restrict__ filt) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ float s_act[MPPI_MAX_NU];
-    combine_update(*(CCfg *)cfg, recs, nrec, 1, nullptr, U, action, beta_eta, s_act, filt);
+    combine_update<kCombineWorldThreads>(*(CCfg *)cfg, recs, nrec, 1, nullptr, U, action, beta_eta, s_act, filt);
     __syncthreads();
     if (threadIdx.x < 4) {
         constexpr int NB = T::NB;
@@ -934,7 +948,7 @@ void launch_rollout_quad_t(mppi_ctx *c) {
 }
 template <class T>
 void launch_combine_world_t(mppi_ctx *p, const float *recs, int n, mppi_ctx *w) {
-    hipLaunchKernelGGL(k_combine_world<T>, dim3(1), dim3(kCombineThreads), 0, p->stream, p->d_cfg, recs, n, p->d_U, p->d_action, p->d_beta_eta,
+    hipLaunchKernelGGL(k_combine_world<T>, dim3(1), dim3(kCombineWorldThreads), 0, p->stream, p->d_cfg, recs, n, p->d_U, p->d_action, p->d_beta_eta,
                        w->d_model, w->d_x0_root, w->d_q, w->d_qd, p->d_x0_dof, p->use_filter ? p->d_filter : nullptr);
 }
 template <class T>
