@@ -203,7 +203,7 @@ __global__ __launch_bounds__(kWave) void k_rollout_quad(const DevModel *__restri
 
 // Combine n records (1024 threads): beta = min, eta and N rescaled by e^{-(beta_r-beta)/lambda}.
 // mode 0: write the combined record to `out`; mode 1: U += N/eta, action = U[0], shift U, append u_init.
-// The record sum over r is split over four 256-thread groups (r mod 4) with two accumulators each.
+// The row sums over the records are split over up to eight groups of H*nu threads (record r belongs to group r mod G).
 constexpr int kCombineThreads = 1024;
 constexpr int kCombineGroups = 8;
 // the fused tail also steps the K = 1 world on one quad: 512 threads leave that quad 256 registers (at 1024 threads the
