@@ -110,6 +110,11 @@ def main():
     # MPPI_BENCH_FORCE_DIST=1: run the sharded code path (process group, record all-gather) even with one rank, so
     # that the RCCL path can be exercised and its per-iteration overhead measured on a single-GPU box
     sharded = world_size > 1 or bool(os.environ.get("MPPI_BENCH_FORCE_DIST"))
+    # stdout carries the ONE result line and nothing else: RCCL / gloo print version and connection banners to fd 1 from C,
+    # so everything written to fd 1 before the result goes to stderr instead
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
     if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -250,7 +255,9 @@ def main():
         }
         if world_size == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(planner, dof0, K_PER_GPU, HORIZON)
-        ctypes.CDLL(None).fflush(None)  # RCCL's version banner (C stdio) goes out before the result line, not after it
+        ctypes.CDLL(None).fflush(None)  # (C stdio of the libraries: out through the redirected fd before it is restored)
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
         print(json.dumps(out), flush=True)
     if sharded:
         dist.destroy_process_group()

@@ -14,8 +14,8 @@ def run_bench(*extra):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "60", "--warmup", "10", *extra],
                          capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
+    lines = out.stdout.strip().splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-2000:]   # stdout = the result line and nothing else
     return json.loads(lines[0])
 
 
@@ -48,7 +48,9 @@ def test_bench_other_workloads_and_the_sharded_code_path():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "60", "--warmup", "10", "--no-cpu-baseline"],
                          capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
-    d = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][0])
+    lines = out.stdout.strip().splitlines()
+    assert len(lines) == 1, out.stdout[-2000:]                 # (RCCL's version banner goes to stderr)
+    d = json.loads(lines[0])
     assert "sample-shard x1 (nccl" in d["config"]["parallelism"] and d["value"] > 100.0   # RCCL process group + all-gather, one rank
 
 
@@ -61,8 +63,8 @@ def test_bench_two_ranks_launched_like_the_driver_does():
                           "--master-port", "29613", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "100", "--warmup", "10"],
                          capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]                 # rank 0 only
+    lines = out.stdout.strip().splitlines()
+    assert len(lines) == 1, out.stdout[-2000:]                 # rank 0 only, no library banners
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "cpu_baseline" not in d
     assert d["config"]["K_per_gpu"] == 4096 and d["config"]["K_total"] == 8192
