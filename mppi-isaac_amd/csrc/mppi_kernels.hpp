@@ -347,11 +347,19 @@ __global__ __launch_bounds__(kCombineWorldThreads) void k_combine_world(const De
                                                                    const float *__restrict__ filt) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ float s_act[MPPI_MAX_NU];
+    // The world's model goes to LDS as in the rollout (in-order ds_read_b128 broadcasts instead of cold scalar-cache
+    // misses in the step's dependency chain).  The copy is made by the upper half of the block, whose wavefronts have no
+    // record of their own to load in the first pass of the combine, so it costs the critical path nothing.
+    constexpr int kModelBytes = (int)((offsetof(DevModel, fr) + 15) / 16 * 16);
+    __shared__ __attribute__((aligned(64))) uint4 s_model[kModelBytes / 16];
+    if (threadIdx.x >= kCombineWorldThreads / 2)
+        for (int i = threadIdx.x - kCombineWorldThreads / 2; i < kModelBytes / 16; i += kCombineWorldThreads / 2)
+            s_model[i] = reinterpret_cast<const uint4 *>(wm)[i];
     combine_update<kCombineWorldThreads>(*(CCfg *)cfg, recs, nrec, 1, nullptr, U, action, beta_eta, s_act, filt);
     __syncthreads();
     if (threadIdx.x < 4) {
         constexpr int NB = T::NB;
-        CModel &M = *(CModel *)wm;  // (staging it in LDS as the rollout does was measured slower here: 29.3 vs 25.0 us)
+        LModel &M = *(LModel *)s_model;
         QF q[NB ? NB : 1], qd[NB ? NB : 1], target[NB ? NB : 1];
         static_for<0, NB>([&](auto ic) {
             constexpr int i = ic;
