@@ -469,6 +469,10 @@ MPPI_HD QF quad_rollout(M &m0, CCfg &cfg0, CCost &cost0, LStep &sc, const float 
     const int g = cfg0.k_offset + k;
     const bool is_null = cfg0.sample_null_action && g == cfg0.k_total - 1;
     const bool is_prior = cfg0.use_priors && prior != nullptr && g == cfg0.k_total - 2;
+    // the first noise row is requested before anything else: its round trip to HBM overlaps the initial kinematics
+    constexpr int MAXC = NB < kMaxNu ? NB : kMaxNu;  // nu <= NB: one command per driven body at most
+    ControlRows<MAXC> rows;
+    load_controls_q<MAXC>(sc, eps, prior, nu, K, 0, k, rows);
     QF q[NB], qd[NB], target[NB];
     static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
         constexpr int i = ic;
@@ -481,9 +485,6 @@ MPPI_HD QF quad_rollout(M &m0, CCfg &cfg0, CCost &cost0, LStep &sc, const float 
     quad_base<T>(m0, root, P);
     quad_fk<T>(m0, q, P);
     M *mp = &m0;
-    constexpr int MAXC = NB < kMaxNu ? NB : kMaxNu;  // nu <= NB: one command per driven body at most
-    ControlRows<MAXC> rows;
-    load_controls_q<MAXC>(sc, eps, prior, nu, K, 0, k, rows);
     for (int t = 0; t < H; t++) {
         float u[kMaxNu];
         ctrl += apply_controls_q<MAXC>(sc, lambda, abs_cost, nu, K, rows, t, k, is_null, is_prior, leader, du, u);
