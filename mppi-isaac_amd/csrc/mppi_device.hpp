@@ -173,9 +173,14 @@ typedef unsigned u32x16 __attribute__((vector_size(64)));
 template <class B, class S>
 MPPI_HD B load_block(const MPPI_CONST_AS S &src) {
     static_assert(sizeof(B) == 64 && sizeof(S) == 64, "64-byte blocks only");
-    const u32x16 v = *reinterpret_cast<const MPPI_CONST_AS u32x16 *>(&src);
     B out;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u32x16 v = *reinterpret_cast<const MPPI_CONST_AS u32x16 *>(&src);
     __builtin_memcpy(&out, &v, 64);
+#else  // host builds (tests/hostemu): no typed access through another type - the optimiser may order such a read
+       // before the float stores that fill the block (seen with g++ -O2 on a StepConsts filled just before the call)
+    __builtin_memcpy(&out, &src, 64);
+#endif
     return out;
 }
 #if defined(__HIP_DEVICE_COMPILE__)
