@@ -257,8 +257,62 @@ __device__ __forceinline__ void combine_update(CCfg &cfg, const float *__restric
     // N[j] = sum_r scale_r * recs[r][2 + j]: the block is cut into G groups of HN threads (one thread per row j, ONE pass
     // whatever HN is); group g takes the records r = g, g + G, ...; the loop is unrolled so that sixteen independent
     // loads are in flight per thread instead of a dependent chain
-    const int G = HN <= NT ? (NT / HN < kCombineGroups ? NT / HN : kCombineGroups) : 1;
-    {
+    // Wide variant (every record in the weight table): a thread takes FOUR adjacent rows, so a
+    // quarter of the threads cover the rows, four times as many groups share the records and the ~nrec/G 16-byte loads of a
+    // thread are all in flight at once - one round trip to memory instead of one per sixteen records.
+    constexpr int kPartFloats = kCombineGroups * MPPI_MAX_H * MPPI_MAX_NU;
+    constexpr int kWideLoads = NT >= 1024 ? 16 : 24;  // (register budget: 128 per thread in a 1024-thread block)
+    const int Q = (HN + 3) >> 2;  // (the last quad of a row count that is no multiple of four is loaded float by float)
+    int Gw = Q > 0 ? NT / Q : 0;
+    if (Gw > 32) Gw = 32;
+    if (Gw * HN > kPartFloats) Gw = kPartFloats / HN;
+    const bool wide = Q <= NT && nrec <= kMaxScale && Gw >= 2;
+    float *s_flat = &s_part[0][0];
+    int G = HN <= NT ? (NT / HN < kCombineGroups ? NT / HN : kCombineGroups) : 1;
+    if (wide) {
+        G = Gw;
+        const int g = tid / Q, cq = tid - g * Q;
+        if (g < G) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 v[kWideLoads];
+            const int nvalid = HN - 4 * cq;  // >= 4 except in the last quad of a ragged row count
+            auto load4 = [&](int r, float4 &w) {
+                const float *src = recs + (size_t)r * RF + 2 + 4 * cq;
+                if (nvalid >= 4) __builtin_memcpy(&w, src, 16);
+                else {
+                    w.x = src[0];
+                    w.y = nvalid > 1 ? src[1] : 0.f;
+                    w.z = nvalid > 2 ? src[2] : 0.f;
+                    w.w = 0.f;
+                }
+            };
+#pragma unroll
+            for (int i = 0; i < kWideLoads; i++) {
+                const int r = g + i * G;
+                if (r < nrec) load4(r, v[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < kWideLoads; i++) {
+                const int r = g + i * G;
+                if (r < nrec) {
+                    const float sc = s_scale[r];
+                    acc.x += v[i].x * sc; acc.y += v[i].y * sc; acc.z += v[i].z * sc; acc.w += v[i].w * sc;
+                }
+            }
+#pragma unroll 8
+            for (int r = g + kWideLoads * G; r < nrec; r += G) {
+                float4 w;
+                load4(r, w);
+                const float sc = s_scale[r];
+                acc.x += w.x * sc; acc.y += w.y * sc; acc.z += w.z * sc; acc.w += w.w * sc;
+            }
+            float *o = s_flat + g * HN + 4 * cq;
+            o[0] = acc.x;
+            if (nvalid > 1) o[1] = acc.y;
+            if (nvalid > 2) o[2] = acc.z;
+            if (nvalid > 3) o[3] = acc.w;
+        }
+    } else {
         const int g = tid / HN, j0 = tid - g * HN;
         if (g < G)
             for (int j = j0; j < HN; j += NT) {  // (more than one trip only if HN > 1024, then G = 1)
@@ -277,16 +331,18 @@ __device__ __forceinline__ void combine_update(CCfg &cfg, const float *__restric
             }
     }
     __syncthreads();
-    float *s_U = s_part[0];  // reused for the updated nominal after the group sums are consumed
+    // the updated nominal goes to the weight table's storage (consumed above; HN <= 1024 floats each for U and F U)
+    float *s_U = s_scale;
     float Unew = 0.f;
+    const int gstride = wide ? HN : MPPI_MAX_H * MPPI_MAX_NU;
     if (tid < 256)
         for (int j = tid; j < HN; j += 256) {
             float N = 0.f;
-            for (int gg = 0; gg < G; gg++) N += s_part[gg][j];
+            for (int gg = 0; gg < G; gg++) N += s_flat[gg * gstride + j];
             if (mode == 0) out[2 + j] = N;
             else {
                 Unew = (j == tid ? U_old : U[j]) + (eta > 0.f ? N / eta : 0.f);
-                s_part[1][j] = Unew;  // column j is read and written by this thread only
+                s_scale[j] = Unew;
             }
         }
     if (mode == 0) {
@@ -297,17 +353,16 @@ __device__ __forceinline__ void combine_update(CCfg &cfg, const float *__restric
         return;
     }
     __syncthreads();
-    s_U = s_part[1];
     if (filt != nullptr) {  // filter_u: U <- F U over the horizon, per control dimension
         const int H = cfg.H;
         for (int j = tid; j < HN; j += NT) {
             const int t = j / nu, c = j - t * nu;
             float acc = 0.f;
-            for (int s2 = 0; s2 < H; s2++) acc += filt[t * H + s2] * s_part[1][s2 * nu + c];
-            s_part[2][j] = acc;
+            for (int s2 = 0; s2 < H; s2++) acc += filt[t * H + s2] * s_scale[s2 * nu + c];
+            s_scale[MPPI_MAX_H * MPPI_MAX_NU + j] = acc;
         }
         __syncthreads();
-        s_U = s_part[2];
+        s_U = s_scale + MPPI_MAX_H * MPPI_MAX_NU;
     }
     if (tid < nu) {
         action[tid] = s_U[tid];
