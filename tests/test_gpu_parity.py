@@ -560,9 +560,10 @@ def test_panda_pick_rollout_matches_oracle(lib, oracle64):
     c.close()
 
 
-@pytest.mark.parametrize("K,H", [(1, 12), (7, 13), (100, 16), (1000, 12)])
+@pytest.mark.parametrize("K,H", [(1, 12), (7, 13), (100, 16), (1000, 12), (200, 15), (64, 10)])
 def test_ragged_sizes(K, H, lib, oracle64):
-    """sample counts that do not fill a quad-wave (16), a wavefront (64) or the XCD chunk mapping."""
+    """sample counts that do not fill a quad-wave (16), a wavefront (64) or the XCD chunk mapping; row counts H*nu of the
+    nominal that leave 0, 1, 2 or 3 rows in the last four-row group of the combine (84, 91, 112, 84, 105, 70)."""
     scene, m, cfg, cost, dof, root = panda_reach(K=K, H=H, sample_null_action=(K > 1))
     c = Ctx(m, cfg, cost)
     c.call("mppi_sample", C.c_uint32(3))
@@ -574,8 +575,9 @@ def test_ragged_sizes(K, H, lib, oracle64):
     S = c.get("mppi_get_costs", (K,))
     So, duo, _ = oracle64.rollout(m, cfg, cost, dof, root, np.zeros((H, 7)), eps)
     np.testing.assert_allclose(S, So, rtol=1e-4)
-    _, ao, _ = oracle64.update(cfg, oracle64.record(cfg, So, duo), np.zeros((H, 7)))
+    Uo, ao, _ = oracle64.update(cfg, oracle64.record(cfg, So, duo), np.zeros((H, 7)))
     np.testing.assert_allclose(a, ao, atol=2e-4)
+    np.testing.assert_allclose(c.get("mppi_get_nominal", (H, 7)), Uo, atol=2e-4)   # every row of the shifted nominal
     c.close()
 
 
