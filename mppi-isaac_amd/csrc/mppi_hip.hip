@@ -201,8 +201,7 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
             const char *mode = std::getenv("MPPI_ROLLOUT");
             c->quad = !(mode && std::string(mode) == "lane");
             c->launch_rollout = c->quad ? e->rollout_scene_quad : e->rollout_scene;
-            // (the K = 1 world of a small tree stays on one lane; a larger tree's world step is 3x faster on a quad)
-            c->launch_sim_step = (c->quad && (cfg->num_samples >= 64 || e->nb > 4)) ? e->sim_step_scene_quad : e->sim_step_scene;
+            c->launch_sim_step = c->quad ? e->sim_step_scene_quad : e->sim_step_scene;  // (the K = 1 world included: one quad)
             c->launch_materialise = e->materialise_scene;
             if (hipSetDevice(device) == hipSuccess) lds_err = e->raise_lds(c->lds_bytes, c->lds_bytes_quad);
         } else {

@@ -290,8 +290,10 @@ MPPI_HD void contact_point(const Gains &P, V3 p, V3 n, float depth, const SV &vA
     }
     // one side static: the spring is evaluated at the END of the step, k (depth - h vn+) - hence the h k
     // term in the implicit normal coefficient (unconditionally stable, no bounce at h = 25 ms); the
-    // damper acts only while approaching; friction is implicit too (see below)
-    const float a = (vn < 0.f ? P.cn : 0.f) + P.kh;
+    // damper acts on approach and on separation (an approach-only damper toggles with the sign of v_n: resting jitter);
+    // friction is implicit too (see below)
+    float a = P.cn + P.kh;
+    if (vn > 0.f && a * vn > P.k * depth) a = P.k * depth * frcp(vn);  // (never adhesive at the start velocity)
     const float fn = fmaxf(0.f, P.k * depth - a * vn);
     // Coulomb friction as an implicit secant viscosity b = min(c_t, mu fn / |v_t|): equals the stick damper
     // at small slip, delivers mu*fn while sliding, and - being implicit - can never reverse the slip

@@ -442,7 +442,11 @@ static void contact_point(int mode, real mu, real k, real cn, real ct, real kh, 
         wrench_add(acc->f, p, f, 1);
         return;
     }
-    real a = (vn < 0 ? cn : 0) + kh;
+    /* Kelvin-Voigt damper on approach AND separation (a law that damps the approach only switches c_n on and off with the
+     * sign of v_n and keeps a body that rests on several points rocking at fp32 rounding level), capped so that the force at
+     * the start velocity never turns adhesive: k depth - a v_n >= 0 */
+    real a = cn + kh;
+    if (vn > 0 && a * vn > k * depth) a = k * depth / vn;
     real fn = k * depth - a * vn; if (fn < 0) fn = 0;
     real b = mu * fn / (vtn + (real)1e-9); if (ct < b) b = ct;
     real f[3];

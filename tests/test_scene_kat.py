@@ -227,15 +227,16 @@ def test_randomised_samples_device_arithmetic_matches_oracle(hostemu, oracle64):
                 root, q, qd, cfo = oracle64.scene_step(mg, root, q, qd, oracle64.cmd_map(m, u))
                 differs += int(np.abs(nominal[:, 7:13] - root[:, 7:13]).max() > 1e-4)
                 steps += 1
-                # a support point touching down inside a substep switches its approach damper on (a velocity jump of
-                # beta * v_n): fp32 and fp64 can take that event one substep apart. Such steps are counted, not hidden.
+                # a support point touching down inside a substep switches its damper on (a velocity jump of beta * v_n):
+                # fp32 and fp64 can take that event one substep apart.  Such steps are counted, not hidden (none occur
+                # since the damper also acts on separation; an approach-only damper gave up to 2 % of them).
                 if np.abs(re[:, 0:7] - root[:, 0:7]).max() > 2e-5 or np.abs(re[:, 7:13] - root[:, 7:13]).max() > 2e-3:
                     switched += 1
                     np.testing.assert_allclose(re[:, 0:7], root[:, 0:7], atol=5e-3)
                     continue
                 worst = max(worst, np.abs(cf - cfo).max() / max(1.0, np.abs(cfo).max()))
-        assert worst < 5e-3
-    assert switched <= 0.02 * steps, (switched, steps)
+        assert worst < 1e-3
+    assert switched <= 1, (switched, steps)
     assert differs > 20      # the perturbed worlds really do evolve differently from the nominal one
 
 
