@@ -439,12 +439,12 @@ def test_boxer_push_rollout_matches_oracle(lib, oracle64):
     c.call("mppi_rollout")
     S = c.get("mppi_get_costs", (K,))
     So, duo, vizo = oracle64.rollout(m, cfg, cost, dof, root, np.zeros((H, 2)), eps * 0.3, want_viz=True)
-    np.testing.assert_allclose(S, So, rtol=1e-3)
-    np.testing.assert_allclose(c.get("mppi_get_rollouts", (H, K, 3)), vizo, atol=2e-3)
+    np.testing.assert_allclose(S, So, rtol=1e-5)                                              # measured 3e-7
+    np.testing.assert_allclose(c.get("mppi_get_rollouts", (H, K, 3)), vizo, atol=1e-4)        # measured 8e-6
     a = np.zeros(2, np.float32)
     c.call("mppi_reduce", None); c.call("mppi_update", None, 1)
     Uo, ao, _ = oracle64.update(cfg, oracle64.record(cfg, So, duo), np.zeros((H, 2)))
-    np.testing.assert_allclose(c.get("mppi_get_action", (2,)), ao, atol=5e-3)
+    np.testing.assert_allclose(c.get("mppi_get_action", (2,)), ao, atol=1e-5)                # measured 3e-7
     # full noise, block in front of the robot: properties
     root[scene.actor_index("block"), 0:3] = [0.0, 1.9, 0.0923]
     c.call("mppi_set_noise_dev", None)
@@ -453,9 +453,11 @@ def test_boxer_push_rollout_matches_oracle(lib, oracle64):
     S = c.get("mppi_get_costs", (K,))
     assert np.isfinite(S).all()
     So, _, _ = oracle64.rollout(m, cfg, cost, dof, root, np.zeros((H, 2)), eps)
-    # same cost distribution: medians within 2 %, and at least 80 % of the samples agree to 1 %
-    assert np.median(S) == pytest.approx(np.median(So), rel=2e-2)
-    assert (np.abs(S - So) <= 1e-2 * np.abs(So)).mean() > 0.8
+    # same cost distribution (measured: medians 2e-7 apart, 99.2 % of the samples within 1e-3, all within 1 %; a touch-down
+    # taken one substep apart in fp32 and fp64 splits the few others)
+    assert np.median(S) == pytest.approx(np.median(So), rel=1e-4)
+    assert (np.abs(S - So) <= 1e-3 * np.abs(So)).mean() > 0.95
+    assert (np.abs(S - So) <= 1e-2 * np.abs(So)).mean() > 0.99
     c.close()
 
 
@@ -552,10 +554,10 @@ def test_panda_pick_rollout_matches_oracle(lib, oracle64):
     c.call("mppi_command", capi.fptr(a))
     S = c.get("mppi_get_costs", (K,))
     So, duo, _ = oracle64.rollout(m, cfg, cost, dof, root, np.zeros((H, 9)), eps)
-    assert (np.abs(S - So) <= 1e-3 * np.abs(So)).mean() > 0.95     # contact switching can split a few samples
-    assert np.median(np.abs(S - So) / np.abs(So)) < 1e-5
+    assert (np.abs(S - So) <= 1e-4 * np.abs(So)).mean() > 0.98     # measured: every sample (a touch-down can split a few)
+    assert np.median(np.abs(S - So) / np.abs(So)) < 1e-5             # measured 7e-7
     Uo, ao, _ = oracle64.update(cfg, oracle64.record(cfg, So, duo), np.zeros((H, 9)))
-    np.testing.assert_allclose(a, ao, atol=2e-3)
+    np.testing.assert_allclose(a, ao, atol=1e-5)                     # measured 1e-8
     c.close()
 
 
