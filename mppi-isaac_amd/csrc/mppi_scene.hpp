@@ -293,7 +293,14 @@ MPPI_HD void contact_point(const Gains &P, V3 p, V3 n, float depth, const SV &vA
     // damper acts on approach and on separation (an approach-only damper toggles with the sign of v_n: resting jitter);
     // friction is implicit too (see below)
     float a = P.cn + P.kh;
-    if (vn > 0.f && a * vn > P.k * depth) a = P.k * depth * frcp(vn);  // (never adhesive at the start velocity)
+    {  // never adhesive at the start velocity: a <= k depth / v_n while separating (branch-free; the raw reciprocal is enough)
+#if defined(__HIP_DEVICE_COMPILE__)
+        const float cap = P.k * depth * __builtin_amdgcn_rcpf(fmaxf(vn, 1e-30f));
+#else
+        const float cap = P.k * depth / fmaxf(vn, 1e-30f);
+#endif
+        a = vn > 0.f ? fminf(a, cap) : a;
+    }
     const float fn = fmaxf(0.f, P.k * depth - a * vn);
     // Coulomb friction as an implicit secant viscosity b = min(c_t, mu fn / |v_t|): equals the stick damper
     // at small slip, delivers mu*fn while sliding, and - being implicit - can never reverse the slip
