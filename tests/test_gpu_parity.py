@@ -486,9 +486,9 @@ def test_randomised_actors_per_sample(lib, oracle64):
     assert (np.abs(S - S_nom) > 1e-3 * np.abs(S_nom)).mean() > 0.3         # the perturbed worlds differ from the nominal one
     So, _, _ = oracle64.rollout(m, cfg, cost, dof, root, np.zeros((H, 2)), eps)
     So_nom, _, _ = oracle64.rollout(m0, cfg, cost, dof, root, np.zeros((H, 2)), eps)
-    agree = (np.abs(S - So) <= 1e-2 * np.abs(So)).mean()
-    assert np.median(S) == pytest.approx(np.median(So), rel=2e-2)
-    assert agree > 0.8
+    agree = (np.abs(S - So) <= 1e-3 * np.abs(So)).mean()                       # measured: every sample; medians 1e-7 apart
+    assert np.median(S) == pytest.approx(np.median(So), rel=1e-4)
+    assert agree > 0.95
     assert agree > (np.abs(S - So_nom) <= 1e-2 * np.abs(So_nom)).mean() + 0.1   # and it is THIS seed's worlds that it follows
     ex = load_config({"defaults": [{"mppi": "boxer_push"}, {"isaacgym": "normal"}]}, overrides={"mppi.num_samples": K, "mppi.horizon": H})
     for r in range(2):
@@ -601,8 +601,8 @@ def test_ragged_sizes_contact_scene(K, lib, oracle64, monkeypatch):
         c.set_state(dof, root)
         a = np.zeros(2, np.float32)
         c.call("mppi_command", capi.fptr(a))
-        np.testing.assert_allclose(c.get("mppi_get_costs", (K,)), So, rtol=1e-3)
-        np.testing.assert_allclose(a, ao, atol=5e-3)
+        np.testing.assert_allclose(c.get("mppi_get_costs", (K,)), So, rtol=1e-5)
+        np.testing.assert_allclose(a, ao, atol=5e-4)   # (a handful of samples: the softmax amplifies 1e-7 cost differences to 1e-4)
         info = C.create_string_buffer(256)
         c.call("mppi_kernel_info", info, 256)
         assert (b"rollout=scene-quad" if mode == "quad" else b"rollout=scene ") in info.value
