@@ -693,8 +693,8 @@ def test_more_robots_rollout(actors, init, link, nu, sigma, umax, lib, oracle64)
     S = c.get("mppi_get_costs", (K,))
     So, duo, _ = oracle64.rollout(m, cfg, cost, dof, root, np.zeros((H, nu)), eps)
     assert np.isfinite(S).all()
-    if oracle64.is_scene(m):   # contact switching: distribution-level agreement
-        assert (np.abs(S - So) <= 2e-3 * np.abs(So)).mean() > 0.9
+    if oracle64.is_scene(m):   # (a touch-down taken one substep apart can split single samples: measured none, max 2.5e-7)
+        assert (np.abs(S - So) <= 1e-4 * np.abs(So)).mean() > 0.97
     else:
         np.testing.assert_allclose(S, So, rtol=2e-4)
     c.close()
