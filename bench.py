@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
 """Closed-loop MPPI benchmark on the BASELINE.json workload (Panda 7-DoF reach, K=4096, H=20).
 
-One "step" = one control iteration: rollout kernel (K samples x H horizon steps of articulated-body
-dynamics + fused cost) -> reduce -> (all-gather of shard records when --gpus > 1) -> nominal update
--> the K=1 world is stepped with the action and its new state is fed back (closed loop, everything
-device-resident) -> the action is copied to the host.  Weak scaling: every GPU owns 4096 samples, the
-softmax weights are combined over all ranks; `value` counts 4096-sample control iterations per second
-summed over ranks (at --gpus 1 it is exactly the control-loop Hz at K=4096, H=20).
+One "step" = one control iteration: rollout kernel (K samples x H horizon steps of articulated-body dynamics +
+fused cost + per-wave / per-XCD softmax records) -> (in-place all-gather of the shard records when --gpus > 1) ->
+combine + nominal update + the K=1 world stepped with the action, its new state fed back (closed loop, everything
+device-resident) -> the action reaches the host.  Weak scaling: every GPU owns K samples, the softmax weights are
+combined over all ranks; `value` counts K-sample control iterations per second summed over ranks (at --gpus 1 it is
+exactly the control-loop Hz at K=4096, H=20).
 
-Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement" for how roofline/cpu_baseline are defined.
+Protocol: W untimed warm-up iterations, then EXACTLY K timed ones bracketed by barrier +
+torch.cuda.synchronize(); `value` = K / elapsed (max over ranks); the per-iteration wall times of the same run give
+median / p5 / p95.  Prints ONE JSON line (rank 0).  DESIGN.md "Measurement" defines roofline / cpu_baseline.
 """
 import argparse
 import ctypes
@@ -23,7 +25,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "mppi-isaac_amd"))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP32_LANE_OPS_PEAK = 157.3e12 / 2  # fp32 vector peak 157.3 TFLOP/s = 78.6e12 lane-instructions/s (an FMA counts 2 flops)
+N_SIMD = 1024               # 256 CUs x 4 SIMDs
 # BASELINE.json configs.  The default - and the only one the driver's bench line uses - is panda_reach.
 WORKLOADS = {
     "panda_reach": dict(desc="panda_stick reach (BASELINE configs[2]): ABA from URDF, no contact, fused reach cost",
@@ -42,66 +46,326 @@ WORKLOADS = {
 }
 
 
-def make_cfg(w, k_total):
+def make_cfg(w, k_total, H=None):
     from mppiisaac.utils.config_store import load_config
     return load_config({"defaults": [{"mppi": w["mppi"]}, {"isaacgym": "normal"}], "actors": w["actors"],
                         "initial_actor_positions": w["init"], "nx": w["nx"]},
-                       overrides={"mppi.num_samples": k_total, "mppi.horizon": w["H"], "mppi.filter_u": False,
+                       overrides={"mppi.num_samples": k_total, "mppi.horizon": H or w["H"], "mppi.filter_u": False,
                                   "mppi.use_priors": False})
 
 
-def cpu_baseline(planner, dof, K_PER_GPU, HORIZON, seconds_budget=20.0):
-    """The oracle (C restatement, fp32, OpenMP over samples) timed on this box's host cores on the same
-    K=4096 x H=20 control iteration.  Bounded sample: as many iterations as fit ~seconds_budget."""
-    from mppiisaac.backend import capi
+class Loop:
+    """planner (K rollout envs + MPPI core) and K=1 world of one workload on this rank's GPU, and its iteration"""
+
+    def __init__(self, name, k_per_gpu, env, sync=True, horizon=None):
+        import torch
+        import torch.distributed as dist
+        from mppiisaac.backend import capi
+        import mppiisaac.objectives as objectives
+        from mppiisaac.planner.isaacgym_wrapper import IsaacGymWrapper
+        from mppiisaac.planner.mppi_isaac import MPPIisaacPlanner
+        self.torch, self.dist, self.capi, self.env = torch, dist, capi, env
+        wl = WORKLOADS[name]
+        self.name, self.wl, self.K, self.H, self.sync = name, wl, k_per_gpu, horizon or wl["H"], sync
+        world_size, rank, sharded = env["world_size"], env["rank"], env["sharded"]
+        cfg = make_cfg(wl, k_per_gpu * world_size, self.H)
+        cfg.mppi.device = f"cuda:{env['local_rank']}"
+        self.cfg = cfg
+        self.objective = getattr(objectives, wl["objective"])(cfg)
+        self.planner = MPPIisaacPlanner(cfg, self.objective, shard=sharded)
+        self.world = IsaacGymWrapper(cfg.isaacgym, actors=cfg.actors, init_positions=cfg.initial_actor_positions, num_envs=1,
+                                     device=cfg.mppi.device)
+        self.lib, self.P, self.W = self.planner.sim._lib, self.planner.sim._ctx, self.world._ctx
+        if wl["goal"] is not None:
+            for sim in (self.planner.sim, self.world):
+                sim.set_actor_position_by_name(wl["goal"], "goal")
+        self.dof0 = self.world._dof_state[0].cpu().numpy().copy()
+        if wl["q0"] is not None:
+            self.dof0[0::2] = wl["q0"]
+        self.root0 = self.world._root_state[0].cpu().numpy()
+        for sim in (self.planner.sim, self.world):
+            sim._push_single_state(self.dof0, self.root0)
+        self.planner._bind_objective()
+        self.nu = self.planner.sim.scene.nu
+        self.action = np.zeros(self.nu, np.float32)
+        self._ap = capi.fptr(self.action)
+        self.graph = None
+        self.n_records = 0
+        lib, P = self.lib, self.P
+        if sharded:
+            # this rank's folded records are written by the rollout kernel straight into its rows of the tensor that is
+            # all-gathered IN PLACE: rollout -> all-gather -> combine/update, no separate reduce launch, no staging copy
+            RF = lib.mppi_record_floats(P)
+            self.cnt = lib.mppi_shard_record_count(P)
+            self.inplace = self.cnt > 0
+            per = self.cnt if self.inplace else 1
+            self.records = torch.zeros((world_size * per, RF), dtype=torch.float32, device=cfg.mppi.device)
+            self.mine = self.records[rank * per:(rank + 1) * per]
+            if self.inplace:
+                capi.check(lib, lib.mppi_set_record_out(P, ctypes.c_void_p(self.mine.data_ptr())))
+            self.n_records = world_size * per
+
+    # ---- one control iteration, enqueued (no host wait)
+    def enqueue(self):
+        lib, P, W, capi, env = self.lib, self.P, self.W, self.capi, self.env
+        capi.check(lib, lib.mppi_rollout(P))
+        if env["sharded"]:
+            if not self.inplace:
+                capi.check(lib, lib.mppi_reduce(P, ctypes.c_void_p(self.mine.data_ptr())))
+            if env["backend"] == "nccl":
+                self.dist.all_gather_into_tensor(self.records.view(-1), self.mine.view(-1))
+            else:  # gloo smoke test on a single-GPU box: records staged through the host
+                host = self.torch.empty(self.records.shape, dtype=self.records.dtype)
+                self.torch.cuda.current_stream().synchronize()
+                self.dist.all_gather_into_tensor(host.view(-1), self.mine.cpu().view(-1))
+                self.records.copy_(host)
+            capi.check(lib, lib.mppi_update_step_world(P, ctypes.c_void_p(self.records.data_ptr()), self.n_records, W))
+        else:
+            capi.check(lib, lib.mppi_update_step_world(P, None, 1, W))  # combine + update + world step + state feedback
+
+    def capture(self):
+        """the sharded iteration as ONE HIP graph (library launches + the RCCL all-gather captured by torch): per-iteration
+        host work shrinks to one graph launch.  Returns False (eager loop stays) if the capture is refused."""
+        torch, lib, capi = self.torch, self.lib, self.capi
+        main = torch.cuda.current_stream()
+        try:
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g):
+                cs = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+                for c in (self.P, self.W):
+                    capi.check(lib, lib.mppi_set_stream(c, cs))
+                self.enqueue()
+            self.graph = g
+        except Exception as e:  # noqa: BLE001 - any refusal (RCCL capture unsupported, sync inside) keeps the eager loop
+            print(f"[bench] graph capture refused: {type(e).__name__}: {e}", file=sys.stderr)
+            self.graph = None
+            torch.cuda.synchronize()
+        finally:
+            for c in (self.P, self.W):
+                capi.check(lib, lib.mppi_set_stream(c, ctypes.c_void_p(main.cuda_stream)))
+        return self.graph is not None
+
+    def iterate(self):
+        lib, P, capi = self.lib, self.P, self.capi
+        if self.graph is not None:
+            self.graph.replay()
+            capi.check(lib, lib.mppi_note_graph_update(P))
+        else:
+            self.enqueue()
+        if self.sync:
+            # the controller output reaches the host as soon as the update kernel has published it (polled sequence
+            # number in mapped host memory); MPPI_BENCH_ACTION=sync waits for the whole stream instead
+            capi.check(lib, (lib.mppi_get_action if self.env["action_sync"] else lib.mppi_wait_action)(P, self._ap))
+
+    def barrier(self):
+        if self.env["sharded"]:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def run(self, steps, warmup, profile=True):
+        """W warm-up + exactly `steps` timed iterations; returns elapsed (max over ranks), per-iteration times, kernel ms"""
+        torch, lib, P, capi = self.torch, self.lib, self.P, self.capi
+        for _ in range(warmup):
+            self.iterate()
+        prof = profile and self.graph is None
+        if prof:
+            capi.check(lib, lib.mppi_set_profiling(P, 4))  # hipEvent brackets around every 4th launch of each kernel
+        stamps = np.zeros(steps + 1)
+        self.barrier()
+        stamps[0] = t0 = time.perf_counter()
+        for i in range(steps):
+            self.iterate()
+            stamps[i + 1] = time.perf_counter()
+        self.barrier()
+        elapsed = time.perf_counter() - t0
+        kms = [0.0, 0.0, 0.0]
+        if prof:
+            for which in range(3):
+                ms = ctypes.c_float()
+                rc = lib.mppi_kernel_ms(P, which, ctypes.byref(ms))  # rc != 0: that kernel was not launched (fused tail)
+                kms[which] = ms.value if rc == 0 else 0.0
+            capi.check(lib, lib.mppi_set_profiling(P, 0))
+        if self.env["sharded"]:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if self.env["backend"] == "nccl" else "cpu")
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, np.diff(stamps), kms
+
+    def profile_kernels(self, steps=40):
+        """kernel durations by hipEvents in an eager pass (a captured graph cannot carry the event brackets)"""
+        g, self.graph = self.graph, None
+        _, _, kms = self.run(steps, 0, profile=True)
+        self.graph = g
+        return kms
+
+
+def hbm_copy_ceiling(torch):
+    """measured HBM ceiling next to the 8 TB/s spec: read + write of a 256 MiB device-to-device copy"""
+    a = torch.empty(64 << 20, dtype=torch.float32, device="cuda")
+    b = torch.empty_like(a)
+    b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 10 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+def time_sampler(loop, n=20):
+    """the halton-spline set is fixed (sampled once at construction, never inside the loop): its one-off cost"""
+    import torch
+    lib, P, capi = loop.lib, loop.P, loop.capi
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(n):
+        capi.check(lib, lib.mppi_sample(P, ctypes.c_uint32(0)))
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def cpu_baseline(loop, budget_s=24.0):
+    """CPU rows beside the GPU number, on this box's host cores, bounded to ~budget_s of CPU work:
+      rows[0], rows[1]  the REFERENCE-STRUCTURED pipeline (oracle/cpu_pipeline.py: Python horizon loop -> batched C env
+                        step -> torch-CPU Objective.compute_cost, reference mppi_isaac.py:57-69) with 1 thread and with
+                        all host threads, on the bench workload;
+      rows[2]           the same pipeline on BASELINE configs[0] (point_robot K=64 H=10, the reference's CPU-runnable case);
+      rows[3]           the oracle's fused C loop (oracle/mppi_oracle.c, OpenMP over samples): faster than the reference
+                        structure, kept as the conservative comparison.
+    `value` = rows[1] (all threads, reference structure, same K x H workload)."""
+    import torch
+    from oracle.cpu_pipeline import CpuPipeline
     from oracle.oracle import Oracle
-    sim = planner.sim
+    import mppiisaac.objectives as objectives
+    from mppiisaac.planner.isaacgym_wrapper import IsaacGymWrapper
+    from mppiisaac.planner.mppi import make_config
+    sim = loop.planner.sim
+    capi = loop.capi
     cores = os.cpu_count() or 1
-    os.environ["OMP_NUM_THREADS"] = str(cores)
-    o = Oracle("f32")
-    nu = sim.scene.nu
-    eps = np.zeros((HORIZON, nu, K_PER_GPU), np.float32)
+    K, H, nu = loop.K, loop.H, loop.nu
+    eps = np.zeros((H, nu, K), np.float32)
     capi.check(sim._lib, sim._lib.mppi_get_noise(sim._ctx, capi.fptr(eps)))
-    root = sim._root_state[0].cpu().numpy()
-    U = np.zeros((HORIZON, nu), np.float32)
-    cost = planner.objective.fused_spec(sim)
+    eps_t = torch.from_numpy(eps)
+    unit = f"Hz (K={K},H={H} control iterations/s)"
+    rows = []
+    # bounded sample: a row times the first K_cpu samples of the same sample set (contact scenes at K=8192 would take minutes
+    # on one thread) and reports the rate scaled to the full K (per-sample work is independent: time is linear in K)
+    per_sample_cost = H * (30 if loop.name in ("boxer_push", "panda_pick") else 1)
+    for threads, share, kmax in ((1, 0.35, max(256, 65536 // per_sample_cost)), (cores, 0.25, max(2048, 2 ** 21 // per_sample_cost))):
+        k_cpu = min(K, kmax)
+        c_cfg = make_config(loop.cfg.mppi, k_offset=loop.env["rank"] * K, k_local=k_cpu, viz_link=sim.scene.viz_link_index())
+        p = CpuPipeline(sim.scene, sim._c_model, c_cfg, loop.objective, threads)
+        dt, n = p.time_iterations(loop.dof0, loop.root0, eps_t[:, :, :k_cpu].contiguous(), budget_s * share, max_iters=10)
+        dt *= K / k_cpu
+        rows.append({"pipeline": "reference-structured (python horizon loop -> batched C step -> torch-CPU Objective)", "threads": threads,
+                     "value": 1.0 / dt, "unit": unit, "ms_per_iteration": dt * 1e3, "iterations": n,
+                     "samples_timed": k_cpu, "scaled_to_K": K})
+    # BASELINE configs[0]: point_robot K=64 H=10 (reference benchmarks/point_robot/setup/exp.yaml:21-22,32-39)
+    w0 = WORKLOADS["point_reach"]
+    cfg0 = make_cfg(w0, 64, 10)
+    from mppiisaac.utils.isaacgym_utils import load_actor_cfgs, load_asset
+    from mppiisaac.planner.isaacgym_wrapper import Scene
+    env0 = load_actor_cfgs(w0["actors"])
+    robots = [a for a in env0 if a.type == "robot"]
+    robots[0].init_pos = list(w0["init"][0])
+    sc0 = Scene(env0, cfg0.isaacgym, load_asset(robots[0]))
+    c0 = make_config(cfg0.mppi, viz_link=sc0.viz_link_index())
+    dof, root = sc0.initial_state()
+    dof[0::2] = w0["q0"]
+    root[sc0.actor_index("goal"), 0:3] = w0["goal"]
+    o32 = Oracle("f32")
+    p0 = CpuPipeline(sc0, sc0.to_c(), c0, objectives.PointReachObjective(cfg0), 1)
+    dt, n = p0.time_iterations(dof, root, torch.from_numpy(o32.sample(c0)), budget_s * 0.1, max_iters=200)
+    rows.append({"pipeline": "reference-structured, BASELINE configs[0] point_robot K=64 H=10", "threads": 1, "value": 1.0 / dt,
+                 "unit": "Hz (K=64,H=10 control iterations/s)", "ms_per_iteration": dt * 1e3, "iterations": n})
+    # fused C loop, all threads
+    o32.lib.orc_set_threads(ctypes.c_int(cores))
+    U = np.zeros((H, nu), np.float32)
+    cost = loop.objective.fused_spec(sim)
     t0 = time.perf_counter()
-    U, a, S = o.command(sim._c_model, sim._mppi_config, cost, dof, root, U, eps)
+    U, a, S = o32.command(sim._c_model, sim._mppi_config, cost, loop.dof0, loop.root0, U, eps)
     first = time.perf_counter() - t0
-    n = max(1, min(20, int(seconds_budget / max(first, 1e-3)) - 1))
+    n = max(1, min(20, int(budget_s * 0.25 / max(first, 1e-3)) - 1))
     t0 = time.perf_counter()
     for _ in range(n):
-        U, a, S = o.command(sim._c_model, sim._mppi_config, cost, dof, root, U, eps)
+        U, a, S = o32.command(sim._c_model, sim._mppi_config, cost, loop.dof0, loop.root0, U, eps)
     dt = (time.perf_counter() - t0) / n
-    return {"value": 1.0 / dt, "unit": f"Hz (K={K_PER_GPU},H={HORIZON} control iterations/s)", "cores": cores, "kind": "port",
-            "sample": f"{n} open-loop control iterations of the same K={K_PER_GPU}xH={HORIZON} workload, oracle/mppi_oracle.c fp32, "
-                      f"OpenMP over samples on {cores} host threads ({dt * 1e3:.1f} ms/iteration)"}
+    rows.append({"pipeline": "oracle fused C loop (oracle/mppi_oracle.c, OpenMP over samples)", "threads": cores, "value": 1.0 / dt,
+                 "unit": unit, "ms_per_iteration": dt * 1e3, "iterations": n})
+    return {"value": rows[1]["value"], "unit": unit, "cores": cores, "kind": "port",
+            "sample": f"{rows[1]['iterations']} open-loop control iterations of the same K={K} x H={H} workload through the "
+                      f"reference-structured CPU pipeline (oracle/cpu_pipeline.py, fp32) on {cores} host threads "
+                      f"({rows[1]['ms_per_iteration']:.1f} ms/iteration); rows: 1 thread, all threads, configs[0], fused C loop",
+            "rows": rows}
+
+
+def roofline(loop, kms, hbm_measured, n_waves):
+    """HBM view (north_star's yardstick) and instruction-issue view (the bound that matters here) of the rollout kernel"""
+    K, H, nu = loop.K, loop.H, loop.nu
+    bytes_alg = 4 * (3 * K * H * nu + 2 * K + H * nu)  # SURVEY.md 8d, per GPU per control iteration
+    achieved = bytes_alg / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+    key = loop.wl["desc"].split(" ")[0]
+    traffic, traffic_src, issue = None, None, None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if os.path.exists(pmc_path):
+        pmc = json.load(open(pmc_path)).get("by_workload", {}).get(key)
+        if pmc and pmc.get("K", K) == K:
+            traffic = pmc.get("k_rollout", {}).get("hbm_traffic_bytes_per_launch")
+            traffic_src = f"profiles/{pmc.get('tag')}_pmc_summary.json (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes of this command)"
+    sq_path = os.path.join(ROOT, "profiles", "sq_latest.json")
+    if os.path.exists(sq_path):
+        sq = json.load(open(sq_path)).get("by_workload", {}).get(key)
+        if sq and sq.get("K", K) == K and kms > 0:
+            k = sq["k_rollout"]
+            valu, waves = k["SQ_INSTS_VALU_per_wave"], k["SQ_WAVES"]
+            issue = {"valu_per_wave": valu, "salu_per_wave": k.get("SQ_INSTS_SALU_per_wave"), "lds_per_wave": k.get("SQ_INSTS_LDS_per_wave"),
+                     "waves": waves, "kernel_ms": kms,
+                     "lane_ops_per_s": valu * waves * 64 / (kms * 1e-3),
+                     "frac_of_fp32_issue_peak": valu * waves * 64 / (kms * 1e-3) / FP32_LANE_OPS_PEAK,
+                     "simd_occupancy": min(1.0, waves / N_SIMD),
+                     "issue_cycles_frac": k.get("issue_cycles_frac"), "wait_cycles_frac": k.get("wait_cycles_frac"),
+                     "lds_bank_conflict_per_wave": k.get("SQ_LDS_BANK_CONFLICT_per_wave"),
+                     "source": f"profiles/{sq.get('tag')}_sq_summary.json (rocprofv3 --pmc SQ_* passes of this command; kernel_ms live)"}
+    lane = os.environ.get("MPPI_ROLLOUT") == "lane"
+    scene = loop.name in ("boxer_push", "panda_pick")
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": traffic_src, "kernel": ("k_rollout_scene" if scene else "k_rollout") + ("" if lane else "_quad"),
+            "peak_measured": hbm_measured, "kernel_ms": kms, "bytes_alg_per_launch": bytes_alg, "wavefronts": n_waves,
+            "issue": issue,
+            "note": "instruction-issue-bound path (SURVEY 8d; DESIGN.md 5-6): one sample per 4-lane quad = K/16 wavefronts on 1024 SIMDs; "
+                    "`issue` restates the kernel against the fp32 vector issue rate from the committed SQ counters; "
+                    "peak_measured = device-to-device copy of 256 MiB (read + write bytes / time) on this GPU"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=200)     # SURVEY 8d: 20 warm-up + 200 timed iterations
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--async-loop", action="store_true", help="do not copy the action to the host every iteration")
+    ap.add_argument("--async-loop", action="store_true", help="do not wait for the action on the host every iteration")
     ap.add_argument("--workload", default="panda_reach", choices=sorted(WORKLOADS), help="BASELINE config (default: the metric's)")
+    ap.add_argument("--k-total", type=int, default=0,
+                    help="total number of samples over all GPUs (default: the workload's K per GPU x --gpus); "
+                         "`--workload panda_pick --k-total 65536` is BASELINE configs[4] at its stated size on however many GPUs")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
-    K_PER_GPU, HORIZON = wl["K"], wl["H"]
 
     import torch
     import torch.distributed as dist
-    from mppiisaac.backend import capi
-    import mppiisaac.objectives as objectives
-    from mppiisaac.planner.isaacgym_wrapper import IsaacGymWrapper
-    from mppiisaac.planner.mppi_isaac import MPPIisaacPlanner
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world_size:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.k_total and args.k_total % world_size:
+        raise SystemExit("--k-total must be a multiple of --gpus")
+    K_PER_GPU = args.k_total // world_size if args.k_total else wl["K"]
     # one process per GPU over RCCL.  MPPI_BENCH_BACKEND=gloo (ranks may then share a GPU, records staged
     # through the host) exists only to smoke-test the sharded loop on a single-GPU box.
     backend = os.environ.get("MPPI_BENCH_BACKEND", "nccl")
@@ -124,115 +388,52 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world_size)
-
-    cfg = make_cfg(wl, K_PER_GPU * world_size)
-    cfg.mppi.device = f"cuda:{local_rank}"
-    objective = getattr(objectives, wl["objective"])(cfg)
-    planner = MPPIisaacPlanner(cfg, objective, shard=sharded)
-    world = IsaacGymWrapper(cfg.isaacgym, actors=cfg.actors, init_positions=cfg.initial_actor_positions, num_envs=1,
-                            device=cfg.mppi.device)
-    lib, P, W = planner.sim._lib, planner.sim._ctx, world._ctx
-    GOAL = wl["goal"]
-    if GOAL is not None:
-        for sim in (planner.sim, world):
-            sim.set_actor_position_by_name(GOAL, "goal")
-    dof0 = world._dof_state[0].cpu().numpy().copy()
-    if wl["q0"] is not None:
-        dof0[0::2] = wl["q0"]
-    root0 = world._root_state[0].cpu().numpy()
-    for sim in (planner.sim, world):
-        sim._push_single_state(dof0, root0)
-    planner._bind_objective()
-    records = planner.mppi._records
-    send = torch.zeros_like(records[0])  # this rank's shard record (written by mppi_reduce, gathered into `records`)
-    nu = planner.sim.scene.nu
-    action = np.zeros(nu, np.float32)
-    ap_ = capi.fptr(action)
-
-    action_sync = os.environ.get("MPPI_BENCH_ACTION") == "sync"
-
-    def iterate(sync):
-        capi.check(lib, lib.mppi_rollout(P))
-        if sharded:
-            capi.check(lib, lib.mppi_reduce(P, ctypes.c_void_p(send.data_ptr())))
-            if backend == "nccl":
-                dist.all_gather_into_tensor(records.view(-1), send)
-            else:
-                host = torch.empty(records.shape, dtype=records.dtype)
-                dist.all_gather_into_tensor(host.view(-1), send.cpu())
-                records.copy_(host)
-            capi.check(lib, lib.mppi_update_step_world(P, ctypes.c_void_p(records.data_ptr()), world_size, W))
-        else:
-            capi.check(lib, lib.mppi_reduce(P, None))
-            capi.check(lib, lib.mppi_update_step_world(P, None, 1, W))  # update + world step + state feedback
-        if sync:
-            # the controller output reaches the host as soon as the update kernel has published it (polled sequence
-            # number in mapped host memory); MPPI_BENCH_ACTION=sync waits for the whole stream instead
-            capi.check(lib, (lib.mppi_get_action if action_sync else lib.mppi_wait_action)(P, ap_))
-
-    def barrier():
-        if sharded:
-            dist.barrier()
-        torch.cuda.synchronize()
-
+    env = dict(world_size=world_size, rank=rank, local_rank=local_rank, sharded=sharded, backend=backend,
+               action_sync=os.environ.get("MPPI_BENCH_ACTION") == "sync")
     sync = not args.async_loop
-    for _ in range(args.warmup):
-        iterate(sync)
-    capi.check(lib, lib.mppi_set_profiling(P, 4))  # hipEvent brackets around every 4th launch of each kernel
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        iterate(sync)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kms = []
-    for which in range(3):
-        ms = ctypes.c_float()
-        rc = lib.mppi_kernel_ms(P, which, ctypes.byref(ms))  # rc != 0: that kernel was not launched (fused tail)
-        kms.append(ms.value if rc == 0 else 0.0)
-    capi.check(lib, lib.mppi_set_profiling(P, 0))
-    if sharded:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    use_graph = sharded and backend == "nccl" and os.environ.get("MPPI_BENCH_GRAPH", "1") != "0"
+
+    def measure(name, k_per_gpu, steps, warmup):
+        loop = Loop(name, k_per_gpu, env, sync=sync)
+        graphed = False
+        if use_graph:
+            for _ in range(3):
+                loop.iterate()     # lazy initialisation (RCCL channels, LDS limits) must not happen under capture
+            graphed = loop.capture()
+        elapsed, per_iter, kms = loop.run(steps, warmup)
+        if graphed:
+            kms = loop.profile_kernels()
+        return loop, elapsed, per_iter, kms, graphed
+
+    loop, elapsed, per_iter, kms, graphed = measure(args.workload, K_PER_GPU, args.steps, args.warmup)
+    # for N > 1 the 177-us panda iteration is dominated by the collective's latency; SURVEY 8e's scaling argument is made
+    # on the 8192-per-GPU panda_pick shard (BASELINE configs[4]), so that workload is timed in the same job as well
+    second = None
+    if world_size > 1 and args.workload == "panda_reach" and os.environ.get("MPPI_BENCH_SECOND", "1") != "0":
+        del_loop = measure("panda_pick", WORKLOADS["panda_pick"]["K"], max(20, min(args.steps, 100)), min(args.warmup, 10))
+        l2, e2, p2, k2, g2 = del_loop
+        second = {"workload": WORKLOADS["panda_pick"]["desc"], "K_per_gpu": l2.K, "K_total": l2.K * world_size, "H": l2.H,
+                  "steps": len(p2), "ms_per_step": 1e3 * e2 / len(p2), "loop_hz": len(p2) / e2, "value_hz_summed_over_gpus": world_size * len(p2) / e2,
+                  "env_steps_per_s": world_size * len(p2) / e2 * l2.K * l2.H, "rollout_kernel_ms": k2[0], "graph": g2}
 
     # final state sanity (default workload): the closed loop must have moved the end effector to the goal
+    world = loop.world
     world._materialise()
     dist_to_goal = None
     final_root = [round(float(v), 4) for v in world._root_state[0, :, 0:3].reshape(-1).cpu().numpy()]  # actor positions: run-to-run sanity
     if args.workload == "panda_reach":
         ee = world.get_actor_link_by_name("panda", "panda_ee_tip")[0, 0:3].cpu().numpy()
-        dist_to_goal = float(np.linalg.norm(ee - np.asarray(GOAL)))
+        dist_to_goal = float(np.linalg.norm(ee - np.asarray(wl["goal"])))
 
     if rank == 0:
         loop_hz = args.steps / elapsed
-        K, H = K_PER_GPU, HORIZON
-        bytes_alg = 4 * (3 * K * H * nu + 2 * K + H * nu)  # SURVEY.md 8d, per GPU per control iteration
-        achieved = bytes_alg / (kms[0] * 1e-3) / 1e9
-        traffic, traffic_src = None, None  # HBM bytes/launch from the last committed rocprofv3 PMC passes
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc_path):
-            pmc = json.load(open(pmc_path)).get("by_workload", {}).get(wl["desc"].split(" ")[0])
-            if pmc:
-                traffic = pmc.get("k_rollout", {}).get("hbm_traffic_bytes_per_launch")
-                traffic_src = f"profiles/{pmc.get('tag')}_pmc_summary.json (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes of this command)"
-        lane = os.environ.get("MPPI_ROLLOUT") == "lane"
-        scene = args.workload in ("boxer_push", "panda_pick")
-        kernel_name = ("k_rollout_scene" if scene else "k_rollout") + ("" if lane else "_quad")
-        # measured HBM ceiling next to the 8 TB/s spec: read + write of a 256 MiB device-to-device copy
-        a = torch.empty(64 << 20, dtype=torch.float32, device="cuda")
-        b = torch.empty_like(a)
-        b.copy_(a)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            b.copy_(a)
-        e1.record()
-        torch.cuda.synchronize()
-        hbm_measured = 10 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-        del a, b
+        K, H, nu = loop.K, loop.H, loop.nu
+        lat = per_iter * 1e3
+        quad = os.environ.get("MPPI_ROLLOUT") != "lane"
+        n_waves = (K + 15) // 16 if quad else (K + 63) // 64
+        sampler_ms = time_sampler(loop) if loop.planner.sim._mppi_config.sampling == 0 else None
         out = {
-            "metric": "MPPI control-loop Hz (K samples x H horizon), Panda 7-DoF K=4096 H=20" if args.workload == "panda_reach"
+            "metric": "MPPI control-loop Hz (K samples x H horizon), Panda 7-DoF K=4096 H=20" if (args.workload == "panda_reach" and K == 4096)
                       else f"MPPI control-loop Hz, {args.workload} K={K} H={H} (not the BASELINE metric)",
             "value": loop_hz * world_size,
             "unit": f"Hz ({K}-sample x {H}-step control iterations per second, summed over GPUs)",
@@ -240,26 +441,31 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "latency_ms": {"median": float(np.median(lat)), "p5": float(np.percentile(lat, 5)), "p95": float(np.percentile(lat, 95)),
+                           "hz_at_median": 1e3 / float(np.median(lat)),
+                           "how": "host wall time between consecutive published actions of the SAME timed run" if sync
+                                  else "enqueue time only (--async-loop)"},
             "config": {"workload": wl["desc"],
-                       "K_per_gpu": K, "K_total": K * world_size, "H": H, "nu": nu, "dt": cfg.isaacgym.dt,
-                       "substeps": cfg.isaacgym.substeps, "closed_loop": True, "action_to_host_every_step": sync,
-                       "parallelism": f"sample-shard x{world_size} ({backend} all-gather of the shard records)" if sharded else "single GPU",
+                       "K_per_gpu": K, "K_total": K * world_size, "H": H, "nu": nu, "dt": loop.cfg.isaacgym.dt,
+                       "substeps": loop.cfg.isaacgym.substeps, "closed_loop": True, "action_to_host_every_step": sync,
+                       "parallelism": (f"sample-shard x{world_size}: rollout -> in-place {backend} all-gather of {loop.n_records} folded records -> combine"
+                                       + (" (one captured HIP graph per iteration)" if graphed else "")) if sharded else "single GPU",
+                       "noise": ("fixed halton-spline set, sampled once at construction (k_sample %.1f us, outside the loop)" % (1e3 * sampler_ms))
+                                if sampler_ms is not None else "gaussian, redrawn on the device every iteration",
                        "loop_hz": loop_hz, "env_steps_per_s": loop_hz * K * H * world_size,
-                       "final_ee_to_goal_m": dist_to_goal, "final_actor_positions": final_root},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": kernel_name, "peak_measured": hbm_measured,
-                         "kernel_ms": kms[0], "bytes_alg_per_launch": bytes_alg,
-                         "note": "instruction-issue-bound path (SURVEY 8d; DESIGN.md 6): one sample per 4-lane quad = K/16 wavefronts, one per CU at K=4096; "
-                                 "peak_measured = device-to-device copy of 256 MiB (read + write bytes / time) on this GPU"},
-            "kernels_ms": {"k_rollout(+record tail)": kms[0], "k_reduce(generic mode only)": kms[1], "k_combine_update": kms[2]},
+                       "final_ee_to_goal_m": dist_to_goal, "final_actor_positions": final_root,
+                       "cfg5_shard": second},
+            "roofline": roofline(loop, kms[0], hbm_copy_ceiling(torch), n_waves),
+            "kernels_ms": {"k_rollout(+record tail)": kms[0], "k_reduce(generic mode only)": kms[1], "k_combine_update(+world step)": kms[2]},
         }
         if world_size == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(planner, dof0, K_PER_GPU, HORIZON)
+            out["cpu_baseline"] = cpu_baseline(loop)
         ctypes.CDLL(None).fflush(None)  # (C stdio of the libraries: out through the redirected fd before it is restored)
         sys.stdout.flush()
         os.dup2(stdout_fd, 1)
         print(json.dumps(out), flush=True)
     if sharded:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MPPI_ABI_VERSION 1
+#define MPPI_ABI_VERSION 2
 
 #define MPPI_MAX_BODIES 12   /* moving bodies (= DOF) of the articulated robot        */
 #define MPPI_MAX_LINKS 24    /* reported rigid bodies of the robot (URDF links)      */
@@ -55,7 +55,14 @@ enum {
     MPPI_COST_BOXER_PUSH = 3,  /* examples/boxer_push/planner.py:26-67                      */
     MPPI_COST_PANDA_PICK = 4   /* examples/panda_pick/planner.py:24-53                      */
 };
-enum { MPPI_SAMPLE_HALTON_SPLINE = 0, MPPI_SAMPLE_EXTERNAL = 1 };
+/* noise sources of the sampler (mppi_mode / sampling_method of the conf/mppi files):
+ *   HALTON_SPLINE  fixed low-discrepancy set: scrambled-Halton knots -> Phi^-1 -> B-spline (mppi_sample, once)
+ *   EXTERNAL       the caller owns a device buffer eps [H][nu][K] (mppi_set_noise_dev)
+ *   NORMAL         counter-based Gaussian draws (Philox4x32-10 keyed by seed, counter = global sample id, control
+ *                  dimension, knot block, iteration; Box-Muller in fp64), redrawn by mppi_sample_normal every
+ *                  control iteration: knots through spline_basis ("halton-spline" mode with sampling_method
+ *                  "random"), or one draw per horizon step when n_knots == horizon (mppi_mode "simple")       */
+enum { MPPI_SAMPLE_HALTON_SPLINE = 0, MPPI_SAMPLE_EXTERNAL = 1, MPPI_SAMPLE_NORMAL = 2 };
 /* collision primitives: URDF <collision> boxes / meshes (as their AABB) / spheres / thin cylinders
  * (wheels, casters: "disc", axis = local z of the shape frame); box and sphere actors
  * (isaacgym_utils.py:26-52).  Contact model: DESIGN.md section 3 (build-normative). */
@@ -171,7 +178,7 @@ typedef struct mppi_config {
     int32_t sample_null_action; /* global sample k_total-1 uses u = 0                    */
     int32_t use_priors;    /* global sample k_total-2 uses the prior sequence            */
     int32_t sampling;      /* MPPI_SAMPLE_*                                              */
-    int32_t n_knots;       /* halton-spline: knots per control dim (H/4; = H if < 3)     */
+    int32_t n_knots;       /* knots per control dim (H/4; = H if < 3); NORMAL: = H -> no spline */
     int32_t noise_abs_cost;
     int32_t want_rollouts; /* record visualize_link positions [H][K][3] (get_rollouts)   */
     int32_t viz_link;      /* link index recorded when want_rollouts                     */
@@ -181,6 +188,7 @@ typedef struct mppi_config {
     double u_init;
     double u_min[MPPI_MAX_NU], u_max[MPPI_MAX_NU];
     double noise_sigma_diag[MPPI_MAX_NU]; /* diagonal of noise_sigma (variances)        */
+    double noise_mu[MPPI_MAX_NU];         /* mean of the sampled noise (MPPIConfig.noise_mu; NORMAL sampling) */
     double spline_basis[MPPI_MAX_H * MPPI_MAX_KNOTS]; /* [H][n_knots] row-major          */
 } mppi_config_t;
 
@@ -215,8 +223,14 @@ int mppi_get_state(mppi_ctx_t *ctx, float *dof_state_host, float *root_state_hos
 /* ---- MPPI core: replaces mppi_torch.MPPIPlanner.command (call sites mppi_isaac.py:84,113) */
 int mppi_set_cost(mppi_ctx_t *ctx, const mppi_cost_t *cost);
 int mppi_sample(mppi_ctx_t *ctx, uint32_t index_base);        /* halton-spline -> eps [H][nu][K] */
+/* NORMAL sampling: eps = noise_mu + sqrt(noise_sigma) * (basis . z), z ~ N(0,1) from Philox4x32-10 with key
+ * (config.seed, 'MPPI') and counter (global sample id, control dim, knot block, iteration): the draw depends on the
+ * GLOBAL sample id only, so any sharding sees the same noise.  Call once per control iteration (what mppi_torch's
+ * simple mode does with torch's generator inside MPPIPlanner.command, call sites mppi_isaac.py:84,113). */
+int mppi_sample_normal(mppi_ctx_t *ctx, uint32_t iteration);
 int mppi_set_noise_dev(mppi_ctx_t *ctx, const float *eps_dev); /* external eps [H][nu][K]        */
 int mppi_set_prior(mppi_ctx_t *ctx, const float *prior_host);  /* [H][nu] for sample k_total-2   */
+int mppi_set_prior_row(mppi_ctx_t *ctx, int t, const float *row_host); /* [nu]: prior(state, t) evaluated AT rollout step t (generic mode) */
 int mppi_set_nominal(mppi_ctx_t *ctx, const float *U_host);    /* [H][nu]                        */
 int mppi_get_nominal(mppi_ctx_t *ctx, float *U_host);
 /* filter_u: linear smoothing operator F [H][H] applied to the updated nominal (U <- F U) before the action is taken;
@@ -225,6 +239,13 @@ int mppi_set_filter(mppi_ctx_t *ctx, const float *F_host);
 int mppi_rollout(mppi_ctx_t *ctx);   /* persistent kernel: K samples x H steps, fused cost -> S[K], du */
 int mppi_reduce(mppi_ctx_t *ctx, float *record_out_dev); /* shard record (beta, eta, N[H*nu]); NULL = internal buffer */
 int mppi_record_floats(const mppi_ctx_t *ctx);               /* 2 + H*nu                             */
+/* The fused quad rollout kernels fold their per-wavefront records per XCD group in their own tail: after mppi_rollout the
+ * shard is described by mppi_shard_record_count() records of mppi_record_floats() floats (8; 1 for grids that are no
+ * multiple of 16 wavefronts; 0 = this context does not fold - lane kernels, generic mode - use mppi_reduce).
+ * mppi_set_record_out points the fold at a caller buffer [count][2+H*nu] (NULL = internal), e.g. this rank's rows of the
+ * tensor that is all-gathered in place: the sharded iteration is then rollout -> all-gather -> mppi_update(all records). */
+int mppi_shard_record_count(const mppi_ctx_t *ctx);
+int mppi_set_record_out(mppi_ctx_t *ctx, float *records_dev);
 int mppi_record_dev(mppi_ctx_t *ctx, float **record_dev);    /* device pointer of this shard's record */
 /* combine n shard records (device, [n][2+H*nu]; NULL = own record), update U, emit action, shift */
 int mppi_update(mppi_ctx_t *ctx, const float *records_dev, int n_records);
@@ -235,6 +256,9 @@ int mppi_get_action(mppi_ctx_t *ctx, float *action_host);     /* [nu]; synchroni
  * behind it on the stream.  Same role as the `.cpu()` of the action in mppi_isaac.py:84. */
 int mppi_wait_action(mppi_ctx_t *ctx, float *action_host);
 int mppi_action_dev(mppi_ctx_t *ctx, float **action_dev);
+/* one update (mppi_update / mppi_update_step_world) was enqueued OUTSIDE this API - the replay of a HIP graph the launches
+ * were captured into: advances the sequence number mppi_wait_action waits for */
+int mppi_note_graph_update(mppi_ctx_t *ctx);
 int mppi_command(mppi_ctx_t *ctx, float *action_host);        /* rollout+reduce+update+get_action     */
 int mppi_get_costs(mppi_ctx_t *ctx, float *S_host);           /* [K] total trajectory costs           */
 int mppi_get_weights_stats(mppi_ctx_t *ctx, float *beta_eta_host); /* [2]                             */

@@ -96,6 +96,9 @@ int create_buffers(mppi_ctx *c, const mppi_config_t *cfg) {
     ALLOC_TRY(c->d_viz, sizeof(float) * (cfg->want_rollouts ? (size_t)c->H * K * 3 : 1));
     ALLOC_TRY(c->d_partials, sizeof(float) * (size_t)c->n_quads * c->RF);
     ALLOC_TRY(c->d_record, sizeof(float) * c->RF);
+    ALLOC_TRY(c->d_fold, sizeof(float) * kFoldGroups * c->RF);
+    ALLOC_TRY(c->d_fold_ctr, sizeof(unsigned) * kFoldGroups);
+    c->fold_out = c->d_fold;
     ALLOC_TRY(c->d_action, sizeof(float) * c->nu);
     ALLOC_TRY(c->d_beta_eta, sizeof(float) * 2);
     ALLOC_TRY(c->d_q, sizeof(float) * c->n * K);
@@ -106,10 +109,13 @@ int create_buffers(mppi_ctx *c, const mppi_config_t *cfg) {
     ALLOC_TRY(c->d_cf, sizeof(float) * 3 * c->B * K);
     ALLOC_TRY(c->d_filter, sizeof(float) * c->H * c->H);
     ALLOC_TRY(c->d_basis, sizeof(double) * MPPI_MAX_H * MPPI_MAX_KNOTS);
-    ALLOC_TRY(c->d_sigma, sizeof(double) * MPPI_MAX_NU);
+    ALLOC_TRY(c->d_sigma, sizeof(double) * 2 * MPPI_MAX_NU);  // sqrt(sigma_diag) | noise_mu
     c->eps_in = c->d_eps;
-    double sig[MPPI_MAX_NU] = {0};
-    for (int j = 0; j < c->nu; j++) sig[j] = std::sqrt(cfg->noise_sigma_diag[j]);
+    double sig[2 * MPPI_MAX_NU] = {0};
+    for (int j = 0; j < c->nu; j++) {
+        sig[j] = std::sqrt(cfg->noise_sigma_diag[j]);
+        sig[MPPI_MAX_NU + j] = cfg->noise_mu[j];
+    }
     HIP_TRY(hipMemcpy(c->d_model, &c->hm, sizeof(DevModel), hipMemcpyHostToDevice));
     // the update kernels also store the action into mapped pinned host memory: mppi_get_action is then a stream
     // synchronise + a host read instead of a D2H copy operation
@@ -134,7 +140,7 @@ void release_ctx(mppi_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *bufs[] = {c->d_model, c->d_cfg, c->d_cost, c->d_x0_dof, c->d_x0_root, c->d_U, c->d_eps, c->d_du, c->d_S, c->d_prior, c->d_viz,
                     c->d_partials, c->d_record, c->d_action, c->d_beta_eta, c->d_q, c->d_qd, c->d_ctrl, c->d_basis, c->d_sigma, c->d_base, c->d_fr, c->d_cf, c->d_filter,
-                    c->d_seq};
+                    c->d_seq, c->d_fold, c->d_fold_ctr};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->h_action) (void)hipHostFree(c->h_action);
@@ -238,6 +244,10 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
         delete c;
         return fail(MPPI_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
     }
+    {   // wave records folded per XCD group inside the quad rollout kernels (MPPI_FOLD=0: A/B switch, one record per wavefront)
+        const char *f = std::getenv("MPPI_FOLD");
+        c->fold = c->quad && !(f && std::string(f) == "0");
+    }
     const int rc = create_buffers(c, cfg);
     if (rc != MPPI_OK) {  // (the error text is already set) nothing allocated so far may leak
         release_ctx(c);
@@ -313,6 +323,15 @@ int mppi_sample(mppi_ctx_t *c, uint32_t index_base) {
     c->eps_in = c->d_eps;
     return launch_check();
 }
+int mppi_sample_normal(mppi_ctx_t *c, uint32_t iteration) {
+    CTX_TRY(c);
+    if (c->cfg.sampling != MPPI_SAMPLE_NORMAL) return fail(MPPI_ESTATE, "mppi_sample_normal: config.sampling is not MPPI_SAMPLE_NORMAL");
+    const int threads = c->K * c->nu;
+    hipLaunchKernelGGL(k_sample_normal, dim3((threads + kWave - 1) / kWave), dim3(kWave), 0, c->stream, c->d_cfg, c->d_basis, c->d_sigma, c->cfg.n_knots,
+                       (uint32_t)c->cfg.seed, iteration, c->d_eps);
+    c->eps_in = c->d_eps;
+    return launch_check();
+}
 int mppi_set_noise_dev(mppi_ctx_t *c, const float *eps_dev) {
     CTX_TRY(c);
     c->eps_in = eps_dev ? eps_dev : c->d_eps;
@@ -325,6 +344,14 @@ int mppi_set_prior(mppi_ctx_t *c, const float *prior) {
         HIP_TRY(hipMemcpyAsync(c->d_prior, prior, sizeof(float) * c->HN, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
+    return MPPI_OK;
+}
+int mppi_set_prior_row(mppi_ctx_t *c, int t, const float *row) {
+    CTX_TRY(c);
+    if (!row || t < 0 || t >= c->H) return fail(MPPI_EINVAL, "mppi_set_prior_row: null row or t outside the horizon");
+    c->has_prior = true;
+    HIP_TRY(hipMemcpyAsync(c->d_prior + (size_t)t * c->nu, row, sizeof(float) * c->nu, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return MPPI_OK;
 }
 int mppi_set_nominal(mppi_ctx_t *c, const float *U) {
@@ -358,7 +385,13 @@ int mppi_rollout(mppi_ctx_t *c) {
         c->launch_rollout(c);
     }
     c->partials_valid = true;
-    c->n_partials = c->quad ? c->n_quads : c->n_waves;
+    if (c->fold) {  // the kernel's tail left one record per XCD group (ragged grids: one) in fold_out
+        c->n_partials = c->n_quads % 16 == 0 ? kFoldGroups : 1;
+        c->recs_cur = c->fold_out;
+    } else {
+        c->n_partials = c->quad ? c->n_quads : c->n_waves;
+        c->recs_cur = c->d_partials;
+    }
     return launch_check();
 }
 int mppi_reduce(mppi_ctx_t *c, float *record_out_dev) {
@@ -368,22 +401,38 @@ int mppi_reduce(mppi_ctx_t *c, float *record_out_dev) {
         hipLaunchKernelGGL(k_reduce, dim3(c->n_waves), dim3(kWave), 0, c->stream, c->d_cfg, c->d_S, c->d_du, c->d_partials);
         c->partials_valid = true;
         c->n_partials = c->n_waves;
+        c->recs_cur = c->d_partials;
     }
-    if (record_out_dev)  // one shard record for the cross-GPU all-gather
-        hipLaunchKernelGGL(k_combine, dim3(1), dim3(kCombineThreads), 0, c->stream, c->d_cfg, c->d_partials, c->n_partials, 0, record_out_dev, c->d_U, c->d_action,
+    if (record_out_dev)  // ONE shard record (API of the first ABI; the fused path all-gathers its folded records instead, mppi_set_record_out)
+        hipLaunchKernelGGL(k_combine, dim3(1), dim3(kCombineThreads), 0, c->stream, c->d_cfg, c->recs_cur, c->n_partials, 0, record_out_dev, c->d_U, c->d_action,
                            c->d_beta_eta, (const float *)nullptr);
     return launch_check();
+}
+int mppi_shard_record_count(const mppi_ctx_t *c) {
+    if (check_ctx(c) != MPPI_OK || !c->fold) return 0;
+    return c->n_quads % 16 == 0 ? kFoldGroups : 1;
+}
+int mppi_set_record_out(mppi_ctx_t *c, float *records_dev) {
+    CTX_TRY(c);
+    if (!c->fold) return fail(MPPI_EUNSUPPORTED, "mppi_set_record_out: this context does not fold its wave records (lane kernels / MPPI_FOLD=0); use mppi_reduce");
+    c->fold_out = records_dev ? records_dev : c->d_fold;
+    return MPPI_OK;
+}
+int mppi_note_graph_update(mppi_ctx_t *c) {
+    CTX_TRY(c);
+    c->seq_expected++;
+    return MPPI_OK;
 }
 int mppi_record_floats(const mppi_ctx_t *c) { return check_ctx(c) == MPPI_OK ? c->RF : 0; }
 int mppi_record_dev(mppi_ctx_t *c, float **record_dev) {
     CTX_TRY(c);
-    hipLaunchKernelGGL(k_combine, dim3(1), dim3(kCombineThreads), 0, c->stream, c->d_cfg, c->d_partials, c->n_partials, 0, c->d_record, c->d_U, c->d_action, c->d_beta_eta, (const float *)nullptr);
+    hipLaunchKernelGGL(k_combine, dim3(1), dim3(kCombineThreads), 0, c->stream, c->d_cfg, c->recs_cur ? c->recs_cur : c->d_partials, c->n_partials, 0, c->d_record, c->d_U, c->d_action, c->d_beta_eta, (const float *)nullptr);
     *record_dev = c->d_record;
     return launch_check();
 }
 int mppi_update(mppi_ctx_t *c, const float *records_dev, int n_records) {
     CTX_TRY(c);
-    const float *recs = records_dev ? records_dev : c->d_partials;
+    const float *recs = records_dev ? records_dev : (c->recs_cur ? c->recs_cur : c->d_partials);
     int n = records_dev ? n_records : c->n_partials;
     if (n < 1) return fail(MPPI_EINVAL, "n_records < 1");
     {
@@ -406,7 +455,7 @@ int mppi_update_step_world(mppi_ctx_t *c, const float *records_dev, int n_record
         if ((rc = mppi_world_step_from(world, c))) return rc;
         return mppi_set_state_from_world(c, world);
     }
-    const float *recs = records_dev ? records_dev : c->d_partials;
+    const float *recs = records_dev ? records_dev : (c->recs_cur ? c->recs_cur : c->d_partials);
     const int n = records_dev ? n_records : c->n_partials;
     if (n < 1) return fail(MPPI_EINVAL, "n_records < 1");
     {
@@ -461,8 +510,8 @@ static int d2h(mppi_ctx_t *c, float *dst, const float *src, size_t nfloats) {
 int mppi_get_costs(mppi_ctx_t *c, float *S) { return d2h(c, S, c ? c->d_S : nullptr, c ? c->K : 0); }
 int mppi_get_weights_stats(mppi_ctx_t *c, float *be) { return d2h(c, be, c ? c->d_beta_eta : nullptr, 2); }
 int mppi_get_rollouts(mppi_ctx_t *c, float *viz) {
-    if (c && !c->cfg.want_rollouts) return fail(MPPI_ESTATE, "config.want_rollouts is off");
-    if (!c) return check_ctx(c);
+    CTX_TRY(c);  // (a stale handle is reported, not dereferenced)
+    if (!c->cfg.want_rollouts) return fail(MPPI_ESTATE, "config.want_rollouts is off");
     // device layout is sample-minor [H][3][K] (full-line coalesced stores); hand out [H][K][3]
     std::vector<float> tmp((size_t)c->H * 3 * c->K);
     int rc = d2h(c, tmp.data(), c->d_viz, tmp.size());

@@ -131,6 +131,90 @@ __device__ __forceinline__ void quad_record(CCfg &cfg, float s, bool live_leader
     }
 }
 
+// Second level of the record tree, still inside the rollout kernel.  The quad kernels deal their chunks so that the
+// workgroups b with b % 8 == g - one XCD - own the contiguous chunks [g*n, (g+1)*n).  Every workgroup takes a ticket
+// from a device-scope counter of its group after publishing its wave record; the LAST one of a group folds the group's
+// n wave records (they sit in its own XCD's L2) into one record, in chunk order whichever workgroup happens to do it:
+//   beta = min beta_r, eta = sum eta_r e^{-(beta_r-beta)/lambda}, N = sum N_r e^{-(beta_r-beta)/lambda}.
+// The combine / update kernel - and the all-gather between GPUs - then deal with 8 records per GPU instead of K/16, and
+// no separate "reduce to a shard record" launch exists on the fused path.  The counter re-arms itself.
+constexpr int kFoldGroups = 8;
+constexpr int kFoldTable = 1024;
+__device__ __forceinline__ void fold_group(CCfg &cfg, const float *__restrict__ partials, int first, int n, unsigned *__restrict__ ctr,
+                                           float *__restrict__ out) {
+    __shared__ float s_sc[kFoldTable];
+    const int lane = threadIdx.x & (kWave - 1);
+    // Hand-off between workgroups (per-XCD L2s are not coherent, a CU's L1 is never refreshed by other CUs' stores):
+    // producer = plain stores -> wait for them -> ONE lane's agent-scope release -> wait again (ROCm 7.2 may drop the
+    // wait behind buffer_wbl2 when its scoreboard looks empty) -> relaxed agent-scope ticket; consumer = the last
+    // ticket holder: ONE lane's agent-scope acquire -> barrier -> plain loads.  Placement-independent: only the speed
+    // of the fold depends on the group really sharing an XCD.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned ticket = 0;
+    if (lane == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ticket = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    ticket = __shfl(ticket, 0, kWave);
+    if (ticket != (unsigned)(n - 1)) return;
+    if (lane == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch
+    }
+    __syncthreads();
+    const int HN = cfg.H * cfg.nu, RF = 2 + HN;
+    const float *recs = partials + (size_t)first * RF;
+    float b = INFINITY;
+    for (int r = lane; r < n; r += kWave)
+        if (recs[(size_t)r * RF + 1] > 0.f) b = fminf(b, recs[(size_t)r * RF]);
+    b = wave_min(b);
+    float e = 0.f;
+    for (int r = lane; r < n; r += kWave) {
+        const float er = recs[(size_t)r * RF + 1];
+        const float sc = er > 0.f ? __expf(-(recs[(size_t)r * RF] - b) * cfg.inv_lambda) : 0.f;
+        if (r < kFoldTable) s_sc[r] = sc;
+        e += er * sc;
+    }
+    e = wave_sum(e);
+    __syncthreads();
+    if (lane == 0) {
+        out[0] = b;
+        out[1] = e;
+    }
+    const int nt = n < kFoldTable ? n : kFoldTable;
+    for (int j = lane; j < HN; j += kWave) {
+        const float *col = recs + 2 + j;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int r = 0;
+        for (; r + 4 <= nt; r += 4) {  // four independent chains: the loads of a trip are in flight together
+            a0 += s_sc[r] * col[(size_t)r * RF];
+            a1 += s_sc[r + 1] * col[(size_t)(r + 1) * RF];
+            a2 += s_sc[r + 2] * col[(size_t)(r + 2) * RF];
+            a3 += s_sc[r + 3] * col[(size_t)(r + 3) * RF];
+        }
+        for (; r < nt; r++) a0 += s_sc[r] * col[(size_t)r * RF];
+        for (; r < n; r++) {  // more records than the table holds (K > 131072 on one GPU): recompute the factor
+            const float er = recs[(size_t)r * RF + 1];
+            a0 += (er > 0.f ? __expf(-(recs[(size_t)r * RF] - b) * cfg.inv_lambda) : 0.f) * col[(size_t)r * RF];
+        }
+        out[2 + j] = (a0 + a1) + (a2 + a3);
+    }
+}
+// chunk owned by workgroup b of nb (XCD-aware dealing, see k_rollout_quad) and the fold group it reports to
+__device__ __forceinline__ void fold_after_record(CCfg &cfg, const float *__restrict__ partials, unsigned *__restrict__ fold_ctr,
+                                                  float *__restrict__ fold_out) {
+    if (fold_ctr == nullptr) return;
+    const int nb = gridDim.x, RF = 2 + cfg.H * cfg.nu;
+    if (nb % 16 == 0) {
+        const int g = (int)(blockIdx.x % kFoldGroups), n = nb / kFoldGroups;
+        fold_group(cfg, partials, g * n, n, fold_ctr + g, fold_out + (size_t)g * RF);
+    } else {
+        fold_group(cfg, partials, 0, nb, fold_ctr, fold_out);  // ragged grids (identity dealing): one group
+    }
+}
+
 __global__ __launch_bounds__(kWave) void k_reduce(const DevCfg *__restrict__ cfg, const float *__restrict__ S,
                                                   const float *__restrict__ du, float *__restrict__ partials) {
     const int k = blockIdx.x * kWave + threadIdx.x;
@@ -163,7 +247,7 @@ __global__ __launch_bounds__(kWave) void k_rollout_quad(const DevModel *__restri
                                                         const float *__restrict__ x0_root, const float *__restrict__ U,
                                                         const float *__restrict__ eps, const float *__restrict__ prior,
                                                         float *__restrict__ du, float *__restrict__ S, float *__restrict__ viz,
-                                                        float *__restrict__ partials) {
+                                                        float *__restrict__ partials, unsigned *__restrict__ fold_ctr, float *__restrict__ fold_out) {
 #if defined(__HIP_DEVICE_COMPILE__)  // (the host pass sees the 4-float emulation type of mppi_quad.hpp)
     // Stage the robot model (header + body + link blocks, ~4 KB) in LDS once per wavefront: constants are then
     // fetched with in-order ds_read_b128 broadcasts into VGPRs - no SMEM round trip (s_waitcnt lgkmcnt(0) on
@@ -198,6 +282,7 @@ __global__ __launch_bounds__(kWave) void k_rollout_quad(const DevModel *__restri
         if (leader) S[k] = s;
     }
     quad_record(*(CCfg *)cfg, s, live && leader, du, chunk * 16, partials + (size_t)chunk * (2 + cfg->H * cfg->nu));
+    fold_after_record(*(CCfg *)cfg, partials, fold_ctr, fold_out);
 #endif
 }
 
@@ -472,7 +557,7 @@ __global__ __launch_bounds__(kWave) void k_rollout_scene_quad(const DevModel *__
                                                               const float *__restrict__ x0_root, const float *__restrict__ U,
                                                               const float *__restrict__ eps, const float *__restrict__ prior,
                                                               float *__restrict__ du, float *__restrict__ S, float *__restrict__ viz,
-                                                              float *__restrict__ partials) {
+                                                              float *__restrict__ partials, unsigned *__restrict__ fold_ctr, float *__restrict__ fold_out) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // The robot part of the model (header, bodies, links: 4.3 KB) is staged in LDS for the quad-layout kinematics and
@@ -495,6 +580,7 @@ __global__ __launch_bounds__(kWave) void k_rollout_scene_quad(const DevModel *__
         if (lane4 == 0) S[k] = s;
     }
     quad_record(*(CCfg *)cfg, s, live && lane4 == 0, du, chunk * 16, partials + (size_t)chunk * (2 + cfg->H * cfg->nu));
+    fold_after_record(*(CCfg *)cfg, partials, fold_ctr, fold_out);
 #endif
 }
 
@@ -729,6 +815,63 @@ __global__ __launch_bounds__(kWave) void k_sample(const DevCfg *__restrict__ cfg
     }
 }
 
+// ---- counter-based Gaussian sampler (MPPI_SAMPLE_NORMAL) ---------------------------------------
+// Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11): ten rounds of two 32x32->64
+// multiplies and a key bump.  Known-answer vectors of the Random123 distribution are checked in tests/.
+__host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t *out) {
+    for (int r = 0; r < 10; r++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+constexpr uint32_t kPhiloxKey1 = 0x4D505049u;  // "MPPI"
+
+// One thread per (sample k, control dimension c); the thread index is k-minor so every store is coalesced.
+// z[i] (knot i of control c of GLOBAL sample g): words (2p, 2p+1) of philox(counter = (g, c, i/4, iteration),
+// key = (seed, "MPPI")) -> u = (x + 0.5) 2^-32 -> Box-Muller pair (r cos, r sin), r = sqrt(-2 ln u_a), angle 2 pi u_b.
+// eps[(t*nu+c)*K + k] = mu_c + sigma_c * sum_i B[t][i] z[i]   (n_knots == H: no spline, eps_t = mu + sigma z_t)
+__global__ __launch_bounds__(kWave) void k_sample_normal(const DevCfg *__restrict__ cfg, const double *__restrict__ basis,
+                                                         const double *__restrict__ sigma_mu, int n_knots, uint32_t seed, uint32_t iteration,
+                                                         float *__restrict__ eps) {
+    const int K = cfg->K, H = cfg->H, nu = cfg->nu;
+    const int idx = blockIdx.x * kWave + threadIdx.x;
+    if (idx >= K * nu) return;
+    const int c = idx / K, k = idx - c * K;
+    const uint32_t g = (uint32_t)(cfg->k_offset + k);
+    const double sg = sigma_mu[c], mu = sigma_mu[MPPI_MAX_NU + c];
+    const bool direct = n_knots == H;
+    double z[MPPI_MAX_KNOTS];
+    for (int b = 0; 4 * b < n_knots; b++) {
+        uint32_t x[4];
+        philox4x32_10(g, (uint32_t)c, (uint32_t)b, iteration, seed, kPhiloxKey1, x);
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const double ua = ((double)x[2 * p] + 0.5) * (1.0 / 4294967296.0), ub = ((double)x[2 * p + 1] + 0.5) * (1.0 / 4294967296.0);
+            const double r = sqrt(-2.0 * log(ua));
+            double sn, cs;
+            sincos(6.283185307179586 * ub, &sn, &cs);
+            const double zz[2] = {r * cs, r * sn};
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const int i = 4 * b + 2 * p + e;
+                if (i < n_knots) {
+                    if (direct) eps[(size_t)(i * nu + c) * K + k] = (float)(mu + sg * zz[e]);
+                    else z[i] = zz[e];
+                }
+            }
+        }
+    }
+    if (!direct)
+        for (int t = 0; t < H; t++) {
+            double s = 0.0;
+            for (int i = 0; i < n_knots; i++) s += basis[t * n_knots + i] * z[i];
+            eps[(size_t)(t * nu + c) * K + k] = (float)(mu + sg * s);
+        }
+}
+
 // ---- batched simulator (generic Objective mode, K=1 world) -------------------------------------
 __global__ void k_sim_reset(int K, int n, const float *__restrict__ x0_dof, float *__restrict__ q, float *__restrict__ qd,
                             float *__restrict__ S, float *__restrict__ ctrl) {
@@ -933,6 +1076,12 @@ struct mppi_ctx {
     const float *eps_in = nullptr;  // d_eps or an external noise buffer
     bool has_prior = false, has_cost = false, profiling = false;
     bool partials_valid = false;  // d_partials holds the records of the current S (written by the fused rollout tail)
+    // fold of the wave records inside the quad rollout kernels (fold_group): per-group counters, the folded records
+    // (own buffer d_fold, or the caller's mppi_set_record_out buffer - e.g. this rank's rows of the all-gather tensor)
+    bool fold = false;
+    unsigned *d_fold_ctr = nullptr;
+    float *d_fold = nullptr, *fold_out = nullptr;
+    const float *recs_cur = nullptr;  // records the next combine reads when the caller passes none
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[3];
     size_t ev_used[3] = {0, 0, 0}, ev_seen[3] = {0, 0, 0};
     int profile_period = 1;  // hipEvent brackets on every n-th launch
@@ -976,7 +1125,7 @@ template <class T>
 void launch_rollout_scene_quad_t(mppi_ctx *c) {
     hipLaunchKernelGGL(k_rollout_scene_quad<T>, dim3(c->n_quads), dim3(kWave), c->lds_bytes_quad, c->stream, c->d_model, c->d_cfg, c->d_cost, c->d_x0_dof,
                        c->d_x0_root, c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_S, c->cfg.want_rollouts ? c->d_viz : nullptr,
-                       c->d_partials);
+                       c->d_partials, c->fold ? c->d_fold_ctr : nullptr, c->fold_out);
 }
 template <class T>
 void launch_sim_step_scene_t(mppi_ctx *c, int mode, int t, const float *u_ext) {
@@ -1007,7 +1156,8 @@ hipError_t raise_lds_limit(size_t lane_bytes, size_t quad_bytes) {
 template <class T>
 void launch_rollout_quad_t(mppi_ctx *c) {
     hipLaunchKernelGGL(k_rollout_quad<T>, dim3(c->n_quads), dim3(kWave), 0, c->stream, c->d_model, c->d_cfg, c->d_cost, c->d_x0_dof, c->d_x0_root,
-                       c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_S, c->cfg.want_rollouts ? c->d_viz : nullptr, c->d_partials);
+                       c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_S, c->cfg.want_rollouts ? c->d_viz : nullptr, c->d_partials,
+                       c->fold ? c->d_fold_ctr : nullptr, c->fold_out);
 }
 template <class T>
 void launch_combine_world_t(mppi_ctx *p, const float *recs, int n, mppi_ctx *w) {

@@ -12,13 +12,13 @@ import os
 MAX_BODIES, MAX_LINKS, MAX_ACTORS, MAX_NU, MAX_H, MAX_KNOTS, MAX_COST_W = 12, 24, 8, 12, 64, 16, 16
 MAX_SHAPES, MAX_PAIRS, MAX_FREE = 24, 48, 2
 SHAPE_BOX, SHAPE_SPHERE, SHAPE_DISC = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 JOINT_REVOLUTE, JOINT_PRISMATIC = 0, 1
 DRIVE_VELOCITY, DRIVE_EFFORT, DRIVE_POSITION = 0, 1, 2
 ACTOR_ROBOT, ACTOR_BOX, ACTOR_SPHERE = 0, 1, 2
 COST_NONE, COST_POINT_REACH, COST_PANDA_REACH, COST_BOXER_PUSH, COST_PANDA_PICK = 0, 1, 2, 3, 4
-SAMPLE_HALTON_SPLINE, SAMPLE_EXTERNAL = 0, 1
+SAMPLE_HALTON_SPLINE, SAMPLE_EXTERNAL, SAMPLE_NORMAL = 0, 1, 2
 
 _d, _i = C.c_double, C.c_int32
 
@@ -64,7 +64,7 @@ class Config(C.Structure):
                 ("k_total", _i), ("sample_null_action", _i), ("use_priors", _i), ("sampling", _i),
                 ("n_knots", _i), ("noise_abs_cost", _i), ("want_rollouts", _i), ("viz_link", _i), ("seed", _i),
                 ("lambda_", _d), ("rollout_var_discount", _d), ("u_init", _d),
-                ("u_min", _d * MAX_NU), ("u_max", _d * MAX_NU), ("noise_sigma_diag", _d * MAX_NU),
+                ("u_min", _d * MAX_NU), ("u_max", _d * MAX_NU), ("noise_sigma_diag", _d * MAX_NU), ("noise_mu", _d * MAX_NU),
                 ("spline_basis", _d * (MAX_H * MAX_KNOTS))]
 
 
@@ -90,14 +90,19 @@ _SIGNATURES = {
     "mppi_get_state": (C.c_int, [_vp, _fp, _fp]),
     "mppi_set_cost": (C.c_int, [_vp, C.POINTER(Cost)]),
     "mppi_sample": (C.c_int, [_vp, C.c_uint32]),
+    "mppi_sample_normal": (C.c_int, [_vp, C.c_uint32]),
     "mppi_set_noise_dev": (C.c_int, [_vp, _vp]),
     "mppi_set_prior": (C.c_int, [_vp, _fp]),
+    "mppi_set_prior_row": (C.c_int, [_vp, C.c_int, _fp]),
     "mppi_set_nominal": (C.c_int, [_vp, _fp]),
     "mppi_get_nominal": (C.c_int, [_vp, _fp]),
     "mppi_set_filter": (C.c_int, [_vp, _fp]),
     "mppi_rollout": (C.c_int, [_vp]),
     "mppi_reduce": (C.c_int, [_vp, _vp]),
     "mppi_record_floats": (C.c_int, [_vp]),
+    "mppi_shard_record_count": (C.c_int, [_vp]),
+    "mppi_set_record_out": (C.c_int, [_vp, _vp]),
+    "mppi_note_graph_update": (C.c_int, [_vp]),
     "mppi_record_dev": (C.c_int, [_vp, C.POINTER(_vp)]),
     "mppi_update": (C.c_int, [_vp, _vp, C.c_int]),
     "mppi_get_action": (C.c_int, [_vp, _fp]),

@@ -1,69 +1,201 @@
-"""Stage-cost Objectives for the BASELINE workloads, honouring the reference's Objective contract
-(`compute_cost(sim) -> [K]`, `reset()`, mutable `.weights`; reference examples/*/planner.py) and
-additionally declaring `fused_spec(sim)` so the planner can evaluate the same cost inside the
-persistent rollout kernel.  `compute_cost` is the reference's torch code path (generic mode);
-tests check fused == generic."""
+"""Stage-cost Objectives as small declarative cost programs.
+
+The reference ships one hand-written `Objective.compute_cost(sim)` per example
+(reference examples/*/planner.py, benchmarks/point_robot/mppi_planner/mppi_planner_wrapper.py).  All of
+them are weighted sums of a handful of geometric measurements on what the simulator reports, so here an
+Objective is DATA - a list of `Term(weight, op, operands)` - and there is exactly one evaluator:
+
+  * `evaluate(terms, weights, sim)` runs the program with torch through the reference's sim getter protocol
+    (`get_actor_link_by_name`, `get_actor_position_by_name`, ...): the generic Objective mode, and what the
+    golden fixtures generated from the reference's own planners are replayed through (tests/golden/);
+  * `fused_spec(sim)` hands the same program to the rollout kernel as an `mppi_cost_t` when it is one of the
+    shapes the kernel evaluates in-line (MPPI_COST_*), so the cost never leaves the GPU registers.
+
+The Objective contract of the reference is kept: `compute_cost(sim) -> [K]`, `reset()`, mutable `.weights`.
+`graph_safe = True`: compute_cost is a pure tensor program of sim tensors and `.weights`, so the planner may
+capture the generic horizon into a HIP graph (planner/mppi.py:_replay_horizon).
+
+Operands (where a 3-vector comes from):  ("link", actor, link) rigid-body position; ("actor", name) root position;
+("dof_xy",) the first two DOF positions; a plain (x, y, z) tuple is a constant.
+
+Ops (each yields one value per env):
+  dist(a, b, n)            Euclidean distance of the first n components of a and b
+  tilt(link)               size of the first two "ZYX" Euler angles of the link quaternion, fed xyzw into a real-first
+                           conversion exactly as the reference's planners do (examples/panda/planner.py:30-32)
+  yaw_abs(actor, ref)      |yaw of the actor's root quaternion - ref|
+  align(a, b, c)           1 + cos of the planar angle at b between the rays to a and to c (0 when a pushes b towards c)
+  force_l1(actor, link, n) sum |F| over the first n components of the body's net contact force
+  speed(actor, n)          norm of the first n components of the actor's root linear velocity
+  dof_sq(which, lo, hi, ref)  sum of squares of DOF positions/velocities lo..hi-1 (minus ref)
+  abs_dz(a, b)             |a.z - b.z|  (b may be a float height)
+  below(a, h)              max(h - a.z, 0)
+"""
+from typing import NamedTuple, Sequence, Tuple, Union
+
 import torch
 
 from mppiisaac.backend import capi
 from mppiisaac.utils.conversions import matrix_to_euler_angles, quaternion_to_matrix, quaternion_to_yaw
 
 
-class PandaReachObjective(object):
-    """reference examples/panda/planner.py:10-40 (incl. the xyzw-into-wxyz quirk, kept as is)."""
+class Term(NamedTuple):
+    weight: Union[str, float]   # key into Objective.weights, or a fixed factor
+    op: str
+    args: Tuple
 
-    def __init__(self, cfg=None, actor="panda", link="panda_ee_tip", goal="goal"):
-        self.weights = {"robot_to_goal": 1.0, "robot_ori": 0.5}
-        self.actor, self.link, self.goal = actor, link, goal
+
+def link(actor: str, name: str):
+    return ("link", actor, name)
+
+
+def actor(name: str):
+    return ("actor", name)
+
+
+def _point(sim, src, like=None):
+    """operand -> [K, 3] positions (a constant operand: [1, 3] in the dtype / on the device of `like`)"""
+    kind = src[0]
+    if kind == "link":
+        return sim.get_actor_link_by_name(src[1], src[2])[:, 0:3]
+    if kind == "actor":
+        return sim.get_actor_position_by_name(src[1])[:, 0:3]
+    if kind == "dof_xy":
+        dof = sim.get_dof_state()
+        return torch.stack((dof[:, 0], dof[:, 2], torch.zeros_like(dof[:, 0])), dim=1)
+    return torch.as_tensor([float(v) for v in src], dtype=like.dtype, device=like.device).view(1, 3)
+
+
+def _norm(v):
+    return torch.sqrt(torch.sum(v * v, dim=1))
+
+
+def _measure(sim, op: str, a: Tuple):
+    if op == "dist":
+        n = a[2]
+        first = _point(sim, a[0])  # (by convention the first operand is never a constant)
+        return _norm(first[:, :n] - _point(sim, a[1], like=first)[:, :n])
+    if op == "tilt":
+        quat = sim.get_actor_link_by_name(a[0][1], a[0][2])[:, 3:7]
+        return _norm(matrix_to_euler_angles(quaternion_to_matrix(quat), "ZYX")[:, 0:2])
+    if op == "yaw_abs":
+        return torch.abs(quaternion_to_yaw(sim.get_actor_orientation_by_name(a[0][1])) - a[1])
+    if op == "align":
+        to_a = (_point(sim, a[0]) - _point(sim, a[1]))[:, :2]
+        to_c = (_point(sim, a[2]) - _point(sim, a[1]))[:, :2]
+        return torch.sum(to_a * to_c, dim=1) / (_norm(to_a) * _norm(to_c)) + 1
+    if op == "force_l1":
+        return torch.sum(torch.abs(sim.get_actor_contact_forces_by_name(a[0], a[1])[:, : a[2]]), dim=1)
+    if op == "speed":
+        return _norm(sim.get_actor_velocity_by_name(a[0][1])[:, : a[1]])
+    if op == "dof_sq":
+        which, lo, hi, ref = a
+        x = sim.get_dof_state()[:, (0 if which == "pos" else 1)::2]
+        hi = x.shape[1] + hi if hi <= 0 else hi
+        lo = x.shape[1] + lo if lo < 0 else lo
+        x = x[:, lo:hi]
+        if ref is not None:
+            x = x - torch.tensor(ref, dtype=torch.float32, device=x.device)  # (fp32 constants, as the reference's planners hold them)
+        return torch.sum(x * x, dim=1)
+    if op == "abs_dz":
+        z = _point(sim, a[0])[:, 2]
+        return torch.abs(z - (a[1] if isinstance(a[1], (int, float)) else _point(sim, a[1])[:, 2]))
+    if op == "below":
+        return torch.clamp(a[1] - _point(sim, a[0])[:, 2], min=0)
+    raise ValueError(f"unknown cost op '{op}'")
+
+
+def evaluate(terms: Sequence[Term], weights: dict, sim) -> torch.Tensor:
+    """sum_i weight_i * measure_i(sim) -> [K]"""
+    total = None
+    for t in terms:
+        w = weights[t.weight] if isinstance(t.weight, str) else t.weight
+        v = w * _measure(sim, t.op, t.args)
+        total = v if total is None else total + v
+    return total
+
+
+class ProgramObjective(object):
+    """Objective contract of the reference (compute_cost / reset / weights) over a term list."""
+    graph_safe = True
+    WEIGHTS: dict = {}
+
+    def __init__(self, cfg=None):
+        self.weights = dict(self.WEIGHTS)
         self.reset()
 
     def reset(self):
         pass
 
-    def compute_cost(self, sim):
-        r_pos = sim.get_actor_link_by_name(self.actor, self.link)
-        goal_pos = sim.get_actor_position_by_name(self.goal)
-        robot_to_goal = r_pos[:, 0:3] - goal_pos[:, 0:3]
-        robot_to_goal_dist = torch.linalg.norm(robot_to_goal, axis=1)
-        robot_rpy = matrix_to_euler_angles(quaternion_to_matrix(r_pos[:, 3:7]), "ZYX")[:, 0:2]
-        robot_rpy_dist = torch.linalg.norm(robot_rpy, axis=1)
-        return self.weights["robot_to_goal"] * robot_to_goal_dist + self.weights["robot_ori"] * robot_rpy_dist
+    def terms(self) -> Sequence[Term]:
+        raise NotImplementedError
 
-    def fused_spec(self, sim) -> capi.Cost:
+    def compute_cost(self, sim):
+        return evaluate(self.terms(), self.weights, sim)
+
+    # shared by the fused specs: weight table -> mppi_cost_t.w in the order the kernel reads it
+    def _spec(self, kind: int, order: Sequence[str]) -> capi.Cost:
         c = capi.Cost()
-        c.kind = capi.COST_PANDA_REACH
-        c.link[0] = sim.scene.rigid_body_index(self.actor, self.link)
-        c.actor[0] = sim.scene.actor_index(self.goal)
-        c.w[0], c.w[1] = self.weights["robot_to_goal"], self.weights["robot_ori"]
+        c.kind = kind
+        for i, k in enumerate(order):
+            c.w[i] = float(self.weights[k])
         return c
 
 
-class PointReachObjective(object):
-    """Navigation term of reference benchmarks/point_robot/mppi_planner/mppi_planner_wrapper.py:10-35:
-    w_nav * || (x, y) - goal ||, x/y = DOF positions 0 and 1.  `goal` is either an actor name or [x, y]."""
+class ReachTiltObjective(ProgramObjective):
+    """end-effector to goal + keep the end effector level: the reach objective of the arm examples (reference
+    examples/panda/planner.py:10-40, examples/panda_effort/planner.py, examples/albert/planner.py differ in the actor,
+    the link and the weights only)."""
+    WEIGHTS = {"robot_to_goal": 1.0, "robot_ori": 0.5}
 
-    def __init__(self, cfg=None, goal="goal", w_nav=2.0):
-        self.weights = {"w_nav": w_nav}
-        self.goal = goal
-        self.reset()
+    def __init__(self, cfg=None, actor="panda", link="panda_ee_tip", goal="goal"):
+        self.actor, self.link, self.goal = actor, link, goal
+        super().__init__(cfg)
 
-    def reset(self):
-        pass
-
-    def _goal_xy(self, sim):
-        if isinstance(self.goal, str):
-            return sim.get_actor_position_by_name(self.goal)[:, 0:2]
-        return torch.tensor(self.goal, dtype=torch.float32, device=sim.device).view(1, 2)
-
-    def compute_cost(self, sim):
-        dof_state = sim.get_dof_state()
-        pos = torch.cat((dof_state[:, 0].unsqueeze(1), dof_state[:, 2].unsqueeze(1)), 1)
-        return self.weights["w_nav"] * torch.linalg.norm(pos - self._goal_xy(sim), axis=1)
+    def terms(self):
+        ee = link(self.actor, self.link)
+        return [Term("robot_to_goal", "dist", (ee, actor(self.goal), 3)), Term("robot_ori", "tilt", (ee,))]
 
     def fused_spec(self, sim) -> capi.Cost:
-        c = capi.Cost()
-        c.kind = capi.COST_POINT_REACH
-        c.w[0] = self.weights["w_nav"]
+        c = self._spec(capi.COST_PANDA_REACH, ("robot_to_goal", "robot_ori"))
+        c.link[0] = sim.scene.rigid_body_index(self.actor, self.link)
+        c.actor[0] = sim.scene.actor_index(self.goal)
+        return c
+
+
+class PandaReachObjective(ReachTiltObjective):
+    """reference examples/panda/planner.py (panda_stick arm, link panda_ee_tip)"""
+
+
+class PandaEffortReachObjective(ReachTiltObjective):
+    """reference examples/panda_effort/planner.py (effort-driven panda, link panda_link7)"""
+
+    def __init__(self, cfg=None, actor="panda", link="panda_link7", goal="goal"):
+        super().__init__(cfg, actor, link, goal)
+
+
+class AlbertReachObjective(ReachTiltObjective):
+    """reference examples/albert/planner.py (diff-drive base + arm, link mmrobot_link7)"""
+    WEIGHTS = {"robot_to_goal": 4.0, "robot_ori": 0.5}
+
+    def __init__(self, cfg=None, actor="albert", link="mmrobot_link7", goal="goal"):
+        super().__init__(cfg, actor, link, goal)
+
+
+class PointReachObjective(ProgramObjective):
+    """navigation term of reference benchmarks/point_robot/mppi_planner/mppi_planner_wrapper.py:10-35: planar distance
+    of the base (DOF positions 0 and 1) to the goal; `goal` is an actor name or a fixed [x, y]."""
+
+    def __init__(self, cfg=None, goal="goal", w_nav=2.0):
+        self.goal = goal
+        super().__init__(cfg)
+        self.weights = {"w_nav": w_nav}
+
+    def terms(self):
+        target = actor(self.goal) if isinstance(self.goal, str) else (float(self.goal[0]), float(self.goal[1]), 0.0)
+        return [Term("w_nav", "dist", (("dof_xy",), target, 2))]
+
+    def fused_spec(self, sim) -> capi.Cost:
+        c = self._spec(capi.COST_POINT_REACH, ("w_nav",))
         if isinstance(self.goal, str):
             c.actor[0] = sim.scene.actor_index(self.goal)
         else:
@@ -72,91 +204,158 @@ class PointReachObjective(object):
         return c
 
 
-class BoxerPushObjective(object):
-    """reference examples/boxer_push/planner.py:9-67: push a block to a goal pose with a differential-drive
-    base while avoiding contact with two obstacles."""
+class PlanarPushObjective(ProgramObjective):
+    """non-prehensile pushing with a mobile base: approach the block, bring it to the goal position and yaw, stay behind
+    it, keep off the obstacles (reference examples/boxer_push/planner.py:9-67, examples/heijn_push/planner.py)."""
+    WEIGHTS = {"robot_to_block": 0.1, "block_to_goal": 2.0, "block_to_goal_ort": 3.0, "push_align": 0.6,
+               "collision": 100, "velocity": 0.0}
 
     def __init__(self, cfg=None, robot="boxer", link="ee_link", block="block", goal="goal",
                  obstacles=("paper_obst1", "paper_obst2")):
-        self.weights = {"robot_to_block": 0.1, "block_to_goal": 2.0, "block_to_goal_ort": 3.0, "push_align": 0.6,
-                        "collision": 100, "velocity": 0.0}
         self.goal_yaw = 0.0
         self.robot, self.link, self.block, self.goal, self.obstacles = robot, link, block, goal, tuple(obstacles)
+        super().__init__(cfg)
 
-    def reset(self):
-        pass
-
-    def compute_cost(self, sim):
-        r_pos = sim.get_actor_link_by_name(actor_name=self.robot, link_name=self.link)
-        block_pos = sim.get_actor_position_by_name(self.block)
-        block_vel = sim.get_actor_velocity_by_name(self.block)
-        block_ort = sim.get_actor_orientation_by_name(self.block)
-        block_goal = sim.get_actor_position_by_name(self.goal)
-        robot_to_block = r_pos[:, 0:2] - block_pos[:, 0:2]
-        block_to_goal = block_goal[:, 0:2] - block_pos[:, 0:2]
-        block_yaws = quaternion_to_yaw(block_ort)
-        robot_to_block_dist = torch.linalg.norm(robot_to_block[:, 0:2], axis=1)
-        block_to_pos_dist = torch.linalg.norm(block_to_goal, axis=1)
-        block_to_ort_dist = torch.abs(block_yaws - self.goal_yaw)
-        push_align = torch.sum(robot_to_block[:, 0:2] * block_to_goal, 1) / (robot_to_block_dist * block_to_pos_dist) + 1
-        obst1_forces = sim.get_actor_contact_forces_by_name(actor_name=self.obstacles[0], link_name="box")
-        obst2_forces = sim.get_actor_contact_forces_by_name(actor_name=self.obstacles[1], link_name="box")
-        coll = torch.sum(torch.abs(obst1_forces[:, 0:2]), axis=1) + torch.sum(torch.abs(obst2_forces[:, 0:2]), axis=1)
-        vel = torch.linalg.norm(block_vel[:, 0:2], axis=1)
-        w = self.weights
-        return (w["robot_to_block"] * robot_to_block_dist + w["block_to_goal"] * block_to_pos_dist
-                + w["block_to_goal_ort"] * block_to_ort_dist + w["push_align"] * push_align
-                + w["velocity"] * vel + w["collision"] * coll)
+    def terms(self):
+        pusher, blk, tgt = link(self.robot, self.link), actor(self.block), actor(self.goal)
+        out = [Term("robot_to_block", "dist", (pusher, blk, 2)), Term("block_to_goal", "dist", (tgt, blk, 2)),
+               Term("block_to_goal_ort", "yaw_abs", (blk, self.goal_yaw)), Term("push_align", "align", (pusher, blk, tgt)),
+               Term("velocity", "speed", (blk, 2))]
+        return out + [Term("collision", "force_l1", (o, "box", 2)) for o in self.obstacles]
 
     def fused_spec(self, sim) -> capi.Cost:
-        c = capi.Cost()
-        c.kind = capi.COST_BOXER_PUSH
+        c = self._spec(capi.COST_BOXER_PUSH, ("robot_to_block", "block_to_goal", "block_to_goal_ort", "push_align", "velocity", "collision"))
         c.link[0] = sim.scene.rigid_body_index(self.robot, self.link)
         c.link[1] = sim.scene.rigid_body_index(self.obstacles[0], "box")
         c.link[2] = sim.scene.rigid_body_index(self.obstacles[1], "box")
         c.actor[0] = sim.scene.actor_index(self.block)
         c.actor[1] = sim.scene.actor_index(self.goal)
-        w = self.weights
-        for i, k in enumerate(("robot_to_block", "block_to_goal", "block_to_goal_ort", "push_align", "velocity", "collision")):
-            c.w[i] = float(w[k])
         c.w[6] = float(self.goal_yaw)
         return c
 
 
-class PandaPickObjective(object):
-    """reference examples/panda_pick/planner.py:9-53: reach the block, bring it to the goal, stay off the table."""
+class BoxerPushObjective(PlanarPushObjective):
+    """reference examples/boxer_push/planner.py"""
+
+
+class HeijnPushObjective(PlanarPushObjective):
+    """reference examples/heijn_push/planner.py (holonomic base, link front_link, softer collision weight)"""
+    WEIGHTS = {"robot_to_block": 0.2, "block_to_goal": 2.0, "block_to_goal_ort": 3.0, "push_align": 0.6,
+               "collision": 10, "velocity": 0.0}
+
+    def __init__(self, cfg=None, robot="heijn", link="front_link", **kw):
+        super().__init__(cfg, robot=robot, link=link, **kw)
+
+
+class BaseReachObjective(ProgramObjective):
+    """drive a mobile base to the goal without leaning on the wall (reference examples/boxer_reach/planner.py,
+    examples/heijn_reach/planner.py: unit weights, no weight table)"""
+
+    def __init__(self, cfg=None, robot="boxer", link="ee_link", goal="goal", wall="wall"):
+        self.robot, self.link, self.goal, self.wall = robot, link, goal, wall
+        super().__init__(cfg)
+
+    def terms(self):
+        return [Term(1.0, "dist", (actor(self.goal), link(self.robot, self.link), 2)), Term(1.0, "force_l1", (self.wall, "box", 3))]
+
+
+class BoxerReachObjective(BaseReachObjective):
+    """reference examples/boxer_reach/planner.py"""
+
+
+class HeijnReachObjective(BaseReachObjective):
+    """reference examples/heijn_reach/planner.py"""
+
+    def __init__(self, cfg=None, robot="heijn", link="front_link", **kw):
+        super().__init__(cfg, robot=robot, link=link, **kw)
+
+
+class PandaPickObjective(ProgramObjective):
+    """reach the block, bring it to the goal, stay off the table, keep the hand level
+    (reference examples/panda_pick/planner.py:9-53)"""
+    WEIGHTS = {"robot_to_block": 40.0, "block_to_goal": 10.0, "collision": 26.0, "robot_ori": 2.0}
 
     def __init__(self, cfg=None, robot="panda", link="panda_ee", block="panda_pick_block", goal="goal", table="table"):
-        self.weights = {"robot_to_block": 40.0, "block_to_goal": 10.0, "collision": 26.0, "robot_ori": 2.0}
         self.robot, self.link, self.block, self.goal, self.table = robot, link, block, goal, table
-        self.reset()
+        super().__init__(cfg)
+
+    def reset(self):  # attributes the reference's planner keeps (never read by its cost)
+        self.prev_block_to_goal_dist = 1
+        self.prev_robot_to_block_dist = 1
+
+    def terms(self):
+        hand, blk = link(self.robot, self.link), actor(self.block)
+        return [Term("robot_to_block", "dist", (hand, blk, 3)), Term("block_to_goal", "dist", (blk, actor(self.goal), 3)),
+                Term("collision", "force_l1", (self.table, "box", 3)), Term("robot_ori", "tilt", (hand,))]
+
+    def fused_spec(self, sim) -> capi.Cost:
+        c = self._spec(capi.COST_PANDA_PICK, ("robot_to_block", "block_to_goal", "collision", "robot_ori"))
+        c.link[0] = sim.scene.rigid_body_index(self.robot, self.link)
+        c.link[1] = sim.scene.rigid_body_index(self.table, "box")
+        c.actor[0] = sim.scene.actor_index(self.block)
+        c.actor[1] = sim.scene.actor_index(self.goal)
+        return c
+
+
+class OmniPandaPickObjective(PandaPickObjective):
+    """mobile manipulator pick: the panda_pick terms plus base / arm speed, a comfortable arm pose and gripper opening,
+    and a floor for the hand (reference examples/omni_panda_pick/planner.py; DOF order: 3 base, 7 arm, 2 fingers)"""
+    WEIGHTS = {"robot_to_block": 10.0, "block_to_goal": 4.0, "collision": 0.1, "robot_ori": 1.0, "base_vel": 2.0,
+               "arm_vel": 0.1, "comfy_gripper_state": 200.0, "comfy_arm_pose": 0.1, "height_cost": 10000.0}
+    COMFY_GRIPPER = (0.025, 0.025)
+    COMFY_ARM = (-1.57, -0.94, 0.0, -2.8, 0.0, 1.8675, 0.75)
+    MIN_HAND_HEIGHT = 0.12
+
+    def __init__(self, cfg=None, robot="omnipanda", link="panda_hand", **kw):
+        super().__init__(cfg, robot=robot, link=link, **kw)
+
+    def terms(self):
+        hand = link(self.robot, self.link)
+        return super().terms() + [
+            Term("base_vel", "dof_sq", ("vel", 0, 3, None)), Term("arm_vel", "dof_sq", ("vel", 3, 10, None)),
+            Term("comfy_gripper_state", "dof_sq", ("pos", -2, 0, self.COMFY_GRIPPER)),
+            Term("comfy_arm_pose", "dof_sq", ("pos", 3, 10, self.COMFY_ARM)),
+            Term("height_cost", "below", (hand, self.MIN_HAND_HEIGHT))]
+
+    fused_spec = None  # no in-kernel form: runs in generic mode
+
+
+class PandaStickPushObjective(ProgramObjective):
+    """push a block over a table with the stick of the panda_stick arm (reference examples/panda_stick_push/planner.py)"""
+    WEIGHTS = {"robot_to_block": 5.0, "block_to_goal": 25.0, "collision": 0.0, "robot_ori": 5.0, "block_height": 20.0,
+               "push_align": 45.0}
+
+    def __init__(self, cfg=None, robot="panda", link="panda_ee_tip", block="panda_push_block", goal="goal", table="table"):
+        self.robot, self.link, self.block, self.goal, self.table = robot, link, block, goal, table
+        super().__init__(cfg)
 
     def reset(self):
         self.prev_block_to_goal_dist = 1
         self.prev_robot_to_block_dist = 1
 
-    def compute_cost(self, sim):
-        r_pos = sim.get_actor_link_by_name(self.robot, self.link)
-        block_pos = sim.get_actor_position_by_name(self.block)
-        goal_pos = sim.get_actor_position_by_name(self.goal)
-        table_forces = sim.get_actor_contact_forces_by_name(self.table, "box")
-        robot_to_block_dist = torch.linalg.norm(r_pos[:, 0:3] - block_pos[:, 0:3], axis=1)
-        block_to_goal_dist = torch.linalg.norm(block_pos[:, 0:3] - goal_pos[:, 0:3], axis=1)
-        robot_rpy = matrix_to_euler_angles(quaternion_to_matrix(r_pos[:, 3:7]), "ZYX")[:, 0:2]
-        robot_rpy_dist = torch.linalg.norm(robot_rpy, axis=1)
-        forces = torch.sum(torch.abs(table_forces[:, 0:3]), axis=1)
-        w = self.weights
-        self.prev_block_to_goal_dist = block_to_goal_dist
-        return (w["robot_to_block"] * robot_to_block_dist + w["block_to_goal"] * block_to_goal_dist
-                + w["collision"] * forces + w["robot_ori"] * robot_rpy_dist)
+    def terms(self):
+        tip, blk, tgt = link(self.robot, self.link), actor(self.block), actor(self.goal)
+        return [Term("robot_to_block", "dist", (tip, blk, 3)), Term("block_to_goal", "dist", (tgt, blk, 3)),
+                Term("collision", "force_l1", (self.table, "box", 3)), Term("robot_ori", "tilt", (tip,)),
+                Term("block_height", "abs_dz", (tip, blk)), Term("push_align", "align", (tip, blk, tgt))]
 
-    def fused_spec(self, sim) -> capi.Cost:
-        c = capi.Cost()
-        c.kind = capi.COST_PANDA_PICK
-        c.link[0] = sim.scene.rigid_body_index(self.robot, self.link)
-        c.link[1] = sim.scene.rigid_body_index(self.table, "box")
-        c.actor[0] = sim.scene.actor_index(self.block)
-        c.actor[1] = sim.scene.actor_index(self.goal)
-        for i, k in enumerate(("robot_to_block", "block_to_goal", "collision", "robot_ori")):
-            c.w[i] = float(self.weights[k])
-        return c
+
+class AnymalWalkObjective(ProgramObjective):
+    """quadruped: trunk to the goal while trunk and knees keep their nominal heights (reference examples/anymal/planner.py)"""
+    WEIGHTS = {"robot_to_goal": 1.0, "robot_off_ground": 5.0, "knees_off_ground": 5.0}
+    TRUNK_HEIGHT, KNEE_HEIGHT = 0.65, 0.35
+    TRUNK_LINKS = ("base", "face_front", "face_rear")
+    KNEE_LINKS = ("LF_KFE", "LH_KFE", "RH_KFE", "RF_KFE")
+
+    def __init__(self, cfg=None, robot="anymal", goal="goal"):
+        self.robot, self.goal = robot, goal
+        super().__init__(cfg)
+
+    def reset(self):
+        self.prev_block_to_goal_dist = 1
+        self.prev_robot_to_block_dist = 1
+
+    def terms(self):
+        out = [Term("robot_to_goal", "dist", (link(self.robot, "base"), actor(self.goal), 3))]
+        out += [Term("robot_off_ground", "abs_dz", (link(self.robot, n), self.TRUNK_HEIGHT)) for n in self.TRUNK_LINKS]
+        return out + [Term("knees_off_ground", "abs_dz", (link(self.robot, n), self.KNEE_HEIGHT)) for n in self.KNEE_LINKS]

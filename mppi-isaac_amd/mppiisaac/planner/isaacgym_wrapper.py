@@ -13,6 +13,7 @@ listeners and line drawing are graphics and out of scope.
 from __future__ import annotations
 
 import ctypes
+import logging
 from dataclasses import dataclass, field
 from enum import Enum
 from typing import List, Optional
@@ -77,6 +78,7 @@ class ActorWrapper:
 DRIVE_GAINS = {"velocity": (capi.DRIVE_VELOCITY, 600.0), "effort": (capi.DRIVE_EFFORT, 10.0),
                "position": (capi.DRIVE_POSITION, 0.0)}  # reference :491-507
 GRAVITY = (0.0, 0.0, -9.8)  # reference :29
+_REPORTED_DROPS = set()
 
 
 def diff_drive_ik(actor: ActorWrapper, u: torch.Tensor):
@@ -156,6 +158,7 @@ class Scene:
         reference's collision filter: same env only, both actors `collision: true`
         (isaacgym_wrapper.py:441), no robot self-collision; wheels/casters collide with the ground only."""
         shapes = []
+        self.dropped_pairs = []  # (shape, shape) candidates the contact model leaves out on purpose
         any_dynamic = any((not a.fixed) for a in self.env_cfg)
         if not any_dynamic:
             return [], []  # nothing can move into contact with anything that reacts: contact-free scene
@@ -206,13 +209,26 @@ class Scene:
                 if si["actor"] == sj["actor"] or (static_i and static_j):
                     continue
                 kinds = {si["type"], sj["type"]}
+                names = (f'{self.env_cfg[si["actor"]].name}:{si["link"]}', f'{self.env_cfg[sj["actor"]].name}:{sj["link"]}')
                 if capi.SHAPE_DISC in kinds:
+                    # modelling decision: wheels and casters are rim contacts against the ground plane only
+                    self.dropped_pairs.append(names)
                     continue
                 if kinds == {capi.SHAPE_SPHERE}:
-                    continue  # sphere-sphere is not implemented (no such pair in the shipped scenes)
+                    # no sphere-sphere narrow phase in the kernels (no such pair in the shipped scenes): refuse the scene
+                    # instead of letting two spheres pass through each other silently
+                    raise NotImplementedError(f"sphere-sphere contact ({names[0]} / {names[1]}) is not implemented; set "
+                                              "`collision: false` or `fixed: true` on one of the two actors")
                 pairs.append((i, j))
         if len(shapes) > capi.MAX_SHAPES or len(pairs) > capi.MAX_PAIRS:
             raise ValueError(f"contact scene too large: {len(shapes)} shapes, {len(pairs)} pairs")
+        if self.dropped_pairs:
+            key = tuple(self.dropped_pairs)
+            if key not in _REPORTED_DROPS:  # once per distinct scene and process
+                _REPORTED_DROPS.add(key)
+                logging.getLogger("mppiisaac").warning(
+                    "contact model: %d wheel/caster pairs collide with the ground only and are not tested against other "
+                    "shapes (e.g. %s / %s); see Scene.dropped_pairs", len(key), *key[0])
         return shapes, pairs
 
     def _is_wheel(self, link: dict, R_shape: np.ndarray) -> bool:

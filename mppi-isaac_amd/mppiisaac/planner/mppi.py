@@ -106,9 +106,17 @@ def make_config(cfg: MPPIConfig, *, k_offset: int = 0, k_local: Optional[int] = 
     """MPPIConfig -> C-ABI mppi_config_t for the shard [k_offset, k_offset + k_local)."""
     if cfg.update_cov:
         raise NotImplementedError("update_cov=True is not supported (False in every shipped conf/mppi file)")
+    if cfg.update_lambda:
+        # mppi_torch's adaptation factors are not visible from the reference tree (SURVEY.md A) and every shipped
+        # conf/mppi file sets it False: refuse instead of silently ignoring it
+        raise NotImplementedError("update_lambda=True is not supported (False in every shipped conf/mppi file)")
+    if cfg.mppi_mode not in ("halton-spline", "simple") or cfg.sampling_method not in ("halton", "random"):
+        raise ValueError(f"unknown mppi_mode / sampling_method: {cfg.mppi_mode!r} / {cfg.sampling_method!r}")
     if cfg.u_per_command != 1:
         raise NotImplementedError("u_per_command != 1 is not supported")
-    sigma = np.asarray(cfg.noise_sigma, dtype=np.float64)
+    if cfg.noise_sigma is None:
+        raise ValueError("noise_sigma is required: its size defines the control dimension")
+    sigma = np.atleast_2d(np.asarray(cfg.noise_sigma, dtype=np.float64))
     nu = sigma.shape[0]
     if sigma.shape != (nu, nu) or np.abs(sigma - np.diag(np.diag(sigma))).max() > 0:
         raise NotImplementedError("noise_sigma must be a diagonal [nu x nu] matrix")
@@ -123,11 +131,18 @@ def make_config(cfg: MPPIConfig, *, k_offset: int = 0, k_local: Optional[int] = 
     c.k_total = int(cfg.num_samples)
     c.sample_null_action = int(bool(cfg.sample_null_action))
     c.use_priors = int(bool(cfg.use_priors))
+    # halton-spline + halton: the fixed low-discrepancy set, sampled once.  Everything else draws fresh Gaussian
+    # noise on the device at every command (counter-based, MPPI_SAMPLE_NORMAL): "simple" mode one draw per horizon
+    # step - whatever sampling_method says, e.g. reference conf/mppi/omnipanda_effort.yaml:4-5 -, halton-spline +
+    # random through the same B-spline as the Halton knots.
     halton = cfg.mppi_mode == "halton-spline" and cfg.sampling_method == "halton"
-    c.sampling = capi.SAMPLE_HALTON_SPLINE if halton else capi.SAMPLE_EXTERNAL
-    nk = knots_for_horizon(cfg.horizon) if halton else 1
-    if nk > capi.MAX_KNOTS:
+    spline = cfg.mppi_mode == "halton-spline"
+    c.sampling = capi.SAMPLE_HALTON_SPLINE if halton else capi.SAMPLE_NORMAL
+    nk = knots_for_horizon(cfg.horizon) if spline else cfg.horizon
+    if nk > capi.MAX_KNOTS and nk != cfg.horizon:
         raise ValueError(f"n_knots={nk} exceeds MPPI_MAX_KNOTS")
+    if halton and nk > capi.MAX_KNOTS:
+        raise ValueError(f"halton sampling without a spline needs horizon <= {capi.MAX_KNOTS} (n_knots = horizon = {nk})")
     c.n_knots = nk
     c.noise_abs_cost = int(bool(cfg.noise_abs_cost))
     c.want_rollouts = int(viz_link >= 0)
@@ -146,7 +161,8 @@ def make_config(cfg: MPPIConfig, *, k_offset: int = 0, k_local: Optional[int] = 
     for j in range(nu):
         c.u_min[j], c.u_max[j] = float(umin[j]) * cfg.u_scale, float(umax[j]) * cfg.u_scale
         c.noise_sigma_diag[j] = float(sigma[j, j])
-    if halton:
+        c.noise_mu[j] = float(cfg.noise_mu[j]) if cfg.noise_mu is not None else 0.0
+    if nk != cfg.horizon or halton:
         B = bspline_basis(cfg.horizon, nk) if nk != cfg.horizon else np.eye(cfg.horizon)
         flat = B.reshape(-1)
         for j, v in enumerate(flat):
@@ -187,6 +203,15 @@ class MPPIPlanner:
             self._world = dist.get_world_size(process_group)
         self._rec_floats = self._lib.mppi_record_floats(self._ctx)
         self._records = torch.zeros((self._world, self._rec_floats), dtype=torch.float32, device=sim.device)
+        # fused mode on the quad kernels: the rollout's own tail folds its wave records to `_fold_n` records per shard and
+        # writes them straight into this rank's rows of the tensor that is all-gathered in place (no reduce launch)
+        self._fold_n = self._lib.mppi_shard_record_count(self._ctx) if shard else 0
+        self._records_fold = None
+        if self._fold_n > 0:
+            import torch.distributed as dist
+            r = dist.get_rank(process_group)
+            self._records_fold = torch.zeros((self._world * self._fold_n, self._rec_floats), dtype=torch.float32, device=sim.device)
+            capi.check(self._lib, self._lib.mppi_set_record_out(self._ctx, C_void(self._records_fold[r * self._fold_n:(r + 1) * self._fold_n])))
         self._fused_cost = None
         self._sample_index = 0
         self._action = np.zeros(self.nu, np.float32)
@@ -197,23 +222,29 @@ class MPPIPlanner:
             F = np.ascontiguousarray(savgol_matrix(self.T), np.float32)
             capi.check(self._lib, self._lib.mppi_set_filter(self._ctx, capi.fptr(F)))
         self._graph, self._graph_sig, self._graph_viz = None, None, []
-        self._graph_state = "off" if os.environ.get("MPPI_GENERIC_GRAPH", "1") == "0" else "on"
+        # MPPI_GENERIC_GRAPH: "0" never capture, "1" capture any Objective, unset: capture Objectives that declare
+        # `graph_safe = True` (see _replay_horizon)
+        self._graph_state = {"0": "off", "1": "on"}.get(os.environ.get("MPPI_GENERIC_GRAPH", ""), "auto")
         self._external_noise = None
-        if sim._mppi_config.sampling == capi.SAMPLE_HALTON_SPLINE:
+        self._iteration = 0   # control iterations so far: the counter of the device-side Gaussian sampler
+        self._sampling = sim._mppi_config.sampling
+        if self._sampling == capi.SAMPLE_HALTON_SPLINE:
             capi.check(self._lib, self._lib.mppi_sample(self._ctx, np.uint32(cfg.seed_val)))
-        else:
-            self._gen = torch.Generator(device=sim.device)
-            self._gen.manual_seed(int(cfg.seed_val) + 7919 * int(sim._mppi_config.k_offset))
-            self._resample_external()
+        elif self._sampling == capi.SAMPLE_NORMAL:
+            capi.check(self._lib, self._lib.mppi_sample_normal(self._ctx, np.uint32(0)))
 
     # -- sampling -----------------------------------------------------------------------
-    def _resample_external(self):
-        """`random` sampling: Gaussian noise drawn with torch on the device, layout [H][nu][K]."""
-        sig = torch.tensor([self.cfg.noise_sigma[j][j] for j in range(self.nu)], device=self.sim.device).sqrt()
-        eps = torch.randn((self.T, self.nu, self.K), generator=self._gen, device=self.sim.device) * sig.view(1, -1, 1)
-        if self.cfg.noise_mu is not None:
-            eps = eps + torch.tensor(self.cfg.noise_mu, device=self.sim.device).view(1, -1, 1)
+    def set_external_noise(self, eps: Optional[torch.Tensor]):
+        """caller-owned noise [H][nu][K] (float32, on the sim's device) for the following commands; None returns to
+        the configured sampler.  The tensor is kept alive here: the library reads it at every rollout."""
+        if eps is None:
+            self._external_noise = None
+            capi.check(self._lib, self._lib.mppi_set_noise_dev(self._ctx, None))
+            return
+        if tuple(eps.shape) != (self.T, self.nu, self.K) or eps.dtype != torch.float32 or not eps.is_cuda:
+            raise ValueError(f"external noise must be a float32 device tensor of shape [{self.T}, {self.nu}, {self.K}]")
         self._external_noise = eps.contiguous()
+        self._graph = None  # a captured horizon has the previous noise pointer baked in
         capi.check(self._lib, self._lib.mppi_set_noise_dev(self._ctx, C_void(self._external_noise)))
 
     # -- properties mirroring mppi_torch attributes used by callers -----------------------
@@ -237,10 +268,16 @@ class MPPIPlanner:
     # -- one control iteration ---------------------------------------------------------------
     def command(self, state=None) -> torch.Tensor:
         lib, ctx = self._lib, self._ctx
-        if self._external_noise is not None and self.cfg.sampling_method == "random":
-            self._resample_external()
-        if self._prior is not None and self.cfg.use_priors:
-            pr = np.ascontiguousarray(np.stack([np.asarray(self._prior(state, t), np.float32).reshape(-1) for t in range(self.T)]))
+        if self._sampling == capi.SAMPLE_NORMAL and self._external_noise is None:
+            # fresh noise every command, drawn on the device into the context's own (fixed-address) buffer: a captured
+            # generic horizon keeps reading the right memory
+            capi.check(lib, lib.mppi_sample_normal(ctx, np.uint32(self._iteration)))
+        self._iteration += 1
+        with_prior = self._prior is not None and self.cfg.use_priors
+        if with_prior and self._fused_cost is not None:
+            # fused mode: the whole horizon runs inside one kernel, so the prior can only be evaluated beforehand, on
+            # the state the rollout starts from (open loop); generic mode evaluates it at every rollout step
+            pr = np.ascontiguousarray(np.stack([_prior_row(self._prior(state, t), self.nu) for t in range(self.T)]))
             capi.check(lib, lib.mppi_set_prior(ctx, capi.fptr(pr)))
         if self._fused_cost is not None:
             capi.check(lib, lib.mppi_rollout(ctx))
@@ -249,7 +286,10 @@ class MPPIPlanner:
             if not self._replay_horizon(state):
                 self._horizon_eager(state)
             capi.check(lib, lib.mppi_sim_finish(ctx))
-        if self._world > 1:
+        if self._shard and self._fused_cost is not None and self._records_fold is not None:
+            allgather_records(self._records_fold, _dist_rank(self._pg), self._pg, per=self._fold_n)
+            capi.check(lib, lib.mppi_update(ctx, C_void(self._records_fold), self._world * self._fold_n))
+        elif self._shard:
             rank = _dist_rank(self._pg)
             capi.check(lib, lib.mppi_reduce(ctx, C_void(self._records[rank])))
             allgather_records(self._records, rank, self._pg)
@@ -264,7 +304,10 @@ class MPPIPlanner:
     def _horizon_eager(self, state):
         """reference loop shape (mppi_isaac.py:57-69): per horizon step dynamics() = apply + step, then running_cost()"""
         lib, ctx = self._lib, self._ctx
+        with_prior = self._prior is not None and self.cfg.use_priors
         for t in range(self.T):
+            if with_prior:  # prior(state, t) on the envs' state AT step t, as the reference's callback sees it (mppi_isaac.py:39)
+                capi.check(lib, lib.mppi_set_prior_row(ctx, t, capi.fptr(_prior_row(self._prior(state, t), self.nu))))
             capi.check(lib, lib.mppi_sim_step_horizon(ctx, t))
             self.sim._materialise()
             if self.sim._visualize_link_present:
@@ -287,11 +330,19 @@ class MPPIPlanner:
         Objective, accumulate).  It is therefore captured ONCE into a HIP graph (torch.cuda.CUDAGraph) and replayed:
         the Objective's Python code runs at capture time only, its tensor program runs every iteration.  Anything
         the Objective reads through `sim` tensors (goal, obstacles, states) stays live; Python-side numbers are
-        baked in, so the capture is redone when the objective object or its `.weights` change.  Objectives that
-        cannot be captured (host synchronisation such as .item()/.cpu() inside compute_cost) fall back to the
-        eager loop for good.  MPPI_GENERIC_GRAPH=0 switches the capture off."""
-        if self._graph_state == "off":
-            return False
+        baked in, so the capture is redone when the objective object or its `.weights` change.  Because ANY other
+        Python-side state of an Objective (float goals, counters, tensors re-created in reset(), data-dependent
+        branches) would silently go stale, the capture is opt-in: an Objective declares `graph_safe = True` when its
+        compute_cost is a pure tensor program of `sim` tensors and `.weights` (the in-tree Objectives are);
+        MPPI_GENERIC_GRAPH=1 forces the capture for any Objective, =0 switches it off.  Objectives that cannot be
+        captured (host synchronisation such as .item()/.cpu() inside compute_cost) fall back to the eager loop for good."""
+        if self._graph_state == "off" or (self._prior is not None and self.cfg.use_priors):
+            return False  # (a prior is arbitrary host code evaluated per step: eager loop)
+        if self._graph_state == "auto":
+            obj = getattr(self._running_cost, "__self__", None)
+            obj = getattr(obj, "objective", obj)
+            if not getattr(obj, "graph_safe", False):
+                return False
         sig = self._objective_signature()
         if self._graph is not None and sig != self._graph_sig:
             self._graph = None                         # objective or weights changed: capture again
@@ -332,6 +383,14 @@ class MPPIPlanner:
         return torch.from_numpy(S)
 
 
+def _prior_row(p, nu: int) -> np.ndarray:
+    """what a prior callback returns (list, numpy, CPU or device tensor) -> contiguous float32 [nu]"""
+    row = torch.as_tensor(p).detach().to(dtype=torch.float32, device="cpu").reshape(-1).numpy()
+    if row.shape[0] != nu:
+        raise ValueError(f"prior returned {row.shape[0]} values, the control dimension is {nu}")
+    return np.ascontiguousarray(row)
+
+
 def C_void(t: torch.Tensor):
     return C.c_void_p(t.data_ptr())
 
@@ -341,12 +400,14 @@ def _dist_rank(group=None) -> int:
     return dist.get_rank(group)
 
 
-def allgather_records(records: torch.Tensor, rank: int, group=None) -> None:
-    """All-gather the per-shard records [world, 2+H*nu] in place (row `rank` holds this shard's
-    record on entry).  One small collective per control iteration: RCCL over xGMI for device
-    tensors (backend "nccl"), gloo for the CPU tests.  ~1 KB per rank: latency-bound."""
+def allgather_records(records: torch.Tensor, rank: int, group=None, per: int = 1) -> None:
+    """All-gather the shard records [world * per, 2+H*nu] in place (rows rank*per .. rank*per+per-1 hold this shard's
+    records on entry).  One small collective per control iteration: RCCL over xGMI for device tensors (backend "nccl":
+    truly in place, the send buffer is this rank's slice of the receive buffer), gloo for the CPU tests.
+    1-9 KB per rank: latency-bound."""
     import torch.distributed as dist
-    dist.all_gather_into_tensor(records.view(-1), records[rank].clone(), group=group)
+    mine = records[rank * per:(rank + 1) * per].reshape(-1)
+    dist.all_gather_into_tensor(records.view(-1), mine if records.is_cuda else mine.clone(), group=group)
 
 
 def _get_rollouts(self) -> torch.Tensor:

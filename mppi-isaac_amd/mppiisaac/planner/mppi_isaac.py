@@ -112,6 +112,10 @@ class MPPIisaacPlanner(object):
         self._bind_objective()
 
     def update_mppi_params(self, params):
+        """reference mppi_isaac.py:126-138: a new MPPI core with the new noise covariance on the EXISTING simulator - the
+        actor list (incl. actors added through add_to_env / obstacle updates), the current world state, the saved root
+        state and the nominal control sequence survive; only the HIP context is rebuilt around the new config."""
         self.cfg.mppi.noise_sigma = params["noise_sigma"]
-        self.sim.stop_sim()
-        self._build(self._prior_obj)
+        self.sim._restart()
+        self._rebind_after_restart()
+        self._bind_objective()

@@ -900,19 +900,25 @@ static const int PRIMES[MPPI_MAX_KNOTS * MPPI_MAX_NU] = {
     877, 881, 883, 887, 907, 911, 919, 929, 937, 941, 947, 953, 967, 971, 977, 983, 991, 997, 1009, 1013, 1019, 1021, 1031,
     1033, 1039, 1049, 1051, 1061, 1063, 1069, 1087, 1091, 1093, 1097, 1103, 1109, 1117, 1123, 1129, 1151, 1153, 1163};
 
-/* linearly digit-scrambled radical inverse: digit -> (digit * mult) mod p, mult = round(0.618 p) */
+/* radical inverse of n in base p with the linear digit scramble digit -> (digit * mult) mod p
+ * (mult = 1: the plain van der Corput / Halton sequence, KAT'ed against scipy.stats.qmc.Halton(scramble=False)) */
+double orc_radical_inverse(uint32_t n, uint32_t p, uint32_t mult) {
+    double f = 1.0 / p, r = 0.0;
+    while (n > 0) {
+        uint32_t dgt = n % p;
+        r += f * (double)((dgt * mult) % p);
+        n /= p;
+        f /= p;
+    }
+    return r;
+}
+int orc_prime(int dim) { return PRIMES[dim]; }
+/* the sampler's sequence: mult = round(0.618 p) */
 double orc_halton(uint32_t n, int dim) {
     int p = PRIMES[dim];
     int mult = (int)(0.6180339887498949 * p + 0.5);
     if (mult < 1) mult = 1;
-    double f = 1.0 / p, r = 0.0;
-    while (n > 0) {
-        uint32_t dgt = n % (uint32_t)p;
-        r += f * (double)((dgt * (uint32_t)mult) % (uint32_t)p);
-        n /= (uint32_t)p;
-        f /= p;
-    }
-    return r;
+    return orc_radical_inverse(n, (uint32_t)p, (uint32_t)mult);
 }
 
 /* inverse standard normal CDF: Acklam's rational approximation + one Halley step (double accuracy) */
@@ -922,6 +928,7 @@ double orc_norminv(double p) {
     static const double c[] = {-7.784894002430293e-03, -3.223964580411365e-01, -2.400758277161838e+00, -2.549732539343734e+00, 4.374664141464968e+00, 2.938163982698783e+00};
     static const double d[] = {7.784695709041462e-03, 3.224671290700398e-01, 2.445134137142996e+00, 3.754408661907416e+00};
     double x, q, r;
+    if (p > 0.5) return -orc_norminv(1 - p); /* 1 - p is exact for p >= 0.5: the refinement below keeps its accuracy in the upper tail */
     if (p < 0.02425) {
         q = sqrt(-2 * log(p));
         x = (((((c[0] * q + c[1]) * q + c[2]) * q + c[3]) * q + c[4]) * q + c[5]) / ((((d[0] * q + d[1]) * q + d[2]) * q + d[3]) * q + 1);
@@ -954,6 +961,50 @@ void orc_sample(const mppi_config_t *cfg, uint32_t index_base, real *eps) {
                 eps[((size_t)t * nu + c) * K + k] = (real)(sqrt(cfg->noise_sigma_diag[c]) * s);
             }
     }
+    free(z);
+}
+
+/* ------------------------------------------------------------------ counter-based Gaussian sampler
+ * MPPI_SAMPLE_NORMAL (include/mppi_hip.h): what mppi_torch's "simple" mode / the random knot source of its
+ * halton-spline mode draw from torch's generator inside MPPIPlanner.command (call sites reference
+ * mppiisaac/planner/mppi_isaac.py:84,113; configs reference conf/mppi/omnipanda_effort.yaml:4-5) is drawn here from
+ * Philox4x32-10 (Salmon et al. SC'11; known-answer vectors of the Random123 distribution in tests/test_oracle_kat.py)
+ * so that every shard, every GPU and this oracle see the same noise for a (seed, iteration). */
+void orc_philox4x32(const uint32_t *ctr, const uint32_t *key, uint32_t *out) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+/* standard normal knot i of control c of global sample g: words (2p, 2p+1) of the block i/4 -> Box-Muller */
+double orc_normal_knot(uint32_t seed, uint32_t iteration, uint32_t g, int c, int i) {
+    uint32_t ctr[4] = {g, (uint32_t)c, (uint32_t)(i / 4), iteration}, key[2] = {seed, 0x4D505049u}, x[4];
+    orc_philox4x32(ctr, key, x);
+    int p = (i % 4) / 2, e = i % 2;
+    double ua = ((double)x[2 * p] + 0.5) / 4294967296.0, ub = ((double)x[2 * p + 1] + 0.5) / 4294967296.0;
+    double r = sqrt(-2.0 * log(ua)), a = 6.283185307179586 * ub;
+    return e == 0 ? r * cos(a) : r * sin(a);
+}
+/* eps[t][c][k] = mu_c + sigma_c * sum_i B[t][i] z_i  (n_knots == H: eps_t = mu_c + sigma_c z_t) */
+void orc_sample_normal(const mppi_config_t *cfg, uint32_t iteration, real *eps) {
+    int K = cfg->num_samples, H = cfg->horizon, nu = cfg->nu, nk = cfg->n_knots;
+    double *z = (double *)malloc(sizeof(double) * nk);
+    for (int k = 0; k < K; k++)
+        for (int c = 0; c < nu; c++) {
+            uint32_t g = (uint32_t)(cfg->k_offset + k);
+            double sg = sqrt(cfg->noise_sigma_diag[c]), mu = cfg->noise_mu[c];
+            for (int i = 0; i < nk; i++) z[i] = orc_normal_knot((uint32_t)cfg->seed, iteration, g, c, i);
+            for (int t = 0; t < H; t++) {
+                double s = 0;
+                if (nk == H) s = z[t];
+                else for (int i = 0; i < nk; i++) s += cfg->spline_basis[t * nk + i] * z[i];
+                eps[((size_t)t * nu + c) * K + k] = (real)(mu + sg * s);
+            }
+        }
     free(z);
 }
 
@@ -1107,6 +1158,39 @@ void orc_command(const mppi_model_t *m, const mppi_config_t *cfg, const mppi_cos
     orc_record(cfg, S, du, rec);
     orc_update(cfg, rec, 1, U, action, NULL);
     free(rec);
+}
+
+/* ------------------------------------------------------------------ batched env step (CPU pipeline baseline)
+ * What `apply_robot_cmd` + `step` + the four tensor refreshes are to the reference's Python horizon loop
+ * (mppiisaac/planner/mppi_isaac.py:57-65, isaacgym_wrapper.py:524-572,639-655): K independent envs advanced by one dt
+ * with per-env commands u [K][nu], their reference-layout state rows rewritten in place: dof [K][2n] interleaved,
+ * root [K][A][13], rigid bodies [K][B][13], net contact forces [K][B][3].  OpenMP over the envs, as Isaac Gym's CPU
+ * pipeline threads over them; orc_set_threads picks the thread count (bench.py times 1 and all host cores). */
+#include <omp.h>
+void orc_set_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
+int orc_get_max_threads(void) { return omp_get_max_threads(); }
+void orc_envs_step(const mppi_model_t *m_nominal, int K, int g0, const real *u, real *dof, real *root, real *rb, real *cf) {
+    const int n = m_nominal->n_bodies, A = m_nominal->n_actors, B = m_nominal->n_rb, nu = m_nominal->nu;
+    const int scene = orc_is_scene(m_nominal);
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < K; k++) {
+        const mppi_model_t *m = m_nominal;
+        mppi_model_t *mine = NULL;
+        if (m_nominal->randomize_seed >= 0) {
+            mine = (mppi_model_t *)malloc(sizeof(mppi_model_t));
+            orc_randomise_model(m_nominal, g0 + k, mine);
+            m = mine;
+        }
+        real q[NBMAX], qd[NBMAX], target[NBMAX];
+        real *d = dof + (size_t)k * 2 * n, *r = root + (size_t)k * 13 * A;
+        for (int i = 0; i < n; i++) { q[i] = d[2 * i]; qd[i] = d[2 * i + 1]; }
+        orc_cmd_map(m, u + (size_t)k * nu, target);
+        if (scene) orc_scene_step(m, r, q, qd, target, cf + (size_t)k * 3 * B);
+        else orc_step(m, r, q, qd, target);
+        for (int i = 0; i < n; i++) { d[2 * i] = q[i]; d[2 * i + 1] = qd[i]; }
+        orc_rigid_body_state(m, r, q, qd, rb + (size_t)k * 13 * B, NULL);
+        free(mine);
+    }
 }
 
 int orc_sizeof_real(void) { return (int)sizeof(real); }

@@ -100,6 +100,20 @@ class Oracle:
         self.lib.orc_sample(C.byref(cfg), C.c_uint32(index_base), self.p(eps))
         return eps
 
+    def sample_normal(self, cfg, iteration=0):
+        eps = np.zeros((cfg.horizon, cfg.nu, cfg.num_samples), self.dtype)
+        self.lib.orc_sample_normal(C.byref(cfg), C.c_uint32(iteration), self.p(eps))
+        return eps
+
+    def philox(self, ctr, key):
+        c, k, o = (C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), (C.c_uint32 * 4)()
+        self.lib.orc_philox4x32(c, k, o)
+        return [int(v) for v in o]
+
+    def normal_knot(self, seed, iteration, g, c, i):
+        self.lib.orc_normal_knot.restype = C.c_double
+        return float(self.lib.orc_normal_knot(C.c_uint32(seed), C.c_uint32(iteration), C.c_uint32(g), C.c_int(c), C.c_int(i)))
+
     def rollout(self, model, cfg, cost, dof0, root0, U, eps, prior=None, want_viz=False):
         dof0, root0, U, eps = map(self.arr, (dof0, root0, U, eps))
         K, H, nu = cfg.num_samples, cfg.horizon, cfg.nu

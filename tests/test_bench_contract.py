@@ -35,9 +35,14 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["frac"] == pytest.approx(r["achieved"] / r["peak"])
     assert 0.05 < r["kernel_ms"] < 5.0
     c = d["cpu_baseline"]
-    for key in ("value", "unit", "cores", "kind", "sample"):
+    for key in ("value", "unit", "cores", "kind", "sample", "rows"):
         assert key in c, key
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
+    assert [row["threads"] for row in c["rows"]] == [1, c["cores"], 1, c["cores"]] and c["value"] == c["rows"][1]["value"]
+    lat = d["latency_ms"]
+    assert lat["p5"] <= lat["median"] <= lat["p95"] and lat["median"] == pytest.approx(d["ms_per_step"], rel=0.25)
+    i = r["issue"]                                              # instruction-issue view from the committed SQ counters
+    assert i is None or (0 < i["frac_of_fp32_issue_peak"] < 1 and i["waves"] == 256)
     assert d["config"]["final_ee_to_goal_m"] < 0.6              # the closed loop moves towards the goal
 
 
@@ -51,7 +56,7 @@ def test_bench_other_workloads_and_the_sharded_code_path():
     lines = out.stdout.strip().splitlines()
     assert len(lines) == 1, out.stdout[-2000:]                 # (RCCL's version banner goes to stderr)
     d = json.loads(lines[0])
-    assert "sample-shard x1 (nccl" in d["config"]["parallelism"] and d["value"] > 100.0   # RCCL process group + all-gather, one rank
+    assert "sample-shard x1" in d["config"]["parallelism"] and "nccl" in d["config"]["parallelism"] and d["value"] > 100.0   # RCCL process group + all-gather, one rank
 
 
 def test_bench_two_ranks_launched_like_the_driver_does():

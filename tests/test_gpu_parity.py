@@ -304,7 +304,7 @@ def test_generic_horizon_graph_replay_equals_eager_loop(lib, monkeypatch):
     monkeypatch.setenv("MPPI_GENERIC_GRAPH", "0")
     eager = MPPIisaacPlanner(cfg, Generic(cfg))
     monkeypatch.delenv("MPPI_GENERIC_GRAPH")
-    assert eager.mppi._graph_state == "off" and graph.mppi._graph_state == "on"
+    assert eager.mppi._graph_state == "off" and graph.mppi._graph_state == "auto"   # in-tree Objectives declare graph_safe
     q = np.array([0.0, -0.94, 0.0, -2.8, 0.0, 1.8675, 0.0])
     goals = [[0.5, -0.4, 0.3], [0.5, -0.4, 0.3], [0.3, 0.4, 0.5], [0.3, 0.4, 0.5]]
     for i, goal in enumerate(goals):                       # iteration 0 captures, 1.. replay; the goal moves at 2
@@ -626,7 +626,7 @@ def test_more_wave_records_than_the_combine_table_holds(lib, oracle64):
 
 
 def test_random_sampling_priors_and_param_update(lib, oracle64):
-    """mppi_mode 'simple' / sampling_method 'random' (torch noise on the device), a prior in sample K-2
+    """mppi_mode 'simple' / sampling_method 'random' (Gaussian noise drawn on the device), a prior in sample K-2
     (reference mppi_isaac.py:38-41) and update_mppi_params (:129-138) through the planner facade."""
     from mppiisaac.objectives import PandaReachObjective
     from mppiisaac.planner.mppi_isaac import MPPIisaacPlanner
@@ -663,16 +663,23 @@ def test_random_sampling_priors_and_param_update(lib, oracle64):
     assert eps.std() == pytest.approx(np.sqrt(0.4), rel=0.1)
 
 
-@pytest.mark.parametrize("actors,init,link,nu,sigma,umax", [
-    (["omnipanda_effort", "goal"], [[0.0, 0.0, 0.0]], "panda_hand", 12, 4.0, 10.0),   # effort mode, 12-DoF tree, quad kernel
-    (["heijn", "goal"], [[0.0, 0.0, 0.0]], "front_link", 3, 1.0, 1.5),                 # holonomic base
-    (["albert", "goal"], [[0.0, 0.0, 0.2]], "mmrobot_link7", 9, 0.2, 0.5),            # diff-drive base + arm: contact scene
+# the shipped jackal.yaml names no wheel joints (the reference raises TypeError on it, isaacgym_wrapper.py:552-555); supply them
+JACKAL_WHEELS = {"left_wheel_joints": ["front_left_wheel", "rear_left_wheel"], "right_wheel_joints": ["front_right_wheel", "rear_right_wheel"]}
+
+
+@pytest.mark.parametrize("actors,init,link,nu,sigma,umax,over", [
+    (["omnipanda_effort", "goal"], [[0.0, 0.0, 0.0]], "panda_hand", 12, 4.0, 10.0, None),   # effort mode, 12-DoF tree, quad kernel
+    (["heijn", "goal"], [[0.0, 0.0, 0.0]], "front_link", 3, 1.0, 1.5, None),                 # holonomic base
+    (["albert", "goal"], [[0.0, 0.0, 0.2]], "mmrobot_link7", 9, 0.2, 0.5, None),            # diff-drive base + arm: contact scene
+    (["jackal", "goal"], [[0.0, 0.0, 0.1]], "base_link", 2, 0.5, 1.0, JACKAL_WHEELS),       # 4-wheel skid steer: contact scene
+    (["panda_effort", "goal"], [[0.0, 0.0, 0.0]], "panda_link7", 7, 20.0, 40.0, None),      # effort mode, fixed base
+    (["omnipanda", "goal"], [[0.0, 0.0, 0.0]], "panda_hand", 12, 0.2, 0.5, None),           # velocity mode, holonomic base + arm + gripper
 ])
-def test_more_robots_rollout(actors, init, link, nu, sigma, umax, lib, oracle64):
+def test_more_robots_rollout(actors, init, link, nu, sigma, umax, over, lib, oracle64):
     """SURVEY 8f rank 1 robots through the HIP path: reach cost on one of their links, rollouts vs the oracle."""
     from mppiisaac.planner.mppi import MPPIConfig, make_config
     from scenes import build_scene
-    scene = build_scene(actors, init)
+    scene = build_scene(actors, init, robot_overrides=over)
     assert scene.nu == nu
     m = scene.to_c()
     K, H = 128, 12

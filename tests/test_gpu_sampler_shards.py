@@ -1,0 +1,200 @@
+"""GPU parity, part 2 (through the C-ABI / the planner facade): the device-side Gaussian sampler, per-step priors,
+and BASELINE config 5 at its real size - K_total = 65536 samples x H = 30 of the panda_pick scene, as one context and
+as the eight 8192-sample shards the 8-GPU run uses, combined on one device."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from mppiisaac.backend import capi
+from scenes import panda_pick, panda_reach
+from test_gpu_parity import Ctx
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    assert torch.cuda.is_available()
+    return capi.load_library()
+
+
+def _panda_cfg(**over):
+    from mppiisaac.utils.config_store import load_config
+    o = {"mppi.num_samples": 256, "mppi.horizon": 12, "mppi.use_priors": False, "mppi.filter_u": False}
+    o.update({f"mppi.{k}": v for k, v in over.items()})
+    return load_config({"defaults": [{"mppi": "panda"}, {"isaacgym": "normal"}], "actors": ["panda_stick", "goal"],
+                        "initial_actor_positions": [[0.0, 0.0, 0.0]], "nx": 14}, overrides=o)
+
+
+@pytest.mark.parametrize("mode,method,K,H", [("simple", "halton", 1000, 20), ("simple", "random", 4096, 30), ("halton-spline", "random", 777, 24)])
+def test_normal_sampler_matches_oracle_and_is_shard_invariant(mode, method, K, H, lib, oracle64):
+    """MPPI_SAMPLE_NORMAL: Philox4x32-10 + Box-Muller on the device == the oracle's restatement (whose integer stream is
+    pinned by the Random123 known answers) to 1e-6; a shard context draws exactly the slice of the global set."""
+    from mppiisaac.planner.mppi import make_config
+    scene, m, _, cost, dof, root = panda_reach(K=K, H=H)
+    ex = _panda_cfg(num_samples=K, horizon=H, mppi_mode=mode, sampling_method=method, seed_val=11,
+                    noise_mu=[0.0, 0.01, -0.02, 0.0, 0.03, 0.0, 0.0]).mppi
+    cfg = make_config(ex, viz_link=scene.viz_link_index())
+    assert cfg.sampling == capi.SAMPLE_NORMAL
+    c = Ctx(m, cfg, cost)
+    for it in (0, 1, 123456):
+        c.call("mppi_sample_normal", C.c_uint32(it))
+        eps = c.get("mppi_get_noise", (H, 7, K))
+        np.testing.assert_allclose(eps, oracle64.sample_normal(cfg, it), atol=1e-6)
+    k0, kl = (K // 3) // 16 * 16 + 5, 100                           # a ragged shard in the middle
+    sc = make_config(ex, k_offset=k0, k_local=kl, viz_link=scene.viz_link_index())
+    s = Ctx(m, sc, cost)
+    s.call("mppi_sample_normal", C.c_uint32(123456))
+    np.testing.assert_array_equal(s.get("mppi_get_noise", (H, 7, kl)), eps[:, :, k0:k0 + kl])
+    # the halton sampler refuses a NORMAL context and vice versa
+    assert lib.mppi_sample(c.ctx, C.c_uint32(0)) == -4 and b"halton" in lib.mppi_last_error()
+    c.close(); s.close()
+
+
+def test_simple_mode_redraws_every_command_in_fused_and_generic_mode(lib, oracle64):
+    """reference conf/mppi/omnipanda_effort.yaml ships mppi_mode 'simple' with sampling_method 'halton': fresh N(mu, Sigma)
+    noise at EVERY command, in both execution modes; in generic mode the captured horizon graph must read the noise
+    of the current iteration (the buffer has a fixed address), i.e. du == clamp(U + eps) - U with the eps of this
+    command, and both modes see the same noise sequence for the same seed."""
+    from mppiisaac.objectives import PandaReachObjective
+    from mppiisaac.planner.mppi_isaac import MPPIisaacPlanner
+    cfg = _panda_cfg(mppi_mode="simple", sampling_method="halton", seed_val=5)
+
+    class Generic(PandaReachObjective):
+        fused_spec = None
+    fused, generic = MPPIisaacPlanner(cfg, PandaReachObjective(cfg)), MPPIisaacPlanner(cfg, Generic(cfg))
+    q = [0.0, -0.94, 0.0, -2.8, 0.0, 1.8675, 0.0]
+    prev = None
+    for it in range(4):
+        noise = []
+        for pl in (fused, generic):
+            pl.sim.set_actor_position_by_name([0.5, -0.4, 0.3], "goal")
+            U = pl.mppi.U.numpy().astype(np.float64)
+            pl.compute_action(q, [0.0] * 7)
+            eps, du = np.zeros((12, 7, 256), np.float32), np.zeros((12, 7, 256), np.float32)
+            capi.check(lib, lib.mppi_get_noise(pl.sim._ctx, capi.fptr(eps)))
+            capi.check(lib, lib.mppi_get_perturbations(pl.sim._ctx, capi.fptr(du)))
+            np.testing.assert_allclose(eps, oracle64.sample_normal(pl.sim._mppi_config, it), atol=1e-6)
+            want = np.clip(U[:, :, None] + eps, -0.2, 0.2) - U[:, :, None]
+            want[:, :, -1] = np.clip(0.0, -0.2, 0.2) - U                   # null-action sample
+            np.testing.assert_allclose(du, want, atol=2e-7)
+            noise.append(eps)
+        np.testing.assert_array_equal(noise[0], noise[1])
+        if prev is not None:
+            assert np.abs(noise[0] - prev).max() > 0.5                      # a new draw, not the previous set
+        prev = noise[0]
+    assert generic.mppi._graph is not None                                  # (the generic horizon did run as a graph)
+
+
+def test_prior_may_return_a_device_tensor_and_sees_the_rollout_state_in_generic_mode(lib):
+    """reference priors (mppiisaac/priors/fabrics_*.py) return device tensors and are called as prior(state, t) while the
+    rollout envs sit at step t: sample K-2 follows the prior; in generic mode the callback observes the stepped sim."""
+    from mppiisaac.objectives import PandaReachObjective
+    from mppiisaac.planner.mppi_isaac import MPPIisaacPlanner
+    cfg = _panda_cfg(use_priors=True)
+    seen = []
+
+    class Prior:
+        def compute_command(self, sim):
+            seen.append(float(sim.get_dof_state()[254, 0]))                # joint 0 of the prior's own env (K-2)
+            return torch.full((7,), 0.07, device=sim.device)               # a CUDA tensor
+
+    class Generic(PandaReachObjective):
+        fused_spec = None
+    q = [0.0, -0.94, 0.0, -2.8, 0.0, 1.8675, 0.0]
+    for Obj in (PandaReachObjective, Generic):
+        seen.clear()
+        pl = MPPIisaacPlanner(cfg, Obj(cfg), prior=Prior())
+        pl.compute_action(q, [0.0] * 7)
+        du = np.zeros((12, 7, 256), np.float32)
+        capi.check(lib, lib.mppi_get_perturbations(pl.sim._ctx, capi.fptr(du)))
+        np.testing.assert_allclose(du[:, :, 254], 0.07, atol=1e-7)         # U = 0: du is the prior sequence
+        assert len(seen) == 12
+        if Obj is Generic:   # evaluated at every rollout step: joint 0 of env K-2 integrates 0.07 rad/s
+            assert seen[0] == pytest.approx(0.0, abs=1e-6) and seen[-1] > 0.02 and all(b > a for a, b in zip(seen, seen[1:]))
+        else:                # fused: open loop on the start state
+            assert max(abs(v) for v in seen) < 1e-6
+
+
+def test_update_mppi_params_keeps_added_actors_and_state(lib):
+    from mppiisaac.objectives import PandaReachObjective
+    from mppiisaac.planner.mppi_isaac import MPPIisaacPlanner
+    cfg = _panda_cfg()
+    pl = MPPIisaacPlanner(cfg, PandaReachObjective(cfg))
+    pl.add_to_env([{"type": "sphere", "name": "ball", "size": [0.05], "fixed": True, "init_pos": [1.0, 1.0, 1.0]}])
+    pl.sim.set_actor_position_by_name([0.5, -0.4, 0.3], "goal")
+    q = [0.0, -0.94, 0.0, -2.8, 0.0, 1.8675, 0.0]
+    pl.compute_action(q, [0.0] * 7)
+    U_before = pl.mppi.U.numpy()
+    pl.update_mppi_params({"noise_sigma": (0.4 * np.eye(7)).tolist()})
+    assert [a.name for a in pl.sim.env_cfg] == ["panda", "goal", "ball"]
+    np.testing.assert_allclose(pl.sim.get_actor_position_by_name("goal")[0].cpu().numpy(), [0.5, -0.4, 0.3], atol=1e-7)
+    np.testing.assert_allclose(pl.sim.get_dof_state()[0, 0::2].cpu().numpy(), q, atol=1e-6)
+    np.testing.assert_array_equal(pl.mppi.U.numpy(), U_before)
+    assert pl.sim._mppi_config.noise_sigma_diag[0] == pytest.approx(0.4)
+    assert np.isfinite(pl.compute_action(q, [0.0] * 7).numpy()).all()
+
+
+def test_config5_full_size_eight_shards_equal_one_context(lib, oracle64):
+    """BASELINE config 5 at its stated size (reference examples/panda_pick/panda_pick.yaml:6, conf/mppi/panda_pick.yaml with
+    K_total = 65536, H = 30): eight 8192-sample shard contexts (what the 8 GPUs own; here on one device) against ONE
+    65536-sample context - per-shard costs bit-equal to the slice, the null-action sample only at global id 65535, the
+    [8, 272] records combined by mppi_update give the single-context action and nominal - and 64 scattered samples
+    against the oracle."""
+    from mppiisaac.planner.mppi import make_config
+    from mppiisaac.utils.config_store import load_config
+    K, G, H, nu = 65536, 8, 30, 9
+    scene, m, cfg, cost, dof, root = panda_pick(K=K, H=H)
+    ex = load_config({"defaults": [{"mppi": "panda_pick"}, {"isaacgym": "normal"}]}, overrides={"mppi.num_samples": K, "mppi.horizon": H})
+    full = Ctx(m, cfg, cost)
+    full.call("mppi_sample", C.c_uint32(0)); full.set_state(dof, root)
+    a_full = np.zeros(nu, np.float32)
+    full.call("mppi_command", capi.fptr(a_full))
+    S_full, U_full = full.get("mppi_get_costs", (K,)), full.get("mppi_get_nominal", (H, nu))
+    du_full = full.get("mppi_get_perturbations", (H, nu, K))
+    eps_full = full.get("mppi_get_noise", (H, nu, K))
+    assert np.isfinite(S_full).all() and np.isfinite(a_full).all()
+    zero = np.where(np.abs(du_full).max(axis=(0, 1)) == 0.0)[0]
+    assert list(zero) == [K - 1]                                            # null-action sample: global id 65535 only
+    RF = lib.mppi_record_floats(full.ctx)
+    assert RF == 2 + H * nu == 272
+    records = torch.zeros((G, RF), dtype=torch.float32, device="cuda")
+    shards = []
+    for r in range(G):
+        sc = make_config(ex.mppi, k_offset=r * K // G, k_local=K // G, viz_link=scene.viz_link_index())
+        s = Ctx(m, sc, cost)
+        s.call("mppi_sample", C.c_uint32(0)); s.set_state(dof, root)
+        s.call("mppi_rollout")
+        sl = slice(r * K // G, (r + 1) * K // G)
+        np.testing.assert_array_equal(s.get("mppi_get_noise", (H, nu, K // G)), eps_full[:, :, sl])
+        np.testing.assert_array_equal(s.get("mppi_get_costs", (K // G,)), S_full[sl])
+        du = s.get("mppi_get_perturbations", (H, nu, K // G))
+        assert (np.abs(du).max(axis=(0, 1)) == 0.0).sum() == (1 if r == G - 1 else 0)
+        s.call("mppi_reduce", C.c_void_p(records[r].data_ptr()))
+        shards.append(s)
+    rec = records.cpu().numpy().astype(np.float64)
+    w = np.exp(-(S_full.astype(np.float64) - S_full.min()) / cfg.lambda_)
+    assert rec[:, 0].min() == S_full.min()
+    eta = (rec[:, 1] * np.exp(-(rec[:, 0] - rec[:, 0].min()) / cfg.lambda_)).sum()
+    assert eta == pytest.approx(w.sum(), rel=1e-5)
+    for s in shards:
+        s.call("mppi_update", C.c_void_p(records.data_ptr()), G)
+        np.testing.assert_allclose(s.get("mppi_get_action", (nu,)), a_full, atol=2e-6)
+        np.testing.assert_allclose(s.get("mppi_get_nominal", (H, nu)), U_full, atol=2e-6)
+        s.close()
+    # the action is the softmax-weighted mean of the effective perturbations (U0 = 0)
+    np.testing.assert_allclose(a_full, (du_full[0].astype(np.float64) * w).sum(1) / w.sum(), atol=2e-6)
+    # 64 samples spread over all eight shards against the oracle (fp64), incl. the first / last of a shard and the null sample
+    idx = sorted(set(list(range(37, K, K // 60)) + [0, K // G - 1, K // G, K - 2, K - 1]))[:64 + 5]
+    rel = []
+    for k in idx:
+        sc = make_config(ex.mppi, k_offset=int(k), k_local=1, viz_link=scene.viz_link_index())
+        sc.k_total = K
+        So, _, _ = oracle64.rollout(m, sc, cost, dof, root, np.zeros((H, nu)), eps_full[:, :, k:k + 1])
+        rel.append(abs(S_full[k] - So[0]) / abs(So[0]))
+    rel = np.array(rel)
+    assert len(idx) >= 64 and np.median(rel) < 1e-5
+    assert (rel < 1e-4).all(), f"{(rel >= 1e-4).sum()} of {len(rel)} samples beyond 1e-4 (max {rel.max():.2e})"
+    full.close()

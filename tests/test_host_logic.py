@@ -140,3 +140,42 @@ def test_savgol_matrix_matches_scipy():
         t = np.arange(H, dtype=float)
         np.testing.assert_allclose(F @ (t ** 3), t ** 3, atol=1e-6)   # cubics are reproduced exactly
     assert np.array_equal(savgol_matrix(2), np.eye(2))
+
+
+def test_every_reference_mppi_file_is_restated_and_builds():
+    """all 18 conf/mppi files: same values as the reference's (tests/golden/mppi_cfgs.json, captured by
+    tools/make_golden.py), and every one of them turns into a valid C config (or is refused for a stated reason)"""
+    import glob
+    import json
+    import os
+    from mppiisaac.backend import capi
+    from mppiisaac.planner.mppi import MPPIConfig, make_config
+    from mppiisaac.utils.config_store import _load_group
+    from mppiisaac.utils.isaacgym_utils import CONF_DIR
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "mppi_cfgs.json")))
+    names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(CONF_DIR, "mppi", "*.yaml")))
+    assert names == sorted(gold) and len(names) == 18
+    for name in names:
+        cfg = _load_group("mppi", name, MPPIConfig)
+        for k, v in gold[name].items():
+            assert getattr(cfg, k) == v, (name, k)
+        if cfg.noise_sigma is None:                # reference conf/mppi/panda_push.yaml ships without a covariance
+            with pytest.raises(ValueError, match="noise_sigma"):
+                make_config(cfg)
+            continue
+        c = make_config(cfg)
+        assert c.nu == len(cfg.noise_sigma) and c.horizon == cfg.horizon
+        if cfg.mppi_mode == "simple":              # e.g. omnipanda_effort: fresh Gaussian noise per command, one draw per step
+            assert c.sampling == capi.SAMPLE_NORMAL and c.n_knots == cfg.horizon
+        else:
+            assert c.sampling == capi.SAMPLE_HALTON_SPLINE
+            assert c.n_knots == (cfg.horizon // 4 if cfg.horizon >= 12 else cfg.horizon)
+
+
+def test_unsupported_mppi_switches_are_refused_not_ignored():
+    from mppiisaac.planner.mppi import MPPIConfig, make_config
+    for kw in ({"update_lambda": True}, {"update_cov": True}, {"u_per_command": 2}):
+        with pytest.raises(NotImplementedError):
+            make_config(MPPIConfig(noise_sigma=[[1.0]], **kw))
+    with pytest.raises(ValueError):
+        make_config(MPPIConfig(noise_sigma=[[1.0]], mppi_mode="spline"))

@@ -322,3 +322,86 @@ def test_null_action_sample_and_clamp(oracle64):
     u = U0[:, :, None] + du
     assert u.max() <= 0.2 + 1e-12 and u.min() >= -0.2 - 1e-12
     np.testing.assert_allclose(u[:, :, -1], 0.0, atol=1e-15)   # sample K-1: u == 0 over the whole horizon
+
+
+# ------------------------------------------------------------------ external pins of the sampler pieces
+def test_radical_inverse_matches_scipy_halton(oracle64):
+    """the oracle's radical inverse with the digit scramble switched off (multiplier 1) IS the Halton sequence:
+    bit-for-bit against scipy.stats.qmc.Halton(scramble=False) in the first 16 bases, indices 1..2048"""
+    from scipy.stats import qmc
+    lib = oracle64.lib
+    lib.orc_radical_inverse.restype = C.c_double
+    lib.orc_radical_inverse.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+    d, n = 16, 2048
+    want = qmc.Halton(d=d, scramble=False).random(n + 1)[1:]      # scipy starts at index 0 (the origin)
+    got = np.array([[lib.orc_radical_inverse(i, lib.orc_prime(j), 1) for j in range(d)] for i in range(1, n + 1)])
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-16)
+    # the sampler's sequence is the same digits through a fixed per-base permutation: a bijection of each digit
+    for dim in (3, 40, 139):
+        p = lib.orc_prime(dim)
+        mult = int(0.6180339887498949 * p + 0.5)
+        assert sorted((dg * mult) % p for dg in range(p)) == list(range(p))
+        assert lib.orc_halton(p + 2, dim) == pytest.approx(((2 * mult) % p) / p + (mult % p) / p ** 2, abs=1e-15)
+
+
+def test_norminv_matches_scipy_ndtri(oracle64):
+    from scipy.special import ndtri
+    p = np.concatenate([np.logspace(-12, -1, 45), np.linspace(0.1, 0.9, 33), 1 - np.logspace(-12, -1, 45)])
+    got = np.array([oracle64.lib.orc_norminv(float(x)) for x in p])
+    np.testing.assert_allclose(got, ndtri(p), rtol=2e-10, atol=1e-12)
+
+
+def test_bspline_basis_matches_scipy_design_matrix():
+    """planner/mppi.py:bspline_basis (the matrix both the kernel and the oracle multiply the knots with) against
+    scipy.interpolate.BSpline.design_matrix on the same clamped uniform knot vector"""
+    from scipy.interpolate import BSpline
+    from mppiisaac.planner.mppi import bspline_basis, knots_for_horizon
+    for H in (12, 16, 20, 25, 30, 48, 64):
+        nk, deg = knots_for_horizon(H), 2
+        t = np.concatenate([np.zeros(deg), np.linspace(0.0, 1.0, nk - deg + 1), np.ones(deg)])
+        x = np.linspace(0.0, 1.0, H)
+        want = BSpline.design_matrix(x, t, deg).toarray()
+        np.testing.assert_allclose(bspline_basis(H, nk), want, atol=1e-13)
+
+
+PHILOX_KAT = [  # Random123 known-answer vectors for philox4x32-10 (counter, key) -> output
+    ([0, 0, 0, 0], [0, 0], [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]),
+    ([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2, [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]),
+    ([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0], [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]),
+]
+
+
+def test_philox_known_answers_and_normal_sampler(oracle64):
+    for ctr, key, want in PHILOX_KAT:
+        assert oracle64.philox(ctr, key) == want
+    from mppiisaac.planner.mppi import make_config
+    from mppiisaac.utils.config_store import load_config
+    ex = load_config({"defaults": [{"mppi": "panda"}]})
+    ex.mppi.num_samples, ex.mppi.horizon, ex.mppi.mppi_mode, ex.mppi.seed_val = 4096, 20, "simple", 3
+    ex.mppi.noise_mu = [0.01 * j for j in range(7)]
+    cfg = make_config(ex.mppi)
+    assert cfg.sampling == capi.SAMPLE_NORMAL and cfg.n_knots == 20
+    eps = oracle64.sample_normal(cfg, 5)
+    # knot (g, c, i) is word pair (i % 4) // 2 of philox(counter = (g, c, i // 4, iteration), key = (seed, "MPPI")) through Box-Muller
+    g, c, i = 77, 4, 13
+    x = oracle64.philox([g, c, i // 4, 5], [3, 0x4D505049])
+    ua, ub = (x[0] + 0.5) / 2 ** 32, (x[1] + 0.5) / 2 ** 32
+    z = math.sqrt(-2 * math.log(ua)) * math.sin(2 * math.pi * ub)   # i % 4 == 1: second value of the first pair
+    assert eps[i, c, g] == pytest.approx(0.01 * c + math.sqrt(0.1) * z, abs=1e-12)
+    # N(mu, sigma) per control dimension, independent over the horizon, and a different set every iteration
+    z = (eps - np.array(ex.mppi.noise_mu)[None, :, None]) / math.sqrt(0.1)
+    assert abs(z.mean()) < 5e-3 and z.std() == pytest.approx(1.0, rel=5e-3)
+    assert abs(np.corrcoef(z[3, 2], z[4, 2])[0, 1]) < 0.05
+    from scipy.stats import kstest
+    assert kstest(z[:, 0, :].ravel(), "norm").pvalue > 1e-3
+    assert np.abs(oracle64.sample_normal(cfg, 6) - eps).max() > 1.0
+    np.testing.assert_array_equal(oracle64.sample_normal(cfg, 5), eps)
+    # shards draw by GLOBAL sample id
+    shard = make_config(ex.mppi, k_offset=1024, k_local=512)
+    np.testing.assert_array_equal(oracle64.sample_normal(shard, 5), eps[:, :, 1024:1536])
+    # halton-spline + random: Gaussian knots through the same B-spline as the Halton knots
+    ex.mppi.mppi_mode, ex.mppi.sampling_method = "halton-spline", "random"
+    cs = make_config(ex.mppi)
+    assert cs.sampling == capi.SAMPLE_NORMAL and cs.n_knots == 5
+    es = oracle64.sample_normal(cs, 0)
+    assert ((es[0] - np.array(ex.mppi.noise_mu)[:, None]) / math.sqrt(0.1)).std() == pytest.approx(1.0, rel=0.03)  # clamped ends = one knot

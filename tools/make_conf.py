@@ -24,3 +24,17 @@ for fname, fields in gold.items():
         f.write(f"# actor '{fname}': restated from the reference's conf/actors/{fname}.yaml (non-default ActorWrapper fields)\n")
         yaml.safe_dump(keep, f, default_flow_style=None, sort_keys=False, width=120)
 print("wrote", len(gold), "actor files")
+
+# ---- MPPI parameter files: conf/mppi/<name>.yaml from tests/golden/mppi_cfgs.json (values of the reference's files)
+mg = json.load(open(os.path.join(ROOT, "tests", "golden", "mppi_cfgs.json")))
+mout = os.path.join(ROOT, "mppi-isaac_amd", "conf", "mppi")
+os.makedirs(mout, exist_ok=True)
+for name, vals in mg.items():
+    note = ""
+    if vals.get("mppi_mode", "halton-spline") == "halton-spline" and int(vals.get("horizon", 30)) < 12:
+        note = "; horizon < 12: fewer than 3 spline knots, every step is sampled directly"
+    with open(os.path.join(mout, name + ".yaml"), "w") as f:
+        f.write(f"# MPPI parameters '{name}' (values: reference conf/mppi/{name}.yaml{note})\n")
+        f.write("defaults: [base_mppi]\n")
+        yaml.safe_dump(vals, f, default_flow_style=None, sort_keys=True, width=120)
+print("wrote", len(mg), "mppi files")

@@ -125,6 +125,16 @@ b = torch_to_bytes(t)
 dump("transport.json", {"tensor": t.tolist(), "nbytes": len(b), "magic": list(b[:4]),
                         "roundtrip": bytes_to_torch(b).tolist()})
 
+# 6b. MPPI parameter files: the VALUES of every reference conf/mppi/*.yaml (data; tools/make_conf.py restates them)
+import glob as _glob
+import yaml as _yaml
+mppi_cfgs = {}
+for path in sorted(_glob.glob(os.path.join(REF, "conf", "mppi", "*.yaml"))):
+    raw = _yaml.safe_load(open(path))
+    raw.pop("defaults", None)
+    mppi_cfgs[os.path.splitext(os.path.basename(path))[0]] = raw
+dump("mppi_cfgs.json", mppi_cfgs)
+
 # 7. Objective.compute_cost of the reference's example planners on seeded random simulator states.
 #    hydra / zerorpc / mppi_torch are mocked (absent, unused by compute_cost).  pytorch3d is absent too: the two
 #    functions the panda objectives call are served by scipy.spatial.transform (an independent implementation of
@@ -178,18 +188,34 @@ class RecordingSim:
     def get_actor_contact_forces_by_name(self, actor_name, link_name):
         # contact is sparse: zero rows in half of the samples
         return self._answer(f"contact:{actor_name}:{link_name}", lambda: self._rand(3) * (self._rand(1) > 0))
+    def get_dof_state(self):
+        # interleaved (q, qdot) of a 12-DOF robot (omnipanda: 3 base + 7 arm + 2 fingers)
+        return self._answer("dof_state", lambda: self._rand(24))
 
 obj_cases = {}
-for case, rel, stand_ins in (("panda", "examples/panda/planner.py", ["pytorch3d.transforms -> scipy"]),
+class _Cfg:  # the one thing an example Objective reads from its config (omni_panda_pick: cfg.mppi.device)
+    class mppi:
+        device = "cpu"
+
+P3D = ["pytorch3d.transforms -> scipy"]
+for case, rel, stand_ins in (("panda", "examples/panda/planner.py", P3D),
                              ("boxer_push", "examples/boxer_push/planner.py", []),
-                             ("panda_pick", "examples/panda_pick/planner.py", ["pytorch3d.transforms -> scipy"])):
+                             ("panda_pick", "examples/panda_pick/planner.py", P3D),
+                             ("boxer_reach", "examples/boxer_reach/planner.py", []),
+                             ("heijn_reach", "examples/heijn_reach/planner.py", []),
+                             ("heijn_push", "examples/heijn_push/planner.py", []),
+                             ("albert", "examples/albert/planner.py", P3D),
+                             ("omni_panda_pick", "examples/omni_panda_pick/planner.py", P3D),
+                             ("panda_effort", "examples/panda_effort/planner.py", P3D),
+                             ("panda_stick_push", "examples/panda_stick_push/planner.py", P3D),
+                             ("anymal", "examples/anymal/planner.py", [])):
     spec = importlib.util.spec_from_file_location(f"ref_example_{case}", os.path.join(REF, rel))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    obj = mod.Objective(None)
+    obj = mod.Objective(_Cfg)
     sim = RecordingSim(K=24, seed=11 + len(obj_cases))
     cost = obj.compute_cost(sim)
-    obj_cases[case] = {"source": rel, "stand_ins": stand_ins, "weights": {k: float(v) for k, v in obj.weights.items()},
+    obj_cases[case] = {"source": rel, "stand_ins": stand_ins, "weights": {k: float(v) for k, v in getattr(obj, "weights", {}).items()},
                        "goal_yaw": float(getattr(obj, "goal_yaw", 0.0)),
                        "inputs": {k: v.tolist() for k, v in sim.calls.items()}, "cost": cost.tolist()}
 dump("objective_costs.json", obj_cases)

@@ -17,7 +17,8 @@ def short(n):
     n = n.replace("(anonymous namespace)::", "").replace("void ", "")
     return n.split("<")[0].split("(")[0]
 out = collections.defaultdict(dict)
-workload = json.load(open(os.path.join(src, "trace_bench.json")))["config"]["workload"].split(" ")[0]
+_bench = json.load(open(os.path.join(src, "trace_bench.json")))
+workload = _bench["config"]["workload"].split(" ")[0]
 if not glob.glob(os.path.join(src, "pmc_fetch", "*", "*_counter_collection.csv")):  # STATS_ONLY run
     print(open(os.path.join(dst, f"{tag}_kernel_stats.csv")).read()[:1500])
     sys.exit(0)
@@ -38,7 +39,7 @@ latest_path = os.path.join(dst, "pmc_latest.json")
 latest = json.load(open(latest_path)) if os.path.exists(latest_path) else {}
 if "by_workload" not in latest:
     latest = {"by_workload": {}}
-latest["by_workload"][workload] = {"tag": tag, "k_rollout": main}   # bench.py reads the entry of ITS workload only
+latest["by_workload"][workload] = {"tag": tag, "K": _bench["config"].get("K_per_gpu"), "k_rollout": main}   # bench.py reads the entry of ITS workload only
 json.dump(latest, open(latest_path, "w"), indent=1, sort_keys=True)
 print(open(os.path.join(dst, f"{tag}_kernel_stats.csv")).read()[:1200])
 print(json.dumps(main, indent=1))
