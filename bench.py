@@ -136,6 +136,7 @@ class Loop:
                 for c in (self.P, self.W):
                     capi.check(lib, lib.mppi_set_stream(c, cs))
                 self.enqueue()
+            capi.check(lib, lib.mppi_note_graph_update(self.P, -1))  # (the update launched under capture was recorded, not run)
             self.graph = g
         except Exception as e:  # noqa: BLE001 - any refusal (RCCL capture unsupported, sync inside) keeps the eager loop
             print(f"[bench] graph capture refused: {type(e).__name__}: {e}", file=sys.stderr)
@@ -150,7 +151,7 @@ class Loop:
         lib, P, capi = self.lib, self.P, self.capi
         if self.graph is not None:
             self.graph.replay()
-            capi.check(lib, lib.mppi_note_graph_update(P))
+            capi.check(lib, lib.mppi_note_graph_update(P, 1))
         else:
             self.enqueue()
         if self.sync:

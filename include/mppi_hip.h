@@ -256,9 +256,10 @@ int mppi_get_action(mppi_ctx_t *ctx, float *action_host);     /* [nu]; synchroni
  * behind it on the stream.  Same role as the `.cpu()` of the action in mppi_isaac.py:84. */
 int mppi_wait_action(mppi_ctx_t *ctx, float *action_host);
 int mppi_action_dev(mppi_ctx_t *ctx, float **action_dev);
-/* one update (mppi_update / mppi_update_step_world) was enqueued OUTSIDE this API - the replay of a HIP graph the launches
- * were captured into: advances the sequence number mppi_wait_action waits for */
-int mppi_note_graph_update(mppi_ctx_t *ctx);
+/* n updates (mppi_update / mppi_update_step_world) ran on the device WITHOUT a call of this API - replays of a HIP graph
+ * the launches were captured into (n = +1 per replay) - or were recorded by this API but never ran - the launches made
+ * while the stream was being captured (n = -1 each): keeps the sequence number mppi_wait_action waits for in step */
+int mppi_note_graph_update(mppi_ctx_t *ctx, int n);
 int mppi_command(mppi_ctx_t *ctx, float *action_host);        /* rollout+reduce+update+get_action     */
 int mppi_get_costs(mppi_ctx_t *ctx, float *S_host);           /* [K] total trajectory costs           */
 int mppi_get_weights_stats(mppi_ctx_t *ctx, float *beta_eta_host); /* [2]                             */
@@ -286,6 +287,10 @@ int mppi_update_step_world(mppi_ctx_t *planner, const float *records_dev, int n_
 int mppi_set_profiling(mppi_ctx_t *ctx, int on);            /* hipEvent brackets on the context's stream: 0 off, n >= 1 every n-th launch */
 int mppi_kernel_ms(mppi_ctx_t *ctx, int which, float *ms); /* mean launch duration since profiling was enabled: 0 rollout 1 reduce 2 update */
 int mppi_kernel_info(mppi_ctx_t *ctx, char *buf, int buflen);
+/* per-wavefront residency of the quad rollout kernels: start / end of every wavefront of the LAST rollout in ticks of the
+ * 100 MHz constant clock (s_memrealtime), [n_wavefronts][2] - load-balance evidence (tools/exp/wave_balance.py) */
+int mppi_set_wave_clock(mppi_ctx_t *ctx, int on);
+int mppi_get_wave_clock(mppi_ctx_t *ctx, uint64_t *start_end_host, int n_wavefronts);
 
 #ifdef __cplusplus
 }

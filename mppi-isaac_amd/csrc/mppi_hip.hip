@@ -140,7 +140,7 @@ void release_ctx(mppi_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *bufs[] = {c->d_model, c->d_cfg, c->d_cost, c->d_x0_dof, c->d_x0_root, c->d_U, c->d_eps, c->d_du, c->d_S, c->d_prior, c->d_viz,
                     c->d_partials, c->d_record, c->d_action, c->d_beta_eta, c->d_q, c->d_qd, c->d_ctrl, c->d_basis, c->d_sigma, c->d_base, c->d_fr, c->d_cf, c->d_filter,
-                    c->d_seq, c->d_fold, c->d_fold_ctr};
+                    c->d_seq, c->d_fold, c->d_fold_ctr, c->d_wave_clk};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->h_action) (void)hipHostFree(c->h_action);
@@ -244,9 +244,12 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
         delete c;
         return fail(MPPI_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
     }
-    {   // wave records folded per XCD group inside the quad rollout kernels (MPPI_FOLD=0: A/B switch, one record per wavefront)
+    {   // MPPI_FOLD=1: fold the wave records per XCD group inside the quad rollout kernels (fold_group).  Measured on MI355X
+        // (profiles/r02a_*): the agent-scope release every workgroup needs before its ticket costs the rollout +8 us, the
+        // combine kernel gets 3 us faster - a net loss of 2.6 % on the 0.17-ms panda iteration, also in the sharded loop -
+        // so the fold is an opt-in experiment and the default keeps one record per wavefront.
         const char *f = std::getenv("MPPI_FOLD");
-        c->fold = c->quad && !(f && std::string(f) == "0");
+        c->fold = c->quad && f && std::string(f) == "1";
     }
     const int rc = create_buffers(c, cfg);
     if (rc != MPPI_OK) {  // (the error text is already set) nothing allocated so far may leak
@@ -418,9 +421,9 @@ int mppi_set_record_out(mppi_ctx_t *c, float *records_dev) {
     c->fold_out = records_dev ? records_dev : c->d_fold;
     return MPPI_OK;
 }
-int mppi_note_graph_update(mppi_ctx_t *c) {
+int mppi_note_graph_update(mppi_ctx_t *c, int n) {
     CTX_TRY(c);
-    c->seq_expected++;
+    c->seq_expected += (unsigned)n;
     return MPPI_OK;
 }
 int mppi_record_floats(const mppi_ctx_t *c) { return check_ctx(c) == MPPI_OK ? c->RF : 0; }
@@ -580,6 +583,21 @@ int mppi_set_state_from_world(mppi_ctx_t *planner, mppi_ctx_t *world) {
     return launch_check();
 }
 
+int mppi_set_wave_clock(mppi_ctx_t *c, int on) {
+    CTX_TRY(c);
+    if (on && !c->d_wave_clk) ALLOC_TRY(c->d_wave_clk, sizeof(unsigned long long) * 2 * (size_t)(c->n_quads > c->n_waves ? c->n_quads : c->n_waves));
+    c->wave_clk_on = on != 0;
+    return MPPI_OK;
+}
+int mppi_get_wave_clock(mppi_ctx_t *c, uint64_t *start_end_host, int n_wavefronts) {
+    CTX_TRY(c);
+    if (!c->d_wave_clk || !start_end_host) return fail(MPPI_ESTATE, "mppi_get_wave_clock: not enabled (mppi_set_wave_clock)");
+    const int n = c->quad ? c->n_quads : c->n_waves;
+    if (n_wavefronts != n) return fail(MPPI_EINVAL, "mppi_get_wave_clock: the rollout kernel runs " + std::to_string(n) + " wavefronts");
+    HIP_TRY(hipMemcpyAsync(start_end_host, c->d_wave_clk, sizeof(unsigned long long) * 2 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MPPI_OK;
+}
 int mppi_set_profiling(mppi_ctx_t *c, int on) {
     CTX_TRY(c);
     c->profiling = on != 0;

@@ -247,8 +247,10 @@ __global__ __launch_bounds__(kWave) void k_rollout_quad(const DevModel *__restri
                                                         const float *__restrict__ x0_root, const float *__restrict__ U,
                                                         const float *__restrict__ eps, const float *__restrict__ prior,
                                                         float *__restrict__ du, float *__restrict__ S, float *__restrict__ viz,
-                                                        float *__restrict__ partials, unsigned *__restrict__ fold_ctr, float *__restrict__ fold_out) {
+                                                        float *__restrict__ partials, unsigned *__restrict__ fold_ctr, float *__restrict__ fold_out,
+                                                        unsigned long long *__restrict__ wave_clk) {
 #if defined(__HIP_DEVICE_COMPILE__)  // (the host pass sees the 4-float emulation type of mppi_quad.hpp)
+    const unsigned long long clk0 = wave_clk != nullptr ? wall_clock64() : 0ull;
     // Stage the robot model (header + body + link blocks, ~4 KB) in LDS once per wavefront: constants are then
     // fetched with in-order ds_read_b128 broadcasts into VGPRs - no SMEM round trip (s_waitcnt lgkmcnt(0) on
     // every block), no SGPR spills, no constant-bus moves.
@@ -283,6 +285,10 @@ __global__ __launch_bounds__(kWave) void k_rollout_quad(const DevModel *__restri
     }
     quad_record(*(CCfg *)cfg, s, live && leader, du, chunk * 16, partials + (size_t)chunk * (2 + cfg->H * cfg->nu));
     fold_after_record(*(CCfg *)cfg, partials, fold_ctr, fold_out);
+    if (wave_clk != nullptr && threadIdx.x == 0) {  // instrumentation (mppi_set_wave_clock): this wavefront's residency
+        wave_clk[2 * chunk] = clk0;
+        wave_clk[2 * chunk + 1] = wall_clock64();
+    }
 #endif
 }
 
@@ -557,8 +563,10 @@ __global__ __launch_bounds__(kWave) void k_rollout_scene_quad(const DevModel *__
                                                               const float *__restrict__ x0_root, const float *__restrict__ U,
                                                               const float *__restrict__ eps, const float *__restrict__ prior,
                                                               float *__restrict__ du, float *__restrict__ S, float *__restrict__ viz,
-                                                              float *__restrict__ partials, unsigned *__restrict__ fold_ctr, float *__restrict__ fold_out) {
+                                                              float *__restrict__ partials, unsigned *__restrict__ fold_ctr, float *__restrict__ fold_out,
+                                                              unsigned long long *__restrict__ wave_clk) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long clk0 = wave_clk != nullptr ? wall_clock64() : 0ull;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // The robot part of the model (header, bodies, links: 4.3 KB) is staged in LDS for the quad-layout kinematics and
     // articulated-body solve; shapes, pairs and free bodies stay behind the scalar cache (staging the WHOLE model was
@@ -581,6 +589,10 @@ __global__ __launch_bounds__(kWave) void k_rollout_scene_quad(const DevModel *__
     }
     quad_record(*(CCfg *)cfg, s, live && lane4 == 0, du, chunk * 16, partials + (size_t)chunk * (2 + cfg->H * cfg->nu));
     fold_after_record(*(CCfg *)cfg, partials, fold_ctr, fold_out);
+    if (wave_clk != nullptr && threadIdx.x == 0) {  // instrumentation (mppi_set_wave_clock): this wavefront's residency
+        wave_clk[2 * chunk] = clk0;
+        wave_clk[2 * chunk + 1] = wall_clock64();
+    }
 #endif
 }
 
@@ -1082,6 +1094,8 @@ struct mppi_ctx {
     unsigned *d_fold_ctr = nullptr;
     float *d_fold = nullptr, *fold_out = nullptr;
     const float *recs_cur = nullptr;  // records the next combine reads when the caller passes none
+    unsigned long long *d_wave_clk = nullptr;  // instrumentation: [wavefront][start, end] of the last quad rollout
+    bool wave_clk_on = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[3];
     size_t ev_used[3] = {0, 0, 0}, ev_seen[3] = {0, 0, 0};
     int profile_period = 1;  // hipEvent brackets on every n-th launch
@@ -1125,7 +1139,7 @@ template <class T>
 void launch_rollout_scene_quad_t(mppi_ctx *c) {
     hipLaunchKernelGGL(k_rollout_scene_quad<T>, dim3(c->n_quads), dim3(kWave), c->lds_bytes_quad, c->stream, c->d_model, c->d_cfg, c->d_cost, c->d_x0_dof,
                        c->d_x0_root, c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_S, c->cfg.want_rollouts ? c->d_viz : nullptr,
-                       c->d_partials, c->fold ? c->d_fold_ctr : nullptr, c->fold_out);
+                       c->d_partials, c->fold ? c->d_fold_ctr : nullptr, c->fold_out, c->wave_clk_on ? c->d_wave_clk : nullptr);
 }
 template <class T>
 void launch_sim_step_scene_t(mppi_ctx *c, int mode, int t, const float *u_ext) {
@@ -1157,7 +1171,7 @@ template <class T>
 void launch_rollout_quad_t(mppi_ctx *c) {
     hipLaunchKernelGGL(k_rollout_quad<T>, dim3(c->n_quads), dim3(kWave), 0, c->stream, c->d_model, c->d_cfg, c->d_cost, c->d_x0_dof, c->d_x0_root,
                        c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_S, c->cfg.want_rollouts ? c->d_viz : nullptr, c->d_partials,
-                       c->fold ? c->d_fold_ctr : nullptr, c->fold_out);
+                       c->fold ? c->d_fold_ctr : nullptr, c->fold_out, c->wave_clk_on ? c->d_wave_clk : nullptr);
 }
 template <class T>
 void launch_combine_world_t(mppi_ctx *p, const float *recs, int n, mppi_ctx *w) {

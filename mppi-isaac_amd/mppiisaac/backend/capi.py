@@ -102,7 +102,7 @@ _SIGNATURES = {
     "mppi_record_floats": (C.c_int, [_vp]),
     "mppi_shard_record_count": (C.c_int, [_vp]),
     "mppi_set_record_out": (C.c_int, [_vp, _vp]),
-    "mppi_note_graph_update": (C.c_int, [_vp]),
+    "mppi_note_graph_update": (C.c_int, [_vp, C.c_int]),
     "mppi_record_dev": (C.c_int, [_vp, C.POINTER(_vp)]),
     "mppi_update": (C.c_int, [_vp, _vp, C.c_int]),
     "mppi_get_action": (C.c_int, [_vp, _fp]),
@@ -126,6 +126,8 @@ _SIGNATURES = {
     "mppi_set_profiling": (C.c_int, [_vp, C.c_int]),
     "mppi_kernel_ms": (C.c_int, [_vp, C.c_int, _fp]),
     "mppi_kernel_info": (C.c_int, [_vp, C.c_char_p, C.c_int]),
+    "mppi_set_wave_clock": (C.c_int, [_vp, C.c_int]),
+    "mppi_get_wave_clock": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.c_int]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

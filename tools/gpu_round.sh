@@ -10,7 +10,7 @@ mkdir -p $OUT
 cd $REPO
 B="python bench.py --no-cpu-baseline"
 if [[ $WHAT == *tests* ]]; then
-  timeout 1200 python -m pytest tests -m gpu -x -q > $OUT/gpu_tests.log 2>&1; echo "pytest rc=$?" >> $OUT/gpu_tests.log
+  timeout 1200 python -m pytest tests -m gpu -q > $OUT/gpu_tests.log 2>&1; echo "pytest rc=$?" >> $OUT/gpu_tests.log
   tail -5 $OUT/gpu_tests.log
 fi
 if [[ $WHAT == *bench* ]]; then
@@ -20,12 +20,12 @@ if [[ $WHAT == *bench* ]]; then
   timeout 600 $B --workload panda_pick --k-total 65536 --steps 40 --warmup 5 > $OUT/bench_panda_pick_65536.json 2>> $OUT/bench.err
 fi
 if [[ $WHAT == *ab* ]]; then
-  MPPI_FOLD=0 timeout 300 $B --steps 2000 --warmup 200 > $OUT/ab_nofold.json 2>> $OUT/ab.err
+  MPPI_FOLD=1 timeout 300 $B --steps 2000 --warmup 200 > $OUT/ab_fold.json 2>> $OUT/ab.err
   MPPI_BENCH_FORCE_DIST=1 timeout 300 $B --steps 2000 --warmup 200 > $OUT/ab_dist_graph.json 2>> $OUT/ab.err
   MPPI_BENCH_FORCE_DIST=1 MPPI_BENCH_GRAPH=0 timeout 300 $B --steps 2000 --warmup 200 > $OUT/ab_dist_eager.json 2>> $OUT/ab.err
-  MPPI_BENCH_FORCE_DIST=1 MPPI_FOLD=0 MPPI_BENCH_GRAPH=0 timeout 300 $B --steps 2000 --warmup 200 > $OUT/ab_dist_eager_nofold.json 2>> $OUT/ab.err
+  MPPI_BENCH_FORCE_DIST=1 MPPI_FOLD=1 timeout 300 $B --steps 2000 --warmup 200 > $OUT/ab_dist_graph_fold.json 2>> $OUT/ab.err
   MPPI_BENCH_FORCE_DIST=1 timeout 300 $B --workload panda_pick > $OUT/ab_dist_graph_pick.json 2>> $OUT/ab.err
-  MPPI_FOLD=0 timeout 300 $B --workload panda_pick > $OUT/ab_nofold_pick.json 2>> $OUT/ab.err
+  MPPI_FOLD=1 timeout 300 $B --workload panda_pick > $OUT/ab_fold_pick.json 2>> $OUT/ab.err
 fi
 if [[ $WHAT == *prof* ]]; then
   WORKLOAD=panda_reach STEPS=300 bash tools/profile_bench.sh ${TAG} > $OUT/prof_reach.log 2>&1
