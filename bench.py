@@ -230,75 +230,53 @@ def time_sampler(loop, n=20):
 
 
 def cpu_baseline(loop, budget_s=24.0):
-    """CPU rows beside the GPU number, on this box's host cores, bounded to ~budget_s of CPU work:
-      rows[0], rows[1]  the REFERENCE-STRUCTURED pipeline (oracle/cpu_pipeline.py: Python horizon loop -> batched C env
-                        step -> torch-CPU Objective.compute_cost, reference mppi_isaac.py:57-69) with 1 thread and with
-                        all host threads, on the bench workload;
+    """CPU rows beside the GPU number, on this box's host cores, bounded to ~budget_s of CPU work.  Every row runs in its own
+    process (oracle/cpu_pipeline.py) so that thread counts and the OpenMP wait policy are fixed before any runtime starts:
+      rows[0], rows[1]  the REFERENCE-STRUCTURED pipeline (Python horizon loop -> batched C env step -> torch-CPU
+                        Objective.compute_cost, reference mppi_isaac.py:57-69) with 1 thread and with all host threads
+                        (OMP_NUM_THREADS = torch threads = os.cpu_count(), SURVEY 8d), on the bench workload and ITS noise;
       rows[2]           the same pipeline on BASELINE configs[0] (point_robot K=64 H=10, the reference's CPU-runnable case);
       rows[3]           the oracle's fused C loop (oracle/mppi_oracle.c, OpenMP over samples): faster than the reference
                         structure, kept as the conservative comparison.
-    `value` = rows[1] (all threads, reference structure, same K x H workload)."""
-    import torch
-    from oracle.cpu_pipeline import CpuPipeline
-    from oracle.oracle import Oracle
-    import mppiisaac.objectives as objectives
-    from mppiisaac.planner.isaacgym_wrapper import IsaacGymWrapper
-    from mppiisaac.planner.mppi import make_config
-    sim = loop.planner.sim
-    capi = loop.capi
+    A row may time the first `samples_timed` samples of the set and scale to K (per-sample work is independent, time is
+    linear in K): contact scenes at K=8192 would take minutes on one thread.  `value` = rows[1]."""
+    import subprocess
+    import tempfile
+    sim, capi = loop.planner.sim, loop.capi
     cores = os.cpu_count() or 1
     K, H, nu = loop.K, loop.H, loop.nu
     eps = np.zeros((H, nu, K), np.float32)
     capi.check(sim._lib, sim._lib.mppi_get_noise(sim._ctx, capi.fptr(eps)))
-    eps_t = torch.from_numpy(eps)
+    tmp = tempfile.mkdtemp(prefix="mppi_cpu_")
+    np.save(os.path.join(tmp, "eps.npy"), eps)
+    np.savez(os.path.join(tmp, "state.npz"), dof0=loop.dof0, root0=loop.root0)
     unit = f"Hz (K={K},H={H} control iterations/s)"
-    rows = []
-    # bounded sample: a row times the first K_cpu samples of the same sample set (contact scenes at K=8192 would take minutes
-    # on one thread) and reports the rate scaled to the full K (per-sample work is independent: time is linear in K)
+    k_total = K * loop.env["world_size"]
+
+    def row(label, threads, mode, k_local, budget, workload=loop.name, kt=k_total, horizon=H, own_inputs=True, max_iters=10):
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), OMP_WAIT_POLICY="PASSIVE", GOMP_SPINCOUNT="0",
+                   OMP_PROC_BIND="false")
+        cmd = [sys.executable, "-m", "oracle.cpu_pipeline", "--workload", workload, "--k-total", str(kt), "--k-local", str(k_local),
+               "--horizon", str(horizon), "--threads", str(threads), "--budget", str(budget), "--mode", mode, "--max-iters", str(max_iters)]
+        if own_inputs:
+            cmd += ["--eps", os.path.join(tmp, "eps.npy"), "--state", os.path.join(tmp, "state.npz")]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+        if out.returncode != 0:
+            raise RuntimeError(f"cpu baseline row failed: {out.stderr[-1500:]}")
+        r = json.loads(out.stdout.strip().splitlines()[-1])
+        dt = r["seconds_per_iteration"] * (kt // loop.env["world_size"] if workload == loop.name else kt) / k_local
+        return {"pipeline": label, "threads": threads, "value": 1.0 / dt, "unit": unit if workload == loop.name else f"Hz (K={kt},H={horizon} control iterations/s)",
+                "ms_per_iteration": dt * 1e3, "iterations": r["iterations"], "samples_timed": k_local, "torch_threads": r["torch_threads"]}
+
     per_sample_cost = H * (30 if loop.name in ("boxer_push", "panda_pick") else 1)
-    for threads, share, kmax in ((1, 0.35, max(256, 65536 // per_sample_cost)), (cores, 0.25, max(2048, 2 ** 21 // per_sample_cost))):
-        k_cpu = min(K, kmax)
-        c_cfg = make_config(loop.cfg.mppi, k_offset=loop.env["rank"] * K, k_local=k_cpu, viz_link=sim.scene.viz_link_index())
-        p = CpuPipeline(sim.scene, sim._c_model, c_cfg, loop.objective, threads)
-        dt, n = p.time_iterations(loop.dof0, loop.root0, eps_t[:, :, :k_cpu].contiguous(), budget_s * share, max_iters=10)
-        dt *= K / k_cpu
-        rows.append({"pipeline": "reference-structured (python horizon loop -> batched C step -> torch-CPU Objective)", "threads": threads,
-                     "value": 1.0 / dt, "unit": unit, "ms_per_iteration": dt * 1e3, "iterations": n,
-                     "samples_timed": k_cpu, "scaled_to_K": K})
-    # BASELINE configs[0]: point_robot K=64 H=10 (reference benchmarks/point_robot/setup/exp.yaml:21-22,32-39)
-    w0 = WORKLOADS["point_reach"]
-    cfg0 = make_cfg(w0, 64, 10)
-    from mppiisaac.utils.isaacgym_utils import load_actor_cfgs, load_asset
-    from mppiisaac.planner.isaacgym_wrapper import Scene
-    env0 = load_actor_cfgs(w0["actors"])
-    robots = [a for a in env0 if a.type == "robot"]
-    robots[0].init_pos = list(w0["init"][0])
-    sc0 = Scene(env0, cfg0.isaacgym, load_asset(robots[0]))
-    c0 = make_config(cfg0.mppi, viz_link=sc0.viz_link_index())
-    dof, root = sc0.initial_state()
-    dof[0::2] = w0["q0"]
-    root[sc0.actor_index("goal"), 0:3] = w0["goal"]
-    o32 = Oracle("f32")
-    p0 = CpuPipeline(sc0, sc0.to_c(), c0, objectives.PointReachObjective(cfg0), 1)
-    dt, n = p0.time_iterations(dof, root, torch.from_numpy(o32.sample(c0)), budget_s * 0.1, max_iters=200)
-    rows.append({"pipeline": "reference-structured, BASELINE configs[0] point_robot K=64 H=10", "threads": 1, "value": 1.0 / dt,
-                 "unit": "Hz (K=64,H=10 control iterations/s)", "ms_per_iteration": dt * 1e3, "iterations": n})
-    # fused C loop, all threads
-    o32.lib.orc_set_threads(ctypes.c_int(cores))
-    U = np.zeros((H, nu), np.float32)
-    cost = loop.objective.fused_spec(sim)
-    t0 = time.perf_counter()
-    U, a, S = o32.command(sim._c_model, sim._mppi_config, cost, loop.dof0, loop.root0, U, eps)
-    first = time.perf_counter() - t0
-    n = max(1, min(20, int(budget_s * 0.25 / max(first, 1e-3)) - 1))
-    t0 = time.perf_counter()
-    for _ in range(n):
-        U, a, S = o32.command(sim._c_model, sim._mppi_config, cost, loop.dof0, loop.root0, U, eps)
-    dt = (time.perf_counter() - t0) / n
-    rows.append({"pipeline": "oracle fused C loop (oracle/mppi_oracle.c, OpenMP over samples)", "threads": cores, "value": 1.0 / dt,
-                 "unit": unit, "ms_per_iteration": dt * 1e3, "iterations": n})
+    k1, kn = min(K, max(256, 65536 // per_sample_cost)), min(K, max(2048, 2 ** 21 // per_sample_cost))
+    ref = "reference-structured (python horizon loop -> batched C step -> torch-CPU Objective)"
+    rows = [row(ref, 1, "pipeline", k1, budget_s * 0.35), row(ref, cores, "pipeline", kn, budget_s * 0.25),
+            row(ref + ", BASELINE configs[0] point_robot K=64 H=10", 1, "pipeline", 64, budget_s * 0.1, workload="point_reach", kt=64, horizon=10,
+                own_inputs=False, max_iters=200),
+            row("oracle fused C loop (oracle/mppi_oracle.c, OpenMP over samples)", cores, "fused", kn, budget_s * 0.25, max_iters=20)]
     return {"value": rows[1]["value"], "unit": unit, "cores": cores, "kind": "port",
-            "sample": f"{rows[1]['iterations']} open-loop control iterations of the same K={K} x H={H} workload through the "
+            "sample": f"{rows[1]['iterations']} open-loop control iterations of the same K={K} x H={H} workload (same noise set) through the "
                       f"reference-structured CPU pipeline (oracle/cpu_pipeline.py, fp32) on {cores} host threads "
                       f"({rows[1]['ms_per_iteration']:.1f} ms/iteration); rows: 1 thread, all threads, configs[0], fused C loop",
             "rows": rows}

@@ -101,3 +101,80 @@ class CpuPipeline:
         for _ in range(n):
             U, a, S = self.command(dof0, root0, U, eps)
         return (time.perf_counter() - t0) / n, n
+
+
+def _main():
+    """one timed row in a clean process (bench.py's cpu_baseline leg): thread counts and the OpenMP wait policy are fixed by
+    the environment BEFORE any runtime starts; prints one JSON object"""
+    import argparse
+    import json
+    import os
+    import sys
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", required=True)
+    ap.add_argument("--k-total", type=int, required=True)
+    ap.add_argument("--k-offset", type=int, default=0)
+    ap.add_argument("--k-local", type=int, required=True)
+    ap.add_argument("--horizon", type=int, required=True)
+    ap.add_argument("--threads", type=int, required=True)
+    ap.add_argument("--budget", type=float, default=6.0)
+    ap.add_argument("--max-iters", type=int, default=10)
+    ap.add_argument("--mode", choices=("pipeline", "fused"), default="pipeline")
+    ap.add_argument("--eps", default="", help=".npy with the GPU run's noise [H, nu, K_local] (default: the oracle's sampler)")
+    ap.add_argument("--state", default="", help=".npz with dof0 / root0 (default: the scene's initial state + the workload's q0 / goal)")
+    a = ap.parse_args()
+    root_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root_dir)
+    import bench
+    import mppiisaac.objectives as objectives
+    from mppiisaac.planner.isaacgym_wrapper import Scene
+    from mppiisaac.planner.mppi import make_config
+    from mppiisaac.utils.isaacgym_utils import load_actor_cfgs, load_asset
+    wl = bench.WORKLOADS[a.workload]
+    cfg = bench.make_cfg(wl, a.k_total, a.horizon)
+    env_cfg = load_actor_cfgs(wl["actors"])
+    robots = [x for x in env_cfg if x.type == "robot"]
+    robots[0].init_pos = list(wl["init"][0])
+    scene = Scene(env_cfg, cfg.isaacgym, load_asset(robots[0]))
+    scene.randomize_seed = 0 if a.k_total > 1 else -1      # as the planner's K rollout envs (IsaacGymWrapper.__init__)
+    c_cfg = make_config(cfg.mppi, k_offset=a.k_offset, k_local=a.k_local, viz_link=scene.viz_link_index())
+    if a.state:
+        z = np.load(a.state)
+        dof, root = z["dof0"], z["root0"]
+    else:
+        dof, root = scene.initial_state()
+        if wl["q0"] is not None:
+            dof[0::2] = wl["q0"]
+        if wl["goal"] is not None:
+            root[scene.actor_index("goal"), 0:3] = wl["goal"]
+    o = Oracle("f32")
+    eps = np.load(a.eps) if a.eps else o.sample(c_cfg)
+    eps = np.ascontiguousarray(eps[:, :, :a.k_local], np.float32)
+    objective = getattr(objectives, wl["objective"])(cfg)
+    m = scene.to_c()
+    if a.mode == "pipeline":
+        p = CpuPipeline(scene, m, c_cfg, objective, a.threads)
+        dt, n = p.time_iterations(dof, root, torch.from_numpy(eps), a.budget, max_iters=a.max_iters)
+    else:
+        o.lib.orc_set_threads(C.c_int(a.threads))
+
+        class _S:  # fused_spec only needs name -> index lookups
+            pass
+        s = _S()
+        s.scene = scene
+        cost = objective.fused_spec(s)
+        U = np.zeros((a.horizon, c_cfg.nu), np.float32)
+        t0 = time.perf_counter()
+        U, act, S = o.command(m, c_cfg, cost, dof, root, U, eps)
+        first = time.perf_counter() - t0
+        n = max(1, min(a.max_iters, int(a.budget / max(first, 1e-3)) - 1))
+        t0 = time.perf_counter()
+        for _ in range(n):
+            U, act, S = o.command(m, c_cfg, cost, dof, root, U, eps)
+        dt = (time.perf_counter() - t0) / n
+    print(json.dumps({"threads": a.threads, "seconds_per_iteration": dt, "iterations": n, "samples_timed": a.k_local,
+                      "omp_max_threads": int(o.lib.orc_get_max_threads()), "torch_threads": torch.get_num_threads()}))
+
+
+if __name__ == "__main__":
+    _main()
