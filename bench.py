@@ -311,11 +311,12 @@ def roofline(loop, kms, hbm_measured, n_waves):
                      "source": f"profiles/{sq.get('tag')}_sq_summary.json (rocprofv3 --pmc SQ_* passes of this command; kernel_ms live)"}
     lane = os.environ.get("MPPI_ROLLOUT") == "lane"
     scene = loop.name in ("boxer_push", "panda_pick")
+    lps = 1 if lane else (4 if (not scene or os.environ.get("MPPI_ROLLOUT") == "quad") else 8)
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": traffic_src, "kernel": ("k_rollout_scene" if scene else "k_rollout") + ("" if lane else "_quad"),
-            "peak_measured": hbm_measured, "kernel_ms": kms, "bytes_alg_per_launch": bytes_alg, "wavefronts": n_waves,
+            "peak_measured": hbm_measured, "kernel_ms": kms, "bytes_alg_per_launch": bytes_alg, "wavefronts": n_waves, "lanes_per_sample": lps,
             "issue": issue,
-            "note": "instruction-issue-bound path (SURVEY 8d; DESIGN.md 5-6): one sample per 4-lane quad = K/16 wavefronts on 1024 SIMDs; "
+            "note": "instruction-issue-bound path (SURVEY 8d; DESIGN.md 5-6): one sample per 4-lane quad (contact scenes: 8-lane octet) = K/16 (K/8) wavefronts on 1024 SIMDs; "
                     "`issue` restates the kernel against the fp32 vector issue rate from the committed SQ counters; "
                     "peak_measured = device-to-device copy of 256 MiB (read + write bytes / time) on this GPU"}
 
@@ -408,8 +409,10 @@ def main():
         loop_hz = args.steps / elapsed
         K, H, nu = loop.K, loop.H, loop.nu
         lat = per_iter * 1e3
-        quad = os.environ.get("MPPI_ROLLOUT") != "lane"
-        n_waves = (K + 15) // 16 if quad else (K + 63) // 64
+        info = ctypes.create_string_buffer(256)
+        loop.capi.check(loop.lib, loop.lib.mppi_kernel_info(loop.P, info, 256))
+        info = dict(kv.split("=") for kv in info.value.decode().split())
+        n_waves = int(info["waves"])
         sampler_ms = time_sampler(loop) if loop.planner.sim._mppi_config.sampling == 0 else None
         out = {
             "metric": "MPPI control-loop Hz (K samples x H horizon), Panda 7-DoF K=4096 H=20" if (args.workload == "panda_reach" and K == 4096)

@@ -81,7 +81,10 @@ int check_ctx(const mppi_ctx *c) {
 int create_buffers(mppi_ctx *c, const mppi_config_t *cfg) {
     c->n = c->hm.nb; c->A = c->hm.n_actors; c->B = c->hm.n_rb; c->K = cfg->num_samples; c->H = cfg->horizon; c->nu = cfg->nu;
     c->HN = c->H * c->nu; c->RF = 2 + c->HN; c->n_waves = (c->K + kWave - 1) / kWave;
-    c->n_quads = (c->K + 15) / 16;
+    {
+        const int spw = c->lanes_per_sample == 8 ? 8 : 16;  // samples per wavefront of the rollout kernel that shares lanes
+        c->n_quads = (c->K + spw - 1) / spw;
+    }
     const size_t K = c->K;
     ALLOC_TRY(c->d_model, sizeof(DevModel));
     ALLOC_TRY(c->d_cfg, sizeof(DevCfg));
@@ -206,7 +209,11 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
             // rollouts: 4 lanes per sample (contact points dealt over the quad) unless MPPI_ROLLOUT=lane
             const char *mode = std::getenv("MPPI_ROLLOUT");
             c->quad = !(mode && std::string(mode) == "lane");
-            c->launch_rollout = c->quad ? e->rollout_scene_quad : e->rollout_scene;
+            // contact scenes: 8 lanes per sample (contact work dealt over an octet, K/8 wavefronts) unless MPPI_ROLLOUT=quad
+            // (4 lanes per sample, the round-1 kernel) or =lane; one-sample contexts (the K = 1 world) keep the quad
+            const bool oct = c->quad && !(mode && std::string(mode) == "quad") && cfg->num_samples >= 8;
+            c->lanes_per_sample = !c->quad ? 1 : (oct ? 8 : 4);
+            c->launch_rollout = c->quad ? (oct ? e->rollout_scene_oct : e->rollout_scene_quad) : e->rollout_scene;
             c->launch_sim_step = c->quad ? e->sim_step_scene_quad : e->sim_step_scene;  // (the K = 1 world included: one quad)
             c->launch_materialise = e->materialise_scene;
             if (hipSetDevice(device) == hipSuccess) lds_err = e->raise_lds(c->lds_bytes, c->lds_bytes_quad);
@@ -215,6 +222,7 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
             // one-lane-per-sample kernel (kept for A/B measurements and as the reference arithmetic)
             const char *mode = std::getenv("MPPI_ROLLOUT");
             c->quad = !(mode && std::string(mode) == "lane");
+            c->lanes_per_sample = c->quad ? 4 : 1;
             c->launch_rollout = c->quad ? e->rollout_quad : e->rollout;
             c->launch_combine_world = e->combine_world;
             // many envs: quad step kernel; the K = 1 world (and tiny K) keeps the one-lane kernel
@@ -624,7 +632,7 @@ int mppi_kernel_ms(mppi_ctx_t *c, int which, float *ms) {
 }
 int mppi_kernel_info(mppi_ctx_t *c, char *buf, int buflen) {
     CTX_TRY(c);
-    std::snprintf(buf, buflen, "topology=%s rollout=%s K=%d H=%d nu=%d waves=%d block=%d bytes_alg=%zu", c->topo.c_str(), c->scene ? (c->quad ? "scene-quad" : "scene") : (c->quad ? "quad" : "lane"), c->K, c->H, c->nu, c->quad ? c->n_quads : c->n_waves, kWave,
+    std::snprintf(buf, buflen, "topology=%s rollout=%s K=%d H=%d nu=%d waves=%d block=%d bytes_alg=%zu", c->topo.c_str(), c->scene ? (c->lanes_per_sample == 8 ? "scene-oct" : (c->quad ? "scene-quad" : "scene")) : (c->quad ? "quad" : "lane"), c->K, c->H, c->nu, c->quad ? c->n_quads : c->n_waves, kWave,
                   (size_t)4 * (3 * (size_t)c->K * c->HN + 2 * (size_t)c->K + c->HN));
     return MPPI_OK;
 }

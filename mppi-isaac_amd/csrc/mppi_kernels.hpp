@@ -95,18 +95,21 @@ __device__ __forceinline__ void wave_record(CCfg &cfg, float s, bool live, const
     }
 }
 
-// The same record for a wavefront of the quad kernels: 16 samples (chunk * 16 ...), sample s held by lanes 4s..4s+3.
-// Instead of a 64-lane butterfly per row (6 shuffle steps x H*nu rows), lane l sums rows l, l + 64, ... over the 16
-// samples itself: the weights are broadcast through LDS, the 16 du values of a row are one contiguous 64-byte read.
+// The same record for a wavefront of the kernels whose lanes share samples: SPW samples (chunk * SPW ...), sample s held
+// by lanes s*LPS .. s*LPS + LPS-1 (LPS = 64 / SPW lanes per sample: 4 - quad kernels - or 8).  Instead of a 64-lane
+// butterfly per row (6 shuffle steps x H*nu rows), lane l sums rows l, l + 64, ... over the SPW samples itself: the
+// weights are broadcast through LDS, the du values of a row are one contiguous 64- or 32-byte read.
+template <int SPW = 16>
 __device__ __forceinline__ void quad_record(CCfg &cfg, float s, bool live_leader, const float *__restrict__ du, int k0, float *__restrict__ rec) {
-    __shared__ float s_w[16];
+    constexpr int LPS = kWave / SPW;
+    __shared__ float s_w[SPW];
     const int K = cfg.K, HN = cfg.H * cfg.nu;
     const int lane = threadIdx.x & (kWave - 1);
     const bool fin = live_leader && isfinite(s);
     const float beta = wave_min(fin ? s : INFINITY);
     const float w = fin ? __expf(-(s - beta) * cfg.inv_lambda) : 0.f;
     const float eta = wave_sum(w);
-    if ((lane & 3) == 0) s_w[lane >> 2] = w;  // non-leader lanes carry w = 0 and are not stored
+    if ((lane & (LPS - 1)) == 0) s_w[lane / LPS] = w;  // non-leader lanes carry w = 0 and are not stored
     if (lane == 0) {
         rec[0] = beta;
         rec[1] = eta;
@@ -115,15 +118,16 @@ __device__ __forceinline__ void quad_record(CCfg &cfg, float s, bool live_leader
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    const int nlive = K - k0 < 16 ? K - k0 : 16;  // samples of this chunk that exist
+    const int nlive = K - k0 < SPW ? K - k0 : SPW;  // samples of this chunk that exist
     for (int j = lane; j < HN; j += kWave) {
         const float *row = du + (size_t)j * K + k0;
         float acc = 0.f;
-        if (nlive == 16 && (K & 3) == 0) {  // aligned full chunk: four 16-byte loads
-            const float4 a = reinterpret_cast<const float4 *>(row)[0], b = reinterpret_cast<const float4 *>(row)[1];
-            const float4 c = reinterpret_cast<const float4 *>(row)[2], d = reinterpret_cast<const float4 *>(row)[3];
-            acc = a.x * s_w[0] + a.y * s_w[1] + a.z * s_w[2] + a.w * s_w[3] + b.x * s_w[4] + b.y * s_w[5] + b.z * s_w[6] + b.w * s_w[7] +
-                  c.x * s_w[8] + c.y * s_w[9] + c.z * s_w[10] + c.w * s_w[11] + d.x * s_w[12] + d.y * s_w[13] + d.z * s_w[14] + d.w * s_w[15];
+        if (nlive == SPW && (K & 3) == 0) {  // aligned full chunk: 16-byte loads
+            float4 v[SPW / 4];
+#pragma unroll
+            for (int q = 0; q < SPW / 4; q++) v[q] = reinterpret_cast<const float4 *>(row)[q];
+#pragma unroll
+            for (int q = 0; q < SPW / 4; q++) acc += v[q].x * s_w[4 * q] + v[q].y * s_w[4 * q + 1] + v[q].z * s_w[4 * q + 2] + v[q].w * s_w[4 * q + 3];
         } else {
             for (int q = 0; q < nlive; q++) acc += row[q] * s_w[q];
         }
@@ -553,11 +557,12 @@ __global__ __launch_bounds__(kWave) void k_rollout_scene(const DevModel *__restr
     wave_record(*(CCfg *)cfg, s, live, du, k, partials + (size_t)blockIdx.x * (2 + cfg->H * cfg->nu));
 }
 
-// Contact scene, 4 lanes per sample: the quad replicates the sample's state arithmetic (idle lanes cost nothing -
-// at K=8192 one lane per sample is only 128 wavefronts on 1024 SIMDs) and deals the contact feature points of
-// every pair over its four lanes (mppi_scene.hpp: kSplitQuad).  The sample's LDS rows are shared by the quad:
-// element i of the wave's s-th sample lives at lds[i*16 + s] (16 banks per row, 4-lane broadcast reads).
-template <class T>
+// Contact scene, LPS = 4 or 8 lanes per sample.  The lanes of a sample replicate its state arithmetic (idle lanes cost
+// nothing - at K=8192 one lane per sample is only 128 wavefronts on 1024 SIMDs), run the robot algebra in the quad layout
+// (both quads of an octet alike) and deal the contact work over all LPS lanes (mppi_scene.hpp: kSplitQuad / kSplitOct).
+// The sample's LDS rows are shared by its lanes: element i of the wave's s-th sample lives at lds[i*SPW + s]
+// (SPW = 64 / LPS samples per wavefront; LPS-lane broadcast reads).
+template <class T, int LPS>
 __global__ __launch_bounds__(kWave) void k_rollout_scene_quad(const DevModel *__restrict__ m, const DevCfg *__restrict__ cfg,
                                                               const DevCost *__restrict__ cost, const float *__restrict__ x0_dof,
                                                               const float *__restrict__ x0_root, const float *__restrict__ U,
@@ -566,6 +571,9 @@ __global__ __launch_bounds__(kWave) void k_rollout_scene_quad(const DevModel *__
                                                               float *__restrict__ partials, unsigned *__restrict__ fold_ctr, float *__restrict__ fold_out,
                                                               unsigned long long *__restrict__ wave_clk) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(LPS == 4 || LPS == 8, "4 or 8 lanes per sample");
+    constexpr int SPW = kWave / LPS;
+    constexpr int kSplit = LPS == 8 ? kSplitOct : kSplitQuad;
     const unsigned long long clk0 = wave_clk != nullptr ? wall_clock64() : 0ull;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // The robot part of the model (header, bodies, links: 4.3 KB) is staged in LDS for the quad-layout kinematics and
@@ -576,18 +584,18 @@ __global__ __launch_bounds__(kWave) void k_rollout_scene_quad(const DevModel *__
     for (int i = threadIdx.x; i < kModelBytes / 16; i += kWave) s_model[i] = reinterpret_cast<const uint4 *>(m)[i];
     __syncthreads();
     LModel &lm = *(LModel *)s_model;
-    const int nb = gridDim.x;  // XCD-aware chunk mapping as in k_rollout_quad
+    const int nb = gridDim.x;  // XCD-aware chunk mapping as in k_rollout_quad (here 128 / (4 SPW) chunks share a line)
     const int chunk = (nb % 16 == 0) ? (int)(blockIdx.x % 8) * (nb / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
-    const int k = chunk * 16 + (threadIdx.x >> 2);
-    const int lane4 = threadIdx.x & 3;
+    const int k = chunk * SPW + (threadIdx.x / LPS);
+    const int sub = threadIdx.x & (LPS - 1);
     const bool live = k < cfg->K;
-    const LMem L{lds + (threadIdx.x >> 2), 16};
+    const LMem L{lds + (threadIdx.x / LPS), SPW};
     float s = INFINITY;
     if (live) {
-        s = rollout_scene<T, kSplitQuad>(*(CModel *)m, lm, *(CCfg *)cfg, *(CCost *)cost, x0_dof, x0_root, U, eps, prior, du, viz, k, L, Split{lane4, 4});
-        if (lane4 == 0) S[k] = s;
+        s = rollout_scene<T, kSplit>(*(CModel *)m, lm, *(CCfg *)cfg, *(CCost *)cost, x0_dof, x0_root, U, eps, prior, du, viz, k, L, Split{sub, LPS});
+        if (sub == 0) S[k] = s;
     }
-    quad_record(*(CCfg *)cfg, s, live && lane4 == 0, du, chunk * 16, partials + (size_t)chunk * (2 + cfg->H * cfg->nu));
+    quad_record<SPW>(*(CCfg *)cfg, s, live && sub == 0, du, chunk * SPW, partials + (size_t)chunk * (2 + cfg->H * cfg->nu));
     fold_after_record(*(CCfg *)cfg, partials, fold_ctr, fold_out);
     if (wave_clk != nullptr && threadIdx.x == 0) {  // instrumentation (mppi_set_wave_clock): this wavefront's residency
         wave_clk[2 * chunk] = clk0;
@@ -1067,7 +1075,8 @@ struct mppi_ctx {
     DevCfg hc;
     DevCost hk;
     int n = 0, A = 0, B = 0, K = 0, H = 0, nu = 0, HN = 0, RF = 0, n_waves = 0;
-    int n_quads = 0;      // wavefronts of the quad-parallel rollout (16 samples each)
+    int n_quads = 0;      // wavefronts of the quad- / octet-parallel rollout (16 / 8 samples each)
+    int lanes_per_sample = 1;  // 1 (lane kernels), 4 (quad kernels), 8 (contact scenes: octets)
     int n_partials = 0;   // records currently held by d_partials
     bool quad = false;
     DevModel *d_model = nullptr;
@@ -1116,6 +1125,7 @@ struct TopoEntry {
     void (*rollout_quad)(mppi_ctx *);
     void (*rollout_scene)(mppi_ctx *);
     void (*rollout_scene_quad)(mppi_ctx *);
+    void (*rollout_scene_oct)(mppi_ctx *);  // 8 lanes per sample
     void (*sim_step)(mppi_ctx *, int, int, const float *);
     void (*sim_step_quad)(mppi_ctx *, int, int, const float *);
     void (*sim_step_scene)(mppi_ctx *, int, int, const float *);
@@ -1135,9 +1145,9 @@ void launch_rollout_scene_t(mppi_ctx *c) {
                        c->d_x0_root, c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_S, c->cfg.want_rollouts ? c->d_viz : nullptr,
                        c->d_partials);
 }
-template <class T>
+template <class T, int LPS>
 void launch_rollout_scene_quad_t(mppi_ctx *c) {
-    hipLaunchKernelGGL(k_rollout_scene_quad<T>, dim3(c->n_quads), dim3(kWave), c->lds_bytes_quad, c->stream, c->d_model, c->d_cfg, c->d_cost, c->d_x0_dof,
+    hipLaunchKernelGGL((k_rollout_scene_quad<T, LPS>), dim3(c->n_quads), dim3(kWave), c->lds_bytes_quad * (kWave / LPS) / 16, c->stream, c->d_model, c->d_cfg, c->d_cost, c->d_x0_dof,
                        c->d_x0_root, c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_S, c->cfg.want_rollouts ? c->d_viz : nullptr,
                        c->d_partials, c->fold ? c->d_fold_ctr : nullptr, c->fold_out, c->wave_clk_on ? c->d_wave_clk : nullptr);
 }
@@ -1148,7 +1158,7 @@ void launch_sim_step_scene_t(mppi_ctx *c, int mode, int t, const float *u_ext) {
 }
 template <class T>
 void launch_sim_step_scene_quad_t(mppi_ctx *c, int mode, int t, const float *u_ext) {
-    hipLaunchKernelGGL(k_sim_step_scene_quad<T>, dim3(c->n_quads), dim3(kWave), c->lds_bytes_quad, c->stream, c->d_model, c->d_cfg, mode, t, u_ext,
+    hipLaunchKernelGGL(k_sim_step_scene_quad<T>, dim3((c->K + 15) / 16), dim3(kWave), c->lds_bytes_quad, c->stream, c->d_model, c->d_cfg, mode, t, u_ext,
                        c->d_x0_root, c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_ctrl, c->d_q, c->d_qd, c->d_base, c->d_fr, c->d_cf);
 }
 template <class T>
@@ -1160,7 +1170,9 @@ template <class T>
 hipError_t raise_lds_limit(size_t lane_bytes, size_t quad_bytes) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rollout_scene<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lane_bytes);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rollout_scene_quad<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)quad_bytes);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rollout_scene_quad<T, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)quad_bytes);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rollout_scene_quad<T, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)quad_bytes);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sim_step_scene_quad<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)quad_bytes);
     if (e != hipSuccess) return e;
@@ -1190,7 +1202,7 @@ void launch_sim_step_t(mppi_ctx *c, int mode, int t, const float *u_ext) {
 }
 template <class T>
 void launch_sim_step_quad_t(mppi_ctx *c, int mode, int t, const float *u_ext) {
-    hipLaunchKernelGGL(k_sim_step_quad<T>, dim3(c->n_quads), dim3(kWave), 0, c->stream, c->d_model, c->d_cfg, mode, t, u_ext, c->d_x0_root, c->d_U,
+    hipLaunchKernelGGL(k_sim_step_quad<T>, dim3((c->K + 15) / 16), dim3(kWave), 0, c->stream, c->d_model, c->d_cfg, mode, t, u_ext, c->d_x0_root, c->d_U,
                        c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_ctrl, c->d_q, c->d_qd);
 }
 template <class T>
@@ -1208,7 +1220,8 @@ TopoEntry make_topo_entry() {
     e.rollout = &launch_rollout_t<T>;
     e.rollout_quad = &launch_rollout_quad_t<T>;
     e.rollout_scene = &launch_rollout_scene_t<T>;
-    e.rollout_scene_quad = &launch_rollout_scene_quad_t<T>;
+    e.rollout_scene_quad = &launch_rollout_scene_quad_t<T, 4>;
+    e.rollout_scene_oct = &launch_rollout_scene_quad_t<T, 8>;
     e.sim_step = &launch_sim_step_t<T>;
     e.sim_step_quad = &launch_sim_step_quad_t<T>;
     e.sim_step_scene = &launch_sim_step_scene_t<T>;

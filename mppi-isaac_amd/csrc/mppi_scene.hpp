@@ -237,8 +237,12 @@ MPPI_HD void pair_add(PairAcc &a, const PairAcc &b) {
 // points sub, sub + n, ...  kSplitNone: one lane per sample.  kSplitQuad: the 4 lanes of a quad hold the same
 // sample state (replicated arithmetic) and share the sample's LDS rows; the partial pair sums are combined with
 // a DPP butterfly so that all four lanes see bit-identical totals.  kSplitEmulate: host restatement of
-// kSplitQuad (the four partial sums are formed one after the other).
-enum { kSplitNone = 0, kSplitQuad = 1, kSplitEmulate = 2 };
+// kSplitQuad (the four partial sums are formed one after the other).  kSplitOct: EIGHT lanes per sample - two quads that
+// replicate the sample's state arithmetic and the quad-layout robot algebra, and deal the contact work (shape poses, broad
+// phase, the 2 x 26 feature points of a box pair) over all eight lanes: K/8 wavefronts (one per SIMD at K = 8192) whose
+// divergent narrow phase waits for the busiest of 8 samples instead of 16, each lane testing half the points.
+enum { kSplitNone = 0, kSplitQuad = 1, kSplitEmulate = 2, kSplitOct = 3 };
+constexpr bool split_on_device(int split) { return split == kSplitQuad || split == kSplitOct; }
 struct Split {
     int sub, n;
 };
@@ -258,14 +262,31 @@ __device__ __forceinline__ unsigned quad_allor(unsigned x) {
     x |= (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xf, 0xf, true);
     return x;
 }
-__device__ __forceinline__ void quad_reduce(PairAcc &a) {
-    a.any = quad_allsum(a.any ? 1.f : 0.f) > 0.f;
-    a.f.a = {quad_allsum(a.f.a.x), quad_allsum(a.f.a.y), quad_allsum(a.f.a.z)};
-    a.f.l = {quad_allsum(a.f.l.x), quad_allsum(a.f.l.y), quad_allsum(a.f.l.z)};
-    a.rep = {quad_allsum(a.rep.x), quad_allsum(a.rep.y), quad_allsum(a.rep.z)};
-    a.C.I = {quad_allsum(a.C.I.xx), quad_allsum(a.C.I.xy), quad_allsum(a.C.I.xz), quad_allsum(a.C.I.yy), quad_allsum(a.C.I.yz), quad_allsum(a.C.I.zz)};
-    for (int j = 0; j < 9; j++) a.C.H[j] = quad_allsum(a.C.H[j]);
-    a.C.M = {quad_allsum(a.C.M.xx), quad_allsum(a.C.M.xy), quad_allsum(a.C.M.xz), quad_allsum(a.C.M.yy), quad_allsum(a.C.M.yz), quad_allsum(a.C.M.zz)};
+// sum / or over the lanes that share a sample, identical in all of them.  Octet: the quad totals (already identical within
+// each quad) are exchanged with row_half_mirror (lane i <-> 7 - i of every 8 lanes): q0 + q1 in one quad, q1 + q0 in the
+// other - the same bits.
+template <int SPLIT>
+__device__ __forceinline__ float group_allsum(float x) {
+    x = quad_allsum(x);
+    if constexpr (SPLIT == kSplitOct) x += scene_dpp<0x141>(x);
+    return x;
+}
+template <int SPLIT>
+__device__ __forceinline__ unsigned group_allor(unsigned x) {
+    x = quad_allor(x);
+    if constexpr (SPLIT == kSplitOct) x |= (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0x141, 0xf, 0xf, true);
+    return x;
+}
+template <int SPLIT>
+__device__ __forceinline__ void group_reduce(PairAcc &a) {
+    auto S = [](float x) { return group_allsum<SPLIT>(x); };
+    a.any = S(a.any ? 1.f : 0.f) > 0.f;
+    a.f.a = {S(a.f.a.x), S(a.f.a.y), S(a.f.a.z)};
+    a.f.l = {S(a.f.l.x), S(a.f.l.y), S(a.f.l.z)};
+    a.rep = {S(a.rep.x), S(a.rep.y), S(a.rep.z)};
+    a.C.I = {S(a.C.I.xx), S(a.C.I.xy), S(a.C.I.xz), S(a.C.I.yy), S(a.C.I.yz), S(a.C.I.zz)};
+    for (int j = 0; j < 9; j++) a.C.H[j] = S(a.C.H[j]);
+    a.C.M = {S(a.C.M.xx), S(a.C.M.xy), S(a.C.M.xz), S(a.C.M.yy), S(a.C.M.yz), S(a.C.M.zz)};
 }
 #endif
 
@@ -576,7 +597,7 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
     // Pays when most pairs are apart in every sample of a wavefront: 23-pair gripper scene -17 % away from contact.
     unsigned alive_lo = ~0u, alive_hi = ~0u;
 #if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (SPLIT == kSplitQuad && (T::NB > 4)) {
+    if constexpr (split_on_device(SPLIT) && (T::NB > 4)) {
         if (m.n_pairs > kDealtBroadPhaseMin) {
             alive_lo = alive_hi = 0u;
             const int trips = (m.n_pairs + split.n - 1) / split.n;
@@ -590,13 +611,13 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
                 alive_lo |= ip < 32 ? bit : 0u;
                 alive_hi |= ip < 32 ? 0u : bit;
             }
-            alive_lo = quad_allor(alive_lo);
-            alive_hi = quad_allor(alive_hi);
+            alive_lo = group_allor<SPLIT>(alive_lo);
+            alive_hi = group_allor<SPLIT>(alive_hi);
         }
     }
 #endif
     for (int ip = 0; ip < m.n_pairs; ip++) {
-        if constexpr (SPLIT == kSplitQuad && (T::NB > 4))
+        if constexpr (split_on_device(SPLIT) && (T::NB > 4))
             if ((((ip < 32 ? alive_lo : alive_hi) >> (ip & 31)) & 1u) == 0u) continue;
         // geometry block of the pair: all the broad phase needs (no dependent loads of the two shape records)
         const PairGeom G = load_block<PairGeom>(m.pr[ip].g);
@@ -737,8 +758,8 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
             points(split, acc);
 #if defined(__HIP_DEVICE_COMPILE__)
             // (wave-uniform skip: most pairs are apart in most samples)
-            if constexpr (SPLIT == kSplitQuad)
-                if (__builtin_amdgcn_ballot_w64(acc.any) != 0) quad_reduce(acc);
+            if constexpr (split_on_device(SPLIT))
+                if (__builtin_amdgcn_ballot_w64(acc.any) != 0) group_reduce<SPLIT>(acc);
 #endif
         }
         if (acc.any) {

@@ -30,7 +30,7 @@ def test_jackal_yaml_as_shipped_is_rejected():
         build_scene(["jackal", "goal"], [[0.0, 0.0, 0.1]])
 
 
-@pytest.mark.parametrize("split", [1, 4])
+@pytest.mark.parametrize("split", [1, 4, 8])
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_step_parity(name, split, hostemu, oracle64):
     """split = 4: the arithmetic of k_rollout_scene_quad on the host (contact points dealt over an emulated quad, robot

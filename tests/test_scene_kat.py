@@ -240,9 +240,10 @@ def test_randomised_samples_device_arithmetic_matches_oracle(hostemu, oracle64):
     assert differs > 20      # the perturbed worlds really do evolve differently from the nominal one
 
 
-def test_quad_split_of_contact_points_is_the_same_contact_model(hostemu, oracle64):
-    """k_rollout_scene_quad deals the feature points of every pair over the 4 lanes of a quad and sums the partial
-    wrenches / dampings: emulated on the host (kSplitEmulate), same steps as the one-lane arithmetic up to fp32
+@pytest.mark.parametrize("lanes", [4, 8])
+def test_quad_split_of_contact_points_is_the_same_contact_model(lanes, hostemu, oracle64):
+    """k_rollout_scene_quad deals the feature points of every pair over the 4 (quad) or 8 (octet) lanes of a sample and sums
+    the partial wrenches / dampings: emulated on the host (kSplitEmulate), same steps as the one-lane arithmetic up to fp32
     summation order, and the same parity with the oracle."""
     scene, m, cfg, cost, dof, root0 = boxer_push()
     q, qd = dof[0::2].astype(float), dof[1::2].astype(float)
@@ -254,7 +255,7 @@ def test_quad_split_of_contact_points_is_the_same_contact_model(hostemu, oracle6
         for u, n in [((0.0, 0.0), 8), ((0.6, 0.0), 20), ((0.4, 0.9), 12)]:
             for _ in range(n):
                 out = []
-                for split, cf in ((1, cf1), (4, cf4)):
+                for split, cf in ((1, cf1), (lanes, cf4)):
                     hostemu.emu_set_scene_split(split)
                     de = np.zeros(2 * scene.n_dof, np.float32)
                     de[0::2], de[1::2] = q, qd
@@ -267,7 +268,7 @@ def test_quad_split_of_contact_points_is_the_same_contact_model(hostemu, oracle6
                 np.testing.assert_allclose(cf4, cf1, atol=2e-3 * max(1.0, np.abs(cf1).max()))
                 root, q, qd, cfo = oracle64.scene_step(m, root, q, qd, oracle64.cmd_map(m, u))
                 np.testing.assert_allclose(out[1][1][:, 0:7], root[:, 0:7], atol=2e-5)
-        hostemu.emu_set_scene_split(4)
+        hostemu.emu_set_scene_split(lanes)
         scene, m, cfg, cost, dof, root = panda_pick(K=16, H=10)
         eps = oracle64.sample(cfg)
         U = np.zeros((10, cfg.nu))

@@ -16,7 +16,9 @@ from mppiisaac.backend import capi
 
 def report(tag, loop):
     lib, P = loop.lib, loop.P
-    n = (loop.K + 15) // 16
+    info = C.create_string_buffer(256)
+    capi.check(lib, lib.mppi_kernel_info(P, info, 256))
+    n = int(dict(kv.split("=") for kv in info.value.decode().split())["waves"])
     capi.check(lib, lib.mppi_set_wave_clock(P, 1))
     capi.check(lib, lib.mppi_rollout(P))
     clk = np.zeros((n, 2), np.uint64)
@@ -31,7 +33,7 @@ def report(tag, loop):
     hist, edges = np.histogram(dur, bins=10)
     print("   residency histogram:", " ".join(f"{int(e)}:{h}" for h, e in zip(hist, edges[:-1])))
     slow = np.argsort(dur)[-5:][::-1]
-    print("   slowest chunks (16 samples each):", [(int(c), round(float(dur[c]), 1)) for c in slow])
+    print("   slowest chunks:", [(int(c), round(float(dur[c]), 1)) for c in slow])
     return dur
 
 
