@@ -33,10 +33,11 @@ def only(ks):
         for i, p in enumerate(keep): m.pairs[i] = p
         m.n_pairs = len(keep)
     return f
-for make, K, H in ((boxer_push, 8192, 25), (panda_pick, 8192, 30)):
-    run(make.__name__ + " full", make, K, H)
-    run(make.__name__ + " no pairs", make, K, H, no_pairs)
-run("panda_pick block pairs only (ground+table)", panda_pick, 8192, 30, only([21, 22]))
+if not os.environ.get("CLOSED_LOOP_ONLY"):
+    for make, K, H in ((boxer_push, 8192, 25), (panda_pick, 8192, 30)):
+        run(make.__name__ + " full", make, K, H)
+        run(make.__name__ + " no pairs", make, K, H, no_pairs)
+    run("panda_pick block pairs only (ground+table)", panda_pick, 8192, 30, only([21, 22]))
 
 
 def closed_loop_variants(workload, steps=150):
@@ -72,6 +73,9 @@ def closed_loop_variants(workload, steps=150):
         dof, root, U = np.ascontiguousarray(z["dof"]), np.ascontiguousarray(z["root"]), np.ascontiguousarray(z["U"])
     print(workload, "closed-loop state after", steps, "steps: q =", np.round(dof[0::2], 2), flush=True)
     model0 = planner.sim._c_model
+    sc = planner.sim.scene
+    names = [f"{sc.env_cfg[sh['actor']].name}:{sh['link']}" for sh in sc.shapes]
+    print("  pairs:", ", ".join(f"{i}={names[a]}/{names[b] if b >= 0 else 'ground'}" for i, (a, b) in enumerate(sc.pairs)), flush=True)
 
     def timed(name, edit):
         m = type(model0).from_buffer_copy(model0)
@@ -93,6 +97,12 @@ def closed_loop_variants(workload, steps=150):
     timed("full (seeded noise)", None)
     timed("full, noise off", no_rnd)
     timed("no pairs", no_pairs)
+    if workload == "boxer_push":
+        ground = [i for i, (a, b) in enumerate(sc.pairs) if b < 0]
+        timed("ground pairs only", only(ground))
+        timed("box-box pairs only", only([i for i in range(len(sc.pairs)) if i not in ground]))
+        for i in range(len(sc.pairs)):
+            timed(f"without pair {i}", only([j for j in range(len(sc.pairs)) if j != i]))
     if workload == "panda_pick":
         timed("block pairs only", only([21, 22]))
         timed("block + finger/hand-block pairs", only([13, 15, 17, 19, 21, 22]))
