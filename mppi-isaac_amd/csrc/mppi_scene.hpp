@@ -278,6 +278,14 @@ __device__ __forceinline__ unsigned group_allor(unsigned x) {
     return x;
 }
 template <int SPLIT>
+__device__ __forceinline__ void group_reduce_explicit(PairAcc &a) {  // mode 0 (both bodies dynamic): wrench and reported force only
+    auto S = [](float x) { return group_allsum<SPLIT>(x); };
+    a.any = S(a.any ? 1.f : 0.f) > 0.f;
+    a.f.a = {S(a.f.a.x), S(a.f.a.y), S(a.f.a.z)};
+    a.f.l = {S(a.f.l.x), S(a.f.l.y), S(a.f.l.z)};
+    a.rep = {S(a.rep.x), S(a.rep.y), S(a.rep.z)};
+}
+template <int SPLIT>
 __device__ __forceinline__ void group_reduce(PairAcc &a) {
     auto S = [](float x) { return group_allsum<SPLIT>(x); };
     a.any = S(a.any ? 1.f : 0.f) > 0.f;
@@ -747,7 +755,13 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
                 else if (typeA == 0 && typeB == 1) sphere_in_box(P, wb.p, hB[0], wa, hA, -1.f, wa.v, wb.v, out);
             }
         };
-        if constexpr (SPLIT == kSplitEmulate) {
+        // pairs with ONE analytic contact point (disc / sphere against the ground or a box): every lane of the sample computes
+        // it - the lanes hold the same state, so the result is already identical in all of them and the cross-lane sum of the
+        // pair's 31 partial values (more instructions than the contact itself) is not needed
+        const bool single_point = has_b ? !(typeA == 0 && typeB == 0) : typeA != 0;
+        if (single_point) {
+            points(Split{0, 1}, acc);
+        } else if constexpr (SPLIT == kSplitEmulate) {
             for (int sb = 0; sb < split.n; sb++) {
                 PairAcc part;
                 pair_zero(part);
@@ -759,7 +773,10 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
 #if defined(__HIP_DEVICE_COMPILE__)
             // (wave-uniform skip: most pairs are apart in most samples)
             if constexpr (split_on_device(SPLIT))
-                if (__builtin_amdgcn_ballot_w64(acc.any) != 0) group_reduce<SPLIT>(acc);
+                if (__builtin_amdgcn_ballot_w64(acc.any) != 0) {
+                    if (G.mode == 0) group_reduce_explicit<SPLIT>(acc);  // two dynamic bodies: no implicit damping block to sum
+                    else group_reduce<SPLIT>(acc);
+                }
 #endif
         }
         if (acc.any) {
