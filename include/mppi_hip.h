@@ -160,6 +160,10 @@ typedef struct mppi_model {
     double contact_alpha;     /* penalty stiffness  k = alpha * m_eff / h^2 per contact patch */
     double contact_beta;      /* normal damping     c = beta  * m_eff / h                     */
     double friction_beta;     /* stick damping      c_t = friction_beta * m_eff / h           */
+    /* depth over which the velocity-proportional part of the normal force (damper + implicit end-of-step spring term)
+     * ramps in linearly, Hunt-Crossley style: the contact force is continuous at touch-down instead of jumping by
+     * (c + k h) v_n.  0 = full strength from the first touch (the law of ABI 1).  Host default: the static sag |g| h^2 / alpha */
+    double contact_ramp_depth;
     /* >= 0: every sample (global id g) draws its own box sizes / masses / frictions from a counter-based
      * hash of (seed, g, actor) - the seeded counterpart of the reference's unseeded np.random draws per env;
      * < 0: nominal values in every sample */

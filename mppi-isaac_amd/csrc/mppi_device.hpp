@@ -100,7 +100,8 @@ struct PairGain {
     int actorA, actorB;   // actors of the two shapes (rows of the per-sample noise draws)
     int robotA, robotB;   // the shape belongs to the robot (never noisy; keeps its own per-shape friction)
     float muA, muB;       // per-shape friction
-    int pad[2];
+    float inv_d0;         // 1 / contact_ramp_depth (0: no ramp)
+    int pad;
 };
 struct DevPair {
     PairGeom g;

@@ -302,6 +302,7 @@ __device__ __forceinline__ void group_reduce(PairAcc &a) {
 struct Gains {  // per-pair contact parameters of THIS sample (equal to the packed nominal ones without randomisation)
     int mode;
     float mu, k, cn, ct, kh;
+    float inv_d0;  // ramp of the velocity-proportional normal terms over the first contact_ramp_depth of penetration
 };
 MPPI_HD void contact_point(const Gains &P, V3 p, V3 n, float depth, const SV &vA, const SV &vB, PairAcc &acc) {
     const V3 vr = vel_at(vA, p) - vel_at(vB, p);
@@ -309,8 +310,11 @@ MPPI_HD void contact_point(const Gains &P, V3 p, V3 n, float depth, const SV &vA
     const V3 vt = vr - vn * n;
     const float vtn = fsqrt(dot(vt, vt));
     acc.any = true;
+    // Hunt-Crossley-style ramp: damper and implicit spring term grow linearly over the first d0 of penetration, so the
+    // normal force (and with it the Coulomb-capped friction) is CONTINUOUS at touch-down; inv_d0 = 0: no ramp
+    const float ramp = P.inv_d0 > 0.f ? fminf(1.f, depth * P.inv_d0) : 1.f;
     if (P.mode == 0) {  // both dynamic: explicit spring-damper, viscous friction capped by the Coulomb cone
-        const float fn = fmaxf(0.f, P.k * depth - P.cn * vn);
+        const float fn = fmaxf(0.f, P.k * depth - ramp * P.cn * vn);
         const float sc = fminf(P.ct, P.mu * fn * frcp(vtn + 1e-9f));
         const V3 f = fn * n - sc * vt;
         acc.f = {acc.f.a + cross(p, f), acc.f.l + f};
@@ -321,7 +325,7 @@ MPPI_HD void contact_point(const Gains &P, V3 p, V3 n, float depth, const SV &vA
     // term in the implicit normal coefficient (unconditionally stable, no bounce at h = 25 ms); the
     // damper acts on approach and on separation (an approach-only damper toggles with the sign of v_n: resting jitter);
     // friction is implicit too (see below)
-    float a = P.cn + P.kh;
+    float a = ramp * (P.cn + P.kh);
     {  // never adhesive at the start velocity: a <= k depth / v_n while separating (branch-free; the raw reciprocal is enough)
 #if defined(__HIP_DEVICE_COMPILE__)
         const float cap = P.k * depth * __builtin_amdgcn_rcpf(fmaxf(vn, 1e-30f));
@@ -700,7 +704,7 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
         if (apart) continue;
         // contact law of the survivors: second block of the pair
         const PairGain Cg = load_block<PairGain>(m.pr[ip].c);
-        Gains P = {G.mode, Cg.mu, Cg.k, Cg.cn, Cg.ct, Cg.kh};
+        Gains P = {G.mode, Cg.mu, Cg.k, Cg.cn, Cg.ct, Cg.kh, Cg.inv_d0};
         if (G.rnd) {  // per-sample friction (min of the two) and contact gains scaled with the per-sample reacting mass
             const float mua = robotA ? Cg.muA : da.mu;
             const float mub = !has_b ? Cg.mub : (robotB ? Cg.muB : db.mu);

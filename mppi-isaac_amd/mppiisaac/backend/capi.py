@@ -55,7 +55,7 @@ class Model(C.Structure):
                 ("drive_mode", _i), ("substeps", _i), ("drive_kd", _d), ("dt", _d), ("gravity", _d * 3),
                 ("nu", _i), ("cmd_col", (_i * 2) * MAX_BODIES), ("cmd_coef", (_d * 2) * MAX_BODIES),
                 ("n_shapes", _i), ("n_pairs", _i), ("shapes", Shape * MAX_SHAPES), ("pairs", Pair * MAX_PAIRS),
-                ("ground_friction", _d), ("contact_alpha", _d), ("contact_beta", _d), ("friction_beta", _d),
+                ("ground_friction", _d), ("contact_alpha", _d), ("contact_beta", _d), ("friction_beta", _d), ("contact_ramp_depth", _d),
                 ("randomize_seed", _i), ("pad2_", _i)]
 
 

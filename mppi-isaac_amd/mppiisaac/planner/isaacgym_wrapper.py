@@ -149,6 +149,9 @@ class Scene:
 
     # contact parameters of the penalty model (build-normative; no reference counterpart)
     CONTACT_ALPHA, CONTACT_BETA, FRICTION_BETA, GROUND_FRICTION = 0.8, 0.8, 1.0, 1.0
+    # depth over which the damper and the implicit spring term of a contact ramp in (None: the static sag |g| h^2 / alpha of a
+    # body resting on its contact patch - 7.7 mm at h = 25 ms -, so a body at rest sees the full law; 0: no ramp)
+    CONTACT_RAMP_DEPTH = None
 
     def _contact_scene(self):
         """Collision primitives and candidate pairs of one env.
@@ -343,6 +346,8 @@ class Scene:
             m.pairs[i].a, m.pairs[i].b = a, b
         m.ground_friction = self.GROUND_FRICTION
         m.contact_alpha, m.contact_beta, m.friction_beta = self.CONTACT_ALPHA, self.CONTACT_BETA, self.FRICTION_BETA
+        hsub = float(self.cfg.dt) / int(self.cfg.substeps)
+        m.contact_ramp_depth = (abs(GRAVITY[2]) * hsub * hsub / self.CONTACT_ALPHA) if self.CONTACT_RAMP_DEPTH is None else float(self.CONTACT_RAMP_DEPTH)
         m.randomize_seed = int(self.randomize_seed)
         if self.robot.dof_mode not in DRIVE_GAINS:
             raise ValueError("Invalid dof_mode")

@@ -425,8 +425,14 @@ typedef struct { real f[6]; real C[36]; real rep[3]; int any; } pair_acc_t;
 
 /* one contact point: normal n from B to A, penetration depth > 0 (same law as csrc/mppi_scene.hpp::contact_point,
  * written from DESIGN.md section 3) */
+static real g_ramp_depth; /* contact_ramp_depth of the model being stepped (set by scene_contacts; per-thread copies are equal) */
+#pragma omp threadprivate(g_ramp_depth)
 static void contact_point(int mode, real mu, real k, real cn, real ct, real kh, const real *p, const real *n, real depth,
                           const real *vA, const real *vB, pair_acc_t *acc) {
+    /* Hunt-Crossley-style ramp of the velocity-proportional normal terms over the first contact_ramp_depth of penetration:
+     * the contact force is continuous at touch-down (include/mppi_hip.h, mppi_model_t.contact_ramp_depth) */
+    real ramp = 1;
+    if (g_ramp_depth > 0) { ramp = depth / g_ramp_depth; if (ramp > 1) ramp = 1; }
     real va[3], vb[3], vr[3], vt[3];
     vel_at(vA, p, va); vel_at(vB, p, vb);
     for (int j = 0; j < 3; j++) vr[j] = va[j] - vb[j];
@@ -435,7 +441,7 @@ static void contact_point(int mode, real mu, real k, real cn, real ct, real kh, 
     real vtn = (real)sqrt((double)(vt[0] * vt[0] + vt[1] * vt[1] + vt[2] * vt[2]));
     acc->any = 1;
     if (mode == 0) {
-        real fn = k * depth - cn * vn; if (fn < 0) fn = 0;
+        real fn = k * depth - ramp * cn * vn; if (fn < 0) fn = 0;
         real sc = mu * fn / (vtn + (real)1e-9); if (ct < sc) sc = ct;
         real f[3];
         for (int j = 0; j < 3; j++) { f[j] = fn * n[j] - sc * vt[j]; acc->rep[j] += f[j]; }
@@ -445,7 +451,7 @@ static void contact_point(int mode, real mu, real k, real cn, real ct, real kh, 
     /* Kelvin-Voigt damper on approach AND separation (a law that damps the approach only switches c_n on and off with the
      * sign of v_n and keeps a body that rests on several points rocking at fp32 rounding level), capped so that the force at
      * the start velocity never turns adhesive: k depth - a v_n >= 0 */
-    real a = cn + kh;
+    real a = ramp * (cn + kh);
     if (vn > 0 && a * vn > k * depth) a = k * depth / vn;
     real fn = k * depth - a * vn; if (fn < 0) fn = 0;
     real b = mu * fn / (vtn + (real)1e-9); if (ct < b) b = ct;
@@ -540,6 +546,7 @@ static int shape_entity(const mppi_model_t *m, const scene_info_t *si, const mpp
 static void scene_contacts(const mppi_model_t *m, const scene_info_t *si, frame_t *fr, const real *root, real *cf) {
     real h = (real)(m->dt / m->substeps);
     int nf = m->n_bodies + 1 + MPPI_MAX_FREE;
+    g_ramp_depth = (real)m->contact_ramp_depth;
     for (int e = 0; e < nf; e++) { memset(fr[e].f, 0, sizeof fr[e].f); memset(fr[e].C, 0, sizeof fr[e].C); }
     for (int j = 0; j < 3 * m->n_rb; j++) cf[j] = 0;
     for (int ip = 0; ip < m->n_pairs; ip++) {

@@ -68,8 +68,10 @@ def closed_loop_variants(workload, steps=150):
     # equal-state A/B of two builds: MPPI_STATE_SAVE=<prefix> records this state, MPPI_STATE_LOAD=<prefix> times at a recorded one
     if os.environ.get("MPPI_STATE_SAVE"):
         np.savez(os.environ["MPPI_STATE_SAVE"] + "_" + workload + ".npz", dof=dof, root=root, U=U)
-    if os.environ.get("MPPI_STATE_LOAD"):
-        z = np.load(os.environ["MPPI_STATE_LOAD"] + "_" + workload + ".npz")
+    default_state = os.path.join(os.path.dirname(os.path.abspath(__file__)), "states", "state")   # recorded with the r02d build
+    load = os.environ.get("MPPI_STATE_LOAD", default_state if not os.environ.get("MPPI_STATE_SAVE") else "")
+    if load and os.path.exists(load + "_" + workload + ".npz"):
+        z = np.load(load + "_" + workload + ".npz")
         dof, root, U = np.ascontiguousarray(z["dof"]), np.ascontiguousarray(z["root"]), np.ascontiguousarray(z["U"])
     print(workload, "closed-loop state after", steps, "steps: q =", np.round(dof[0::2], 2), flush=True)
     model0 = planner.sim._c_model
@@ -94,8 +96,11 @@ def closed_loop_variants(workload, steps=150):
         print(f"  {name:44s} {1e3 * (time.perf_counter() - t) / 20:8.3f} ms", flush=True)
         lib.mppi_destroy(ctx)
     def no_rnd(m): m.randomize_seed = -1
+    def no_effort(m):
+        for i in range(m.n_bodies): m.bodies[i].effort = 0.0
     timed("full (seeded noise)", None)
     timed("full, noise off", no_rnd)
+    timed("full, no joint effort limits (never a 2nd solve)", no_effort)
     timed("no pairs", no_pairs)
     if workload == "boxer_push":
         ground = [i for i, (a, b) in enumerate(sc.pairs) if b < 0]
