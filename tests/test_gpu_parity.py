@@ -218,8 +218,8 @@ def test_full_size_properties(lib, oracle64):
 def test_full_size_properties_contact_scenes(make, K, H, nu, lib, oracle64, monkeypatch):
     """BASELINE sizes of the contact scenes (configs 4 and 5, one GPU's shard) through properties that do not need the
     oracle at full size: finite costs, clamped perturbations, the action as the weighted mean of the perturbations, bitwise
-    determinism, the quad kernel against the one-lane kernel on the same inputs, and a handful of samples against the
-    oracle (chaotic contact switching aside, most of them agree to 1 %)."""
+    determinism, the shared-lane (octet) kernel against the one-lane kernel on the same inputs - EVERY sample within 2 % and
+    99.5 % of them within 1e-3 - and 32 samples against the fp64 oracle (all within 1 %, nine in ten within 1e-4)."""
     scene, m, cfg, cost, dof, root = make(K=K, H=H)
     c = Ctx(m, cfg, cost)
     c.call("mppi_sample", C.c_uint32(0)); c.set_state(dof, root)
@@ -242,18 +242,24 @@ def test_full_size_properties_contact_scenes(make, K, H, nu, lib, oracle64, monk
     l.call("mppi_sample", C.c_uint32(0)); l.set_state(dof, root); l.call("mppi_rollout")
     Sl = l.get("mppi_get_costs", (K,))
     l.close()
-    assert (np.abs(S - Sl) <= 1e-2 * np.abs(Sl)).mean() > 0.9
-    assert np.median(S) == pytest.approx(np.median(Sl), rel=1e-3)
+    # per-sample bounds (the contact force is continuous at touch-down, mppi_model_t.contact_ramp_depth; measured on MI355X,
+    # tools/exp/contact_agreement.py: boxer 99.9 % within 1e-3 / max 8.5e-3, gripper scene max 1e-6)
+    rel = np.abs(S - Sl) / np.abs(Sl)
+    print(f"{make.__name__}: shared-lane kernel vs one-lane kernel: within 1e-3 {np.mean(rel <= 1e-3):.4f}, max {rel.max():.2e}")
+    assert (rel <= 1e-3).mean() > 0.995 and rel.max() <= 2e-2
+    assert np.median(S) == pytest.approx(np.median(Sl), rel=1e-4)
     from mppiisaac.planner.mppi import make_config
     from mppiisaac.utils.config_store import load_config
     name = "boxer_push" if make is boxer_push else "panda_pick"
     ex = load_config({"defaults": [{"mppi": name}, {"isaacgym": "normal"}]}, overrides={"mppi.num_samples": K, "mppi.horizon": H})
-    ok = 0
-    for k in range(5, K, K // 8):
+    rel = []
+    for k in range(5, K, K // 32):                                  # 32 samples spread over the set against the fp64 oracle
         sc = make_config(ex.mppi, k_offset=int(k), k_local=1, viz_link=scene.viz_link_index())
         So, _, _ = oracle64.rollout(m, sc, cost, dof, root, np.zeros((H, nu)), eps[:, :, k:k + 1])
-        ok += abs(S[k] - So[0]) <= 1e-2 * abs(So[0])
-    assert ok >= 6
+        rel.append(abs(S[k] - So[0]) / abs(So[0]))
+    rel = np.array(rel)
+    print(f"{make.__name__}: vs oracle on {len(rel)} samples: median {np.median(rel):.1e}, within 1e-4 {np.mean(rel <= 1e-4):.3f}, max {rel.max():.2e}")
+    assert (rel <= 1e-2).all() and (rel <= 1e-4).mean() >= 0.9      # measured: 99 % within 1e-4, max 3.7e-3 (boxer); 3e-7 (gripper scene)
 
 
 def test_generic_objective_mode_equals_fused(lib):
@@ -538,7 +544,9 @@ def test_boxer_generic_mode_and_world(lib, oracle64):
     af = bytes_to_torch(fused.compute_action_tensor(db, rbts)).numpy()
     ag = bytes_to_torch(generic.compute_action_tensor(db, rbts)).numpy()
     Sf, Sg = fused.mppi.get_costs().numpy(), generic.mppi.get_costs().numpy()
-    assert (np.abs(Sf - Sg) <= 2e-3 * np.abs(Sf)).mean() > 0.9     # same kernels, same arithmetic; contact chaos aside
+    relc = np.abs(Sf - Sg) / np.abs(Sf)
+    print(f"boxer generic vs fused: costs within 1e-3 {np.mean(relc <= 1e-3):.4f}, max {relc.max():.2e}; action diff {np.abs(ag - af).max():.2e}")
+    assert (relc <= 2e-3).mean() > 0.9     # same kernels, same arithmetic; contact chaos aside
     np.testing.assert_allclose(ag, af, atol=5e-2)
 
 
