@@ -510,6 +510,10 @@ MPPI_HD void sphere_in_box(const Gains &P, V3 ps, float r, const ShapeW &Y, cons
 }
 
 constexpr int kDealtBroadPhaseMin = 16;  // candidate pairs above which the quad kernels deal the broad phase over the lanes
+constexpr int kDealtBroadPhaseMinOct = 8;  // ... and the octet kernels (two trips cover 16 pairs)
+// quad kernels: larger trees only (measured neutral-to-slower on the short ones); octet kernels: every tree
+template <class T>
+constexpr bool dealt_broad_phase(int split) { return split == kSplitOct || (split == kSplitQuad && T::NB > 4); }
 // Poses, per-sample sizes and broad-phase verdict of one candidate pair.
 struct PairPose {
     ShapeW wa, wb;
@@ -609,8 +613,8 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
     // Pays when most pairs are apart in every sample of a wavefront: 23-pair gripper scene -17 % away from contact.
     unsigned alive_lo = ~0u, alive_hi = ~0u;
 #if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (split_on_device(SPLIT) && (T::NB > 4)) {
-        if (m.n_pairs > kDealtBroadPhaseMin) {
+    if constexpr (dealt_broad_phase<T>(SPLIT)) {
+        if (m.n_pairs > (SPLIT == kSplitOct ? kDealtBroadPhaseMinOct : kDealtBroadPhaseMin)) {
             alive_lo = alive_hi = 0u;
             const int trips = (m.n_pairs + split.n - 1) / split.n;
             for (int it = 0; it < trips; it++) {
@@ -629,7 +633,7 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
     }
 #endif
     for (int ip = 0; ip < m.n_pairs; ip++) {
-        if constexpr (split_on_device(SPLIT) && (T::NB > 4))
+        if constexpr (dealt_broad_phase<T>(SPLIT))
             if ((((ip < 32 ? alive_lo : alive_hi) >> (ip & 31)) & 1u) == 0u) continue;
         // geometry block of the pair: all the broad phase needs (no dependent loads of the two shape records)
         const PairGeom G = load_block<PairGeom>(m.pr[ip].g);
