@@ -510,10 +510,10 @@ MPPI_HD void sphere_in_box(const Gains &P, V3 ps, float r, const ShapeW &Y, cons
 }
 
 constexpr int kDealtBroadPhaseMin = 16;  // candidate pairs above which the quad kernels deal the broad phase over the lanes
-constexpr int kDealtBroadPhaseMinOct = 8;  // ... and the octet kernels (two trips cover 16 pairs)
-// quad kernels: larger trees only (measured neutral-to-slower on the short ones); octet kernels: every tree
+// larger trees only: on the pushing scene (2-body tree, 11 pairs that are mostly near each other) the dealt pass is pure
+// overhead - measured +8 % on the octet kernel at equal state (1.386 -> 1.494 ms), as it was on the quad kernel
 template <class T>
-constexpr bool dealt_broad_phase(int split) { return split == kSplitOct || (split == kSplitQuad && T::NB > 4); }
+constexpr bool dealt_broad_phase(int split) { return split_on_device(split) && T::NB > 4; }
 // Poses, per-sample sizes and broad-phase verdict of one candidate pair.
 struct PairPose {
     ShapeW wa, wb;
@@ -614,7 +614,7 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
     unsigned alive_lo = ~0u, alive_hi = ~0u;
 #if defined(__HIP_DEVICE_COMPILE__)
     if constexpr (dealt_broad_phase<T>(SPLIT)) {
-        if (m.n_pairs > (SPLIT == kSplitOct ? kDealtBroadPhaseMinOct : kDealtBroadPhaseMin)) {
+        if (m.n_pairs > kDealtBroadPhaseMin) {
             alive_lo = alive_hi = 0u;
             const int trips = (m.n_pairs + split.n - 1) / split.n;
             for (int it = 0; it < trips; it++) {
