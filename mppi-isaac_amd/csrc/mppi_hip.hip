@@ -252,12 +252,13 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
         delete c;
         return fail(MPPI_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
     }
-    {   // MPPI_FOLD=1: fold the wave records per XCD group inside the quad rollout kernels (fold_group).  Measured on MI355X
-        // (profiles/r02a_*): the agent-scope release every workgroup needs before its ticket costs the rollout +8 us, the
-        // combine kernel gets 3 us faster - a net loss of 2.6 % on the 0.17-ms panda iteration, also in the sharded loop -
-        // so the fold is an opt-in experiment and the default keeps one record per wavefront.
+    {   // Fold of the wave records per XCD group inside the quad / octet rollout kernels (fold_group).  Measured on MI355X
+        // (profiles/r02a_*, r02f_*): the agent-scope release every workgroup needs before its ticket costs the rollout +8 us.
+        // Contact scenes (K/8 wavefronts = 1024 records of up to 272 floats for ONE combine workgroup: 32 us in the gripper
+        // scene) win - 445 -> 460 Hz -, the 0.17-ms panda iteration (256 records, 10 us combine) loses 2.6 %: the fold is
+        // on for contact scenes and off for the contact-free kernel; MPPI_FOLD=0 / =1 overrides either way.
         const char *f = std::getenv("MPPI_FOLD");
-        c->fold = c->quad && f && std::string(f) == "1";
+        c->fold = c->quad && (f ? std::string(f) == "1" : c->scene);
     }
     const int rc = create_buffers(c, cfg);
     if (rc != MPPI_OK) {  // (the error text is already set) nothing allocated so far may leak
