@@ -430,15 +430,17 @@ class IsaacGymWrapper:
         capi.check(self._lib, self._lib.mppi_set_stream(ctx, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
         K, A, B, n = self.num_envs, len(self.env_cfg), sc.n_rb, sc.n_dof
         f32 = dict(dtype=torch.float32, device=self.device)
-        self._dof_state = torch.zeros((K, 2 * n), **f32)
-        self._root_state = torch.zeros((K, A, 13), **f32)
-        self._rigid_body_state = torch.zeros((K, B, 13), **f32)
-        self._net_contact_force = torch.zeros((K, B, 3), **f32)
+        # the four gym state tensors (reference :186-199) are refreshed LAZILY: the state of truth lives in the library's
+        # sample-minor buffers, and a fused-mode planner never reads these copies - the `_dof_state` ... properties below
+        # materialise them on first access after a change (one kernel), so the per-command path of
+        # compute_action_tensor is set_state -> rollout with no [K, ...] tensor written
+        self._state_t = {"dof": torch.zeros((K, 2 * n), **f32), "root": torch.zeros((K, A, 13), **f32),
+                         "rb": torch.zeros((K, B, 13), **f32), "cf": torch.zeros((K, B, 3), **f32)}
+        self._stale, self._needs_reset = True, False
         self._visualize_link_present = sc.viz_link_index() >= 0
         self.visualize_link_buffer = []
         if self._visualize_link_present:
             self.robot_rigid_body_viz_idx = sc.rigid_body_index(sc.robot.name, sc.robot.visualize_link)
-            self.visualize_link_pos = self._rigid_body_state[:, self.robot_rigid_body_viz_idx, 0:3]
         self.robot_indices = torch.tensor([i for i, a in enumerate(self.env_cfg) if a.type == "robot"], device=self.device)
         self.obstacle_indices = torch.tensor(
             [i for i, a in enumerate(self.env_cfg) if (a.type in ["sphere", "box"] and a.name != "dummy")], device=self.device)
@@ -462,13 +464,36 @@ class IsaacGymWrapper:
         dof = np.ascontiguousarray(dof, np.float32).reshape(-1)
         root = np.ascontiguousarray(root, np.float32).reshape(-1)
         capi.check(self._lib, self._lib.mppi_set_state(self._ctx, capi.fptr(dof), capi.fptr(root)))
-        capi.check(self._lib, self._lib.mppi_sim_reset(self._ctx))
-        self._materialise()
+        if self.num_envs == 1:   # the K=1 world is also stepped through the C-ABI directly (closed loops on the device)
+            capi.check(self._lib, self._lib.mppi_sim_reset(self._ctx))
+        else:                    # K rollout envs: broadcast x0 only when somebody steps or reads them
+            self._needs_reset = True
+        self._stale = True
+
+    def _reset_envs_if_needed(self):
+        if self._needs_reset:
+            capi.check(self._lib, self._lib.mppi_sim_reset(self._ctx))
+            self._needs_reset = False
 
     def _materialise(self):
-        capi.check(self._lib, self._lib.mppi_sim_materialise(
-            self._ctx, _dev_ptr(self._dof_state), _dev_ptr(self._root_state),
-            _dev_ptr(self._rigid_body_state), _dev_ptr(self._net_contact_force)))
+        self._reset_envs_if_needed()
+        t = self._state_t
+        capi.check(self._lib, self._lib.mppi_sim_materialise(self._ctx, _dev_ptr(t["dof"]), _dev_ptr(t["root"]), _dev_ptr(t["rb"]), _dev_ptr(t["cf"])))
+        self._stale = False
+
+    def _fresh(self, key):
+        if self._stale:
+            self._materialise()
+        return self._state_t[key]
+
+    _dof_state = property(lambda self: self._fresh("dof"))
+    _root_state = property(lambda self: self._fresh("root"))
+    _rigid_body_state = property(lambda self: self._fresh("rb"))
+    _net_contact_force = property(lambda self: self._fresh("cf"))
+
+    @property
+    def visualize_link_pos(self):
+        return self._rigid_body_state[:, self.robot_rigid_body_viz_idx, 0:3]
 
     def reset_to_initial_poses(self):
         dof, root = self.scene.initial_state()
@@ -563,8 +588,9 @@ class IsaacGymWrapper:
         shared = 1 if u.shape[0] == 1 and self.num_envs != 1 else 0
         if not shared and u.shape[0] != self.num_envs:
             raise ValueError("command batch does not match num_envs")
+        self._reset_envs_if_needed()
         capi.check(self._lib, self._lib.mppi_sim_step(self._ctx, _dev_ptr(u), shared))
-        self._materialise()
+        self._stale = True
         if self._visualize_link_present:
             self.visualize_link_buffer.append(self.visualize_link_pos.clone())
 
@@ -647,8 +673,8 @@ class IsaacGymWrapper:
         attribute).  The HIP context is rebuilt for the new actor list; `generation` lets owners of
         the old context (the MPPI driver) notice."""
         from mppiisaac.utils.isaacgym_utils import load_asset
-        keep_root = self._root_state[0].clone() if hasattr(self, "_root_state") else None
-        keep_dof = self._dof_state[0].clone() if hasattr(self, "_dof_state") else None
+        keep_root = self._root_state[0].clone() if hasattr(self, "_state_t") else None
+        keep_dof = self._dof_state[0].clone() if hasattr(self, "_state_t") else None
         n_old = keep_root.shape[0] if keep_root is not None else 0
         # the nominal control sequence lives in the context that is about to be destroyed: carry it over here
         # (nobody may touch the old handle afterwards - in the reference the mppi object simply survives)

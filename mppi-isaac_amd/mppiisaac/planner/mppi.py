@@ -283,9 +283,11 @@ class MPPIPlanner:
             capi.check(lib, lib.mppi_rollout(ctx))
         else:
             capi.check(lib, lib.mppi_sim_reset(ctx))
+            self.sim._needs_reset = False
             if not self._replay_horizon(state):
                 self._horizon_eager(state)
             capi.check(lib, lib.mppi_sim_finish(ctx))
+            self.sim._stale = True
         if self._shard and self._fused_cost is not None and self._records_fold is not None:
             allgather_records(self._records_fold, _dist_rank(self._pg), self._pg, per=self._fold_n)
             capi.check(lib, lib.mppi_update(ctx, C_void(self._records_fold), self._world * self._fold_n))

@@ -284,6 +284,11 @@ void orc_cmd_map(const mppi_model_t *m, const real *u, real *target) {
         target[i] = (real)m->cmd_coef[i][0] * u[m->cmd_col[i][0]] + (real)m->cmd_coef[i][1] * u[m->cmd_col[i][1]];
 }
 
+/* diagnostics (tools/exp/saturation_stats.py): per substep, the set of joints whose drive saturated (bit i) and the sign
+ * of the clamped force (bit 16 + i); NULL = off */
+static uint32_t *g_sat_log = NULL;
+static int g_sat_n = 0;
+#pragma omp threadprivate(g_sat_log, g_sat_n)
 /* One simulator step of dt = substeps * h (IsaacGymWrapper.step, isaacgym_wrapper.py:639-645). */
 void orc_step(const mppi_model_t *m, const real *root, real *q, real *qd, const real *target) {
     int n = m->n_bodies;
@@ -303,11 +308,13 @@ void orc_step(const mppi_model_t *m, const real *root, real *q, real *qd, const 
         /* drive-force clamp (URDF <limit effort>): joints whose implicit drive force exceeds the
          * limit are re-solved with the constant saturated force (one re-solve) */
         int any = 0;
+        uint32_t satmask = 0;
         for (int i = 0; i < n; i++) {
             real lim = (real)m->bodies[i].effort;
             real tt = ff[i] + kd * (vs[i] - qd[i] - h * qdd[i]);
-            if (lim > 0 && (real)fabs((double)tt) > lim) { any = 1; tau[i] = tt > 0 ? lim : -lim; kdh[i] = 0; }
+            if (lim > 0 && (real)fabs((double)tt) > lim) { any = 1; tau[i] = tt > 0 ? lim : -lim; kdh[i] = 0; satmask |= (1u << i) | (tt > 0 ? (1u << (16 + i)) : 0u); }
         }
+        if (g_sat_log) g_sat_log[g_sat_n++] = satmask;
         if (any) aba_solve(m, &k, tau, kdh, qdd);
         for (int i = 0; i < n; i++) {
             const mppi_body_t *b = &m->bodies[i];
@@ -783,11 +790,13 @@ void orc_scene_step(const mppi_model_t *m, real *root, real *q, real *qd, const 
         }
         scene_aba(m, &si, fr, qd, tau, kdh, qdd, abase);
         int any = 0;
+        uint32_t satmask = 0;
         for (int i = 0; i < n; i++) {
             real lim = (real)m->bodies[i].effort;
             real tt = ff[i] + kd * (vs[i] - qd[i] - h * qdd[i]);
-            if (lim > 0 && (real)fabs((double)tt) > lim) { any = 1; tau[i] = tt > 0 ? lim : -lim; kdh[i] = 0; }
+            if (lim > 0 && (real)fabs((double)tt) > lim) { any = 1; tau[i] = tt > 0 ? lim : -lim; kdh[i] = 0; satmask |= (1u << i) | (tt > 0 ? (1u << (16 + i)) : 0u); }
         }
+        if (g_sat_log) g_sat_log[g_sat_n++] = satmask;
         if (any) scene_aba(m, &si, fr, qd, tau, kdh, qdd, abase);
         for (int i = 0; i < n; i++) {
             const mppi_body_t *b = &m->bodies[i];
@@ -1198,6 +1207,17 @@ void orc_envs_step(const mppi_model_t *m_nominal, int K, int g0, const real *u, 
         orc_rigid_body_state(m, r, q, qd, rb + (size_t)k * 13 * B, NULL);
         free(mine);
     }
+}
+
+/* diagnostics: the rollout of ONE sample k with its per-substep saturation sets written to log[H * substeps] */
+real orc_rollout_satlog(const mppi_model_t *m, const mppi_config_t *cfg, const mppi_cost_t *cost, const real *dof0, const real *root0,
+                        const real *U, const real *eps, int k, uint32_t *log) {
+    real *du = (real *)calloc((size_t)cfg->horizon * cfg->nu * cfg->num_samples, sizeof(real));
+    g_sat_log = log; g_sat_n = 0;
+    real S = rollout_one(m, cfg, cost, dof0, root0, U, eps, NULL, k, du, NULL);
+    g_sat_log = NULL;
+    free(du);
+    return S;
 }
 
 int orc_sizeof_real(void) { return (int)sizeof(real); }

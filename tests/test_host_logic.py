@@ -179,3 +179,43 @@ def test_unsupported_mppi_switches_are_refused_not_ignored():
             make_config(MPPIConfig(noise_sigma=[[1.0]], **kw))
     with pytest.raises(ValueError):
         make_config(MPPIConfig(noise_sigma=[[1.0]], mppi_mode="spline"))
+
+
+def test_transport_fast_path_is_byte_compatible_with_torch_save_and_load():
+    """torch_to_bytes / bytes_to_torch patch / view the payload of a cached torch.save archive: what they produce must load
+    with plain torch.load, what plain torch.save produces must load through them, for every dtype / shape the planner
+    exchanges; anything unusual takes the plain torch path"""
+    import io
+    import torch
+    from mppiisaac.utils import transport as T
+    T._SAVE_TEMPLATES.clear(); T._LOAD_LAYOUTS.clear()
+    g = torch.Generator().manual_seed(0)
+    for shape, dtype in (((1, 14), torch.float32), ((1, 2, 13), torch.float32), ((7,), torch.float32), ((12, 256, 3), torch.float32),
+                         ((3,), torch.float64), ((2, 2), torch.int64)):
+        for rep in range(3):   # 0: template built (slow path), 1..: patched template / cached layout
+            t = (torch.randn(shape, generator=g) * 10).to(dtype)
+            blob = T.torch_to_bytes(t)
+            ref = io.BytesIO(); torch.save(t, ref)
+            assert len(blob) == len(ref.getvalue())
+            assert torch.equal(torch.load(io.BytesIO(blob)), t)              # a stock peer reads our blob
+            assert torch.equal(T.bytes_to_torch(ref.getvalue()), t)          # we read a stock peer's blob
+            back = T.bytes_to_torch(blob, map_location="cpu")
+            assert torch.equal(back, t) and back.dtype == dtype and tuple(back.shape) == shape
+            back += 1                                                        # a private, writable copy
+    assert (torch.float32, (1, 14)) in T._SAVE_TEMPLATES and len(T._LOAD_LAYOUTS) >= 6
+    # a payload that does not match its CRC is not served from the fast path: torch.load decides what happens with it
+    t = torch.arange(14, dtype=torch.float32).reshape(1, 14)
+    blob = bytearray(T.torch_to_bytes(t))
+    off = T._SAVE_TEMPLATES[(torch.float32, (1, 14))][1]
+    blob[off + 1] ^= 0x40
+    calls = []
+    orig = torch.load
+    torch.load = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        got = T.bytes_to_torch(bytes(blob))
+    finally:
+        torch.load = orig
+    assert calls and torch.equal(got, orig(io.BytesIO(bytes(blob))))
+    # non-contiguous / grad tensors: plain torch path, same result
+    nc = torch.arange(12, dtype=torch.float32).reshape(3, 4).t()
+    assert torch.equal(torch.load(io.BytesIO(T.torch_to_bytes(nc))), nc)

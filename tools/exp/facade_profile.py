@@ -17,7 +17,12 @@ def it():
     a = bytes_to_torch(planner.compute_action_tensor(torch_to_bytes(world._dof_state), torch_to_bytes(world._root_state)))
     world.apply_robot_cmd(a.to(world.device).reshape(1, -1))
     world.step()
+import time
 for _ in range(20): it()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(500): it()
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 500
+print(f"bytes-API closed loop (compute_action_tensor + python world step): {1 / dt:.0f} Hz, {dt * 1e3:.3f} ms/iteration", flush=True)
 pr = cProfile.Profile(); pr.enable()
 for _ in range(300): it()
 torch.cuda.synchronize(); pr.disable()
