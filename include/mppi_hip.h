@@ -53,8 +53,42 @@ enum {
     MPPI_COST_POINT_REACH = 1, /* benchmarks/point_robot/mppi_planner/mppi_planner_wrapper.py:17-35 (nav term) */
     MPPI_COST_PANDA_REACH = 2, /* examples/panda/planner.py:22-40                           */
     MPPI_COST_BOXER_PUSH = 3,  /* examples/boxer_push/planner.py:26-67                      */
-    MPPI_COST_PANDA_PICK = 4   /* examples/panda_pick/planner.py:24-53                      */
+    MPPI_COST_PANDA_PICK = 4,  /* examples/panda_pick/planner.py:24-53                      */
+    MPPI_COST_PROGRAM = 5      /* a list of mppi_term_t: every Objective of examples/<x>/planner.py is a weighted sum of the
+                                * measurements below; evaluated inside the rollout kernels (contact scenes: the octet kernel;
+                                * contact-free scenes: the one-lane kernel)                                             */
 };
+/* measurements of a cost program (one value per env; mppiisaac/objectives.py holds the same algebra for generic mode) */
+enum {
+    MPPI_OP_DIST = 1,     /* || a[:n] - b[:n] ||                                                              */
+    MPPI_OP_TILT = 2,     /* size of the first two "ZYX" Euler angles of body a's quaternion read xyzw-as-(r,i,j,k), as the
+                           * reference's arm objectives do (examples/panda/planner.py:30-32)                    */
+    MPPI_OP_YAW_ABS = 3,  /* | yaw(quaternion of actor a) - p[3] |   (mppiisaac/utils/conversions.py:4-11)      */
+    MPPI_OP_ALIGN = 4,    /* 1 + cos of the planar angle at b between the rays to a and to c                   */
+    MPPI_OP_FORCE_L1 = 5, /* sum_j<n |net contact force of rigid body idx[0]|_j                                */
+    MPPI_OP_SPEED = 6,    /* || linear velocity of actor a [:n] ||                                             */
+    MPPI_OP_DOF_SQ = 7,   /* sum_{i = idx[0]}^{idx[1]-1} (x_i - p[i - idx[0]])^2, x = DOF positions (n = 0) / velocities (n = 1);
+                           * idx[2] = number of reference values given in p (0: none)                           */
+    MPPI_OP_ABS_DZ = 8,   /* | a.z - b.z |                                                                     */
+    MPPI_OP_BELOW = 9     /* max(p[3] - a.z, 0)                                                                */
+};
+/* where an operand's 3-vector comes from */
+enum {
+    MPPI_SRC_NONE = 0,
+    MPPI_SRC_RB = 1,      /* position (TILT: orientation) of rigid body idx - a robot link or a box / sphere body */
+    MPPI_SRC_ACTOR = 2,   /* root row of actor idx (position; SPEED: linear velocity; YAW_ABS: quaternion)      */
+    MPPI_SRC_DOF_XY = 3,  /* (q_0, q_1, 0): the planar base of the point robot                                 */
+    MPPI_SRC_CONST = 4    /* the constant (p[0], p[1], p[2])                                                   */
+};
+#define MPPI_MAX_TERMS 16
+typedef struct mppi_term {
+    int32_t op;        /* MPPI_OP_*                                                                     */
+    int32_t n;         /* number of components (DIST, FORCE_L1, SPEED); DOF_SQ: 0 positions, 1 velocities */
+    int32_t src[3];    /* MPPI_SRC_* of the operands a, b, c                                            */
+    int32_t idx[3];    /* their rigid-body / actor indices (DOF_SQ, FORCE_L1: see the op)               */
+    double w;          /* weight of the term                                                            */
+    double p[8];       /* constants (see the ops)                                                       */
+} mppi_term_t;
 /* noise sources of the sampler (mppi_mode / sampling_method of the conf/mppi files):
  *   HALTON_SPLINE  fixed low-discrepancy set: scrambled-Halton knots -> Phi^-1 -> B-spline (mppi_sample, once)
  *   EXTERNAL       the caller owns a device buffer eps [H][nu][K] (mppi_set_noise_dev)
@@ -201,6 +235,9 @@ typedef struct mppi_cost {
     int32_t link[4];       /* rigid-body / link indices used by the cost                 */
     int32_t actor[6];      /* actor indices used by the cost                             */
     double w[MPPI_MAX_COST_W]; /* weights / scalar parameters            */
+    int32_t n_terms;       /* MPPI_COST_PROGRAM: cost = sum_i terms[i].w * measurement_i        */
+    int32_t pad_;
+    mppi_term_t terms[MPPI_MAX_TERMS];
 } mppi_cost_t;
 
 typedef struct mppi_ctx mppi_ctx_t;

@@ -140,9 +140,21 @@ struct alignas(64) DevCfg {
     CtrlBlock u_min, u_max, inv_sigma;  // per control dimension, zero beyond nu; inv_sigma = 1 / noise_sigma[c][c]
 };
 
+// one term of a cost program (include/mppi_hip.h mppi_term_t after pack_cost): operand kinds are resolved for the device -
+// a rigid body is either a robot link (kSrcLink, robot-local index) or the single body of a box / sphere actor (kSrcActor)
+enum { kSrcNone = 0, kSrcLink = 1, kSrcActor = 2, kSrcDofXY = 3, kSrcConst = 4 };
+enum { kOpDist = 1, kOpTilt = 2, kOpYawAbs = 3, kOpAlign = 4, kOpForceL1 = 5, kOpSpeed = 6, kOpDofSq = 7, kOpAbsDz = 8, kOpBelow = 9 };
+constexpr int kMaxTerms = 16;
+struct DevTerm {
+    int op, n, src[3], idx[3];
+    float w, p[8];
+    int pad[3];
+};
 struct DevCost {
     int kind, link[4], actor[6], pad;
     float w[16];
+    int n_terms, pad2[3];
+    DevTerm t[kMaxTerms];
 };
 
 // Uniform (per-launch constant) structs are read through the CONSTANT address space on the GPU:
@@ -211,7 +223,7 @@ MPPI_HD P *launder(P *p) {
     return p;
 }
 
-enum { kCostNone = 0, kCostPointReach = 1, kCostPandaReach = 2, kCostBoxerPush = 3, kCostPandaPick = 4 };
+enum { kCostNone = 0, kCostPointReach = 1, kCostPandaReach = 2, kCostBoxerPush = 3, kCostPandaPick = 4, kCostProgram = 5 };
 enum { kDriveVelocity = 0, kDriveEffort = 1, kDrivePosition = 2 };
 
 // ---- compile-time kinematic tree -------------------------------------------------------
@@ -715,6 +727,81 @@ MPPI_HD void link_pose(M &m, const Pose<T> &P, int l, M3 &R, V3 &p) {
 
 MPPI_HD float clamp1(float x) { return fminf(fmaxf(x, -1.f), 1.f); }
 
+// ---- cost programs (MPPI_COST_PROGRAM) ------------------------------------------------------------------
+// cost = sum_i w_i * measurement_i over the term list of DevCost (every Objective of the reference's examples is such a
+// sum; include/mppi_hip.h MPPI_OP_*).  The term list is uniform over the wavefront, so every branch below is a scalar
+// branch.  `E` answers what the env looks like for THIS sample: actor rows (position / quaternion / velocity of the robot
+// base, the free actors, the static actors) and net contact forces; link poses come from the sample's kinematics `P`.
+template <class T, class M, class E>
+MPPI_HD float program_cost(M &m, CCost &c, const float *q, const float *qd, const Pose<T> &P, const E &env) {
+    float total = 0.f;
+    for (int it = 0; it < c.n_terms; it++) {
+        auto &t = c.t[it];
+        auto point = [&](int a) MPPI_LAMBDA {
+            const int src = t.src[a], idx = t.idx[a];
+            if (src == kSrcLink) {
+                M3 R;
+                V3 p;
+                link_pose<T>(m, P, idx, R, p);
+                return p;
+            }
+            if (src == kSrcActor) return env.vec(idx, 0);
+            if (src == kSrcDofXY) return V3{q[0], q[T::NB > 1 ? 1 : 0], 0.f};
+            if (src == kSrcConst) return V3{t.p[0], t.p[1], t.p[2]};
+            return V3{0.f, 0.f, 0.f};
+        };
+        float v = 0.f;
+        const int op = t.op;
+        if (op == kOpDist) {
+            const V3 d = point(0) - point(1);
+            v = fsqrt(d.x * d.x + d.y * d.y + (t.n > 2 ? d.z * d.z : 0.f));
+        } else if (op == kOpTilt) {
+            M3 R;
+            V3 p;
+            link_pose<T>(m, P, t.idx[0], R, p);
+            const float a0 = atan2f(R.a[7], -R.a[8]), a1 = asinf(clamp1(R.a[6]));  // see PANDA_REACH
+            v = fsqrt(a0 * a0 + a1 * a1);
+        } else if (op == kOpYawAbs) {
+            float qq[4];
+            env.quat(t.idx[0], qq);
+            v = fabsf(atan2f(2.f * (qq[3] * qq[2] + qq[0] * qq[1]), qq[3] * qq[3] + qq[0] * qq[0] - qq[1] * qq[1] - qq[2] * qq[2]) - t.p[3]);
+        } else if (op == kOpAlign) {
+            const V3 b = point(1), a = point(0) - b, cc = point(2) - b;
+            v = (a.x * cc.x + a.y * cc.y) * frcp(fsqrt(a.x * a.x + a.y * a.y) * fsqrt(cc.x * cc.x + cc.y * cc.y)) + 1.f;
+        } else if (op == kOpForceL1) {
+            v = fabsf(env.cf(t.idx[0], 0)) + (t.n > 1 ? fabsf(env.cf(t.idx[0], 1)) : 0.f) + (t.n > 2 ? fabsf(env.cf(t.idx[0], 2)) : 0.f);
+        } else if (op == kOpSpeed) {
+            const V3 u = env.vec(t.idx[0], 7);
+            v = fsqrt(u.x * u.x + (t.n > 1 ? u.y * u.y : 0.f) + (t.n > 2 ? u.z * u.z : 0.f));
+        } else if (op == kOpDofSq) {
+            const int lo = t.idx[0], hi = t.idx[1], nref = t.idx[2];
+            static_for<0, T::NB>([&](auto ic) MPPI_LAMBDA {
+                constexpr int i = ic;
+                if (i >= lo && i < hi) {
+                    const int j = i - lo;
+                    const float x = (t.n == 0 ? q[i] : qd[i]) - (j < nref ? t.p[j < 8 ? j : 7] : 0.f);
+                    v += x * x;
+                }
+            });
+        } else if (op == kOpAbsDz) {
+            v = fabsf(point(0).z - point(1).z);
+        } else if (op == kOpBelow) {
+            v = fmaxf(t.p[3] - point(0).z, 0.f);
+        }
+        total += t.w * v;
+    }
+    return total;
+}
+// env of a fixed-base contact-free scene: every actor row is the static x0 row, nothing touches anything
+struct StaticEnv {
+    const float *root;
+    MPPI_HD V3 vec(int actor, int off) const { return loadv(root + 13 * actor + off); }
+    MPPI_HD void quat(int actor, float *qq) const {
+        for (int j = 0; j < 4; j++) qq[j] = root[13 * actor + 3 + j];
+    }
+    MPPI_HD float cf(int, int) const { return 0.f; }
+};
+
 // Fused stage cost (DevCost.kind) for a given pose.  See include/mppi_hip.h for the reference Objective each restates.
 template <class T, class M>
 MPPI_HD float stage_cost_pose(M &m, CCost &c, const float *root, const float *q, const Pose<T> &P) {
@@ -742,6 +829,11 @@ MPPI_HD float stage_cost_pose(M &m, CCost &c, const float *root, const float *q,
 
 template <class T>
 MPPI_HD float stage_cost(CModel &m, CCost &c, const float *root, const float *q, const float *qd) {
+    if (c.kind == kCostProgram) {
+        Pose<T> P;
+        forward_kinematics<T>(m, root, q, P);
+        return program_cost<T>(m, c, q, qd, P, StaticEnv{root});
+    }
     if (c.kind != kCostPandaReach) {
         Pose<T> none;  // not read by the pose-free costs
         return stage_cost_pose<T>(m, c, root, q, none);

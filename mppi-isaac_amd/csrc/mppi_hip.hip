@@ -224,6 +224,7 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
             c->quad = !(mode && std::string(mode) == "lane");
             c->lanes_per_sample = c->quad ? 4 : 1;
             c->launch_rollout = c->quad ? e->rollout_quad : e->rollout;
+            c->launch_rollout_lane = e->rollout;  // cost programs on contact-free scenes run on the one-lane kernel
             c->launch_combine_world = e->combine_world;
             // many envs: quad step kernel; the K = 1 world (and tiny K) keeps the one-lane kernel
             c->launch_sim_step = (c->quad && cfg->num_samples >= 64) ? e->sim_step_quad : e->sim_step;
@@ -320,8 +321,11 @@ int mppi_set_cost(mppi_ctx_t *c, const mppi_cost_t *cost) {
     if (!cost) return fail(MPPI_EINVAL, "null cost");
     std::string err;
     DevCost hk;
-    if (!pack_cost(*cost, c->hm, hk, err)) return fail(cost->kind > MPPI_COST_PANDA_PICK || cost->kind < 0 ? MPPI_EINVAL : MPPI_EUNSUPPORTED, err);
+    if (!pack_cost(*cost, c->hm, hk, err)) return fail(cost->kind > MPPI_COST_PROGRAM || cost->kind < 0 || cost->kind == MPPI_COST_PROGRAM ? MPPI_EINVAL : MPPI_EUNSUPPORTED, err);
     c->hk = hk;
+    // MPPI_COST_PROGRAM on a contact-free scene: the quad kernel's in-line costs stay as they are (its instruction stream is
+    // the metric's); the interpreter lives in the one-lane kernel there, and in the scene kernels
+    c->prog_lane = hk.kind == kCostProgram && !c->scene && c->quad && c->launch_rollout_lane != nullptr;
     HIP_TRY(hipMemcpyAsync(c->d_cost, &c->hk, sizeof(DevCost), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->has_cost = true;
@@ -394,10 +398,14 @@ int mppi_rollout(mppi_ctx_t *c) {
     if (!c->has_cost) return fail(MPPI_ESTATE, "mppi_rollout: no fused cost set (mppi_set_cost); use the mppi_sim_* path for host-side costs");
     {
         EvScope ev(c, 0);
-        c->launch_rollout(c);
+        if (c->prog_lane) c->launch_rollout_lane(c);
+        else c->launch_rollout(c);
     }
     c->partials_valid = true;
-    if (c->fold) {  // the kernel's tail left one record per XCD group (ragged grids: one) in fold_out
+    if (c->prog_lane) {
+        c->n_partials = c->n_waves;
+        c->recs_cur = c->d_partials;
+    } else if (c->fold) {  // the kernel's tail left one record per XCD group (ragged grids: one) in fold_out
         c->n_partials = c->n_quads % 16 == 0 ? kFoldGroups : 1;
         c->recs_cur = c->fold_out;
     } else {

@@ -1109,6 +1109,8 @@ struct mppi_ctx {
     size_t ev_used[3] = {0, 0, 0}, ev_seen[3] = {0, 0, 0};
     int profile_period = 1;  // hipEvent brackets on every n-th launch
     void (*launch_rollout)(mppi_ctx *) = nullptr;
+    void (*launch_rollout_lane)(mppi_ctx *) = nullptr;  // one-lane kernel of a contact-free scene (cost programs)
+    bool prog_lane = false;
     void (*launch_sim_step)(mppi_ctx *, int, int, const float *) = nullptr;
     void (*launch_materialise)(mppi_ctx *, float *, float *, float *, float *) = nullptr;
     void (*launch_combine_world)(mppi_ctx *, const float *, int, mppi_ctx *) = nullptr;  // fused closed-loop tail (quad scenes)

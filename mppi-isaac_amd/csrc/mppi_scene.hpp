@@ -1124,11 +1124,48 @@ MPPI_HD float stage_cost_scene_link(M &m, CCost &c, const float *root, const Sce
     return c.w[0] * fsqrt(dot(drb, drb)) + c.w[1] * fsqrt(dot(dbg, dbg)) + c.w[2] * forces + c.w[3] * fsqrt(a0 * a0 + a1 * a1);
 }
 
+// env of a contact scene as a cost program sees it: the robot's root row is the sample's own base state, free actors their
+// own rows, everything else the static x0 rows; net contact forces from the sample's LDS rows
+template <class T, class M>
+struct SceneEnv {
+    M &m;
+    const float *root;
+    const SceneState<T> &s;
+    const LMem &L;
+    MPPI_HD float at(int actor, int j) const {
+        float v = root[13 * actor + j];
+        if (actor == m.robot_actor && m.floating) v = s.base[j];
+        for (int f = 0; f < kMaxFree; f++)
+            if (f < m.n_free && m.fr[f].actor == actor) v = s.fr[f][j];
+        return v;
+    }
+    MPPI_HD V3 vec(int actor, int off) const {
+        V3 o = loadv(root + 13 * actor + off);
+        if (actor == m.robot_actor && m.floating) o = loadv(s.base + off);
+        for (int f = 0; f < kMaxFree; f++)
+            if (f < m.n_free && m.fr[f].actor == actor) o = loadv(s.fr[f] + off);
+        return o;
+    }
+    MPPI_HD void quat(int actor, float *qq) const {
+        for (int j = 0; j < 4; j++) qq[j] = root[13 * actor + 3 + j];
+        if (actor == m.robot_actor && m.floating)
+            for (int j = 0; j < 4; j++) qq[j] = s.base[3 + j];
+        for (int f = 0; f < kMaxFree; f++)
+            if (f < m.n_free && m.fr[f].actor == actor)
+                for (int j = 0; j < 4; j++) qq[j] = s.fr[f][3 + j];
+    }
+    MPPI_HD float cf(int rb, int j) const { return L[SceneLayout<T>::kCf + 3 * rb + j]; }
+};
+
 template <class T, class M>
 MPPI_HD float stage_cost_scene(M &m, CCost &c, const float *root, const SceneState<T> &s, const LMem &L) {
     Pose<T> P;
     P.pb = loadv(s.base);
     P.Rb = quat_to_R(s.base + 3);
+    if (c.kind == kCostProgram) {
+        forward_kinematics_base<T>(m, s.q, P);
+        return program_cost<T>(m, c, s.q, s.qd, P, SceneEnv<T, M>{m, root, s, L});
+    }
     if (c.kind == kCostBoxerPush || c.kind == kCostPandaPick) {
         forward_kinematics_base<T>(m, s.q, P);
         M3 R;

@@ -17,7 +17,10 @@ ABI_VERSION = 2
 JOINT_REVOLUTE, JOINT_PRISMATIC = 0, 1
 DRIVE_VELOCITY, DRIVE_EFFORT, DRIVE_POSITION = 0, 1, 2
 ACTOR_ROBOT, ACTOR_BOX, ACTOR_SPHERE = 0, 1, 2
-COST_NONE, COST_POINT_REACH, COST_PANDA_REACH, COST_BOXER_PUSH, COST_PANDA_PICK = 0, 1, 2, 3, 4
+COST_NONE, COST_POINT_REACH, COST_PANDA_REACH, COST_BOXER_PUSH, COST_PANDA_PICK, COST_PROGRAM = 0, 1, 2, 3, 4, 5
+OP_DIST, OP_TILT, OP_YAW_ABS, OP_ALIGN, OP_FORCE_L1, OP_SPEED, OP_DOF_SQ, OP_ABS_DZ, OP_BELOW = 1, 2, 3, 4, 5, 6, 7, 8, 9
+SRC_NONE, SRC_RB, SRC_ACTOR, SRC_DOF_XY, SRC_CONST = 0, 1, 2, 3, 4
+MAX_TERMS = 16
 SAMPLE_HALTON_SPLINE, SAMPLE_EXTERNAL, SAMPLE_NORMAL = 0, 1, 2
 
 _d, _i = C.c_double, C.c_int32
@@ -68,8 +71,13 @@ class Config(C.Structure):
                 ("spline_basis", _d * (MAX_H * MAX_KNOTS))]
 
 
+class Term(C.Structure):
+    _fields_ = [("op", _i), ("n", _i), ("src", _i * 3), ("idx", _i * 3), ("w", _d), ("p", _d * 8)]
+
+
 class Cost(C.Structure):
-    _fields_ = [("kind", _i), ("link", _i * 4), ("actor", _i * 6), ("w", _d * MAX_COST_W)]
+    _fields_ = [("kind", _i), ("link", _i * 4), ("actor", _i * 6), ("w", _d * MAX_COST_W), ("n_terms", _i), ("pad_", _i),
+                ("terms", Term * MAX_TERMS)]
 
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -114,6 +114,70 @@ def evaluate(terms: Sequence[Term], weights: dict, sim) -> torch.Tensor:
     return total
 
 
+_OPS = {"dist": capi.OP_DIST, "tilt": capi.OP_TILT, "yaw_abs": capi.OP_YAW_ABS, "align": capi.OP_ALIGN, "force_l1": capi.OP_FORCE_L1,
+        "speed": capi.OP_SPEED, "dof_sq": capi.OP_DOF_SQ, "abs_dz": capi.OP_ABS_DZ, "below": capi.OP_BELOW}
+
+
+def compile_program(terms: Sequence[Term], weights: dict, scene) -> capi.Cost:
+    """Term list -> mppi_cost_t of kind MPPI_COST_PROGRAM for `scene` (Scene: name -> index lookups)."""
+    if len(terms) > capi.MAX_TERMS:
+        raise ValueError(f"{len(terms)} terms exceed MPPI_MAX_TERMS = {capi.MAX_TERMS}")
+    c = capi.Cost()
+    c.kind, c.n_terms = capi.COST_PROGRAM, len(terms)
+
+    def operand(t, slot, src):
+        if src[0] == "link":
+            t.src[slot], t.idx[slot] = capi.SRC_RB, scene.rigid_body_index(src[1], src[2])
+        elif src[0] == "actor":
+            t.src[slot], t.idx[slot] = capi.SRC_ACTOR, scene.actor_index(src[1])
+        elif src[0] == "dof_xy":
+            t.src[slot] = capi.SRC_DOF_XY
+        else:
+            if slot != 1:
+                raise ValueError("a constant point can only be the second operand of a term")
+            t.src[slot] = capi.SRC_CONST
+            for j in range(3):
+                t.p[j] = float(src[j])
+
+    for i, term in enumerate(terms):
+        t, a = c.terms[i], term.args
+        t.op = _OPS[term.op]
+        t.w = float(weights[term.weight] if isinstance(term.weight, str) else term.weight)
+        if term.op == "dist":
+            operand(t, 0, a[0]); operand(t, 1, a[1]); t.n = int(a[2])
+        elif term.op == "tilt":
+            operand(t, 0, a[0])
+            if t.src[0] != capi.SRC_RB:
+                raise ValueError("tilt needs a link operand")
+        elif term.op == "yaw_abs":
+            operand(t, 0, a[0]); t.p[3] = float(a[1])
+        elif term.op == "align":
+            operand(t, 0, a[0]); operand(t, 1, a[1]); operand(t, 2, a[2])
+        elif term.op == "force_l1":
+            t.src[0], t.idx[0], t.n = capi.SRC_RB, scene.rigid_body_index(a[0], a[1]), int(a[2])
+        elif term.op == "speed":
+            operand(t, 0, a[0]); t.n = int(a[1])
+            if t.src[0] != capi.SRC_ACTOR:
+                raise ValueError("speed needs an actor operand")
+        elif term.op == "dof_sq":
+            which, lo, hi, ref = a
+            n = scene.n_dof
+            t.n = 0 if which == "pos" else 1
+            t.idx[0], t.idx[1] = (n + lo if lo < 0 else lo), (n + hi if hi <= 0 else hi)
+            ref = list(ref or [])
+            if len(ref) > 8 or (ref and len(ref) != t.idx[1] - t.idx[0]):
+                raise ValueError("dof_sq: the reference needs one value per DOF of the range (at most 8)")
+            t.idx[2] = len(ref)
+            for j, v in enumerate(ref):
+                t.p[j] = float(v)
+        elif term.op == "abs_dz":
+            operand(t, 0, a[0])
+            operand(t, 1, (0.0, 0.0, float(a[1])) if isinstance(a[1], (int, float)) else a[1])
+        elif term.op == "below":
+            operand(t, 0, a[0]); t.p[3] = float(a[1])
+    return c
+
+
 class ProgramObjective(object):
     """Objective contract of the reference (compute_cost / reset / weights) over a term list."""
     graph_safe = True
@@ -131,6 +195,14 @@ class ProgramObjective(object):
 
     def compute_cost(self, sim):
         return evaluate(self.terms(), self.weights, sim)
+
+    def program_spec(self, sim) -> capi.Cost:
+        """the term list as an MPPI_COST_PROGRAM (include/mppi_hip.h): names resolved to rigid-body / actor indices of the
+        sim's scene, weights taken from `.weights` - evaluated inside the rollout kernel like the in-line kinds"""
+        return compile_program(self.terms(), self.weights, sim.scene)
+
+    def fused_spec(self, sim) -> capi.Cost:
+        return self.program_spec(sim)
 
     # shared by the fused specs: weight table -> mppi_cost_t.w in the order the kernel reads it
     def _spec(self, kind: int, order: Sequence[str]) -> capi.Cost:
@@ -317,7 +389,8 @@ class OmniPandaPickObjective(PandaPickObjective):
             Term("comfy_arm_pose", "dof_sq", ("pos", 3, 10, self.COMFY_ARM)),
             Term("height_cost", "below", (hand, self.MIN_HAND_HEIGHT))]
 
-    fused_spec = None  # no in-kernel form: runs in generic mode
+    def fused_spec(self, sim) -> capi.Cost:   # (the parent's in-line PANDA_PICK kind does not know the extra terms)
+        return self.program_spec(sim)
 
 
 class PandaStickPushObjective(ProgramObjective):

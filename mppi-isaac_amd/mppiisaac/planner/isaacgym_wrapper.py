@@ -162,9 +162,9 @@ class Scene:
         (isaacgym_wrapper.py:441), no robot self-collision; wheels/casters collide with the ground only."""
         shapes = []
         self.dropped_pairs = []  # (shape, shape) candidates the contact model leaves out on purpose
-        any_dynamic = any((not a.fixed) for a in self.env_cfg)
-        if not any_dynamic:
-            return [], []  # nothing can move into contact with anything that reacts: contact-free scene
+        # (a scene in which no candidate pair survives the filter below - e.g. a fixed-base arm and a collision-free goal -
+        # is contact-free: the contact-free kernels run it.  A FIXED-base robot still moves its links into static geometry:
+        # heijn_reach's base against the wall, an arm against a fixed obstacle sphere)
         for ai, a in enumerate(self.env_cfg):
             if not a.collision:
                 continue
@@ -223,6 +223,8 @@ class Scene:
                     raise NotImplementedError(f"sphere-sphere contact ({names[0]} / {names[1]}) is not implemented; set "
                                               "`collision: false` or `fixed: true` on one of the two actors")
                 pairs.append((i, j))
+        if not pairs:
+            return [], []  # nothing can come into contact with anything that reacts
         if len(shapes) > capi.MAX_SHAPES or len(pairs) > capi.MAX_PAIRS:
             raise ValueError(f"contact scene too large: {len(shapes)} shapes, {len(pairs)} pairs")
         if self.dropped_pairs:

@@ -841,7 +841,6 @@ void orc_scene_step(const mppi_model_t *m, real *root, real *q, real *qd, const 
 static real clamp1(real x) { return x > 1 ? 1 : (x < -1 ? -1 : x); }
 
 real orc_cost(const mppi_model_t *m, const mppi_cost_t *c, const real *root, const real *q, const real *qd, const real *rb, const real *cf) {
-    (void)m; (void)qd;
     switch (c->kind) {
     case MPPI_COST_POINT_REACH: {
         /* w_nav * || (x, y) - goal ||, x,y = DOF positions 0 and 1 (mppi_planner_wrapper.py:18-21,35) */
@@ -899,6 +898,76 @@ real orc_cost(const mppi_model_t *m, const mppi_cost_t *c, const real *root, con
         real a0 = (real)atan2((double)M10, (double)M00), a1 = (real)asin((double)clamp1(-M20));
         return (real)c->w[0] * (real)sqrt((double)d1) + (real)c->w[1] * (real)sqrt((double)d2) + (real)c->w[2] * forces
                + (real)c->w[3] * (real)sqrt((double)(a0 * a0 + a1 * a1));
+    }
+    case MPPI_COST_PROGRAM: {
+        /* a weighted sum of the measurements every Objective of the reference's examples/<x>/planner.py is built from
+         * (include/mppi_hip.h MPPI_OP_*): distances between link / actor positions, the tilt of a link (the ZYX-Euler quirk
+         * above), yaw error, push alignment, contact-force L1 norms, actor speed, DOF terms, height terms.  rb rows cover
+         * every rigid body of the env (robot links and box / sphere bodies), root rows every actor. */
+        real total = 0;
+        int n_dof = m->n_bodies;
+        for (int it = 0; it < c->n_terms; it++) {
+            const mppi_term_t *t = &c->terms[it];
+            real P[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+            for (int a = 0; a < 3; a++) {
+                const real *src = NULL;
+                if (t->src[a] == MPPI_SRC_RB) src = rb + 13 * t->idx[a];
+                else if (t->src[a] == MPPI_SRC_ACTOR) src = root + 13 * t->idx[a];
+                if (src) for (int j = 0; j < 3; j++) P[a][j] = src[j];
+                else if (t->src[a] == MPPI_SRC_DOF_XY) { P[a][0] = q[0]; P[a][1] = q[1]; }
+                else if (t->src[a] == MPPI_SRC_CONST) for (int j = 0; j < 3; j++) P[a][j] = (real)t->p[j];
+            }
+            real v = 0;
+            switch (t->op) {
+            case MPPI_OP_DIST: {
+                double s2 = 0;
+                for (int j = 0; j < t->n; j++) s2 += (double)(P[0][j] - P[1][j]) * (double)(P[0][j] - P[1][j]);
+                v = (real)sqrt(s2);
+                break;
+            }
+            case MPPI_OP_TILT: {
+                const real *ee = rb + 13 * t->idx[0];
+                real r = ee[3], i = ee[4], j = ee[5], kk = ee[6];
+                real two_s = 2 / (r * r + i * i + j * j + kk * kk);
+                real M00 = 1 - two_s * (j * j + kk * kk), M10 = two_s * (i * j + kk * r), M20 = two_s * (i * kk - j * r);
+                real a0 = (real)atan2((double)M10, (double)M00), a1 = (real)asin((double)clamp1(-M20));
+                v = (real)sqrt((double)(a0 * a0 + a1 * a1));
+                break;
+            }
+            case MPPI_OP_YAW_ABS: {
+                const real *qq = root + 13 * t->idx[0] + 3;
+                real yaw = (real)atan2((double)(2 * (qq[3] * qq[2] + qq[0] * qq[1])), (double)(qq[3] * qq[3] + qq[0] * qq[0] - qq[1] * qq[1] - qq[2] * qq[2]));
+                v = (real)fabs((double)(yaw - (real)t->p[3]));
+                break;
+            }
+            case MPPI_OP_ALIGN: {
+                real ax = P[0][0] - P[1][0], ay = P[0][1] - P[1][1], cx = P[2][0] - P[1][0], cy = P[2][1] - P[1][1];
+                v = (ax * cx + ay * cy) / ((real)sqrt((double)(ax * ax + ay * ay)) * (real)sqrt((double)(cx * cx + cy * cy))) + 1;
+                break;
+            }
+            case MPPI_OP_FORCE_L1:
+                if (cf) for (int j = 0; j < t->n; j++) v += (real)fabs((double)cf[3 * t->idx[0] + j]);
+                break;
+            case MPPI_OP_SPEED: {
+                const real *vv = root + 13 * t->idx[0] + 7;
+                double s2 = 0;
+                for (int j = 0; j < t->n; j++) s2 += (double)vv[j] * (double)vv[j];
+                v = (real)sqrt(s2);
+                break;
+            }
+            case MPPI_OP_DOF_SQ:
+                for (int i = t->idx[0]; i < t->idx[1] && i < n_dof; i++) {
+                    real x = (t->n == 0 ? q[i] : qd[i]) - (i - t->idx[0] < t->idx[2] ? (real)(float)t->p[i - t->idx[0]] : 0); /* fp32 constants, as the planners hold them */
+                    v += x * x;
+                }
+                break;
+            case MPPI_OP_ABS_DZ: v = (real)fabs((double)(P[0][2] - P[1][2])); break;
+            case MPPI_OP_BELOW: v = (real)t->p[3] - P[0][2]; if (v < 0) v = 0; break;
+            default: break;
+            }
+            total += (real)t->w * v;
+        }
+        return total;
     }
     default:
         return 0;

@@ -174,3 +174,48 @@ def test_oracle_stage_cost_matches_reference_objective(case, oracle64):
     q = np.zeros(16)
     got = [oracle64.cost(model, c, root[k], q, q, rb[k], cf[k]) for k in range(K)]
     np.testing.assert_allclose(got, g["cost"], rtol=1e-6, atol=1e-6)  # (weights travel as fp32 in mppi_cost_t)
+
+
+EXAMPLE_SCENES = {   # actors of the reference's example configs (examples/<x>/*.yaml), for name -> index resolution
+    "panda": ["panda_stick", "goal"], "boxer_push": ["boxer", "block", "paper_obst1", "paper_obst2", "goal"],
+    "panda_pick": ["panda_gripper", "xaxis", "yaxis", "panda_pick_block", "table", "goal"], "boxer_reach": ["boxer", "wall", "goal"],
+    "heijn_reach": ["heijn", "wall", "goal"], "heijn_push": ["heijn", "block", "paper_obst1", "paper_obst2", "goal"],
+    "albert": ["albert", "goal"], "omni_panda_pick": ["omnipanda_effort", "xaxis", "yaxis", "block2", "table2", "goal"],
+    "panda_effort": ["panda_effort", "goal"], "panda_stick_push": ["panda_stick", "xaxis", "yaxis", "panda_push_block", "table", "goal"]}
+
+
+@pytest.mark.parametrize("case", sorted(EXAMPLE_SCENES))
+def test_oracle_cost_program_matches_reference_objective(case, oracle64):
+    """MPPI_COST_PROGRAM: the term list of each Objective compiled for its example scene (names -> rigid-body / actor indices)
+    and evaluated by the oracle's interpreter (what the in-kernel interpreter is checked against) == the reference planner's
+    compute_cost on the same simulator answers (tests/golden/objective_costs.json)"""
+    import mppiisaac.objectives as objectives
+    from scenes import build_scene
+    g = gold("objective_costs.json")[case]
+    scene = build_scene(EXAMPLE_SCENES[case], [[0.0, 0.0, 0.05]])
+    m = scene.to_c()
+    obj = getattr(objectives, OBJECTIVES[case])(None)
+
+    class Sim:
+        pass
+    sim = Sim()
+    sim.scene = scene
+    spec = obj.program_spec(sim)
+    inp = {k: np.array(v) for k, v in g["inputs"].items()}
+    got = []
+    for k in range(len(g["cost"])):
+        rb, root, cf = np.zeros((m.n_rb, 13)), np.zeros((m.n_actors, 13)), np.zeros((m.n_rb, 3))
+        q, qd = np.zeros(16), np.zeros(16)
+        for key, val in inp.items():
+            kind, *names = key.split(":")
+            if kind == "link":
+                rb[scene.rigid_body_index(*names)] = val[k]
+            elif kind == "contact":
+                cf[scene.rigid_body_index(*names)] = val[k]
+            elif kind == "dof_state":
+                q[:scene.n_dof], qd[:scene.n_dof] = val[k][0::2][:scene.n_dof], val[k][1::2][:scene.n_dof]
+            else:
+                col = {"position": slice(0, 3), "orientation": slice(3, 7), "velocity": slice(7, 10)}[kind]
+                root[scene.actor_index(names[0]), col] = val[k]
+        got.append(oracle64.cost(m, spec, root, q, qd, rb, cf))
+    np.testing.assert_allclose(got, g["cost"], rtol=1e-6, atol=1e-6)   # (weights and constants travel through the C struct as doubles; fp32 refs)

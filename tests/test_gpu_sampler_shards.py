@@ -198,3 +198,65 @@ def test_config5_full_size_eight_shards_equal_one_context(lib, oracle64):
     assert len(idx) >= 64 and np.median(rel) < 1e-5
     assert (rel < 1e-4).all(), f"{(rel >= 1e-4).sum()} of {len(rel)} samples beyond 1e-4 (max {rel.max():.2e})"
     full.close()
+
+
+EXAMPLES = {   # example -> (actors, conf/mppi name, isaacgym conf, nx, robot init position, Objective)
+    "boxer_reach": (["boxer", "wall", "goal"], "boxer_reach", "normal", 4, [0.0, 0.0, 0.05], "BoxerReachObjective"),
+    "heijn_reach": (["heijn", "wall", "goal"], "heijn_reach", "normal", 6, [0.0, 0.0, 0.05], "HeijnReachObjective"),
+    "heijn_push": (["heijn", "block", "paper_obst1", "paper_obst2", "goal"], "heijn_push", "push", 6, [0.0, 1.5, 0.05], "HeijnPushObjective"),
+    "albert": (["albert", "goal"], "albert", "normal", 18, [0.0, 0.0, 0.05], "AlbertReachObjective"),
+    "omni_panda_pick": (["omnipanda_effort", "xaxis", "yaxis", "block2", "table2", "goal"], "omnipanda_effort", "pick", 24, [1.0, 2.0, 0.0], "OmniPandaPickObjective"),
+    "panda_stick_push": (["panda_stick", "xaxis", "yaxis", "panda_push_block", "table", "goal"], "panda_stick_push", "normal", 14, [0.0, 0.0, 0.0], "PandaStickPushObjective"),
+    "panda_effort": (["panda_effort", "goal"], "panda_effort", "normal", 14, [0.0, 0.0, 0.0], "PandaEffortReachObjective"),
+}
+
+
+@pytest.mark.parametrize("case", sorted(EXAMPLES))
+def test_example_objectives_run_fused_as_cost_programs(case, lib, oracle64):
+    """every example Objective of the reference on its own example scene (reference examples/<case>/*.yaml): the term list runs
+    INSIDE the rollout kernel (MPPI_COST_PROGRAM) and gives what the reference-shaped generic mode (Python compute_cost per
+    horizon step) and the oracle give"""
+    import mppiisaac.objectives as objectives
+    from mppiisaac.planner.isaacgym_wrapper import IsaacGymWrapper
+    from mppiisaac.planner.mppi_isaac import MPPIisaacPlanner
+    from mppiisaac.utils.config_store import load_config
+    from mppiisaac.utils.transport import bytes_to_torch, torch_to_bytes
+    actors, mppi, gym, nx, init, obj_name = EXAMPLES[case]
+    K, H = 256, 12
+    cfg = load_config({"defaults": [{"mppi": mppi}, {"isaacgym": gym}], "actors": actors, "initial_actor_positions": [init], "nx": nx},
+                      overrides={"mppi.num_samples": K, "mppi.horizon": H, "mppi.filter_u": False, "mppi.use_priors": False})
+    Obj = getattr(objectives, obj_name)
+
+    class Generic(Obj):
+        fused_spec = None
+    fused, generic = MPPIisaacPlanner(cfg, Obj(cfg)), MPPIisaacPlanner(cfg, Generic(cfg))
+    assert fused.mppi._fused_cost is not None and generic.mppi._fused_cost is None
+    kind = fused.mppi._fused_cost.kind
+    assert kind == (capi.COST_PANDA_REACH if case in ("albert", "panda_effort") else capi.COST_BOXER_PUSH if case == "heijn_push" else capi.COST_PROGRAM)
+    if kind != capi.COST_PROGRAM:   # these three have an in-line kind; force the interpreter for this test
+        fused.objective.fused_spec = fused.objective.program_spec
+    world = IsaacGymWrapper(cfg.isaacgym, actors=cfg.actors, init_positions=cfg.initial_actor_positions, num_envs=1)
+    for _ in range(5):   # let a floating robot settle on its wheels
+        world.step()
+    db, rbts = torch_to_bytes(world._dof_state.cpu()), torch_to_bytes(world._root_state.cpu())
+    af = bytes_to_torch(fused.compute_action_tensor(db, rbts)).numpy()
+    ag = bytes_to_torch(generic.compute_action_tensor(db, rbts)).numpy()
+    assert fused.mppi._fused_cost.kind == capi.COST_PROGRAM
+    Sf, Sg = fused.mppi.get_costs().numpy(), generic.mppi.get_costs().numpy()
+    rel = np.abs(Sf - Sg) / np.abs(Sf)
+    assert np.isfinite(Sf).all() and (rel <= 2e-3).mean() > 0.97, (np.sort(rel)[-5:])
+    umax = max(abs(float(v)) for v in cfg.mppi.u_max)
+    np.testing.assert_allclose(ag, af, atol=2e-3 * umax)
+    # and the oracle on a few samples
+    sim = fused.sim
+    eps = np.zeros((H, sim.scene.nu, K), np.float32)
+    capi.check(lib, lib.mppi_get_noise(sim._ctx, capi.fptr(eps)))
+    dof, root = world._dof_state[0].cpu().numpy(), world._root_state[0].cpu().numpy()
+    from mppiisaac.planner.mppi import make_config
+    spec = fused.objective.program_spec(sim)
+    ok = 0
+    for k in range(3, K, K // 8):
+        sc = make_config(cfg.mppi, k_offset=int(k), k_local=1, viz_link=sim.scene.viz_link_index())
+        So, _, _ = oracle64.rollout(sim._c_model, sc, spec, dof, root, np.zeros((H, sim.scene.nu)), eps[:, :, k:k + 1])
+        ok += abs(Sf[k] - So[0]) <= 2e-3 * abs(So[0])
+    assert ok >= 7
