@@ -216,7 +216,9 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
             c->launch_rollout = c->quad ? (oct ? e->rollout_scene_oct : e->rollout_scene_quad) : e->rollout_scene;
             c->launch_sim_step = c->quad ? e->sim_step_scene_quad : e->sim_step_scene;  // (the K = 1 world included: one quad)
             c->launch_materialise = e->materialise_scene;
-            if (hipSetDevice(device) == hipSuccess) lds_err = e->raise_lds(c->lds_bytes, c->lds_bytes_quad);
+            // (large scenes - e.g. the 12-DoF mobile manipulator with table and block - do not fit the one-lane kernels' 64 rows
+            // per wavefront into 160 KiB: those kernels are then simply not available, MPPI_ROLLOUT=lane is refused below)
+            if (hipSetDevice(device) == hipSuccess) lds_err = e->raise_lds(c->lds_bytes <= 160 * 1024 ? c->lds_bytes : 0, c->lds_bytes_quad);
         } else {
             // fixed-base contact-free scenes: one sample per 4-lane quad unless MPPI_ROLLOUT=lane asks for the
             // one-lane-per-sample kernel (kept for A/B measurements and as the reference arithmetic)
@@ -232,7 +234,7 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
         }
         break;
     }
-    if (ok && (c->lds_bytes > 160 * 1024 || c->lds_bytes_quad > 160 * 1024)) {
+    if (ok && ((c->quad ? 0 : c->lds_bytes) > 160 * 1024 || c->lds_bytes_quad > 160 * 1024)) {
         delete c;
         return fail(MPPI_EUNSUPPORTED, "contact scene needs more than 160 KiB of LDS per wavefront");
     }

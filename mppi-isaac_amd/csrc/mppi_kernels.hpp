@@ -1169,14 +1169,14 @@ void launch_materialise_scene_t(mppi_ctx *c, float *dof, float *root, float *rb,
                        c->d_fr, c->d_cf, dof, root, rb, cf);
 }
 template <class T>
-hipError_t raise_lds_limit(size_t lane_bytes, size_t quad_bytes) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rollout_scene<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lane_bytes);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rollout_scene_quad<T, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)quad_bytes);
+hipError_t raise_lds_limit(size_t lane_bytes, size_t quad_bytes) {  // lane_bytes == 0: the one-lane kernels are not used
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rollout_scene_quad<T, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)quad_bytes);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rollout_scene_quad<T, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)quad_bytes);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sim_step_scene_quad<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)quad_bytes);
+    if (e != hipSuccess || lane_bytes == 0) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rollout_scene<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lane_bytes);
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sim_step_scene<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lane_bytes);
 }
