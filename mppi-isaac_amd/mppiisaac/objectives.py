@@ -65,6 +65,17 @@ def _point(sim, src, like=None):
     return torch.as_tensor([float(v) for v in src], dtype=like.dtype, device=like.device).view(1, 3)
 
 
+_CONSTS = {}
+
+
+def _const_tensor(values: tuple, device) -> torch.Tensor:
+    """fp32 constant on `device`, created once (no host-to-device copy inside compute_cost: the horizon stays graph-capturable)"""
+    key = (values, str(device))
+    if key not in _CONSTS:
+        _CONSTS[key] = torch.tensor(values, dtype=torch.float32, device=device)
+    return _CONSTS[key]
+
+
 def _norm(v):
     return torch.sqrt(torch.sum(v * v, dim=1))
 
@@ -94,7 +105,7 @@ def _measure(sim, op: str, a: Tuple):
         lo = x.shape[1] + lo if lo < 0 else lo
         x = x[:, lo:hi]
         if ref is not None:
-            x = x - torch.tensor(ref, dtype=torch.float32, device=x.device)  # (fp32 constants, as the reference's planners hold them)
+            x = x - _const_tensor(tuple(float(v) for v in ref), x.device)  # (fp32 constants, as the reference's planners hold them)
         return torch.sum(x * x, dim=1)
     if op == "abs_dz":
         z = _point(sim, a[0])[:, 2]
