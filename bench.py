@@ -72,6 +72,8 @@ class Loop:
         cfg.mppi.device = f"cuda:{env['local_rank']}"
         self.cfg = cfg
         self.objective = getattr(objectives, wl["objective"])(cfg)
+        if os.environ.get("MPPI_BENCH_PROGRAM"):  # A/B: the same cost through the in-kernel term interpreter (MPPI_COST_PROGRAM)
+            self.objective.fused_spec = self.objective.program_spec
         self.planner = MPPIisaacPlanner(cfg, self.objective, shard=sharded)
         self.world = IsaacGymWrapper(cfg.isaacgym, actors=cfg.actors, init_positions=cfg.initial_actor_positions, num_envs=1,
                                      device=cfg.mppi.device)

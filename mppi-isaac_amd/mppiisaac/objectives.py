@@ -62,6 +62,8 @@ def _point(sim, src, like=None):
     if kind == "dof_xy":
         dof = sim.get_dof_state()
         return torch.stack((dof[:, 0], dof[:, 2], torch.zeros_like(dof[:, 0])), dim=1)
+    if like.dtype == torch.float32:
+        return _const_tensor(tuple(float(v) for v in src), like.device).view(1, 3)
     return torch.as_tensor([float(v) for v in src], dtype=like.dtype, device=like.device).view(1, 3)
 
 
