@@ -732,8 +732,9 @@ MPPI_HD float clamp1(float x) { return fminf(fmaxf(x, -1.f), 1.f); }
 // sum; include/mppi_hip.h MPPI_OP_*).  The term list is uniform over the wavefront, so every branch below is a scalar
 // branch.  `E` answers what the env looks like for THIS sample: actor rows (position / quaternion / velocity of the robot
 // base, the free actors, the static actors) and net contact forces; link poses come from the sample's kinematics `P`.
-template <class T, class M, class E>
-MPPI_HD float program_cost(M &m, CCost &c, const float *q, const float *qd, const Pose<T> &P, const E &env) {
+// `link_of(l, R, p)` yields the world pose of robot link l from whatever kinematics the caller holds.
+template <class T, class LP, class E>
+MPPI_HD float program_cost_with(CCost &c, const float *q, const float *qd, const LP &link_of, const E &env) {
     float total = 0.f;
     for (int it = 0; it < c.n_terms; it++) {
         auto &t = c.t[it];
@@ -742,7 +743,7 @@ MPPI_HD float program_cost(M &m, CCost &c, const float *q, const float *qd, cons
             if (src == kSrcLink) {
                 M3 R;
                 V3 p;
-                link_pose<T>(m, P, idx, R, p);
+                link_of(idx, R, p);
                 return p;
             }
             if (src == kSrcActor) return env.vec(idx, 0);
@@ -758,7 +759,7 @@ MPPI_HD float program_cost(M &m, CCost &c, const float *q, const float *qd, cons
         } else if (op == kOpTilt) {
             M3 R;
             V3 p;
-            link_pose<T>(m, P, t.idx[0], R, p);
+            link_of(t.idx[0], R, p);
             const float a0 = atan2f(R.a[7], -R.a[8]), a1 = asinf(clamp1(R.a[6]));  // see PANDA_REACH
             v = fsqrt(a0 * a0 + a1 * a1);
         } else if (op == kOpYawAbs) {
@@ -791,6 +792,10 @@ MPPI_HD float program_cost(M &m, CCost &c, const float *q, const float *qd, cons
         total += t.w * v;
     }
     return total;
+}
+template <class T, class M, class E>
+MPPI_HD float program_cost(M &m, CCost &c, const float *q, const float *qd, const Pose<T> &P, const E &env) {
+    return program_cost_with<T>(c, q, qd, [&](int l, M3 &R, V3 &p) MPPI_LAMBDA { link_pose<T>(m, P, l, R, p); }, env);
 }
 // env of a fixed-base contact-free scene: every actor row is the static x0 row, nothing touches anything
 struct StaticEnv {

@@ -350,10 +350,23 @@ MPPI_HD float step_tail_scene_quad(M &m, MR &mr, CCfg &cfg, CCost &c, const floa
                                    bool leader) {
     const bool want_viz = cfg.want_rollouts && viz != nullptr;
     const bool link_cost = c.kind == kCostBoxerPush || c.kind == kCostPandaPick;
+    const bool program = c.kind == kCostProgram;
     float cost;
     QPose<T> P;
-    if (link_cost || want_viz) quad_scene_pose<T>(mr, s, P);
-    if (link_cost) {
+    if (link_cost || want_viz || program) quad_scene_pose<T>(mr, s, P);
+    if (program) {  // link poses of a cost program from the quad-layout kinematics (gathered to replicated values)
+        cost = program_cost_with<T>(c, s.q, s.qd, [&](int l, M3 &R, V3 &p) MPPI_LAMBDA {
+            QM3 Rq;
+            QF pq;
+            quad_link_pose<T>(mr, P, l, Rq, pq);
+            for (int cc = 0; cc < 3; cc++) {
+                R.a[cc] = qget<0>(Rq.c[cc]);
+                R.a[3 + cc] = qget<1>(Rq.c[cc]);
+                R.a[6 + cc] = qget<2>(Rq.c[cc]);
+            }
+            p = qv3_gather(pq);
+        }, SceneEnv<T, M>{m, root, s, L});
+    } else if (link_cost) {
         QM3 Rq;
         QF pq;
         quad_link_pose<T>(mr, P, c.link[0], Rq, pq);
