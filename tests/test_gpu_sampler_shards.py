@@ -260,3 +260,25 @@ def test_example_objectives_run_fused_as_cost_programs(case, lib, oracle64):
         So, _, _ = oracle64.rollout(sim._c_model, sc, spec, dof, root, np.zeros((H, sim.scene.nu)), eps[:, :, k:k + 1])
         ok += abs(Sf[k] - So[0]) <= 2e-3 * abs(So[0])
     assert ok >= 7
+
+
+def test_every_example_scene_runs_closed_loop(lib):
+    """mppi-isaac_amd/examples/run.py: each example of the reference as shipped (its own conf/mppi file: K, H, lambda, noise,
+    sampler), planner + K=1 world through the bytes API for 40 control iterations: finite actions, and the example's own
+    stage cost of the WORLD state does not blow up (most of them fall)"""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mppi-isaac_amd", "examples", "run.py")
+    spec = importlib.util.spec_from_file_location("examples_run", path)
+    run = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(run)
+    improved = 0
+    for name in sorted(run.EXAMPLES):
+        cfg = run.config(name, filter_u=False)
+        planner = run.make_planner(name, cfg)
+        assert planner.mppi._fused_cost is not None, name            # every example objective runs inside the kernel
+        first, last, rate = run.run_world(name, cfg, planner, 40, report=False)
+        assert np.isfinite(last) and last < 5 * first + 5.0, (name, first, last)
+        improved += last < first
+        planner.sim.stop_sim()
+    assert improved >= 6
