@@ -35,6 +35,17 @@ def _worker(rank, world, port, out):
     records[rank] = torch.from_numpy(o.record(shard, S, du))
     allgather_records(records, rank)
     U, action, be = o.update(cfg_full, records.numpy(), U0)
+    # the folded layout of the contact-scene kernels: `per` records per shard (here: the shard cut into 4 groups of samples),
+    # written into this rank's rows and all-gathered in place - the combine of world * per records is the same update
+    per, Kl = 4, K // world
+    folded = torch.zeros((world * per, 2 + H * 7), dtype=torch.float64)
+    for g in range(per):
+        sub = make_config(ex.mppi, k_offset=rank * Kl + g * Kl // per, k_local=Kl // per, viz_link=scene.viz_link_index())
+        sl = slice(g * Kl // per, (g + 1) * Kl // per)
+        folded[rank * per + g] = torch.from_numpy(o.record(sub, S[sl], np.ascontiguousarray(du[:, :, sl])))
+    allgather_records(folded, rank, per=per)
+    Uf4, af4, bef4 = o.update(cfg_full, folded.numpy(), U0)
+    assert np.allclose(af4, action, rtol=1e-10, atol=1e-12) and np.allclose(Uf4, U, rtol=1e-10, atol=1e-12)
     if rank == 0:  # unsharded reference
         Sf, duf, _ = o.rollout(m, cfg_full, cost, dof, root, U0, o.sample(cfg_full))
         Uf, af, bef = o.update(cfg_full, o.record(cfg_full, Sf, duf), U0)
