@@ -604,7 +604,8 @@ int mppi_set_state_from_world(mppi_ctx_t *planner, mppi_ctx_t *world) {
 
 int mppi_set_wave_clock(mppi_ctx_t *c, int on) {
     CTX_TRY(c);
-    if (on && !c->d_wave_clk) ALLOC_TRY(c->d_wave_clk, sizeof(unsigned long long) * 2 * (size_t)(c->n_quads > c->n_waves ? c->n_quads : c->n_waves));
+    // (the instrumented build keeps 12 section counters per wavefront behind the [start, end] rows)
+    if (on && !c->d_wave_clk) ALLOC_TRY(c->d_wave_clk, sizeof(unsigned long long) * (2 + 12) * (size_t)(c->n_quads > c->n_waves ? c->n_quads : c->n_waves));
     c->wave_clk_on = on != 0;
     return MPPI_OK;
 }
@@ -617,6 +618,16 @@ int mppi_get_wave_clock(mppi_ctx_t *c, uint64_t *start_end_host, int n_wavefront
     HIP_TRY(hipStreamSynchronize(c->stream));
     return MPPI_OK;
 }
+#if defined(MPPI_SECTION_CLOCKS)
+/* instrumented build only: [n_wavefronts][12] shader-clock ticks per section of the last scene rollout */
+int mppi_get_section_clock(mppi_ctx_t *c, uint64_t *host, int n_wavefronts) {
+    CTX_TRY(c);
+    if (!c->d_wave_clk || !host || n_wavefronts != c->n_quads) return fail(MPPI_ESTATE, "mppi_get_section_clock: enable mppi_set_wave_clock first");
+    HIP_TRY(hipMemcpyAsync(host, c->d_wave_clk + 2 * (size_t)c->n_quads, sizeof(unsigned long long) * 12 * (size_t)c->n_quads, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MPPI_OK;
+}
+#endif
 int mppi_set_profiling(mppi_ctx_t *c, int on) {
     CTX_TRY(c);
     c->profiling = on != 0;

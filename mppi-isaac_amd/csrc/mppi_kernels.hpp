@@ -575,6 +575,10 @@ __global__ __launch_bounds__(kWave) void k_rollout_scene_quad(const DevModel *__
     constexpr int SPW = kWave / LPS;
     constexpr int kSplit = LPS == 8 ? kSplitOct : kSplitQuad;
     const unsigned long long clk0 = wave_clk != nullptr ? wall_clock64() : 0ull;
+#if defined(MPPI_SECTION_CLOCKS)
+    if (threadIdx.x <= kSections) section_counters()[threadIdx.x] = threadIdx.x == kSections ? __builtin_readcyclecounter() : 0ull;
+    __syncthreads();
+#endif
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // The robot part of the model (header, bodies, links: 4.3 KB) is staged in LDS for the quad-layout kinematics and
     // articulated-body solve; shapes, pairs and free bodies stay behind the scalar cache (staging the WHOLE model was
@@ -597,9 +601,13 @@ __global__ __launch_bounds__(kWave) void k_rollout_scene_quad(const DevModel *__
     }
     quad_record<SPW>(*(CCfg *)cfg, s, live && sub == 0, du, chunk * SPW, partials + (size_t)chunk * (2 + cfg->H * cfg->nu));
     fold_after_record(*(CCfg *)cfg, partials, fold_ctr, fold_out);
+    MPPI_SEC(10);
     if (wave_clk != nullptr && threadIdx.x == 0) {  // instrumentation (mppi_set_wave_clock): this wavefront's residency
         wave_clk[2 * chunk] = clk0;
         wave_clk[2 * chunk + 1] = wall_clock64();
+#if defined(MPPI_SECTION_CLOCKS)
+        for (int j = 0; j < kSections; j++) wave_clk[2 * (size_t)gridDim.x + (size_t)chunk * kSections + j] = section_counters()[j];
+#endif
     }
 #endif
 }

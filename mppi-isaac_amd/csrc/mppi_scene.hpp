@@ -21,6 +21,31 @@
 
 namespace mppi {
 
+// Section clocks (instrumented build only: MPPI_BUILD_VARIANT=sec -> -DMPPI_SECTION_CLOCKS, tools/exp/section_clocks.py):
+// MPPI_SEC(id) charges the shader-clock time since the previous mark to section `id`, per wavefront, in a small static LDS
+// array that the rollout kernel writes out behind its wave-clock rows.  Compiled out of the product build.
+#if defined(MPPI_SECTION_CLOCKS) && defined(__HIP_DEVICE_COMPILE__)
+constexpr int kSections = 12;
+__device__ __forceinline__ unsigned long long *section_counters() {
+    __shared__ unsigned long long s_sec[kSections + 1];
+    return s_sec;
+}
+#define MPPI_SEC(id)                                                   \
+    do {                                                               \
+        if ((threadIdx.x & 63) == 0) {                                 \
+            unsigned long long *sc_ = section_counters();              \
+            const unsigned long long now_ = __builtin_readcyclecounter(); \
+            sc_[id] += now_ - sc_[kSections];                          \
+            sc_[kSections] = now_;                                     \
+        }                                                              \
+    } while (0)
+#else
+#define MPPI_SEC(id) do { } while (0)
+#endif
+// section ids: 0 kinematics + frame stores, 1 accumulator clears + shape poses, 2 dealt broad phase, 3 pair loop,
+// 4 inertias / bias forces, 5 first articulated solve, 6 saturation check + second solve, 7 integration + free bodies,
+// 8 control sampling + command map, 9 stage cost + rollout point, 10 everything else (init, record tail)
+
 // per-sample indexed scratch ("working set staged in LDS"): element i of this lane lives at p[i*stride]
 struct LMem {
     float *p;
@@ -606,6 +631,7 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
     const SV zero = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
     constexpr bool kCached = SPLIT != kSplitNone;
     if constexpr (kCached) shape_cache_update<T>(m, root, L, SPLIT == kSplitEmulate ? Split{0, 1} : split, false);
+    MPPI_SEC(1);
     // Dealt broad phase (quad kernels of the larger trees, whose scenes carry a candidate pair per link and obstacle):
     // lane r of the quad tests the pairs r, r + 4, ... on its own and the verdicts are OR-ed over the quad; the pair
     // loop then visits only the survivors.  pair_broad_phase() restates the test of the loop body term by term - the
@@ -632,6 +658,7 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
         }
     }
 #endif
+    MPPI_SEC(2);
     for (int ip = 0; ip < m.n_pairs; ip++) {
         if constexpr (dealt_broad_phase<T>(SPLIT))
             if ((((ip < 32 ? alive_lo : alive_hi) >> (ip & 31)) & 1u) == 0u) continue;
@@ -811,6 +838,7 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
     }
     acc_dirty = touched;
     cf_dirty = cf_touched;
+    MPPI_SEC(3);
     return touched;
 }
 
@@ -1026,6 +1054,7 @@ MPPI_HD void step_scene(M &m0, const float *root, SceneState<T> &s, const float 
         Pose<T> P;
         SV vbase;
         scene_frames<T>(m, root, s, P, vbase, L);
+        MPPI_SEC(0);
         contact_forces<T, SPLIT>(m, root, L, s.acc_dirty, s.cf_dirty, split);
         float tau[NB ? NB : 1], kdh[NB ? NB : 1], qdd[NB ? NB : 1], ff[NB ? NB : 1], vs[NB ? NB : 1];
         static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
@@ -1037,6 +1066,7 @@ MPPI_HD void step_scene(M &m0, const float *root, SceneState<T> &s, const float 
         });
         SV abase;
         aba_scene<T>(m, P, vbase, s.qd, tau, kdh, L, qdd, abase);
+        MPPI_SEC(5);
         bool any = false;
         static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
             constexpr int i = ic;
@@ -1049,6 +1079,7 @@ MPPI_HD void step_scene(M &m0, const float *root, SceneState<T> &s, const float 
             }
         });
         if (any) aba_scene<T>(*launder(mp), P, vbase, s.qd, tau, kdh, L, qdd, abase);
+        MPPI_SEC(6);
         static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
             constexpr int i = ic;
             const BodyK1 b = load_block<BodyK1>(m.b[i].k1);
@@ -1064,6 +1095,7 @@ MPPI_HD void step_scene(M &m0, const float *root, SceneState<T> &s, const float 
         });
         if (m.floating) root_integrate(s.base, abase, h);
         step_free_bodies<T>(m, s, L, h);
+        MPPI_SEC(7);
     }
 }
 
@@ -1214,11 +1246,13 @@ MPPI_HD float rollout_scene(M &m0, MR &mr0, CCfg &cfg0, CCost &cost0, const floa
     M *mp = &m0;
     CCfg *cp = &cfg0;
     CCost *kp = &cost0;
+    MPPI_SEC(10);
     for (int t = 0; t < H; t++) {
         CCfg &cfg = *launder(cp);
         ctrl += sample_controls<(NB < kMaxNu ? (NB ? NB : 1) : kMaxNu)>(cfg, U, eps, prior, t, k, is_null, is_prior, leader, du, u);
         if constexpr (SPLIT == kSplitNone) cmd_map<T>(*launder(mp), u, target);
         else cmd_map<T>(mr0, u, target);  // (the kernel's LDS copy of the robot part: no scalar-cache round trips)
+        MPPI_SEC(8);
         step_scene_any<T, SPLIT>(*mp, mr0, root, s, target, L, split);
         if constexpr (SPLIT == kSplitNone || T::NB <= 4) {
             S += disc * stage_cost_scene<T>(*launder(mp), *launder(kp), root, s, L);
@@ -1238,6 +1272,7 @@ MPPI_HD float rollout_scene(M &m0, MR &mr0, CCfg &cfg0, CCost &cost0, const floa
         } else {
             S += disc * step_tail_scene_quad<T>(*launder(mp), mr0, cfg, *launder(kp), root, s, L, viz, t, k, leader);
         }
+        MPPI_SEC(9);
         disc *= cfg.gamma;
     }
     return S + ctrl;

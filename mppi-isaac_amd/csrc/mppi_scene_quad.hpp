@@ -299,6 +299,7 @@ MPPI_HD void step_scene_quad(M &m0, MR &mr0, const float *root, SceneState<T> &s
                     frame_store(L, NB + 1 + f, quat_to_R(rs + 3), p, SV{w, vl - cross(w, p)});
                 }
         }
+        MPPI_SEC(0);
         const unsigned touched = contact_forces<T, SPLIT>(m, root, L, s.acc_dirty, s.cf_dirty, split);
         QF tau[NBs], kdh[NBs], qdd[NBs], ff[NBs], vs[NBs];
         JointLimits lim[NBs];
@@ -313,7 +314,9 @@ MPPI_HD void step_scene_quad(M &m0, MR &mr0, const float *root, SceneState<T> &s
         SV abase;
         QAbaPrep<T> prep;
         quad_aba_prepare<T>(mr, P, vbase, qd, L, touched, prep, lim);
+        MPPI_SEC(4);
         quad_aba_solve<T>(mr, P, prep, tau, kdh, qdd, abase);
+        MPPI_SEC(5);
         bool any = false;
         static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
             constexpr int i = ic;
@@ -326,6 +329,7 @@ MPPI_HD void step_scene_quad(M &m0, MR &mr0, const float *root, SceneState<T> &s
             }
         });
         if (any) quad_aba_solve<T>(*launder(mrp), P, prep, tau, kdh, qdd, abase);
+        MPPI_SEC(6);
         static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
             constexpr int i = ic;
             const JointLimits b = lim[i];
@@ -340,6 +344,7 @@ MPPI_HD void step_scene_quad(M &m0, MR &mr0, const float *root, SceneState<T> &s
         });
         if (m.floating) root_integrate(s.base, abase, h);
         step_free_bodies<T>(mr, s, L, h);
+        MPPI_SEC(7);
     }
 }
 
