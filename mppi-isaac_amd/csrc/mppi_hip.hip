@@ -605,7 +605,7 @@ int mppi_set_state_from_world(mppi_ctx_t *planner, mppi_ctx_t *world) {
 int mppi_set_wave_clock(mppi_ctx_t *c, int on) {
     CTX_TRY(c);
     // (the instrumented build keeps 12 section counters per wavefront behind the [start, end] rows)
-    if (on && !c->d_wave_clk) ALLOC_TRY(c->d_wave_clk, sizeof(unsigned long long) * (2 + 12) * (size_t)(c->n_quads > c->n_waves ? c->n_quads : c->n_waves));
+    if (on && !c->d_wave_clk) ALLOC_TRY(c->d_wave_clk, sizeof(unsigned long long) * (2 + 16) * (size_t)(c->n_quads > c->n_waves ? c->n_quads : c->n_waves));
     c->wave_clk_on = on != 0;
     return MPPI_OK;
 }
@@ -623,7 +623,7 @@ int mppi_get_wave_clock(mppi_ctx_t *c, uint64_t *start_end_host, int n_wavefront
 int mppi_get_section_clock(mppi_ctx_t *c, uint64_t *host, int n_wavefronts) {
     CTX_TRY(c);
     if (!c->d_wave_clk || !host || n_wavefronts != c->n_quads) return fail(MPPI_ESTATE, "mppi_get_section_clock: enable mppi_set_wave_clock first");
-    HIP_TRY(hipMemcpyAsync(host, c->d_wave_clk + 2 * (size_t)c->n_quads, sizeof(unsigned long long) * 12 * (size_t)c->n_quads, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(host, c->d_wave_clk + 2 * (size_t)c->n_quads, sizeof(unsigned long long) * 16 * (size_t)c->n_quads, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return MPPI_OK;
 }

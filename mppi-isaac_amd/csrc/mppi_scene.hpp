@@ -25,7 +25,7 @@ namespace mppi {
 // MPPI_SEC(id) charges the shader-clock time since the previous mark to section `id`, per wavefront, in a small static LDS
 // array that the rollout kernel writes out behind its wave-clock rows.  Compiled out of the product build.
 #if defined(MPPI_SECTION_CLOCKS) && defined(__HIP_DEVICE_COMPILE__)
-constexpr int kSections = 12;
+constexpr int kSections = 16;
 __device__ __forceinline__ unsigned long long *section_counters() {
     __shared__ unsigned long long s_sec[kSections + 1];
     return s_sec;
@@ -41,6 +41,13 @@ __device__ __forceinline__ unsigned long long *section_counters() {
     } while (0)
 #else
 #define MPPI_SEC(id) do { } while (0)
+#endif
+// Duplication profiling (MPPI_BUILD_VARIANT=dup<k> -> -DMPPI_DUP=k, tools/exp/dup_costs.sh): section k of the pair loop is
+// executed TWICE with the second result thrown away (kept alive for the optimiser only), so the physics is bit-identical and
+// the kernel-time difference to the product build IS the cost of that section - no timer instructions in the way.
+#if defined(MPPI_DUP) && defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void dup_keep(float x) { asm volatile("" ::"v"(x)); }
+__device__ __forceinline__ float launder_zero() { float z = 0.f; asm volatile("" : "+v"(z)); return z; }  // a zero the optimiser cannot see
 #endif
 // section ids: 0 kinematics + frame stores, 1 accumulator clears + shape poses, 2 dealt broad phase, 3 pair loop,
 // 4 inertias / bias forces, 5 first articulated solve, 6 saturation check + second solve, 7 integration + free bodies,
@@ -113,6 +120,14 @@ template <class T, class M>
 MPPI_HD ActorDraw actor_draw(M &m, int a, const LMem &L) {
     const int slot = m.rnd_slot[a];
     if (slot < 0) return ActorDraw{{0.f, 0.f, 0.f}, 1.f, m.actor_mu[a]};
+    const int o = SceneLayout<T>::kCf + 3 * m.n_rb + 5 * slot;
+    return ActorDraw{{L[o], L[o + 1], L[o + 2]}, L[o + 3], L[o + 4]};
+}
+
+// the same by LDS slot (candidate pairs carry the slots of their two actors in PairGeom::rnd); slot < 0: nominal
+template <class T, class M>
+MPPI_HD ActorDraw actor_draw_slot(M &m, int slot, float mu_nominal, const LMem &L) {
+    if (slot < 0) return ActorDraw{{0.f, 0.f, 0.f}, 1.f, mu_nominal};
     const int o = SceneLayout<T>::kCf + 3 * m.n_rb + 5 * slot;
     return ActorDraw{{L[o], L[o + 1], L[o + 2]}, L[o + 3], L[o + 4]};
 }
@@ -569,16 +584,16 @@ MPPI_HD bool pair_broad_phase(M &m, int ip, const PairGeom &G, const float *root
     o.robotA = true;
     o.robotB = true;
     if (G.rnd) {  // this sample's own size of the noisy actors in the pair (friction and mass scale: see contact_forces)
-        auto &Cn = m.pr[ip].c;
-        o.robotA = Cn.robotA != 0;
-        o.robotB = Cn.robotB != 0 || !has_b;
-        if (!o.robotA) {
-            o.da = actor_draw<T>(m, Cn.actorA, L);
+        const int sa = ((G.rnd >> 8) & 15) - 1, sb = ((G.rnd >> 12) & 15) - 1;
+        o.robotA = sa < 0;
+        o.robotB = sb < 0;
+        if (sa >= 0) {
+            o.da = actor_draw_slot<T>(m, sa, 0.f, L);
             if (G.typeA == 0) for (int j = 0; j < 3; j++) hA[j] += 0.5f * o.da.d[j];
             else if (G.typeA == 1) hA[0] += o.da.d[0];
         }
-        if (!o.robotB) {
-            o.db = actor_draw<T>(m, Cn.actorB, L);
+        if (sb >= 0) {
+            o.db = actor_draw_slot<T>(m, sb, 0.f, L);
             if (G.typeB == 0) for (int j = 0; j < 3; j++) hB[j] += 0.5f * o.db.d[j];
             else if (G.typeB == 1) hB[0] += o.db.d[0];
         }
@@ -659,11 +674,35 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
     }
 #endif
     MPPI_SEC(2);
-    for (int ip = 0; ip < m.n_pairs; ip++) {
-        if constexpr (dealt_broad_phase<T>(SPLIT))
-            if ((((ip < 32 ? alive_lo : alive_hi) >> (ip & 31)) & 1u) == 0u) continue;
-        // geometry block of the pair: all the broad phase needs (no dependent loads of the two shape records)
-        const PairGeom G = load_block<PairGeom>(m.pr[ip].g);
+    // The loop visits the pairs that are alive (all of them without the dealt pass).  Both 64-byte blocks of the NEXT pair
+    // are requested while the current one is worked on: measured with the section clocks (tools/exp/section_clocks.py), a
+    // quarter of the whole kernel was the exposed latency of this preamble - scalar loads of the pair record, then the
+    // dependent LDS reads of the two shape poses, then the noise lookup behind two more dependent scalar loads.
+    auto next_alive = [&](int from) MPPI_LAMBDA {
+        if constexpr (dealt_broad_phase<T>(SPLIT)) {
+            if (m.n_pairs > kDealtBroadPhaseMin) {
+                const unsigned long long alive = (unsigned long long)alive_lo | ((unsigned long long)alive_hi << 32);
+                const unsigned long long rest = from < 64 ? alive >> from : 0ull;
+                return rest != 0ull ? from + (int)__builtin_ctzll(rest) : (int)m.n_pairs;
+            }
+        }
+        return from;
+    };
+    int next = next_alive(0);
+    PairGeom Gn;
+    PairGain Cn_;
+    if (next < m.n_pairs) {
+        Gn = load_block<PairGeom>(m.pr[next].g);
+        Cn_ = load_block<PairGain>(m.pr[next].c);
+    }
+    for (int ip = next; ip < m.n_pairs; ip = next) {
+        const PairGeom G = Gn;
+        const PairGain Cg = Cn_;
+        next = next_alive(ip + 1);
+        if (next < m.n_pairs) {
+            Gn = load_block<PairGeom>(m.pr[next].g);
+            Cn_ = load_block<PairGain>(m.pr[next].c);
+        }
         const bool has_b = G.b >= 0;
         ShapeW wa, wb;
         if constexpr (kCached) {
@@ -677,21 +716,39 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
         ActorDraw da = {{0.f, 0.f, 0.f}, 1.f, 0.f}, db = {{0.f, 0.f, 0.f}, 1.f, 0.f};
         bool robotA = true, robotB = true;
         if (G.rnd) {  // this sample's own size of the noisy actors in the pair (friction and mass scale: see below)
-            auto &Cn = m.pr[ip].c;
-            robotA = Cn.robotA != 0;
-            robotB = Cn.robotB != 0 || !has_b;
-            if (!robotA) {
-                da = actor_draw<T>(m, Cn.actorA, L);
+            const int sa = ((G.rnd >> 8) & 15) - 1, sb = ((G.rnd >> 12) & 15) - 1;
+            robotA = sa < 0;   // (here: "takes its nominal values")
+            robotB = sb < 0;
+            if (sa >= 0) {
+                da = actor_draw_slot<T>(m, sa, 0.f, L);
                 if (G.typeA == 0) for (int j = 0; j < 3; j++) hA[j] += 0.5f * da.d[j];
                 else if (G.typeA == 1) hA[0] += da.d[0];
             }
-            if (!robotB) {
-                db = actor_draw<T>(m, Cn.actorB, L);
+            if (sb >= 0) {
+                db = actor_draw_slot<T>(m, sb, 0.f, L);
                 if (G.typeB == 0) for (int j = 0; j < 3; j++) hB[j] += 0.5f * db.d[j];
                 else if (G.typeB == 1) hB[0] += db.d[0];
             }
         }
         const int typeA = G.typeA, typeB = G.typeB, rbB = G.rbB, entB = G.entB;
+#if defined(MPPI_DUP) && defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (MPPI_DUP == 1 && kCached) {  // the preamble again: pair record from memory, both shape poses, noise draws
+            const PairGeom G2 = load_block<PairGeom>(launder(&m)->pr[ip].g);
+            const ShapeW w2 = shape_cached<T>(m, G2.a, L);
+            float acc2 = w2.R.a[0] + w2.R.a[4] + w2.R.a[8] + w2.p.x + w2.p.y + w2.p.z + G2.hA[0];
+            if (G2.b >= 0) {
+                const ShapeW w3 = shape_cached<T>(m, G2.b, L);
+                acc2 += w3.R.a[1] + w3.R.a[5] + w3.R.a[6] + w3.p.x + w3.p.y + w3.p.z;
+            }
+            if (G2.rnd) {
+                const int sa2 = ((G2.rnd >> 8) & 15) - 1, sb2 = ((G2.rnd >> 12) & 15) - 1;
+                if (sa2 >= 0) { const ActorDraw d2 = actor_draw_slot<T>(m, sa2, 0.f, L); acc2 += d2.d[0] + d2.d[1] + d2.d[2]; }
+                if (sb2 >= 0) { const ActorDraw d2 = actor_draw_slot<T>(m, sb2, 0.f, L); acc2 += d2.d[0] + d2.d[1] + d2.d[2]; }
+            }
+            dup_keep(acc2);
+        }
+#endif
+        MPPI_SEC(11);  // pair record, shape poses, per-sample sizes
         // Broad phase: six-axis SAT for two boxes, otherwise the bounding sphere of one shape against the other shape's
         // box grown by that radius (both ways).  Conservative by construction (a margin covers rounding), so skipping
         // changes no result; it removes the 2 x 26 feature-point tests of the many link-vs-table / link-vs-block
@@ -732,9 +789,15 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
             }
         }
 #endif
+#if defined(MPPI_DUP) && defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (MPPI_DUP == 2) {
+            PairPose pp2;
+            dup_keep(pair_broad_phase<T, kCached>(m, ip, G, root, L, pp2) ? 1.f : 0.f);  // (poses + sizes + the SAT / sphere tests again)
+        }
+#endif
+        MPPI_SEC(12);  // broad-phase arithmetic
         if (apart) continue;
-        // contact law of the survivors: second block of the pair
-        const PairGain Cg = load_block<PairGain>(m.pr[ip].c);
+        // contact law of the survivors: second block of the pair (already here: requested one pair ahead)
         Gains P = {G.mode, Cg.mu, Cg.k, Cg.cn, Cg.ct, Cg.kh, Cg.inv_d0};
         if (G.rnd) {  // per-sample friction (min of the two) and contact gains scaled with the per-sample reacting mass
             const float mua = robotA ? Cg.muA : da.mu;
@@ -790,6 +853,7 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
                 else if (typeA == 0 && typeB == 1) sphere_in_box(P, wb.p, hB[0], wa, hA, -1.f, wa.v, wb.v, out);
             }
         };
+        MPPI_SEC(13);  // contact law, velocities
         // pairs with ONE analytic contact point (disc / sphere against the ground or a box): every lane of the sample computes
         // it - the lanes hold the same state, so the result is already identical in all of them and the cross-lane sum of the
         // pair's 31 partial values (more instructions than the contact itself) is not needed
@@ -814,6 +878,23 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
                 }
 #endif
         }
+#if defined(MPPI_DUP) && defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (MPPI_DUP == 3) {  // the feature points / analytic contact point of the pair again (no cross-lane sum)
+            PairAcc a2;
+            pair_zero(a2);
+            points(single_point ? Split{0, 1} : split, a2);
+            dup_keep(a2.f.a.x + a2.f.a.y + a2.f.a.z + a2.f.l.x + a2.f.l.y + a2.f.l.z + a2.rep.x + a2.C.I.xx + a2.C.I.yz + a2.C.M.zz + a2.C.H[1] + a2.C.H[5] + a2.C.H[6]);
+        }
+        if constexpr (MPPI_DUP == 4 && split_on_device(SPLIT)) {  // the cross-lane sum of a contact-bearing pair again
+            if (!single_point && __builtin_amdgcn_ballot_w64(acc.any) != 0) {
+                PairAcc a2 = acc;
+                if (G.mode == 0) group_reduce_explicit<SPLIT>(a2);
+                else group_reduce<SPLIT>(a2);
+                dup_keep(a2.f.a.x + a2.f.l.z + a2.rep.y + a2.C.I.xy + a2.C.M.xx + a2.C.H[3]);
+            }
+        }
+#endif
+        MPPI_SEC(14);  // feature points + cross-lane sum
         if (acc.any) {
             const SV neg = {{-acc.f.a.x, -acc.f.a.y, -acc.f.a.z}, {-acc.f.l.x, -acc.f.l.y, -acc.f.l.z}};
             if (G.mode == 0) {
@@ -835,6 +916,18 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
                 L[ob] -= acc.rep.x; L[ob + 1] -= acc.rep.y; L[ob + 2] -= acc.rep.z;
             }
         }
+#if defined(MPPI_DUP) && defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (MPPI_DUP == 5) {  // the same read-modify-write traffic on the accumulator rows with zeros
+            if (acc.any) {
+                PairAcc z2;
+                pair_zero(z2);
+                z2.f.a.x = launder_zero();
+                if (G.mode == 0) { acc_add(L, Lay::kAcc, G.entA, z2.f, nullptr); acc_add(L, Lay::kAcc, entB, z2.f, nullptr); }
+                else acc_add(L, Lay::kAcc, G.mode == 1 ? G.entA : entB, z2.f, &z2.C);
+            }
+        }
+#endif
+        MPPI_SEC(15);  // accumulate into the frames' LDS rows
     }
     acc_dirty = touched;
     cf_dirty = cf_touched;

@@ -15,7 +15,8 @@ from scenes import boxer_push, panda_pick
 
 NAMES = ["kinematics + frame stores", "acc clears + shape poses", "dealt broad phase", "pair loop (narrow phase, accumulate)", "inertias / bias (prepare)",
          "first articulated solve", "saturation check + second solve", "integration + free bodies", "controls + command map", "stage cost + viz",
-         "init + record tail", "-"]
+         "init + record tail", "pair: record, poses, sizes", "pair: broad-phase arithmetic", "pair: contact law, velocities", "pair: feature points + cross-lane sum",
+         "pair: accumulate into LDS rows"]
 lib = capi.load_library()
 lib.mppi_get_section_clock.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
 for name in (sys.argv[1:] or ["boxer_push", "panda_pick"]):
@@ -34,13 +35,13 @@ for name in (sys.argv[1:] or ["boxer_push", "panda_pick"]):
     for _ in range(2):
         capi.check(lib, lib.mppi_rollout(ctx))
     n = (K + 7) // 8
-    sec = np.zeros((n, 12), np.uint64)
+    sec = np.zeros((n, 16), np.uint64)
     capi.check(lib, lib.mppi_get_section_clock(ctx, sec.ctypes.data_as(C.POINTER(C.c_uint64)), n))
     sec = sec.astype(np.float64)
     tot = sec.sum(1)
     slow = tot >= np.percentile(tot, 95)
     print(f"{name}: {n} wavefronts; ticks per wavefront mean {tot.mean():.3e}, max {tot.max():.3e} (mean/max {tot.mean() / tot.max():.3f})")
-    for j in range(11):
+    for j in range(16):
         print(f"   {NAMES[j]:40s} {100 * sec[:, j].sum() / tot.sum():5.1f} %   slowest 5 %: {100 * sec[slow, j].sum() / tot[slow].sum():5.1f} %   "
               f"(extra ticks of the slow ones: {sec[slow, j].mean() - sec[:, j].mean():+.2e})")
     lib.mppi_destroy(ctx)
