@@ -242,6 +242,27 @@ MPPI_HD void acc_add(const LMem &L, int base, int ent, const SV &f, const AI *C)
         L[o + 21] += C->M.xx; L[o + 22] += C->M.xy; L[o + 23] += C->M.xz; L[o + 24] += C->M.yy; L[o + 25] += C->M.yz; L[o + 26] += C->M.zz;
     }
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+// x += v inside the LDS unit (ds_add_f32, no return value): one instruction and no read - wait - add - write round trip
+__device__ __forceinline__ void lds_add(float &x, float v) { (void)__hip_atomic_fetch_add(&x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// The same accumulation for the kernels whose lanes share a sample: after the cross-lane sum every lane of the sample holds
+// the same totals, so ONE lane (`leader`) adds them, with LDS float adds.  One lane per address and LDS operations of a
+// wavefront execute in order: the result is deterministic and is the same IEEE sum as the read-modify-write above.
+// Measured by duplication (tools/exp/dup_costs.sh): the read-modify-write version was 21 % of the pushing scene's rollout.
+__device__ __forceinline__ void acc_add_shared(const LMem &L, int base, int ent, const SV &f, const AI *C, bool leader) {
+    if (!leader) return;
+    const int o = base + ent * 27;
+    lds_add(L[o + 0], f.a.x); lds_add(L[o + 1], f.a.y); lds_add(L[o + 2], f.a.z);
+    lds_add(L[o + 3], f.l.x); lds_add(L[o + 4], f.l.y); lds_add(L[o + 5], f.l.z);
+    if (C != nullptr) {
+        lds_add(L[o + 6], C->I.xx); lds_add(L[o + 7], C->I.xy); lds_add(L[o + 8], C->I.xz);
+        lds_add(L[o + 9], C->I.yy); lds_add(L[o + 10], C->I.yz); lds_add(L[o + 11], C->I.zz);
+        for (int j = 0; j < 9; j++) lds_add(L[o + 12 + j], C->H[j]);
+        lds_add(L[o + 21], C->M.xx); lds_add(L[o + 22], C->M.xy); lds_add(L[o + 23], C->M.xz);
+        lds_add(L[o + 24], C->M.yy); lds_add(L[o + 25], C->M.yz); lds_add(L[o + 26], C->M.zz);
+    }
+}
+#endif
 MPPI_HD void acc_load(const LMem &L, int base, int ent, SV &f, AI &C) {
     const int o = base + ent * 27;
     f = {{L[o + 0], L[o + 1], L[o + 2]}, {L[o + 3], L[o + 4], L[o + 5]}};
@@ -395,6 +416,43 @@ MPPI_HD void contact_point(const Gains &P, V3 p, V3 n, float depth, const SV &vA
     acc.C.M.yy += b + ab * n.y * n.y; acc.C.M.yz += ab * n.y * n.z; acc.C.M.zz += b + ab * n.z * n.z;
     // reported force = penalty force evaluated with the substep's start velocities
     acc.rep = acc.rep + f - (ab * vn) * n - b * vr;
+}
+
+// The same contact law against the ground plane z = 0 (unit normal +z, static partner): contact_point with n = (0, 0, 1) and
+// vB = 0 written out.  Without fast-math the compiler may not drop the products with the zero components of n (NaN / Inf
+// semantics), so the general form costs ~170 instructions per point where ~100 do; only exact-zero terms are dropped, the
+// results are the same bits.  Ground pairs are always "dynamic body against static geometry" (implicit).
+MPPI_HD void contact_point_ground(const Gains &P, V3 p, float depth, const SV &vA, PairAcc &acc) {
+    const V3 vr = vel_at(vA, p);
+    const float vn = vr.z;
+    const float vtn = fsqrt(vr.x * vr.x + vr.y * vr.y);
+    acc.any = true;
+    const float ramp = P.inv_d0 > 0.f ? fminf(1.f, depth * P.inv_d0) : 1.f;
+    float a = ramp * (P.cn + P.kh);
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const float cap = P.k * depth * __builtin_amdgcn_rcpf(fmaxf(vn, 1e-30f));
+#else
+        const float cap = P.k * depth / fmaxf(vn, 1e-30f);
+#endif
+        a = vn > 0.f ? fminf(a, cap) : a;
+    }
+    const float fn = fmaxf(0.f, P.k * depth - a * vn);
+    const float b = fminf(P.ct, P.mu * fn * frcp(vtn + 1e-9f));
+    const float fz = P.k * depth;
+    acc.f.a.x += p.y * fz; acc.f.a.y += -(p.x * fz);  // p x (0, 0, fz)
+    acc.f.l.z += fz;
+    const float ab = a - b;
+    const float mx = p.y, my = -p.x;  // p x n
+    const float pp = dot(p, p);
+    acc.C.I.xx += b * (pp - p.x * p.x) + ab * mx * mx; acc.C.I.xy += -b * p.x * p.y + ab * mx * my;
+    acc.C.I.xz += -b * p.x * p.z;                      acc.C.I.yy += b * (pp - p.y * p.y) + ab * my * my;
+    acc.C.I.yz += -b * p.y * p.z;                      acc.C.I.zz += b * (pp - p.z * p.z);
+    acc.C.H[1] += -b * p.z;  acc.C.H[2] += b * p.y + ab * mx;
+    acc.C.H[3] += b * p.z;   acc.C.H[5] += -b * p.x + ab * my;
+    acc.C.H[6] += -b * p.y;  acc.C.H[7] += b * p.x;
+    acc.C.M.xx += b; acc.C.M.yy += b; acc.C.M.zz += b + ab;
+    acc.rep.x += -(b * vr.x); acc.rep.y += -(b * vr.y); acc.rep.z += fz - ab * vn - b * vr.z;
 }
 
 struct ShapeW {
@@ -817,24 +875,23 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
         }
         auto points = [&](Split sp, PairAcc &out) MPPI_LAMBDA {
             if (!has_b) {  // ground plane z = 0, normal +z (from ground to A)
-                const V3 ez = {0.f, 0.f, 1.f};
                 if (typeA == 0) {
                     for (int c = sp.sub; c < 8; c += sp.n) {
                         V3 loc = {(c & 1) ? hA[0] : -hA[0], (c & 2) ? hA[1] : -hA[1], (c & 4) ? hA[2] : -hA[2]};
                         V3 pw = wa.p + mul(wa.R, loc);
-                        if (pw.z < 0.f) contact_point(P, pw, ez, -pw.z, wa.v, zero, out);
+                        if (pw.z < 0.f) contact_point_ground(P, pw, -pw.z, wa.v, out);
                     }
                 } else if (sp.sub == 0) {
                     if (typeA == 1) {
                         V3 pw = {wa.p.x, wa.p.y, wa.p.z - hA[0]};
-                        if (pw.z < 0.f) contact_point(P, pw, ez, -pw.z, wa.v, zero, out);
+                        if (pw.z < 0.f) contact_point_ground(P, pw, -pw.z, wa.v, out);
                     } else {  // disc: lowest point of the rim, axis = local z
                         V3 ax = {wa.R.a[2], wa.R.a[5], wa.R.a[8]};
                         V3 d = {ax.z * ax.x, ax.z * ax.y, ax.z * ax.z - 1.f};
                         float l2 = dot(d, d);
                         if (l2 > 1e-8f) {
                             V3 pw = wa.p + (hA[0] * frsqrt(l2)) * d;
-                            if (pw.z < 0.f) contact_point(P, pw, ez, -pw.z, wa.v, zero, out);
+                            if (pw.z < 0.f) contact_point_ground(P, pw, -pw.z, wa.v, out);
                         }
                     }
                 }
@@ -897,23 +954,35 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
         MPPI_SEC(14);  // feature points + cross-lane sum
         if (acc.any) {
             const SV neg = {{-acc.f.a.x, -acc.f.a.y, -acc.f.a.z}, {-acc.f.l.x, -acc.f.l.y, -acc.f.l.z}};
-            if (G.mode == 0) {
-                touched |= (1u << G.entA) | (1u << entB);
-                acc_add(L, Lay::kAcc, G.entA, acc.f, nullptr);
-                acc_add(L, Lay::kAcc, entB, neg, nullptr);
-            } else if (G.mode == 1) {
-                touched |= 1u << G.entA;
-                acc_add(L, Lay::kAcc, G.entA, acc.f, &acc.C);
-            } else {
-                touched |= 1u << entB;
-                acc_add(L, Lay::kAcc, entB, neg, &acc.C);
-            }
-            const int ocf = Lay::kCf + 3 * G.rbA;
-            L[ocf] += acc.rep.x; L[ocf + 1] += acc.rep.y; L[ocf + 2] += acc.rep.z;
+            const int ocf = Lay::kCf + 3 * G.rbA, ob = Lay::kCf + 3 * (rbB >= 0 ? rbB : 0);
             cf_touched |= (1u << (G.rbA & 31)) | (rbB >= 0 ? 1u << (rbB & 31) : 0u);
-            if (rbB >= 0) {
-                const int ob = Lay::kCf + 3 * rbB;
-                L[ob] -= acc.rep.x; L[ob + 1] -= acc.rep.y; L[ob + 2] -= acc.rep.z;
+            touched |= G.mode == 0 ? (1u << G.entA) | (1u << entB) : (G.mode == 1 ? 1u << G.entA : 1u << entB);
+#if defined(__HIP_DEVICE_COMPILE__)
+            if constexpr (split_on_device(SPLIT)) {
+                const bool leader = split.sub == 0;
+                if (G.mode == 0) {
+                    acc_add_shared(L, Lay::kAcc, G.entA, acc.f, nullptr, leader);
+                    acc_add_shared(L, Lay::kAcc, entB, neg, nullptr, leader);
+                } else {
+                    acc_add_shared(L, Lay::kAcc, G.mode == 1 ? G.entA : entB, G.mode == 1 ? acc.f : neg, &acc.C, leader);
+                }
+                if (leader) {
+                    lds_add(L[ocf], acc.rep.x); lds_add(L[ocf + 1], acc.rep.y); lds_add(L[ocf + 2], acc.rep.z);
+                    if (rbB >= 0) { lds_add(L[ob], -acc.rep.x); lds_add(L[ob + 1], -acc.rep.y); lds_add(L[ob + 2], -acc.rep.z); }
+                }
+            } else
+#endif
+            {
+                if (G.mode == 0) {
+                    acc_add(L, Lay::kAcc, G.entA, acc.f, nullptr);
+                    acc_add(L, Lay::kAcc, entB, neg, nullptr);
+                } else if (G.mode == 1) {
+                    acc_add(L, Lay::kAcc, G.entA, acc.f, &acc.C);
+                } else {
+                    acc_add(L, Lay::kAcc, entB, neg, &acc.C);
+                }
+                L[ocf] += acc.rep.x; L[ocf + 1] += acc.rep.y; L[ocf + 2] += acc.rep.z;
+                if (rbB >= 0) { L[ob] -= acc.rep.x; L[ob + 1] -= acc.rep.y; L[ob + 2] -= acc.rep.z; }
             }
         }
 #if defined(MPPI_DUP) && defined(__HIP_DEVICE_COMPILE__)
