@@ -206,6 +206,7 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
         if (c->scene) {
             c->lds_bytes = sizeof(float) * kWave * (e->scene_lds_floats + 3 * (size_t)c->hm.n_rb + 5 * (size_t)c->hm.n_rnd);
             c->lds_bytes_quad = sizeof(float) * 16 * (e->scene_lds_floats + 3 * (size_t)c->hm.n_rb + 5 * (size_t)c->hm.n_rnd + 12 * (size_t)c->hm.n_shapes);
+            c->lds_bytes_table = sizeof(unsigned) * (size_t)scene_table_dwords(c->hm.n_shapes, c->hm.n_pairs);
             // rollouts: 4 lanes per sample (contact points dealt over the quad) unless MPPI_ROLLOUT=lane
             const char *mode = std::getenv("MPPI_ROLLOUT");
             c->quad = !(mode && std::string(mode) == "lane");
@@ -218,7 +219,7 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
             c->launch_materialise = e->materialise_scene;
             // (large scenes - e.g. the 12-DoF mobile manipulator with table and block - do not fit the one-lane kernels' 64 rows
             // per wavefront into 160 KiB: those kernels are then simply not available, MPPI_ROLLOUT=lane is refused below)
-            if (hipSetDevice(device) == hipSuccess) lds_err = e->raise_lds(c->lds_bytes <= 160 * 1024 ? c->lds_bytes : 0, c->lds_bytes_quad);
+            if (hipSetDevice(device) == hipSuccess) lds_err = e->raise_lds(c->lds_bytes <= 160 * 1024 ? c->lds_bytes : 0, c->lds_bytes_quad + c->lds_bytes_table);
         } else {
             // fixed-base contact-free scenes: one sample per 4-lane quad unless MPPI_ROLLOUT=lane asks for the
             // one-lane-per-sample kernel (kept for A/B measurements and as the reference arithmetic)
@@ -234,7 +235,7 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
         }
         break;
     }
-    if (ok && ((c->quad ? 0 : c->lds_bytes) > 160 * 1024 || c->lds_bytes_quad > 160 * 1024)) {
+    if (ok && ((c->quad ? 0 : c->lds_bytes) > 160 * 1024 || c->lds_bytes_quad + c->lds_bytes_table > 160 * 1024)) {
         delete c;
         return fail(MPPI_EUNSUPPORTED, "contact scene needs more than 160 KiB of LDS per wavefront");
     }

@@ -593,7 +593,11 @@ __global__ __launch_bounds__(kWave) void k_rollout_scene_quad(const DevModel *__
     const int k = chunk * SPW + (threadIdx.x / LPS);
     const int sub = threadIdx.x & (LPS - 1);
     const bool live = k < cfg->K;
-    const LMem L{lds + (threadIdx.x / LPS), SPW};
+    // behind the SPW-wide sample rows: the wave-shared table of shape records and pair geometry blocks (scene_table_fill)
+    unsigned *tab = reinterpret_cast<unsigned *>(lds + (size_t)SPW * scene_row_floats<T>(*(CModel *)m));
+    scene_table_fill(*(CModel *)m, tab, threadIdx.x, kWave);
+    __syncthreads();
+    const LMem L{lds + (threadIdx.x / LPS), SPW, tab};
     float s = INFINITY;
     if (live) {
         s = rollout_scene<T, kSplit>(*(CModel *)m, lm, *(CCfg *)cfg, *(CCost *)cost, x0_dof, x0_root, U, eps, prior, du, viz, k, L, Split{sub, LPS});
@@ -1101,6 +1105,7 @@ struct mppi_ctx {
     bool use_filter = false;
     bool scene = false;
     size_t lds_bytes = 0, lds_bytes_quad = 0;  // dynamic LDS of the lane-per-sample / quad-per-sample scene kernels
+    size_t lds_bytes_table = 0;                // ... plus the wave-shared shape / pair table of the shared-lane rollout kernels
     double *d_basis = nullptr, *d_sigma = nullptr;
     const float *eps_in = nullptr;  // d_eps or an external noise buffer
     bool has_prior = false, has_cost = false, profiling = false;
@@ -1157,7 +1162,7 @@ void launch_rollout_scene_t(mppi_ctx *c) {
 }
 template <class T, int LPS>
 void launch_rollout_scene_quad_t(mppi_ctx *c) {
-    hipLaunchKernelGGL((k_rollout_scene_quad<T, LPS>), dim3(c->n_quads), dim3(kWave), c->lds_bytes_quad * (kWave / LPS) / 16, c->stream, c->d_model, c->d_cfg, c->d_cost, c->d_x0_dof,
+    hipLaunchKernelGGL((k_rollout_scene_quad<T, LPS>), dim3(c->n_quads), dim3(kWave), c->lds_bytes_quad * (kWave / LPS) / 16 + c->lds_bytes_table, c->stream, c->d_model, c->d_cfg, c->d_cost, c->d_x0_dof,
                        c->d_x0_root, c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_S, c->cfg.want_rollouts ? c->d_viz : nullptr,
                        c->d_partials, c->fold ? c->d_fold_ctr : nullptr, c->fold_out, c->wave_clk_on ? c->d_wave_clk : nullptr);
 }

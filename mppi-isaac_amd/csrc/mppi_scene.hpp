@@ -57,8 +57,42 @@ __device__ __forceinline__ float launder_zero() { float z = 0.f; asm volatile(""
 struct LMem {
     float *p;
     int stride;
+    // wave-shared copy of the model's shape records and pair geometry blocks (rollout kernels whose lanes share a sample:
+    // the dealt passes index them PER LANE, which through the constant address space means 64-byte vector loads from
+    // memory per lane and trip; from LDS it is four ds_read_b128).  Null: read the model.
+    const unsigned *tab = nullptr;
     MPPI_HD float &operator[](int i) const { return p[(size_t)i * stride]; }
 };
+// layout of the table: n_shapes records of kTabShape dwords (DevShape as is), then n_pairs geometry blocks of 16 dwords
+constexpr int kTabShape = (int)(sizeof(DevShape) / 4);
+static_assert(sizeof(DevShape) == 80 && sizeof(PairGeom) == 64 && sizeof(DevPair) == 128, "table layout");
+MPPI_HD constexpr int scene_table_dwords(int n_shapes, int n_pairs) { return kTabShape * n_shapes + 16 * n_pairs; }
+// cooperative fill by the 64 lanes of the wavefront
+template <class M>
+MPPI_HD void scene_table_fill(M &m, unsigned *tab, int lane, int lanes) {
+    const int ns = m.n_shapes, np = m.n_pairs;
+    for (int i = lane; i < kTabShape * ns; i += lanes) tab[i] = reinterpret_cast<const MPPI_CONST_AS unsigned *>(&m.sh[0])[i];
+    for (int i = lane; i < 16 * np; i += lanes) tab[kTabShape * ns + i] = reinterpret_cast<const MPPI_CONST_AS unsigned *>(&m.pr[i >> 4].g)[i & 15];
+}
+struct TabShape {  // the fields shape_world() reads, from the table
+    int ent, src_actor;
+    float R[9], p[3];
+};
+MPPI_HD TabShape tab_shape(const LMem &L, int i) {
+    const unsigned *r = L.tab + kTabShape * i;
+    TabShape S;
+    S.ent = (int)r[0];
+    S.src_actor = (int)r[1];
+    for (int j = 0; j < 9; j++) S.R[j] = __builtin_bit_cast(float, r[8 + j]);
+    for (int j = 0; j < 3; j++) S.p[j] = __builtin_bit_cast(float, r[17 + j]);
+    return S;
+}
+template <class M>
+MPPI_HD PairGeom tab_pair_geom(M &m, const LMem &L, int ip) {
+    PairGeom G;
+    __builtin_memcpy(&G, L.tab + kTabShape * m.n_shapes + 16 * ip, 64);
+    return G;
+}
 
 template <class T>
 struct SceneLayout {
@@ -131,6 +165,10 @@ MPPI_HD ActorDraw actor_draw_slot(M &m, int slot, float mu_nominal, const LMem &
     const int o = SceneLayout<T>::kCf + 3 * m.n_rb + 5 * slot;
     return ActorDraw{{L[o], L[o + 1], L[o + 2]}, L[o + 3], L[o + 4]};
 }
+
+// floats of one sample's LDS rows in the kernels whose lanes share a sample (incl. the shape-pose cache)
+template <class T, class M>
+MPPI_HD int scene_row_floats(M &m) { return SceneLayout<T>::floats(m.n_rb, m.n_rnd, m.n_shapes); }
 
 constexpr int scene_floats_max(int nb) { return (nb + 1 + kMaxFree) * 45 + 3 * (kMaxLinks + kMaxActors); }
 
@@ -487,9 +525,16 @@ template <class T, class M>
 MPPI_HD void shape_cache_update(M &m, const float *root, const LMem &L, Split sp, bool statics) {
     const int base = shape_cache_base<T>(m);
     for (int i = sp.sub; i < m.n_shapes; i += sp.n) {
-        auto &S = m.sh[i];
-        if ((S.ent < 0) != statics) continue;
-        const ShapeW w = shape_world(S, root, L);
+        ShapeW w;
+        if (L.tab != nullptr) {
+            const TabShape S = tab_shape(L, i);
+            if ((S.ent < 0) != statics) continue;
+            w = shape_world(S, root, L);
+        } else {
+            auto &S = m.sh[i];
+            if ((S.ent < 0) != statics) continue;
+            w = shape_world(S, root, L);
+        }
         const int o = base + 12 * i;
         for (int j = 0; j < 9; j++) L[o + j] = w.R.a[j];
         L[o + 9] = w.p.x; L[o + 10] = w.p.y; L[o + 11] = w.p.z;
@@ -719,7 +764,7 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
             for (int it = 0; it < trips; it++) {
                 const int ip = it * split.n + split.sub;
                 const int ic = ip < m.n_pairs ? ip : m.n_pairs - 1;
-                const PairGeom G = load_block<PairGeom>(m.pr[ic].g);
+                const PairGeom G = L.tab != nullptr ? tab_pair_geom(m, L, ic) : load_block<PairGeom>(m.pr[ic].g);
                 PairPose pp;
                 const bool apart = pair_broad_phase<T, true>(m, ic, G, root, L, pp);
                 const unsigned bit = (!apart && ip < m.n_pairs) ? 1u << (ip & 31) : 0u;
