@@ -282,3 +282,33 @@ def test_every_example_scene_runs_closed_loop(lib):
         improved += last < first
         planner.sim.stop_sim()
     assert improved >= 6
+
+
+def test_external_noise_is_used_and_kept_alive(lib):
+    """MPPIPlanner.set_external_noise: caller-owned perturbations [H, nu, K] replace the configured sampler (fused and generic
+    mode read the same buffer); None returns to the sampler"""
+    from mppiisaac.objectives import PandaReachObjective
+    from mppiisaac.planner.mppi_isaac import MPPIisaacPlanner
+    cfg = _panda_cfg()
+    pl = MPPIisaacPlanner(cfg, PandaReachObjective(cfg))
+    pl.sim.set_actor_position_by_name([0.5, -0.4, 0.3], "goal")
+    q = [0.0, -0.94, 0.0, -2.8, 0.0, 1.8675, 0.0]
+    g = torch.Generator(device="cuda").manual_seed(3)
+    eps = 0.05 * torch.randn((12, 7, 256), generator=g, device="cuda")
+    pl.mppi.set_external_noise(eps)
+    del eps                                                     # the planner keeps the tensor alive
+    torch.cuda.empty_cache()
+    pl.compute_action(q, [0.0] * 7)
+    got = np.zeros((12, 7, 256), np.float32)
+    capi.check(lib, lib.mppi_get_noise(pl.sim._ctx, capi.fptr(got)))
+    want = 0.05 * torch.randn((12, 7, 256), generator=torch.Generator(device="cuda").manual_seed(3), device="cuda")
+    np.testing.assert_array_equal(got, want.cpu().numpy())
+    du = np.zeros((12, 7, 256), np.float32)
+    capi.check(lib, lib.mppi_get_perturbations(pl.sim._ctx, capi.fptr(du)))
+    np.testing.assert_allclose(du[:, :, :255], got[:, :, :255], atol=1e-7)   # U = 0, |eps| << u_max: du == eps (last sample: null action)
+    with pytest.raises(ValueError):
+        pl.mppi.set_external_noise(torch.zeros((12, 7, 255), device="cuda"))
+    pl.mppi.set_external_noise(None)
+    pl.compute_action(q, [0.0] * 7)
+    capi.check(lib, lib.mppi_get_noise(pl.sim._ctx, capi.fptr(got)))
+    assert np.abs(got).std() > 0.1                              # the halton-spline set again (sigma 0.1 -> std 0.3)
