@@ -30,7 +30,7 @@ def hostemu():
     """test-only g++ build of the per-sample device functions (tests/hostemu/hostemu.cpp)."""
     import ctypes as C
     d = os.path.join(ROOT, "tests", "hostemu")
-    subprocess.run(["make", "-C", d, "-s"], check=True)
+    subprocess.run(["make", "-C", d, "-s", "-j3"], check=True)
     lib = C.CDLL(os.path.join(d, "libhostemu.so"))
     lib.emu_cost.restype = C.c_float
     return lib

@@ -13,12 +13,24 @@
 
 using namespace mppi;
 
-static int g_scene_split = 1;  // 4: contact feature points dealt over an emulated quad (kSplitEmulate)
+// The file is compiled three times (HOSTEMU_PART = 1, 2, 3: the Makefile builds the parts in parallel - one translation unit
+// with every kinematic tree in every entry point took over two minutes) and linked into one library.
+#ifndef HOSTEMU_PART
+#error "compile with -DHOSTEMU_PART=1|2|3 (tests/hostemu/Makefile)"
+#endif
+#if HOSTEMU_PART == 3
+int g_scene_split = 1;  // 4 / 8: contact feature points dealt over an emulated quad / octet (kSplitEmulate)
+#else
+extern int g_scene_split;
+#endif
 
 extern "C" {
 
+#if HOSTEMU_PART == 3
 void emu_set_scene_split(int n) { g_scene_split = n; }
+#endif
 
+#if HOSTEMU_PART == 1
 int emu_rollout(const mppi_model_t *model, const mppi_config_t *cfg, const mppi_cost_t *cost, const float *dof0, const float *root0,
                 const float *U, const float *eps, const float *prior, float *S, float *du, float *viz) {
     DevModel m; DevCfg c; DevCost k; std::string err;
@@ -44,6 +56,8 @@ int emu_rollout(const mppi_model_t *model, const mppi_config_t *cfg, const mppi_
     return ok ? 0 : -3;
 }
 
+#endif  // part 1
+#if HOSTEMU_PART == 2
 // quad-parallel rollout (csrc/mppi_quad.hpp) with the 4-lane quad emulated as a 4-float struct
 int emu_rollout_quad(const mppi_model_t *model, const mppi_config_t *cfg, const mppi_cost_t *cost, const float *dof0, const float *root0,
                      const float *U, const float *eps, const float *prior, float *S, float *du, float *viz) {
@@ -99,6 +113,8 @@ int emu_rigid_body_state(const mppi_model_t *model, const float *root, const flo
     return ok ? 0 : -3;
 }
 
+#endif  // part 2
+#if HOSTEMU_PART == 3
 // one dt step of a contact scene: dof [2n] and root [A][13] are updated in place; rb/cf = reference-layout rows
 int emu_scene_step_g(const mppi_model_t *model, float *dof, float *root, const float *u, float *rb, float *cf, int sample_id) {
     DevModel m; std::string err;
@@ -131,6 +147,8 @@ int emu_scene_step(const mppi_model_t *model, float *dof, float *root, const flo
     return emu_scene_step_g(model, dof, root, u, rb, cf, 0);
 }
 
+#endif  // part 3
+#if HOSTEMU_PART == 2
 float emu_cost(const mppi_model_t *model, const mppi_cost_t *cost, const float *root, const float *q, const float *qd) {
     DevModel m; DevCost k; std::string err;
     if (!pack_model(*model, m, err) || !pack_cost(*cost, m, k, err)) return -1e30f;
@@ -143,4 +161,5 @@ float emu_cost(const mppi_model_t *model, const mppi_cost_t *cost, const float *
     });
     return out;
 }
+#endif  // part 2 (cost)
 }
