@@ -305,7 +305,8 @@ def test_external_noise_is_used_and_kept_alive(lib):
     np.testing.assert_array_equal(got, want.cpu().numpy())
     du = np.zeros((12, 7, 256), np.float32)
     capi.check(lib, lib.mppi_get_perturbations(pl.sim._ctx, capi.fptr(du)))
-    np.testing.assert_allclose(du[:, :, :255], got[:, :, :255], atol=1e-7)   # U = 0, |eps| << u_max: du == eps (last sample: null action)
+    # U = 0, u_max = 0.2: du == clamp(eps) (last sample: the null action)
+    np.testing.assert_allclose(du[:, :, :255], np.clip(got[:, :, :255], -0.2, 0.2), atol=1e-7)
     with pytest.raises(ValueError):
         pl.mppi.set_external_noise(torch.zeros((12, 7, 255), device="cuda"))
     pl.mppi.set_external_noise(None)
