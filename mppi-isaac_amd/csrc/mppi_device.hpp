@@ -208,6 +208,23 @@ __device__ __forceinline__ B load_block(const MPPI_LDS_AS S &src) {
     __builtin_memcpy(&out, &v, 64);
     return out;
 }
+// the same block through the VECTOR memory path although the address is wave-uniform: scalar loads count on lgkmcnt together
+// with LDS operations and return out of order, so a scalar load issued ahead of time is waited for by the very next LDS
+// wait - it cannot be a prefetch in code that works out of LDS.  Vector loads count on vmcnt and return in order.
+template <class B, class S>
+__device__ __forceinline__ B load_block_vmem(const MPPI_CONST_AS S &src) {
+    static_assert(sizeof(B) == 64 && sizeof(S) == 64, "64-byte blocks only");
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    unsigned zero;
+    asm("v_mov_b32 %0, 0" : "=v"(zero));  // (opaque: keeps the address in a VGPR)
+    const __attribute__((address_space(1))) char *p = (const __attribute__((address_space(1))) char *)(unsigned long long)(&src) + zero;
+    u32x4 v[4];
+    for (int j = 0; j < 4; j++) v[j] = *reinterpret_cast<const __attribute__((address_space(1))) u32x4 *>(p + 16 * j);
+    B out;
+    __builtin_memcpy(&out, v, 64);
+    return out;
+}
+__device__ __forceinline__ int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 typedef const MPPI_LDS_AS DevModel LModel;
 __device__ __forceinline__ LModel *launder(LModel *p) {
     asm volatile("" : "+v"(p));

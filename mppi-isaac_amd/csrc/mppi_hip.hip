@@ -215,6 +215,9 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
             const bool oct = c->quad && !(mode && std::string(mode) == "quad") && cfg->num_samples >= 8;
             c->lanes_per_sample = !c->quad ? 1 : (oct ? 8 : 4);
             c->launch_rollout = c->quad ? (oct ? e->rollout_scene_oct : e->rollout_scene_quad) : e->rollout_scene;
+            // short trees: the octet kernel with a helper wavefront per sample group (kSplitOctPair) unless MPPI_ROLLOUT=oct
+            c->helper_wave = oct && e->rollout_scene_pair != nullptr && !(mode && std::string(mode) == "oct");
+            if (c->helper_wave) c->launch_rollout = e->rollout_scene_pair;
             c->launch_sim_step = c->quad ? e->sim_step_scene_quad : e->sim_step_scene;  // (the K = 1 world included: one quad)
             c->launch_materialise = e->materialise_scene;
             // (large scenes - e.g. the 12-DoF mobile manipulator with table and block - do not fit the one-lane kernels' 64 rows
@@ -655,7 +658,7 @@ int mppi_kernel_ms(mppi_ctx_t *c, int which, float *ms) {
 }
 int mppi_kernel_info(mppi_ctx_t *c, char *buf, int buflen) {
     CTX_TRY(c);
-    std::snprintf(buf, buflen, "topology=%s rollout=%s K=%d H=%d nu=%d waves=%d block=%d bytes_alg=%zu", c->topo.c_str(), c->scene ? (c->lanes_per_sample == 8 ? "scene-oct" : (c->quad ? "scene-quad" : "scene")) : (c->quad ? "quad" : "lane"), c->K, c->H, c->nu, c->quad ? c->n_quads : c->n_waves, kWave,
+    std::snprintf(buf, buflen, "topology=%s rollout=%s K=%d H=%d nu=%d waves=%d block=%d bytes_alg=%zu", c->topo.c_str(), c->scene ? (c->helper_wave ? "scene-oct-pair" : (c->lanes_per_sample == 8 ? "scene-oct" : (c->quad ? "scene-quad" : "scene"))) : (c->quad ? "quad" : "lane"), c->K, c->H, c->nu, c->quad ? c->n_quads : c->n_waves, kWave,
                   (size_t)4 * (3 * (size_t)c->K * c->HN + 2 * (size_t)c->K + c->HN));
     return MPPI_OK;
 }

@@ -562,8 +562,13 @@ __global__ __launch_bounds__(kWave) void k_rollout_scene(const DevModel *__restr
 // (both quads of an octet alike) and deal the contact work over all LPS lanes (mppi_scene.hpp: kSplitQuad / kSplitOct).
 // The sample's LDS rows are shared by its lanes: element i of the wave's s-th sample lives at lds[i*SPW + s]
 // (SPW = 64 / LPS samples per wavefront; LPS-lane broadcast reads).
-template <class T, int LPS>
-__global__ __launch_bounds__(kWave) void k_rollout_scene_quad(const DevModel *__restrict__ m, const DevCfg *__restrict__ cfg,
+#if defined(MPPI_SCENE_WAVES_PER_EU)  // experiment builds (MPPI_BUILD_VARIANT=w2): register budget for N resident wavefronts per SIMD
+#define MPPI_SCENE_OCCUPANCY __attribute__((amdgpu_waves_per_eu(MPPI_SCENE_WAVES_PER_EU, MPPI_SCENE_WAVES_PER_EU)))
+#else
+#define MPPI_SCENE_OCCUPANCY
+#endif
+template <class T, int LPS, int NW = 1>
+__global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW))) MPPI_SCENE_OCCUPANCY void k_rollout_scene_quad(const DevModel *__restrict__ m, const DevCfg *__restrict__ cfg,
                                                               const DevCost *__restrict__ cost, const float *__restrict__ x0_dof,
                                                               const float *__restrict__ x0_root, const float *__restrict__ U,
                                                               const float *__restrict__ eps, const float *__restrict__ prior,
@@ -572,8 +577,9 @@ __global__ __launch_bounds__(kWave) void k_rollout_scene_quad(const DevModel *__
                                                               unsigned long long *__restrict__ wave_clk) {
 #if defined(__HIP_DEVICE_COMPILE__)
     static_assert(LPS == 4 || LPS == 8, "4 or 8 lanes per sample");
+    static_assert(NW == 1 || (NW == 2 && LPS == 8 && T::NB <= 4), "helper wavefront: octet layout of the short trees only");
     constexpr int SPW = kWave / LPS;
-    constexpr int kSplit = LPS == 8 ? kSplitOct : kSplitQuad;
+    constexpr int kSplit = NW == 2 ? kSplitOctPair : (LPS == 8 ? kSplitOct : kSplitQuad);
     const unsigned long long clk0 = wave_clk != nullptr ? wall_clock64() : 0ull;
 #if defined(MPPI_SECTION_CLOCKS)
     if (threadIdx.x <= kSections) section_counters()[threadIdx.x] = threadIdx.x == kSections ? __builtin_readcyclecounter() : 0ull;
@@ -585,22 +591,39 @@ __global__ __launch_bounds__(kWave) void k_rollout_scene_quad(const DevModel *__
     // measured slower: the contact loop's constants then occupy VGPRs of code that already spills)
     constexpr int kModelBytes = (int)((offsetof(DevModel, sh) + 15) / 16 * 16);  // header, bodies, links, free bodies
     __shared__ __attribute__((aligned(64))) uint4 s_model[kModelBytes / 16];
-    for (int i = threadIdx.x; i < kModelBytes / 16; i += kWave) s_model[i] = reinterpret_cast<const uint4 *>(m)[i];
+    for (int i = threadIdx.x; i < kModelBytes / 16; i += kWave * NW) s_model[i] = reinterpret_cast<const uint4 *>(m)[i];
     __syncthreads();
     LModel &lm = *(LModel *)s_model;
     const int nb = gridDim.x;  // XCD-aware chunk mapping as in k_rollout_quad (here 128 / (4 SPW) chunks share a line)
     const int chunk = (nb % 16 == 0) ? (int)(blockIdx.x % 8) * (nb / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
-    const int k = chunk * SPW + (threadIdx.x / LPS);
-    const int sub = threadIdx.x & (LPS - 1);
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int k = chunk * SPW + (lane / LPS);
+    const int sub = lane & (LPS - 1);
     const bool live = k < cfg->K;
     // behind the SPW-wide sample rows: the wave-shared table of shape records and pair geometry blocks (scene_table_fill)
-    unsigned *tab = reinterpret_cast<unsigned *>(lds + (size_t)SPW * scene_row_floats<T>(*(CModel *)m));
-    scene_table_fill(*(CModel *)m, tab, threadIdx.x, kWave);
+    CModel &M = *(CModel *)m;
+    const int row = scene_row_floats<T>(M) + (NW == 2 ? scene_pair_floats<T>(M) : 0);
+    unsigned *tab = reinterpret_cast<unsigned *>(lds + (size_t)SPW * row);
+    scene_table_fill(M, tab, threadIdx.x, kWave * NW);
     __syncthreads();
-    const LMem L{lds + (threadIdx.x / LPS), SPW, tab};
+    LMem L{lds + (lane / LPS), SPW, tab};
+    if constexpr (NW == 2) {
+        L.set1 = scene_row_floats<T>(M);
+        L.xch = L.set1 + scene_pair_floats<T>(M) - 2;
+        if (wave != 0) {
+            // HELPER WAVEFRONT: its half of the shape poses and candidate pairs of every substep, out of and into LDS (see
+            // kSplitOctPair); the barriers inside contact_forces pair with those of the first wavefront's calls
+            if (live) {
+                unsigned acc_dirty = ~0u, cf_dirty = ~0u;
+                const int steps = cfg->H * M.substeps;
+                for (int it = 0; it < steps; it++) contact_forces<T, kSplitOctPair>(*launder(&M), x0_root, L, acc_dirty, cf_dirty, Split{sub, LPS, 1});
+            }
+            return;
+        }
+    }
     float s = INFINITY;
     if (live) {
-        s = rollout_scene<T, kSplit>(*(CModel *)m, lm, *(CCfg *)cfg, *(CCost *)cost, x0_dof, x0_root, U, eps, prior, du, viz, k, L, Split{sub, LPS});
+        s = rollout_scene<T, kSplit>(M, lm, *(CCfg *)cfg, *(CCost *)cost, x0_dof, x0_root, U, eps, prior, du, viz, k, L, Split{sub, LPS});
         if (sub == 0) S[k] = s;
     }
     quad_record<SPW>(*(CCfg *)cfg, s, live && sub == 0, du, chunk * SPW, partials + (size_t)chunk * (2 + cfg->H * cfg->nu));
@@ -1089,6 +1112,7 @@ struct mppi_ctx {
     int n = 0, A = 0, B = 0, K = 0, H = 0, nu = 0, HN = 0, RF = 0, n_waves = 0;
     int n_quads = 0;      // wavefronts of the quad- / octet-parallel rollout (16 / 8 samples each)
     int lanes_per_sample = 1;  // 1 (lane kernels), 4 (quad kernels), 8 (contact scenes: octets)
+    bool helper_wave = false;  // octet rollout kernel with a second wavefront per sample group for half of the contact pairs
     int n_partials = 0;   // records currently held by d_partials
     bool quad = false;
     DevModel *d_model = nullptr;
@@ -1141,6 +1165,7 @@ struct TopoEntry {
     void (*rollout_scene)(mppi_ctx *);
     void (*rollout_scene_quad)(mppi_ctx *);
     void (*rollout_scene_oct)(mppi_ctx *);  // 8 lanes per sample
+    void (*rollout_scene_pair)(mppi_ctx *); // 8 lanes per sample + a helper wavefront (null: trees of more than 4 bodies)
     void (*sim_step)(mppi_ctx *, int, int, const float *);
     void (*sim_step_quad)(mppi_ctx *, int, int, const float *);
     void (*sim_step_scene)(mppi_ctx *, int, int, const float *);
@@ -1166,6 +1191,20 @@ void launch_rollout_scene_quad_t(mppi_ctx *c) {
                        c->d_x0_root, c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_S, c->cfg.want_rollouts ? c->d_viz : nullptr,
                        c->d_partials, c->fold ? c->d_fold_ctr : nullptr, c->fold_out, c->wave_clk_on ? c->d_wave_clk : nullptr);
 }
+// octet layout with a helper wavefront per sample group (short trees: kSplitOctPair)
+template <class T>
+size_t pair_lds_bytes(const mppi_ctx *c) {
+    const size_t row = c->lds_bytes_quad / 16 + sizeof(float) * ((size_t)SceneLayout<T>::NF * 27 + 3 * (size_t)c->hm.n_rb + 2);
+    return row * (kWave / 8) + c->lds_bytes_table;
+}
+template <class T>
+void launch_rollout_scene_pair_t(mppi_ctx *c) {
+    if constexpr (T::NB <= 4) {
+        hipLaunchKernelGGL((k_rollout_scene_quad<T, 8, 2>), dim3(c->n_quads), dim3(2 * kWave), pair_lds_bytes<T>(c), c->stream, c->d_model, c->d_cfg, c->d_cost, c->d_x0_dof,
+                           c->d_x0_root, c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_S, c->cfg.want_rollouts ? c->d_viz : nullptr,
+                           c->d_partials, c->fold ? c->d_fold_ctr : nullptr, c->fold_out, c->wave_clk_on ? c->d_wave_clk : nullptr);
+    }
+}
 template <class T>
 void launch_sim_step_scene_t(mppi_ctx *c, int mode, int t, const float *u_ext) {
     hipLaunchKernelGGL(k_sim_step_scene<T>, dim3(c->n_waves), dim3(kWave), c->lds_bytes, c->stream, c->d_model, c->d_cfg, mode, t, u_ext, c->d_x0_root,
@@ -1187,6 +1226,10 @@ hipError_t raise_lds_limit(size_t lane_bytes, size_t quad_bytes) {  // lane_byte
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rollout_scene_quad<T, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)quad_bytes);
     if (e != hipSuccess) return e;
+    if constexpr (T::NB <= 4) {  // (+ the helper's accumulator set: bounded by the quad kernel's 16-sample figure)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rollout_scene_quad<T, 8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)quad_bytes);
+        if (e != hipSuccess) return e;
+    }
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sim_step_scene_quad<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)quad_bytes);
     if (e != hipSuccess || lane_bytes == 0) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rollout_scene<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lane_bytes);
@@ -1237,6 +1280,7 @@ TopoEntry make_topo_entry() {
     e.rollout_scene = &launch_rollout_scene_t<T>;
     e.rollout_scene_quad = &launch_rollout_scene_quad_t<T, 4>;
     e.rollout_scene_oct = &launch_rollout_scene_quad_t<T, 8>;
+    e.rollout_scene_pair = T::NB <= 4 ? &launch_rollout_scene_pair_t<T> : nullptr;
     e.sim_step = &launch_sim_step_t<T>;
     e.sim_step_quad = &launch_sim_step_quad_t<T>;
     e.sim_step_scene = &launch_sim_step_scene_t<T>;

@@ -61,6 +61,10 @@ struct LMem {
     // the dealt passes index them PER LANE, which through the constant address space means 64-byte vector loads from
     // memory per lane and trip; from LDS it is four ds_read_b128).  Null: read the model.
     const unsigned *tab = nullptr;
+    // kSplitOctPair (two wavefronts per sample group): row index of the helper wavefront's own accumulator set
+    // ([NF][27] wrench / damping rows, then [n_rb][3] contact-force rows - the layout of set 0 from kAcc on) and of the two
+    // words in which it hands its "touched" masks to the first wavefront
+    int set1 = 0, xch = 0;
     MPPI_HD float &operator[](int i) const { return p[(size_t)i * stride]; }
 };
 // layout of the table: n_shapes records of kTabShape dwords (DevShape as is), then n_pairs geometry blocks of 16 dwords
@@ -169,6 +173,10 @@ MPPI_HD ActorDraw actor_draw_slot(M &m, int slot, float mu_nominal, const LMem &
 // floats of one sample's LDS rows in the kernels whose lanes share a sample (incl. the shape-pose cache)
 template <class T, class M>
 MPPI_HD int scene_row_floats(M &m) { return SceneLayout<T>::floats(m.n_rb, m.n_rnd, m.n_shapes); }
+
+// extra floats per sample row of the kernels with a helper wavefront (kSplitOctPair): its accumulator set + two mask words
+template <class T, class M>
+MPPI_HD int scene_pair_floats(M &m) { return SceneLayout<T>::NF * 27 + 3 * m.n_rb + 2; }
 
 constexpr int scene_floats_max(int nb) { return (nb + 1 + kMaxFree) * 45 + 3 * (kMaxLinks + kMaxActors); }
 
@@ -340,10 +348,18 @@ MPPI_HD void pair_add(PairAcc &a, const PairAcc &b) {
 // replicate the sample's state arithmetic and the quad-layout robot algebra, and deal the contact work (shape poses, broad
 // phase, the 2 x 26 feature points of a box pair) over all eight lanes: K/8 wavefronts (one per SIMD at K = 8192) whose
 // divergent narrow phase waits for the busiest of 8 samples instead of 16, each lane testing half the points.
-enum { kSplitNone = 0, kSplitQuad = 1, kSplitEmulate = 2, kSplitOct = 3 };
-constexpr bool split_on_device(int split) { return split == kSplitQuad || split == kSplitOct; }
+// kSplitOctPair: the octet layout with a HELPER WAVEFRONT per sample group (short trees only: their kernels fit the register
+// budget of two resident wavefronts per SIMD).  The candidate-pair loop is 70 % of such a kernel and works out of LDS only -
+// frames and shape poses in, wrench / damping rows out - so a second wavefront of the workgroup takes every other pair (and
+// half of the shape poses), accumulating into a row set of its own; the first wavefront adds that set to its own after the
+// barrier, in a fixed order (deterministic), and goes on alone with the solve.  Two resident wavefronts per SIMD overlap
+// where one only waits: measured 1.3x the time for 2x the wavefronts (tools/exp/w2_overlap.sh).
+enum { kSplitNone = 0, kSplitQuad = 1, kSplitEmulate = 2, kSplitOct = 3, kSplitOctPair = 4 };
+constexpr bool split_on_device(int split) { return split == kSplitQuad || split == kSplitOct || split == kSplitOctPair; }
+constexpr bool split_octet(int split) { return split == kSplitOct || split == kSplitOctPair; }
 struct Split {
     int sub, n;
+    int wave = 0;  // kSplitOctPair: 0 = the wavefront that owns the sample state, 1 = its helper
 };
 #if defined(__HIP_DEVICE_COMPILE__)
 template <int CTRL>
@@ -367,13 +383,13 @@ __device__ __forceinline__ unsigned quad_allor(unsigned x) {
 template <int SPLIT>
 __device__ __forceinline__ float group_allsum(float x) {
     x = quad_allsum(x);
-    if constexpr (SPLIT == kSplitOct) x += scene_dpp<0x141>(x);
+    if constexpr (split_octet(SPLIT)) x += scene_dpp<0x141>(x);
     return x;
 }
 template <int SPLIT>
 __device__ __forceinline__ unsigned group_allor(unsigned x) {
     x = quad_allor(x);
-    if constexpr (SPLIT == kSplitOct) x |= (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0x141, 0xf, 0xf, true);
+    if constexpr (split_octet(SPLIT)) x |= (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0x141, 0xf, 0xf, true);
     return x;
 }
 template <int SPLIT>
@@ -710,7 +726,10 @@ MPPI_HD bool pair_broad_phase(M &m, int ip, const PairGeom &G, const float *root
         constexpr float kMargin = 1e-4f;
         const float rA = typeA == 0 ? fsqrt(hA[0] * hA[0] + hA[1] * hA[1] + hA[2] * hA[2]) * 1.000001f : hA[0];  // (rounded up: conservative)
         if (!has_b) {
-            apart = typeA != 2 && wa.p.z > rA + kMargin;
+            // ground: a box by its support function along z (lowest corner at p.z - sum |R_zj| h_j: the chassis of a wheeled
+            // base hovers within its bounding sphere's reach of the ground for ever), a sphere by its radius
+            apart = typeA == 0 ? wa.p.z - (fabsf(wa.R.a[6]) * hA[0] + fabsf(wa.R.a[7]) * hA[1] + fabsf(wa.R.a[8]) * hA[2]) > kMargin
+                               : (typeA != 2 && wa.p.z > rA + kMargin);
         } else if (typeA != 2 && typeB != 2) {
             const float rB = typeB == 0 ? fsqrt(hB[0] * hB[0] + hB[1] * hB[1] + hB[2] * hB[2]) * 1.000001f : hB[0];
             const V3 d = wa.p - wb.p;
@@ -737,18 +756,32 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
     unsigned touched = 0;  // entities (dynamic frames) whose accumulator rows are non-zero after this call
     using Lay = SceneLayout<T>;
     // contacts are sparse: clear only what the previous pass wrote (375 LDS rows per substep in the gripper scene otherwise)
+    // accumulator rows this wavefront writes (kSplitOctPair: the helper has its own set, merged below)
+    constexpr bool kPair = SPLIT == kSplitOctPair;
+    const bool helper = kPair && split.wave != 0;
+    const int kAccW = helper ? L.set1 : (int)Lay::kAcc, kCfW = kAccW + (Lay::kCf - Lay::kAcc);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (kPair) __syncthreads();  // the frames of this substep are written; the previous merge is done
+#endif
     for (int e = 0; e < Lay::NF; e++)
         if ((acc_dirty >> e) & 1u)
-            for (int j = 0; j < 27; j++) L[Lay::kAcc + 27 * e + j] = 0.f;
+            for (int j = 0; j < 27; j++) L[kAccW + 27 * e + j] = 0.f;
     const bool cf_all = m.n_rb > 32;
     for (int r = 0; r < m.n_rb; r++)
         if (cf_all || ((cf_dirty >> r) & 1u)) {
-            L[Lay::kCf + 3 * r] = 0.f; L[Lay::kCf + 3 * r + 1] = 0.f; L[Lay::kCf + 3 * r + 2] = 0.f;
+            L[kCfW + 3 * r] = 0.f; L[kCfW + 3 * r + 1] = 0.f; L[kCfW + 3 * r + 2] = 0.f;
         }
     unsigned cf_touched = 0;
     const SV zero = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
     constexpr bool kCached = SPLIT != kSplitNone;
-    if constexpr (kCached) shape_cache_update<T>(m, root, L, SPLIT == kSplitEmulate ? Split{0, 1} : split, false);
+    if constexpr (kPair) {
+        shape_cache_update<T>(m, root, L, Split{split.sub + split.n * split.wave, 2 * split.n}, false);  // dealt over both wavefronts
+#if defined(__HIP_DEVICE_COMPILE__)
+        __syncthreads();
+#endif
+    } else if constexpr (kCached) {
+        shape_cache_update<T>(m, root, L, SPLIT == kSplitEmulate ? Split{0, 1} : split, false);
+    }
     MPPI_SEC(1);
     // Dealt broad phase (quad kernels of the larger trees, whose scenes carry a candidate pair per link and obstacle):
     // lane r of the quad tests the pairs r, r + 4, ... on its own and the verdicts are OR-ed over the quad; the pair
@@ -782,6 +815,7 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
     // quarter of the whole kernel was the exposed latency of this preamble - scalar loads of the pair record, then the
     // dependent LDS reads of the two shape poses, then the noise lookup behind two more dependent scalar loads.
     auto next_alive = [&](int from) MPPI_LAMBDA {
+        if constexpr (kPair) return from + ((from ^ split.wave) & 1);  // pairs of this wavefront's parity
         if constexpr (dealt_broad_phase<T>(SPLIT)) {
             if (m.n_pairs > kDealtBroadPhaseMin) {
                 const unsigned long long alive = (unsigned long long)alive_lo | ((unsigned long long)alive_hi << 32);
@@ -791,21 +825,36 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
         }
         return from;
     };
+    // (small trees walk all pairs in order: wave-uniform records, which the compiler would fetch with scalar loads - no
+    // prefetch at all next to LDS work, see load_block_vmem; their integer fields go back to SGPRs for the scalar branches)
+    constexpr bool kVmemRecords = split_on_device(SPLIT) && !dealt_broad_phase<T>(SPLIT);
+    auto fetch = [&](int i, PairGeom &g, PairGain &c) MPPI_LAMBDA {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (kVmemRecords) {
+            g = load_block_vmem<PairGeom>(m.pr[i].g);
+            c = load_block_vmem<PairGain>(m.pr[i].c);
+            return;
+        }
+#endif
+        g = load_block<PairGeom>(m.pr[i].g);
+        c = load_block<PairGain>(m.pr[i].c);
+    };
     int next = next_alive(0);
     PairGeom Gn;
     PairGain Cn_;
-    if (next < m.n_pairs) {
-        Gn = load_block<PairGeom>(m.pr[next].g);
-        Cn_ = load_block<PairGain>(m.pr[next].c);
-    }
+    if (next < m.n_pairs) fetch(next, Gn, Cn_);
     for (int ip = next; ip < m.n_pairs; ip = next) {
-        const PairGeom G = Gn;
+        PairGeom G = Gn;
         const PairGain Cg = Cn_;
-        next = next_alive(ip + 1);
-        if (next < m.n_pairs) {
-            Gn = load_block<PairGeom>(m.pr[next].g);
-            Cn_ = load_block<PairGain>(m.pr[next].c);
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (kVmemRecords) {
+            G.a = uniform(G.a); G.b = uniform(G.b); G.mode = uniform(G.mode); G.rnd = uniform(G.rnd);
+            G.typeA = uniform(G.typeA); G.typeB = uniform(G.typeB); G.entA = uniform(G.entA); G.entB = uniform(G.entB);
+            G.rbA = uniform(G.rbA); G.rbB = uniform(G.rbB);
         }
+#endif
+        next = next_alive(ip + 1);
+        if (next < m.n_pairs) fetch(next, Gn, Cn_);
         const bool has_b = G.b >= 0;
         ShapeW wa, wb;
         if constexpr (kCached) {
@@ -865,7 +914,10 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
             constexpr float kMargin = 1e-4f;
             const float rA = typeA == 0 ? fsqrt(hA[0] * hA[0] + hA[1] * hA[1] + hA[2] * hA[2]) * 1.000001f : hA[0];  // (rounded up: conservative)
             if (!has_b) {
-                apart = typeA != 2 && wa.p.z > rA + kMargin;
+                // ground: a box by its support function along z (lowest corner at p.z - sum |R_zj| h_j: the chassis of a wheeled
+                // base hovers within its bounding sphere's reach of the ground for ever), a sphere by its radius
+                apart = typeA == 0 ? wa.p.z - (fabsf(wa.R.a[6]) * hA[0] + fabsf(wa.R.a[7]) * hA[1] + fabsf(wa.R.a[8]) * hA[2]) > kMargin
+                                   : (typeA != 2 && wa.p.z > rA + kMargin);
             } else if (typeA != 2 && typeB != 2) {
                 const float rB = typeB == 0 ? fsqrt(hB[0] * hB[0] + hB[1] * hB[1] + hB[2] * hB[2]) * 1.000001f : hB[0];
                 const V3 d = wa.p - wb.p;
@@ -999,17 +1051,17 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
         MPPI_SEC(14);  // feature points + cross-lane sum
         if (acc.any) {
             const SV neg = {{-acc.f.a.x, -acc.f.a.y, -acc.f.a.z}, {-acc.f.l.x, -acc.f.l.y, -acc.f.l.z}};
-            const int ocf = Lay::kCf + 3 * G.rbA, ob = Lay::kCf + 3 * (rbB >= 0 ? rbB : 0);
+            const int ocf = kCfW + 3 * G.rbA, ob = kCfW + 3 * (rbB >= 0 ? rbB : 0);
             cf_touched |= (1u << (G.rbA & 31)) | (rbB >= 0 ? 1u << (rbB & 31) : 0u);
             touched |= G.mode == 0 ? (1u << G.entA) | (1u << entB) : (G.mode == 1 ? 1u << G.entA : 1u << entB);
 #if defined(__HIP_DEVICE_COMPILE__)
             if constexpr (split_on_device(SPLIT)) {
                 const bool leader = split.sub == 0;
                 if (G.mode == 0) {
-                    acc_add_shared(L, Lay::kAcc, G.entA, acc.f, nullptr, leader);
-                    acc_add_shared(L, Lay::kAcc, entB, neg, nullptr, leader);
+                    acc_add_shared(L, kAccW, G.entA, acc.f, nullptr, leader);
+                    acc_add_shared(L, kAccW, entB, neg, nullptr, leader);
                 } else {
-                    acc_add_shared(L, Lay::kAcc, G.mode == 1 ? G.entA : entB, G.mode == 1 ? acc.f : neg, &acc.C, leader);
+                    acc_add_shared(L, kAccW, G.mode == 1 ? G.entA : entB, G.mode == 1 ? acc.f : neg, &acc.C, leader);
                 }
                 if (leader) {
                     lds_add(L[ocf], acc.rep.x); lds_add(L[ocf + 1], acc.rep.y); lds_add(L[ocf + 2], acc.rep.z);
@@ -1043,6 +1095,28 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
 #endif
         MPPI_SEC(15);  // accumulate into the frames' LDS rows
     }
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (kPair) {
+        if (helper && split.sub == 0) {
+            L[L.xch] = __builtin_bit_cast(float, touched);
+            L[L.xch + 1] = __builtin_bit_cast(float, cf_touched);
+        }
+        __syncthreads();  // both halves of the pair list are accumulated
+        if (!helper) {
+            // set 0 += set 1, rows the helper wrote: each of the sample's lanes takes every 8th value (one lane per address,
+            // LDS operations of a wavefront execute in order: the readers below see the sums)
+            const unsigned t1 = __builtin_bit_cast(unsigned, L[L.xch]), c1 = __builtin_bit_cast(unsigned, L[L.xch + 1]);
+            for (int e = 0; e < Lay::NF; e++)
+                if ((t1 >> e) & 1u)
+                    for (int j = split.sub; j < 27; j += split.n) L[Lay::kAcc + 27 * e + j] += L[L.set1 + 27 * e + j];
+            const int cf1 = L.set1 + (Lay::kCf - Lay::kAcc);
+            for (int j = split.sub; j < 3 * m.n_rb; j += split.n)
+                if (cf_all || ((c1 >> (j / 3)) & 1u)) L[Lay::kCf + j] += L[cf1 + j];
+            touched |= t1;
+            cf_touched |= c1;
+        }
+    }
+#endif
     acc_dirty = touched;
     cf_dirty = cf_touched;
     MPPI_SEC(3);

@@ -30,6 +30,7 @@ def report(tag, loop):
     print(f"{tag}: {n} wavefronts, kernel span {end.max():.1f} us; start spread {start.max():.1f} us; wavefront residency "
           f"min {dur.min():.1f} / mean {dur.mean():.1f} / median {np.median(dur):.1f} / p95 {np.percentile(dur, 95):.1f} / max {dur.max():.1f} us; "
           f"mean/max = {dur.mean() / dur.max():.3f}")
+    print(f"   started later than 10 % of the span: {(start > 0.1 * end.max()).mean():.3f} of the wavefronts")
     hist, edges = np.histogram(dur, bins=10)
     print("   residency histogram:", " ".join(f"{int(e)}:{h}" for h, e in zip(hist, edges[:-1])))
     slow = np.argsort(dur)[-5:][::-1]
@@ -41,7 +42,7 @@ if __name__ == "__main__":
     names = sys.argv[1:] or ["panda_reach", "boxer_push", "panda_pick"]
     env = dict(world_size=1, rank=0, local_rank=0, sharded=False, backend="nccl", action_sync=False)
     for name in names:
-        loop = bench.Loop(name, bench.WORKLOADS[name]["K"], env)
+        loop = bench.Loop(name, int(os.environ.get("K_TOTAL", bench.WORKLOADS[name]["K"])), env)
         report(f"{name} initial state", loop)
         for _ in range(int(os.environ.get("STEPS", "200"))):
             loop.iterate()
