@@ -596,7 +596,22 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW))
     LModel &lm = *(LModel *)s_model;
     const int nb = gridDim.x;  // XCD-aware chunk mapping as in k_rollout_quad (here 128 / (4 SPW) chunks share a line)
     const int chunk = (nb % 16 == 0) ? (int)(blockIdx.x % 8) * (nb / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+#if defined(MPPI_HWID_DEBUG)
+    unsigned long long hwdbg = 0;
+#endif
+    // (NW == 2: the wavefront index decides who owns the sample state and who helps.  Measured placement on MI355X
+    // (tools/exp/hwid_dump.py): the two wavefronts of the four workgroups of a CU go to SIMDs 1,3 | 3,0 | 0,2 | 2,1 - every SIMD
+    // hosts one owner and one helper, which is what the solve phase, where helpers only wait, wants.)
+#if defined(MPPI_HWID_DEBUG)
+    if constexpr (NW == 2) {
+        __shared__ unsigned s_hw[2];
+        if (lane == 0) s_hw[wave] = __builtin_amdgcn_s_getreg((31 << 11) | 4);  // HW_ID: wave slot [3:0], SIMD [5:4], CU [11:8], SE [15:13]
+        __syncthreads();
+        hwdbg = (unsigned long long)s_hw[0] | ((unsigned long long)s_hw[1] << 32);
+    }
+#endif
     const int k = chunk * SPW + (lane / LPS);
     const int sub = lane & (LPS - 1);
     const bool live = k < cfg->K;
@@ -629,8 +644,12 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW))
     quad_record<SPW>(*(CCfg *)cfg, s, live && sub == 0, du, chunk * SPW, partials + (size_t)chunk * (2 + cfg->H * cfg->nu));
     fold_after_record(*(CCfg *)cfg, partials, fold_ctr, fold_out);
     MPPI_SEC(10);
-    if (wave_clk != nullptr && threadIdx.x == 0) {  // instrumentation (mppi_set_wave_clock): this wavefront's residency
+    if (wave_clk != nullptr && lane == 0) {  // instrumentation (mppi_set_wave_clock): this wavefront's residency
+#if defined(MPPI_HWID_DEBUG)
+        wave_clk[2 * chunk] = hwdbg;
+#else
         wave_clk[2 * chunk] = clk0;
+#endif
         wave_clk[2 * chunk + 1] = wall_clock64();
 #if defined(MPPI_SECTION_CLOCKS)
         for (int j = 0; j < kSections; j++) wave_clk[2 * (size_t)gridDim.x + (size_t)chunk * kSections + j] = section_counters()[j];

@@ -32,7 +32,7 @@ __device__ __forceinline__ unsigned long long *section_counters() {
 }
 #define MPPI_SEC(id)                                                   \
     do {                                                               \
-        if ((threadIdx.x & 63) == 0) {                                 \
+        if (threadIdx.x == 0) { /* (kernels with a helper wavefront: the owner's clocks) */ \
             unsigned long long *sc_ = section_counters();              \
             const unsigned long long now_ = __builtin_readcyclecounter(); \
             sc_[id] += now_ - sc_[kSections];                          \
@@ -775,7 +775,8 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
     const SV zero = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
     constexpr bool kCached = SPLIT != kSplitNone;
     if constexpr (kPair) {
-        shape_cache_update<T>(m, root, L, Split{split.sub + split.n * split.wave, 2 * split.n}, false);  // dealt over both wavefronts
+        // dealt over both wavefronts (the owner posing all shapes before the first barrier, one barrier less, measured the same)
+        shape_cache_update<T>(m, root, L, Split{split.sub + split.n * split.wave, 2 * split.n}, false);
 #if defined(__HIP_DEVICE_COMPILE__)
         __syncthreads();
 #endif
@@ -815,7 +816,14 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
     // quarter of the whole kernel was the exposed latency of this preamble - scalar loads of the pair record, then the
     // dependent LDS reads of the two shape poses, then the noise lookup behind two more dependent scalar loads.
     auto next_alive = [&](int from) MPPI_LAMBDA {
-        if constexpr (kPair) return from + ((from ^ split.wave) & 1);  // pairs of this wavefront's parity
+        if constexpr (kPair) {
+#if defined(MPPI_PAIR_SPLIT)  // experiment builds (MPPI_BUILD_VARIANT=ps<k>): 1 = parities swapped, 2 = all pairs on the helper, 3 = none
+            if (MPPI_PAIR_SPLIT == 1) return from + ((from ^ split.wave ^ 1) & 1);
+            if (MPPI_PAIR_SPLIT == 2) return split.wave ? from : (int)m.n_pairs;
+            if (MPPI_PAIR_SPLIT == 3) return split.wave ? (int)m.n_pairs : from;
+#endif
+            return from + ((from ^ split.wave) & 1);  // pairs of this wavefront's parity
+        }
         if constexpr (dealt_broad_phase<T>(SPLIT)) {
             if (m.n_pairs > kDealtBroadPhaseMin) {
                 const unsigned long long alive = (unsigned long long)alive_lo | ((unsigned long long)alive_hi << 32);
@@ -826,7 +834,9 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
         return from;
     };
     // (small trees walk all pairs in order: wave-uniform records, which the compiler would fetch with scalar loads - no
-    // prefetch at all next to LDS work, see load_block_vmem; their integer fields go back to SGPRs for the scalar branches)
+    // prefetch at all next to LDS work, see load_block_vmem; their integer fields go back to SGPRs for the scalar branches.
+    // Measured alternatives at equal state, pushing scene: scalar loads requested one pair ahead 1.358 ms, vector loads one
+    // pair ahead 1.324 ms, the records from the wavefront's LDS table one pair ahead 1.375 ms)
     constexpr bool kVmemRecords = split_on_device(SPLIT) && !dealt_broad_phase<T>(SPLIT);
     auto fetch = [&](int i, PairGeom &g, PairGain &c) MPPI_LAMBDA {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -250,6 +250,17 @@ def test_full_size_properties_contact_scenes(make, K, H, nu, lib, oracle64, monk
     # worst sample of the pushing scene has been 0.85 % - 2.1 %)
     assert (rel <= 1e-3).mean() > 0.995 and np.percentile(rel, 99.9) <= 1.5e-2 and rel.max() <= 5e-2
     assert np.median(S) == pytest.approx(np.median(Sl), rel=1e-4)
+    if make is boxer_push:   # short tree: the default kernel has a helper wavefront per sample group; the plain octet kernel too
+        info = C.create_string_buffer(256)
+        monkeypatch.setenv("MPPI_ROLLOUT", "oct")
+        o = Ctx(m, cfg, cost)
+        o.call("mppi_kernel_info", info, 256)
+        assert b"rollout=scene-oct " in info.value
+        o.call("mppi_sample", C.c_uint32(0)); o.set_state(dof, root); o.call("mppi_rollout")
+        rel = np.abs(o.get("mppi_get_costs", (K,)) - Sl) / np.abs(Sl)
+        o.close()
+        assert (rel <= 1e-3).mean() > 0.995 and np.percentile(rel, 99.9) <= 1.5e-2 and rel.max() <= 5e-2
+    monkeypatch.delenv("MPPI_ROLLOUT")
     from mppiisaac.planner.mppi import make_config
     from mppiisaac.utils.config_store import load_config
     name = "boxer_push" if make is boxer_push else "panda_pick"
@@ -594,8 +605,9 @@ def test_ragged_sizes(K, H, lib, oracle64):
 
 @pytest.mark.parametrize("K", [1, 7, 100, 272])
 def test_ragged_sizes_contact_scene(K, lib, oracle64, monkeypatch):
-    """the quad-per-sample contact kernel with sample counts that leave quads / wavefronts partly empty (and 272 = 17
-    wavefronts: the XCD chunk mapping falls back to the identity), and the one-lane kernel on the same inputs"""
+    """the contact kernels that share a sample between 4 / 8 lanes (and 8 lanes + a helper wavefront) with sample counts that
+    leave quads / wavefronts partly empty (and 272 = 17 wavefronts: the XCD chunk mapping falls back to the identity), and the
+    one-lane kernel on the same inputs"""
     H = 10
     scene, m, cfg, cost, dof, root = boxer_push(K=K, H=H, sample_null_action=(K > 1))
     root[0, 2] = 0.019
@@ -603,8 +615,12 @@ def test_ragged_sizes_contact_scene(K, lib, oracle64, monkeypatch):
     eps = oracle64.sample(cfg) * 0.3
     So, duo, _ = oracle64.rollout(m, cfg, cost, dof, root, np.zeros((H, 2)), eps)
     _, ao, _ = oracle64.update(cfg, oracle64.record(cfg, So, duo), np.zeros((H, 2)))
-    for mode in ("quad", "lane"):
-        monkeypatch.setenv("MPPI_ROLLOUT", mode)
+    # (default for this two-wheel tree: octets with a helper wavefront that takes every other candidate pair)
+    kernels = {"quad": b"rollout=scene-quad", "lane": b"rollout=scene ", "oct": b"rollout=scene-oct " if K >= 8 else b"rollout=scene-quad",
+               "": b"rollout=scene-oct-pair" if K >= 8 else b"rollout=scene-quad"}
+    for mode in ("quad", "lane", "oct", ""):
+        if mode: monkeypatch.setenv("MPPI_ROLLOUT", mode)
+        else: monkeypatch.delenv("MPPI_ROLLOUT", raising=False)
         c = Ctx(m, cfg, cost)
         ext = torch.tensor(eps, dtype=torch.float32, device="cuda").contiguous()
         c.call("mppi_set_noise_dev", C.c_void_p(ext.data_ptr()))
@@ -615,7 +631,7 @@ def test_ragged_sizes_contact_scene(K, lib, oracle64, monkeypatch):
         np.testing.assert_allclose(a, ao, atol=5e-4)   # (a handful of samples: the softmax amplifies 1e-7 cost differences to 1e-4)
         info = C.create_string_buffer(256)
         c.call("mppi_kernel_info", info, 256)
-        assert (b"rollout=scene-quad" if mode == "quad" else b"rollout=scene ") in info.value
+        assert kernels[mode] in info.value, (mode, info.value)
         c.close()
 
 
