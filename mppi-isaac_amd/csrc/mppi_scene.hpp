@@ -838,11 +838,14 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
     // Measured alternatives at equal state, pushing scene: scalar loads requested one pair ahead 1.358 ms, vector loads one
     // pair ahead 1.324 ms, the records from the wavefront's LDS table one pair ahead 1.375 ms)
     constexpr bool kVmemRecords = split_on_device(SPLIT) && !dealt_broad_phase<T>(SPLIT);
+    // (the kernel with a helper wavefront runs on half the register file: the contact-law block of the pairs that survive the
+    // broad phase is fetched when it is needed instead of occupying 16 registers across the whole pair)
+    constexpr bool kLazyGains = kPair;
     auto fetch = [&](int i, PairGeom &g, PairGain &c) MPPI_LAMBDA {
 #if defined(__HIP_DEVICE_COMPILE__)
         if constexpr (kVmemRecords) {
             g = load_block_vmem<PairGeom>(m.pr[i].g);
-            c = load_block_vmem<PairGain>(m.pr[i].c);
+            if constexpr (!kLazyGains) c = load_block_vmem<PairGain>(m.pr[i].c);
             return;
         }
 #endif
@@ -855,7 +858,7 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
     if (next < m.n_pairs) fetch(next, Gn, Cn_);
     for (int ip = next; ip < m.n_pairs; ip = next) {
         PairGeom G = Gn;
-        const PairGain Cg = Cn_;
+        PairGain Cg = Cn_;
 #if defined(__HIP_DEVICE_COMPILE__)
         if constexpr (kVmemRecords) {
             G.a = uniform(G.a); G.b = uniform(G.b); G.mode = uniform(G.mode); G.rnd = uniform(G.rnd);
@@ -963,6 +966,7 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
         MPPI_SEC(12);  // broad-phase arithmetic
         if (apart) continue;
         // contact law of the survivors: second block of the pair (already here: requested one pair ahead)
+        if constexpr (kLazyGains) Cg = load_block<PairGain>(m.pr[ip].c);
         Gains P = {G.mode, Cg.mu, Cg.k, Cg.cn, Cg.ct, Cg.kh, Cg.inv_d0};
         if (G.rnd) {  // per-sample friction (min of the two) and contact gains scaled with the per-sample reacting mass
             const float mua = robotA ? Cg.muA : da.mu;

@@ -1,9 +1,9 @@
 #!/bin/bash
 # One gpurun call's worth of work: GPU test suite, bench lines of every workload, A/B switches, rocprofv3 passes.
-#   usage (on the GPU box, from the repo root): tools/gpu_round.sh <tag> [tests] [bench] [ab] [prof]
+#   usage (on the GPU box, from the repo root): tools/gpu_round.sh <tag> [tests] [bench] [ab] [prof] [exp]
 set -u
 TAG=${1:-r02a}; shift
-WHAT="${*:-tests bench ab prof}"
+WHAT="${*:-tests bench ab prof exp}"
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
@@ -34,6 +34,12 @@ if [[ $WHAT == *prof* ]]; then
   WORKLOAD=panda_reach STEPS=100 bash tools/pmc_sq.sh ${TAG} > $OUT/sq_reach.log 2>&1
   WORKLOAD=boxer_push STEPS=60 bash tools/pmc_sq.sh ${TAG}_boxer > $OUT/sq_boxer.log 2>&1
   WORKLOAD=panda_pick STEPS=40 bash tools/pmc_sq.sh ${TAG}_pick > $OUT/sq_pick.log 2>&1
+fi
+if [[ $WHAT == *exp* ]]; then
+  CLOSED_LOOP_ONLY=1 timeout 300 python tools/exp/scene_breakdown.py > $OUT/breakdown.log 2>&1
+  MPPI_ROLLOUT=oct CLOSED_LOOP_ONLY=1 timeout 300 python tools/exp/scene_breakdown.py > $OUT/breakdown_oct.log 2>&1
+  timeout 300 python tools/exp/wave_balance.py boxer_push panda_pick > $OUT/wave_balance.log 2>&1
+  MPPI_ROLLOUT=oct timeout 300 $B --workload boxer_push > $OUT/ab_boxer_oct.json 2>> $OUT/ab.err
 fi
 for f in $OUT/bench*.json $OUT/ab_*.json; do [ -f $f ] && python - "$f" <<'PY'
 import json, sys
