@@ -307,7 +307,7 @@ def roofline(loop, kms, hbm_measured, n_waves):
                      "waves": waves, "kernel_ms": kms,
                      "lane_ops_per_s": valu * waves * 64 / (kms * 1e-3),
                      "frac_of_fp32_issue_peak": valu * waves * 64 / (kms * 1e-3) / FP32_LANE_OPS_PEAK,
-                     "simd_occupancy": min(1.0, waves / N_SIMD),
+                     "simd_occupancy": min(1.0, waves / N_SIMD), "waves_per_simd": waves / N_SIMD,
                      "issue_cycles_frac": k.get("issue_cycles_frac"), "wait_cycles_frac": k.get("wait_cycles_frac"),
                      "lds_bank_conflict_per_wave": k.get("SQ_LDS_BANK_CONFLICT_per_wave"),
                      "source": f"profiles/{sq.get('tag')}_sq_summary.json (rocprofv3 --pmc SQ_* passes of this command; kernel_ms live)"}
