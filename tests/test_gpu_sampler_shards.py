@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from mppiisaac.backend import capi
-from scenes import panda_pick, panda_reach
+from scenes import boxer_push, panda_pick, panda_reach
 from test_gpu_parity import Ctx
 
 pytestmark = pytest.mark.gpu
@@ -209,6 +209,45 @@ EXAMPLES = {   # example -> (actors, conf/mppi name, isaacgym conf, nx, robot in
     "panda_stick_push": (["panda_stick", "xaxis", "yaxis", "panda_push_block", "table", "goal"], "panda_stick_push", "normal", 14, [0.0, 0.0, 0.0], "PandaStickPushObjective"),
     "panda_effort": (["panda_effort", "goal"], "panda_effort", "normal", 14, [0.0, 0.0, 0.0], "PandaEffortReachObjective"),
 }
+
+
+def test_pushing_scene_shards_equal_one_context_with_the_helper_wavefront(lib):
+    """BASELINE config 4's scene (boxer_push: floating diff-drive base, contact) sharded: the kernel of the short trees runs a
+    helper wavefront per sample group that takes every other candidate pair; a sample's arithmetic must not depend on which
+    samples share its wavefronts, so shard contexts - also one that starts in the middle of an octet - reproduce the slice of
+    the single context bit for bit, per-sample actor noise included, and the combined records give the same action."""
+    from mppiisaac.planner.mppi import make_config
+    from mppiisaac.utils.config_store import load_config
+    K, H, nu = 4096, 25, 2
+    scene, m, cfg, cost, dof, root = boxer_push(K=K, H=H)
+    m.randomize_seed = 0
+    ex = load_config({"defaults": [{"mppi": "boxer_push"}, {"isaacgym": "normal"}]}, overrides={"mppi.num_samples": K, "mppi.horizon": H})
+    full = Ctx(m, cfg, cost)
+    info = C.create_string_buffer(256)
+    full.call("mppi_kernel_info", info, 256)
+    assert b"rollout=scene-oct-pair" in info.value
+    full.call("mppi_sample", C.c_uint32(0)); full.set_state(dof, root)
+    a_full = np.zeros(nu, np.float32)
+    full.call("mppi_command", capi.fptr(a_full))
+    S_full = full.get("mppi_get_costs", (K,))
+    assert np.isfinite(S_full).all()
+    bounds = [0, 1029, 2048, K]                                               # (1029 = 128 octets + 5: a ragged boundary)
+    RF = lib.mppi_record_floats(full.ctx)
+    records = torch.zeros((len(bounds) - 1, RF), dtype=torch.float32, device="cuda")
+    shards = []
+    for r in range(len(bounds) - 1):
+        sc = make_config(ex.mppi, k_offset=bounds[r], k_local=bounds[r + 1] - bounds[r], viz_link=scene.viz_link_index())
+        s = Ctx(m, sc, cost)
+        s.call("mppi_sample", C.c_uint32(0)); s.set_state(dof, root)
+        s.call("mppi_rollout")
+        np.testing.assert_array_equal(s.get("mppi_get_costs", (bounds[r + 1] - bounds[r],)), S_full[bounds[r]:bounds[r + 1]])
+        s.call("mppi_reduce", C.c_void_p(records[r].data_ptr()))
+        shards.append(s)
+    for s in shards:
+        s.call("mppi_update", C.c_void_p(records.data_ptr()), len(shards))
+        np.testing.assert_allclose(s.get("mppi_get_action", (nu,)), a_full, atol=2e-6)
+        s.close()
+    full.close()
 
 
 @pytest.mark.parametrize("case", sorted(EXAMPLES))
