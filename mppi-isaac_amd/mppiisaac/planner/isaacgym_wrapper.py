@@ -12,6 +12,7 @@ listeners and line drawing are graphics and out of scope.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import logging
 from dataclasses import dataclass, field
@@ -487,6 +488,17 @@ class IsaacGymWrapper:
         if self._stale:
             self._materialise()
         return self._state_t[key]
+
+    @contextlib.contextmanager
+    def _horizon_view(self, tensors: dict, n_rows: int):
+        """the four state tensors replaced by [H*K, ...] blocks (row block t = the envs after horizon step t) and num_envs by
+        H*K, for ONE compute_cost call over a whole horizon (planner/mppi.py: _horizon_batched)"""
+        saved = (self._state_t, self.num_envs, self._stale)
+        self._state_t, self.num_envs, self._stale = tensors, int(n_rows), False
+        try:
+            yield self
+        finally:
+            self._state_t, self.num_envs, self._stale = saved[0], saved[1], True
 
     _dof_state = property(lambda self: self._fresh("dof"))
     _root_state = property(lambda self: self._fresh("root"))

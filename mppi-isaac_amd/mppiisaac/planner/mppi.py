@@ -225,6 +225,10 @@ class MPPIPlanner:
         # MPPI_GENERIC_GRAPH: "0" never capture, "1" capture any Objective, unset: capture Objectives that declare
         # `graph_safe = True` (see _replay_horizon)
         self._graph_state = {"0": "off", "1": "on"}.get(os.environ.get("MPPI_GENERIC_GRAPH", ""), "auto")
+        # MPPI_GENERIC_BATCH: "0" per-step cost calls only, "1" one cost call over the whole horizon without the check,
+        # unset: checked on the first command of every Objective (see _horizon_batched)
+        self._batch_state = {"0": "off", "1": "on"}.get(os.environ.get("MPPI_GENERIC_BATCH", ""), "auto")
+        self._batch_sig, self._batch_buf, self._batch_graph = None, None, None
         self._external_noise = None
         self._iteration = 0   # control iterations so far: the counter of the device-side Gaussian sampler
         self._sampling = sim._mppi_config.sampling
@@ -244,7 +248,7 @@ class MPPIPlanner:
         if tuple(eps.shape) != (self.T, self.nu, self.K) or eps.dtype != torch.float32 or not eps.is_cuda:
             raise ValueError(f"external noise must be a float32 device tensor of shape [{self.T}, {self.nu}, {self.K}]")
         self._external_noise = eps.contiguous()
-        self._graph = None  # a captured horizon has the previous noise pointer baked in
+        self._graph = self._batch_graph = None  # a captured horizon has the previous noise pointer baked in
         capi.check(self._lib, self._lib.mppi_set_noise_dev(self._ctx, C_void(self._external_noise)))
 
     # -- properties mirroring mppi_torch attributes used by callers -----------------------
@@ -284,7 +288,7 @@ class MPPIPlanner:
         else:
             capi.check(lib, lib.mppi_sim_reset(ctx))
             self.sim._needs_reset = False
-            if not self._replay_horizon(state):
+            if not self._horizon_batched(state) and not self._replay_horizon(state):
                 self._horizon_eager(state)
             capi.check(lib, lib.mppi_sim_finish(ctx))
             self.sim._stale = True
@@ -303,7 +307,99 @@ class MPPIPlanner:
         return torch.from_numpy(self._action.copy()).unsqueeze(0) if self.cfg.u_per_command > 1 else torch.from_numpy(self._action.copy())
 
     # -- generic Objective mode: the horizon loop ---------------------------------------------------
-    def _horizon_eager(self, state):
+    def _horizon_batched(self, state) -> bool:
+        """ONE cost call for the whole horizon.  The rollout dynamics never depend on the running cost, and a reference-style
+        Objective is a function of the envs' state tensors, row by row (reference examples/*/planner.py): so the H steps are
+        simulated first, each step's states materialised into row block t of [H*K, ...] tensors, and `compute_cost(sim)` is
+        evaluated once on a sim whose `num_envs` is H*K - ~20 tensor kernels per control iteration instead of ~20 per horizon
+        step (the generic mode is launch-bound: panda reach K=4096 H=20, 8.1 ms per-step -> 3.3 ms as a captured graph ->
+        see DESIGN.md for this path).  S_k = sum_t gamma^t c[t*K + k] goes into the same accumulator.
+        An Objective whose cost depends on anything but the sim tensors (a call counter, the horizon step) would differ:
+        on the first command of every Objective object (and after its `.weights` change) the horizon is evaluated BOTH
+        ways - the command itself uses the reference loop shape - and the batched evaluation is adopted only if the
+        trajectory costs agree; MPPI_GENERIC_BATCH=0 switches it off, =1 skips the check.  Priors are host callbacks per
+        rollout step: they keep the per-step loop."""
+        if self._batch_state == "off" or (self._prior is not None and self.cfg.use_priors):
+            return False
+        sig = self._objective_signature()
+        if self._batch_state == "auto" and self._batch_sig != ("ok", sig):
+            if self._batch_sig == ("no", sig):
+                return False
+            self._batch_sig = ("no", sig)
+            try:
+                S_b = self._batched_costs(state).clone()
+                self.sim.visualize_link_buffer = []
+                capi.check(self._lib, self._lib.mppi_sim_reset(self._ctx))
+                per_step = []
+                self._horizon_eager(state, collect=per_step)      # (this command: the reference loop shape)
+                disc = float(self.cfg.rollout_var_discount) ** torch.arange(self.T, device=S_b.device, dtype=torch.float32)
+                S_e = (torch.stack(per_step) * disc[:, None]).sum(0)
+                scale = float(S_e.abs().max().clamp_min(1e-6))
+                if bool(torch.isfinite(S_b).all()) and float((S_b - S_e).abs().max()) <= 1e-4 * scale:
+                    self._batch_sig = ("ok", sig)
+                else:
+                    warnings.warn("the Objective's cost of a whole horizon evaluated at once differs from its per-step costs "
+                                  "(it depends on more than the sim tensors): keeping one compute_cost call per horizon step")
+            except Exception as e:  # noqa: BLE001 - e.g. an Objective that indexes envs with a fixed num_envs
+                warnings.warn(f"the Objective cannot be evaluated over a whole horizon at once ({type(e).__name__}: {e}); "
+                              "keeping one compute_cost call per horizon step")
+                capi.check(self._lib, self._lib.mppi_sim_reset(self._ctx))
+                self.sim.visualize_link_buffer = []
+                return False
+            return True   # the eager horizon above has produced this command's costs
+        S_b = self._batched_costs(state)
+        capi.check(self._lib, self._lib.mppi_sim_accumulate_cost(self._ctx, 0, C_void(S_b)))
+        return True
+
+    def _batched_costs(self, state) -> torch.Tensor:
+        """simulate the horizon, then S_add [K] = sum_t gamma^t c_t from ONE compute_cost over the [H*K]-env view"""
+        lib, ctx, sim = self._lib, self._ctx, self.sim
+        H, K = self.T, self.K
+        if self._batch_buf is None:
+            f32 = dict(dtype=torch.float32, device=sim.device)
+            t = sim._state_t
+            self._batch_buf = {k: torch.zeros((H * K,) + tuple(v.shape[1:]), **f32) for k, v in t.items()}
+            self._batch_disc = (float(self.cfg.rollout_var_discount) ** torch.arange(H, **f32))[:, None].contiguous()
+            self._batch_graph = None
+        b = self._batch_buf
+
+        def simulate():
+            for t in range(H):
+                capi.check(lib, lib.mppi_sim_step_horizon(ctx, t))
+                capi.check(lib, lib.mppi_sim_materialise(ctx, C_void(b["dof"][t * K]), C_void(b["root"][t * K]), C_void(b["rb"][t * K]),
+                                                         C_void(b["cf"][t * K])))
+        # the 2H launches are library kernels on fixed buffers (no Python inside): captured once, replayed as one launch
+        if self._batch_graph is None and self._graph_state != "off":
+            simulate()                                  # warm-up outside the capture
+            capi.check(lib, lib.mppi_sim_reset(ctx))
+            torch.cuda.synchronize()
+            g, main = torch.cuda.CUDAGraph(), torch.cuda.current_stream()
+            try:
+                with torch.cuda.graph(g):
+                    capi.check(lib, lib.mppi_set_stream(ctx, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+                    simulate()
+                self._batch_graph = g
+            except Exception as e:  # noqa: BLE001
+                warnings.warn(f"the simulated horizon could not be captured into a HIP graph ({type(e).__name__}: {e}); launching it step by step")
+                self._batch_graph = False
+            finally:
+                capi.check(lib, lib.mppi_set_stream(ctx, C.c_void_p(main.cuda_stream)))
+            capi.check(lib, lib.mppi_sim_reset(ctx))
+        if self._batch_graph:
+            self._batch_graph.replay()
+        else:
+            simulate()
+        with sim._horizon_view(b, H * K):
+            c = self._running_cost(state)
+            if sim._visualize_link_present:
+                viz = sim.visualize_link_pos.reshape(H, K, 3)
+                sim.visualize_link_buffer.extend(viz[t] for t in range(H))
+        c = c.to(dtype=torch.float32, device=sim.device)
+        if c.shape != (H * K,):
+            raise ValueError(f"compute_cost must return one cost per env ([{H * K}] over the horizon view), got {tuple(c.shape)}")
+        return (c.view(H, K) * self._batch_disc).sum(0).contiguous()
+
+    def _horizon_eager(self, state, collect=None):
         """reference loop shape (mppi_isaac.py:57-69): per horizon step dynamics() = apply + step, then running_cost()"""
         lib, ctx = self._lib, self._ctx
         with_prior = self._prior is not None and self.cfg.use_priors
@@ -319,6 +415,8 @@ class MPPIPlanner:
             if c.shape != (self.K,):
                 raise ValueError(f"compute_cost must return a [{self.K}] tensor, got {tuple(c.shape)}")
             capi.check(lib, lib.mppi_sim_accumulate_cost(ctx, t, C_void(c)))
+            if collect is not None:
+                collect.append(c.clone())
 
     def _objective_signature(self):
         """what a captured horizon bakes in from the Python side: the objective object and its weights"""

@@ -319,6 +319,7 @@ def test_generic_horizon_graph_replay_equals_eager_loop(lib, monkeypatch):
 
     class Generic(PandaReachObjective):
         fused_spec = None
+    monkeypatch.setenv("MPPI_GENERIC_BATCH", "0")          # (the whole-horizon cost call would take precedence: next test)
     graph = MPPIisaacPlanner(cfg, Generic(cfg))
     monkeypatch.setenv("MPPI_GENERIC_GRAPH", "0")
     eager = MPPIisaacPlanner(cfg, Generic(cfg))
@@ -354,6 +355,88 @@ def test_generic_horizon_graph_replay_equals_eager_loop(lib, monkeypatch):
     assert s.mppi._graph_state == "off" and np.isfinite(a1).all()
     a2 = s.compute_action(list(q), [0.0] * 7).numpy()     # and keeps working eagerly
     assert np.isfinite(a2).all()
+
+
+def test_generic_horizon_in_one_cost_call_equals_the_per_step_loop(lib, monkeypatch):
+    """generic Objective mode evaluates compute_cost ONCE over an [H*K]-env view of the whole horizon after checking, on the
+    first command of an Objective, that this gives the trajectory costs of the reference loop shape; it must follow state /
+    goal / weight changes, keep the rollout visualisation, and refuse Objectives whose cost depends on more than the sim
+    tensors (call counters) or that cannot take H*K envs."""
+    from mppiisaac.objectives import PandaReachObjective, PlanarPushObjective
+    from mppiisaac.planner.mppi_isaac import MPPIisaacPlanner
+    from mppiisaac.utils.config_store import load_config
+    from mppiisaac.utils.transport import bytes_to_torch
+    cfg = load_config({"defaults": [{"mppi": "panda"}, {"isaacgym": "normal"}], "actors": ["panda_stick", "goal"],
+                       "initial_actor_positions": [[0.0, 0.0, 0.0]], "nx": 14},
+                      overrides={"mppi.num_samples": 256, "mppi.horizon": 12, "mppi.use_priors": False, "mppi.filter_u": False})
+
+    class Generic(PandaReachObjective):
+        fused_spec = None
+    batched = MPPIisaacPlanner(cfg, Generic(cfg))
+    monkeypatch.setenv("MPPI_GENERIC_BATCH", "0"); monkeypatch.setenv("MPPI_GENERIC_GRAPH", "0")
+    eager = MPPIisaacPlanner(cfg, Generic(cfg))
+    monkeypatch.delenv("MPPI_GENERIC_BATCH"); monkeypatch.delenv("MPPI_GENERIC_GRAPH")
+    assert batched.mppi._batch_state == "auto" and eager.mppi._batch_state == "off"
+    q = np.array([0.0, -0.94, 0.0, -2.8, 0.0, 1.8675, 0.0])
+    goals = [[0.5, -0.4, 0.3], [0.5, -0.4, 0.3], [0.3, 0.4, 0.5], [0.3, 0.4, 0.5]]
+    for i, goal in enumerate(goals):                       # command 0 checks (and uses the per-step loop), 1.. one call per horizon
+        for pl in (batched, eager):
+            pl.sim.set_actor_position_by_name(goal, "goal")
+        qi = q + 0.05 * i
+        ab, ae = batched.compute_action(list(qi), [0.0] * 7).numpy(), eager.compute_action(list(qi), [0.0] * 7).numpy()
+        np.testing.assert_allclose(batched.mppi.get_costs().numpy(), eager.mppi.get_costs().numpy(), rtol=1e-5)
+        np.testing.assert_allclose(ab, ae, atol=1e-5)
+        np.testing.assert_allclose(bytes_to_torch(batched.get_rollouts()).cpu().numpy(), bytes_to_torch(eager.get_rollouts()).cpu().numpy(), atol=1e-6)
+        assert batched.mppi._batch_sig[0] == "ok" and batched.mppi._graph is None
+    for pl in (batched, eager):                            # a weight change is checked again
+        pl.objective.weights["robot_ori"] = 1.5
+    sig = batched.mppi._batch_sig
+    batched.compute_action(list(q), [0.0] * 7); eager.compute_action(list(q), [0.0] * 7)
+    assert batched.mppi._batch_sig != sig and batched.mppi._batch_sig[0] == "ok"
+    np.testing.assert_allclose(batched.mppi.get_costs().numpy(), eager.mppi.get_costs().numpy(), rtol=1e-5)
+
+    class Counting(PandaReachObjective):                   # the cost depends on how often it was asked: not a function of sim
+        fused_spec = None
+        calls = 0
+        def compute_cost(self, sim):
+            self.calls += 1
+            return super().compute_cost(sim) * (1.0 + 0.01 * (self.calls % 7))
+    with pytest.warns(UserWarning, match="differs from its per-step costs"):
+        c = MPPIisaacPlanner(cfg, Counting(cfg))
+        c.sim.set_actor_position_by_name(goals[0], "goal")
+        a1 = c.compute_action(list(q), [0.0] * 7).numpy()
+    assert c.mppi._batch_sig[0] == "no" and np.isfinite(a1).all()
+    n = c.objective.calls
+    c.compute_action(list(q), [0.0] * 7)                    # and stays with one call per horizon step (graph-captured or not)
+    assert c.mppi._batch_sig[0] == "no"
+
+    class FixedK(PandaReachObjective):                     # sized for K envs at construction: cannot take the H*K view
+        fused_spec = None
+        def compute_cost(self, sim):
+            return super().compute_cost(sim) + torch.zeros(256, device=sim.device)
+    with pytest.warns(UserWarning, match="cannot be evaluated over a whole horizon"):
+        f = MPPIisaacPlanner(cfg, FixedK(cfg))
+        f.sim.set_actor_position_by_name(goals[0], "goal")
+        a1 = f.compute_action(list(q), [0.0] * 7).numpy()
+    assert np.isfinite(a1).all() and np.isfinite(f.compute_action(list(q), [0.0] * 7).numpy()).all()
+
+    # a contact scene: the pushing example with a Python Objective (floating base, per-sample actor noise, contact forces)
+    pcfg = load_config({"defaults": [{"mppi": "boxer_push"}, {"isaacgym": "normal"}],
+                        "actors": ["boxer", "block", "paper_obst1", "paper_obst2", "goal"], "initial_actor_positions": [[0.0, 2.5, 0.05]], "nx": 4},
+                       overrides={"mppi.num_samples": 128, "mppi.horizon": 8, "mppi.use_priors": False, "mppi.filter_u": False})
+
+    class GenericPush(PlanarPushObjective):
+        fused_spec = None
+    pb = MPPIisaacPlanner(pcfg, GenericPush(pcfg))
+    monkeypatch.setenv("MPPI_GENERIC_BATCH", "0"); monkeypatch.setenv("MPPI_GENERIC_GRAPH", "0")
+    pe = MPPIisaacPlanner(pcfg, GenericPush(pcfg))
+    monkeypatch.delenv("MPPI_GENERIC_BATCH"); monkeypatch.delenv("MPPI_GENERIC_GRAPH")
+    for i in range(3):
+        ab = pb.compute_action([0.02 * i, 2.5, 0.0], [0.0] * 3).numpy()
+        ae = pe.compute_action([0.02 * i, 2.5, 0.0], [0.0] * 3).numpy()
+        np.testing.assert_allclose(pb.mppi.get_costs().numpy(), pe.mppi.get_costs().numpy(), rtol=1e-5)
+        np.testing.assert_allclose(ab, ae, atol=2e-4)   # (u_max 2: the softmax amplifies the summation order of the costs)
+    assert pb.mppi._batch_sig[0] == "ok"
 
 
 def test_world_sim_matches_oracle_and_reference_layouts(lib, oracle64):
