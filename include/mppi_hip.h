@@ -318,6 +318,14 @@ int mppi_sim_step_horizon(mppi_ctx_t *ctx, int t);         /* u = clamp(U[t]+eps
 int mppi_sim_materialise(mppi_ctx_t *ctx, float *dof_dev, float *root_dev, float *rb_dev, float *cf_dev);
 int mppi_sim_accumulate_cost(mppi_ctx_t *ctx, int t, const float *cost_dev); /* S += gamma^t c      */
 int mppi_sim_finish(mppi_ctx_t *ctx);                      /* S += control cost                     */
+/* The same horizon in TWO launches for host-side costs that are functions of the state tensors (mppi_isaac.py:57-69 evaluates
+ * running_cost once per horizon step; the dynamics never depend on it): the fused rollout kernel with MPPI_COST_NONE and
+ * every step's env state kept (S = control cost, du as in mppi_rollout), then the reference-layout tensors of all H*K
+ * env-steps - dof [H*K][2n], root [H*K][A][13], rb [H*K][B][13], cf [H*K][B][3], row t*K + k = env k after step t; NULL =
+ * skip.  Costs evaluated on those rows are added with mppi_sim_accumulate_cost(ctx, 0, sum_t gamma^t c_t).
+ * MPPI_EUNSUPPORTED for contexts that run the one-lane kernels or a contact scene with fewer than 8 samples. */
+int mppi_rollout_trajectory(mppi_ctx_t *ctx);
+int mppi_materialise_trajectory(mppi_ctx_t *ctx, float *dof_dev, float *root_dev, float *rb_dev, float *cf_dev);
 /* device-resident closed loop: step a K=1 world with the planner's action, feed its state back */
 int mppi_world_step_from(mppi_ctx_t *world, mppi_ctx_t *planner);
 int mppi_set_state_from_world(mppi_ctx_t *planner, mppi_ctx_t *world);

@@ -143,7 +143,7 @@ void release_ctx(mppi_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *bufs[] = {c->d_model, c->d_cfg, c->d_cost, c->d_x0_dof, c->d_x0_root, c->d_U, c->d_eps, c->d_du, c->d_S, c->d_prior, c->d_viz,
                     c->d_partials, c->d_record, c->d_action, c->d_beta_eta, c->d_q, c->d_qd, c->d_ctrl, c->d_basis, c->d_sigma, c->d_base, c->d_fr, c->d_cf, c->d_filter,
-                    c->d_seq, c->d_fold, c->d_fold_ctr, c->d_wave_clk};
+                    c->d_seq, c->d_fold, c->d_fold_ctr, c->d_wave_clk, c->d_traj, c->d_cost_none};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->h_action) (void)hipHostFree(c->h_action);
@@ -218,6 +218,10 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
             // short trees: the octet kernel with a helper wavefront per sample group (kSplitOctPair) unless MPPI_ROLLOUT=oct
             c->helper_wave = oct && e->rollout_scene_pair != nullptr && !(mode && std::string(mode) == "oct");
             if (c->helper_wave) c->launch_rollout = e->rollout_scene_pair;
+            if (oct) {  // (whole-horizon trajectories for host-side costs: the octet kernel)
+                c->launch_rollout_traj = e->rollout_scene_traj;
+                c->launch_materialise_traj = e->materialise_scene_traj;
+            }
             c->launch_sim_step = c->quad ? e->sim_step_scene_quad : e->sim_step_scene;  // (the K = 1 world included: one quad)
             c->launch_materialise = e->materialise_scene;
             // (large scenes - e.g. the 12-DoF mobile manipulator with table and block - do not fit the one-lane kernels' 64 rows
@@ -231,6 +235,10 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
             c->lanes_per_sample = c->quad ? 4 : 1;
             c->launch_rollout = c->quad ? e->rollout_quad : e->rollout;
             c->launch_rollout_lane = e->rollout;  // cost programs on contact-free scenes run on the one-lane kernel
+            if (c->quad) {
+                c->launch_rollout_traj = e->rollout_traj;
+                c->launch_materialise_traj = e->materialise_traj;
+            }
             c->launch_combine_world = e->combine_world;
             // many envs: quad step kernel; the K = 1 world (and tiny K) keeps the one-lane kernel
             c->launch_sim_step = (c->quad && cfg->num_samples >= 64) ? e->sim_step_quad : e->sim_step;
@@ -418,6 +426,31 @@ int mppi_rollout(mppi_ctx_t *c) {
         c->n_partials = c->quad ? c->n_quads : c->n_waves;
         c->recs_cur = c->d_partials;
     }
+    return launch_check();
+}
+// ---- generic Objective mode, whole horizon at once -------------------------------------------------------------------
+int mppi_rollout_trajectory(mppi_ctx_t *c) {
+    CTX_TRY(c);
+    if (!c->launch_rollout_traj)
+        return fail(MPPI_EUNSUPPORTED, "mppi_rollout_trajectory: this context runs a kernel without the trajectory dump (MPPI_ROLLOUT=lane, or a contact scene with fewer than 8 samples); use the mppi_sim_* steps");
+    const size_t HK = (size_t)c->H * c->K;
+    if (!c->d_traj) {
+        const size_t rows = c->scene ? 2 * (size_t)c->n + 13 + 13 * (size_t)kMaxFree + 3 * (size_t)c->hm.n_rb : 2 * (size_t)c->n;
+        ALLOC_TRY(c->d_traj, sizeof(float) * rows * HK);
+        ALLOC_TRY(c->d_cost_none, sizeof(DevCost));
+        HIP_TRY(hipMemsetAsync(c->d_cost_none, 0, sizeof(DevCost), c->stream));  // kind = MPPI_COST_NONE
+    }
+    {
+        EvScope ev(c, 0);
+        c->launch_rollout_traj(c);
+    }
+    c->partials_valid = false;  // S holds the control cost only: the records follow the host-side costs (mppi_reduce)
+    return launch_check();
+}
+int mppi_materialise_trajectory(mppi_ctx_t *c, float *dof, float *root, float *rb, float *cf) {
+    CTX_TRY(c);
+    if (!c->launch_materialise_traj || !c->d_traj) return fail(MPPI_ESTATE, "mppi_materialise_trajectory: no trajectory (mppi_rollout_trajectory)");
+    c->launch_materialise_traj(c, dof, root, rb, cf);
     return launch_check();
 }
 int mppi_reduce(mppi_ctx_t *c, float *record_out_dev) {

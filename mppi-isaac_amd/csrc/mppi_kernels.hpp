@@ -245,14 +245,14 @@ __global__ __launch_bounds__(kWave) void k_rollout(const DevModel *__restrict__ 
 }
 
 // Quad-parallel rollout (mppi_quad.hpp): 4 lanes per sample, 16 samples per wavefront.
-template <class T>
+template <class T, bool DUMP = false>
 __global__ __launch_bounds__(kWave) void k_rollout_quad(const DevModel *__restrict__ m, const DevCfg *__restrict__ cfg,
                                                         const DevCost *__restrict__ cost, const float *__restrict__ x0_dof,
                                                         const float *__restrict__ x0_root, const float *__restrict__ U,
                                                         const float *__restrict__ eps, const float *__restrict__ prior,
                                                         float *__restrict__ du, float *__restrict__ S, float *__restrict__ viz,
                                                         float *__restrict__ partials, unsigned *__restrict__ fold_ctr, float *__restrict__ fold_out,
-                                                        unsigned long long *__restrict__ wave_clk) {
+                                                        unsigned long long *__restrict__ wave_clk, float *__restrict__ traj = nullptr) {
 #if defined(__HIP_DEVICE_COMPILE__)  // (the host pass sees the 4-float emulation type of mppi_quad.hpp)
     const unsigned long long clk0 = wave_clk != nullptr ? wall_clock64() : 0ull;
     // Stage the robot model (header + body + link blocks, ~4 KB) in LDS once per wavefront: constants are then
@@ -283,8 +283,8 @@ __global__ __launch_bounds__(kWave) void k_rollout_quad(const DevModel *__restri
     float s = INFINITY;
     if (live) {
         // one wave-uniform branch picks the instruction stream specialised for an all-revolute tree
-        if (((CModel *)m)->all_revolute) s = quad_rollout<T, 0>(lm, *(CCfg *)cfg, *(CCost *)cost, sc, x0_dof, x0_root, eps, prior, du, viz, k, leader, quad_row(), lane4 < 3);
-        else s = quad_rollout<T, -1>(lm, *(CCfg *)cfg, *(CCost *)cost, sc, x0_dof, x0_root, eps, prior, du, viz, k, leader, quad_row(), lane4 < 3);
+        if (((CModel *)m)->all_revolute) s = quad_rollout<T, 0, DUMP>(lm, *(CCfg *)cfg, *(CCost *)cost, sc, x0_dof, x0_root, eps, prior, du, viz, k, leader, quad_row(), lane4 < 3, traj);
+        else s = quad_rollout<T, -1, DUMP>(lm, *(CCfg *)cfg, *(CCost *)cost, sc, x0_dof, x0_root, eps, prior, du, viz, k, leader, quad_row(), lane4 < 3, traj);
         if (leader) S[k] = s;
     }
     quad_record(*(CCfg *)cfg, s, live && leader, du, chunk * 16, partials + (size_t)chunk * (2 + cfg->H * cfg->nu));
@@ -567,17 +567,18 @@ __global__ __launch_bounds__(kWave) void k_rollout_scene(const DevModel *__restr
 #else
 #define MPPI_SCENE_OCCUPANCY
 #endif
-template <class T, int LPS, int NW = 1>
+template <class T, int LPS, int NW = 1, bool DUMP = false>
 __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW))) MPPI_SCENE_OCCUPANCY void k_rollout_scene_quad(const DevModel *__restrict__ m, const DevCfg *__restrict__ cfg,
                                                               const DevCost *__restrict__ cost, const float *__restrict__ x0_dof,
                                                               const float *__restrict__ x0_root, const float *__restrict__ U,
                                                               const float *__restrict__ eps, const float *__restrict__ prior,
                                                               float *__restrict__ du, float *__restrict__ S, float *__restrict__ viz,
                                                               float *__restrict__ partials, unsigned *__restrict__ fold_ctr, float *__restrict__ fold_out,
-                                                              unsigned long long *__restrict__ wave_clk) {
+                                                              unsigned long long *__restrict__ wave_clk, float *__restrict__ traj = nullptr) {
 #if defined(__HIP_DEVICE_COMPILE__)
     static_assert(LPS == 4 || LPS == 8, "4 or 8 lanes per sample");
     static_assert(NW == 1 || (NW == 2 && LPS == 8 && T::NB <= 4), "helper wavefront: octet layout of the short trees only");
+    static_assert(!DUMP || NW == 1, "trajectory dump: single-wavefront kernels");
     constexpr int SPW = kWave / LPS;
     constexpr int kSplit = NW == 2 ? kSplitOctPair : (LPS == 8 ? kSplitOct : kSplitQuad);
     const unsigned long long clk0 = wave_clk != nullptr ? wall_clock64() : 0ull;
@@ -638,7 +639,7 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW))
     }
     float s = INFINITY;
     if (live) {
-        s = rollout_scene<T, kSplit>(M, lm, *(CCfg *)cfg, *(CCost *)cost, x0_dof, x0_root, U, eps, prior, du, viz, k, L, Split{sub, LPS});
+        s = rollout_scene<T, kSplit, DUMP>(M, lm, *(CCfg *)cfg, *(CCost *)cost, x0_dof, x0_root, U, eps, prior, du, viz, k, L, Split{sub, LPS}, traj);
         if (sub == 0) S[k] = s;
     }
     quad_record<SPW>(*(CCfg *)cfg, s, live && sub == 0, du, chunk * SPW, partials + (size_t)chunk * (2 + cfg->H * cfg->nu));
@@ -1131,6 +1132,10 @@ struct mppi_ctx {
     int n = 0, A = 0, B = 0, K = 0, H = 0, nu = 0, HN = 0, RF = 0, n_waves = 0;
     int n_quads = 0;      // wavefronts of the quad- / octet-parallel rollout (16 / 8 samples each)
     int lanes_per_sample = 1;  // 1 (lane kernels), 4 (quad kernels), 8 (contact scenes: octets)
+    float *d_traj = nullptr;          // per-step env states of one rollout set (mppi_rollout_trajectory), allocated on first use
+    DevCost *d_cost_none = nullptr;    // a zero cost for those rollouts
+    void (*launch_rollout_traj)(mppi_ctx *) = nullptr;
+    void (*launch_materialise_traj)(mppi_ctx *, float *, float *, float *, float *) = nullptr;
     bool helper_wave = false;  // octet rollout kernel with a second wavefront per sample group for half of the contact pairs
     int n_partials = 0;   // records currently held by d_partials
     bool quad = false;
@@ -1185,6 +1190,10 @@ struct TopoEntry {
     void (*rollout_scene_quad)(mppi_ctx *);
     void (*rollout_scene_oct)(mppi_ctx *);  // 8 lanes per sample
     void (*rollout_scene_pair)(mppi_ctx *); // 8 lanes per sample + a helper wavefront (null: trees of more than 4 bodies)
+    void (*rollout_traj)(mppi_ctx *);        // fused rollouts with the per-step states dumped (generic Objective mode)
+    void (*rollout_scene_traj)(mppi_ctx *);
+    void (*materialise_traj)(mppi_ctx *, float *, float *, float *, float *);
+    void (*materialise_scene_traj)(mppi_ctx *, float *, float *, float *, float *);
     void (*sim_step)(mppi_ctx *, int, int, const float *);
     void (*sim_step_quad)(mppi_ctx *, int, int, const float *);
     void (*sim_step_scene)(mppi_ctx *, int, int, const float *);
@@ -1224,6 +1233,21 @@ void launch_rollout_scene_pair_t(mppi_ctx *c) {
                            c->d_partials, c->fold ? c->d_fold_ctr : nullptr, c->fold_out, c->wave_clk_on ? c->d_wave_clk : nullptr);
     }
 }
+// generic Objective mode, whole horizon at once: the fused rollout with the per-step states dumped (cost NONE), then the
+// reference-layout tensors of all H*K env-steps from ONE materialise launch
+template <class T>
+void launch_rollout_scene_traj_t(mppi_ctx *c) {
+    hipLaunchKernelGGL((k_rollout_scene_quad<T, 8, 1, true>), dim3(c->n_quads), dim3(kWave), c->lds_bytes_quad * (kWave / 8) / 16 + c->lds_bytes_table, c->stream, c->d_model, c->d_cfg, c->d_cost_none, c->d_x0_dof,
+                       c->d_x0_root, c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_S, (float *)nullptr,
+                       c->d_partials, (unsigned *)nullptr, c->fold_out, (unsigned long long *)nullptr, c->d_traj);
+}
+template <class T>
+void launch_materialise_scene_traj_t(mppi_ctx *c, float *dof, float *root, float *rb, float *cf) {
+    const size_t HK = (size_t)c->H * c->K;
+    float *q = c->d_traj, *qd = q + (size_t)T::NB * HK, *base = qd + (size_t)T::NB * HK, *fr = base + 13 * HK, *cfr = fr + (size_t)13 * kMaxFree * HK;
+    hipLaunchKernelGGL(k_materialise_scene<T>, dim3((unsigned)((HK + kWave - 1) / kWave)), dim3(kWave), 0, c->stream, c->d_model, (int)HK, c->d_x0_root, q, qd, base,
+                       fr, cfr, dof, root, rb, cf);
+}
 template <class T>
 void launch_sim_step_scene_t(mppi_ctx *c, int mode, int t, const float *u_ext) {
     hipLaunchKernelGGL(k_sim_step_scene<T>, dim3(c->n_waves), dim3(kWave), c->lds_bytes, c->stream, c->d_model, c->d_cfg, mode, t, u_ext, c->d_x0_root,
@@ -1245,6 +1269,8 @@ hipError_t raise_lds_limit(size_t lane_bytes, size_t quad_bytes) {  // lane_byte
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rollout_scene_quad<T, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)quad_bytes);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rollout_scene_quad<T, 8, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)quad_bytes);
+    if (e != hipSuccess) return e;
     if constexpr (T::NB <= 4) {  // (+ the helper's accumulator set: bounded by the quad kernel's 16-sample figure)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rollout_scene_quad<T, 8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)quad_bytes);
         if (e != hipSuccess) return e;
@@ -1261,6 +1287,18 @@ void launch_rollout_quad_t(mppi_ctx *c) {
     hipLaunchKernelGGL(k_rollout_quad<T>, dim3(c->n_quads), dim3(kWave), 0, c->stream, c->d_model, c->d_cfg, c->d_cost, c->d_x0_dof, c->d_x0_root,
                        c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_S, c->cfg.want_rollouts ? c->d_viz : nullptr, c->d_partials,
                        c->fold ? c->d_fold_ctr : nullptr, c->fold_out, c->wave_clk_on ? c->d_wave_clk : nullptr);
+}
+template <class T>
+void launch_rollout_traj_t(mppi_ctx *c) {
+    hipLaunchKernelGGL((k_rollout_quad<T, true>), dim3(c->n_quads), dim3(kWave), 0, c->stream, c->d_model, c->d_cfg, c->d_cost_none, c->d_x0_dof, c->d_x0_root,
+                       c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_S, (float *)nullptr, c->d_partials,
+                       (unsigned *)nullptr, c->fold_out, (unsigned long long *)nullptr, c->d_traj);
+}
+template <class T>
+void launch_materialise_traj_t(mppi_ctx *c, float *dof, float *root, float *rb, float *cf) {
+    const size_t HK = (size_t)c->H * c->K;
+    hipLaunchKernelGGL(k_materialise<T>, dim3((unsigned)((HK + kWave - 1) / kWave)), dim3(kWave), 0, c->stream, c->d_model, (int)HK, c->d_x0_root, c->d_traj,
+                       c->d_traj + (size_t)T::NB * HK, dof, root, rb, cf);
 }
 template <class T>
 void launch_combine_world_t(mppi_ctx *p, const float *recs, int n, mppi_ctx *w) {
@@ -1304,6 +1342,10 @@ TopoEntry make_topo_entry() {
     e.sim_step_quad = &launch_sim_step_quad_t<T>;
     e.sim_step_scene = &launch_sim_step_scene_t<T>;
     e.sim_step_scene_quad = &launch_sim_step_scene_quad_t<T>;
+    e.rollout_traj = &launch_rollout_traj_t<T>;
+    e.rollout_scene_traj = &launch_rollout_scene_traj_t<T>;
+    e.materialise_traj = &launch_materialise_traj_t<T>;
+    e.materialise_scene_traj = &launch_materialise_scene_traj_t<T>;
     e.materialise = &launch_materialise_t<T>;
     e.materialise_scene = &launch_materialise_scene_t<T>;
     e.combine_world = &launch_combine_world_t<T>;

@@ -457,9 +457,11 @@ MPPI_HD float apply_controls_q(LStep &sc, float lambda, bool abs_cost, int nu, i
 
 // Whole-horizon rollout of the sample owned by this quad.  Every lane of the quad returns the same S.
 // `leader` is true in exactly one lane of the quad (it performs the du store); lanes 0..2 store viz.
-template <class T, int JT, class M>
+// DUMP: the state after every step goes to `traj` as well (q rows [NB][H*K], then qd rows: column t*K + k) - the generic
+// Objective mode evaluates Python costs on the materialised trajectory (mppi_rollout_trajectory).
+template <class T, int JT, bool DUMP = false, class M = void>
 MPPI_HD QF quad_rollout(M &m0, CCfg &cfg0, CCost &cost0, LStep &sc, const float *dof0, const float *root, const float *eps,
-                        const float *prior, float *du, float *viz, int k, bool leader, int row, bool viz_lane) {
+                        const float *prior, float *du, float *viz, int k, bool leader, int row, bool viz_lane, float *traj = nullptr) {
     constexpr int NB = T::NB;
     // read once, kept in SGPRs across the horizon (not laundered)
     const int K = cfg0.K, nu = cfg0.nu, H = cfg0.H, kind = cost0.kind, link = cost0.link[0], viz_link = cfg0.viz_link;
@@ -504,6 +506,14 @@ MPPI_HD QF quad_rollout(M &m0, CCfg &cfg0, CCost &cost0, LStep &sc, const float 
             });
         }
         quad_step<T>(*mp, P, q, qd, target);
+        if constexpr (DUMP) {  // (the four lanes of a quad hold the same values: same-address stores, as for du)
+            const unsigned HK = (unsigned)H * (unsigned)K, col = (unsigned)t * (unsigned)K + (unsigned)k;
+            static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
+                constexpr int i = ic;
+                traj[(unsigned)i * HK + col] = qlane0(q[i]);
+                traj[(unsigned)(NB + i) * HK + col] = qlane0(qd[i]);
+            });
+        }
         QM3 Rl;  // pose of the cost link, shared with the rollout visualisation when that shows the same link
         QF pl = qrep(0.f);
         for (int c = 0; c < 3; c++) Rl.c[c] = qrep(0.f);

@@ -1524,9 +1524,12 @@ MPPI_HD void step_scene_any(M &m, MR &mr, const float *root, SceneState<T> &s, c
 }
 
 // mr0: view of the same model for the robot algebra of the quad path (an LDS copy of the model prefix in the kernel)
-template <class T, int SPLIT = kSplitNone, class M = CModel, class MR = CModel>
+// DUMP: the env state after every step goes to `traj` as well, in the sample-minor layout of the simulator's state arrays with
+// H*K columns (column t*K + k): q [NB], qd [NB], base [13], free actors [kMaxFree*13], net contact forces [3*n_rb] - the generic
+// Objective mode evaluates Python costs on the materialised trajectory (mppi_rollout_trajectory).
+template <class T, int SPLIT = kSplitNone, bool DUMP = false, class M = CModel, class MR = CModel>
 MPPI_HD float rollout_scene(M &m0, MR &mr0, CCfg &cfg0, CCost &cost0, const float *dof0, const float *root, const float *U, const float *eps,
-                            const float *prior, float *du, float *viz, int k, const LMem &L, Split split = Split{0, 1}) {
+                            const float *prior, float *du, float *viz, int k, const LMem &L, Split split = Split{0, 1}, float *traj = nullptr) {
     const bool leader = split.sub == 0;  // lanes sharing a sample hold identical values: one of them writes
     constexpr int NB = T::NB;
     const int K = cfg0.K, nu = cfg0.nu, H = cfg0.H;
@@ -1566,6 +1569,25 @@ MPPI_HD float rollout_scene(M &m0, MR &mr0, CCfg &cfg0, CCost &cost0, const floa
             }
         } else {
             S += disc * step_tail_scene_quad<T>(*launder(mp), mr0, cfg, *launder(kp), root, s, L, viz, t, k, leader);
+        }
+        if constexpr (DUMP) {
+            if (leader) {
+                const size_t HK = (size_t)H * K, col = (size_t)t * K + k;
+                float *o = traj + col;
+                static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
+                    constexpr int i = ic;
+                    o[(size_t)i * HK] = s.q[i];
+                    o[(size_t)(NB + i) * HK] = s.qd[i];
+                });
+                o += (size_t)2 * NB * HK;
+                for (int j = 0; j < 13; j++) o[(size_t)j * HK] = s.base[j];
+                o += (size_t)13 * HK;
+                for (int f = 0; f < kMaxFree; f++)
+                    for (int j = 0; j < 13; j++) o[(size_t)(f * 13 + j) * HK] = s.fr[f][j];
+                o += (size_t)13 * kMaxFree * HK;
+                const int n_cf = 3 * launder(mp)->n_rb;
+                for (int j = 0; j < n_cf; j++) o[(size_t)j * HK] = L[SceneLayout<T>::kCf + j];
+            }
         }
         MPPI_SEC(9);
         disc *= cfg.gamma;

@@ -361,7 +361,19 @@ class MPPIPlanner:
             self._batch_buf = {k: torch.zeros((H * K,) + tuple(v.shape[1:]), **f32) for k, v in t.items()}
             self._batch_disc = (float(self.cfg.rollout_var_discount) ** torch.arange(H, **f32))[:, None].contiguous()
             self._batch_graph = None
+            self._batch_fused = None   # None: not tried yet; True / False: the library's whole-horizon rollout is / is not available
         b = self._batch_buf
+        # the whole horizon in two launches: the fused rollout kernel (no cost, per-step states kept), then one materialise
+        # over all H*K env-steps; contexts without that kernel simulate step by step below
+        if self._batch_fused is not False:
+            rc = lib.mppi_rollout_trajectory(ctx)
+            if self._batch_fused is None:
+                self._batch_fused = rc == 0
+            elif rc != 0:
+                capi.check(lib, rc)
+        if self._batch_fused:
+            capi.check(lib, lib.mppi_materialise_trajectory(ctx, C_void(b["dof"]), C_void(b["root"]), C_void(b["rb"]), C_void(b["cf"])))
+            return self._horizon_costs(state, b)
 
         def simulate():
             for t in range(H):
@@ -389,6 +401,10 @@ class MPPIPlanner:
             self._batch_graph.replay()
         else:
             simulate()
+        return self._horizon_costs(state, b)
+
+    def _horizon_costs(self, state, b) -> torch.Tensor:
+        sim, H, K = self.sim, self.T, self.K
         with sim._horizon_view(b, H * K):
             c = self._running_cost(state)
             if sim._visualize_link_present:

@@ -388,6 +388,7 @@ def test_generic_horizon_in_one_cost_call_equals_the_per_step_loop(lib, monkeypa
         np.testing.assert_allclose(ab, ae, atol=1e-5)
         np.testing.assert_allclose(bytes_to_torch(batched.get_rollouts()).cpu().numpy(), bytes_to_torch(eager.get_rollouts()).cpu().numpy(), atol=1e-6)
         assert batched.mppi._batch_sig[0] == "ok" and batched.mppi._graph is None
+    assert batched.mppi._batch_fused is True               # the horizon came from the fused rollout kernel with the state dump
     for pl in (batched, eager):                            # a weight change is checked again
         pl.objective.weights["robot_ori"] = 1.5
     sig = batched.mppi._batch_sig
@@ -435,8 +436,23 @@ def test_generic_horizon_in_one_cost_call_equals_the_per_step_loop(lib, monkeypa
         ab = pb.compute_action([0.02 * i, 2.5, 0.0], [0.0] * 3).numpy()
         ae = pe.compute_action([0.02 * i, 2.5, 0.0], [0.0] * 3).numpy()
         np.testing.assert_allclose(pb.mppi.get_costs().numpy(), pe.mppi.get_costs().numpy(), rtol=1e-5)
-        np.testing.assert_allclose(ab, ae, atol=2e-4)   # (u_max 2: the softmax amplifies the summation order of the costs)
-    assert pb.mppi._batch_sig[0] == "ok"
+        # (the single call runs the octet rollout kernel, the per-step loop the 4-lane step kernel: contact sums in another
+        # order, and the softmax - lambda 0.01, u_max 2 - amplifies 1e-6 cost differences)
+        np.testing.assert_allclose(ab, ae, atol=1e-3)
+    assert pb.mppi._batch_sig[0] == "ok" and pb.mppi._batch_fused is True
+    # contexts without the dumping kernel (here: one lane per sample) simulate the horizon step by step, captured as a graph
+    monkeypatch.setenv("MPPI_ROLLOUT", "lane")
+    lane = MPPIisaacPlanner(cfg, Generic(cfg))
+    monkeypatch.setenv("MPPI_GENERIC_BATCH", "0"); monkeypatch.setenv("MPPI_GENERIC_GRAPH", "0")
+    lane_eager = MPPIisaacPlanner(cfg, Generic(cfg))
+    for v in ("MPPI_ROLLOUT", "MPPI_GENERIC_BATCH", "MPPI_GENERIC_GRAPH"): monkeypatch.delenv(v)
+    for i, goal in enumerate(goals[:3]):
+        for pl in (lane, lane_eager):
+            pl.sim.set_actor_position_by_name(goal, "goal")
+        al, ae = lane.compute_action(list(q), [0.0] * 7).numpy(), lane_eager.compute_action(list(q), [0.0] * 7).numpy()
+        np.testing.assert_allclose(lane.mppi.get_costs().numpy(), lane_eager.mppi.get_costs().numpy(), rtol=1e-5)
+        np.testing.assert_allclose(al, ae, atol=1e-5)
+    assert lane.mppi._batch_sig[0] == "ok" and lane.mppi._batch_fused is False and lane.mppi._batch_graph
 
 
 def test_world_sim_matches_oracle_and_reference_layouts(lib, oracle64):
