@@ -308,58 +308,58 @@ class MPPIPlanner:
 
     # -- generic Objective mode: the horizon loop ---------------------------------------------------
     def _horizon_batched(self, state) -> bool:
-        """ONE cost call for the whole horizon.  The rollout dynamics never depend on the running cost, and a reference-style
-        Objective is a function of the envs' state tensors, row by row (reference examples/*/planner.py): so the H steps are
-        simulated first, each step's states materialised into row block t of [H*K, ...] tensors, and `compute_cost(sim)` is
-        evaluated once on a sim whose `num_envs` is H*K - ~20 tensor kernels per control iteration instead of ~20 per horizon
-        step (the generic mode is launch-bound: panda reach K=4096 H=20, 8.1 ms per-step -> 3.3 ms as a captured graph ->
-        see DESIGN.md for this path).  S_k = sum_t gamma^t c[t*K + k] goes into the same accumulator.
-        An Objective whose cost depends on anything but the sim tensors (a call counter, the horizon step) would differ:
-        on the first command of every Objective object (and after its `.weights` change) the horizon is evaluated BOTH
-        ways - the command itself uses the reference loop shape - and the batched evaluation is adopted only if the
-        trajectory costs agree; MPPI_GENERIC_BATCH=0 switches it off, =1 skips the check.  Priors are host callbacks per
-        rollout step: they keep the per-step loop."""
+        """The horizon without a simulator launch per step.  The rollout dynamics never depend on the running cost, so the H
+        steps are simulated first (`_simulate_horizon`: the fused rollout kernel with every step's env state kept, or 2H step /
+        materialise launches replayed as a graph) into [H*K, ...] state tensors - row t*K + k = env k after horizon step t.
+        The Objective then sees them either
+          * in ONE call, through a view of the simulator whose `num_envs` is H*K: a reference-style Objective is a row-wise
+            function of the state tensors (reference examples/*/planner.py), so this is the same cost with ~H times fewer
+            kernel launches (generic mode is launch-bound); or
+          * in H calls on the [K]-row blocks, in horizon order - the reference's call pattern (mppi_isaac.py:57-69) on
+            precomputed states, valid for any Objective that only READS the simulator.
+        Which one: on the first command of every Objective object (and after its `.weights` change) both are evaluated on the
+        same states; the single call is adopted if the costs agree, otherwise (a call counter, a dependence on the horizon
+        step, tensors sized for K envs) the H calls stay, with a warning.  S_k = sum_t gamma^t c_t[k] goes into the same
+        accumulator.  MPPI_GENERIC_BATCH=0 keeps the reference loop shape (step, cost, step, ...), =1 skips the check;
+        priors are host callbacks that see the envs' state at every rollout step: they keep the step-by-step loop too."""
         if self._batch_state == "off" or (self._prior is not None and self.cfg.use_priors):
             return False
         sig = self._objective_signature()
-        if self._batch_state == "auto" and self._batch_sig != ("ok", sig):
-            if self._batch_sig == ("no", sig):
-                return False
+        b = self._simulate_horizon()
+        single = self._batch_state == "on" or self._batch_sig == ("ok", sig)
+        if not single and self._batch_sig != ("no", sig):       # first command of this Objective: check
             self._batch_sig = ("no", sig)
+            viz = list(self.sim.visualize_link_buffer)
+            S_one = None
             try:
-                S_b = self._batched_costs(state).clone()
-                self.sim.visualize_link_buffer = []
-                capi.check(self._lib, self._lib.mppi_sim_reset(self._ctx))
-                per_step = []
-                self._horizon_eager(state, collect=per_step)      # (this command: the reference loop shape)
-                disc = float(self.cfg.rollout_var_discount) ** torch.arange(self.T, device=S_b.device, dtype=torch.float32)
-                S_e = (torch.stack(per_step) * disc[:, None]).sum(0)
-                scale = float(S_e.abs().max().clamp_min(1e-6))
-                if bool(torch.isfinite(S_b).all()) and float((S_b - S_e).abs().max()) <= 1e-4 * scale:
+                S_one = self._horizon_costs(state, b, single=True)
+            except Exception as e:  # noqa: BLE001 - e.g. an Objective with tensors sized for K envs
+                warnings.warn(f"the Objective cannot be evaluated over a whole horizon in one call ({type(e).__name__}: {e}); "
+                              "keeping one compute_cost call per horizon step")
+            self.sim.visualize_link_buffer = viz
+            S_add = self._horizon_costs(state, b, single=False)   # (this command: the reference's call pattern)
+            if S_one is not None:
+                scale = float(S_add.abs().max().clamp_min(1e-6))
+                if bool(torch.isfinite(S_one).all()) and float((S_one - S_add).abs().max()) <= 1e-5 * scale:
                     self._batch_sig = ("ok", sig)
                 else:
-                    warnings.warn("the Objective's cost of a whole horizon evaluated at once differs from its per-step costs "
+                    warnings.warn("the Objective's cost of a whole horizon evaluated in one call differs from its per-step costs "
                                   "(it depends on more than the sim tensors): keeping one compute_cost call per horizon step")
-            except Exception as e:  # noqa: BLE001 - e.g. an Objective that indexes envs with a fixed num_envs
-                warnings.warn(f"the Objective cannot be evaluated over a whole horizon at once ({type(e).__name__}: {e}); "
-                              "keeping one compute_cost call per horizon step")
-                capi.check(self._lib, self._lib.mppi_sim_reset(self._ctx))
-                self.sim.visualize_link_buffer = []
-                return False
-            return True   # the eager horizon above has produced this command's costs
-        S_b = self._batched_costs(state)
-        capi.check(self._lib, self._lib.mppi_sim_accumulate_cost(self._ctx, 0, C_void(S_b)))
+        else:
+            S_add = self._horizon_costs(state, b, single=single)
+        capi.check(self._lib, self._lib.mppi_sim_accumulate_cost(self._ctx, 0, C_void(S_add)))
         return True
 
-    def _batched_costs(self, state) -> torch.Tensor:
-        """simulate the horizon, then S_add [K] = sum_t gamma^t c_t from ONE compute_cost over the [H*K]-env view"""
+    def _simulate_horizon(self) -> dict:
+        """the envs' state after every horizon step as reference-layout tensors [H*K, ...] (row t*K + k)"""
         lib, ctx, sim = self._lib, self._ctx, self.sim
         H, K = self.T, self.K
         if self._batch_buf is None:
             f32 = dict(dtype=torch.float32, device=sim.device)
             t = sim._state_t
             self._batch_buf = {k: torch.zeros((H * K,) + tuple(v.shape[1:]), **f32) for k, v in t.items()}
-            self._batch_disc = (float(self.cfg.rollout_var_discount) ** torch.arange(H, **f32))[:, None].contiguous()
+            self._batch_gamma = [float(self.cfg.rollout_var_discount) ** t for t in range(H)]
+            self._batch_disc = torch.tensor(self._batch_gamma, **f32)[:, None].contiguous()
             self._batch_graph = None
             self._batch_fused = None   # None: not tried yet; True / False: the library's whole-horizon rollout is / is not available
         b = self._batch_buf
@@ -373,7 +373,7 @@ class MPPIPlanner:
                 capi.check(lib, rc)
         if self._batch_fused:
             capi.check(lib, lib.mppi_materialise_trajectory(ctx, C_void(b["dof"]), C_void(b["root"]), C_void(b["rb"]), C_void(b["cf"])))
-            return self._horizon_costs(state, b)
+            return b
 
         def simulate():
             for t in range(H):
@@ -401,21 +401,33 @@ class MPPIPlanner:
             self._batch_graph.replay()
         else:
             simulate()
-        return self._horizon_costs(state, b)
+        return b
 
-    def _horizon_costs(self, state, b) -> torch.Tensor:
+    def _horizon_costs(self, state, b, single: bool) -> torch.Tensor:
+        """S_add [K] = sum_t gamma^t c_t from ONE compute_cost over the [H*K]-env view, or from H calls on its [K]-row blocks"""
         sim, H, K = self.sim, self.T, self.K
-        with sim._horizon_view(b, H * K):
-            c = self._running_cost(state)
-            if sim._visualize_link_present:
-                viz = sim.visualize_link_pos.reshape(H, K, 3)
-                sim.visualize_link_buffer.extend(viz[t] for t in range(H))
-        c = c.to(dtype=torch.float32, device=sim.device)
-        if c.shape != (H * K,):
-            raise ValueError(f"compute_cost must return one cost per env ([{H * K}] over the horizon view), got {tuple(c.shape)}")
-        return (c.view(H, K) * self._batch_disc).sum(0).contiguous()
+        if single:
+            with sim._horizon_view(b, H * K):
+                c = self._running_cost(state)
+                if sim._visualize_link_present:
+                    viz = sim.visualize_link_pos.reshape(H, K, 3)
+                    sim.visualize_link_buffer.extend(viz[t] for t in range(H))
+            c = c.to(dtype=torch.float32, device=sim.device)
+            if c.shape != (H * K,):
+                raise ValueError(f"compute_cost must return one cost per env ([{H * K}] over the horizon view), got {tuple(c.shape)}")
+            return (c.view(H, K) * self._batch_disc).sum(0).contiguous()
+        S = torch.zeros(K, dtype=torch.float32, device=sim.device)
+        for t in range(H):
+            with sim._horizon_view({k: v[t * K:(t + 1) * K] for k, v in b.items()}, K):
+                if sim._visualize_link_present:
+                    sim.visualize_link_buffer.append(sim.visualize_link_pos.clone())
+                c = self._running_cost(state).to(dtype=torch.float32, device=sim.device)
+            if c.shape != (K,):
+                raise ValueError(f"compute_cost must return a [{K}] tensor, got {tuple(c.shape)}")
+            S += self._batch_gamma[t] * c
+        return S
 
-    def _horizon_eager(self, state, collect=None):
+    def _horizon_eager(self, state):
         """reference loop shape (mppi_isaac.py:57-69): per horizon step dynamics() = apply + step, then running_cost()"""
         lib, ctx = self._lib, self._ctx
         with_prior = self._prior is not None and self.cfg.use_priors
@@ -431,8 +443,6 @@ class MPPIPlanner:
             if c.shape != (self.K,):
                 raise ValueError(f"compute_cost must return a [{self.K}] tensor, got {tuple(c.shape)}")
             capi.check(lib, lib.mppi_sim_accumulate_cost(ctx, t, C_void(c)))
-            if collect is not None:
-                collect.append(c.clone())
 
     def _objective_signature(self):
         """what a captured horizon bakes in from the Python side: the objective object and its weights"""
