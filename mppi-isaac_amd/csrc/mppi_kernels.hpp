@@ -578,7 +578,6 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW))
 #if defined(__HIP_DEVICE_COMPILE__)
     static_assert(LPS == 4 || LPS == 8, "4 or 8 lanes per sample");
     static_assert(NW == 1 || (NW == 2 && LPS == 8 && T::NB <= 4), "helper wavefront: octet layout of the short trees only");
-    static_assert(!DUMP || NW == 1, "trajectory dump: single-wavefront kernels");
     constexpr int SPW = kWave / LPS;
     constexpr int kSplit = NW == 2 ? kSplitOctPair : (LPS == 8 ? kSplitOct : kSplitQuad);
     const unsigned long long clk0 = wave_clk != nullptr ? wall_clock64() : 0ull;
@@ -1237,6 +1236,15 @@ void launch_rollout_scene_pair_t(mppi_ctx *c) {
 // reference-layout tensors of all H*K env-steps from ONE materialise launch
 template <class T>
 void launch_rollout_scene_traj_t(mppi_ctx *c) {
+    if constexpr (T::NB <= 4) {  // short trees: the kernel with the helper wavefront (pair_lds_bytes is defined below)
+        if (c->helper_wave) {
+            const size_t row = c->lds_bytes_quad / 16 + sizeof(float) * ((size_t)SceneLayout<T>::NF * 27 + 3 * (size_t)c->hm.n_rb + 2);
+            hipLaunchKernelGGL((k_rollout_scene_quad<T, 8, 2, true>), dim3(c->n_quads), dim3(2 * kWave), row * (kWave / 8) + c->lds_bytes_table, c->stream, c->d_model, c->d_cfg, c->d_cost_none,
+                               c->d_x0_dof, c->d_x0_root, c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_S, (float *)nullptr,
+                               c->d_partials, (unsigned *)nullptr, c->fold_out, (unsigned long long *)nullptr, c->d_traj);
+            return;
+        }
+    }
     hipLaunchKernelGGL((k_rollout_scene_quad<T, 8, 1, true>), dim3(c->n_quads), dim3(kWave), c->lds_bytes_quad * (kWave / 8) / 16 + c->lds_bytes_table, c->stream, c->d_model, c->d_cfg, c->d_cost_none, c->d_x0_dof,
                        c->d_x0_root, c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_S, (float *)nullptr,
                        c->d_partials, (unsigned *)nullptr, c->fold_out, (unsigned long long *)nullptr, c->d_traj);
@@ -1273,6 +1281,8 @@ hipError_t raise_lds_limit(size_t lane_bytes, size_t quad_bytes) {  // lane_byte
     if (e != hipSuccess) return e;
     if constexpr (T::NB <= 4) {  // (+ the helper's accumulator set: bounded by the quad kernel's 16-sample figure)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rollout_scene_quad<T, 8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)quad_bytes);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rollout_scene_quad<T, 8, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)quad_bytes);
         if (e != hipSuccess) return e;
     }
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sim_step_scene_quad<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)quad_bytes);
