@@ -1,5 +1,6 @@
+"""Where a control iteration of the generic Objective mode goes (panda reach K=4096 H=20, Python Objective): experiment."""
 import os, sys, time
-ROOT="/root/repo" if os.path.exists("/root/repo/bench.py") else os.getcwd()
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "mppi-isaac_amd"))
 import torch
 from mppiisaac.objectives import PandaReachObjective
@@ -18,7 +19,7 @@ def timed(f, n=50):
     for _ in range(n): f()
     torch.cuda.synchronize(); return 1e3*(time.perf_counter()-t)/n
 print("compute_action total", timed(lambda: pl.compute_action(q, [0.0]*7)))
-print("simulate graph replay", timed(lambda: m._batch_graph.replay()))
+print("simulated horizon (fused rollout with state dump + one materialise over H*K env-steps)", timed(lambda: m._simulate_horizon()))
 b = m._batch_buf
 def cost():
     with pl.sim._horizon_view(b, m.T*m.K):
