@@ -948,3 +948,73 @@ def test_body_force_reference_test_shape(lib, oracle64):
     for _ in range(200):
         root, q, qd, _ = oracle64.scene_step(m, root, q, qd, target)
     np.testing.assert_allclose(sim._root_state[0, 0, 0:3].cpu().numpy(), root[0, 0:3], atol=2e-2)
+
+
+@pytest.mark.gpu
+def test_rollout_trajectory_states_match_oracle_stepping(lib, oracle64):
+    """mppi_rollout_trajectory + mppi_materialise_trajectory through the raw C-ABI: row t*K + k of the reference-layout tensors
+    is env k after horizon step t of the SAME rollout the fused kernel runs - checked against the oracle stepping each sample
+    with its clamped controls (contact-free arm: 1e-5; pushing scene with floating base, free block and contact forces)."""
+    # contact-free: panda reach
+    K, H = 64, 6
+    scene, m, cfg, cost, dof, root = panda_reach(K=K, H=H)
+    c = Ctx(m, cfg)                                              # (no fused cost: the generic-mode context)
+    c.call("mppi_sample", C.c_uint32(0)); c.set_state(dof, root)
+    A, B, n = len(scene.env_cfg), scene.n_rb, scene.n_dof
+    f32 = dict(dtype=torch.float32, device="cuda")
+    T = {"dof": torch.zeros((H * K, 2 * n), **f32), "root": torch.zeros((H * K, A, 13), **f32),
+         "rb": torch.zeros((H * K, B, 13), **f32), "cf": torch.zeros((H * K, B, 3), **f32)}
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    c.call("mppi_rollout_trajectory")
+    c.call("mppi_materialise_trajectory", ptr(T["dof"]), ptr(T["root"]), ptr(T["rb"]), ptr(T["cf"]))
+    du, eps = c.get("mppi_get_perturbations", (H, 7, K)), c.get("mppi_get_noise", (H, 7, K))
+    S = c.get("mppi_get_costs", (K,))
+    dofs, rbs = T["dof"].cpu().numpy().reshape(H, K, 2 * n), T["rb"].cpu().numpy().reshape(H, K, B, 13)
+    assert not T["cf"].any()
+    for k in (0, 17, K - 2, K - 1):
+        q, qd = dof[0::2].astype(np.float64), dof[1::2].astype(np.float64)
+        for t in range(H):
+            u = du[t, :, k].astype(np.float64)                  # U = 0: the applied control is the effective perturbation
+            q, qd = oracle64.step(m, root, q, qd, oracle64.cmd_map(m, u))
+            np.testing.assert_allclose(dofs[t, k, 0::2], q, atol=1e-5)
+            np.testing.assert_allclose(dofs[t, k, 1::2], qd, atol=2e-4)
+            rbo, _ = oracle64.rigid_body_state(m, root, q, qd)
+            np.testing.assert_allclose(rbs[t, k, :, 0:3], rbo[:, 0:3], atol=2e-5)
+    assert np.abs(du[:, :, K - 1]).max() == 0.0                  # the null-action sample
+    # S holds the control cost only (no fused cost): lambda * sum_t U^T Sigma^-1 du = 0 for U = 0
+    np.testing.assert_allclose(S, 0.0, atol=1e-7)
+    info = C.create_string_buffer(256)
+    c.call("mppi_kernel_info", info, 256)
+    c.close()
+    # contact scene: boxer push (helper-wavefront kernel with the dump), per-sample actor noise off
+    K, H = 64, 5
+    scene, m, cfg, cost, dof, root = boxer_push(K=K, H=H)
+    c = Ctx(m, cfg)
+    c.call("mppi_sample", C.c_uint32(0)); c.set_state(dof, root)
+    A, B, n = len(scene.env_cfg), scene.n_rb, scene.n_dof
+    T = {"dof": torch.zeros((H * K, 2 * n), **f32), "root": torch.zeros((H * K, A, 13), **f32),
+         "rb": torch.zeros((H * K, B, 13), **f32), "cf": torch.zeros((H * K, B, 3), **f32)}
+    c.call("mppi_rollout_trajectory")
+    c.call("mppi_materialise_trajectory", ptr(T["dof"]), ptr(T["root"]), ptr(T["rb"]), ptr(T["cf"]))
+    du = c.get("mppi_get_perturbations", (H, 2, K))
+    dofs, roots = T["dof"].cpu().numpy().reshape(H, K, 2 * n), T["root"].cpu().numpy().reshape(H, K, A, 13)
+    cfs = T["cf"].cpu().numpy().reshape(H, K, B, 3)
+    for k in (0, 9, K - 2):
+        r, q, qd = root.astype(np.float64), dof[0::2].astype(np.float64), dof[1::2].astype(np.float64)
+        for t in range(H):
+            r, q, qd, cfo = oracle64.scene_step(m, r, q, qd, oracle64.cmd_map(m, du[t, :, k].astype(np.float64)))
+            np.testing.assert_allclose(roots[t, k, :, 0:7], r[:, 0:7], atol=1e-4)
+            np.testing.assert_allclose(dofs[t, k, 0::2], q, atol=1e-3)
+            # (N; touch-down loads of 5-17 kN here; a contact that starts a rounding error earlier or later shows up as ~1 N,
+            # the law being continuous at zero depth)
+            np.testing.assert_allclose(cfs[t, k], cfo, rtol=5e-3, atol=5.0)
+    c.close()
+    # contexts on the one-lane kernels have no dumping kernel: refused with a reason, the mppi_sim_* steps remain
+    os.environ["MPPI_ROLLOUT"] = "lane"
+    try:
+        scene, m, cfg, cost, dof, root = panda_reach(K=64, H=6)
+        c = Ctx(m, cfg)
+        assert lib.mppi_rollout_trajectory(c.ctx) == -3 and b"trajectory" in lib.mppi_last_error()   # MPPI_EUNSUPPORTED
+        c.close()
+    finally:
+        del os.environ["MPPI_ROLLOUT"]
