@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MPPI_ABI_VERSION 2
+#define MPPI_ABI_VERSION 3
 
 #define MPPI_MAX_BODIES 12   /* moving bodies (= DOF) of the articulated robot        */
 #define MPPI_MAX_LINKS 24    /* reported rigid bodies of the robot (URDF links)      */
@@ -37,7 +37,7 @@ extern "C" {
 #define MPPI_MAX_H 64        /* horizon                                              */
 #define MPPI_MAX_KNOTS 16    /* spline knots of the halton-spline sampler            */
 #define MPPI_MAX_COST_W 16
-#define MPPI_MAX_SHAPES 24   /* collision primitives per env                              */
+#define MPPI_MAX_SHAPES 40   /* collision primitives per env (anymal: 37)                 */
 #define MPPI_MAX_PAIRS 48    /* candidate contact pairs per env                           */
 #define MPPI_MAX_FREE 2      /* free (non-fixed) box/sphere actors per env                */
 

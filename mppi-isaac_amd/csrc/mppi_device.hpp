@@ -37,7 +37,7 @@ constexpr int kMaxBodies = 12;
 constexpr int kMaxLinks = 24;
 constexpr int kMaxActors = 8;
 constexpr int kMaxNu = 12;
-constexpr int kMaxShapes = 24;
+constexpr int kMaxShapes = 40;
 constexpr int kMaxPairs = 48;
 constexpr int kMaxFree = 2;
 

@@ -43,11 +43,16 @@ EXAMPLES = {
                             init=[[1.0, 2.0, 0.0]], nx=24, objective="OmniPandaPickObjective"),
     "panda_stick_push": dict(mppi="panda_stick_push", isaacgym="normal", actors=["panda_stick", "xaxis", "yaxis", "panda_push_block", "table", "goal"],
                              init=[[0.0, 0.0, 0.0]], nx=14, objective="PandaStickPushObjective"),
+    # reference examples/anymal: its conf/mppi/anymal.yaml ships with `noise_sigma` commented out (the planner cannot be built
+    # from it there); the runner supplies one - joint velocity noise of 1 (rad/s)^2 on the twelve leg joints
+    "anymal": dict(mppi="anymal", isaacgym="push", actors=["anymal", "goal"], init=[[0.0, 2.0, 1.2]], nx=24, objective="AnymalWalkObjective",
+                   goal=[2.0, 2.0, 0.5], overrides={"noise_sigma": [[1.0 if i == j else 0.0 for j in range(12)] for i in range(12)]}),
 }
 
 
 def config(name, **overrides):
     e = EXAMPLES[name]
+    overrides = {**e.get("overrides", {}), **overrides}
     return load_config({"defaults": [{"mppi": e["mppi"]}, {"isaacgym": e["isaacgym"]}], "actors": e["actors"], "initial_actor_positions": e["init"],
                         "nx": e["nx"]}, overrides={f"mppi.{k}": v for k, v in overrides.items()})
 

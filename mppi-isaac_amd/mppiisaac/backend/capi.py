@@ -10,9 +10,9 @@ import ctypes as C
 import os
 
 MAX_BODIES, MAX_LINKS, MAX_ACTORS, MAX_NU, MAX_H, MAX_KNOTS, MAX_COST_W = 12, 24, 8, 12, 64, 16, 16
-MAX_SHAPES, MAX_PAIRS, MAX_FREE = 24, 48, 2
+MAX_SHAPES, MAX_PAIRS, MAX_FREE = 40, 48, 2
 SHAPE_BOX, SHAPE_SPHERE, SHAPE_DISC = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 JOINT_REVOLUTE, JOINT_PRISMATIC = 0, 1
 DRIVE_VELOCITY, DRIVE_EFFORT, DRIVE_POSITION = 0, 1, 2

@@ -343,6 +343,26 @@ def compile_urdf(urdf_path: str, name: Optional[str] = None) -> dict:
     }
 
 
+def prune_links(model: dict, keep=()) -> dict:
+    """Drop the links nobody can observe - no collision geometry, not named in `keep` - from the reported rigid bodies of a
+    compiled model (their inertia is already merged into the bodies).  Isaac Gym reports every URDF link as a rigid body; the
+    78 links of the ANYmal URDF (camera frames, shells, ...) are three times MPPI_MAX_LINKS.  Objectives address links by name,
+    so the rows that remain keep their meaning; only their count differs from the reference's tensor."""
+    links = model["links"]
+    kept = [i for i, l in enumerate(links) if i == 0 or l["collision"] or l["name"] in keep]
+    new_index = {old: new for new, old in enumerate(kept)}
+
+    def kept_ancestor(i):
+        i = links[i]["parent_link"]
+        while i >= 0 and i not in new_index:
+            i = links[i]["parent_link"]
+        return new_index.get(i, -1)
+    out = dict(model)
+    out["links"] = [dict(links[i], parent_link=kept_ancestor(i)) for i in kept]
+    out["pruned_links"] = len(links) - len(kept)
+    return out
+
+
 def save_model(model: dict, path: str) -> None:
     def rnd(o):
         if isinstance(o, float):

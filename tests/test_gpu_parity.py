@@ -801,6 +801,7 @@ JACKAL_WHEELS = {"left_wheel_joints": ["front_left_wheel", "rear_left_wheel"], "
     (["jackal", "goal"], [[0.0, 0.0, 0.1]], "base_link", 2, 0.5, 1.0, JACKAL_WHEELS),       # 4-wheel skid steer: contact scene
     (["panda_effort", "goal"], [[0.0, 0.0, 0.0]], "panda_link7", 7, 20.0, 40.0, None),      # effort mode, fixed base
     (["omnipanda", "goal"], [[0.0, 0.0, 0.0]], "panda_hand", 12, 0.2, 0.5, None),           # velocity mode, holonomic base + arm + gripper
+    (["anymal", "goal"], [[0.0, 0.0, 0.62]], "base", 12, 1.0, 5.5, None),                     # quadruped on its feet: floating trunk, four legs
 ])
 def test_more_robots_rollout(actors, init, link, nu, sigma, umax, over, lib, oracle64):
     """SURVEY 8f rank 1 robots through the HIP path: reach cost on one of their links, rollouts vs the oracle."""

@@ -208,7 +208,10 @@ EXAMPLES = {   # example -> (actors, conf/mppi name, isaacgym conf, nx, robot in
     "omni_panda_pick": (["omnipanda_effort", "xaxis", "yaxis", "block2", "table2", "goal"], "omnipanda_effort", "pick", 24, [1.0, 2.0, 0.0], "OmniPandaPickObjective"),
     "panda_stick_push": (["panda_stick", "xaxis", "yaxis", "panda_push_block", "table", "goal"], "panda_stick_push", "normal", 14, [0.0, 0.0, 0.0], "PandaStickPushObjective"),
     "panda_effort": (["panda_effort", "goal"], "panda_effort", "normal", 14, [0.0, 0.0, 0.0], "PandaEffortReachObjective"),
+    # (the reference's conf/mppi/anymal.yaml has no noise_sigma - commented out there; supplied below)
+    "anymal": (["anymal", "goal"], "anymal", "push", 24, [0.0, 2.0, 0.62], "AnymalWalkObjective"),
 }
+EXTRA = {"anymal": {"mppi.noise_sigma": np.eye(12).tolist()}}
 
 
 def test_pushing_scene_shards_equal_one_context_with_the_helper_wavefront(lib):
@@ -263,7 +266,7 @@ def test_example_objectives_run_fused_as_cost_programs(case, lib, oracle64):
     actors, mppi, gym, nx, init, obj_name = EXAMPLES[case]
     K, H = 256, 12
     cfg = load_config({"defaults": [{"mppi": mppi}, {"isaacgym": gym}], "actors": actors, "initial_actor_positions": [init], "nx": nx},
-                      overrides={"mppi.num_samples": K, "mppi.horizon": H, "mppi.filter_u": False, "mppi.use_priors": False})
+                      overrides={"mppi.num_samples": K, "mppi.horizon": H, "mppi.filter_u": False, "mppi.use_priors": False, **EXTRA.get(case, {})})
     Obj = getattr(objectives, obj_name)
 
     class Generic(Obj):

@@ -18,6 +18,8 @@ CASES = {
     "heijn": (["heijn", "goal"], [[0.0, 0.0, 0.0]], 3, 1.0),
     "jackal": (["jackal", "goal"], [[0.0, 0.0, 0.1]], 2, 1.0),
     "albert": (["albert", "goal"], [[0.0, 0.0, 0.2]], 9, 0.5),
+    # 12-DoF quadruped: free-floating trunk, four 3-joint legs, 37 collision primitives against the ground
+    "anymal": (["anymal", "goal"], [[0.0, 0.0, 0.62]], 12, 1.0),
 }
 
 

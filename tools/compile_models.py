@@ -5,7 +5,7 @@ container); the GPU box uses the committed JSON.  Usage: python tools/compile_mo
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "mppi-isaac_amd"))
-from mppiisaac.backend.urdf_compile import compile_urdf, save_model
+from mppiisaac.backend.urdf_compile import compile_urdf, prune_links, save_model
 
 REF = os.environ.get("MPPI_REFERENCE", "/root/reference")
 # urdf_file value used in conf/actors/*.yaml  ->  fixture name
@@ -19,7 +19,11 @@ URDFS = {
     "jackal/jackal.urdf": "jackal",
     "albert/albert.urdf": "albert",
     "omni_panda/omniPandaWithGripper.urdf": "omni_panda_gripper",
+    "anymal_c/urdf/anymal.urdf": "anymal",
 }
+# models whose URDF has more links than MPPI_MAX_LINKS: only links with collision geometry and the ones the example objectives
+# name stay reported rigid bodies (reference examples/anymal/planner.py:24-41)
+KEEP_LINKS = {"anymal": ("base", "face_front", "face_rear", "LF_KFE", "LH_KFE", "RH_KFE", "RF_KFE")}
 out_dir = os.path.join(ROOT, "mppi-isaac_amd", "assets", "compiled")
 os.makedirs(out_dir, exist_ok=True)
 for rel, name in URDFS.items():
@@ -27,6 +31,8 @@ for rel, name in URDFS.items():
     if not os.path.exists(path):
         print("skip (missing)", rel); continue
     m = compile_urdf(path, name=name)
+    if name in KEEP_LINKS:
+        m = prune_links(m, KEEP_LINKS[name])
     m["urdf_file"] = rel
     save_model(m, os.path.join(out_dir, name + ".json"))
     print(f"{name}: {len(m['links'])} links, {len(m['bodies'])} dof;",
