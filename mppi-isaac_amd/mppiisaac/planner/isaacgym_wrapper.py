@@ -98,29 +98,89 @@ def interleave_dof_state(q, qdot, n_dof: int) -> np.ndarray:
     return dof
 
 
+def _quat_to_R(q) -> np.ndarray:
+    x, y, z, w = (float(v) for v in q)
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def merge_fixed_base_robots(env_cfg: List["ActorWrapper"], robots: List[int], models: List[dict]):
+    """Several robots in one env (reference isaacgym_wrapper.py:101-106,220-236,534-559,574-612: commands, joint states and
+    initial joint poses of the robots are concatenated in env order).  Fixed-base robots are independent trees hanging off the
+    world, so together they are ONE articulated forest: the compiled models are concatenated, every later robot's root joints
+    and base-welded links carry its base pose relative to the first robot's.  -> (merged model, actor index per link)"""
+    for i in robots:
+        a = env_cfg[i]
+        if not a.fixed or a.differential_drive:
+            raise NotImplementedError(f"several robots per env: only fixed-base robots can share an env ('{a.name}' has a moving base: "
+                                      "the engine carries one floating base per env)")
+        if a.dof_mode != env_cfg[robots[0]].dof_mode:
+            raise ValueError("All robots must have the same dof_mode")        # (reference :541-542)
+    if robots != list(range(robots[0], robots[0] + len(robots))):
+        raise NotImplementedError("several robots per env: list the robot actors next to each other (their rigid-body rows form one block)")
+    first = env_cfg[robots[0]]
+    R0, p0 = _quat_to_R(first.init_ori), np.asarray(first.init_pos, float)
+    merged = {"format": models[0]["format"], "name": "+".join(m["name"] for m in models), "root_link": models[0]["root_link"],
+              "links": [], "bodies": [], "base": models[0]["base"]}
+    owner = []
+    for i, m in zip(robots, models):
+        a = env_cfg[i]
+        R_rel = R0.T @ _quat_to_R(a.init_ori)
+        p_rel = R0.T @ (np.asarray(a.init_pos, float) - p0)
+        boff, loff = len(merged["bodies"]), len(merged["links"])
+        for b in m["bodies"]:
+            nb = dict(b)
+            if b["parent"] < 0:
+                nb["R_tree"] = (R_rel @ np.asarray(b["R_tree"])).tolist()
+                nb["p_tree"] = (R_rel @ np.asarray(b["p_tree"]) + p_rel).tolist()
+            else:
+                nb["parent"] = b["parent"] + boff
+            merged["bodies"].append(nb)
+        for l in m["links"]:
+            nl = dict(l)
+            nl["parent_link"] = l["parent_link"] + loff if l["parent_link"] >= 0 else -1
+            if l["body"] < 0:
+                nl["R"] = (R_rel @ np.asarray(l["R"])).tolist()
+                nl["p"] = (R_rel @ np.asarray(l["p"]) + p_rel).tolist()
+            else:
+                nl["body"] = l["body"] + boff
+            merged["links"].append(nl)
+            owner.append(i)
+    return merged, owner
+
+
 class Scene:
     """Host description of one env: actors + compiled robot model -> C-ABI mppi_model_t."""
 
-    def __init__(self, env_cfg: List[ActorWrapper], cfg: IsaacGymConfig, robot_model: dict):
+    def __init__(self, env_cfg: List[ActorWrapper], cfg: IsaacGymConfig, robot_model):
         robots = [i for i, a in enumerate(env_cfg) if a.type == "robot"]
-        if len(robots) != 1:
-            raise NotImplementedError(f"exactly one robot actor per env is supported, got {len(robots)}")
+        if not robots:
+            raise NotImplementedError("an env needs a robot actor")
         if len(env_cfg) > capi.MAX_ACTORS:
             raise ValueError("too many actors")
         self.env_cfg = env_cfg
         self.cfg = cfg
+        self.robot_ids = robots
         self.robot_idx = robots[0]
         self.robot = env_cfg[self.robot_idx]
+        if len(robots) > 1:   # robot_model: one compiled model per robot actor, in env order
+            if not isinstance(robot_model, (list, tuple)) or len(robot_model) != len(robots):
+                raise ValueError("several robots per env: pass one compiled model per robot actor")
+            robot_model, self.link_owner = merge_fixed_base_robots(env_cfg, robots, list(robot_model))
+        else:
+            robot_model = robot_model[0] if isinstance(robot_model, (list, tuple)) else robot_model
+            self.link_owner = [self.robot_idx] * len(robot_model["links"])
         self.robot_model = robot_model
         self.dof_names = [b["joint"] for b in robot_model["bodies"]]
         self.n_dof = len(self.dof_names)
         self.link_names = [l["name"] for l in robot_model["links"]]
         # rigid-body rows: actors in env order; a robot contributes its links, box/sphere one body
         self.first_rb, self.rb_names = [], []
-        for a in env_cfg:
+        for i, a in enumerate(env_cfg):
             self.first_rb.append(len(self.rb_names))
             if a.type == "robot":
-                self.rb_names += [(a.name, n) for n in self.link_names]
+                self.rb_names += [(a.name, n) for n, o in zip(self.link_names, self.link_owner) if o == i]
             else:
                 self.rb_names.append((a.name, a.type))  # primitive bodies are named "box"/"sphere"
         self.n_rb = len(self.rb_names)
@@ -138,6 +198,7 @@ class Scene:
                 # TypeError (isaacgym_wrapper.py:552-555); fail with a message instead
                 raise ValueError(f"actor '{a.name}': differential_drive needs left_wheel_joints and right_wheel_joints")
             idx = 2
+        # (several fixed-base robots: their DOFs follow one another and take the next commands in turn, reference :534-559)
         for name in self.dof_names:
             if a.differential_drive and name in (a.left_wheel_joints or []):
                 terms.append(((0, 1.0 / a.wheel_radius), (1, -a.wheel_base / (2 * a.wheel_radius))))
@@ -172,6 +233,8 @@ class Scene:
             if a.type == "robot":
                 casters = set(a.caster_links or [])
                 for li, l in enumerate(self.robot_model["links"]):
+                    if self.link_owner[li] != ai:
+                        continue
                     Rl, pl = np.asarray(l["R"]), np.asarray(l["p"])
                     for c in l["collision"]:
                         Rc, pc = np.asarray(c["R"]), np.asarray(c["p"])
@@ -190,7 +253,9 @@ class Scene:
                             pc = pc + Rc @ (0.5 * (hi + lo))
                         else:
                             continue
-                        shapes.append(dict(actor=ai, body=l["body"], type=kind, rb=self.first_rb[ai] + li, size=size,
+                        # (several robots form one articulated forest: their link shapes all belong to it - and do not collide
+                        # with each other, like the links of one robot)
+                        shapes.append(dict(actor=self.robot_idx, body=l["body"], type=kind, rb=self.first_rb[self.robot_idx] + li, size=size,
                                            R=Rl @ Rc, p=Rl @ pc + pl, friction=0.0 if l["name"] in casters else a.friction,
                                            fixed=bool(a.fixed), link=l["name"]))
             elif a.type == "box":
@@ -261,14 +326,24 @@ class Scene:
         """dof_state [2n] (interleaved q, qdot) and root_state [A,13] of the initial pose
         (reference :219-236 and reset_to_initial_poses :238-246)."""
         dof = np.zeros(2 * self.n_dof, np.float32)
-        if self.robot.init_joint_pose:
-            pose = np.asarray(self.robot.init_joint_pose, np.float32)
-            dof[:len(pose)] = pose
+        off = 0
+        for i in self.robot_ids:   # (the reference keeps only the LAST robot's pose here, :220-233 - a defect; each robot gets its own)
+            a = self.env_cfg[i]
+            n = self._n_dof_of(i)
+            if a.init_joint_pose:
+                pose = np.asarray(a.init_joint_pose, np.float32)[:2 * n]
+                dof[2 * off:2 * off + len(pose)] = pose
+            off += n
         root = np.zeros((len(self.env_cfg), 13), np.float32)
         for i, a in enumerate(self.env_cfg):
             root[i, 0:3] = a.init_pos
             root[i, 3:7] = a.init_ori
         return dof, root
+
+    def _n_dof_of(self, actor_idx: int) -> int:
+        """DOFs of one robot actor of a multi-robot env (bodies whose links that actor owns)"""
+        bodies = {l["body"] for l, o in zip(self.robot_model["links"], self.link_owner) if o == actor_idx and l["body"] >= 0}
+        return len(bodies)
 
     def to_c(self) -> capi.Model:
         m = capi.Model()
@@ -292,7 +367,7 @@ class Scene:
                 ca.noise_percentage_mass = float(a.noise_percentage_mass)
                 ca.noise_percentage_friction = float(a.noise_percentage_friction)
             ca.first_rb = self.first_rb[i]
-            ca.n_rb = len(self.link_names) if a.type == "robot" else 1
+            ca.n_rb = sum(1 for o in self.link_owner if o == i) if a.type == "robot" else 1
         m.robot_actor = self.robot_idx
         rm = self.robot_model
         if len(rm["bodies"]) > capi.MAX_BODIES or len(rm["links"]) > capi.MAX_LINKS:
@@ -395,7 +470,7 @@ class IsaacGymWrapper:
         self._mppi_config = mppi_config
         self._mppi_config_factory = mppi_config  # kept to rebuild the C config when the actor list changes
         self.generation = 0
-        self.scene = Scene(self.env_cfg, cfg, load_asset(robots[0]) if robots else None)
+        self.scene = Scene(self.env_cfg, cfg, [load_asset(r) for r in robots])
         # The reference draws a different size/mass/friction for every env of noisy box actors (unseeded
         # np.random, :430-475).  Here the K rollout envs draw from a seeded hash of the global sample id; a
         # single env (the K=1 "world") keeps the nominal values unless a seed is passed explicitly.
@@ -700,7 +775,7 @@ class IsaacGymWrapper:
         for i, a in enumerate(self.env_cfg):
             a.handle = i
         robots = [a for a in self.env_cfg if a.type == "robot"]
-        self.scene = Scene(self.env_cfg, self.cfg, load_asset(robots[0]))
+        self.scene = Scene(self.env_cfg, self.cfg, [load_asset(r) for r in robots])
         self.scene.randomize_seed = self._randomize_seed
         self._mppi_config = self._mppi_config_factory
         self.generation += 1
@@ -757,6 +832,9 @@ class IsaacGymWrapper:
 
     # setters of the reference (:359-397): the root row of one actor in every env; takes effect for the next rollout / step
     def _set_root_columns(self, actor_idx, lo: int, hi: int, value) -> None:
+        if len(self.scene.robot_ids) > 1 and self._as_index(actor_idx) in self.scene.robot_ids:
+            raise NotImplementedError("the fixed bases of several robots in one env are part of the compiled forest: place them "
+                                      "with initial_actor_positions")
         root = self._root_state[0].clone()
         root[self._as_index(actor_idx), lo:hi] = torch.as_tensor(value, dtype=torch.float32, device=self.device).reshape(-1)[: hi - lo]
         self._push_single_state(self._dof_state[0].cpu().numpy(), root.cpu().numpy())

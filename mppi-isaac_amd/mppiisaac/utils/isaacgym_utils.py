@@ -22,7 +22,9 @@ COMPILED_DIR = os.path.join(PKG_ROOT, "assets", "compiled")
 def load_actor_cfgs(actors: List[str]) -> List[ActorWrapper]:
     actor_cfgs = []
     for actor_name in actors:
-        with open(os.path.join(CONF_DIR, "actors", f"{actor_name}.yaml")) as f:
+        # (an actor may also be given as the path of its YAML file: a second robot of the same kind needs a name of its own)
+        path = actor_name if str(actor_name).endswith(".yaml") and os.path.exists(actor_name) else os.path.join(CONF_DIR, "actors", f"{actor_name}.yaml")
+        with open(path) as f:
             actor_cfgs.append(ActorWrapper(**yaml.load(f, Loader=yaml.SafeLoader)))
     return actor_cfgs
 

@@ -19,7 +19,7 @@ def build_scene(actors, init_positions=None, isaacgym="normal", overrides=None, 
     cfg = load_config({"defaults": [{"isaacgym": isaacgym}]}).isaacgym
     for k, v in (overrides or {}).items():
         setattr(cfg, k, v)
-    return Scene(env_cfg, cfg, load_asset(robots[0]))
+    return Scene(env_cfg, cfg, [load_asset(r) for r in robots])
 
 
 def panda_reach(K=64, H=20, goal=(0.5, -0.4, 0.3), **mppi_over):

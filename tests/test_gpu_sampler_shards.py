@@ -355,3 +355,59 @@ def test_external_noise_is_used_and_kept_alive(lib):
     pl.compute_action(q, [0.0] * 7)
     capi.check(lib, lib.mppi_get_noise(pl.sim._ctx, capi.fptr(got)))
     assert np.abs(got).std() > 0.1                              # the halton-spline set again (sigma 0.1 -> std 0.3)
+
+
+def test_two_robots_in_one_env(lib, oracle64, tmp_path):
+    """several robots per env (reference conf/mppi/multi-pointbot.yaml: two point robots, nu = 6; isaacgym_wrapper.py:534-559
+    scatters the command over the robots in env order): through the planner facade with the reference's MPPI parameters, a
+    cost program that sends each robot to its own goal - rollouts vs the oracle, and both robots arrive in closed loop"""
+    import yaml
+    from mppiisaac.objectives import ProgramObjective, Term, actor, link
+    from mppiisaac.planner.isaacgym_wrapper import IsaacGymWrapper
+    from mppiisaac.planner.mppi import make_config
+    from mppiisaac.planner.mppi_isaac import MPPIisaacPlanner
+    from mppiisaac.utils.config_store import load_config
+    from mppiisaac.utils.transport import bytes_to_torch, torch_to_bytes
+    second, goal2 = tmp_path / "point_robot2.yaml", tmp_path / "goal2.yaml"
+    second.write_text(yaml.safe_dump({"type": "robot", "name": "point_robot2", "fixed": True, "urdf_file": "point_robot.urdf"}))
+    goal2.write_text(yaml.safe_dump({"type": "sphere", "name": "goal2", "fixed": True, "collision": False, "size": [0.1], "init_pos": [-1.0, 1.0, 0.05]}))
+    K, H = 256, 20
+    cfg = load_config({"defaults": [{"mppi": "multi-pointbot"}, {"isaacgym": "normal"}], "actors": ["point_robot", str(second), "goal", str(goal2)],
+                       "initial_actor_positions": [[0.0, 0.0, 0.05], [1.0, -0.5, 0.05]], "nx": 12},
+                      overrides={"mppi.num_samples": K, "mppi.horizon": H, "mppi.use_priors": False})
+
+    class TwoReach(ProgramObjective):
+        WEIGHTS = {"first": 1.0, "second": 1.0}
+
+        def terms(self):
+            return [Term("first", "dist", (link("point_robot", "base_link"), actor("goal"), 2)),
+                    Term("second", "dist", (link("point_robot2", "base_link"), actor("goal2"), 2))]
+    planner = MPPIisaacPlanner(cfg, TwoReach(cfg))
+    sim = planner.sim
+    assert sim.scene.nu == 6 and sim.scene.n_dof == 6 and planner.mppi._fused_cost is not None
+    sim.set_actor_position_by_name([1.5, 1.0, 0.05], "goal")
+    world = IsaacGymWrapper(cfg.isaacgym, actors=cfg.actors, init_positions=cfg.initial_actor_positions, num_envs=1)
+    world.set_actor_position_by_name([1.5, 1.0, 0.05], "goal")
+    assert world.num_robots == 2 and tuple(world.robot_positions.shape) == (1, 2, 3)
+    a = bytes_to_torch(planner.compute_action_tensor(torch_to_bytes(world._dof_state.cpu()), torch_to_bytes(world._root_state.cpu()))).numpy()
+    assert a.shape == (6,) and np.isfinite(a).all()
+    # rollouts vs the oracle on a few samples (same cost program)
+    S = planner.mppi.get_costs().numpy()
+    eps = np.zeros((H, 6, K), np.float32)
+    capi.check(lib, lib.mppi_get_noise(sim._ctx, capi.fptr(eps)))
+    dof, root = world._dof_state[0].cpu().numpy(), world._root_state[0].cpu().numpy()
+    spec = planner.objective.fused_spec(sim)
+    for k in range(5, K, K // 8):
+        sc = make_config(cfg.mppi, k_offset=int(k), k_local=1, viz_link=sim.scene.viz_link_index())
+        So, _, _ = oracle64.rollout(sim._c_model, sc, spec, dof, root, np.zeros((H, 6)), eps[:, :, k:k + 1])
+        assert S[k] == pytest.approx(So[0], rel=2e-4)
+    for _ in range(160):
+        a = bytes_to_torch(planner.compute_action_tensor(torch_to_bytes(world._dof_state.cpu()), torch_to_bytes(world._root_state.cpu())))
+        world.apply_robot_cmd(a.to(world.device).reshape(1, -1))
+        world.step()
+    p1 = world.get_actor_link_by_name("point_robot", "base_link")[0, 0:2].cpu().numpy()
+    p2 = world.get_actor_link_by_name("point_robot2", "base_link")[0, 0:2].cpu().numpy()
+    # (sigma = 1 m/s noise with 256 samples: the robots hover a few decimetres around their goals; they started 1.8 m and 2.5 m away)
+    assert np.linalg.norm(p1 - [1.5, 1.0]) < 0.45 and np.linalg.norm(p2 - [-1.0, 1.0]) < 0.6, (p1, p2)
+    with pytest.raises(NotImplementedError, match="compiled forest"):
+        world.set_actor_position_by_robot_index([0.0, 0.0, 0.05], 1)

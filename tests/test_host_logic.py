@@ -219,3 +219,55 @@ def test_transport_fast_path_is_byte_compatible_with_torch_save_and_load():
     # non-contiguous / grad tensors: plain torch path, same result
     nc = torch.arange(12, dtype=torch.float32).reshape(3, 4).t()
     assert torch.equal(torch.load(io.BytesIO(T.torch_to_bytes(nc))), nc)
+
+
+def test_two_fixed_base_robots_form_one_forest(oracle64, tmp_path):
+    """several robots per env (reference isaacgym_wrapper.py:101-106,534-559,574-612; conf/mppi/multi-pointbot.yaml, nu = 6):
+    fixed-base robots are merged into one articulated forest - commands, joint states and rigid-body rows of the robots follow
+    one another in env order - and simulate exactly like the robots on their own; moving bases and scattered robot actors are
+    refused with a reason"""
+    import yaml
+    from mppiisaac.planner.isaacgym_wrapper import Scene
+    from mppiisaac.utils.config_store import load_config
+    from mppiisaac.utils.isaacgym_utils import load_actor_cfgs, load_asset
+    second = tmp_path / "point_robot2.yaml"
+    second.write_text(yaml.safe_dump({"type": "robot", "name": "point_robot2", "fixed": True, "urdf_file": "point_robot.urdf"}))
+    ig = load_config({"defaults": [{"isaacgym": "normal"}]}).isaacgym
+    env = load_actor_cfgs(["point_robot", str(second), "goal"])
+    env[0].init_pos, env[1].init_pos = [0.0, 0.0, 0.05], [1.0, -0.5, 0.05]
+    env[1].init_ori = [0.0, 0.0, float(np.sin(0.4)), float(np.cos(0.4))]          # the second base is also turned by 0.8 rad
+    scene = Scene(env, ig, [load_asset(env[0]), load_asset(env[1])])
+    assert scene.n_dof == 6 and scene.nu == 6 and [b["parent"] for b in scene.robot_model["bodies"]] == [-1, 0, 1, -1, 3, 4]
+    n1 = len(load_asset(env[0])["links"])
+    assert scene.first_rb == [0, n1, 2 * n1] and scene.n_rb == 2 * n1 + 1
+    assert scene.rigid_body_index("point_robot2", "base_link") == n1 + scene.rigid_body_index("point_robot", "base_link")
+    m = scene.to_c()
+    assert m.actors[1].first_rb == n1 and m.actors[1].n_rb == n1 and m.robot_actor == 0
+    dof, root = scene.initial_state()
+    q, qd = dof[0::2].astype(float), dof[1::2].astype(float)
+    singles = []
+    for k in (0, 1):
+        e = load_actor_cfgs(["point_robot" if k == 0 else str(second), "goal"])
+        e[0].init_pos, e[0].init_ori = list(env[k].init_pos), list(env[k].init_ori)
+        s = Scene(e, ig, load_asset(e[0]))
+        d, r = s.initial_state()
+        singles.append([s, s.to_c(), r, d[0::2].astype(float), d[1::2].astype(float)])
+    u = np.array([0.5, -0.2, 0.3, -0.4, 0.6, -0.1])
+    for _ in range(10):
+        q, qd = oracle64.step(m, root, q, qd, oracle64.cmd_map(m, u))
+        for k, s in enumerate(singles):
+            s[3], s[4] = oracle64.step(s[1], s[2], s[3], s[4], oracle64.cmd_map(s[1], u[3 * k:3 * k + 3]))
+    np.testing.assert_allclose(q, np.concatenate([singles[0][3], singles[1][3]]), atol=1e-12)
+    np.testing.assert_allclose(qd, np.concatenate([singles[0][4], singles[1][4]]), atol=1e-12)
+    rb, _ = oracle64.rigid_body_state(m, root, q, qd)
+    for k, s in enumerate(singles):
+        rbk, _ = oracle64.rigid_body_state(s[1], s[2], s[3], s[4])
+        np.testing.assert_allclose(rb[k * n1:(k + 1) * n1], rbk[:n1], atol=1e-12)
+    np.testing.assert_allclose(rb[2 * n1], root[2])                            # the goal's row follows the two robots
+    # refused: a moving base among several robots; robot actors that are not listed next to each other
+    boxer = load_actor_cfgs(["boxer", "point_robot", "goal"])
+    with pytest.raises(NotImplementedError, match="moving base"):
+        Scene(boxer, ig, [load_asset(boxer[0]), load_asset(boxer[1])])
+    apart = load_actor_cfgs(["point_robot", "goal", str(second)])
+    with pytest.raises(NotImplementedError, match="next to each other"):
+        Scene(apart, ig, [load_asset(apart[0]), load_asset(apart[2])])
