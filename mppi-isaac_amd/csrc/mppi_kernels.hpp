@@ -624,14 +624,17 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW))
     LMem L{lds + (lane / LPS), SPW, tab};
     if constexpr (NW == 2) {
         L.set1 = scene_row_floats<T>(M);
-        L.xch = L.set1 + scene_pair_floats<T>(M) - 2;
+        L.xch = L.set1 + scene_pair_floats<T>(M) - 2 - 6 * kMaxFree;
         if (wave != 0) {
             // HELPER WAVEFRONT: its half of the shape poses and candidate pairs of every substep, out of and into LDS (see
             // kSplitOctPair); the barriers inside contact_forces pair with those of the first wavefront's calls
             if (live) {
                 unsigned acc_dirty = ~0u, cf_dirty = ~0u;
                 const int steps = cfg->H * M.substeps;
-                for (int it = 0; it < steps; it++) contact_forces<T, kSplitOctPair>(*launder(&M), x0_root, L, acc_dirty, cf_dirty, Split{sub, LPS, 1});
+                for (int it = 0; it < steps; it++) {
+                    contact_forces<T, kSplitOctPair>(*launder(&M), x0_root, L, acc_dirty, cf_dirty, Split{sub, LPS, 1});
+                    helper_free_bodies<T>(*launder(&M), L, Split{sub, LPS, 1});
+                }
             }
             return;
         }
@@ -1221,7 +1224,7 @@ void launch_rollout_scene_quad_t(mppi_ctx *c) {
 // octet layout with a helper wavefront per sample group (short trees: kSplitOctPair)
 template <class T>
 size_t pair_lds_bytes(const mppi_ctx *c) {
-    const size_t row = c->lds_bytes_quad / 16 + sizeof(float) * ((size_t)SceneLayout<T>::NF * 27 + 3 * (size_t)c->hm.n_rb + 2);
+    const size_t row = c->lds_bytes_quad / 16 + sizeof(float) * ((size_t)SceneLayout<T>::NF * 27 + 3 * (size_t)c->hm.n_rb + 2 + 6 * kMaxFree);
     return row * (kWave / 8) + c->lds_bytes_table;
 }
 template <class T>
@@ -1238,7 +1241,7 @@ template <class T>
 void launch_rollout_scene_traj_t(mppi_ctx *c) {
     if constexpr (T::NB <= 4) {  // short trees: the kernel with the helper wavefront (pair_lds_bytes is defined below)
         if (c->helper_wave) {
-            const size_t row = c->lds_bytes_quad / 16 + sizeof(float) * ((size_t)SceneLayout<T>::NF * 27 + 3 * (size_t)c->hm.n_rb + 2);
+            const size_t row = c->lds_bytes_quad / 16 + sizeof(float) * ((size_t)SceneLayout<T>::NF * 27 + 3 * (size_t)c->hm.n_rb + 2 + 6 * kMaxFree);
             hipLaunchKernelGGL((k_rollout_scene_quad<T, 8, 2, true>), dim3(c->n_quads), dim3(2 * kWave), row * (kWave / 8) + c->lds_bytes_table, c->stream, c->d_model, c->d_cfg, c->d_cost_none,
                                c->d_x0_dof, c->d_x0_root, c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_S, (float *)nullptr,
                                c->d_partials, (unsigned *)nullptr, c->fold_out, (unsigned long long *)nullptr, c->d_traj);

@@ -174,9 +174,10 @@ MPPI_HD ActorDraw actor_draw_slot(M &m, int slot, float mu_nominal, const LMem &
 template <class T, class M>
 MPPI_HD int scene_row_floats(M &m) { return SceneLayout<T>::floats(m.n_rb, m.n_rnd, m.n_shapes); }
 
-// extra floats per sample row of the kernels with a helper wavefront (kSplitOctPair): its accumulator set + two mask words
+// extra floats per sample row of the kernels with a helper wavefront (kSplitOctPair): its accumulator set, two mask words and
+// the accelerations of the free actors it solves (6 each, at xch + 2)
 template <class T, class M>
-MPPI_HD int scene_pair_floats(M &m) { return SceneLayout<T>::NF * 27 + 3 * m.n_rb + 2; }
+MPPI_HD int scene_pair_floats(M &m) { return SceneLayout<T>::NF * 27 + 3 * m.n_rb + 2 + 6 * kMaxFree; }
 
 constexpr int scene_floats_max(int nb) { return (nb + 1 + kMaxFree) * 45 + 3 * (kMaxLinks + kMaxActors); }
 
@@ -1120,13 +1121,14 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
             // set 0 += set 1, rows the helper wrote: each of the sample's lanes takes every 8th value (one lane per address,
             // LDS operations of a wavefront execute in order: the readers below see the sums)
             const unsigned t1 = __builtin_bit_cast(unsigned, L[L.xch]), c1 = __builtin_bit_cast(unsigned, L[L.xch + 1]);
-            for (int e = 0; e < Lay::NF; e++)
+            // (the rows of the free actors stay apart: the helper solves those bodies itself from both sets, free_body_accel)
+            for (int e = 0; e <= T::NB; e++)
                 if ((t1 >> e) & 1u)
                     for (int j = split.sub; j < 27; j += split.n) L[Lay::kAcc + 27 * e + j] += L[L.set1 + 27 * e + j];
             const int cf1 = L.set1 + (Lay::kCf - Lay::kAcc);
             for (int j = split.sub; j < 3 * m.n_rb; j += split.n)
                 if (cf_all || ((c1 >> (j / 3)) & 1u)) L[Lay::kCf + j] += L[cf1 + j];
-            touched |= t1;
+            touched |= t1 & ((2u << T::NB) - 1u);
             cf_touched |= c1;
         }
     }
@@ -1296,46 +1298,73 @@ MPPI_HD void scene_frames(M &m, const float *root, const SceneState<T> &s, Pose<
 }
 
 // free rigid bodies (frames and accumulators of this substep in L): (I + h C) a = -(v x* I v + C v - f - f_g)
+// `set1` > 0: the accumulator rows are the sum of the owner's set and the helper wavefront's set at that row offset
+// (kSplitOctPair: the helper solves the free actors while the owner solves the robot)
 template <class T, class M>
-MPPI_HD void step_free_bodies(M &m, SceneState<T> &s, const LMem &L, float h) {
+MPPI_HD SV free_body_accel(M &m, int f, const LMem &L, float h, int set1 = 0) {
     constexpr int NB = T::NB;
+    auto &F = m.fr[f];
+    M3 R;
+    V3 p;
+    SV v;
+    frame_load(L, NB + 1 + f, R, p, v);
+    float fm = F.m, Ic6[6] = {F.Ic[0], 0.f, 0.f, F.Ic[1], 0.f, F.Ic[2]};
+    if (m.rnd_slot[F.actor] >= 0) {  // this sample's own mass and size
+        const ActorDraw dr = actor_draw<T>(m, F.actor, L);
+        fm *= dr.ms;
+        if (F.type == 1) {  // MPPI_ACTOR_BOX
+            const float x = F.size[0] + dr.d[0], y = F.size[1] + dr.d[1], z = F.size[2] + dr.d[2];
+            const float m12 = fm * (1.f / 12.f);
+            Ic6[0] = m12 * (y * y + z * z); Ic6[3] = m12 * (x * x + z * z); Ic6[5] = m12 * (x * x + y * y);
+        } else {  // sphere
+            const float r = F.size[0] + dr.d[0];
+            Ic6[0] = Ic6[3] = Ic6[5] = 0.4f * fm * r * r;
+        }
+    }
+    AI A;
+    SV pA;
+    V3 hw;
+    rigid_world(R, p, fm, V3{0.f, 0.f, 0.f}, Ic6, v, A, pA, hw);
+    SV fe;
+    AI C;
+    acc_load(L, SceneLayout<T>::kAcc, NB + 1 + f, fe, C);
+    if (set1 > 0) {  // (fixed order: owner's set + helper's set, as the owner's merge does for the robot's rows)
+        SV fe1;
+        AI C1;
+        acc_load(L, set1, NB + 1 + f, fe1, C1);
+        fe = fe + fe1;
+        add_to(C, C1);
+    }
+    const V3 g = F.gravity ? V3{m.g[0], m.g[1], m.g[2]} : V3{0.f, 0.f, 0.f};
+    SV Cv = mul(C, v);
+    pA = {pA.a + Cv.a - fe.a - cross(hw, g), pA.l + Cv.l - fe.l - fm * g};
+    A.I.xx += h * C.I.xx; A.I.xy += h * C.I.xy; A.I.xz += h * C.I.xz; A.I.yy += h * C.I.yy; A.I.yz += h * C.I.yz; A.I.zz += h * C.I.zz;
+    for (int j = 0; j < 9; j++) A.H[j] += h * C.H[j];
+    A.M.xx += h * C.M.xx; A.M.xy += h * C.M.xy; A.M.xz += h * C.M.xz; A.M.yy += h * C.M.yy; A.M.yz += h * C.M.yz; A.M.zz += h * C.M.zz;
+    SV rhs = {{-pA.a.x, -pA.a.y, -pA.a.z}, {-pA.l.x, -pA.l.y, -pA.l.z}};
+    return solve6(A, rhs);
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+// helper wavefront of kSplitOctPair, after its half of the pairs: the free actors' accelerations from both accumulator sets,
+// handed to the owner through the sample's LDS row; the barrier pairs with the owner's in step_scene
+template <class T, class M>
+__device__ __forceinline__ void helper_free_bodies(M &m, const LMem &L, Split split) {
+    const float h = m.h;
     for (int f = 0; f < kMaxFree; f++)
         if (f < m.n_free) {
-            auto &F = m.fr[f];
-            float *rs = s.fr[f];
-            M3 R;
-            V3 p;
-            SV v;
-            frame_load(L, NB + 1 + f, R, p, v);
-            float fm = F.m, Ic6[6] = {F.Ic[0], 0.f, 0.f, F.Ic[1], 0.f, F.Ic[2]};
-            if (m.rnd_slot[F.actor] >= 0) {  // this sample's own mass and size
-                const ActorDraw dr = actor_draw<T>(m, F.actor, L);
-                fm *= dr.ms;
-                if (F.type == 1) {  // MPPI_ACTOR_BOX
-                    const float x = F.size[0] + dr.d[0], y = F.size[1] + dr.d[1], z = F.size[2] + dr.d[2];
-                    const float m12 = fm * (1.f / 12.f);
-                    Ic6[0] = m12 * (y * y + z * z); Ic6[3] = m12 * (x * x + z * z); Ic6[5] = m12 * (x * x + y * y);
-                } else {  // sphere
-                    const float r = F.size[0] + dr.d[0];
-                    Ic6[0] = Ic6[3] = Ic6[5] = 0.4f * fm * r * r;
-                }
+            const SV a = free_body_accel<T>(m, f, L, h, L.set1);
+            if (split.sub == 0) {
+                const int o = L.xch + 2 + 6 * f;
+                L[o] = a.a.x; L[o + 1] = a.a.y; L[o + 2] = a.a.z; L[o + 3] = a.l.x; L[o + 4] = a.l.y; L[o + 5] = a.l.z;
             }
-            AI A;
-            SV pA;
-            V3 hw;
-            rigid_world(R, p, fm, V3{0.f, 0.f, 0.f}, Ic6, v, A, pA, hw);
-            SV fe;
-            AI C;
-            acc_load(L, SceneLayout<T>::kAcc, NB + 1 + f, fe, C);
-            const V3 g = F.gravity ? V3{m.g[0], m.g[1], m.g[2]} : V3{0.f, 0.f, 0.f};
-            SV Cv = mul(C, v);
-            pA = {pA.a + Cv.a - fe.a - cross(hw, g), pA.l + Cv.l - fe.l - fm * g};
-            A.I.xx += h * C.I.xx; A.I.xy += h * C.I.xy; A.I.xz += h * C.I.xz; A.I.yy += h * C.I.yy; A.I.yz += h * C.I.yz; A.I.zz += h * C.I.zz;
-            for (int j = 0; j < 9; j++) A.H[j] += h * C.H[j];
-            A.M.xx += h * C.M.xx; A.M.xy += h * C.M.xy; A.M.xz += h * C.M.xz; A.M.yy += h * C.M.yy; A.M.yz += h * C.M.yz; A.M.zz += h * C.M.zz;
-            SV rhs = {{-pA.a.x, -pA.a.y, -pA.a.z}, {-pA.l.x, -pA.l.y, -pA.l.z}};
-            root_integrate(rs, solve6(A, rhs), h);
         }
+    __syncthreads();
+}
+#endif
+template <class T, class M>
+MPPI_HD void step_free_bodies(M &m, SceneState<T> &s, const LMem &L, float h) {
+    for (int f = 0; f < kMaxFree; f++)
+        if (f < m.n_free) root_integrate(s.fr[f], free_body_accel<T>(m, f, L, h), h);
 }
 
 // One simulator step of a contact scene (dt = substeps * h).  `root` carries the static actors.
@@ -1389,6 +1418,17 @@ MPPI_HD void step_scene(M &m0, const float *root, SceneState<T> &s, const float 
             s.qd[i] = v;
         });
         if (m.floating) root_integrate(s.base, abase, h);
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (SPLIT == kSplitOctPair) {
+            // the helper wavefront has solved the free actors while this one solved the robot (helper_free_bodies)
+            __syncthreads();
+            for (int f = 0; f < kMaxFree; f++)
+                if (f < m.n_free) {
+                    const int o = L.xch + 2 + 6 * f;
+                    root_integrate(s.fr[f], SV{{L[o], L[o + 1], L[o + 2]}, {L[o + 3], L[o + 4], L[o + 5]}}, h);
+                }
+        } else
+#endif
         step_free_bodies<T>(m, s, L, h);
         MPPI_SEC(7);
     }
