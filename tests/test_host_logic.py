@@ -271,3 +271,31 @@ def test_two_fixed_base_robots_form_one_forest(oracle64, tmp_path):
     apart = load_actor_cfgs(["point_robot", "goal", str(second)])
     with pytest.raises(NotImplementedError, match="next to each other"):
         Scene(apart, ig, [load_asset(apart[0]), load_asset(apart[2])])
+
+
+def test_pruned_link_list_keeps_what_can_be_observed():
+    """urdf_compile.prune_links (ANYmal: 78 URDF links, MPPI_MAX_LINKS = 24): the root, every link with collision geometry and
+    every link the example objective names survive, parent indices point at surviving ancestors, bodies and inertias are
+    untouched"""
+    import json
+    from mppiisaac.backend.urdf_compile import prune_links
+    from mppiisaac.utils.isaacgym_utils import COMPILED_DIR
+    m = json.load(open(os.path.join(COMPILED_DIR, "anymal.json")))
+    names = [l["name"] for l in m["links"]]
+    assert len(names) == 21 and m["pruned_links"] == 57 and names[0] == "base" and len(m["bodies"]) == 12
+    for n in ("base", "face_front", "face_rear", "LF_KFE", "LH_KFE", "RH_KFE", "RF_KFE", "LF_FOOT", "RH_FOOT"):
+        assert n in names
+    for i, l in enumerate(m["links"]):
+        assert -1 <= l["parent_link"] < i and -1 <= l["body"] < 12
+        assert i == 0 or l["collision"] or l["name"] in ("base", "face_front", "face_rear", "LF_KFE", "LH_KFE", "RH_KFE", "RF_KFE")
+    # pruning again changes nothing; pruning a model to its root only keeps the chain of ancestors consistent
+    again = prune_links(m, ("face_front",))
+    assert [l["name"] for l in again["links"]] == names
+    full = json.load(open(os.path.join(COMPILED_DIR, "franka_panda_stick.json")))
+    small = prune_links(full, ("panda_ee_tip",))
+    kept = [l["name"] for l in small["links"]]
+    assert kept[0] == full["links"][0]["name"] and "panda_ee_tip" in kept and small["bodies"] == full["bodies"]
+    tip = small["links"][kept.index("panda_ee_tip")]
+    assert 0 <= tip["parent_link"] < kept.index("panda_ee_tip")
+    total = sum(b["inertia"]["mass"] for b in m["bodies"]) + m["base"]["inertia"]["mass"]
+    assert total == pytest.approx(81.51, abs=0.01)        # every URDF inertial is still in the bodies, whatever the link list says
