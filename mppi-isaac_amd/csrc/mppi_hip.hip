@@ -457,9 +457,15 @@ int mppi_reduce(mppi_ctx_t *c, float *record_out_dev) {
     CTX_TRY(c);
     if (!c->partials_valid) {  // generic mode: S came from host-side costs, build the per-wave records now
         EvScope ev(c, 1);
-        hipLaunchKernelGGL(k_reduce, dim3(c->n_waves), dim3(kWave), 0, c->stream, c->d_cfg, c->d_S, c->d_du, c->d_partials);
+        const int n16 = (c->K + 15) / 16;
+        if (n16 <= c->n_quads) {  // (the record buffer holds n_quads records: every context but the one-lane ones)
+            hipLaunchKernelGGL(k_reduce_quad, dim3(n16), dim3(kWave), 0, c->stream, c->d_cfg, c->d_S, c->d_du, c->d_partials);
+            c->n_partials = n16;
+        } else {
+            hipLaunchKernelGGL(k_reduce, dim3(c->n_waves), dim3(kWave), 0, c->stream, c->d_cfg, c->d_S, c->d_du, c->d_partials);
+            c->n_partials = c->n_waves;
+        }
         c->partials_valid = true;
-        c->n_partials = c->n_waves;
         c->recs_cur = c->d_partials;
     }
     if (record_out_dev)  // ONE shard record (API of the first ABI; the fused path all-gathers its folded records instead, mppi_set_record_out)

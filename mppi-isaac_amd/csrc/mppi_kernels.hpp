@@ -226,6 +226,16 @@ __global__ __launch_bounds__(kWave) void k_reduce(const DevCfg *__restrict__ cfg
     wave_record(*(CCfg *)cfg, live ? S[k] : INFINITY, live, du, k, partials + (size_t)blockIdx.x * (2 + cfg->H * cfg->nu));
 }
 
+// the same records from 16 samples per wavefront (K/16 wavefronts instead of K/64: the per-row sums of quad_record instead of
+// a 64-lane butterfly per row) - the record kernel of the generic mode was 24 us at K = 4096 with 64 wavefronts
+__global__ __launch_bounds__(kWave) void k_reduce_quad(const DevCfg *__restrict__ cfg, const float *__restrict__ S,
+                                                       const float *__restrict__ du, float *__restrict__ partials) {
+    const int k0 = blockIdx.x * 16, k = k0 + (int)(threadIdx.x >> 2);
+    const bool live = k < cfg->K;
+    quad_record<16>(*(CCfg *)cfg, live ? S[k] : INFINITY, live && (threadIdx.x & 3) == 0, du, k0, partials + (size_t)blockIdx.x * (2 + cfg->H * cfg->nu));
+}
+
+
 template <class T>
 __global__ __launch_bounds__(kWave) void k_rollout(const DevModel *__restrict__ m, const DevCfg *__restrict__ cfg,
                                                    const DevCost *__restrict__ cost, const float *__restrict__ x0_dof,

@@ -386,7 +386,7 @@ def test_generic_horizon_in_one_cost_call_equals_the_per_step_loop(lib, monkeypa
         ab, ae = batched.compute_action(list(qi), [0.0] * 7).numpy(), eager.compute_action(list(qi), [0.0] * 7).numpy()
         np.testing.assert_allclose(batched.mppi.get_costs().numpy(), eager.mppi.get_costs().numpy(), rtol=1e-5)
         np.testing.assert_allclose(ab, ae, atol=1e-5)
-        np.testing.assert_allclose(bytes_to_torch(batched.get_rollouts()).cpu().numpy(), bytes_to_torch(eager.get_rollouts()).cpu().numpy(), atol=1e-6)
+        np.testing.assert_allclose(bytes_to_torch(batched.get_rollouts()).cpu().numpy(), bytes_to_torch(eager.get_rollouts()).cpu().numpy(), atol=5e-6)
         assert batched.mppi._batch_sig[0] == "ok" and batched.mppi._graph is None
     assert batched.mppi._batch_fused is True               # the horizon came from the fused rollout kernel with the state dump
     for pl in (batched, eager):                            # a weight change is checked again
