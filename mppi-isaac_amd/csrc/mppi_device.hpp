@@ -101,7 +101,7 @@ struct PairGain {
     int robotA, robotB;   // the shape belongs to the robot (never noisy; keeps its own per-shape friction)
     float muA, muB;       // per-shape friction
     float inv_d0;         // 1 / contact_ramp_depth (0: no ramp)
-    int pad;
+    float npts;           // nominal patch size (4: box against box / ground, else 1); mode-0 pairs carry per-point gains for npts = 1
 };
 struct DevPair {
     PairGeom g;
@@ -672,6 +672,15 @@ MPPI_HD void cmd_map(M &m, const float *u, float *target) {
     });
 }
 
+// Inelastic joint limit: the position is clamped and the velocity becomes the displacement that actually happened over the
+// step, (x_new - x_old) / h - never pointing back out of the range.  (Zeroing the velocity at the stop is a jump: a joint that
+// reaches its limit one substep earlier or later - 1e-9 rad decide - differs by its full speed for that substep; in the
+// gripper scene that was the largest single source of fp32 / fp64 disagreement.)
+MPPI_HD void joint_limit(float x_old, float &x, float &v, float lower, float upper, float inv_h) {
+    if (x < lower) { x = lower; v = fminf((lower - x_old) * inv_h, 0.f); }
+    if (x > upper) { x = upper; v = fmaxf((upper - x_old) * inv_h, 0.f); }
+}
+
 // One simulator step dt = substeps * h (semi-implicit Euler, implicit velocity-level drive,
 // drive-force clamp by one re-solve, velocity clamp, inelastic joint limits).  SURVEY.md B.
 template <class T>
@@ -710,10 +719,7 @@ MPPI_HD void step(CModel &m0, const float *root, float *q, float *qd, const floa
             float v = qd[i] + h * qdd[i];
             if (b.vmax > 0.f) v = fminf(fmaxf(v, -b.vmax), b.vmax);
             float x = q[i] + h * v;
-            if (b.limited) {
-                if (x < b.lower) { x = b.lower; v = fmaxf(v, 0.f); }
-                if (x > b.upper) { x = b.upper; v = fminf(v, 0.f); }
-            }
+            if (b.limited) joint_limit(q[i], x, v, b.lower, b.upper, 1.f / h);
             q[i] = x;
             qd[i] = v;
         });

@@ -300,7 +300,7 @@ MPPI_HD void quad_step(M &m0, QPose<T, JT> &P, QF *q, QF *qd, const QF *target) 
     M *mp = &m0;
     for (int s = 0; s < m0.substeps; s++) {
         M &m = *launder(mp);
-        const float h = m.h, kd = m.kd;
+        const float h = m.h, kd = m.kd, inv_h = frcp(h);
         QF tau[NB], kdh[NB], qdd[NB], ff[NB], vs[NB];
         JointLimits lim[NB];
         const int drive_mode = m.drive_mode;
@@ -328,13 +328,17 @@ MPPI_HD void quad_step(M &m0, QPose<T, JT> &P, QF *q, QF *qd, const QF *target) 
             constexpr int i = ic;
             const JointLimits b = lim[i];
             QF v = qd[i] + h * qdd[i];
-            v = qclamp(v, qrep(-b.vmax), qrep(b.vmax));  // absent limits are +-inf (mppi_pack.hpp): no branches
-            QF x = q[i] + h * v;
+            QF x;
             {
+                // velocity limit and inelastic stops as ONE pair of bounds (absent limits are +-inf, mppi_pack.hpp: no branches).
+                // joint_limit() of mppi_device.hpp says: at a stop the velocity becomes the displacement that happened,
+                // ve = (limit - x_old) / h, never pointing back out of the range.  x_old + h v < lo is the same as v < ve_lo, so
+                // the stop is the unconditional bound v >= min(ve_lo, 0) - and the two clamps compose into one because both
+                // intervals contain 0: v in [med3(ve_lo, -vmax, 0), med3(ve_hi, 0, vmax)]
                 const QF lo = qrep(b.lower), hi = qrep(b.upper), z = qrep(0.f);
-                // inelastic stop: below the lower limit only v >= 0 survives, above the upper one only v <= 0
-                v = qclamp(v, qwhere_lt(x, lo, z, qrep(-INFINITY)), qwhere_gt(x, hi, z, qrep(INFINITY)));
-                x = qclamp(x, lo, hi);
+                const QF vlo = qclamp((lo - q[i]) * inv_h, qrep(-b.vmax), z), vhi = qclamp((hi - q[i]) * inv_h, z, qrep(b.vmax));
+                v = qclamp(v, vlo, vhi);
+                x = qclamp(q[i] + h * v, lo, hi);
             }
             q[i] = x;
             qd[i] = v;

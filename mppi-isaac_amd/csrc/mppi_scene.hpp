@@ -323,6 +323,7 @@ struct PairAcc {
     SV f;    // explicit wrench on shape A's side (about the world origin)
     AI C;    // implicit damping on the dynamic side (modes 1, 2)
     V3 rep;  // reported contact force on A (B receives the opposite)
+    float wsum;  // mode 0: sum of the points' ramps (patch normalisation, see pair_normalise)
     bool any;
 };
 MPPI_HD void pair_zero(PairAcc &a) {
@@ -331,6 +332,7 @@ MPPI_HD void pair_zero(PairAcc &a) {
     for (int j = 0; j < 9; j++) a.C.H[j] = 0.f;
     a.C.M = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     a.rep = {0.f, 0.f, 0.f};
+    a.wsum = 0.f;
     a.any = false;
 }
 
@@ -338,6 +340,7 @@ MPPI_HD void pair_add(PairAcc &a, const PairAcc &b) {
     a.f = a.f + b.f;
     add_to(a.C, b.C);
     a.rep = a.rep + b.rep;
+    a.wsum += b.wsum;
     a.any = a.any || b.any;
 }
 
@@ -400,6 +403,7 @@ __device__ __forceinline__ void group_reduce_explicit(PairAcc &a) {  // mode 0 (
     a.f.a = {S(a.f.a.x), S(a.f.a.y), S(a.f.a.z)};
     a.f.l = {S(a.f.l.x), S(a.f.l.y), S(a.f.l.z)};
     a.rep = {S(a.rep.x), S(a.rep.y), S(a.rep.z)};
+    a.wsum = S(a.wsum);
 }
 template <int SPLIT>
 __device__ __forceinline__ void group_reduce(PairAcc &a) {
@@ -418,8 +422,19 @@ __device__ __forceinline__ void group_reduce(PairAcc &a) {
 struct Gains {  // per-pair contact parameters of THIS sample (equal to the packed nominal ones without randomisation)
     int mode;
     float mu, k, cn, ct, kh;
-    float inv_d0;  // ramp of the velocity-proportional normal terms over the first contact_ramp_depth of penetration
+    float inv_d0;  // ramp of the velocity-proportional terms over the first contact_ramp_depth of penetration
+    float npts;    // nominal patch size of the pair (mode 0: divisor floor of pair_normalise)
 };
+// Two dynamic bodies (mode 0, explicit law): a fixed 1/npts share per point lets a face-to-face contact of 18 feature points
+// carry 4.5 times the nominal stiffness - beyond the stability limit of an explicit spring-damper at h = 25 ms for the lighter
+// body, and the contact chatters (the closed-loop pushing state: perturbations grew 1e4-fold per rollout).  The points of such a
+// pair carry the FULL gains (packed with npts = 1) and the pair's summed force is divided by max(npts, sum of the points'
+// ramps): the patch never exceeds the nominal stiffness, continuously in the number of points that take part.
+MPPI_HD void pair_normalise(const Gains &P, PairAcc &a) {
+    const float sc = frcp(fmaxf(P.npts, a.wsum));
+    a.f = {sc * a.f.a, sc * a.f.l};
+    a.rep = sc * a.rep;
+}
 MPPI_HD void contact_point(const Gains &P, V3 p, V3 n, float depth, const SV &vA, const SV &vB, PairAcc &acc) {
     const V3 vr = vel_at(vA, p) - vel_at(vB, p);
     const float vn = dot(vr, n);
@@ -429,9 +444,13 @@ MPPI_HD void contact_point(const Gains &P, V3 p, V3 n, float depth, const SV &vA
     // Hunt-Crossley-style ramp: damper and implicit spring term grow linearly over the first d0 of penetration, so the
     // normal force (and with it the Coulomb-capped friction) is CONTINUOUS at touch-down; inv_d0 = 0: no ramp
     const float ramp = P.inv_d0 > 0.f ? fminf(1.f, depth * P.inv_d0) : 1.f;
+    // the stick cap of the friction viscosity ramps in as well: a grazing contact (f_n -> 0) of a body at rest (|v_t| -> 0)
+    // would otherwise get the full stick damper c_t from the ratio of two vanishing numbers
+    const float ctr = ramp * P.ct;
     if (P.mode == 0) {  // both dynamic: explicit spring-damper, viscous friction capped by the Coulomb cone
+        acc.wsum += ramp;
         const float fn = fmaxf(0.f, P.k * depth - ramp * P.cn * vn);
-        const float sc = fminf(P.ct, P.mu * fn * frcp(vtn + 1e-9f));
+        const float sc = fminf(ctr, P.mu * fn * frcp(vtn + 1e-9f));
         const V3 f = fn * n - sc * vt;
         acc.f = {acc.f.a + cross(p, f), acc.f.l + f};
         acc.rep = acc.rep + f;
@@ -454,7 +473,7 @@ MPPI_HD void contact_point(const Gains &P, V3 p, V3 n, float depth, const SV &vA
     // Coulomb friction as an implicit secant viscosity b = min(c_t, mu fn / |v_t|): equals the stick damper
     // at small slip, delivers mu*fn while sliding, and - being implicit - can never reverse the slip
     // velocity (an explicit mu*fn chatters: the yaw inertia seen by a wheel contact is far below the mass)
-    const float b = fminf(P.ct, P.mu * fn * frcp(vtn + 1e-9f));
+    const float b = fminf(ctr, P.mu * fn * frcp(vtn + 1e-9f));
     const V3 f = (P.k * depth) * n;
     acc.f = {acc.f.a + cross(p, f), acc.f.l + f};
     // C6 = J^T (b 1 + (a-b) n n^T) J,  J = [-[p]x  1]
@@ -493,7 +512,7 @@ MPPI_HD void contact_point_ground(const Gains &P, V3 p, float depth, const SV &v
         a = vn > 0.f ? fminf(a, cap) : a;
     }
     const float fn = fmaxf(0.f, P.k * depth - a * vn);
-    const float b = fminf(P.ct, P.mu * fn * frcp(vtn + 1e-9f));
+    const float b = fminf(ramp * P.ct, P.mu * fn * frcp(vtn + 1e-9f));
     const float fz = P.k * depth;
     acc.f.a.x += p.y * fz; acc.f.a.y += -(p.x * fz);  // p x (0, 0, fz)
     acc.f.l.z += fz;
@@ -602,6 +621,21 @@ MPPI_HD bool boxes_apart(const BoxRel &r, const float *hx, const float *hy, floa
     return apart;
 }
 
+// Penetration depth and push-out direction (box frame) of a point inside a box, continuous everywhere in the interior: with
+// the distances dx, dy, dz > 0 to the three nearest faces, depth = (dx^-2 + dy^-2 + dz^-2)^-1/2 - a smooth minimum that
+// vanishes on every face, equals the nearest-face distance next to a face and blends near edges and corners - and the normal
+// is the unit vector along its gradient, sum_i (depth / d_i)^3 n_i.  (The nearest-face rule switched the direction of the
+// force by 90 degrees where two distances tie; a point leaving through a side face kept its front-face force until the end.)
+MPPI_HD void box_interior(float dx, float dy, float dz, V3 y, V3 &nl, float &depth) {
+    const float ix = frcp(dx), iy = frcp(dy), iz = frcp(dz);
+    const float ds = frsqrt(ix * ix + iy * iy + iz * iz);
+    float wx = ds * ix, wy = ds * iy, wz = ds * iz;
+    wx = wx * wx * wx; wy = wy * wy * wy; wz = wz * wz * wz;
+    const float nn = frsqrt(wx * wx + wy * wy + wz * wz);
+    nl = {(y.x > 0.f ? wx : -wx) * nn, (y.y > 0.f ? wy : -wy) * nn, (y.z > 0.f ? wz : -wz) * nn};
+    depth = ds;
+}
+
 // Feature points of box X (8 corners, 12 edge midpoints, 6 face centres) that lie inside box Y; a pure
 // vertex test misses boxes that cross like a plus sign (a tall block against a wide chassis face).
 // yc = centre of X in Y's frame, col[j] = column j of R_Y^T R_X scaled by the half extent hx[j];
@@ -634,9 +668,7 @@ MPPI_HD void box_points_in_box(const Gains &P, V3 yc, const V3 *col, const Shape
         point(sp.sub + j * sp.n, y, dx, dy, dz);
         V3 nl;
         float depth;
-        if (dx <= dy && dx <= dz) { nl = {y.x > 0.f ? 1.f : -1.f, 0.f, 0.f}; depth = dx; }
-        else if (dy <= dz) { nl = {0.f, y.y > 0.f ? 1.f : -1.f, 0.f}; depth = dy; }
-        else { nl = {0.f, 0.f, y.z > 0.f ? 1.f : -1.f}; depth = dz; }
+        box_interior(dx, dy, dz, y, nl, depth);
         const V3 pw = Y.p + mul(Y.R, y);
         const V3 n = sign * mul(Y.R, nl);  // outward normal of Y, oriented from B to A
         contact_point(P, pw, n, depth, vA, vB, acc);
@@ -661,9 +693,8 @@ MPPI_HD void sphere_in_box(const Gains &P, V3 ps, float r, const ShapeW &Y, cons
         depth = r - dist;
     } else {  // centre inside: push out through the nearest face
         const float dx = hy[0] - fabsf(y.x), dy = hy[1] - fabsf(y.y), dz = hy[2] - fabsf(y.z);
-        if (dx <= dy && dx <= dz) { nl = {y.x > 0.f ? 1.f : -1.f, 0.f, 0.f}; depth = dx + r; }
-        else if (dy <= dz) { nl = {0.f, y.y > 0.f ? 1.f : -1.f, 0.f}; depth = dy + r; }
-        else { nl = {0.f, 0.f, y.z > 0.f ? 1.f : -1.f}; depth = dz + r; }
+        box_interior(fmaxf(dx, 1e-9f), fmaxf(dy, 1e-9f), fmaxf(dz, 1e-9f), y, nl, depth);  // (centre on the surface: positive distances)
+        depth += r;
     }
     const V3 pw = Y.p + mul(Y.R, cl);
     contact_point(P, pw, sign * mul(Y.R, nl), depth, vA, vB, acc);
@@ -968,7 +999,7 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
         if (apart) continue;
         // contact law of the survivors: second block of the pair (already here: requested one pair ahead)
         if constexpr (kLazyGains) Cg = load_block<PairGain>(m.pr[ip].c);
-        Gains P = {G.mode, Cg.mu, Cg.k, Cg.cn, Cg.ct, Cg.kh, Cg.inv_d0};
+        Gains P = {G.mode, Cg.mu, Cg.k, Cg.cn, Cg.ct, Cg.kh, Cg.inv_d0, Cg.npts};
         if (G.rnd) {  // per-sample friction (min of the two) and contact gains scaled with the per-sample reacting mass
             const float mua = robotA ? Cg.muA : da.mu;
             const float mub = !has_b ? Cg.mub : (robotB ? Cg.muB : db.mu);
@@ -1064,6 +1095,7 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
         }
 #endif
         MPPI_SEC(14);  // feature points + cross-lane sum
+        if (G.mode == 0 && acc.any) pair_normalise(P, acc);
         if (acc.any) {
             const SV neg = {{-acc.f.a.x, -acc.f.a.y, -acc.f.a.z}, {-acc.f.l.x, -acc.f.l.y, -acc.f.l.z}};
             const int ocf = kCfW + 3 * G.rbA, ob = kCfW + 3 * (rbB >= 0 ? rbB : 0);
@@ -1410,10 +1442,7 @@ MPPI_HD void step_scene(M &m0, const float *root, SceneState<T> &s, const float 
             float v = s.qd[i] + h * qdd[i];
             if (b.vmax > 0.f) v = fminf(fmaxf(v, -b.vmax), b.vmax);
             float x = s.q[i] + h * v;
-            if (b.limited) {
-                if (x < b.lower) { x = b.lower; v = fmaxf(v, 0.f); }
-                if (x > b.upper) { x = b.upper; v = fminf(v, 0.f); }
-            }
+            if (b.limited) joint_limit(s.q[i], x, v, b.lower, b.upper, 1.f / h);
             s.q[i] = x;
             s.qd[i] = v;
         });

@@ -271,7 +271,7 @@ MPPI_HD void step_scene_quad(M &m0, MR &mr0, const float *root, SceneState<T> &s
     for (int sub = 0; sub < m0.substeps; sub++) {
         M &m = *launder(mp);
         MR &mr = *launder(mrp);
-        const float h = m.h, kd = m.kd;
+        const float h = m.h, kd = m.kd, inv_h = frcp(h);
         QPose<T> P;
         quad_scene_pose<T>(mr, s, P);
         QSV vbase = {qrep(0.f), qrep(0.f)};
@@ -334,11 +334,11 @@ MPPI_HD void step_scene_quad(M &m0, MR &mr0, const float *root, SceneState<T> &s
             constexpr int i = ic;
             const JointLimits b = lim[i];
             QF v = qd[i] + h * qdd[i];
-            v = qclamp(v, qrep(-b.vmax), qrep(b.vmax));
-            QF x = qrep(s.q[i]) + h * v;
-            const QF lo = qrep(b.lower), hi = qrep(b.upper), z = qrep(0.f);
-            v = qclamp(v, qwhere_lt(x, lo, z, qrep(-INFINITY)), qwhere_gt(x, hi, z, qrep(INFINITY)));
-            x = qclamp(x, lo, hi);
+            // velocity limit and inelastic stops as one pair of bounds (see quad_step in mppi_quad.hpp / joint_limit)
+            const QF lo = qrep(b.lower), hi = qrep(b.upper), z = qrep(0.f), x0 = qrep(s.q[i]);
+            const QF vlo = qclamp((lo - x0) * inv_h, qrep(-b.vmax), z), vhi = qclamp((hi - x0) * inv_h, z, qrep(b.vmax));
+            v = qclamp(v, vlo, vhi);
+            const QF x = qclamp(x0 + h * v, lo, hi);
             s.q[i] = qlane0(x);
             s.qd[i] = qlane0(v);
         });

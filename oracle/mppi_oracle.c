@@ -290,6 +290,14 @@ static uint32_t *g_sat_log = NULL;
 static int g_sat_n = 0;
 #pragma omp threadprivate(g_sat_log, g_sat_n)
 /* One simulator step of dt = substeps * h (IsaacGymWrapper.step, isaacgym_wrapper.py:639-645). */
+/* Inelastic joint limit: the position is clamped and the velocity becomes the displacement that actually happened over the
+ * step, (q_new - q_old) / h - never pointing back out of the range.  (Setting the velocity to zero at the stop is a jump: a
+ * joint that reaches its limit one substep earlier or later - 1e-9 rad decide - differs by its full speed for that substep.) */
+static void joint_limit(real qold, real *q, real *qd, real lower, real upper, real h) {
+    if (*q < lower) { *q = lower; real ve = (lower - qold) / h; *qd = ve < 0 ? ve : 0; }
+    if (*q > upper) { *q = upper; real ve = (upper - qold) / h; *qd = ve > 0 ? ve : 0; }
+}
+
 void orc_step(const mppi_model_t *m, const real *root, real *q, real *qd, const real *target) {
     int n = m->n_bodies;
     real h = (real)(m->dt / m->substeps), kd = (real)m->drive_kd;
@@ -321,11 +329,9 @@ void orc_step(const mppi_model_t *m, const real *root, real *q, real *qd, const 
             real vmax = (real)b->velocity;
             qd[i] += h * qdd[i];
             if (vmax > 0) { if (qd[i] > vmax) qd[i] = vmax; if (qd[i] < -vmax) qd[i] = -vmax; }
+            const real qold = q[i];
             q[i] += h * qd[i];
-            if (b->limited) {
-                if (q[i] < (real)b->lower) { q[i] = (real)b->lower; if (qd[i] < 0) qd[i] = 0; }
-                if (q[i] > (real)b->upper) { q[i] = (real)b->upper; if (qd[i] > 0) qd[i] = 0; }
-            }
+            if (b->limited) joint_limit(qold, &q[i], &qd[i], (real)b->lower, (real)b->upper, h);
         }
     }
 }
@@ -428,7 +434,7 @@ static void vel_at(const real *v6, const real *p, real *out) {
 typedef struct { real R[9], p[3]; const real *v; int ent; } shape_w_t;
 static const real ZERO6[6] = {0, 0, 0, 0, 0, 0};
 
-typedef struct { real f[6]; real C[36]; real rep[3]; int any; } pair_acc_t;
+typedef struct { real f[6]; real C[36]; real rep[3]; int any; real wsum; /* sum of the points' ramps (mode 0: patch normalisation) */ } pair_acc_t;
 
 /* one contact point: normal n from B to A, penetration depth > 0 (same law as csrc/mppi_scene.hpp::contact_point,
  * written from DESIGN.md section 3) */
@@ -447,6 +453,10 @@ static void contact_point(int mode, real mu, real k, real cn, real ct, real kh, 
     for (int j = 0; j < 3; j++) vt[j] = vr[j] - vn * n[j];
     real vtn = (real)sqrt((double)(vt[0] * vt[0] + vt[1] * vt[1] + vt[2] * vt[2]));
     acc->any = 1;
+    acc->wsum += ramp;
+    /* the stick cap of the friction viscosity ramps in with the penetration as well: a grazing contact (f_n -> 0) of a body at
+     * rest (|v_t| -> 0) would otherwise get the full stick damper c_t from the ratio of two vanishing numbers */
+    ct *= ramp;
     if (mode == 0) {
         real fn = k * depth - ramp * cn * vn; if (fn < 0) fn = 0;
         real sc = mu * fn / (vtn + (real)1e-9); if (ct < sc) sc = ct;
@@ -483,6 +493,21 @@ static void shape_world(const mppi_model_t *m, const mppi_shape_t *S, int ent, c
     (void)m;
 }
 
+/* Penetration depth and push-out direction of a point inside a box, continuous everywhere in the interior: with the
+ * distances dx, dy, dz > 0 to the three nearest faces, depth = (dx^-2 + dy^-2 + dz^-2)^-1/2 - a smooth minimum that vanishes
+ * on every face, equals the nearest-face distance next to a face and blends near edges and corners - and the normal is the
+ * unit vector along its gradient, sum_i (depth/d_i)^3 n_i.  (The nearest-face rule switched the direction of the force by 90
+ * degrees where two distances tie; a point leaving through a side face kept its front-face force until the last moment.) */
+static void box_interior(real dx, real dy, real dz, const real *y, real *nl, real *depth) {
+    real ix = 1 / dx, iy = 1 / dy, iz = 1 / dz;
+    real ds = 1 / (real)sqrt((double)(ix * ix + iy * iy + iz * iz));
+    real wx = ds * ix, wy = ds * iy, wz = ds * iz;
+    wx = wx * wx * wx; wy = wy * wy * wy; wz = wz * wz * wz;
+    real nn = 1 / (real)sqrt((double)(wx * wx + wy * wy + wz * wz));
+    nl[0] = (y[0] > 0 ? wx : -wx) * nn; nl[1] = (y[1] > 0 ? wy : -wy) * nn; nl[2] = (y[2] > 0 ? wz : -wz) * nn;
+    *depth = ds;
+}
+
 static void corners_in_box(int mode, real mu, real k, real cn, real ct, real kh, const shape_w_t *X, const double *hx, const shape_w_t *Y,
                            const double *hy, real sign, const real *vA, const real *vB, pair_acc_t *acc) {
     /* feature points of X: 8 corners, 12 edge midpoints, 6 face centres (26 = 3^3 - centre) */
@@ -495,10 +520,8 @@ static void corners_in_box(int mode, real mu, real k, real cn, real ct, real kh,
         m3_tvec(Y->R, d, y);
         real dx = (real)hy[0] - (real)fabs((double)y[0]), dy = (real)hy[1] - (real)fabs((double)y[1]), dz = (real)hy[2] - (real)fabs((double)y[2]);
         if (dx > 0 && dy > 0 && dz > 0) {
-            real nl[3] = {0, 0, 0}, depth;
-            if (dx <= dy && dx <= dz) { nl[0] = y[0] > 0 ? 1 : -1; depth = dx; }
-            else if (dy <= dz) { nl[1] = y[1] > 0 ? 1 : -1; depth = dy; }
-            else { nl[2] = y[2] > 0 ? 1 : -1; depth = dz; }
+            real nl[3], depth;
+            box_interior(dx, dy, dz, y, nl, &depth);
             real n[3];
             m3_vec(Y->R, nl, n);
             for (int j = 0; j < 3; j++) n[j] *= sign;
@@ -525,9 +548,9 @@ static void sphere_in_box(int mode, real mu, real k, real cn, real ct, real kh, 
         depth = r - dist;
     } else {
         real dx = (real)hy[0] - (real)fabs((double)y[0]), dy = (real)hy[1] - (real)fabs((double)y[1]), dz = (real)hy[2] - (real)fabs((double)y[2]);
-        if (dx <= dy && dx <= dz) { nl[0] = y[0] > 0 ? 1 : -1; depth = dx + r; }
-        else if (dy <= dz) { nl[1] = y[1] > 0 ? 1 : -1; depth = dy + r; }
-        else { nl[2] = y[2] > 0 ? 1 : -1; depth = dz + r; }
+        real tiny = (real)1e-9;  /* centre on the surface: the smooth minimum needs positive distances */
+        box_interior(dx > tiny ? dx : tiny, dy > tiny ? dy : tiny, dz > tiny ? dz : tiny, y, nl, &depth);
+        depth += r;
     }
     real pw[3], n[3], t[3];
     m3_vec(Y->R, cl, t);
@@ -570,6 +593,13 @@ static void scene_contacts(const mppi_model_t *m, const scene_info_t *si, frame_
         else { mode = 2; meff = mb; }
         int tb = B ? B->type : -1;
         real npts = (A->type == MPPI_SHAPE_BOX && (tb == MPPI_SHAPE_BOX || tb == -1)) ? 4 : 1;
+        /* two dynamic bodies (explicit law): a fixed 1/npts share per point lets a face-to-face contact of 18 feature points
+         * carry 4.5 times the nominal stiffness - beyond the stability limit of an explicit spring-damper at this step for the
+         * lighter body (alpha + 2 beta < 4 per unit of n / npts).  Their points carry the FULL gains and the pair's summed force
+         * is divided by max(npts, sum of the points' ramps): the stiffness of the patch never exceeds the nominal one, and it is
+         * continuous in the number of points that take part */
+        const real npts_nom = npts;
+        if (mode == 0) npts = 1;
         real k = (real)m->contact_alpha * meff / (h * h) / npts, cn = (real)m->contact_beta * meff / h / npts;
         real ct = (real)m->friction_beta * meff / h / npts, kh = (real)m->contact_alpha * meff / h / npts;
         shape_w_t wa, wb;
@@ -612,6 +642,9 @@ static void scene_contacts(const mppi_model_t *m, const scene_info_t *si, frame_
         }
         if (!acc.any) continue;
         if (mode == 0) {
+            const real sc = 1 / (acc.wsum > npts_nom ? acc.wsum : npts_nom);
+            for (int j = 0; j < 6; j++) acc.f[j] *= sc;
+            for (int j = 0; j < 3; j++) acc.rep[j] *= sc;
             for (int j = 0; j < 6; j++) { fr[ea].f[j] += acc.f[j]; fr[eb].f[j] -= acc.f[j]; }
         } else if (mode == 1) {
             for (int j = 0; j < 6; j++) fr[ea].f[j] += acc.f[j];
@@ -803,11 +836,9 @@ void orc_scene_step(const mppi_model_t *m, real *root, real *q, real *qd, const 
             real vmax = (real)b->velocity;
             qd[i] += h * qdd[i];
             if (vmax > 0) { if (qd[i] > vmax) qd[i] = vmax; if (qd[i] < -vmax) qd[i] = -vmax; }
+            const real qold = q[i];
             q[i] += h * qd[i];
-            if (b->limited) {
-                if (q[i] < (real)b->lower) { q[i] = (real)b->lower; if (qd[i] < 0) qd[i] = 0; }
-                if (q[i] > (real)b->upper) { q[i] = (real)b->upper; if (qd[i] > 0) qd[i] = 0; }
-            }
+            if (b->limited) joint_limit(qold, &q[i], &qd[i], (real)b->lower, (real)b->upper, h);
         }
         if (si.floating) root_integrate(root + 13 * m->robot_actor, abase, h);
         for (int f = 0; f < si.n_free; f++) {
