@@ -771,7 +771,7 @@ MPPI_HD float program_cost_with(CCost &c, const float *q, const float *qd, const
             }
             if (src == kSrcActor) return env.vec(idx, 0);
             if (src == kSrcDofXY) return V3{q[0], q[T::NB > 1 ? 1 : 0], 0.f};
-            if (src == kSrcConst) return V3{t.p[0], t.p[1], t.p[2]};
+            if (src == kSrcConst) return env.constant_point(t.p[0], t.p[1], t.p[2]);
             return V3{0.f, 0.f, 0.f};
         };
         float v = 0.f;
@@ -828,6 +828,7 @@ struct StaticEnv {
         for (int j = 0; j < 4; j++) qq[j] = root[13 * actor + 3 + j];
     }
     MPPI_HD float cf(int, int) const { return 0.f; }
+    MPPI_HD V3 constant_point(float x, float y, float z) const { return V3{x, y, z}; }
 };
 
 // Fused stage cost (DevCost.kind) for a given pose.  See include/mppi_hip.h for the reference Objective each restates.

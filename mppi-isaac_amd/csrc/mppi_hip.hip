@@ -436,9 +436,11 @@ int mppi_rollout_trajectory(mppi_ctx_t *c) {
     const size_t HK = (size_t)c->H * c->K;
     if (!c->d_traj) {
         const size_t rows = c->scene ? 2 * (size_t)c->n + 13 + 13 * (size_t)kMaxFree + 3 * (size_t)c->hm.n_rb : 2 * (size_t)c->n;
-        ALLOC_TRY(c->d_traj, sizeof(float) * rows * HK);
-        ALLOC_TRY(c->d_cost_none, sizeof(DevCost));
-        HIP_TRY(hipMemsetAsync(c->d_cost_none, 0, sizeof(DevCost), c->stream));  // kind = MPPI_COST_NONE
+        if (!c->d_cost_none) {
+            ALLOC_TRY(c->d_cost_none, sizeof(DevCost));
+            HIP_TRY(hipMemsetAsync(c->d_cost_none, 0, sizeof(DevCost), c->stream));  // kind = MPPI_COST_NONE
+        }
+        ALLOC_TRY(c->d_traj, sizeof(float) * rows * HK);  // (last: a failure here leaves nothing the next call would trust)
     }
     {
         EvScope ev(c, 0);
@@ -474,7 +476,9 @@ int mppi_reduce(mppi_ctx_t *c, float *record_out_dev) {
     return launch_check();
 }
 int mppi_shard_record_count(const mppi_ctx_t *c) {
-    if (check_ctx(c) != MPPI_OK || !c->fold) return 0;
+    // (a cost program on a contact-free scene runs the one-lane kernel, which leaves per-wave records and folds nothing:
+    // callers that asked before mppi_set_cost ask again after it)
+    if (check_ctx(c) != MPPI_OK || !c->fold || c->prog_lane) return 0;
     return c->n_quads % 16 == 0 ? kFoldGroups : 1;
 }
 int mppi_set_record_out(mppi_ctx_t *c, float *records_dev) {

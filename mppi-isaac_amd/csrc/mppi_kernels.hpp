@@ -99,10 +99,17 @@ __device__ __forceinline__ void wave_record(CCfg &cfg, float s, bool live, const
 // by lanes s*LPS .. s*LPS + LPS-1 (LPS = 64 / SPW lanes per sample: 4 - quad kernels - or 8).  Instead of a 64-lane
 // butterfly per row (6 shuffle steps x H*nu rows), lane l sums rows l, l + 64, ... over the SPW samples itself: the
 // weights are broadcast through LDS, the du values of a row are one contiguous 64- or 32-byte read.
+// `owner` = false: a helper wavefront of the workgroup (k_rollout_scene_quad with NW = 2) - it owns no samples and only keeps
+// the workgroup barrier company (every wavefront of a workgroup must reach every __syncthreads()).
 template <int SPW = 16>
-__device__ __forceinline__ void quad_record(CCfg &cfg, float s, bool live_leader, const float *__restrict__ du, int k0, float *__restrict__ rec) {
+__device__ __forceinline__ void quad_record(CCfg &cfg, float s, bool live_leader, const float *__restrict__ du, int k0, float *__restrict__ rec,
+                                            bool owner = true) {
     constexpr int LPS = kWave / SPW;
     __shared__ float s_w[SPW];
+    if (!owner) {
+        __syncthreads();
+        return;
+    }
     const int K = cfg.K, HN = cfg.H * cfg.nu;
     const int lane = threadIdx.x & (kWave - 1);
     const bool fin = live_leader && isfinite(s);
@@ -144,9 +151,13 @@ __device__ __forceinline__ void quad_record(CCfg &cfg, float s, bool live_leader
 // no separate "reduce to a shard record" launch exists on the fused path.  The counter re-arms itself.
 constexpr int kFoldGroups = 8;
 constexpr int kFoldTable = 1024;
+// NW = wavefronts per workgroup: ONE ticket per workgroup (thread 0); with a helper wavefront (NW = 2) the ticket travels
+// through LDS so that both wavefronts take the same way through the barriers below, and the helper does none of the work.
+template <int NW = 1>
 __device__ __forceinline__ void fold_group(CCfg &cfg, const float *__restrict__ partials, int first, int n, unsigned *__restrict__ ctr,
                                            float *__restrict__ out) {
     __shared__ float s_sc[kFoldTable];
+    __shared__ unsigned s_ticket;
     const int lane = threadIdx.x & (kWave - 1);
     // Hand-off between workgroups (per-XCD L2s are not coherent, a CU's L1 is never refreshed by other CUs' stores):
     // producer = plain stores -> wait for them -> ONE lane's agent-scope release -> wait again (ROCm 7.2 may drop the
@@ -156,18 +167,29 @@ __device__ __forceinline__ void fold_group(CCfg &cfg, const float *__restrict__ 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     unsigned ticket = 0;
-    if (lane == 0) {
+    if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ticket = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (NW > 1) s_ticket = ticket;
     }
-    ticket = __shfl(ticket, 0, kWave);
-    if (ticket != (unsigned)(n - 1)) return;
-    if (lane == 0) {
+    if constexpr (NW > 1) {
+        __syncthreads();
+        ticket = s_ticket;
+    } else {
+        ticket = __shfl(ticket, 0, kWave);
+    }
+    if (ticket != (unsigned)(n - 1)) return;  // (workgroup-uniform)
+    if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch
     }
     __syncthreads();
+    if constexpr (NW > 1)
+        if (threadIdx.x >= kWave) {  // helper wavefront: the barrier of the fold below, none of its work
+            __syncthreads();
+            return;
+        }
     const int HN = cfg.H * cfg.nu, RF = 2 + HN;
     const float *recs = partials + (size_t)first * RF;
     float b = INFINITY;
@@ -207,15 +229,16 @@ __device__ __forceinline__ void fold_group(CCfg &cfg, const float *__restrict__ 
     }
 }
 // chunk owned by workgroup b of nb (XCD-aware dealing, see k_rollout_quad) and the fold group it reports to
+template <int NW = 1>
 __device__ __forceinline__ void fold_after_record(CCfg &cfg, const float *__restrict__ partials, unsigned *__restrict__ fold_ctr,
                                                   float *__restrict__ fold_out) {
     if (fold_ctr == nullptr) return;
     const int nb = gridDim.x, RF = 2 + cfg.H * cfg.nu;
     if (nb % 16 == 0) {
         const int g = (int)(blockIdx.x % kFoldGroups), n = nb / kFoldGroups;
-        fold_group(cfg, partials, g * n, n, fold_ctr + g, fold_out + (size_t)g * RF);
+        fold_group<NW>(cfg, partials, g * n, n, fold_ctr + g, fold_out + (size_t)g * RF);
     } else {
-        fold_group(cfg, partials, 0, nb, fold_ctr, fold_out);  // ragged grids (identity dealing): one group
+        fold_group<NW>(cfg, partials, 0, nb, fold_ctr, fold_out);  // ragged grids (identity dealing): one group
     }
 }
 
@@ -558,10 +581,15 @@ __global__ __launch_bounds__(kWave) void k_rollout_scene(const DevModel *__restr
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int k = blockIdx.x * kWave + threadIdx.x;
     const bool live = k < cfg->K;
-    const LMem L{lds + threadIdx.x, kWave};  // lane-minor rows: conflict-free ds_read/ds_write
+    LMem L{lds + threadIdx.x, kWave};  // lane-minor rows: conflict-free ds_read/ds_write
+    // start state in rollout coordinates (relative to the robot's start position, mppi_scene.hpp root_relative)
+    __shared__ float s_root[13 * kMaxActors];
+    root_origin(*(CModel *)m, x0_root, L.ox, L.oy);
+    for (int j = threadIdx.x; j < 13 * m->n_actors; j += kWave) s_root[j] = root_relative_entry(x0_root, j, L.ox, L.oy);
+    __syncthreads();
     float s = INFINITY;
     if (live) {
-        s = rollout_scene<T>(*(CModel *)m, *(CModel *)m, *(CCfg *)cfg, *(CCost *)cost, x0_dof, x0_root, U, eps, prior, du, viz, k, L);
+        s = rollout_scene<T>(*(CModel *)m, *(CModel *)m, *(CCfg *)cfg, *(CCost *)cost, x0_dof, s_root, U, eps, prior, du, viz, k, L);
         S[k] = s;
     }
     wave_record(*(CCfg *)cfg, s, live, du, k, partials + (size_t)blockIdx.x * (2 + cfg->H * cfg->nu));
@@ -630,8 +658,12 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW))
     const int row = scene_row_floats<T>(M) + (NW == 2 ? scene_pair_floats<T>(M) : 0);
     unsigned *tab = reinterpret_cast<unsigned *>(lds + (size_t)SPW * row);
     scene_table_fill(M, tab, threadIdx.x, kWave * NW);
-    __syncthreads();
     LMem L{lds + (lane / LPS), SPW, tab};
+    // start state in rollout coordinates (relative to the robot's start position, mppi_scene.hpp root_relative)
+    __shared__ float s_root[13 * kMaxActors];
+    root_origin(M, x0_root, L.ox, L.oy);
+    for (int j = threadIdx.x; j < 13 * M.n_actors; j += kWave * NW) s_root[j] = root_relative_entry(x0_root, j, L.ox, L.oy);
+    __syncthreads();
     if constexpr (NW == 2) {
         L.set1 = scene_row_floats<T>(M);
         L.xch = L.set1 + scene_pair_floats<T>(M) - 2 - 6 * kMaxFree;
@@ -642,20 +674,23 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW))
                 unsigned acc_dirty = ~0u, cf_dirty = ~0u;
                 const int steps = cfg->H * M.substeps;
                 for (int it = 0; it < steps; it++) {
-                    contact_forces<T, kSplitOctPair>(*launder(&M), x0_root, L, acc_dirty, cf_dirty, Split{sub, LPS, 1});
+                    contact_forces<T, kSplitOctPair>(*launder(&M), s_root, L, acc_dirty, cf_dirty, Split{sub, LPS, 1});
                     helper_free_bodies<T>(*launder(&M), L, Split{sub, LPS, 1});
                 }
             }
+            // the record tail's barriers are the workgroup's: the helper reaches them too and does none of the work
+            quad_record<SPW>(*(CCfg *)cfg, INFINITY, false, du, chunk * SPW, partials, false);
+            fold_after_record<NW>(*(CCfg *)cfg, partials, fold_ctr, fold_out);
             return;
         }
     }
     float s = INFINITY;
     if (live) {
-        s = rollout_scene<T, kSplit, DUMP>(M, lm, *(CCfg *)cfg, *(CCost *)cost, x0_dof, x0_root, U, eps, prior, du, viz, k, L, Split{sub, LPS}, traj);
+        s = rollout_scene<T, kSplit, DUMP>(M, lm, *(CCfg *)cfg, *(CCost *)cost, x0_dof, s_root, U, eps, prior, du, viz, k, L, Split{sub, LPS}, traj);
         if (sub == 0) S[k] = s;
     }
     quad_record<SPW>(*(CCfg *)cfg, s, live && sub == 0, du, chunk * SPW, partials + (size_t)chunk * (2 + cfg->H * cfg->nu));
-    fold_after_record(*(CCfg *)cfg, partials, fold_ctr, fold_out);
+    fold_after_record<NW>(*(CCfg *)cfg, partials, fold_ctr, fold_out);
     MPPI_SEC(10);
     if (wave_clk != nullptr && lane == 0) {  // instrumentation (mppi_set_wave_clock): this wavefront's residency
 #if defined(MPPI_HWID_DEBUG)

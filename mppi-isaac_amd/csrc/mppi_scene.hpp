@@ -65,8 +65,27 @@ struct LMem {
     // ([NF][27] wrench / damping rows, then [n_rb][3] contact-force rows - the layout of set 0 from kAcc on) and of the two
     // words in which it hands its "touched" masks to the first wavefront
     int set1 = 0, xch = 0;
+    // origin of the rollout's coordinates (root_relative): added back to the positions a rollout writes out
+    float ox = 0.f, oy = 0.f;
     MPPI_HD float &operator[](int i) const { return p[(size_t)i * stride]; }
 };
+// Rollouts of a floating-base scene run in coordinates RELATIVE to where the robot starts (x, y; the ground stays z = 0).
+// The world-frame spatial algebra refers every inertia, wrench and velocity to the coordinate origin: two metres away from it
+// a 270-kg base carries m |c|^2 = 6 times its own yaw inertia as the parallel-axis term, and fp32 loses in the cancellation
+// what fp64 does not - at the recorded closed-loop pushing state (robot at (2.1, 1.4)) the fp32 / fp64 gap of the SAME code was a
+// median 3e-4 of the cost, 1e-5 with the robot at the origin.  The physics is translation invariant and every cost term is a
+// function of differences (constant points of a cost program are shifted by SceneEnv), so the start state is staged with the
+// robot's (x, y) subtracted from every actor's row; rollout_scene adds it back to what it writes out (visualisation points,
+// dumped trajectories).  out[13 * n_actors]; origin = 0 for fixed-base robots (they stand where their model says).
+MPPI_HD float root_relative_entry(const float *root, int j, float ox, float oy) {
+    const int c = j % 13;
+    return root[j] - (c == 0 ? ox : (c == 1 ? oy : 0.f));
+}
+template <class M>
+MPPI_HD void root_origin(M &m, const float *root, float &ox, float &oy) {
+    ox = m.floating ? root[13 * m.robot_actor] : 0.f;
+    oy = m.floating ? root[13 * m.robot_actor + 1] : 0.f;
+}
 // layout of the table: n_shapes records of kTabShape dwords (DevShape as is), then n_pairs geometry blocks of 16 dwords
 constexpr int kTabShape = (int)(sizeof(DevShape) / 4);
 static_assert(sizeof(DevShape) == 80 && sizeof(PairGeom) == 64 && sizeof(DevPair) == 128, "table layout");
@@ -1551,6 +1570,7 @@ struct SceneEnv {
                 for (int j = 0; j < 4; j++) qq[j] = s.fr[f][3 + j];
     }
     MPPI_HD float cf(int rb, int j) const { return L[SceneLayout<T>::kCf + 3 * rb + j]; }
+    MPPI_HD V3 constant_point(float x, float y, float z) const { return V3{x - L.ox, y - L.oy, z}; }  // (rollout coordinates, see root_relative)
 };
 
 template <class T, class M>
@@ -1632,8 +1652,8 @@ MPPI_HD float rollout_scene(M &m0, MR &mr0, CCfg &cfg0, CCost &cost0, const floa
                 M3 R;
                 V3 p;
                 link_pose<T>(m, P, cfg.viz_link, R, p);
-                viz[((size_t)t * 3 + 0) * K + k] = p.x;
-                viz[((size_t)t * 3 + 1) * K + k] = p.y;
+                viz[((size_t)t * 3 + 0) * K + k] = p.x + L.ox;
+                viz[((size_t)t * 3 + 1) * K + k] = p.y + L.oy;
                 viz[((size_t)t * 3 + 2) * K + k] = p.z;
             }
         } else {
@@ -1649,10 +1669,10 @@ MPPI_HD float rollout_scene(M &m0, MR &mr0, CCfg &cfg0, CCost &cost0, const floa
                     o[(size_t)(NB + i) * HK] = s.qd[i];
                 });
                 o += (size_t)2 * NB * HK;
-                for (int j = 0; j < 13; j++) o[(size_t)j * HK] = s.base[j];
+                for (int j = 0; j < 13; j++) o[(size_t)j * HK] = s.base[j] + (j == 0 ? L.ox : (j == 1 ? L.oy : 0.f));
                 o += (size_t)13 * HK;
                 for (int f = 0; f < kMaxFree; f++)
-                    for (int j = 0; j < 13; j++) o[(size_t)(f * 13 + j) * HK] = s.fr[f][j];
+                    for (int j = 0; j < 13; j++) o[(size_t)(f * 13 + j) * HK] = s.fr[f][j] + (j == 0 ? L.ox : (j == 1 ? L.oy : 0.f));
                 o += (size_t)13 * kMaxFree * HK;
                 const int n_cf = 3 * launder(mp)->n_rb;
                 for (int j = 0; j < n_cf; j++) o[(size_t)j * HK] = L[SceneLayout<T>::kCf + j];

@@ -392,8 +392,8 @@ MPPI_HD float step_tail_scene_quad(M &m, MR &mr, CCfg &cfg, CCost &c, const floa
         const V3 p = qv3_gather(pq);
         if (leader) {
             const int K = cfg.K;
-            viz[((size_t)t * 3 + 0) * K + k] = p.x;
-            viz[((size_t)t * 3 + 1) * K + k] = p.y;
+            viz[((size_t)t * 3 + 0) * K + k] = p.x + L.ox;
+            viz[((size_t)t * 3 + 1) * K + k] = p.y + L.oy;
             viz[((size_t)t * 3 + 2) * K + k] = p.z;
         }
     }

@@ -13,6 +13,8 @@ MAX_BODIES, MAX_LINKS, MAX_ACTORS, MAX_NU, MAX_H, MAX_KNOTS, MAX_COST_W = 12, 24
 MAX_SHAPES, MAX_PAIRS, MAX_FREE = 40, 48, 2
 SHAPE_BOX, SHAPE_SPHERE, SHAPE_DISC = 0, 1, 2
 ABI_VERSION = 3
+# error codes of include/mppi_hip.h
+MPPI_OK, MPPI_EINVAL, MPPI_EHIP, MPPI_EUNSUPPORTED, MPPI_ESTATE = 0, -1, -2, -3, -4
 
 JOINT_REVOLUTE, JOINT_PRISMATIC = 0, 1
 DRIVE_VELOCITY, DRIVE_EFFORT, DRIVE_POSITION = 0, 1, 2

@@ -242,8 +242,10 @@ class MPPIPlanner:
         """caller-owned noise [H][nu][K] (float32, on the sim's device) for the following commands; None returns to
         the configured sampler.  The tensor is kept alive here: the library reads it at every rollout."""
         if eps is None:
-            self._external_noise = None
+            # (a captured horizon has the released tensor's pointer baked into its step kernels: recapture)
+            self._graph = self._batch_graph = None
             capi.check(self._lib, self._lib.mppi_set_noise_dev(self._ctx, None))
+            self._external_noise = None
             return
         if tuple(eps.shape) != (self.T, self.nu, self.K) or eps.dtype != torch.float32 or not eps.is_cuda:
             raise ValueError(f"external noise must be a float32 device tensor of shape [{self.T}, {self.nu}, {self.K}]")
@@ -266,6 +268,9 @@ class MPPIPlanner:
             if blob != getattr(self, "_fused_cost_blob", None):
                 capi.check(self._lib, self._lib.mppi_set_cost(self._ctx, C.byref(cost)))
                 self._fused_cost_blob = blob
+                # which kernel runs depends on the cost (a cost program on a contact-free scene: the one-lane kernel, which
+                # folds no records): the folded all-gather is used only while the library says it folds
+                self._fold_active = self._records_fold is not None and self._lib.mppi_shard_record_count(self._ctx) == self._fold_n
         else:
             self._fused_cost_blob = None
 
@@ -292,7 +297,7 @@ class MPPIPlanner:
                 self._horizon_eager(state)
             capi.check(lib, lib.mppi_sim_finish(ctx))
             self.sim._stale = True
-        if self._shard and self._fused_cost is not None and self._records_fold is not None:
+        if self._shard and self._fused_cost is not None and self._records_fold is not None and getattr(self, "_fold_active", True):
             allgather_records(self._records_fold, _dist_rank(self._pg), self._pg, per=self._fold_n)
             capi.check(lib, lib.mppi_update(ctx, C_void(self._records_fold), self._world * self._fold_n))
         elif self._shard:
@@ -307,6 +312,8 @@ class MPPIPlanner:
         return torch.from_numpy(self._action.copy()).unsqueeze(0) if self.cfg.u_per_command > 1 else torch.from_numpy(self._action.copy())
 
     # -- generic Objective mode: the horizon loop ---------------------------------------------------
+    BATCH_RECHECK = 64   # commands between two validations of the one-call-per-horizon evaluation of an Objective
+
     def _horizon_batched(self, state) -> bool:
         """The horizon without a simulator launch per step.  The rollout dynamics never depend on the running cost, so the H
         steps are simulated first (`_simulate_horizon`: the fused rollout kernel with every step's env state kept, or 2H step /
@@ -327,7 +334,13 @@ class MPPIPlanner:
         sig = self._objective_signature()
         b = self._simulate_horizon()
         single = self._batch_state == "on" or self._batch_sig == ("ok", sig)
-        if not single and self._batch_sig != ("no", sig):       # first command of this Objective: check
+        # an Objective whose Python-side state drifts AFTER its first command (a call counter that starts to matter, a schedule)
+        # would go stale silently: the adopted single call is re-validated every BATCH_RECHECK-th command
+        self._batch_age = getattr(self, "_batch_age", 0) + 1
+        if single and self._batch_state != "on" and self._batch_age >= self.BATCH_RECHECK:
+            single, self._batch_sig = False, None
+        if not single and self._batch_sig != ("no", sig):       # first command of this Objective (or a re-validation): check
+            self._batch_age = 0
             self._batch_sig = ("no", sig)
             viz = list(self.sim.visualize_link_buffer)
             S_one = None
@@ -367,10 +380,11 @@ class MPPIPlanner:
         # over all H*K env-steps; contexts without that kernel simulate step by step below
         if self._batch_fused is not False:
             rc = lib.mppi_rollout_trajectory(ctx)
-            if self._batch_fused is None:
-                self._batch_fused = rc == 0
-            elif rc != 0:
-                capi.check(lib, rc)
+            if self._batch_fused is None and rc == capi.MPPI_EUNSUPPORTED:
+                self._batch_fused = False   # this context has no whole-horizon kernel: step by step below
+            else:
+                capi.check(lib, rc)         # (any other failure - a hipMalloc of the trajectory buffer, a launch error - is an error)
+                self._batch_fused = True
         if self._batch_fused:
             capi.check(lib, lib.mppi_materialise_trajectory(ctx, C_void(b["dof"]), C_void(b["root"]), C_void(b["rb"]), C_void(b["cf"])))
             return b

@@ -43,9 +43,13 @@ int emu_rollout(const mppi_model_t *model, const mppi_config_t *cfg, const mppi_
         if (is_scene(m)) {
             std::vector<float> lmem(SceneLayout<T>::floats(m.n_rb, m.n_rnd, m.n_shapes));
             LMem L{lmem.data(), 1};
+            // as the rollout kernels do: start state relative to the robot's start position (mppi_scene.hpp root_relative)
+            std::vector<float> rel(13 * m.n_actors);
+            root_origin(m, root0, L.ox, L.oy);
+            for (int j = 0; j < 13 * m.n_actors; j++) rel[j] = root_relative_entry(root0, j, L.ox, L.oy);
             for (int s = 0; s < c.K; s++)
-                S[s] = g_scene_split > 1 ? rollout_scene<T, kSplitEmulate>(m, m, c, k, dof0, root0, U, eps, prior, du, viz ? v.data() : nullptr, s, L, Split{0, g_scene_split})
-                                         : rollout_scene<T>(m, m, c, k, dof0, root0, U, eps, prior, du, viz ? v.data() : nullptr, s, L);
+                S[s] = g_scene_split > 1 ? rollout_scene<T, kSplitEmulate>(m, m, c, k, dof0, rel.data(), U, eps, prior, du, viz ? v.data() : nullptr, s, L, Split{0, g_scene_split})
+                                         : rollout_scene<T>(m, m, c, k, dof0, rel.data(), U, eps, prior, du, viz ? v.data() : nullptr, s, L);
         } else
         for (int s = 0; s < c.K; s++) S[s] = rollout_sample<T>(m, c, k, dof0, root0, U, eps, prior, du, viz ? v.data() : nullptr, s);
         if (viz)  // device layout [H][3][K] -> reference layout [H][K][3]

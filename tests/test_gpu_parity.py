@@ -202,7 +202,7 @@ def test_full_size_properties(lib, oracle64):
     from mppiisaac.planner.mppi import make_config
     from mppiisaac.utils.config_store import load_config
     ex = load_config({"defaults": [{"mppi": "panda"}]}, overrides={"mppi.num_samples": K, "mppi.horizon": H})
-    for k in idx[:8]:
+    for k in idx:
         sc = make_config(ex.mppi, k_offset=int(k), k_local=1, viz_link=scene.viz_link_index())
         So, _, _ = oracle64.rollout(m, sc, cost, dof, root, np.zeros((H, 7)), eps[:, :, k:k + 1])
         assert S[k] == pytest.approx(So[0], rel=1e-4)
@@ -273,6 +273,59 @@ def test_full_size_properties_contact_scenes(make, K, H, nu, lib, oracle64, monk
     rel = np.array(rel)
     print(f"{make.__name__}: vs oracle on {len(rel)} samples: median {np.median(rel):.1e}, within 1e-4 {np.mean(rel <= 1e-4):.3f}, max {rel.max():.2e}")
     assert (rel <= 1e-2).all() and (rel <= 1e-4).mean() >= 0.9      # measured: 99 % within 1e-4, max 3.7e-3 (boxer); 3e-7 (gripper scene)
+
+
+CLOSED_LOOP_STATES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "closed_loop_states.npz")
+
+
+@pytest.mark.parametrize("make,name,K,H,nu,states", [
+    (boxer_push, "boxer_push", 8192, 25, 2, ("recorded", "68_9", "13_20")),
+    (panda_pick, "panda_pick", 8192, 30, 9, ("recorded", "77_20"))])
+def test_contact_rich_states_match_oracle(make, name, K, H, nu, states, lib, oracle64, monkeypatch):
+    """BASELINE configs 4 and 5 where the controller actually works: `recorded` = the closed-loop state after some hundred
+    iterations (block against the chassis and an obstacle / gripper over the block on the table; tests/golden/
+    closed_loop_states.npz, with the nominal plan U of that moment), the others = states a few steps into violent rollouts
+    from there (chassis on the ground, block on the chassis, fingers in the table).  128 samples spread over the K = 8192
+    against the fp64 oracle, and the shared-lane kernel against the one-lane kernel on all of them.
+    Round 2 measured 62 % of the samples within 1e-3 at the recorded pushing state (max 25 %): the contact law was
+    discontinuous (stick friction of grazing contacts, face-to-face patches beyond the explicit stability limit, joint stops)
+    and the world-frame fp32 algebra lost digits two metres from the origin.  Bounds asserted here, per state:
+    recorded: >= 98 % within 1e-3, every sample within 1e-2; derived (violent) states: >= 96 % within 1e-3, >= 99 % within 1e-2."""
+    from mppiisaac.planner.mppi import make_config
+    from mppiisaac.utils.config_store import load_config
+    Z = np.load(CLOSED_LOOP_STATES)
+    scene, m, cfg, cost, dof0, root0 = make(K=K, H=H)
+    ex = load_config({"defaults": [{"mppi": name}, {"isaacgym": "normal"}]}, overrides={"mppi.num_samples": K, "mppi.horizon": H})
+    for st in states:
+        dof, root = Z[f"{name}_{st}_dof"], Z[f"{name}_{st}_root"]
+        U = Z[f"{name}_{st}_U"] if f"{name}_{st}_U" in Z.files else np.zeros((H, nu), np.float32)
+        c = Ctx(m, cfg, cost)
+        c.call("mppi_sample", C.c_uint32(0)); c.set_state(dof, root); c.set_U(U); c.call("mppi_rollout")
+        S, eps = c.get("mppi_get_costs", (K,)), c.get("mppi_get_noise", (H, nu, K))
+        c.close()
+        monkeypatch.setenv("MPPI_ROLLOUT", "lane")
+        l = Ctx(m, cfg, cost)
+        l.call("mppi_sample", C.c_uint32(0)); l.set_state(dof, root); l.set_U(U); l.call("mppi_rollout")
+        Sl = l.get("mppi_get_costs", (K,))
+        l.close()
+        monkeypatch.delenv("MPPI_ROLLOUT")
+        assert np.isfinite(S).all() and np.isfinite(Sl).all()
+        rl = np.abs(S - Sl) / np.abs(Sl)
+        rel = []
+        for k in range(3, K, K // 128):
+            sc = make_config(ex.mppi, k_offset=int(k), k_local=1, viz_link=scene.viz_link_index())
+            So, _, _ = oracle64.rollout(m, sc, cost, dof, root, U, eps[:, :, k:k + 1])
+            rel.append(abs(S[k] - So[0]) / abs(So[0]))
+        rel = np.array(rel)
+        print(f"{name} {st}: vs fp64 oracle ({len(rel)} samples) median {np.median(rel):.1e} within 1e-4 {np.mean(rel <= 1e-4):.3f} "
+              f"1e-3 {np.mean(rel <= 1e-3):.3f} 1e-2 {np.mean(rel <= 1e-2):.3f} max {rel.max():.1e} | shared-lane vs one-lane kernel (K samples) "
+              f"within 1e-3 {np.mean(rl <= 1e-3):.4f} 1e-2 {np.mean(rl <= 1e-2):.4f} max {rl.max():.1e}")
+        if st == "recorded":
+            assert np.mean(rel <= 1e-3) >= 0.98 and rel.max() <= 1e-2
+            assert np.mean(rl <= 1e-3) >= 0.98 and np.mean(rl <= 1e-2) >= 0.998
+        else:
+            assert np.mean(rel <= 1e-3) >= 0.96 and np.mean(rel <= 1e-2) >= 0.99
+            assert np.mean(rl <= 1e-3) >= 0.96 and np.mean(rl <= 1e-2) >= 0.99
 
 
 def test_generic_objective_mode_equals_fused(lib):
