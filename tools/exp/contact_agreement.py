@@ -40,7 +40,7 @@ def costs(m, cfg, cost, dof, root, mode=None):
     return S, eps
 
 
-for ramp in (0.0, None):
+for ramp in (None,):
     Scene.CONTACT_RAMP_DEPTH = ramp
     for make, name, K, H in ((boxer_push, "boxer_push", 8192, 25), (panda_pick, "panda_pick", 8192, 30)):
         for label, state in (("initial", None), ("closed-loop", os.path.join(os.path.dirname(os.path.abspath(__file__)), "states", f"state_{name}.npz"))):
