@@ -652,7 +652,15 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW))
 #endif
     const int k = chunk * SPW + (lane / LPS);
     const int sub = lane & (LPS - 1);
-    const bool live = k < cfg->K;
+    const bool live = k < ((CCfg *)cfg)->K;  // (constant address space: a scalar load, not a register per lane)
+    // instrumentation (mppi_set_wave_clock): the start stamp goes out now instead of occupying a register pair for the whole rollout
+    if (wave_clk != nullptr && threadIdx.x == 0) {
+#if defined(MPPI_HWID_DEBUG)
+        wave_clk[2 * chunk] = hwdbg;
+#else
+        wave_clk[2 * chunk] = clk0;
+#endif
+    }
     // behind the SPW-wide sample rows: the wave-shared table of shape records and pair geometry blocks (scene_table_fill)
     CModel &M = *(CModel *)m;
     const int row = scene_row_floats<T>(M) + (NW == 2 ? scene_pair_floats<T>(M) : 0);
@@ -665,8 +673,11 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW))
     for (int j = threadIdx.x; j < 13 * M.n_actors; j += kWave * NW) s_root[j] = root_relative_entry(x0_root, j, L.ox, L.oy);
     __syncthreads();
     if constexpr (NW == 2) {
+        // (forward offsets only: an address formed as "end of the region minus a constant" cannot use the DS instructions'
+        // unsigned immediate offset and costs a register per row - the compiler spilled those to scratch)
         L.set1 = scene_row_floats<T>(M);
-        L.xch = L.set1 + scene_pair_floats<T>(M) - 2 - 6 * kMaxFree;
+        L.xch = L.set1 + SceneLayout<T>::NF * 27 + 3 * M.n_rb;
+        L.park = L.xch + 2 + 6 * kMaxFree;
         if (wave != 0) {
             // HELPER WAVEFRONT: its half of the shape poses and candidate pairs of every substep, out of and into LDS (see
             // kSplitOctPair); the barriers inside contact_forces pair with those of the first wavefront's calls
@@ -687,17 +698,12 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW))
     float s = INFINITY;
     if (live) {
         s = rollout_scene<T, kSplit, DUMP>(M, lm, *(CCfg *)cfg, *(CCost *)cost, x0_dof, s_root, U, eps, prior, du, viz, k, L, Split{sub, LPS}, traj);
-        if (sub == 0) S[k] = s;
+        if (sub == 0) S[(unsigned)k] = s;
     }
     quad_record<SPW>(*(CCfg *)cfg, s, live && sub == 0, du, chunk * SPW, partials + (size_t)chunk * (2 + cfg->H * cfg->nu));
     fold_after_record<NW>(*(CCfg *)cfg, partials, fold_ctr, fold_out);
     MPPI_SEC(10);
     if (wave_clk != nullptr && lane == 0) {  // instrumentation (mppi_set_wave_clock): this wavefront's residency
-#if defined(MPPI_HWID_DEBUG)
-        wave_clk[2 * chunk] = hwdbg;
-#else
-        wave_clk[2 * chunk] = clk0;
-#endif
         wave_clk[2 * chunk + 1] = wall_clock64();
 #if defined(MPPI_SECTION_CLOCKS)
         for (int j = 0; j < kSections; j++) wave_clk[2 * (size_t)gridDim.x + (size_t)chunk * kSections + j] = section_counters()[j];
@@ -1269,7 +1275,7 @@ void launch_rollout_scene_quad_t(mppi_ctx *c) {
 // octet layout with a helper wavefront per sample group (short trees: kSplitOctPair)
 template <class T>
 size_t pair_lds_bytes(const mppi_ctx *c) {
-    const size_t row = c->lds_bytes_quad / 16 + sizeof(float) * ((size_t)SceneLayout<T>::NF * 27 + 3 * (size_t)c->hm.n_rb + 2 + 6 * kMaxFree);
+    const size_t row = c->lds_bytes_quad / 16 + sizeof(float) * ((size_t)SceneLayout<T>::NF * 27 + 3 * (size_t)c->hm.n_rb + 2 + 6 * kMaxFree + scene_park_floats<T>());
     return row * (kWave / 8) + c->lds_bytes_table;
 }
 template <class T>
@@ -1286,7 +1292,7 @@ template <class T>
 void launch_rollout_scene_traj_t(mppi_ctx *c) {
     if constexpr (T::NB <= 4) {  // short trees: the kernel with the helper wavefront (pair_lds_bytes is defined below)
         if (c->helper_wave) {
-            const size_t row = c->lds_bytes_quad / 16 + sizeof(float) * ((size_t)SceneLayout<T>::NF * 27 + 3 * (size_t)c->hm.n_rb + 2 + 6 * kMaxFree);
+            const size_t row = c->lds_bytes_quad / 16 + sizeof(float) * ((size_t)SceneLayout<T>::NF * 27 + 3 * (size_t)c->hm.n_rb + 2 + 6 * kMaxFree + scene_park_floats<T>());
             hipLaunchKernelGGL((k_rollout_scene_quad<T, 8, 2, true>), dim3(c->n_quads), dim3(2 * kWave), row * (kWave / 8) + c->lds_bytes_table, c->stream, c->d_model, c->d_cfg, c->d_cost_none,
                                c->d_x0_dof, c->d_x0_root, c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_S, (float *)nullptr,
                                c->d_partials, (unsigned *)nullptr, c->fold_out, (unsigned long long *)nullptr, c->d_traj);

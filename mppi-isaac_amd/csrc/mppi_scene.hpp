@@ -65,6 +65,9 @@ struct LMem {
     // ([NF][27] wrench / damping rows, then [n_rb][3] contact-force rows - the layout of set 0 from kAcc on) and of the two
     // words in which it hands its "touched" masks to the first wavefront
     int set1 = 0, xch = 0;
+    // kSplitOctPair: row index of the region in which the owner wavefront parks the sample's state while the candidate pairs
+    // are walked (state_park; 0: none)
+    int park = 0;
     // origin of the rollout's coordinates (root_relative): added back to the positions a rollout writes out
     float ox = 0.f, oy = 0.f;
     MPPI_HD float &operator[](int i) const { return p[(size_t)i * stride]; }
@@ -83,8 +86,10 @@ MPPI_HD float root_relative_entry(const float *root, int j, float ox, float oy) 
 }
 template <class M>
 MPPI_HD void root_origin(M &m, const float *root, float &ox, float &oy) {
-    ox = m.floating ? root[13 * m.robot_actor] : 0.f;
-    oy = m.floating ? root[13 * m.robot_actor + 1] : 0.f;
+    // (through the constant address space: a scalar load - the two values are wave-uniform and live for the whole rollout)
+    const MPPI_CONST_AS float *r = (const MPPI_CONST_AS float *)root;
+    ox = m.floating ? r[13 * m.robot_actor] : 0.f;
+    oy = m.floating ? r[13 * m.robot_actor + 1] : 0.f;
 }
 // layout of the table: n_shapes records of kTabShape dwords (DevShape as is), then n_pairs geometry blocks of 16 dwords
 constexpr int kTabShape = (int)(sizeof(DevShape) / 4);
@@ -195,8 +200,11 @@ MPPI_HD int scene_row_floats(M &m) { return SceneLayout<T>::floats(m.n_rb, m.n_r
 
 // extra floats per sample row of the kernels with a helper wavefront (kSplitOctPair): its accumulator set, two mask words and
 // the accelerations of the free actors it solves (6 each, at xch + 2)
+// ... and the region in which the owner parks the sample's state during the pair walk (q, qd, base row, free actors' rows)
+template <class T>
+constexpr int scene_park_floats() { return 2 * T::NB + 13 + 13 * kMaxFree + (T::NB ? T::NB : 1) + 3; }  // + drive targets, + S / ctrl / disc of the rollout
 template <class T, class M>
-MPPI_HD int scene_pair_floats(M &m) { return SceneLayout<T>::NF * 27 + 3 * m.n_rb + 2 + 6 * kMaxFree; }
+MPPI_HD int scene_pair_floats(M &m) { return SceneLayout<T>::NF * 27 + 3 * m.n_rb + 2 + 6 * kMaxFree + scene_park_floats<T>(); }
 
 constexpr int scene_floats_max(int nb) { return (nb + 1 + kMaxFree) * 45 + 3 * (kMaxLinks + kMaxActors); }
 
@@ -576,12 +584,14 @@ MPPI_HD ShapeW shape_world(SH &S, const float *root, const LMem &L) {
 // dealt over the lanes; static shapes are posed once per rollout, the others once per substep.
 template <class T, class M>
 MPPI_HD int shape_cache_base(M &m) { return SceneLayout<T>::kCf + 3 * m.n_rb + 5 * m.n_rnd; }
-template <class T, class M>
+// TAB: the caller knows that the wave-shared table exists (octet rollout kernels) - the per-lane fetch of shape records from
+// the model is then not even compiled (its 64-bit per-lane address cost the helper-wavefront kernel a spilled register pair)
+template <class T, bool TAB = false, class M>
 MPPI_HD void shape_cache_update(M &m, const float *root, const LMem &L, Split sp, bool statics) {
     const int base = shape_cache_base<T>(m);
     for (int i = sp.sub; i < m.n_shapes; i += sp.n) {
         ShapeW w;
-        if (L.tab != nullptr) {
+        if (TAB || L.tab != nullptr) {
             const TabShape S = tab_shape(L, i);
             if ((S.ent < 0) != statics) continue;
             w = shape_world(S, root, L);
@@ -827,12 +837,12 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
     constexpr bool kCached = SPLIT != kSplitNone;
     if constexpr (kPair) {
         // dealt over both wavefronts (the owner posing all shapes before the first barrier, one barrier less, measured the same)
-        shape_cache_update<T>(m, root, L, Split{split.sub + split.n * split.wave, 2 * split.n}, false);
+        shape_cache_update<T, true>(m, root, L, Split{split.sub + split.n * split.wave, 2 * split.n}, false);
 #if defined(__HIP_DEVICE_COMPILE__)
         __syncthreads();
 #endif
     } else if constexpr (kCached) {
-        shape_cache_update<T>(m, root, L, SPLIT == kSplitEmulate ? Split{0, 1} : split, false);
+        shape_cache_update<T, split_octet(SPLIT)>(m, root, L, SPLIT == kSplitEmulate ? Split{0, 1} : split, false);
     }
     MPPI_SEC(1);
     // Dealt broad phase (quad kernels of the larger trees, whose scenes carry a candidate pair per link and obstacle):
@@ -888,7 +898,13 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
     // prefetch at all next to LDS work, see load_block_vmem; their integer fields go back to SGPRs for the scalar branches.
     // Measured alternatives at equal state, pushing scene: scalar loads requested one pair ahead 1.358 ms, vector loads one
     // pair ahead 1.324 ms, the records from the wavefront's LDS table one pair ahead 1.375 ms)
+#if defined(MPPI_PAIR_VMEM_RECORDS)   // experiment builds: the helper-wavefront kernel with vector-memory record prefetch as well
     constexpr bool kVmemRecords = split_on_device(SPLIT) && !dealt_broad_phase<T>(SPLIT);
+#else
+    // (not the kernel with a helper wavefront: 16 registers for the record of the NEXT pair across the whole pair body is what
+    // its 256-register budget does not have - with them the kernel keeps 17 values in scratch memory)
+    constexpr bool kVmemRecords = split_on_device(SPLIT) && !dealt_broad_phase<T>(SPLIT) && !kPair;
+#endif
     // (the kernel with a helper wavefront runs on half the register file: the contact-law block of the pairs that survive the
     // broad phase is fetched when it is needed instead of occupying 16 registers across the whole pair)
     constexpr bool kLazyGains = kPair;
@@ -1418,6 +1434,61 @@ MPPI_HD void step_free_bodies(M &m, SceneState<T> &s, const LMem &L, float h) {
         if (f < m.n_free) root_integrate(s.fr[f], free_body_accel<T>(m, f, L, h), h);
 }
 
+// The kernel with a helper wavefront lives on half the register file (256 registers), and the candidate-pair loop alone wants
+// ~170 of them: whatever else is alive across it goes to scratch memory - the compiler parked 19 registers around the loop of
+// every substep and 79 in all (~250 MB of scratch write-back per launch at K = 8192, twelve times the algorithmic traffic).
+// The sample's state (q, qd, base row, free actors' rows: 43 values for the pushing scene) is not touched while the pairs are
+// walked, and the link poses the solve needs afterwards are the frames scene_frames() has just written to the sample's LDS
+// rows: the owner's leader lane parks the state in the sample's row before the walk, every lane reads it back after it (same
+// wavefront, LDS operations in order, bit-identical values), and the poses are re-read from the frames instead of being kept.
+template <class T>
+MPPI_HD void state_park(const SceneState<T> &s, int n_free, const LMem &L, bool leader) {
+    if (!leader) return;
+    constexpr int NB = T::NB;
+    int o = L.park;
+    static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
+        constexpr int i = ic;
+        L[o + i] = s.q[i];
+        L[o + NB + i] = s.qd[i];
+    });
+    o += 2 * NB;
+    for (int j = 0; j < 13; j++) L[o + j] = s.base[j];
+    o += 13;
+    for (int f = 0; f < kMaxFree; f++)
+        if (f < n_free)
+            for (int j = 0; j < 13; j++) L[o + 13 * f + j] = s.fr[f][j];
+}
+template <class T>
+MPPI_HD void state_unpark(SceneState<T> &s, int n_free, const LMem &L) {
+    constexpr int NB = T::NB;
+    int o = L.park;
+    static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
+        constexpr int i = ic;
+        s.q[i] = L[o + i];
+        s.qd[i] = L[o + NB + i];
+    });
+    o += 2 * NB;
+    for (int j = 0; j < 13; j++) s.base[j] = L[o + j];
+    o += 13;
+    for (int f = 0; f < kMaxFree; f++)
+        if (f < n_free)
+            for (int j = 0; j < 13; j++) s.fr[f][j] = L[o + 13 * f + j];
+}
+// link poses and base velocity back from the frames of this substep (what scene_frames stored)
+template <class T, class M>
+MPPI_HD void pose_from_frames(M &m, const LMem &L, Pose<T> &P, SV &vbase) {
+    constexpr int NB = T::NB;
+    static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
+        constexpr int i = ic;
+        const int o = i * 18;
+        for (int j = 0; j < 9; j++) P.R[i].a[j] = L[o + j];
+        P.p[i] = {L[o + 9], L[o + 10], L[o + 11]};
+    });
+    SV vb;
+    frame_load(L, NB, P.Rb, P.pb, vb);
+    vbase = m.floating ? vb : SV{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+}
+
 // One simulator step of a contact scene (dt = substeps * h).  `root` carries the static actors.
 template <class T, int SPLIT = kSplitNone, class M = CModel>
 MPPI_HD void step_scene(M &m0, const float *root, SceneState<T> &s, const float *target, const LMem &L, Split split = Split{0, 1}) {
@@ -1430,12 +1501,32 @@ MPPI_HD void step_scene(M &m0, const float *root, SceneState<T> &s, const float 
         SV vbase;
         scene_frames<T>(m, root, s, P, vbase, L);
         MPPI_SEC(0);
+#if defined(MPPI_NO_PARK)
+        constexpr bool kPark = false;
+#else
+        constexpr bool kPark = SPLIT == kSplitOctPair;
+#endif
+        constexpr int kParkTarget = 2 * NB + 13 + 13 * kMaxFree;  // (behind the state, see scene_park_floats)
+        float tgt[NB ? NB : 1];
+        if constexpr (kPark) {
+            state_park<T>(s, m.n_free, L, split.sub == 0);
+            if (sub == 0 && split.sub == 0)  // the drive targets of this step: the caller's registers are free from here on
+                static_for<0, NB>([&](auto ic) MPPI_LAMBDA { L[L.park + kParkTarget + ic] = target[ic]; });
+        }
         contact_forces<T, SPLIT>(m, root, L, s.acc_dirty, s.cf_dirty, split);
+        if constexpr (kPark) {
+            M &m2 = *launder(mp);
+            state_unpark<T>(s, m2.n_free, L);
+            pose_from_frames<T>(m2, L, P, vbase);
+            static_for<0, NB>([&](auto ic) MPPI_LAMBDA { tgt[ic] = L[L.park + kParkTarget + ic]; });
+        } else {
+            static_for<0, NB>([&](auto ic) MPPI_LAMBDA { tgt[ic] = target[ic]; });
+        }
         float tau[NB ? NB : 1], kdh[NB ? NB : 1], qdd[NB ? NB : 1], ff[NB ? NB : 1], vs[NB ? NB : 1];
         static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
             constexpr int i = ic;
-            ff[i] = m.drive_mode == kDriveEffort ? target[i] : 0.f;
-            vs[i] = m.drive_mode == kDriveVelocity ? target[i] : 0.f;
+            ff[i] = m.drive_mode == kDriveEffort ? tgt[i] : 0.f;
+            vs[i] = m.drive_mode == kDriveVelocity ? tgt[i] : 0.f;
             tau[i] = ff[i] + kd * (vs[i] - s.qd[i]);
             kdh[i] = kd * h;
         });
@@ -1627,7 +1718,7 @@ MPPI_HD float rollout_scene(M &m0, MR &mr0, CCfg &cfg0, CCost &cost0, const floa
     const bool is_prior = cfg0.use_priors && prior != nullptr && g == cfg0.k_total - 2;
     SceneState<T> s;
     scene_init<T>(m0, dof0, root, s, g, L);
-    if constexpr (SPLIT != kSplitNone) shape_cache_update<T>(m0, root, L, SPLIT == kSplitEmulate ? Split{0, 1} : split, true);
+    if constexpr (SPLIT != kSplitNone) shape_cache_update<T, split_octet(SPLIT)>(m0, root, L, SPLIT == kSplitEmulate ? Split{0, 1} : split, true);
     float target[NB ? NB : 1], u[kMaxNu];
     float S = 0.f, ctrl = 0.f, disc = 1.f;
     M *mp = &m0;
@@ -1640,7 +1731,12 @@ MPPI_HD float rollout_scene(M &m0, MR &mr0, CCfg &cfg0, CCost &cost0, const floa
         if constexpr (SPLIT == kSplitNone) cmd_map<T>(*launder(mp), u, target);
         else cmd_map<T>(mr0, u, target);  // (the kernel's LDS copy of the robot part: no scalar-cache round trips)
         MPPI_SEC(8);
+        constexpr bool kParkSums = SPLIT == kSplitOctPair;  // (the helper-wavefront kernel: everything that idles during a step is parked)
+        constexpr int kParkSumsAt = 2 * NB + 13 + 13 * kMaxFree + (NB ? NB : 1);
+        if constexpr (kParkSums)
+            if (leader) { L[L.park + kParkSumsAt] = S; L[L.park + kParkSumsAt + 1] = ctrl; L[L.park + kParkSumsAt + 2] = disc; }
         step_scene_any<T, SPLIT>(*mp, mr0, root, s, target, L, split);
+        if constexpr (kParkSums) { S = L[L.park + kParkSumsAt]; ctrl = L[L.park + kParkSumsAt + 1]; disc = L[L.park + kParkSumsAt + 2]; }
         if constexpr (SPLIT == kSplitNone || T::NB <= 4) {
             S += disc * stage_cost_scene<T>(*launder(mp), *launder(kp), root, s, L);
             if (cfg.want_rollouts && viz != nullptr && leader) {
@@ -1652,9 +1748,10 @@ MPPI_HD float rollout_scene(M &m0, MR &mr0, CCfg &cfg0, CCost &cost0, const floa
                 M3 R;
                 V3 p;
                 link_pose<T>(m, P, cfg.viz_link, R, p);
-                viz[((size_t)t * 3 + 0) * K + k] = p.x + L.ox;
-                viz[((size_t)t * 3 + 1) * K + k] = p.y + L.oy;
-                viz[((size_t)t * 3 + 2) * K + k] = p.z;
+                // (32-bit element indices, 3 H K < 2^31 by pack_config: a 64-bit per-lane index is two registers for the whole rollout)
+                viz[(unsigned)(t * 3 + 0) * (unsigned)K + (unsigned)k] = p.x + L.ox;
+                viz[(unsigned)(t * 3 + 1) * (unsigned)K + (unsigned)k] = p.y + L.oy;
+                viz[(unsigned)(t * 3 + 2) * (unsigned)K + (unsigned)k] = p.z;
             }
         } else {
             S += disc * step_tail_scene_quad<T>(*launder(mp), mr0, cfg, *launder(kp), root, s, L, viz, t, k, leader);

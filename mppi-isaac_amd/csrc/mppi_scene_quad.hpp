@@ -21,6 +21,10 @@ namespace mppi {
 template <int R>
 __device__ __forceinline__ float qget(QF x) { return bc<R>(x); }
 // lane r reads / writes L[base + o_r]
+// (Measured and NOT kept, round 3: the optimiser folds the compile-time `base` into the select - every access site becomes an
+// address register of its own, ~200 in the gripper scene's kernel, hoisted out of the rollout loops into AGPRs.  Making the
+// lane's pick opaque (`asm("" : "+v"(v))`) turns them into ten lane parts plus DS immediate offsets: 229 -> 166 AGPRs, but
+// the kernel ran 0.7 % SLOWER at equal state (1.9446 -> 1.9582 ms): the AGPR copies were not what it waits for.)
 __device__ __forceinline__ QF qgather(const LMem &L, int base, int o0, int o1, int o2) {
     const int r = quad_row();
     return L[base + (r == 0 ? o0 : (r == 1 ? o1 : o2))];
@@ -391,10 +395,10 @@ MPPI_HD float step_tail_scene_quad(M &m, MR &mr, CCfg &cfg, CCost &c, const floa
         quad_link_pose<T>(mr, P, cfg.viz_link, Rq, pq);
         const V3 p = qv3_gather(pq);
         if (leader) {
-            const int K = cfg.K;
-            viz[((size_t)t * 3 + 0) * K + k] = p.x + L.ox;
-            viz[((size_t)t * 3 + 1) * K + k] = p.y + L.oy;
-            viz[((size_t)t * 3 + 2) * K + k] = p.z;
+            const unsigned K = (unsigned)cfg.K;
+            viz[(unsigned)(t * 3 + 0) * K + (unsigned)k] = p.x + L.ox;
+            viz[(unsigned)(t * 3 + 1) * K + (unsigned)k] = p.y + L.oy;
+            viz[(unsigned)(t * 3 + 2) * K + (unsigned)k] = p.z;
         }
     }
     return cost;

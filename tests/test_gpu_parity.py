@@ -246,9 +246,9 @@ def test_full_size_properties_contact_scenes(make, K, H, nu, lib, oracle64, monk
     # tools/exp/contact_agreement.py: boxer 99.9 % within 1e-3 / max 8.5e-3, gripper scene max 1e-6)
     rel = np.abs(S - Sl) / np.abs(Sl)
     print(f"{make.__name__}: shared-lane kernel vs one-lane kernel: within 1e-3 {np.mean(rel <= 1e-3):.4f}, max {rel.max():.2e}")
-    # (a sample whose block touches down one substep apart in the two kernels lands a few per cent away: between builds the
-    # worst sample of the pushing scene has been 0.85 % - 2.1 %)
-    assert (rel <= 1e-3).mean() > 0.995 and np.percentile(rel, 99.9) <= 1.5e-2 and rel.max() <= 5e-2
+    # (round 3, continuous contact law + rollout coordinates relative to the robot: every sample of the pushing scene within 1e-3
+    # - worst 9.9e-4 -, gripper scene 1.1e-6; round 2 asserted 99.5 % within 1e-3 and max 5 %)
+    assert (rel <= 1e-3).mean() > 0.999 and np.percentile(rel, 99.9) <= 5e-3 and rel.max() <= 2e-2
     assert np.median(S) == pytest.approx(np.median(Sl), rel=1e-4)
     if make is boxer_push:   # short tree: the default kernel has a helper wavefront per sample group; the plain octet kernel too
         info = C.create_string_buffer(256)
@@ -259,7 +259,7 @@ def test_full_size_properties_contact_scenes(make, K, H, nu, lib, oracle64, monk
         o.call("mppi_sample", C.c_uint32(0)); o.set_state(dof, root); o.call("mppi_rollout")
         rel = np.abs(o.get("mppi_get_costs", (K,)) - Sl) / np.abs(Sl)
         o.close()
-        assert (rel <= 1e-3).mean() > 0.995 and np.percentile(rel, 99.9) <= 1.5e-2 and rel.max() <= 5e-2
+        assert (rel <= 1e-3).mean() > 0.999 and np.percentile(rel, 99.9) <= 5e-3 and rel.max() <= 2e-2
     monkeypatch.delenv("MPPI_ROLLOUT")
     from mppiisaac.planner.mppi import make_config
     from mppiisaac.utils.config_store import load_config
@@ -272,7 +272,7 @@ def test_full_size_properties_contact_scenes(make, K, H, nu, lib, oracle64, monk
         rel.append(abs(S[k] - So[0]) / abs(So[0]))
     rel = np.array(rel)
     print(f"{make.__name__}: vs oracle on {len(rel)} samples: median {np.median(rel):.1e}, within 1e-4 {np.mean(rel <= 1e-4):.3f}, max {rel.max():.2e}")
-    assert (rel <= 1e-2).all() and (rel <= 1e-4).mean() >= 0.9      # measured: 99 % within 1e-4, max 3.7e-3 (boxer); 3e-7 (gripper scene)
+    assert (rel <= 5e-3).all() and (rel <= 1e-4).mean() >= 0.95     # measured (round 3): all within 1e-4, max 2.6e-6 (boxer), 9.5e-7 (gripper scene)
 
 
 CLOSED_LOOP_STATES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "closed_loop_states.npz")
@@ -629,8 +629,10 @@ def test_boxer_push_rollout_matches_oracle(lib, oracle64):
     # same cost distribution (measured: medians 2e-7 apart, 99.2 % of the samples within 1e-3, all within 1 %; a touch-down
     # taken one substep apart in fp32 and fp64 splits the few others)
     assert np.median(S) == pytest.approx(np.median(So), rel=1e-4)
-    assert (np.abs(S - So) <= 1e-3 * np.abs(So)).mean() > 0.95
-    assert (np.abs(S - So) <= 1e-2 * np.abs(So)).mean() > 0.99
+    rel = np.abs(S - So) / np.abs(So)
+    print(f"pushing scene, block in front of the robot: within 1e-4 {np.mean(rel <= 1e-4):.4f} 1e-3 {np.mean(rel <= 1e-3):.4f} 1e-2 {np.mean(rel <= 1e-2):.4f} max {rel.max():.2e}")
+    assert (rel <= 1e-3).mean() > 0.98
+    assert (rel <= 1e-2).mean() > 0.995
     c.close()
 
 
@@ -662,6 +664,7 @@ def test_randomised_actors_per_sample(lib, oracle64):
     # measured with the helper-wavefront kernel: 95-96 % of the samples within 1e-3 (87 % within 1e-4), medians 8e-7 apart, worst
     # sample 3.9 % - pushed blocks of different sizes touch down a substep apart in fp32 and fp64 in a few samples
     agree = (np.abs(S - So) <= 1e-3 * np.abs(So)).mean()
+    print(f"randomised actors: within 1e-4 {np.mean(np.abs(S - So) <= 1e-4 * np.abs(So)):.4f} 1e-3 {agree:.4f} max {np.max(np.abs(S - So) / np.abs(So)):.2e}")
     assert np.median(S) == pytest.approx(np.median(So), rel=1e-4)
     assert agree > 0.92 and (np.abs(S - So) <= 5e-2 * np.abs(So)).all()
     assert agree > (np.abs(S - So_nom) <= 1e-2 * np.abs(So_nom)).mean() + 0.1   # and it is THIS seed's worlds that it follows
