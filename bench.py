@@ -106,12 +106,101 @@ class Loop:
             if self.inplace:
                 capi.check(lib, lib.mppi_set_record_out(P, ctypes.c_void_p(self.mine.data_ptr())))
             self.n_records = world_size * per
+            self.exchange = "rccl"
+            if env.get("exchange") == "mailbox":
+                self.exchange = "mailbox" if self._connect_mailbox() else "rccl"
+
+    def _connect_mailbox(self):
+        """The library's own exchange of the shard records (mppi_mailbox_*: every rank stores its records into every rank's inbox
+        and polls its own) instead of the RCCL all-gather.  Guarded: the inboxes are connected through hipIpc
+        handles, then three probe iterations run BOTH exchanges on the same records and compare them bit for bit on every rank;
+        any refusal, timed-out wait or mismatch on any rank keeps the RCCL path for the whole job."""
+        torch, dist, lib, P, capi, env = self.torch, self.dist, self.lib, self.P, self.capi, self.env
+        rank, world = env["rank"], env["world_size"]
+        ok, why = 1, ""
+        try:
+            capi.check(lib, lib.mppi_mailbox_create(P, rank, world))
+            h = (ctypes.c_ubyte * 64)()
+            capi.check(lib, lib.mppi_mailbox_ipc_handle(P, h))
+        except Exception as e:  # noqa: BLE001
+            ok, why, h = 0, f"create: {e}", (ctypes.c_ubyte * 64)()
+        handles = [None] * world
+        dist.all_gather_object(handles, (ok, bytes(h)))
+        if not all(o for o, _ in handles):
+            print(f"[bench] mailbox exchange not available ({why or 'a peer refused'}); RCCL all-gather", file=sys.stderr)
+            return False
+        try:
+            for r, (_, hb) in enumerate(handles):
+                if r != rank:
+                    capi.check(lib, lib.mppi_mailbox_open(P, r, (ctypes.c_ubyte * 64).from_buffer_copy(hb)))
+            gp, gn = ctypes.c_void_p(), ctypes.c_int()
+            capi.check(lib, lib.mppi_mailbox_gathered(P, ctypes.byref(gp), ctypes.byref(gn)))
+            self.gathered, self.n_gathered = gp, gn.value
+        except Exception as e:  # noqa: BLE001
+            ok, why = 0, f"open: {e}"
+        flags = [None] * world
+        dist.all_gather_object(flags, ok)
+        if not all(flags):
+            print(f"[bench] mailbox exchange not available ({why or 'a peer could not open an inbox'}); RCCL all-gather", file=sys.stderr)
+            return False
+        # probe: same records through both exchanges
+        RF = lib.mppi_record_floats(P)
+        hip = ctypes.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        mine = torch.zeros((self.n_records, RF), dtype=torch.float32, device=self.records.device)
+        for _ in range(3):
+            capi.check(lib, lib.mppi_rollout(P))
+            if not self.inplace:
+                capi.check(lib, lib.mppi_reduce(P, ctypes.c_void_p(self.mine.data_ptr())))
+            if env["backend"] == "nccl":
+                dist.all_gather_into_tensor(self.records.view(-1), self.mine.view(-1))
+            else:
+                host = torch.empty(self.records.shape, dtype=self.records.dtype)
+                torch.cuda.current_stream().synchronize()
+                dist.all_gather_into_tensor(host.view(-1), self.mine.cpu().view(-1))
+                self.records.copy_(host)
+            capi.check(lib, lib.mppi_exchange(P))
+            late = ctypes.c_int(0)
+            capi.check(lib, lib.mppi_exchange_status(P, ctypes.byref(late)))
+            torch.cuda.synchronize()
+            same = 0
+            if self.n_gathered == self.n_records and not late.value:
+                hip.hipMemcpy(ctypes.c_void_p(mine.data_ptr()), self.gathered, self.n_records * RF * 4, 3)   # device to device
+                torch.cuda.synchronize()
+                same = int(torch.equal(mine, self.records))
+            res = [None] * world
+            dist.all_gather_object(res, same)
+            if not all(res):
+                print(f"[bench] mailbox probe failed (late={late.value}, equal per rank={res}); RCCL all-gather", file=sys.stderr)
+                return False
+            capi.check(lib, lib.mppi_update(P, self.gathered, self.n_gathered))
+        return True
+
+    def time_exchange(self, n=50):
+        """per-iteration cost of the exchange alone (same records again and again): enqueue + wait, mean over n"""
+        torch, lib, P, capi = self.torch, self.lib, self.P, self.capi
+        if not self.env["sharded"]:
+            return None
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            if self.exchange == "mailbox":
+                capi.check(lib, lib.mppi_exchange(P))
+            elif self.env["backend"] == "nccl":
+                self.dist.all_gather_into_tensor(self.records.view(-1), self.mine.view(-1))
+            else:
+                return None
+            torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / n
 
     # ---- one control iteration, enqueued (no host wait)
     def enqueue(self):
         lib, P, W, capi, env = self.lib, self.P, self.W, self.capi, self.env
         capi.check(lib, lib.mppi_rollout(P))
-        if env["sharded"]:
+        if env["sharded"] and self.exchange == "mailbox":
+            capi.check(lib, lib.mppi_exchange(P))   # publish into every inbox, poll the own one (two small kernels)
+            capi.check(lib, lib.mppi_update_step_world(P, self.gathered, self.n_gathered, W))
+        elif env["sharded"]:
             if not self.inplace:
                 capi.check(lib, lib.mppi_reduce(P, ctypes.c_void_p(self.mine.data_ptr())))
             if env["backend"] == "nccl":
@@ -370,18 +459,24 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world_size)
-    env = dict(world_size=world_size, rank=rank, local_rank=local_rank, sharded=sharded, backend=backend,
+    # MPPI_BENCH_EXCHANGE: "mailbox" = the library's own exchange of the shard records (guarded by a probe against the all-gather,
+    # falls back to it), "rccl" = all-gather only.  Default: mailbox for real multi-rank RCCL jobs, rccl for the one-rank
+    # measurement of the sharded loop (MPPI_BENCH_FORCE_DIST) so that its number stays the RCCL path's
+    exchange = os.environ.get("MPPI_BENCH_EXCHANGE", "mailbox" if (world_size > 1 and backend == "nccl") else "rccl")
+    env = dict(world_size=world_size, rank=rank, local_rank=local_rank, sharded=sharded, backend=backend, exchange=exchange,
                action_sync=os.environ.get("MPPI_BENCH_ACTION") == "sync")
     sync = not args.async_loop
     # The sharded iteration as one captured HIP graph (library launches + the RCCL all-gather): measured with one rank
     # (MPPI_BENCH_FORCE_DIST=1) 0.1897 -> 0.1813 ms per iteration.  Default: on for the one-rank measurement, OFF for real
     # multi-rank runs unless MPPI_BENCH_GRAPH=1 - a capture of an 8-rank RCCL collective could not be exercised on the
     # one-GPU development box, and a hang inside a replay cannot be caught.
-    use_graph = sharded and backend == "nccl" and os.environ.get("MPPI_BENCH_GRAPH", "1" if world_size == 1 else "0") == "1"
+    # With the mailbox exchange the captured iteration contains library kernels only, and their waits are bounded: the graph is on.
+    use_graph_rccl = sharded and backend == "nccl" and os.environ.get("MPPI_BENCH_GRAPH", "1" if world_size == 1 else "0") == "1"
 
     def measure(name, k_per_gpu, steps, warmup):
         loop = Loop(name, k_per_gpu, env, sync=sync)
         graphed = False
+        use_graph = use_graph_rccl or (sharded and getattr(loop, "exchange", "") == "mailbox" and os.environ.get("MPPI_BENCH_GRAPH", "1") == "1")
         if use_graph:
             for _ in range(3):
                 loop.iterate()     # lazy initialisation (RCCL channels, LDS limits) must not happen under capture
@@ -411,6 +506,7 @@ def main():
         ee = world.get_actor_link_by_name("panda", "panda_ee_tip")[0, 0:3].cpu().numpy()
         dist_to_goal = float(np.linalg.norm(ee - np.asarray(wl["goal"])))
 
+    exchange_ms = loop.time_exchange() if sharded else None   # (every rank takes part)
     if rank == 0:
         loop_hz = args.steps / elapsed
         K, H, nu = loop.K, loop.H, loop.nu
@@ -436,12 +532,15 @@ def main():
             "config": {"workload": wl["desc"],
                        "K_per_gpu": K, "K_total": K * world_size, "H": H, "nu": nu, "dt": loop.cfg.isaacgym.dt,
                        "substeps": loop.cfg.isaacgym.substeps, "closed_loop": True, "action_to_host_every_step": sync,
-                       "parallelism": (f"sample-shard x{world_size}: rollout -> in-place {backend} all-gather of {loop.n_records} folded records -> combine"
+                       "parallelism": (f"sample-shard x{world_size}: rollout -> "
+                                       + (f"mailbox exchange (library kernels: store into every rank's inbox, poll the own one) of {loop.n_gathered} records"
+                                          if loop.exchange == "mailbox" else f"in-place {backend} all-gather of {loop.n_records} folded records") + " -> combine"
                                        + (" (one captured HIP graph per iteration)" if graphed else "")) if sharded else "single GPU",
                        "noise": ("fixed halton-spline set, sampled once at construction (k_sample %.1f us, outside the loop)" % (1e3 * sampler_ms))
                                 if sampler_ms is not None else "gaussian, redrawn on the device every iteration",
                        "loop_hz": loop_hz, "env_steps_per_s": loop_hz * K * H * world_size,
                        "final_ee_to_goal_m": dist_to_goal, "final_actor_positions": final_root,
+                       "exchange_ms": exchange_ms,
                        "cfg5_shard": second},
             "roofline": roofline(loop, kms[0], hbm_copy_ceiling(torch), n_waves),
             "kernels_ms": {"k_rollout(+record tail)": kms[0], "k_reduce(generic mode only)": kms[1], "k_combine_update(+world step)": kms[2]},

@@ -22,13 +22,14 @@
 #ifndef MPPI_HIP_H
 #define MPPI_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define MPPI_ABI_VERSION 3
+#define MPPI_ABI_VERSION 4
 
 #define MPPI_MAX_BODIES 12   /* moving bodies (= DOF) of the articulated robot        */
 #define MPPI_MAX_LINKS 24    /* reported rigid bodies of the robot (URDF links)      */
@@ -288,6 +289,32 @@ int mppi_record_floats(const mppi_ctx_t *ctx);               /* 2 + H*nu        
 int mppi_shard_record_count(const mppi_ctx_t *ctx);
 int mppi_set_record_out(mppi_ctx_t *ctx, float *records_dev);
 int mppi_record_dev(mppi_ctx_t *ctx, float **record_dev);    /* device pointer of this shard's record */
+/* Direct exchange of the shard records between the GPUs of one node, owned by the library ("each rank stores its
+ * record into a mailbox on every peer, then flag / poll" - the 1-hop all-gather over the fully connected xGMI mesh; the
+ * reference has no counterpart, isaacgym_wrapper.py:126 is single-GPU).  The alternative to all-gathering the records with
+ * RCCL: no collective library, no host thread per iteration, two small kernels that live in a captured graph.
+ *   mppi_mailbox_create   after mppi_set_cost: this rank's inbox (n_ranks flags + 2 x n_ranks slots of
+ *                         max(1, mppi_shard_record_count) records), in fine-grained device memory where available
+ *   mppi_mailbox_ptr / mppi_mailbox_ipc_handle   what peers need: the device pointer (same process) or a 64-byte hipIpc handle
+ *   mppi_mailbox_set_peer / mppi_mailbox_open    connect rank `peer_rank`'s inbox by pointer / by IPC handle (own rank: no-op)
+ *   mppi_exchange         after mppi_rollout, on the context's stream: publish own records to every inbox, wait (bounded: ~2 s)
+ *                         for every rank's records of this iteration, copy them to the fixed buffer of mppi_mailbox_gathered
+ *   mppi_mailbox_gathered [n_ranks * count][2+H*nu] device buffer (fixed address) and its record count, for mppi_update /
+ *                         mppi_update_step_world
+ *   mppi_exchange_publish / mppi_exchange_wait   the two halves of mppi_exchange.  A caller that drives several ranks of ONE
+ *                         device from one thread (tests) enqueues every rank's publish before any rank's wait: a waiting
+ *                         kernel occupies its hardware queue, and streams of one process may share hardware queues
+ *   mppi_exchange_status  1 if a wait ever timed out (a peer never published) */
+int mppi_mailbox_create(mppi_ctx_t *ctx, int rank, int n_ranks);
+int mppi_mailbox_ptr(mppi_ctx_t *ctx, void **inbox_dev, size_t *bytes);
+int mppi_mailbox_ipc_handle(mppi_ctx_t *ctx, void *handle64);
+int mppi_mailbox_set_peer(mppi_ctx_t *ctx, int peer_rank, void *inbox_dev);
+int mppi_mailbox_open(mppi_ctx_t *ctx, int peer_rank, const void *handle64);
+int mppi_mailbox_gathered(mppi_ctx_t *ctx, float **records_dev, int *n_records);
+int mppi_exchange(mppi_ctx_t *ctx);
+int mppi_exchange_publish(mppi_ctx_t *ctx);
+int mppi_exchange_wait(mppi_ctx_t *ctx);
+int mppi_exchange_status(mppi_ctx_t *ctx, int *timed_out);
 /* combine n shard records (device, [n][2+H*nu]; NULL = own record), update U, emit action, shift */
 int mppi_update(mppi_ctx_t *ctx, const float *records_dev, int n_records);
 int mppi_get_action(mppi_ctx_t *ctx, float *action_host);     /* [nu]; synchronises the stream        */

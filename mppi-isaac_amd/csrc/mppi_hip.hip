@@ -143,9 +143,11 @@ void release_ctx(mppi_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *bufs[] = {c->d_model, c->d_cfg, c->d_cost, c->d_x0_dof, c->d_x0_root, c->d_U, c->d_eps, c->d_du, c->d_S, c->d_prior, c->d_viz,
                     c->d_partials, c->d_record, c->d_action, c->d_beta_eta, c->d_q, c->d_qd, c->d_ctrl, c->d_basis, c->d_sigma, c->d_base, c->d_fr, c->d_cf, c->d_filter,
-                    c->d_seq, c->d_fold, c->d_fold_ctr, c->d_wave_clk, c->d_traj, c->d_cost_none};
+                    c->d_seq, c->d_fold, c->d_fold_ctr, c->d_wave_clk, c->d_traj, c->d_cost_none, c->d_inbox, c->d_peers, c->d_mb_seq, c->d_mb_status,
+                    c->d_gathered, c->d_own_rec};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
+    for (void *p : c->ipc_opened) (void)hipIpcCloseMemHandle(p);
     if (c->h_action) (void)hipHostFree(c->h_action);
     for (auto &v : c->ev)
         for (auto &p : v) {
@@ -487,6 +489,136 @@ int mppi_set_record_out(mppi_ctx_t *c, float *records_dev) {
     c->fold_out = records_dev ? records_dev : c->d_fold;
     return MPPI_OK;
 }
+
+// ---- direct exchange of the shard records (mailbox all-gather) ------------------------------------------------
+int mppi_mailbox_create(mppi_ctx_t *c, int rank, int n_ranks) {
+    CTX_TRY(c);
+    if (n_ranks < 1 || n_ranks > 64 || rank < 0 || rank >= n_ranks) return fail(MPPI_EINVAL, "mppi_mailbox_create: need 0 <= rank < n_ranks <= 64");
+    if (c->d_inbox) return fail(MPPI_ESTATE, "mppi_mailbox_create: this context already has a mailbox");
+    const int cnt = mppi_shard_record_count(c);
+    c->mb_rank = rank; c->mb_n = n_ranks; c->mb_nrec = cnt > 0 ? cnt : 1;
+    c->inbox_bytes = MailboxHeader::bytes(n_ranks, c->mb_nrec, c->RF);
+    HIP_TRY(hipSetDevice(c->device));
+    // fine-grained device memory: stores of a peer GPU become visible while this GPU's kernels run (coarse-grained memory is
+    // only guaranteed at kernel boundaries); plain device memory when the runtime refuses (single-device use needs no more)
+    if (hipExtMallocWithFlags(&c->d_inbox, c->inbox_bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+        (void)hipGetLastError();
+        HIP_TRY(hipMalloc(&c->d_inbox, c->inbox_bytes));
+    }
+    HIP_TRY(hipMemset(c->d_inbox, 0, c->inbox_bytes));
+    ALLOC_TRY(c->d_peers, sizeof(void *) * n_ranks);
+    ALLOC_TRY(c->d_mb_seq, sizeof(unsigned));
+    ALLOC_TRY(c->d_mb_status, sizeof(unsigned));
+    ALLOC_TRY(c->d_gathered, sizeof(float) * (size_t)n_ranks * c->mb_nrec * c->RF);
+    ALLOC_TRY(c->d_own_rec, sizeof(float) * c->RF);
+    c->h_peers.assign(n_ranks, nullptr);
+    c->h_peers[rank] = c->d_inbox;
+    c->peers_dirty = true;
+    return MPPI_OK;
+}
+int mppi_mailbox_ptr(mppi_ctx_t *c, void **inbox_dev, size_t *bytes) {
+    CTX_TRY(c);
+    if (!c->d_inbox) return fail(MPPI_ESTATE, "no mailbox (mppi_mailbox_create)");
+    if (inbox_dev) *inbox_dev = c->d_inbox;
+    if (bytes) *bytes = c->inbox_bytes;
+    return MPPI_OK;
+}
+int mppi_mailbox_ipc_handle(mppi_ctx_t *c, void *handle64) {
+    CTX_TRY(c);
+    if (!c->d_inbox || !handle64) return fail(MPPI_ESTATE, "no mailbox (mppi_mailbox_create)");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+    hipIpcMemHandle_t h;
+    HIP_TRY(hipIpcGetMemHandle(&h, c->d_inbox));
+    std::memcpy(handle64, &h, 64);
+    return MPPI_OK;
+}
+int mppi_mailbox_set_peer(mppi_ctx_t *c, int peer_rank, void *inbox_dev) {
+    CTX_TRY(c);
+    if (!c->d_inbox || peer_rank < 0 || peer_rank >= c->mb_n || !inbox_dev) return fail(MPPI_EINVAL, "mppi_mailbox_set_peer: bad rank / pointer, or no mailbox");
+    c->h_peers[peer_rank] = inbox_dev;
+    c->peers_dirty = true;
+    return MPPI_OK;
+}
+int mppi_mailbox_open(mppi_ctx_t *c, int peer_rank, const void *handle64) {
+    CTX_TRY(c);
+    if (!c->d_inbox || peer_rank < 0 || peer_rank >= c->mb_n || !handle64) return fail(MPPI_EINVAL, "mppi_mailbox_open: bad rank / handle, or no mailbox");
+    if (peer_rank == c->mb_rank) return MPPI_OK;
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handle64, 64);
+    void *p = nullptr;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+    c->ipc_opened.push_back(p);
+    c->h_peers[peer_rank] = p;
+    c->peers_dirty = true;
+    return MPPI_OK;
+}
+int mppi_mailbox_gathered(mppi_ctx_t *c, float **records_dev, int *n_records) {
+    CTX_TRY(c);
+    if (!c->d_inbox) return fail(MPPI_ESTATE, "no mailbox (mppi_mailbox_create)");
+    if (records_dev) *records_dev = c->d_gathered;
+    if (n_records) *n_records = c->mb_n * c->mb_nrec;
+    return MPPI_OK;
+}
+/* publish this shard's records of the current rollout into every rank's inbox, wait for all ranks' records of this
+ * iteration: afterwards mppi_update(ctx, gathered, n) / mppi_update_step_world combine them (mppi_mailbox_gathered) */
+static int mailbox_own_records(mppi_ctx_t *c, const float **own_out) {
+    if (!c->d_inbox) return fail(MPPI_ESTATE, "no mailbox (mppi_mailbox_create)");
+    for (void *p : c->h_peers)
+        if (!p) return fail(MPPI_ESTATE, "mppi_exchange: a peer's inbox is not connected (mppi_mailbox_set_peer / mppi_mailbox_open)");
+    if (c->peers_dirty) {
+        HIP_TRY(hipMemcpyAsync(c->d_peers, c->h_peers.data(), sizeof(void *) * c->mb_n, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->peers_dirty = false;
+    }
+    const float *own;
+    const int folded = mppi_shard_record_count(c);
+    if (c->partials_valid && folded > 0 && folded == c->mb_nrec) {
+        own = c->fold_out;  // the rollout's tail has folded the wave records already
+    } else {
+        if (c->mb_nrec != 1) return fail(MPPI_ESTATE, "mppi_exchange: the mailbox was sized for folded records, but this rollout folded none (set the cost before mppi_mailbox_create)");
+        int rc = mppi_reduce(c, c->d_own_rec);  // ONE shard record
+        if (rc) return rc;
+        own = c->d_own_rec;
+    }
+    *own_out = own;
+    return MPPI_OK;
+}
+int mppi_exchange_publish(mppi_ctx_t *c) {
+    CTX_TRY(c);
+    const float *own = nullptr;
+    int rc = mailbox_own_records(c, &own);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_mailbox_publish, dim3(1), dim3(256), 0, c->stream, own, c->mb_nrec, c->RF, c->mb_rank, c->mb_n, (void *const *)c->d_peers, c->d_mb_seq);
+    return launch_check();
+}
+int mppi_exchange_wait(mppi_ctx_t *c) {
+    CTX_TRY(c);
+    if (!c->d_inbox) return fail(MPPI_ESTATE, "no mailbox (mppi_mailbox_create)");
+    // a peer that never publishes ends the wait after ~2 s of the 100 MHz wall clock instead of hanging the device
+    hipLaunchKernelGGL(k_mailbox_wait, dim3(1), dim3(256), 0, c->stream, c->d_inbox, c->mb_nrec, c->RF, c->mb_n, (const unsigned *)c->d_mb_seq, c->d_gathered,
+                       c->d_mb_status, 200000000ull);
+    return launch_check();
+}
+int mppi_exchange(mppi_ctx_t *c) {
+    CTX_TRY(c);
+    const float *own = nullptr;
+    int rc = mailbox_own_records(c, &own);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_mailbox_exchange, dim3(1), dim3(256), 0, c->stream, own, c->mb_nrec, c->RF, c->mb_rank, c->mb_n, (void *const *)c->d_peers, c->d_mb_seq,
+                       c->d_inbox, c->d_gathered, c->d_mb_status, 200000000ull);
+    return launch_check();
+}
+int mppi_exchange_status(mppi_ctx_t *c, int *timed_out) {
+    CTX_TRY(c);
+    if (!c->d_inbox || !timed_out) return fail(MPPI_ESTATE, "no mailbox (mppi_mailbox_create)");
+    unsigned s = 0;
+    HIP_TRY(hipMemcpyAsync(&s, c->d_mb_status, sizeof s, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *timed_out = (int)s;
+    return MPPI_OK;
+}
+
 int mppi_note_graph_update(mppi_ctx_t *c, int n) {
     CTX_TRY(c);
     c->seq_expected += (unsigned)n;

@@ -519,6 +519,91 @@ __global__ __launch_bounds__(kCombineThreads) void k_combine(const DevCfg *__res
     combine_update<kCombineThreads>(*(CCfg *)cfg, recs, nrec, mode, out, U, action, beta_eta, nullptr, filt);
 }
 
+
+// ---- direct exchange of the shard records between the GPUs of a node (the 1-hop mailbox all-gather) ----------
+// Every rank owns an INBOX in device memory that its peers can write (same process: plain device pointers, other processes:
+// hipIpc handles, other GPUs: xGMI peer access): n flags (one 64-byte line each) and 2 x n slots of `nrec` records.  Per
+// control iteration a rank PUBLISHES its records into slot [seq & 1][rank] of every inbox (its own included), releases, and
+// stores the iteration's sequence number into flag [rank] of every inbox; then it WAITS until the n flags of its own inbox have
+// reached the sequence number, acquires, and copies the n x nrec records of that parity into a buffer with a fixed address -
+// what the combine / update kernels read (fixed pointers: the iteration can live in a captured graph).  Two slots are enough:
+// a rank cannot publish iteration i+2 before every peer has published i+1, which a peer does only after it has consumed i.
+// The spin is bounded (status word 1 = timed out: a peer never published); release / acquire are system-scope, so the same
+// code serves one device (tests: N contexts on N streams) and xGMI peers.
+constexpr int kMailboxFlagStride = 16;  // uints: one flag per 64-byte line
+struct MailboxHeader {                  // layout of an inbox: flags [n][16] uint, then records [2][n][nrec][RF] float
+    static size_t bytes(int n, int nrec, int RF) { return sizeof(unsigned) * kMailboxFlagStride * (size_t)n + sizeof(float) * 2 * (size_t)n * nrec * RF; }
+};
+__device__ __forceinline__ float *mailbox_slot(void *inbox, int n, int nrec, int RF, int parity, int rank) {
+    return reinterpret_cast<float *>(reinterpret_cast<unsigned *>(inbox) + (size_t)kMailboxFlagStride * n) + ((size_t)parity * n + rank) * nrec * RF;
+}
+__device__ __forceinline__ void mailbox_publish(const float *__restrict__ own, int nrec, int RF, int rank, int n, void *const *__restrict__ peers,
+                                                unsigned *__restrict__ seq_ctr) {
+    const unsigned seq = *seq_ctr + 1u;
+    const int parity = (int)(seq & 1u), len = nrec * RF;
+    for (int p = 0; p < n; p++) {
+        float *dst = mailbox_slot(peers[p], n, nrec, RF, parity, rank);
+        for (int j = threadIdx.x; j < len; j += blockDim.x) dst[j] = own[j];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: the records are visible before the flags
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int p = 0; p < n; p++)
+            __hip_atomic_store(reinterpret_cast<unsigned *>(peers[p]) + (size_t)kMailboxFlagStride * rank, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(seq_ctr, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ void mailbox_wait(void *__restrict__ inbox, int nrec, int RF, int n, const unsigned *__restrict__ seq_ctr,
+                                             float *__restrict__ gathered, unsigned *__restrict__ status, unsigned long long max_ticks) {
+    __shared__ int s_late;
+    __shared__ unsigned s_seq;
+    if (threadIdx.x == 0) {
+        s_late = 0;
+        s_seq = __hip_atomic_load(seq_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (stored by the publish ahead of this wait)
+    }
+    __syncthreads();
+    const unsigned seq = s_seq;
+    if ((int)threadIdx.x < n) {
+        const unsigned *flag = reinterpret_cast<const unsigned *>(inbox) + (size_t)kMailboxFlagStride * threadIdx.x;
+        const unsigned long long t0 = wall_clock64();
+        // (sequence numbers only grow; the comparison survives the 2^32 wrap)
+        while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > max_ticks) {
+                s_late = 1;
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        if (s_late) *status = 1u;
+    }
+    __syncthreads();
+    const float *src = mailbox_slot(inbox, n, nrec, RF, (int)(seq & 1u), 0);
+    const int len = n * nrec * RF;
+    for (int j = threadIdx.x; j < len; j += blockDim.x) gathered[j] = __builtin_nontemporal_load(src + j);
+}
+__global__ __launch_bounds__(256) void k_mailbox_publish(const float *__restrict__ own, int nrec, int RF, int rank, int n, void *const *__restrict__ peers,
+                                                         unsigned *__restrict__ seq_ctr) {
+    mailbox_publish(own, nrec, RF, rank, n, peers, seq_ctr);
+}
+__global__ __launch_bounds__(256) void k_mailbox_wait(void *__restrict__ inbox, int nrec, int RF, int n, const unsigned *__restrict__ seq_ctr,
+                                                      float *__restrict__ gathered, unsigned *__restrict__ status, unsigned long long max_ticks) {
+    mailbox_wait(inbox, nrec, RF, n, seq_ctr, gathered, status, max_ticks);
+}
+// both halves in one launch (mppi_exchange: one kernel boundary less per control iteration)
+__global__ __launch_bounds__(256) void k_mailbox_exchange(const float *__restrict__ own, int nrec, int RF, int rank, int n, void *const *__restrict__ peers,
+                                                          unsigned *__restrict__ seq_ctr, void *__restrict__ inbox, float *__restrict__ gathered,
+                                                          unsigned *__restrict__ status, unsigned long long max_ticks) {
+    mailbox_publish(own, nrec, RF, rank, n, peers, seq_ctr);
+    __syncthreads();
+    mailbox_wait(inbox, nrec, RF, n, seq_ctr, gathered, status, max_ticks);
+}
+
 // Closed-loop tail in ONE launch: combine + nominal update, then the K = 1 world is stepped with the new
 // action by one quad of the same workgroup and its state becomes the planner's next x0
 // (replaces k_combine + k_sim_step + k_state_from_world; fixed-base contact-free scenes only).
@@ -1229,6 +1314,15 @@ struct mppi_ctx {
     void (*launch_materialise)(mppi_ctx *, float *, float *, float *, float *) = nullptr;
     void (*launch_combine_world)(mppi_ctx *, const float *, int, mppi_ctx *) = nullptr;  // fused closed-loop tail (quad scenes)
     std::string topo;
+    // direct exchange of the shard records (mppi_mailbox_*): this rank's inbox, the peers' inboxes, the gathered records
+    void *d_inbox = nullptr;
+    void **d_peers = nullptr;
+    std::vector<void *> h_peers, ipc_opened;
+    int mb_rank = -1, mb_n = 0, mb_nrec = 0;
+    unsigned *d_mb_seq = nullptr, *d_mb_status = nullptr;
+    float *d_gathered = nullptr, *d_own_rec = nullptr;
+    size_t inbox_bytes = 0;
+    bool peers_dirty = false;
 };
 
 // one row of the launch table: the kinematic tree and its kernel launchers

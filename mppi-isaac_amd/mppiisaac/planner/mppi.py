@@ -212,6 +212,12 @@ class MPPIPlanner:
             r = dist.get_rank(process_group)
             self._records_fold = torch.zeros((self._world * self._fold_n, self._rec_floats), dtype=torch.float32, device=sim.device)
             capi.check(self._lib, self._lib.mppi_set_record_out(self._ctx, C_void(self._records_fold[r * self._fold_n:(r + 1) * self._fold_n])))
+        # how the shard records travel: "rccl" = torch.distributed all-gather (the portable path), "mailbox" = the
+        # library's direct peer-to-peer exchange (one node; the inboxes are connected through hipIpc handles at the first command)
+        self._exchange = os.environ.get("MPPI_EXCHANGE", "rccl") if shard else None
+        if self._exchange not in (None, "rccl", "mailbox"):
+            raise ValueError(f"MPPI_EXCHANGE={self._exchange!r}: 'rccl' or 'mailbox'")
+        self._mailbox_state = None
         self._fused_cost = None
         self._sample_index = 0
         self._action = np.zeros(self.nu, np.float32)
@@ -297,7 +303,13 @@ class MPPIPlanner:
                 self._horizon_eager(state)
             capi.check(lib, lib.mppi_sim_finish(ctx))
             self.sim._stale = True
-        if self._shard and self._fused_cost is not None and self._records_fold is not None and getattr(self, "_fold_active", True):
+        if self._shard and self._exchange == "mailbox":
+            # the library's own exchange (include/mppi_hip.h mppi_mailbox_*): every rank stores its records into every rank's
+            # inbox over xGMI and polls its own - no collective library on the per-iteration path
+            gathered, n = self._mailbox()
+            capi.check(lib, lib.mppi_exchange(ctx))
+            capi.check(lib, lib.mppi_update(ctx, gathered, n))
+        elif self._shard and self._fused_cost is not None and self._records_fold is not None and getattr(self, "_fold_active", True):
             allgather_records(self._records_fold, _dist_rank(self._pg), self._pg, per=self._fold_n)
             capi.check(lib, lib.mppi_update(ctx, C_void(self._records_fold), self._world * self._fold_n))
         elif self._shard:
@@ -310,6 +322,28 @@ class MPPIPlanner:
             capi.check(lib, lib.mppi_update(ctx, None, 1))
         capi.check(lib, lib.mppi_get_action(ctx, capi.fptr(self._action)))
         return torch.from_numpy(self._action.copy()).unsqueeze(0) if self.cfg.u_per_command > 1 else torch.from_numpy(self._action.copy())
+
+    def _mailbox(self):
+        """(gathered records pointer, count) of this rank's mailbox; created and connected on first use - after the cost is set,
+        because the number of records a shard publishes depends on the kernel the cost selects.  The 64-byte IPC handles of the
+        inboxes travel once through the process group (as CPU bytes: any backend)."""
+        if self._mailbox_state is None:
+            import torch.distributed as dist
+            lib, ctx = self._lib, self._ctx
+            rank, world = dist.get_rank(self._pg), self._world
+            capi.check(lib, lib.mppi_mailbox_create(ctx, rank, world))
+            h = (C.c_ubyte * 64)()
+            capi.check(lib, lib.mppi_mailbox_ipc_handle(ctx, h))
+            handles = [None] * world
+            dist.all_gather_object(handles, bytes(h), group=self._pg)
+            for r, hb in enumerate(handles):
+                if r != rank:
+                    capi.check(lib, lib.mppi_mailbox_open(ctx, r, (C.c_ubyte * 64).from_buffer_copy(hb)))
+            p, n = C.c_void_p(), C.c_int()
+            capi.check(lib, lib.mppi_mailbox_gathered(ctx, C.byref(p), C.byref(n)))
+            dist.barrier(group=self._pg)   # every inbox is open before anybody publishes
+            self._mailbox_state = (p, n.value)
+        return self._mailbox_state
 
     # -- generic Objective mode: the horizon loop ---------------------------------------------------
     BATCH_RECHECK = 64   # commands between two validations of the one-call-per-horizon evaluation of an Objective

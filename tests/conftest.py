@@ -4,6 +4,10 @@ import sys
 
 import pytest
 
+# tests/test_gpu_mailbox.py runs eight shard contexts on eight streams of ONE device with kernels that wait for each other: every
+# stream needs a hardware queue of its own (the HIP runtime multiplexes streams onto 4 by default and reads this at start-up)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "mppi-isaac_amd"))
 sys.path.insert(0, ROOT)

