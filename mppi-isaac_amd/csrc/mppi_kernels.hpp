@@ -107,7 +107,7 @@ __device__ __forceinline__ void quad_record(CCfg &cfg, float s, bool live_leader
     constexpr int LPS = kWave / SPW;
     __shared__ float s_w[SPW];
     if (!owner) {
-        __syncthreads();
+        MPPI_BARRIER(5);
         return;
     }
     const int K = cfg.K, HN = cfg.H * cfg.nu;
@@ -123,7 +123,7 @@ __device__ __forceinline__ void quad_record(CCfg &cfg, float s, bool live_leader
     }
     // this wavefront's own du stores must be visible to its other lanes
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
+    MPPI_BARRIER(5);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const int nlive = K - k0 < SPW ? K - k0 : SPW;  // samples of this chunk that exist
     for (int j = lane; j < HN; j += kWave) {
@@ -165,7 +165,7 @@ __device__ __forceinline__ void fold_group(CCfg &cfg, const float *__restrict__ 
     // ticket holder: ONE lane's agent-scope acquire -> barrier -> plain loads.  Placement-independent: only the speed
     // of the fold depends on the group really sharing an XCD.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    MPPI_BARRIER(6);
     unsigned ticket = 0;
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -174,7 +174,7 @@ __device__ __forceinline__ void fold_group(CCfg &cfg, const float *__restrict__ 
         if constexpr (NW > 1) s_ticket = ticket;
     }
     if constexpr (NW > 1) {
-        __syncthreads();
+        MPPI_BARRIER(7);
         ticket = s_ticket;
     } else {
         ticket = __shfl(ticket, 0, kWave);
@@ -184,10 +184,10 @@ __device__ __forceinline__ void fold_group(CCfg &cfg, const float *__restrict__ 
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch
     }
-    __syncthreads();
+    MPPI_BARRIER(8);
     if constexpr (NW > 1)
         if (threadIdx.x >= kWave) {  // helper wavefront: the barrier of the fold below, none of its work
-            __syncthreads();
+            MPPI_BARRIER(9);
             return;
         }
     const int HN = cfg.H * cfg.nu, RF = 2 + HN;
@@ -204,7 +204,7 @@ __device__ __forceinline__ void fold_group(CCfg &cfg, const float *__restrict__ 
         e += er * sc;
     }
     e = wave_sum(e);
-    __syncthreads();
+    MPPI_BARRIER(9);
     if (lane == 0) {
         out[0] = b;
         out[1] = e;
@@ -752,6 +752,9 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW))
     unsigned *tab = reinterpret_cast<unsigned *>(lds + (size_t)SPW * row);
     scene_table_fill(M, tab, threadIdx.x, kWave * NW);
     LMem L{lds + (lane / LPS), SPW, tab};
+#if defined(MPPI_CHECK)
+    L.limit = row;  // (floats of one sample's rows: any index beyond them belongs to the wave's table or to nobody)
+#endif
     // start state in rollout coordinates (relative to the robot's start position, mppi_scene.hpp root_relative)
     __shared__ float s_root[13 * kMaxActors];
     root_origin(M, x0_root, L.ox, L.oy);

@@ -70,8 +70,41 @@ struct LMem {
     int park = 0;
     // origin of the rollout's coordinates (root_relative): added back to the positions a rollout writes out
     float ox = 0.f, oy = 0.f;
+#if defined(MPPI_CHECK)
+    // check build (MPPI_BUILD_VARIANT=check, tests/test_gpu_check_build.py): every access to the sample's rows is bounds-checked
+    // against the row length the kernel allocated; a violation traps (the launch fails instead of corrupting a neighbour's row)
+    int limit = 0x7fffffff;
+    MPPI_HD float &operator[](int i) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if ((unsigned)i >= (unsigned)limit) __builtin_trap();
+#endif
+        return p[(size_t)i * stride];
+    }
+#else
     MPPI_HD float &operator[](int i) const { return p[(size_t)i * stride]; }
+#endif
 };
+// Workgroup barriers of the kernels in which two wavefronts hand data over through LDS (owner / helper, mppi_scene.hpp
+// kSplitOctPair).  Product build: a plain barrier.  Check build: a PHASE CANARY - every wavefront posts the id of the barrier it
+// believes it is at, and after the barrier all posted ids must agree; a wavefront that took another path through the
+// barrier sequence (a missed or an extra barrier on one side - the failure mode of such hand-offs) traps at the first
+// barrier where the two disagree instead of silently pairing the wrong phases.
+#if defined(MPPI_CHECK) && defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void check_barrier(int id) {
+    __shared__ int s_phase[16];
+    const int w = (int)(threadIdx.x >> 6), nw = (int)(blockDim.x >> 6);
+    if ((threadIdx.x & 63) == 0) s_phase[w] = id;
+    __syncthreads();
+    for (int j = 1; j < nw; j++)
+        if (s_phase[j] != s_phase[0]) __builtin_trap();
+    __syncthreads();
+}
+#define MPPI_BARRIER(id) check_barrier(id)
+#elif defined(__HIP_DEVICE_COMPILE__)
+#define MPPI_BARRIER(id) __syncthreads()
+#else
+#define MPPI_BARRIER(id) do { } while (0)
+#endif
 // Rollouts of a floating-base scene run in coordinates RELATIVE to where the robot starts (x, y; the ground stays z = 0).
 // The world-frame spatial algebra refers every inertia, wrench and velocity to the coordinate origin: two metres away from it
 // a 270-kg base carries m |c|^2 = 6 times its own yaw inertia as the parallel-axis term, and fp32 loses in the cancellation
@@ -822,7 +855,7 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
     const bool helper = kPair && split.wave != 0;
     const int kAccW = helper ? L.set1 : (int)Lay::kAcc, kCfW = kAccW + (Lay::kCf - Lay::kAcc);
 #if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (kPair) __syncthreads();  // the frames of this substep are written; the previous merge is done
+    if constexpr (kPair) MPPI_BARRIER(1);  // the frames of this substep are written; the previous merge is done
 #endif
     for (int e = 0; e < Lay::NF; e++)
         if ((acc_dirty >> e) & 1u)
@@ -838,9 +871,7 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
     if constexpr (kPair) {
         // dealt over both wavefronts (the owner posing all shapes before the first barrier, one barrier less, measured the same)
         shape_cache_update<T, true>(m, root, L, Split{split.sub + split.n * split.wave, 2 * split.n}, false);
-#if defined(__HIP_DEVICE_COMPILE__)
-        __syncthreads();
-#endif
+        MPPI_BARRIER(2);
     } else if constexpr (kCached) {
         shape_cache_update<T, split_octet(SPLIT)>(m, root, L, SPLIT == kSplitEmulate ? Split{0, 1} : split, false);
     }
@@ -1183,7 +1214,7 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
             L[L.xch] = __builtin_bit_cast(float, touched);
             L[L.xch + 1] = __builtin_bit_cast(float, cf_touched);
         }
-        __syncthreads();  // both halves of the pair list are accumulated
+        MPPI_BARRIER(3);  // both halves of the pair list are accumulated
         if (!helper) {
             // set 0 += set 1, rows the helper wrote: each of the sample's lanes takes every 8th value (one lane per address,
             // LDS operations of a wavefront execute in order: the readers below see the sums)
@@ -1425,7 +1456,7 @@ __device__ __forceinline__ void helper_free_bodies(M &m, const LMem &L, Split sp
                 L[o] = a.a.x; L[o + 1] = a.a.y; L[o + 2] = a.a.z; L[o + 3] = a.l.x; L[o + 4] = a.l.y; L[o + 5] = a.l.z;
             }
         }
-    __syncthreads();
+    MPPI_BARRIER(4);
 }
 #endif
 template <class T, class M>
@@ -1560,7 +1591,7 @@ MPPI_HD void step_scene(M &m0, const float *root, SceneState<T> &s, const float 
 #if defined(__HIP_DEVICE_COMPILE__)
         if constexpr (SPLIT == kSplitOctPair) {
             // the helper wavefront has solved the free actors while this one solved the robot (helper_free_bodies)
-            __syncthreads();
+            MPPI_BARRIER(4);
             for (int f = 0; f < kMaxFree; f++)
                 if (f < m.n_free) {
                     const int o = L.xch + 2 + 6 * f;

@@ -20,9 +20,12 @@ def build():
 
 class Oracle:
     def __init__(self, precision="f64"):
-        path = os.path.join(HERE, f"liboracle_{precision}.so")
+        # ORACLE_VARIANT=asan: the AddressSanitizer / UBSan build (make -C oracle asan; the process must have the sanitizer
+        # runtime preloaded - tests/test_sanitizers.py)
+        variant = os.environ.get("ORACLE_VARIANT", "")
+        path = os.path.join(HERE, f"liboracle_{precision}{'_' + variant if variant else ''}.so")
         if not os.path.exists(path):
-            build()
+            subprocess.run(["make", "-C", HERE, "-s", variant], check=True) if variant else build()
         self.lib = C.CDLL(path)
         self.dtype = np.float64 if precision == "f64" else np.float32
         self.ctype = C.c_double if precision == "f64" else C.c_float

@@ -34,7 +34,8 @@ def hostemu():
     """test-only g++ build of the per-sample device functions (tests/hostemu/hostemu.cpp)."""
     import ctypes as C
     d = os.path.join(ROOT, "tests", "hostemu")
-    subprocess.run(["make", "-C", d, "-s", "-j3"], check=True)
-    lib = C.CDLL(os.path.join(d, "libhostemu.so"))
+    variant = os.environ.get("HOSTEMU_VARIANT", "")   # "asan": tests/test_sanitizers.py
+    subprocess.run(["make", "-C", d, "-s", "-j3"] + ([variant] if variant else []), check=True)
+    lib = C.CDLL(os.path.join(d, f"libhostemu{'_' + variant if variant else ''}.so"))
     lib.emu_cost.restype = C.c_float
     return lib
