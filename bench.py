@@ -46,18 +46,22 @@ WORKLOADS = {
 }
 
 
-def make_cfg(w, k_total, H=None):
+def make_cfg(w, k_total, H=None, shipped=False):
+    """conf/mppi/<workload>.yaml with num_samples / horizon overridden.  The measured configuration also switches
+    `filter_u` off (mppi_torch's Savitzky-Golay window / order cannot be verified, SURVEY.md A) and `use_priors` off;
+    shipped=True keeps both as the reference's file ships them (`value_shipped_conf` of the result line)."""
     from mppiisaac.utils.config_store import load_config
+    over = {"mppi.num_samples": k_total, "mppi.horizon": H or w["H"]}
+    if not shipped:
+        over.update({"mppi.filter_u": False, "mppi.use_priors": False})
     return load_config({"defaults": [{"mppi": w["mppi"]}, {"isaacgym": "normal"}], "actors": w["actors"],
-                        "initial_actor_positions": w["init"], "nx": w["nx"]},
-                       overrides={"mppi.num_samples": k_total, "mppi.horizon": H or w["H"], "mppi.filter_u": False,
-                                  "mppi.use_priors": False})
+                        "initial_actor_positions": w["init"], "nx": w["nx"]}, overrides=over)
 
 
 class Loop:
     """planner (K rollout envs + MPPI core) and K=1 world of one workload on this rank's GPU, and its iteration"""
 
-    def __init__(self, name, k_per_gpu, env, sync=True, horizon=None):
+    def __init__(self, name, k_per_gpu, env, sync=True, horizon=None, shipped=False):
         import torch
         import torch.distributed as dist
         from mppiisaac.backend import capi
@@ -68,7 +72,9 @@ class Loop:
         wl = WORKLOADS[name]
         self.name, self.wl, self.K, self.H, self.sync = name, wl, k_per_gpu, horizon or wl["H"], sync
         world_size, rank, sharded = env["world_size"], env["rank"], env["sharded"]
-        cfg = make_cfg(wl, k_per_gpu * world_size, self.H)
+        cfg = make_cfg(wl, k_per_gpu * world_size, self.H, shipped=shipped)
+        if shipped and cfg.mppi.use_priors:
+            cfg.mppi.use_priors = False   # (a prior is a host callback of the example scripts; none is part of the conf file)
         cfg.mppi.device = f"cuda:{env['local_rank']}"
         self.cfg = cfg
         self.objective = getattr(objectives, wl["objective"])(cfg)
@@ -473,8 +479,8 @@ def main():
     # With the mailbox exchange the captured iteration contains library kernels only, and their waits are bounded: the graph is on.
     use_graph_rccl = sharded and backend == "nccl" and os.environ.get("MPPI_BENCH_GRAPH", "1" if world_size == 1 else "0") == "1"
 
-    def measure(name, k_per_gpu, steps, warmup):
-        loop = Loop(name, k_per_gpu, env, sync=sync)
+    def measure(name, k_per_gpu, steps, warmup, shipped=False):
+        loop = Loop(name, k_per_gpu, env, sync=sync, shipped=shipped)
         graphed = False
         use_graph = use_graph_rccl or (sharded and getattr(loop, "exchange", "") == "mailbox" and os.environ.get("MPPI_BENCH_GRAPH", "1") == "1")
         if use_graph:
@@ -496,6 +502,15 @@ def main():
         second = {"workload": WORKLOADS["panda_pick"]["desc"], "K_per_gpu": l2.K, "K_total": l2.K * world_size, "H": l2.H,
                   "steps": len(p2), "ms_per_step": 1e3 * e2 / len(p2), "loop_hz": len(p2) / e2, "value_hz_summed_over_gpus": world_size * len(p2) / e2,
                   "env_steps_per_s": world_size * len(p2) / e2 * l2.K * l2.H, "rollout_kernel_ms": k2[0], "graph": g2}
+
+    # the same workload with the conf file AS THE REFERENCE SHIPS IT (filter_u: True in conf/mppi/panda.yaml:22): the smoothing
+    # operator U <- F U runs inside the same combine kernel, the iteration costs the same
+    shipped = None
+    if os.environ.get("MPPI_BENCH_SHIPPED", "1") != "0":
+        ls, es, ps, ks, gs = measure(args.workload, K_PER_GPU, max(20, args.steps // 2), min(args.warmup, 10), shipped=True)
+        shipped = {"value": world_size * len(ps) / es, "ms_per_step": 1e3 * es / len(ps), "filter_u": bool(ls.cfg.mppi.filter_u),
+                   "steps": len(ps), "graph": gs}
+        del ls
 
     # final state sanity (default workload): the closed loop must have moved the end effector to the goal
     world = loop.world
@@ -520,6 +535,7 @@ def main():
             "metric": "MPPI control-loop Hz (K samples x H horizon), Panda 7-DoF K=4096 H=20" if (args.workload == "panda_reach" and K == 4096)
                       else f"MPPI control-loop Hz, {args.workload} K={K} H={H} (not the BASELINE metric)",
             "value": loop_hz * world_size,
+            "value_shipped_conf": shipped["value"] if shipped else None,
             "unit": f"Hz ({K}-sample x {H}-step control iterations per second, summed over GPUs)",
             "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
@@ -541,6 +557,7 @@ def main():
                        "loop_hz": loop_hz, "env_steps_per_s": loop_hz * K * H * world_size,
                        "final_ee_to_goal_m": dist_to_goal, "final_actor_positions": final_root,
                        "exchange_ms": exchange_ms,
+                       "shipped_conf": shipped,
                        "cfg5_shard": second},
             "roofline": roofline(loop, kms[0], hbm_copy_ceiling(torch), n_waves),
             "kernels_ms": {"k_rollout(+record tail)": kms[0], "k_reduce(generic mode only)": kms[1], "k_combine_update(+world step)": kms[2]},

@@ -631,8 +631,9 @@ def test_boxer_push_rollout_matches_oracle(lib, oracle64):
     assert np.median(S) == pytest.approx(np.median(So), rel=1e-4)
     rel = np.abs(S - So) / np.abs(So)
     print(f"pushing scene, block in front of the robot: within 1e-4 {np.mean(rel <= 1e-4):.4f} 1e-3 {np.mean(rel <= 1e-3):.4f} 1e-2 {np.mean(rel <= 1e-2):.4f} max {rel.max():.2e}")
-    assert (rel <= 1e-3).mean() > 0.98
-    assert (rel <= 1e-2).mean() > 0.995
+    # round 3 (continuous contact law, rollout coordinates relative to the robot): every sample within 4.2e-4, 99.2 % within 1e-4
+    # (round 2 asserted 95 % within 1e-3)
+    assert (rel <= 1e-3).mean() > 0.995 and rel.max() <= 1e-2
     c.close()
 
 
@@ -666,7 +667,8 @@ def test_randomised_actors_per_sample(lib, oracle64):
     agree = (np.abs(S - So) <= 1e-3 * np.abs(So)).mean()
     print(f"randomised actors: within 1e-4 {np.mean(np.abs(S - So) <= 1e-4 * np.abs(So)):.4f} 1e-3 {agree:.4f} max {np.max(np.abs(S - So) / np.abs(So)):.2e}")
     assert np.median(S) == pytest.approx(np.median(So), rel=1e-4)
-    assert agree > 0.92 and (np.abs(S - So) <= 5e-2 * np.abs(So)).all()
+    # round 3: every sample within 3.3e-4 (round 2: 95-96 % within 1e-3, worst 3.9 %)
+    assert agree > 0.99 and (np.abs(S - So) <= 1e-2 * np.abs(So)).all()
     assert agree > (np.abs(S - So_nom) <= 1e-2 * np.abs(So_nom)).mean() + 0.1   # and it is THIS seed's worlds that it follows
     ex = load_config({"defaults": [{"mppi": "boxer_push"}, {"isaacgym": "normal"}]}, overrides={"mppi.num_samples": K, "mppi.horizon": H})
     for r in range(2):
