@@ -404,6 +404,36 @@ MPPI_HD float frcp(float x) {
 #endif
 }
 
+// atan2 and asin for the tilt term of the arm objectives, from the hardware reciprocal / square root and short polynomials
+// (cephes atanf / asinf kernels, |error| < 2e-7 rad - tests/test_hostemu_parity.py): ~30 / ~20 instructions instead of the
+// ~50 / ~35 of the library sequences.  Experiment builds only (MPPI_BUILD_VARIANT=xmppi_fast_atan): measured
+// on the headline kernel, see the variant table there.
+MPPI_HD float fast_atan_pos(float a) {  // a >= 0
+    // cephes atanf: two range reductions to |t| <= tan(pi/8), then a degree-7 odd polynomial
+    const bool big = a > 2.414213562373095f, mid = a > 0.4142135623730950f;
+    const float t = big ? -frcp(a) : (mid ? (a - 1.f) * frcp(a + 1.f) : a);
+    const float base = big ? 1.5707963267948966f : (mid ? 0.7853981633974483f : 0.f);
+    const float z = t * t;
+    const float p = (((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * t + t;
+    return base + p;
+}
+MPPI_HD float fast_atan2(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    float r = ax > 0.f || ay > 0.f ? fast_atan_pos(ay * frcp(fmaxf(ax, 1e-30f))) : 0.f;
+    r = ax * 4.e18f < ay ? 1.5707963267948966f : r;  // (x == 0 or the ratio overflows)
+    r = x < 0.f ? 3.14159265358979f - r : r;
+    return y < 0.f ? -r : r;
+}
+MPPI_HD float fast_asin(float x) {  // |x| <= 1
+    const float a = fabsf(x);
+    const bool big = a > 0.5f;
+    const float z = big ? 0.5f * (1.f - a) : a * a;
+    const float s = big ? fsqrt(z) : a;
+    const float p = ((((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z + 7.4953002686e-2f) * z + 1.6666752422e-1f) * z * s + s;
+    const float r = big ? 1.5707963267948966f - 2.f * p : p;
+    return x < 0.f ? -r : r;
+}
+
 // clamp to [lo, hi]: one v_med3_f32 on the device (fminf(fmaxf()) costs two operations plus a canonicalisation each)
 MPPI_HD float clampf(float v, float lo, float hi) {
 #if defined(__HIP_DEVICE_COMPILE__)

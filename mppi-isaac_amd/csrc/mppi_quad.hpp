@@ -47,8 +47,13 @@ __device__ __forceinline__ QF qabs(QF x) { return fabsf(x); }
 __device__ __forceinline__ QF qclamp(QF v, QF lo, QF hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
 __device__ __forceinline__ QF qmin(QF a, QF b) { return fminf(a, b); }
 __device__ __forceinline__ QF qmax(QF a, QF b) { return fmaxf(a, b); }
+#if defined(MPPI_FAST_ATAN)   // experiment build (variant table of the headline kernel)
+__device__ __forceinline__ QF qatan2(QF a, QF b) { return fast_atan2(a, b); }
+__device__ __forceinline__ QF qasin(QF a) { return fast_asin(a); }
+#else
 __device__ __forceinline__ QF qatan2(QF a, QF b) { return atan2f(a, b); }
 __device__ __forceinline__ QF qasin(QF a) { return asinf(a); }
+#endif
 // hardware v_sin_f32 / v_cos_f32: measured max abs error 6.6e-7 / 4.4e-7 on [-6.4, 6.4] (tools/exp/sin_acc.hip),
 // 3 instructions instead of ~28 for the polynomial version the host build keeps
 __device__ __forceinline__ void qsincos(QF x, QF &s, QF &c) { s = __sinf(x); c = __cosf(x); }

@@ -762,6 +762,23 @@ MPPI_HD void sphere_in_box(const Gains &P, V3 ps, float r, const ShapeW &Y, cons
     contact_point(P, pw, sign * mul(Y.R, nl), depth, vA, vB, acc);
 }
 
+// two spheres: normal along the line of centres (from B to A), contact point in the middle of the overlap; coincident centres
+// push apart along +z (sphere obstacles of the plannerbenchmark adapters against sphere-shaped links,
+// reference benchmarks/panda_arm/mppi_planner/mppi_planner_wrapper.py:58-79)
+MPPI_HD void sphere_sphere(const Gains &P, V3 pa, float ra, V3 pb, float rb, const SV &vA, const SV &vB, PairAcc &acc) {
+    const V3 d = pa - pb;
+    const float dist2 = dot(d, d), rs = ra + rb;
+    if (dist2 >= rs * rs) return;
+    V3 n = {0.f, 0.f, 1.f};
+    float dist = 0.f;
+    if (dist2 > 1e-12f) {
+        dist = fsqrt(dist2);
+        n = frcp(dist) * d;
+    }
+    const float depth = rs - dist;
+    contact_point(P, pb + (rb - 0.5f * depth) * n, n, depth, vA, vB, acc);
+}
+
 constexpr int kDealtBroadPhaseMin = 16;  // candidate pairs above which the quad kernels deal the broad phase over the lanes
 // larger trees only: on the pushing scene (2-body tree, 11 pairs that are mostly near each other) the dealt pass is pure
 // overhead - measured +8 % on the octet kernel at equal state (1.386 -> 1.494 ms), as it was on the quad kernel
@@ -1117,6 +1134,7 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
             } else if (sp.sub == 0) {
                 if (typeA == 1 && typeB == 0) sphere_in_box(P, wa.p, hA[0], wb, hB, 1.f, wa.v, wb.v, out);
                 else if (typeA == 0 && typeB == 1) sphere_in_box(P, wb.p, hB[0], wa, hA, -1.f, wa.v, wb.v, out);
+                else if (typeA == 1 && typeB == 1) sphere_sphere(P, wa.p, hA[0], wb.p, hB[0], wa.v, wb.v, out);
             }
         };
         MPPI_SEC(13);  // contact law, velocities

@@ -283,11 +283,6 @@ class Scene:
                     # modelling decision: wheels and casters are rim contacts against the ground plane only
                     self.dropped_pairs.append(names)
                     continue
-                if kinds == {capi.SHAPE_SPHERE}:
-                    # no sphere-sphere narrow phase in the kernels (no such pair in the shipped scenes): refuse the scene
-                    # instead of letting two spheres pass through each other silently
-                    raise NotImplementedError(f"sphere-sphere contact ({names[0]} / {names[1]}) is not implemented; set "
-                                              "`collision: false` or `fixed: true` on one of the two actors")
                 pairs.append((i, j))
         if not pairs:
             return [], []  # nothing can come into contact with anything that reacts

@@ -560,6 +560,21 @@ static void sphere_in_box(int mode, real mu, real k, real cn, real ct, real kh, 
     contact_point(mode, mu, k, cn, ct, kh, pw, n, depth, vA, vB, acc);
 }
 
+/* two spheres: normal along the line of centres (from B to A), contact point in the middle of the overlap; coincident centres
+ * push apart along +z.  (The plannerbenchmark adapters add sphere obstacles next to sphere-shaped robot links,
+ * benchmarks/panda_arm/mppi_planner/mppi_planner_wrapper.py:58-79.) */
+static void sphere_sphere(int mode, real mu, real k, real cn, real ct, real kh, const real *pa, real ra, const real *pb, real rb,
+                          const real *vA, const real *vB, pair_acc_t *acc) {
+    real d[3] = {pa[0] - pb[0], pa[1] - pb[1], pa[2] - pb[2]};
+    real dist2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2], rs = ra + rb;
+    if (dist2 >= rs * rs) return;
+    real n[3] = {0, 0, 1}, dist = 0;
+    if (dist2 > (real)1e-12) { dist = (real)sqrt((double)dist2); for (int j = 0; j < 3; j++) n[j] = d[j] / dist; }
+    real depth = rs - dist, pw[3];
+    for (int j = 0; j < 3; j++) pw[j] = pb[j] + n[j] * (rb - (real)0.5 * depth);
+    contact_point(mode, mu, k, cn, ct, kh, pw, n, depth, vA, vB, acc);
+}
+
 /* dynamic frame index of a shape (-1: static), and the mass that scales its contact gains */
 static int shape_entity(const mppi_model_t *m, const scene_info_t *si, const mppi_shape_t *S, real *mass) {
     *mass = -1;
@@ -638,6 +653,8 @@ static void scene_contacts(const mppi_model_t *m, const scene_info_t *si, frame_
                 sphere_in_box(mode, mu, k, cn, ct, kh, wa.p, (real)A->size[0], &wb, B->size, 1, wa.v, wb.v, &acc);
             } else if (A->type == MPPI_SHAPE_BOX && B->type == MPPI_SHAPE_SPHERE) {
                 sphere_in_box(mode, mu, k, cn, ct, kh, wb.p, (real)B->size[0], &wa, A->size, -1, wa.v, wb.v, &acc);
+            } else if (A->type == MPPI_SHAPE_SPHERE && B->type == MPPI_SHAPE_SPHERE) {
+                sphere_sphere(mode, mu, k, cn, ct, kh, wa.p, (real)A->size[0], wb.p, (real)B->size[0], wa.v, wb.v, &acc);
             }
         }
         if (!acc.any) continue;

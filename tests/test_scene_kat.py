@@ -351,3 +351,57 @@ def test_floating_tree_conserves_momentum_without_external_forces(oracle64):
     assert p2 < 2e-3 and l2 < 3e-3, drift                                   # measured: 6.6e-4 / 1.2e-3 at h = 25 ms
     assert 0.45 * p2 < p4 < 0.55 * p2 and 0.45 * p4 < p8 < 0.55 * p4, drift   # first order in h: halves with the step
     assert 0.45 * l2 < l4 < 0.55 * l2 and 0.45 * l4 < l8 < 0.55 * l4, drift
+
+
+# ---------------------------------------------------------------- sphere against sphere
+def _ball_scene(offset_x=0.0):
+    """a fixed-base point robot (irrelevant here), a FIXED ball of radius 0.1 resting on the ground and a FREE 1-kg ball of the
+    same radius dropped onto it - the sphere obstacles of the plannerbenchmark adapters against sphere-shaped bodies
+    (reference benchmarks/panda_arm/mppi_planner/mppi_planner_wrapper.py:58-79)"""
+    import copy
+    from mppiisaac.planner.isaacgym_wrapper import Scene
+    from mppiisaac.utils.config_store import load_config
+    from mppiisaac.utils.isaacgym_utils import load_actor_cfgs, load_asset
+    env = load_actor_cfgs(["point_robot", "goal", "goal"])
+    fixed, free = env[1], copy.deepcopy(env[2])
+    fixed.name, fixed.collision, fixed.fixed, fixed.size, fixed.init_pos = "ball_fixed", True, True, [0.1], [1.0, 1.0, 0.1]
+    free.name, free.collision, free.fixed, free.gravity, free.mass, free.size = "ball_free", True, False, True, 1.0, [0.1]
+    free.init_pos = [1.0 + offset_x, 1.0, 0.35]
+    env = [env[0], fixed, free]
+    scene = Scene(env, load_config({"defaults": [{"isaacgym": "normal"}]}).isaacgym, [load_asset(env[0])])
+    return scene, scene.to_c()
+
+
+def test_sphere_rests_on_sphere(oracle64):
+    scene, m = _ball_scene()
+    pairs = {(m.pairs[i].a, m.pairs[i].b) for i in range(m.n_pairs)}
+    balls = [i for i in range(m.n_shapes) if m.shapes[i].actor in (1, 2)]
+    assert (balls[0], balls[1]) in pairs                                     # the sphere-sphere pair exists (it used to be refused)
+    dof, root = scene.initial_state()
+    q, qd, r = dof[0::2].astype(float), dof[1::2].astype(float), root.astype(float)
+    for _ in range(30):
+        r, q, qd, cf = oracle64.scene_step(m, r, q, qd, np.zeros(scene.n_dof))
+    d0 = 9.8 * 0.025 ** 2 / 0.8                                              # static sag of a one-point contact (DESIGN.md 3)
+    assert r[2, 2] == pytest.approx(0.3 - d0, abs=1e-6) and np.abs(r[2, 7:10]).max() < 1e-6
+    assert cf[scene.rigid_body_index("ball_free", "sphere"), 2] == pytest.approx(9.8, rel=1e-6)
+    assert cf[scene.rigid_body_index("ball_fixed", "sphere"), 2] == pytest.approx(-9.8, rel=1e-6)
+
+
+def test_sphere_rolls_off_sphere_device_arithmetic_matches_oracle(hostemu, oracle64):
+    """dropped 3 cm off centre the ball slides / rolls down the other one and lands on the ground; the host build of the device
+    code follows the oracle step by step"""
+    scene, m = _ball_scene(offset_x=0.03)
+    dof, root = scene.initial_state()
+    q, qd, r = dof[0::2].astype(float), dof[1::2].astype(float), root.astype(float)
+    rb = np.zeros((m.n_rb, 13), np.float32)
+    cfe = np.zeros((m.n_rb, 3), np.float32)
+    for i in range(40):                     # (re-synchronised every step, as in test_device_arithmetic_matches_oracle_stepwise)
+        de = np.zeros(2 * scene.n_dof, np.float32)
+        de[0::2], de[1::2] = q, qd
+        re = f32(r).copy()
+        assert hostemu.emu_scene_step(C.byref(m), fp(de), fp(re.reshape(-1)), fp(f32(np.zeros(scene.nu))), fp(rb), fp(cfe)) == 0
+        r, q, qd, cf = oracle64.scene_step(m, r, q, qd, oracle64.cmd_map(m, np.zeros(scene.nu)))
+        np.testing.assert_allclose(re[:, 0:7], r[:, 0:7], atol=2e-5)
+        np.testing.assert_allclose(re[:, 7:13], r[:, 7:13], atol=2e-3)
+        np.testing.assert_allclose(cfe, cf, atol=5e-3 * max(1.0, np.abs(cf).max()))
+    assert r[2, 0] > 1.15 and r[2, 2] < 0.1                                   # it has left the top and sits on the ground
