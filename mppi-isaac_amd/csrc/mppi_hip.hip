@@ -225,6 +225,7 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
                 c->launch_materialise_traj = e->materialise_scene_traj;
             }
             c->launch_sim_step = c->quad ? e->sim_step_scene_quad : e->sim_step_scene;  // (the K = 1 world included: one quad)
+            c->step_feeds_back = c->quad;
             c->launch_materialise = e->materialise_scene;
             // (large scenes - e.g. the 12-DoF mobile manipulator with table and block - do not fit the one-lane kernels' 64 rows
             // per wavefront into 160 KiB: those kernels are then simply not available, MPPI_ROLLOUT=lane is refused below)
@@ -650,9 +651,17 @@ int mppi_update_step_world(mppi_ctx_t *c, const float *records_dev, int n_record
     CTX_TRY(world);
     if (world->K != 1 || world->n != c->n || world->A != c->A || world->device != c->device)
         return fail(MPPI_EINVAL, "world must be a K=1 context of the same scene on the same device");
-    if (c->launch_combine_world == nullptr || c->scene || world->scene) {  // contact scenes: three launches
+    if (c->launch_combine_world == nullptr || c->scene || world->scene) {  // contact scenes
         int rc;
         if ((rc = mppi_update(c, records_dev, n_records))) return rc;
+        if (world->scene && world->step_feeds_back && world->K == 1) {
+            // TWO launches: combine + update, then the world's step kernel, which writes the planner's next start state itself
+            world->fb_dof = c->d_x0_dof;
+            world->fb_root = c->d_x0_root;
+            world->launch_sim_step(world, 1, 0, c->d_action);
+            world->fb_dof = world->fb_root = nullptr;
+            return launch_check();
+        }
         if ((rc = mppi_world_step_from(world, c))) return rc;
         return mppi_set_state_from_world(c, world);
     }

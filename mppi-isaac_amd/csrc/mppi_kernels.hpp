@@ -869,7 +869,11 @@ __global__ __launch_bounds__(kWave) void k_sim_step_scene_quad(const DevModel *_
                                                                const float *__restrict__ u_ext, const float *__restrict__ x0_root,
                                                                const float *__restrict__ U, const float *__restrict__ eps, const float *__restrict__ prior,
                                                                float *__restrict__ du, float *__restrict__ ctrl, float *__restrict__ q_, float *__restrict__ qd_,
-                                                               float *__restrict__ base_, float *__restrict__ fr_, float *__restrict__ cf_) {
+                                                               float *__restrict__ base_, float *__restrict__ fr_, float *__restrict__ cf_,
+                                                               float *__restrict__ fb_dof = nullptr, float *__restrict__ fb_root = nullptr) {
+    // fb_dof / fb_root (K = 1 world of a closed loop): the stepped state goes straight into the PLANNER's next start state
+    // (x0_dof [2n] interleaved, x0_root [A][13]) - what k_state_from_world, a device-to-device copy and k_root_from_world did
+    // in three more launches behind this one
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NB = T::NB;
@@ -933,6 +937,18 @@ __global__ __launch_bounds__(kWave) void k_sim_step_scene_quad(const DevModel *_
         for (int f = 0; f < kMaxFree; f++)
             for (int j = 0; j < 13; j++) fr_[(size_t)(f * 13 + j) * K + k] = s.fr[f][j];
         for (int j = 0; j < 3 * M.n_rb; j++) cf_[(size_t)j * K + k] = L[SceneLayout<T>::kCf + j];
+        if (fb_dof != nullptr && k == 0) {
+            static_for<0, NB>([&](auto ic) {
+                constexpr int i = ic;
+                fb_dof[2 * i] = s.q[i];
+                fb_dof[2 * i + 1] = s.qd[i];
+            });
+            for (int j = 0; j < 13 * M.n_actors; j++) fb_root[j] = x0_root[j];   // static actors: as the world holds them
+            for (int j = 0; j < 13; j++) fb_root[13 * M.robot_actor + j] = s.base[j];
+            for (int f = 0; f < kMaxFree; f++)
+                if (f < M.n_free)
+                    for (int j = 0; j < 13; j++) fb_root[13 * M.fr[f].actor + j] = s.fr[f][j];
+        }
     }
 #endif
 }
@@ -1317,6 +1333,9 @@ struct mppi_ctx {
     void (*launch_materialise)(mppi_ctx *, float *, float *, float *, float *) = nullptr;
     void (*launch_combine_world)(mppi_ctx *, const float *, int, mppi_ctx *) = nullptr;  // fused closed-loop tail (quad scenes)
     std::string topo;
+    // closed loop: where the K = 1 world's step kernel writes the planner's next start state (mppi_update_step_world; null otherwise)
+    float *fb_dof = nullptr, *fb_root = nullptr;
+    bool step_feeds_back = false;  // the context's step kernel honours fb_dof / fb_root (the quad step kernel of contact scenes)
     // direct exchange of the shard records (mppi_mailbox_*): this rank's inbox, the peers' inboxes, the gathered records
     void *d_inbox = nullptr;
     void **d_peers = nullptr;
@@ -1415,7 +1434,8 @@ void launch_sim_step_scene_t(mppi_ctx *c, int mode, int t, const float *u_ext) {
 template <class T>
 void launch_sim_step_scene_quad_t(mppi_ctx *c, int mode, int t, const float *u_ext) {
     hipLaunchKernelGGL(k_sim_step_scene_quad<T>, dim3((c->K + 15) / 16), dim3(kWave), c->lds_bytes_quad, c->stream, c->d_model, c->d_cfg, mode, t, u_ext,
-                       c->d_x0_root, c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_ctrl, c->d_q, c->d_qd, c->d_base, c->d_fr, c->d_cf);
+                       c->d_x0_root, c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_ctrl, c->d_q, c->d_qd, c->d_base, c->d_fr, c->d_cf,
+                       c->K == 1 ? c->fb_dof : nullptr, c->K == 1 ? c->fb_root : nullptr);
 }
 template <class T>
 void launch_materialise_scene_t(mppi_ctx *c, float *dof, float *root, float *rb, float *cf) {
