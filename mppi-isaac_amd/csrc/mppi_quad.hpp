@@ -115,8 +115,131 @@ struct QAI {  // symmetric 6x6 [[I,H],[H^T,M]], ROTATED rows: x[j] = X[r][(r+j)%
     QF I[3], H[3], Ht[3], M[3];
 };
 
+
+// ---- rotations folded into the multiply-adds (device only) -----------------------------------------------------------------
+// The quad layout's matrix products multiply ROTATED copies of a distributed vector.  The compiler folds a quad_perm into a
+// multiply or an add (v_mul_f32_dpp, v_add_f32_dpp) but never into a fused multiply-add: at the time its DPP combiner runs the
+// operation is still the three-address v_fma_f32, which has no DPP form on gfx9; it becomes the two-address v_fmac_f32 (which
+// has one) only after register allocation.  So every rotated operand of an FMA chain cost a v_mov_b32_dpp of its own - 450 of
+// the 3 414 vector instructions of one horizon step of k_rollout_quad (ISA listing), on a kernel that is bound by exactly that
+// count.  These blocks issue v_fmac_f32_dpp themselves.  Hazard: a DPP operand must not have been written by the two preceding
+// VALU instructions (the compiler pads its own with s_nop and does not look into inline assembly): every block starts with at
+// least two plain instructions and only ever reads its INPUTS through DPP, so no padding is needed.
+// Same arithmetic as the C++ forms below them up to the association of the sums (last-bit differences).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MPPI_NO_DPP_FMAC)
+#define MPPI_DPP_FMAC 1
+#define MPPI_R1 "quad_perm:[1,2,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+#define MPPI_R2 "quad_perm:[2,0,1,2] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+__device__ __forceinline__ QSV qmul_fused(const QF *I, const QF *H, const QF *Ht, const QF *M, QF xa, QF xl) {
+    QF ya, yl;
+    asm("v_mul_f32 %0, %2, %14\n\t"                 // ya  = I0 xa
+        "v_mul_f32 %1, %8, %14\n\t"                 // yl  = Ht0 xa
+        "v_fmac_f32_dpp %0, %14, %3 " MPPI_R1 "\n\t"   // ya += rot1(xa) I1
+        "v_fmac_f32_dpp %1, %14, %9 " MPPI_R1 "\n\t"   // yl += rot1(xa) Ht1
+        "v_fmac_f32_dpp %0, %14, %4 " MPPI_R2 "\n\t"   // ya += rot2(xa) I2
+        "v_fmac_f32_dpp %1, %14, %10 " MPPI_R2 "\n\t"  // yl += rot2(xa) Ht2
+        "v_fmac_f32 %0, %5, %15\n\t"                // ya += H0 xl
+        "v_fmac_f32 %1, %11, %15\n\t"               // yl += M0 xl
+        "v_fmac_f32_dpp %0, %15, %6 " MPPI_R1 "\n\t"   // ya += rot1(xl) H1
+        "v_fmac_f32_dpp %1, %15, %12 " MPPI_R1 "\n\t"  // yl += rot1(xl) M1
+        "v_fmac_f32_dpp %0, %15, %7 " MPPI_R2 "\n\t"   // ya += rot2(xl) H2
+        "v_fmac_f32_dpp %1, %15, %13 " MPPI_R2         // yl += rot2(xl) M2
+        : "=&v"(ya), "=&v"(yl)
+        : "v"(I[0]), "v"(I[1]), "v"(I[2]), "v"(H[0]), "v"(H[1]), "v"(H[2]), "v"(Ht[0]), "v"(Ht[1]), "v"(Ht[2]), "v"(M[0]), "v"(M[1]), "v"(M[2]),
+          "v"(xa), "v"(xl));
+    return QSV{ya, yl};
+}
+// X[j] += s * rot_j(y) for one rotated-row block, j = 0, 1, 2 (the rank-one update of the articulated inertia: s = -u_r / d)
+__device__ __forceinline__ void qrank1_fused(QF *Ia, QF *Ha, QF *Hta, QF *Ma, QF sn, QF sf, QF ua, QF ul) {
+    asm("v_fmac_f32 %0, %12, %14\n\t"                // I0  += sn ua
+        "v_fmac_f32 %3, %12, %15\n\t"                // H0  += sn ul
+        "v_fmac_f32 %6, %13, %14\n\t"                // Ht0 += sf ua
+        "v_fmac_f32 %9, %13, %15\n\t"                // M0  += sf ul
+        "v_fmac_f32_dpp %1, %14, %12 " MPPI_R1 "\n\t"   // I1  += rot1(ua) sn
+        "v_fmac_f32_dpp %2, %14, %12 " MPPI_R2 "\n\t"   // I2  += rot2(ua) sn
+        "v_fmac_f32_dpp %4, %15, %12 " MPPI_R1 "\n\t"   // H1  += rot1(ul) sn
+        "v_fmac_f32_dpp %5, %15, %12 " MPPI_R2 "\n\t"   // H2  += rot2(ul) sn
+        "v_fmac_f32_dpp %7, %14, %13 " MPPI_R1 "\n\t"   // Ht1 += rot1(ua) sf
+        "v_fmac_f32_dpp %8, %14, %13 " MPPI_R2 "\n\t"   // Ht2 += rot2(ua) sf
+        "v_fmac_f32_dpp %10, %15, %13 " MPPI_R1 "\n\t"  // M1  += rot1(ul) sf
+        "v_fmac_f32_dpp %11, %15, %13 " MPPI_R2         // M2  += rot2(ul) sf
+        : "+v"(Ia[0]), "+v"(Ia[1]), "+v"(Ia[2]), "+v"(Ha[0]), "+v"(Ha[1]), "+v"(Ha[2]), "+v"(Hta[0]), "+v"(Hta[1]), "+v"(Hta[2]), "+v"(Ma[0]),
+          "+v"(Ma[1]), "+v"(Ma[2])
+        : "v"(sn), "v"(sf), "v"(ua), "v"(ul));
+}
+// rotated rows of R Ic R^T - h cw^T:  X_j = Tr0 rot_j(R0) + Tr1 rot_j(R1) + Tr2 rot_j(R2) + nh rot_j(cw); j = 0 comes without
+// its h cw term (the caller adds the diagonal's |h|^2/m - h cw), which also gives the block its three plain leading instructions
+__device__ __forceinline__ void qinertia_rows_fused(const QF *Tr, const QF *Rc, QF nh, QF cw, QF &I0, QF &I1, QF &I2) {
+    QF x0, x1, x2;
+    asm("v_mul_f32 %0, %3, %6\n\t"                      // x0  = Tr0 R0
+        "v_fmac_f32 %0, %4, %7\n\t"                     // x0 += Tr1 R1
+        "v_fmac_f32 %0, %5, %8\n\t"                     // x0 += Tr2 R2
+        "v_mul_f32_dpp %1, %6, %3 " MPPI_R1 "\n\t"      // x1  = rot1(R0) Tr0
+        "v_mul_f32_dpp %2, %6, %3 " MPPI_R2 "\n\t"      // x2  = rot2(R0) Tr0
+        "v_fmac_f32_dpp %1, %7, %4 " MPPI_R1 "\n\t"
+        "v_fmac_f32_dpp %2, %7, %4 " MPPI_R2 "\n\t"
+        "v_fmac_f32_dpp %1, %8, %5 " MPPI_R1 "\n\t"
+        "v_fmac_f32_dpp %2, %8, %5 " MPPI_R2 "\n\t"
+        "v_fmac_f32_dpp %1, %10, %9 " MPPI_R1 "\n\t"    // x1 += rot1(cw) nh
+        "v_fmac_f32_dpp %2, %10, %9 " MPPI_R2
+        : "=&v"(x0), "=&v"(x1), "=&v"(x2)
+        : "v"(Tr[0]), "v"(Tr[1]), "v"(Tr[2]), "v"(Rc[0]), "v"(Rc[1]), "v"(Rc[2]), "v"(nh), "v"(cw));
+    I0 = x0;
+    I1 = x1;
+    I2 = x2;
+}
+// v = v_parent + S qd and the velocity-product bias c = v_parent x (S qd) of one joint (pass 1 of the articulated-body solve):
+// cross products as  rot1(a rot1(b) - rot1(a) b), the two of c.l summed before their common rotation
+__device__ __forceinline__ void qvel_bias_fused(QF vpa, QF vpl, QF Sa, QF Sl, QF qd, QF &va, QF &vl, QF &cba, QF &cbl) {
+    QF sja, sjl, ta, tl;
+    asm("v_mul_f32 %4, %12, %10\n\t"                    //  1 sja = qd Sa
+        "v_mul_f32 %5, %12, %11\n\t"                    //  2 sjl = qd Sl
+        "v_add_f32 %0, %8, %4\n\t"                      //  3 va  = vpa + sja
+        "v_mul_f32_dpp %6, %4, %8 " MPPI_R1 "\n\t"      //  4 ta  = rot1(sja) vpa
+        "v_fmac_f32_dpp %6, %8, -%4 " MPPI_R1 "\n\t"    //  5 ta -= rot1(vpa) sja
+        "v_mul_f32_dpp %7, %5, %8 " MPPI_R1 "\n\t"      //  6 tl  = rot1(sjl) vpa
+        "v_fmac_f32_dpp %7, %8, -%5 " MPPI_R1 "\n\t"    //  7 tl -= rot1(vpa) sjl
+        "v_fmac_f32_dpp %7, %4, %9 " MPPI_R1 "\n\t"     //  8 tl += rot1(sja) vpl
+        "v_fmac_f32_dpp %7, %9, -%4 " MPPI_R1 "\n\t"    //  9 tl -= rot1(vpl) sja
+        "v_mov_b32_dpp %2, %6 " MPPI_R1 "\n\t"          // 10 cba = rot1(ta)      (ta written at 5)
+        "v_add_f32 %1, %9, %5\n\t"                      // 11 vl  = vpl + sjl
+        "v_mov_b32_dpp %3, %7 " MPPI_R1                 // 12 cbl = rot1(tl)      (tl written at 9)
+        : "=&v"(va), "=&v"(vl), "=&v"(cba), "=&v"(cbl), "=&v"(sja), "=&v"(sjl), "=&v"(ta), "=&v"(tl)
+        : "v"(vpa), "v"(vpl), "v"(Sa), "v"(Sl), "v"(qd));
+}
+// velocity-product force of a rigid body about the world origin, pA = v x* (I v):
+//   n = I w + h x vl,  f = m vl + w x h,  pA = (w x n + vl x f, w x f)      (I in rotated rows I0, I1, I2; h = m c)
+__device__ __forceinline__ void qbias_force_fused(QF I0, QF I1, QF I2, QF h, QF m, QF w, QF vl, QF &pAa, QF &pAl) {
+    QF n, f, t1, t2, t3, t4;
+    asm("v_mul_f32 %2, %8, %13\n\t"                     //  1 n   = I0 w
+        "v_mul_f32 %3, %12, %14\n\t"                    //  2 f   = m vl
+        "v_mul_f32_dpp %4, %14, %11 " MPPI_R1 "\n\t"    //  3 t1  = rot1(vl) h
+        "v_fmac_f32_dpp %4, %11, -%14 " MPPI_R1 "\n\t"  //  4 t1 -= rot1(h) vl        t1 = (h x vl) before its rotation
+        "v_mul_f32_dpp %5, %11, %13 " MPPI_R1 "\n\t"    //  5 t2  = rot1(h) w
+        "v_fmac_f32_dpp %5, %13, -%11 " MPPI_R1 "\n\t"  //  6 t2 -= rot1(w) h         t2 = (w x h) before its rotation
+        "v_fmac_f32_dpp %2, %13, %9 " MPPI_R1 "\n\t"    //  7 n  += rot1(w) I1
+        "v_fmac_f32_dpp %2, %13, %10 " MPPI_R2 "\n\t"   //  8 n  += rot2(w) I2
+        "v_add_f32_dpp %2, %4, %2 " MPPI_R1 "\n\t"      //  9 n  += rot1(t1)          (t1 written at 4)
+        "v_add_f32_dpp %3, %5, %3 " MPPI_R1 "\n\t"      // 10 f  += rot1(t2)          (t2 written at 6)
+        "v_mul_f32_dpp %6, %13, -%2 " MPPI_R1 "\n\t"    // 11 t3  = -rot1(w) n
+        "v_mul_f32_dpp %7, %13, -%3 " MPPI_R1 "\n\t"    // 12 t4  = -rot1(w) f
+        "v_fmac_f32_dpp %6, %2, %13 " MPPI_R1 "\n\t"    // 13 t3 += rot1(n) w         (n written at 9)
+        "v_fmac_f32_dpp %7, %3, %13 " MPPI_R1 "\n\t"    // 14 t4 += rot1(f) w         (f written at 10)
+        "v_fmac_f32_dpp %6, %3, %14 " MPPI_R1 "\n\t"    // 15 t3 += rot1(f) vl
+        "v_fmac_f32_dpp %6, %14, -%3 " MPPI_R1 "\n\t"   // 16 t3 -= rot1(vl) f
+        "v_mov_b32_dpp %1, %7 " MPPI_R1 "\n\t"          // 17 pAl = rot1(t4)          (t4 written at 14)
+        "s_nop 0\n\t"                                   //    (t3 written at 16: one more wait state)
+        "v_mov_b32_dpp %0, %6 " MPPI_R1                 // 18 pAa = rot1(t3)
+        : "=&v"(pAa), "=&v"(pAl), "=&v"(n), "=&v"(f), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4)
+        : "v"(I0), "v"(I1), "v"(I2), "v"(h), "v"(m), "v"(w), "v"(vl));
+}
+#endif
+
 // y = A x for the 6x6: rotated rows meet rotated copies of the distributed vector
 MPPI_HD QSV qmul(const QAI &A, const QSV &x) {
+#if defined(MPPI_DPP_FMAC)
+    return qmul_fused(A.I, A.H, A.Ht, A.M, x.a, x.l);
+#endif
     const QF a1 = rot1(x.a), a2 = rot2(x.a), l1 = rot1(x.l), l2 = rot2(x.l);
     QSV y;
     y.a = A.I[0] * x.a + A.I[1] * a1 + A.I[2] * a2 + A.H[0] * x.l + A.H[1] * l1 + A.H[2] * l2;
@@ -207,8 +330,12 @@ MPPI_HD void quad_aba(M &m, const QPose<T, JT> &P, const QF *qd, const QF *tau_e
             cb[i] = {zero, zero};
         } else {
             const QSV vp = v[par < 0 ? 0 : par];
+#if defined(MPPI_DPP_FMAC)
+            qvel_bias_fused(vp.a, vp.l, S.a, S.l, qd[i], v[i].a, v[i].l, cb[i].a, cb[i].l);
+#else
             v[i] = {vp.a + sj.a, vp.l + sj.l};
             cb[i] = {qcross(vp.a, sj.a), qcross(vp.a, sj.l) + qcross(vp.l, sj.a)};
+#endif
         }
         has_acc[i] = false;
     });
@@ -231,17 +358,27 @@ MPPI_HD void quad_aba(M &m, const QPose<T, JT> &P, const QF *qd, const QF *tau_e
         const QF hh = qsum(h * cw);
         const QF h1 = rot1(h), h2 = rot2(h);
         QAI A;
+#if defined(MPPI_DPP_FMAC)
+        qinertia_rows_fused(Tr, R.c, -h, cw, A.I[0], A.I[1], A.I[2]);
+        A.I[0] += hh - h * cw;
+#else
         A.I[0] = Tr[0] * R.c[0] + Tr[1] * R.c[1] + Tr[2] * R.c[2] + hh - h * cw;
         A.I[1] = Tr[0] * rot1(R.c[0]) + Tr[1] * rot1(R.c[1]) + Tr[2] * rot1(R.c[2]) - h * rot1(cw);
         A.I[2] = Tr[0] * rot2(R.c[0]) + Tr[1] * rot2(R.c[1]) + Tr[2] * rot2(R.c[2]) - h * rot2(cw);
+#endif
         A.H[0] = qrep(0.f); A.H[1] = -h2;       A.H[2] = h1;        // skew(h), rotated rows
         A.Ht[0] = A.H[0];  A.Ht[1] = h2;       A.Ht[2] = -h1;      // skew(h)^T = -skew(h)
         A.M[0] = qrep(b.m); A.M[1] = A.H[0];   A.M[2] = A.H[0];
         // bias force v x* (I v)
         const QF w = v[i].a, vl = v[i].l;
+#if defined(MPPI_DPP_FMAC)
+        QSV pA;
+        qbias_force_fused(A.I[0], A.I[1], A.I[2], h, qrep(b.m), w, vl, pA.a, pA.l);
+#else
         const QF n = A.I[0] * w + A.I[1] * rot1(w) + A.I[2] * rot2(w) + qcross(h, vl);
         const QF f = b.m * vl + qcross(w, h);
         QSV pA = {qcross(w, n) + qcross(vl, f), qcross(w, f)};
+#endif
         if (has_acc[i]) {
             for (int j = 0; j < 3; j++) { A.I[j] += acc[i].I[j]; A.H[j] += acc[i].H[j]; A.Ht[j] += acc[i].Ht[j]; A.M[j] += acc[i].M[j]; }
             pA = {pA.a + pacc[i].a, pA.l + pacc[i].l};
@@ -256,12 +393,17 @@ MPPI_HD void quad_aba(M &m, const QPose<T, JT> &P, const QF *qd, const QF *tau_e
             const QF k = (u[i] - qdot6(U[i], c)) * invd[i];
             const QSV pa = {pA.a + Ac.a + k * U[i].a, pA.l + Ac.l + k * U[i].l};
             // Ia = IA - U U^T / d  (rotated rows: X[r][(r+j)%3] -= x_r * rot_j(y))
+#if defined(MPPI_DPP_FMAC)
+            const QF ninvd = -invd[i];
+            qrank1_fused(A.I, A.H, A.Ht, A.M, U[i].a * ninvd, U[i].l * ninvd, U[i].a, U[i].l);
+#else
             const QF un = U[i].a * invd[i], uf = U[i].l * invd[i];
             const QF n1 = rot1(U[i].a), n2 = rot2(U[i].a), f1 = rot1(U[i].l), f2 = rot2(U[i].l);
             A.I[0] -= un * U[i].a; A.I[1] -= un * n1; A.I[2] -= un * n2;
             A.H[0] -= un * U[i].l; A.H[1] -= un * f1; A.H[2] -= un * f2;
             A.Ht[0] -= uf * U[i].a; A.Ht[1] -= uf * n1; A.Ht[2] -= uf * n2;
             A.M[0] -= uf * U[i].l; A.M[1] -= uf * f1; A.M[2] -= uf * f2;
+#endif
             constexpr int pj = par < 0 ? 0 : par;
             if (has_acc[pj]) {
                 for (int j = 0; j < 3; j++) { acc[pj].I[j] += A.I[j]; acc[pj].H[j] += A.H[j]; acc[pj].Ht[j] += A.Ht[j]; acc[pj].M[j] += A.M[j]; }

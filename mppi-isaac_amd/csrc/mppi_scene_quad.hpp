@@ -97,16 +97,25 @@ MPPI_HD void qrigid_world(const QM3 &R, QF p, float mass, const F *hb, const F *
     const QF cw = invm * h;
     const QF hh = qsum(h * cw);
     const QF h1 = rot1(h), h2 = rot2(h);
+#if defined(MPPI_DPP_FMAC)
+    qinertia_rows_fused(Tr, R.c, -h, cw, A.I[0], A.I[1], A.I[2]);   // (rotations folded into the multiply-adds, mppi_quad.hpp)
+    A.I[0] += hh - h * cw;
+#else
     A.I[0] = Tr[0] * R.c[0] + Tr[1] * R.c[1] + Tr[2] * R.c[2] + hh - h * cw;
     A.I[1] = Tr[0] * rot1(R.c[0]) + Tr[1] * rot1(R.c[1]) + Tr[2] * rot1(R.c[2]) - h * rot1(cw);
     A.I[2] = Tr[0] * rot2(R.c[0]) + Tr[1] * rot2(R.c[1]) + Tr[2] * rot2(R.c[2]) - h * rot2(cw);
+#endif
     A.H[0] = qrep(0.f); A.H[1] = -h2;     A.H[2] = h1;   // skew(h), rotated rows
     A.Ht[0] = A.H[0];  A.Ht[1] = h2;      A.Ht[2] = -h1;
     A.M[0] = qrep(mass); A.M[1] = A.H[0]; A.M[2] = A.H[0];
     const QF w = v.a, vl = v.l;
+#if defined(MPPI_DPP_FMAC)
+    qbias_force_fused(A.I[0], A.I[1], A.I[2], h, qrep(mass), w, vl, pA.a, pA.l);
+#else
     const QF n = A.I[0] * w + A.I[1] * rot1(w) + A.I[2] * rot2(w) + qcross(h, vl);
     const QF f = mass * vl + qcross(w, h);
     pA = {qcross(w, n) + qcross(vl, f), qcross(w, f)};
+#endif
 }
 
 // gravity, contact wrench and implicit contact damping of one frame: (IA + h C) a + (pA + C v - f - f_g) = 0
@@ -159,8 +168,12 @@ MPPI_HD void quad_aba_prepare(M &m, const QPose<T> &P, const QSV &vbase, const Q
         W.Sl[i] = S.l;
         const QSV sj = {qd[i] * S.a, qd[i] * S.l};
         const QSV vp = par < 0 ? vbase : v[par < 0 ? 0 : par];
+#if defined(MPPI_DPP_FMAC)
+        qvel_bias_fused(vp.a, vp.l, S.a, S.l, qd[i], v[i].a, v[i].l, W.cb[i].a, W.cb[i].l);
+#else
         v[i] = {vp.a + sj.a, vp.l + sj.l};
         W.cb[i] = {qcross(vp.a, sj.a), qcross(vp.a, sj.l) + qcross(vp.l, sj.a)};
+#endif
     });
     BodyK1 blk[NBs];
     static_rfor<0, NB>([&](auto ic) MPPI_LAMBDA { blk[ic] = load_block<BodyK1>(m.b[ic].k1); });
@@ -209,12 +222,17 @@ MPPI_HD void quad_aba_solve(M &m, const QPose<T> &P, const QAbaPrep<T> &W, const
             const QSV Ac = qmul(A, c);
             const QF k = (u[i] - qdot6(U[i], c)) * invd[i];
             const QSV pa = {pA.a + Ac.a + k * U[i].a, pA.l + Ac.l + k * U[i].l};
+#if defined(MPPI_DPP_FMAC)
+            const QF ninvd = -invd[i];
+            qrank1_fused(A.I, A.H, A.Ht, A.M, U[i].a * ninvd, U[i].l * ninvd, U[i].a, U[i].l);
+#else
             const QF un = U[i].a * invd[i], uf = U[i].l * invd[i];
             const QF n1 = rot1(U[i].a), n2 = rot2(U[i].a), f1 = rot1(U[i].l), f2 = rot2(U[i].l);
             A.I[0] -= un * U[i].a; A.I[1] -= un * n1; A.I[2] -= un * n2;
             A.H[0] -= un * U[i].l; A.H[1] -= un * f1; A.H[2] -= un * f2;
             A.Ht[0] -= uf * U[i].a; A.Ht[1] -= uf * n1; A.Ht[2] -= uf * n2;
             A.M[0] -= uf * U[i].l; A.M[1] -= uf * f1; A.M[2] -= uf * f2;
+#endif
             if (has_acc[pj]) {
                 for (int j = 0; j < 3; j++) { acc[pj].I[j] += A.I[j]; acc[pj].H[j] += A.H[j]; acc[pj].Ht[j] += A.Ht[j]; acc[pj].M[j] += A.M[j]; }
                 pacc[pj] = {pacc[pj].a + pa.a, pacc[pj].l + pa.l};

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Static check of the gfx9 DPP hazard in AMDGPU assembly listings (hipcc -S): a VGPR read through a DPP lane permutation must
+not have been written by the previous two wait states (VALU instructions; `s_nop N` counts N + 1).  The compiler pads its own DPP
+instructions; the hand-written blocks of csrc/mppi_quad.hpp (rotations folded into v_fmac_f32_dpp) are invisible to its hazard
+recogniser, so their spacing is by construction - and verified here, over every instruction of the listing, whoever emitted it.
+    python tools/check_dpp_hazards.py file.s [...]      -> exit status 1 and the offending lines if a hazard is found
+    python tools/check_dpp_hazards.py --library libmppi_hip.so   -> the same over the disassembly of every gfx950 code object in the
+                                                                 library (llvm-objdump --offloading, then -d)"""
+import re
+import sys
+
+VREG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+
+
+def regs(tok):
+    out = set()
+    for m in VREG.finditer(tok):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def check(path):
+    bad = 0
+    recent = []   # [(wait states ago, set of vgprs written)]
+    for ln, line in enumerate(open(path, errors="replace"), 1):
+        code = line.split(";")[0].split("//")[0].strip()   # (hipcc -S comments with ';', llvm-objdump -d with '//')
+        if not code or code.endswith(":") or code.startswith("."):
+            if code.endswith(":"):
+                recent = []      # a label: control flow may come from anywhere - the compiler's own padding is trusted across blocks
+            continue
+        parts = code.split(None, 1)
+        op, rest = parts[0], (parts[1] if len(parts) > 1 else "")
+        if op == "s_nop":
+            n = int(rest.strip(), 0) + 1
+            recent = [(a + n, w) for a, w in recent if a + n <= 2]
+            continue
+        ops = [o.strip() for o in rest.split(",")]
+        if "_dpp" in op and len(ops) >= 2:
+            src0 = ops[1].split()[0].lstrip("-|")
+            for r in regs(src0):
+                for ago, written in recent:
+                    if ago < 2 and r in written:
+                        print(f"{path}:{ln}: DPP read of v{r} {ago} wait state(s) after its write: {code}")
+                        bad += 1
+        is_valu = op.startswith("v_")
+        if is_valu or not op.startswith("s_"):   # every non-scalar instruction advances the wait states
+            recent = [(a + 1, w) for a, w in recent if a + 1 <= 2]
+        elif op.startswith("s_"):
+            recent = [(a + 1, w) for a, w in recent if a + 1 <= 2]
+        if is_valu and ops and not op.startswith(("v_cmp", "v_cmpx", "v_readlane", "v_readfirstlane")):
+            recent.append((0, regs(ops[0])))
+    return bad
+
+
+def check_library(lib, objdump="/opt/rocm/lib/llvm/bin/llvm-objdump"):
+    """disassemble every gfx950 code object of a HIP shared library and check it; returns (hazards, dpp instructions seen)"""
+    import glob
+    import os
+    import shutil
+    import subprocess
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="dpp_check_")
+    try:
+        shutil.copy(lib, os.path.join(tmp, "lib.so"))
+        subprocess.run([objdump, "--offloading", "lib.so"], cwd=tmp, check=True, capture_output=True)
+        bad = seen = 0
+        for co in sorted(glob.glob(os.path.join(tmp, "lib.so.*gfx950"))):
+            dis = co + ".dis"
+            with open(dis, "w") as f:
+                subprocess.run([objdump, "-d", co], stdout=f, check=True)
+            seen += sum(1 for line in open(dis, errors="replace") if "_dpp" in line)
+            bad += check(dis)
+        return bad, seen
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--library":
+        total, seen = check_library(sys.argv[2])
+        print(f"{total} DPP hazard(s) among {seen} DPP instructions of {sys.argv[2]}")
+    else:
+        total = sum(check(p) for p in sys.argv[1:])
+        print(f"{total} DPP hazard(s) in {len(sys.argv) - 1} file(s)")
+    sys.exit(1 if total else 0)
