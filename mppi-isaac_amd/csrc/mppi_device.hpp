@@ -48,17 +48,29 @@ struct CmdBlock {
 // Three 64-byte blocks, each fetched with ONE s_load_dwordx16 where it is used (load_block below):
 // block 0 = kinematics, block 1 = inertia + limits, block 2 = command map row.
 struct BodyK0 {
-    float Rt[9];  // joint frame in parent body frame (child->parent), q = 0
-    float pt[3];
-    int jtype, parent, pad0[2];
+    // joint frame in the parent body's frame (child->parent) at q = 0 as ONE row-major 3x4 block [Rt | pt]: the quad layout's
+    // kinematics multiply register PAIRS (v_pk_fma_f32), and (Rt[r][0], Rt[r][1]) and (Rt[r][2], pt[r]) are such pairs as the
+    // block arrives from LDS (mppi_quad.hpp quad_fk)
+    float T[12];
+    int jtype, parent;
+    float lower, upper;  // joint range (-inf / +inf: none)
+    MPPI_HD float rt(int j) const { return T[4 * (j / 3) + j % 3]; }  // Rt[j], row-major 3x3
+    MPPI_HD float pt(int r) const { return T[4 * r + 3]; }
 };
 struct BodyK1 {
-    float m;
-    float hb[3];  // m * com, body frame
-    float Ic[6];  // inertia about the COM, body axes: xx xy xz yy yz zz
-    float lower, upper, effort, vmax;
-    int limited;
-    float invm;   // 1/m (0 for massless bodies)
+    // first moment hb = m * com and inertia about the COM Ic (xx xy xz yy yz zz), body axes, laid out as the constant PAIRS of
+    // the quad layout's packed products (mppi_quad.hpp quad_aba):  (h, Tr0) = c0 (hb0, Ic0) + c1 (hb1, Ic1) + c2 (hb2, Ic2) and
+    // (Tr1, Tr2) = c0 (Ic1, Ic2) + c1 (Ic3, Ic4) + c2 (Ic4, Ic5)  for the columns c of R;  hb() / Ic() read single entries
+    float hI[6];  // hb0 Ic0 | hb1 Ic1 | hb2 Ic2
+    float II[6];  // Ic1 Ic2 | Ic3 Ic4 | Ic4 Ic5
+    float m, invm;  // mass, 1/m (0 for massless bodies)
+    float effort, vmax;  // +inf: no limit
+    MPPI_HD float hb(int j) const { return hI[2 * j]; }
+    MPPI_HD float Ic(int k) const { return k < 3 ? hI[2 * k + 1] : (k == 3 ? II[2] : (k == 4 ? II[3] : II[5])); }
+    MPPI_HD void set(const float *hb3, const float *Ic6) {
+        for (int j = 0; j < 3; j++) { hI[2 * j] = hb3[j]; hI[2 * j + 1] = Ic6[j]; }
+        II[0] = Ic6[1]; II[1] = Ic6[2]; II[2] = Ic6[3]; II[3] = Ic6[4]; II[4] = Ic6[4]; II[5] = Ic6[5];
+    }
 };
 struct alignas(64) DevBody {
     BodyK0 k0;
@@ -555,8 +567,10 @@ MPPI_HD void forward_kinematics_base(M &m, const float *q, Pose<T> &P) {
         P.jt[i] = b.jtype;
         const M3 &Rp = par < 0 ? P.Rb : P.R[par < 0 ? 0 : par];
         const V3 pp = par < 0 ? P.pb : P.p[par < 0 ? 0 : par];
-        M3 RT = mul(Rp, load3(b.Rt));
-        V3 pw = pp + mul(Rp, loadv(b.pt));
+        M3 Rt0;
+        for (int j = 0; j < 9; j++) Rt0.a[j] = b.rt(j);
+        M3 RT = mul(Rp, Rt0);
+        V3 pw = pp + mul(Rp, V3{b.pt(0), b.pt(1), b.pt(2)});
         if (b.jtype == 0) {  // revolute about local z: R = RT * Rz(q)
             float s, c;
             fast_sincos(q[i], s, c);
@@ -614,13 +628,13 @@ MPPI_HD void aba_world(CModel &m, const Pose<T> &P, const float *qd, const float
         const M3 &R = P.R[i];
         SV S = joint_subspace<T, i>(m, P);
         // rigid inertia about the world origin: I_O = R Ic R^T + m(|cw|^2 1 - cw cw^T), h = m cw
-        V3 h = mul(R, loadv(b.hb)) + b.m * P.p[i];
+        V3 h = mul(R, V3{b.hb(0), b.hb(1), b.hb(2)}) + b.m * P.p[i];
         float T9[9];  // T = R * Ic
         for (int r = 0; r < 3; r++) {
             float r0 = R.a[3 * r], r1 = R.a[3 * r + 1], r2 = R.a[3 * r + 2];
-            T9[3 * r + 0] = r0 * b.Ic[0] + r1 * b.Ic[1] + r2 * b.Ic[2];
-            T9[3 * r + 1] = r0 * b.Ic[1] + r1 * b.Ic[3] + r2 * b.Ic[4];
-            T9[3 * r + 2] = r0 * b.Ic[2] + r1 * b.Ic[4] + r2 * b.Ic[5];
+            T9[3 * r + 0] = r0 * b.Ic(0) + r1 * b.Ic(1) + r2 * b.Ic(2);
+            T9[3 * r + 1] = r0 * b.Ic(1) + r1 * b.Ic(3) + r2 * b.Ic(4);
+            T9[3 * r + 2] = r0 * b.Ic(2) + r1 * b.Ic(4) + r2 * b.Ic(5);
         }
         float invm = b.invm;
         V3 cw = invm * h;
@@ -749,7 +763,8 @@ MPPI_HD void step(CModel &m0, const float *root, float *q, float *qd, const floa
             float v = qd[i] + h * qdd[i];
             if (b.vmax > 0.f) v = fminf(fmaxf(v, -b.vmax), b.vmax);
             float x = q[i] + h * v;
-            if (b.limited) joint_limit(q[i], x, v, b.lower, b.upper, 1.f / h);
+            const float lo = m.b[i].k0.lower, hi = m.b[i].k0.upper;
+            if (lo > -INFINITY || hi < INFINITY) joint_limit(q[i], x, v, lo, hi, 1.f / h);
             q[i] = x;
             qd[i] = v;
         });

@@ -100,6 +100,8 @@ inline QF qwhere_lt(QF a, QF b, QF x, QF y) { QF o; for (int i = 0; i < 4; i++) 
 
 // sum over the three components, taken from lane 0 so that replicated scalars (d, u, qdd, costs) are
 // bit-identical across the quad whatever the summation order of each lane would have been
+// (as (x0 + x1) + x2 from three broadcasts: the same value as bc<0>(x + rot1(x) + rot2(x)), and only the first of the three
+// DPP reads can follow the write of x - one hazard wait instead of two on the dependent chains the dots sit in)
 MPPI_HD QF qsum(QF x) { return bc<0>(x + rot1(x) + rot2(x)); }
 // (a x b)_r = t_{r+1} with t_r = a_r b_{r+1} - a_{r+1} b_r: three permutations instead of four, two of
 // them foldable into the multiply as DPP source modifiers
@@ -114,6 +116,16 @@ struct QM3 {  // 3x3, STANDARD row r per lane
 struct QAI {  // symmetric 6x6 [[I,H],[H^T,M]], ROTATED rows: x[j] = X[r][(r+j)%3]
     QF I[3], H[3], Ht[3], M[3];
 };
+// Two distributed values in ONE aligned register pair: the operand shape of the packed fp32 instructions (v_pk_mul_f32,
+// v_pk_fma_f32: two multiply-adds per issue slot, each source half selectable by op_sel - a lone wavefront pays one issue slot
+// of ~4.75 cycles per instruction whatever it does, tools/exp/issue_rate.hip).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float QF2 __attribute__((ext_vector_type(2)));
+#else
+struct QF2 {
+    QF x, y;
+};
+#endif
 
 
 // ---- rotations folded into the multiply-adds (device only) -----------------------------------------------------------------
@@ -128,8 +140,18 @@ struct QAI {  // symmetric 6x6 [[I,H],[H^T,M]], ROTATED rows: x[j] = X[r][(r+j)%
 // Same arithmetic as the C++ forms below them up to the association of the sums (last-bit differences).
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(MPPI_NO_DPP_FMAC)
 #define MPPI_DPP_FMAC 1
+// A block whose FIRST instructions are DPP reads is only safe where the compiler does not write one of their operands right
+// in front of it (a copy, a reload from the AGPR file): the register-starved contact-scene kernels do, so their translation
+// units define MPPI_DPP_LEAD_WAIT and such blocks start with the two wait states; the contact-free kernels go without, and
+// tests/test_dpp_hazards.py checks every DPP instruction of the built library either way.
+#if defined(MPPI_DPP_LEAD_WAIT)
+#define MPPI_LEAD "s_nop 1\n\t"
+#else
+#define MPPI_LEAD ""
+#endif
 #define MPPI_R1 "quad_perm:[1,2,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1"
 #define MPPI_R2 "quad_perm:[2,0,1,2] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+#if defined(MPPI_NO_PK_QMUL)  // (A/B switch: the scalar forms)
 __device__ __forceinline__ QSV qmul_fused(const QF *I, const QF *H, const QF *Ht, const QF *M, QF xa, QF xl) {
     QF ya, yl;
     asm("v_mul_f32 %0, %2, %14\n\t"                 // ya  = I0 xa
@@ -167,6 +189,59 @@ __device__ __forceinline__ void qrank1_fused(QF *Ia, QF *Ha, QF *Hta, QF *Ma, QF
           "+v"(Ma[1]), "+v"(Ma[2])
         : "v"(sn), "v"(sf), "v"(ua), "v"(ul));
 }
+#else
+// (the four UNROTATED products of a 6x6 times a spatial vector pair up as (I0, Ht0) xa + (H0, M0) xl: two packed
+// multiply-adds; the register pairs are formed from the rows where they live - the allocator places them, no copies)
+__device__ __forceinline__ QSV qmul_fused(const QF *I, const QF *H, const QF *Ht, const QF *M, QF xa, QF xl) {
+    QF2 y;
+    const QF2 IHt0 = {I[0], Ht[0]}, HM0 = {H[0], M[0]}, x = {xa, xl};
+    asm("v_pk_mul_f32 %0, %1, %3 op_sel_hi:[1,0]\n\t"                       // (ya, yl)  = (I0, Ht0) xa
+        "v_pk_fma_f32 %0, %2, %3, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]"        // (ya, yl) += (H0, M0) xl
+        : "=&v"(y)
+        : "v"(IHt0), "v"(HM0), "v"(x));
+    // the rotated terms read xa, xl through DPP: as halves of the pair the packed instructions above have just read, so that
+    // their last write lies at least those two instructions back (tests/test_dpp_hazards.py checks the built library)
+    QF ya = y.x, yl = y.y;
+    xa = x.x;
+    xl = x.y;
+    asm(MPPI_LEAD
+        "v_fmac_f32_dpp %0, %10, %2 " MPPI_R1 "\n\t"   // ya += rot1(xa) I1
+        "v_fmac_f32_dpp %1, %10, %6 " MPPI_R1 "\n\t"   // yl += rot1(xa) Ht1
+        "v_fmac_f32_dpp %0, %10, %3 " MPPI_R2 "\n\t"   // ya += rot2(xa) I2
+        "v_fmac_f32_dpp %1, %10, %7 " MPPI_R2 "\n\t"   // yl += rot2(xa) Ht2
+        "v_fmac_f32_dpp %0, %11, %4 " MPPI_R1 "\n\t"   // ya += rot1(xl) H1
+        "v_fmac_f32_dpp %1, %11, %8 " MPPI_R1 "\n\t"   // yl += rot1(xl) M1
+        "v_fmac_f32_dpp %0, %11, %5 " MPPI_R2 "\n\t"   // ya += rot2(xl) H2
+        "v_fmac_f32_dpp %1, %11, %9 " MPPI_R2            // yl += rot2(xl) M2
+        : "+v"(ya), "+v"(yl)
+        : "v"(I[1]), "v"(I[2]), "v"(H[1]), "v"(H[2]), "v"(Ht[1]), "v"(Ht[2]), "v"(M[1]), "v"(M[2]), "v"(xa), "v"(xl));
+    return QSV{ya, yl};
+}
+// X[j] += s * rot_j(y) for one rotated-row block, j = 0, 1, 2 (the rank-one update of the articulated inertia: s = -u_r / d)
+__device__ __forceinline__ void qrank1_fused(QF *Ia, QF *Ha, QF *Hta, QF *Ma, QF sn, QF sf, QF ua, QF ul) {
+    QF2 IHt0 = {Ia[0], Hta[0]}, HM0 = {Ha[0], Ma[0]};
+    const QF2 s = {sn, sf}, u = {ua, ul};
+    asm("v_pk_fma_f32 %0, %2, %3, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"  // (I0, Ht0) += (sn, sf) ua
+        "v_pk_fma_f32 %1, %2, %3, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]"        // (H0, M0)  += (sn, sf) ul
+        : "+v"(IHt0), "+v"(HM0)
+        : "v"(s), "v"(u));
+    Ia[0] = IHt0.x; Hta[0] = IHt0.y;
+    Ha[0] = HM0.x;  Ma[0] = HM0.y;
+    ua = u.x;  // (DPP operands below: the halves the packed instructions have just read, see qmul_fused)
+    ul = u.y;
+    asm(MPPI_LEAD
+        "v_fmac_f32_dpp %0, %10, %8 " MPPI_R1 "\n\t"   // I1  += rot1(ua) sn
+        "v_fmac_f32_dpp %1, %10, %8 " MPPI_R2 "\n\t"   // I2  += rot2(ua) sn
+        "v_fmac_f32_dpp %2, %11, %8 " MPPI_R1 "\n\t"   // H1  += rot1(ul) sn
+        "v_fmac_f32_dpp %3, %11, %8 " MPPI_R2 "\n\t"   // H2  += rot2(ul) sn
+        "v_fmac_f32_dpp %4, %10, %9 " MPPI_R1 "\n\t"   // Ht1 += rot1(ua) sf
+        "v_fmac_f32_dpp %5, %10, %9 " MPPI_R2 "\n\t"   // Ht2 += rot2(ua) sf
+        "v_fmac_f32_dpp %6, %11, %9 " MPPI_R1 "\n\t"   // M1  += rot1(ul) sf
+        "v_fmac_f32_dpp %7, %11, %9 " MPPI_R2            // M2  += rot2(ul) sf
+        : "+v"(Ia[1]), "+v"(Ia[2]), "+v"(Ha[1]), "+v"(Ha[2]), "+v"(Hta[1]), "+v"(Hta[2]), "+v"(Ma[1]), "+v"(Ma[2])
+        : "v"(sn), "v"(sf), "v"(ua), "v"(ul));
+}
+#endif
 // rotated rows of R Ic R^T - h cw^T:  X_j = Tr0 rot_j(R0) + Tr1 rot_j(R1) + Tr2 rot_j(R2) + nh rot_j(cw); j = 0 comes without
 // its h cw term (the caller adds the diagonal's |h|^2/m - h cw), which also gives the block its three plain leading instructions
 __device__ __forceinline__ void qinertia_rows_fused(const QF *Tr, const QF *Rc, QF nh, QF cw, QF &I0, QF &I1, QF &I2) {
@@ -233,6 +308,41 @@ __device__ __forceinline__ void qbias_force_fused(QF I0, QF I1, QF I2, QF h, QF 
         : "=&v"(pAa), "=&v"(pAl), "=&v"(n), "=&v"(f), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4)
         : "v"(I0), "v"(I1), "v"(I2), "v"(h), "v"(m), "v"(w), "v"(vl));
 }
+// the two 6-dots of a joint with their consumers: d = kdh + S.x and u = tau - S.y, summed over the quad from broadcasts in
+// every lane alike ((c + t0) + t1) + t2 - replicated scalars stay bit-identical across the quad - and interleaved so that no
+// DPP read follows the write of its operand (a dot on its own is mul, fmac, WAIT, DPP, DPP, WAIT, DPP)
+#define MPPI_B(k) "quad_perm:[" #k "," #k "," #k "," #k "] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+__device__ __forceinline__ void qdot6_pair_fused(QF Sa, QF Sl, QF xa, QF xl, QF ya, QF yl, QF kdh, QF tau, QF &d, QF &u) {
+    QF t1, t2;
+    asm("v_mul_f32 %2, %4, %6\n\t"                       //  1 t1  = Sa xa
+        "v_fmac_f32 %2, %5, %7\n\t"                      //  2 t1 += Sl xl
+        "v_mul_f32 %3, %4, %8\n\t"                       //  3 t2  = Sa ya
+        "v_fmac_f32 %3, %5, %9\n\t"                      //  4 t2 += Sl yl
+        "v_add_f32_dpp %0, %2, %10 " MPPI_B(0) "\n\t"    //  5 d   = t1[0] + kdh      (t1 written at 2)
+        "v_add_f32_dpp %0, %2, %0 " MPPI_B(1) "\n\t"     //  6 d  += t1[1]
+        "v_subrev_f32_dpp %1, %3, %11 " MPPI_B(0) "\n\t" //  7 u   = tau - t2[0]      (t2 written at 4)
+        "v_add_f32_dpp %0, %2, %0 " MPPI_B(2) "\n\t"     //  8 d  += t1[2]
+        "v_subrev_f32_dpp %1, %3, %1 " MPPI_B(1) "\n\t"  //  9 u  -= t2[1]
+        "v_subrev_f32_dpp %1, %3, %1 " MPPI_B(2)           // 10 u  -= t2[2]
+        : "=&v"(d), "=&v"(u), "=&v"(t1), "=&v"(t2)
+        : "v"(Sa), "v"(Sl), "v"(xa), "v"(xl), "v"(ya), "v"(yl), "v"(kdh), "v"(tau));
+}
+// outward pass of one joint: qdd = k + W . a_parent,  a = (a_parent + c) + qdd S; the two sums a_parent + c fill the wait
+// between the dot's products and their first DPP read
+__device__ __forceinline__ void qoutward_fused(QF Wa, QF Wl, QF apa, QF apl, QF ca, QF cl, QF Sa, QF Sl, QF k, QF &dd, QF &aa, QF &al) {
+    QF t;
+    asm("v_mul_f32 %3, %4, %6\n\t"                       //  1 t   = Wa apa
+        "v_fmac_f32 %3, %5, %7\n\t"                      //  2 t  += Wl apl
+        "v_add_f32 %1, %6, %8\n\t"                       //  3 aa  = apa + ca
+        "v_add_f32 %2, %7, %9\n\t"                       //  4 al  = apl + cl
+        "v_add_f32_dpp %0, %3, %12 " MPPI_B(0) "\n\t"    //  5 dd  = t[0] + k         (t written at 2)
+        "v_add_f32_dpp %0, %3, %0 " MPPI_B(1) "\n\t"     //  6 dd += t[1]
+        "v_add_f32_dpp %0, %3, %0 " MPPI_B(2) "\n\t"     //  7 dd += t[2]
+        "v_fmac_f32 %1, %0, %10\n\t"                     //  8 aa += dd Sa
+        "v_fmac_f32 %2, %0, %11"                          //  9 al += dd Sl
+        : "=&v"(dd), "=&v"(aa), "=&v"(al), "=&v"(t)
+        : "v"(Wa), "v"(Wl), "v"(apa), "v"(apl), "v"(ca), "v"(cl), "v"(Sa), "v"(Sl), "v"(k));
+}
 #endif
 
 // y = A x for the 6x6: rotated rows meet rotated copies of the distributed vector
@@ -251,23 +361,57 @@ MPPI_HD QF qdot6(const QSV &p, const QSV &q) { return qsum(p.a * q.a + p.l * q.l
 // JT: joint types known at compile time (0: every joint is revolute, -1: read per joint from the model).  The kernel picks
 // the instantiation with ONE wave-uniform branch; inside, an all-revolute arm then has no per-joint type test at all
 // (each was a compare on a VGPR-resident uniform value plus an exec-mask region or a select).
+// World poses of the moving bodies, kept as the pairs the kinematics produce and consume: (column 0, column 1) of R and
+// (column 2, position).  rot() / pos() hand out the halves.
 template <class T, int JT = -1>
 struct QPose {
-    QM3 R[T::NB ? T::NB : 1];
-    QF p[T::NB ? T::NB : 1];
+    QF2 R01[T::NB ? T::NB : 1], R2p[T::NB ? T::NB : 1];
     int jt[T::NB ? T::NB : 1];
-    QM3 Rb;
-    QF pb;
+    QF2 Rb01, Rb2p;
     MPPI_HD bool revolute(int i) const {
         if constexpr (JT == 0) return true;
         else return jt[i] == 0;
     }
+    MPPI_HD QM3 rot(int i) const { return QM3{{R01[i].x, R01[i].y, R2p[i].x}}; }
+    MPPI_HD QF pos(int i) const { return R2p[i].y; }
+    MPPI_HD QM3 rot_base() const { return QM3{{Rb01.x, Rb01.y, Rb2p.x}}; }
+    MPPI_HD QF pos_base() const { return Rb2p.y; }
+    MPPI_HD void set_base(const QM3 &R, QF p) {
+        Rb01.x = R.c[0]; Rb01.y = R.c[1];
+        Rb2p.x = R.c[2]; Rb2p.y = p;
+    }
 };
+
+// first moment h = R hb + m p and Tr = R Ic of a body posed at (R, p), the inputs of its world-frame rigid inertia: thirteen
+// products-and-sums, on the device as six packed multiply-adds over the constant pairs of BodyK1 plus one for m p
+MPPI_HD void qmoments(QF2 R01, QF2 R2p, const BodyK1 &b, QF &h, QF *Tr) {
+#if defined(MPPI_DPP_FMAC) && !defined(MPPI_NO_PK_MOMENTS)
+    const QF2 A0 = {b.hI[0], b.hI[1]}, A1 = {b.hI[2], b.hI[3]}, A2 = {b.hI[4], b.hI[5]}, B0 = {b.II[0], b.II[1]}, B1 = {b.II[2], b.II[3]},
+              B2 = {b.II[4], b.II[5]};
+    QF2 X, Y;
+    asm("v_pk_mul_f32 %0, %2, %4 op_sel_hi:[0,1]\n\t"                          // (h, Tr0)    = c0 (hb0, Ic0)
+        "v_pk_mul_f32 %1, %2, %7 op_sel_hi:[0,1]\n\t"                          // (Tr1, Tr2)  = c0 (Ic1, Ic2)
+        "v_pk_fma_f32 %0, %2, %5, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"     // (h, Tr0)   += c1 (hb1, Ic1)
+        "v_pk_fma_f32 %1, %2, %8, %1 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"     // (Tr1, Tr2) += c1 (Ic3, Ic4)
+        "v_pk_fma_f32 %0, %3, %6, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"     // (h, Tr0)   += c2 (hb2, Ic2)
+        "v_pk_fma_f32 %1, %3, %9, %1 op_sel:[0,0,0] op_sel_hi:[0,1,1]"           // (Tr1, Tr2) += c2 (Ic4, Ic5)
+        : "=&v"(X), "=&v"(Y)
+        : "v"(R01), "v"(R2p), "v"(A0), "v"(A1), "v"(A2), "v"(B0), "v"(B1), "v"(B2));
+    h = X.x + b.m * R2p.y;
+    Tr[0] = X.y;
+    Tr[1] = Y.x;
+    Tr[2] = Y.y;
+#else
+    const QF c0 = R01.x, c1 = R01.y, c2 = R2p.x;
+    h = c0 * b.hb(0) + c1 * b.hb(1) + c2 * b.hb(2) + b.m * R2p.y;
+    Tr[0] = c0 * b.Ic(0) + c1 * b.Ic(1) + c2 * b.Ic(2);
+    Tr[1] = c0 * b.Ic(1) + c1 * b.Ic(3) + c2 * b.Ic(4);
+    Tr[2] = c0 * b.Ic(2) + c1 * b.Ic(4) + c2 * b.Ic(5);
+#endif
+}
 
 template <class T, class M, int JT>
 MPPI_HD void quad_fk(M &m, const QF *q, QPose<T, JT> &P) {
-    // the 64-byte constant block of body i+1 is requested before body i is computed, so its scalar-load
-    // latency hides under ~100 VALU instructions instead of stalling the (only) wave of this SIMD
     // all kinematic blocks are requested up front (LDS returns in order, so body i only waits for its own
     // block while the later ones stream in behind the arithmetic)
     BodyK0 blk[T::NB ? T::NB : 1];
@@ -277,45 +421,67 @@ MPPI_HD void quad_fk(M &m, const QF *q, QPose<T, JT> &P) {
         constexpr int par = T::par[i];
         const BodyK0 &b = blk[i];
         P.jt[i] = b.jtype;
-        const QM3 &Rp = par < 0 ? P.Rb : P.R[par < 0 ? 0 : par];
-        const QF pp = par < 0 ? P.pb : P.p[par < 0 ? 0 : par];
-        QM3 RT;
-        for (int c = 0; c < 3; c++) RT.c[c] = Rp.c[0] * b.Rt[c] + Rp.c[1] * b.Rt[3 + c] + Rp.c[2] * b.Rt[6 + c];
-        const QF pw = pp + Rp.c[0] * b.pt[0] + Rp.c[1] * b.pt[1] + Rp.c[2] * b.pt[2];
-        if (JT == 0 || b.jtype == 0) {
-            QF s, c;
-            qsincos(q[i], s, c);
-            P.R[i].c[0] = c * RT.c[0] + s * RT.c[1];
-            P.R[i].c[1] = c * RT.c[1] - s * RT.c[0];
-            P.R[i].c[2] = RT.c[2];
-            P.p[i] = pw;
-        } else {
-            P.R[i] = RT;
-            P.p[i] = pw + q[i] * RT.c[2];
-        }
+        const QF2 Rp01 = par < 0 ? P.Rb01 : P.R01[par < 0 ? 0 : par], Rp2p = par < 0 ? P.Rb2p : P.R2p[par < 0 ? 0 : par];
+        const bool rev = JT == 0 || b.jtype == 0;
+        QF sn = qrep(0.f), cn = qrep(1.f);  // prismatic: the identity rotation
+        if (rev) qsincos(q[i], sn, cn);
+        QF2 R01, RT2p;  // columns 0, 1 of R_parent Rt Rz(q) | column 2 and R_parent pt
+#if defined(MPPI_DPP_FMAC) && !defined(MPPI_NO_PK_FK)
+        // six packed multiply-adds for the twelve products-and-sums of [R_parent Rt | R_parent pt] - the parent's column k is
+        // broadcast to both halves by op_sel, the constants are the 3x4 block's row pairs - and two for the rotation about the
+        // joint's z, (c0', c1') = cos q (c0, c1) + sin q (c1, -c0).
+        // HAZARD (gfx940+): a VALU instruction must not read the result of a transcendental (v_sin, v_cos, v_rcp ...) in the
+        // very next issue slot.  The compiler pads its own code, not inline assembly: (cos, sin) is an operand of THIS block, so
+        // it is complete before the block starts and first read six instructions in (tools/check_dpp_hazards.py looks for
+        // this as well; a separate rotation block right behind v_sin / v_cos read a stale sine).
+        const QF2 K01 = {b.T[0], b.T[1]}, K23 = {b.T[2], b.T[3]}, K45 = {b.T[4], b.T[5]}, K67 = {b.T[6], b.T[7]}, K89 = {b.T[8], b.T[9]},
+                  Kab = {b.T[10], b.T[11]}, cs = {cn, sn};
+        QF2 RT01;
+        asm("v_pk_mul_f32 %0, %3, %5 op_sel_hi:[0,1]\n\t"                                      // RT01  = c0 (Rt00, Rt01)
+            "v_pk_mul_f32 %1, %3, %6 op_sel_hi:[0,1]\n\t"                                      // RT2p  = c0 (Rt02, pt0)
+            "v_pk_fma_f32 %0, %3, %7, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"                 // RT01 += c1 (Rt10, Rt11)
+            "v_pk_fma_f32 %1, %3, %8, %1 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"                 // RT2p += c1 (Rt12, pt1)
+            "v_pk_fma_f32 %0, %4, %9, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"                 // RT01 += c2 (Rt20, Rt21)
+            "v_pk_fma_f32 %1, %4, %10, %1 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"                // RT2p += c2 (Rt22, pt2)
+            "v_pk_mul_f32 %2, %0, %11 op_sel_hi:[1,0]\n\t"                                     // R01   = (c0, c1) cos
+            "v_pk_fma_f32 %2, %0, %11, %2 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]"      // R01  += (c1 sin, -c0 sin)
+            : "=&v"(RT01), "=&v"(RT2p), "=&v"(R01)
+            : "v"(Rp01), "v"(Rp2p), "v"(K01), "v"(K23), "v"(K45), "v"(K67), "v"(K89), "v"(Kab), "v"(cs));
+#else
+        const QF c0 = Rp01.x, c1 = Rp01.y, c2 = Rp2p.x;
+        const QF r0 = c0 * b.rt(0) + c1 * b.rt(3) + c2 * b.rt(6);
+        const QF r1 = c0 * b.rt(1) + c1 * b.rt(4) + c2 * b.rt(7);
+        RT2p.x = c0 * b.rt(2) + c1 * b.rt(5) + c2 * b.rt(8);
+        RT2p.y = c0 * b.pt(0) + c1 * b.pt(1) + c2 * b.pt(2);
+        R01.x = cn * r0 + sn * r1;
+        R01.y = cn * r1 - sn * r0;
+#endif
+        P.R01[i] = R01;
+        P.R2p[i].x = RT2p.x;
+        const QF pw = Rp2p.y + RT2p.y;
+        P.R2p[i].y = rev ? pw : pw + q[i] * RT2p.x;  // prismatic along the joint's z
     });
 }
 
 template <class T, int i, int JT>
 MPPI_HD QSV quad_subspace(const QPose<T, JT> &P) {
-    const QF az = P.R[i].c[2];  // third column of R: component r lives in lane r's row
-    if (P.revolute(i)) return {az, qcross(P.p[i], az)};
+    const QF az = P.R2p[i].x;  // third column of R: component r lives in lane r's row
+    if (P.revolute(i)) return {az, qcross(P.pos(i), az)};
     return {qrep(0.f), az};
 }
 
 // Articulated-body solve, quad-parallel.  tau/kdh/qd/qdd are replicated scalars (same in all lanes of a quad).
-struct JointLimits {  // wave-uniform per-joint limits, cached from block 1 while the ABA has it in SGPRs
-    float effort, lower, upper, vmax;
-    int limited;
+struct JointLimits {  // per-joint drive limits, cached from block 1 while the solve has it in registers (+inf: none)
+    float effort, vmax;
 };
 
 template <class T, class M, int JT>
 MPPI_HD void quad_aba(M &m, const QPose<T, JT> &P, const QF *qd, const QF *tau_exp, const QF *kdh, QF *qdd, JointLimits *lim) {
     constexpr int NB = T::NB;
-    QSV v[NB], U[NB], pacc[NB], cb[NB];
+    QSV v[NB], W[NB], pacc[NB], cb[NB];
     QF Sl[NB];  // linear part of the joint subspace (the angular part is the third column of R)
     QAI acc[NB];
-    QF invd[NB], u[NB];
+    QF kk[NB];
     bool has_acc[NB];
     const QF zero = qrep(0.f);
     // pass 1: velocities, and the two quantities both later sweeps need: S_i and c_i = v_parent x (S_i qd_i)
@@ -345,15 +511,12 @@ MPPI_HD void quad_aba(M &m, const QPose<T, JT> &P, const QF *qd, const QF *tau_e
         constexpr int i = ic;
         constexpr int par = T::par[i];
         const BodyK1 &b = blk[i];
-        lim[i] = {b.effort, b.lower, b.upper, b.vmax, b.limited};
-        const QM3 &R = P.R[i];
+        lim[i] = {b.effort, b.vmax};
+        const QM3 R = P.rot(i);
         const QSV S = {P.revolute(i) ? R.c[2] : zero, Sl[i]};
         // rigid inertia about the world origin: I_O = R Ic R^T + m(|cw|^2 1 - cw cw^T), h = m cw
-        const QF h = R.c[0] * b.hb[0] + R.c[1] * b.hb[1] + R.c[2] * b.hb[2] + b.m * P.p[i];
-        QF Tr[3];
-        Tr[0] = R.c[0] * b.Ic[0] + R.c[1] * b.Ic[1] + R.c[2] * b.Ic[2];
-        Tr[1] = R.c[0] * b.Ic[1] + R.c[1] * b.Ic[3] + R.c[2] * b.Ic[4];
-        Tr[2] = R.c[0] * b.Ic[2] + R.c[1] * b.Ic[4] + R.c[2] * b.Ic[5];
+        QF h, Tr[3];
+        qmoments(P.R01[i], P.R2p[i], b, h, Tr);
         const QF cw = b.invm * h;
         const QF hh = qsum(h * cw);
         const QF h1 = rot1(h), h2 = rot2(h);
@@ -366,9 +529,19 @@ MPPI_HD void quad_aba(M &m, const QPose<T, JT> &P, const QF *qd, const QF *tau_e
         A.I[1] = Tr[0] * rot1(R.c[0]) + Tr[1] * rot1(R.c[1]) + Tr[2] * rot1(R.c[2]) - h * rot1(cw);
         A.I[2] = Tr[0] * rot2(R.c[0]) + Tr[1] * rot2(R.c[1]) + Tr[2] * rot2(R.c[2]) - h * rot2(cw);
 #endif
-        A.H[0] = qrep(0.f); A.H[1] = -h2;       A.H[2] = h1;        // skew(h), rotated rows
-        A.Ht[0] = A.H[0];  A.Ht[1] = h2;       A.Ht[2] = -h1;      // skew(h)^T = -skew(h)
-        A.M[0] = qrep(b.m); A.M[1] = A.H[0];   A.M[2] = A.H[0];
+        // skew(h) in rotated rows is (0, -h2, h1), its transpose the negative, the mass block (m, 0, 0): on top of the children's
+        // articulated inertias where there are any (written out per entry - the sums with the structural zeros are not
+        // the compiler's to drop without fast-math)
+        if (has_acc[i]) {
+            const QAI &C = acc[i];
+            A.H[0] = C.H[0];        A.H[1] = C.H[1] - h2;   A.H[2] = C.H[2] + h1;
+            A.Ht[0] = C.Ht[0];      A.Ht[1] = C.Ht[1] + h2; A.Ht[2] = C.Ht[2] - h1;
+            A.M[0] = C.M[0] + b.m;  A.M[1] = C.M[1];        A.M[2] = C.M[2];
+        } else {
+            A.H[0] = qrep(0.f); A.H[1] = -h2;       A.H[2] = h1;
+            A.Ht[0] = A.H[0];  A.Ht[1] = h2;       A.Ht[2] = -h1;
+            A.M[0] = qrep(b.m); A.M[1] = A.H[0];   A.M[2] = A.H[0];
+        }
         // bias force v x* (I v)
         const QF w = v[i].a, vl = v[i].l;
 #if defined(MPPI_DPP_FMAC)
@@ -379,30 +552,39 @@ MPPI_HD void quad_aba(M &m, const QPose<T, JT> &P, const QF *qd, const QF *tau_e
         const QF f = b.m * vl + qcross(w, h);
         QSV pA = {qcross(w, n) + qcross(vl, f), qcross(w, f)};
 #endif
-        if (has_acc[i]) {
-            for (int j = 0; j < 3; j++) { A.I[j] += acc[i].I[j]; A.H[j] += acc[i].H[j]; A.Ht[j] += acc[i].Ht[j]; A.M[j] += acc[i].M[j]; }
+        if (has_acc[i]) {  // (the velocity-product force above is the RIGID body's: its inertia rows meet the children's only now)
+            for (int j = 0; j < 3; j++) A.I[j] += acc[i].I[j];
             pA = {pA.a + pacc[i].a, pA.l + pacc[i].l};
         }
-        U[i] = qmul(A, S);
-        const QF d = qdot6(S, U[i]) + kdh[i];
-        invd[i] = qrcp(d);
-        u[i] = tau_exp[i] - qdot6(S, pA);
+        const QSV Ui = qmul(A, S);
+#if defined(MPPI_DPP_FMAC) && !defined(MPPI_NO_PAIR_DOT)
+        QF d, ui;
+        qdot6_pair_fused(S.a, S.l, Ui.a, Ui.l, pA.a, pA.l, kdh[i], tau_exp[i], d, ui);
+        const QF invd = qrcp(d);
+#else
+        const QF invd = qrcp(qdot6(S, Ui) + kdh[i]), ui = tau_exp[i] - qdot6(S, pA);
+#endif
+        // what the outward pass needs of this joint: qdd_i = k_i + W_i . a_parent with W = -U/d and k = (u - U.c)/d
+        // (the parent's acceleration enters through one dot; c_i is already folded into k_i here)
+        const QF ninvd = -invd;
+        W[i] = {Ui.a * ninvd, Ui.l * ninvd};
+        if constexpr (par < 0) kk[i] = ui * invd;
         if constexpr (par >= 0) {
             const QSV c = cb[i];
             const QSV Ac = qmul(A, c);
-            const QF k = (u[i] - qdot6(U[i], c)) * invd[i];
-            const QSV pa = {pA.a + Ac.a + k * U[i].a, pA.l + Ac.l + k * U[i].l};
-            // Ia = IA - U U^T / d  (rotated rows: X[r][(r+j)%3] -= x_r * rot_j(y))
+            const QF k = (ui - qdot6(Ui, c)) * invd;
+            kk[i] = k;
+            const QSV pa = {pA.a + Ac.a + k * Ui.a, pA.l + Ac.l + k * Ui.l};
+            // Ia = IA - U U^T / d  (rotated rows: X[r][(r+j)%3] += W_r * rot_j(U))
 #if defined(MPPI_DPP_FMAC)
-            const QF ninvd = -invd[i];
-            qrank1_fused(A.I, A.H, A.Ht, A.M, U[i].a * ninvd, U[i].l * ninvd, U[i].a, U[i].l);
+            qrank1_fused(A.I, A.H, A.Ht, A.M, W[i].a, W[i].l, Ui.a, Ui.l);
 #else
-            const QF un = U[i].a * invd[i], uf = U[i].l * invd[i];
-            const QF n1 = rot1(U[i].a), n2 = rot2(U[i].a), f1 = rot1(U[i].l), f2 = rot2(U[i].l);
-            A.I[0] -= un * U[i].a; A.I[1] -= un * n1; A.I[2] -= un * n2;
-            A.H[0] -= un * U[i].l; A.H[1] -= un * f1; A.H[2] -= un * f2;
-            A.Ht[0] -= uf * U[i].a; A.Ht[1] -= uf * n1; A.Ht[2] -= uf * n2;
-            A.M[0] -= uf * U[i].l; A.M[1] -= uf * f1; A.M[2] -= uf * f2;
+            const QF un = -W[i].a, uf = -W[i].l;
+            const QF n1 = rot1(Ui.a), n2 = rot2(Ui.a), f1 = rot1(Ui.l), f2 = rot2(Ui.l);
+            A.I[0] -= un * Ui.a; A.I[1] -= un * n1; A.I[2] -= un * n2;
+            A.H[0] -= un * Ui.l; A.H[1] -= un * f1; A.H[2] -= un * f2;
+            A.Ht[0] -= uf * Ui.a; A.Ht[1] -= uf * n1; A.Ht[2] -= uf * n2;
+            A.M[0] -= uf * Ui.l; A.M[1] -= uf * f1; A.M[2] -= uf * f2;
 #endif
             constexpr int pj = par < 0 ? 0 : par;
             if (has_acc[pj]) {
@@ -421,12 +603,17 @@ MPPI_HD void quad_aba(M &m, const QPose<T, JT> &P, const QF *qd, const QF *tau_e
     static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
         constexpr int i = ic;
         constexpr int par = T::par[i];
-        const QSV S = {P.revolute(i) ? P.R[i].c[2] : zero, Sl[i]};
-        QSV ap = a0;
-        if constexpr (par >= 0) ap = {a[par < 0 ? 0 : par].a + cb[i].a, a[par < 0 ? 0 : par].l + cb[i].l};
-        const QF dd = (u[i] - qdot6(U[i], ap)) * invd[i];
+        const QSV S = {P.revolute(i) ? P.R2p[i].x : zero, Sl[i]};
+        const QSV apar = par >= 0 ? a[par < 0 ? 0 : par] : a0;
+#if defined(MPPI_DPP_FMAC)
+        qoutward_fused(W[i].a, W[i].l, apar.a, apar.l, cb[i].a, cb[i].l, S.a, S.l, kk[i], qdd[i], a[i].a, a[i].l);  // (root: c = 0)
+#else
+        const QF dd = kk[i] + qdot6(W[i], apar);
         qdd[i] = dd;
+        QSV ap = a0;
+        if constexpr (par >= 0) ap = {apar.a + cb[i].a, apar.l + cb[i].l};
         a[i] = {ap.a + dd * S.a, ap.l + dd * S.l};
+#endif
     });
 }
 
@@ -435,8 +622,9 @@ template <class T, class M, int JT>
 MPPI_HD void quad_base(M &m, const float *root, QPose<T, JT> &P) {
     const float *rs = root + 13 * m.robot_actor;
     const M3 R = quat_to_R(rs + 3);
-    P.pb = qsel(rs[0], rs[1], rs[2]);
-    for (int c = 0; c < 3; c++) P.Rb.c[c] = qsel(R.a[c], R.a[3 + c], R.a[6 + c]);
+    QM3 Rb;
+    for (int c = 0; c < 3; c++) Rb.c[c] = qsel(R.a[c], R.a[3 + c], R.a[6 + c]);
+    P.set_base(Rb, qsel(rs[0], rs[1], rs[2]));
 }
 
 // One simulator step.  P must hold the forward kinematics of q on entry (base pose included) and holds the
@@ -482,7 +670,7 @@ MPPI_HD void quad_step(M &m0, QPose<T, JT> &P, QF *q, QF *qd, const QF *target) 
                 // ve = (limit - x_old) / h, never pointing back out of the range.  x_old + h v < lo is the same as v < ve_lo, so
                 // the stop is the unconditional bound v >= min(ve_lo, 0) - and the two clamps compose into one because both
                 // intervals contain 0: v in [med3(ve_lo, -vmax, 0), med3(ve_hi, 0, vmax)]
-                const QF lo = qrep(b.lower), hi = qrep(b.upper), z = qrep(0.f);
+                const QF lo = qrep(m.b[i].k0.lower), hi = qrep(m.b[i].k0.upper), z = qrep(0.f);  // (absent: -inf, +inf)
                 const QF vlo = qclamp((lo - q[i]) * inv_h, qrep(-b.vmax), z), vhi = qclamp((hi - q[i]) * inv_h, z, qrep(b.vmax));
                 v = qclamp(v, vlo, vhi);
                 x = qclamp(q[i] + h * v, lo, hi);
@@ -494,21 +682,42 @@ MPPI_HD void quad_step(M &m0, QPose<T, JT> &P, QF *q, QF *qd, const QF *target) 
     }
 }
 
+// pose of moving body `body` (wave-uniform; < 0: the base) out of the kinematics: a binary tree of UNIFORM branches - three
+// scalar compares and four copies.  (Written as arithmetic selects, R += [body == i] R_i, it was a compare, a select and four
+// multiply-adds per body: ~70 vector instructions per horizon step for a choice that never changes during a rollout; the
+// empty asm keeps the optimiser from turning the branches back into selects.)
+template <class T, int JT, int LO, int HI>
+MPPI_HD void quad_body_pose(const QPose<T, JT> &P, int body, QM3 &Rb, QF &pb) {
+    if constexpr (HI - LO == 1) {
+        if constexpr (LO < 0) {
+            Rb = P.rot_base();
+            pb = P.pos_base();
+        } else {
+            Rb = P.rot(LO);
+            pb = P.pos(LO);
+        }
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("");
+#endif
+    } else {
+        constexpr int MID = LO + (HI - LO) / 2;
+        if (body < MID) quad_body_pose<T, JT, LO, MID>(P, body, Rb, pb);
+        else quad_body_pose<T, JT, MID, HI>(P, body, Rb, pb);
+    }
+}
+
 // world pose of link l: row r of R (standard) and component r of p
 template <class T, class M, int JT>
 MPPI_HD void quad_link_pose(M &m, const QPose<T, JT> &P, int l, QM3 &R, QF &p) {
     auto &L = m.l[l];
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int body = __builtin_amdgcn_readfirstlane(L.body);  // (from the LDS copy of the model it arrives in a vector register)
+#else
     const int body = L.body;
-    const float wb = body < 0 ? 1.f : 0.f;
+#endif
     QM3 Rb;
-    for (int c = 0; c < 3; c++) Rb.c[c] = wb * P.Rb.c[c];
-    QF pb = wb * P.pb;
-    static_for<0, T::NB>([&](auto ic) MPPI_LAMBDA {
-        constexpr int i = ic;
-        const float w = body == i ? 1.f : 0.f;
-        for (int c = 0; c < 3; c++) Rb.c[c] += w * P.R[i].c[c];
-        pb += w * P.p[i];
-    });
+    QF pb;
+    quad_body_pose<T, JT, -1, T::NB>(P, body < 0 ? -1 : (body < T::NB ? body : T::NB - 1), Rb, pb);
     for (int c = 0; c < 3; c++) R.c[c] = Rb.c[0] * L.R[c] + Rb.c[1] * L.R[3 + c] + Rb.c[2] * L.R[6 + c];
     p = pb + Rb.c[0] * L.p[0] + Rb.c[1] * L.p[1] + Rb.c[2] * L.p[2];
 }

@@ -1313,7 +1313,8 @@ MPPI_HD void aba_scene(M &m, const Pose<T> &P, const SV &vbase, const float *qd,
         AI A;
         SV pA;
         V3 hw;
-        rigid_world(P.R[i], P.p[i], b.m, loadv(b.hb), b.Ic, v[i], A, pA, hw);
+        const float Ic6[6] = {b.Ic(0), b.Ic(1), b.Ic(2), b.Ic(3), b.Ic(4), b.Ic(5)};
+        rigid_world(P.R[i], P.p[i], b.m, V3{b.hb(0), b.hb(1), b.hb(2)}, Ic6, v[i], A, pA, hw);
         // gravity, contact wrench, implicit contact damping:  (IA + h C) a + (pA + C v - f - f_g) = 0
         SV fe;
         AI C;
@@ -1601,7 +1602,8 @@ MPPI_HD void step_scene(M &m0, const float *root, SceneState<T> &s, const float 
             float v = s.qd[i] + h * qdd[i];
             if (b.vmax > 0.f) v = fminf(fmaxf(v, -b.vmax), b.vmax);
             float x = s.q[i] + h * v;
-            if (b.limited) joint_limit(s.q[i], x, v, b.lower, b.upper, 1.f / h);
+            const float lo = m.b[i].k0.lower, hi = m.b[i].k0.upper;
+            if (lo > -INFINITY || hi < INFINITY) joint_limit(s.q[i], x, v, lo, hi, 1.f / h);
             s.q[i] = x;
             s.qd[i] = v;
         });

@@ -86,13 +86,8 @@ MPPI_HD V3 qv3_gather(QF x) { return V3{qget<0>(x), qget<1>(x), qget<2>(x)}; }
 
 // rigid inertia about the world origin and velocity-product force of a body posed at (R, p) moving with v:
 // the block of quad_aba, shared by the bodies and the floating base
-template <class F>
-MPPI_HD void qrigid_world(const QM3 &R, QF p, float mass, const F *hb, const F *Ic, const QSV &v, QAI &A, QSV &pA, QF &h) {
-    h = R.c[0] * hb[0] + R.c[1] * hb[1] + R.c[2] * hb[2] + mass * p;
-    QF Tr[3];
-    Tr[0] = R.c[0] * Ic[0] + R.c[1] * Ic[1] + R.c[2] * Ic[2];
-    Tr[1] = R.c[0] * Ic[1] + R.c[1] * Ic[3] + R.c[2] * Ic[4];
-    Tr[2] = R.c[0] * Ic[2] + R.c[1] * Ic[4] + R.c[2] * Ic[5];
+// (h and Tr = R Ic come from the caller: qmoments() for the bodies, the plain sums below for the base)
+MPPI_HD void qrigid_tail(const QM3 &R, float mass, QF h, const QF *Tr, const QSV &v, QAI &A, QSV &pA) {
     const float invm = mass > 0.f ? frcp(mass) : 0.f;
     const QF cw = invm * h;
     const QF hh = qsum(h * cw);
@@ -116,6 +111,16 @@ MPPI_HD void qrigid_world(const QM3 &R, QF p, float mass, const F *hb, const F *
     const QF f = mass * vl + qcross(w, h);
     pA = {qcross(w, n) + qcross(vl, f), qcross(w, f)};
 #endif
+}
+
+template <class F>
+MPPI_HD void qrigid_world(const QM3 &R, QF p, float mass, const F *hb, const F *Ic, const QSV &v, QAI &A, QSV &pA, QF &h) {
+    h = R.c[0] * hb[0] + R.c[1] * hb[1] + R.c[2] * hb[2] + mass * p;
+    QF Tr[3];
+    Tr[0] = R.c[0] * Ic[0] + R.c[1] * Ic[1] + R.c[2] * Ic[2];
+    Tr[1] = R.c[0] * Ic[1] + R.c[1] * Ic[3] + R.c[2] * Ic[4];
+    Tr[2] = R.c[0] * Ic[2] + R.c[1] * Ic[4] + R.c[2] * Ic[5];
+    qrigid_tail(R, mass, h, Tr, v, A, pA);
 }
 
 // gravity, contact wrench and implicit contact damping of one frame: (IA + h C) a + (pA + C v - f - f_g) = 0
@@ -180,14 +185,15 @@ MPPI_HD void quad_aba_prepare(M &m, const QPose<T> &P, const QSV &vbase, const Q
     static_rfor<0, NB>([&](auto ic) MPPI_LAMBDA {
         constexpr int i = ic;
         const BodyK1 &b = blk[i];
-        lim[i] = {b.effort, b.lower, b.upper, b.vmax, b.limited};
-        QF h;
-        qrigid_world(P.R[i], P.p[i], b.m, b.hb, b.Ic, v[i], W.A[i], W.pA[i], h);
+        lim[i] = {b.effort, b.vmax};
+        QF h, Tr[3];
+        qmoments(P.R01[i], P.R2p[i], b, h, Tr);
+        qrigid_tail(P.rot(i), b.m, h, Tr, v[i], W.A[i], W.pA[i]);
         qexternal(L, Lay::kAcc, i, (touched >> i) & 1u, hstep, h, b.m, gq, v[i], W.A[i], W.pA[i]);
     });
     if (m.floating != 0) {
         QF h;
-        qrigid_world(P.Rb, P.pb, m.base_m, m.base_hb, m.base_Ic, vbase, W.A[NB], W.pA[NB], h);
+        qrigid_world(P.rot_base(), P.pos_base(), m.base_m, m.base_hb, m.base_Ic, vbase, W.A[NB], W.pA[NB], h);
         qexternal(L, Lay::kAcc, NB, (touched >> NB) & 1u, hstep, h, m.base_m, gq, vbase, W.A[NB], W.pA[NB]);
     }
 }
@@ -195,9 +201,9 @@ template <class T, class M>
 MPPI_HD void quad_aba_solve(M &m, const QPose<T> &P, const QAbaPrep<T> &W, const QF *tau_exp, const QF *kdh, QF *qdd, SV &abase) {
     constexpr int NB = T::NB;
     constexpr int NBs = NB ? NB : 1;
-    QSV U[NBs], pacc[NBs + 1];
+    QSV Wn[NBs], pacc[NBs + 1];  // Wn = -U/d and kk = (u - U.c)/d: what the outward pass needs of a joint (qdd = kk + Wn . a_parent)
     QAI acc[NBs + 1];
-    QF invd[NBs], u[NBs];
+    QF kk[NBs];
     bool has_acc[NBs + 1];
     const QF zero = qrep(0.f);
     const bool floating = m.floating != 0;
@@ -205,33 +211,39 @@ MPPI_HD void quad_aba_solve(M &m, const QPose<T> &P, const QAbaPrep<T> &W, const
     static_rfor<0, NB>([&](auto ic) MPPI_LAMBDA {
         constexpr int i = ic;
         constexpr int par = T::par[i];
-        const QSV S = {P.revolute(i) ? P.R[i].c[2] : zero, W.Sl[i]};
+        const QSV S = {P.revolute(i) ? P.R2p[i].x : zero, W.Sl[i]};
         QAI A = W.A[i];
         QSV pA = W.pA[i];
         if (has_acc[i]) {
             for (int j = 0; j < 3; j++) { A.I[j] += acc[i].I[j]; A.H[j] += acc[i].H[j]; A.Ht[j] += acc[i].Ht[j]; A.M[j] += acc[i].M[j]; }
             pA = {pA.a + pacc[i].a, pA.l + pacc[i].l};
         }
-        U[i] = qmul(A, S);
-        const QF d = qdot6(S, U[i]) + kdh[i];
-        invd[i] = qrcp(d);
-        u[i] = tau_exp[i] - qdot6(S, pA);
+        const QSV Ui = qmul(A, S);
+#if defined(MPPI_DPP_FMAC)
+        QF d, ui;
+        qdot6_pair_fused(S.a, S.l, Ui.a, Ui.l, pA.a, pA.l, kdh[i], tau_exp[i], d, ui);
+        const QF invd = qrcp(d);
+#else
+        const QF invd = qrcp(qdot6(S, Ui) + kdh[i]), ui = tau_exp[i] - qdot6(S, pA);
+#endif
+        const QF ninvd = -invd;
+        Wn[i] = {Ui.a * ninvd, Ui.l * ninvd};
+        const QSV c = W.cb[i];
+        const QF k = (ui - qdot6(Ui, c)) * invd;
+        kk[i] = k;
         constexpr int pj = par < 0 ? NB : par;  // the base accumulator lives at index NB
         if (par >= 0 || floating) {
-            const QSV c = W.cb[i];
             const QSV Ac = qmul(A, c);
-            const QF k = (u[i] - qdot6(U[i], c)) * invd[i];
-            const QSV pa = {pA.a + Ac.a + k * U[i].a, pA.l + Ac.l + k * U[i].l};
+            const QSV pa = {pA.a + Ac.a + k * Ui.a, pA.l + Ac.l + k * Ui.l};
 #if defined(MPPI_DPP_FMAC)
-            const QF ninvd = -invd[i];
-            qrank1_fused(A.I, A.H, A.Ht, A.M, U[i].a * ninvd, U[i].l * ninvd, U[i].a, U[i].l);
+            qrank1_fused(A.I, A.H, A.Ht, A.M, Wn[i].a, Wn[i].l, Ui.a, Ui.l);
 #else
-            const QF un = U[i].a * invd[i], uf = U[i].l * invd[i];
-            const QF n1 = rot1(U[i].a), n2 = rot2(U[i].a), f1 = rot1(U[i].l), f2 = rot2(U[i].l);
-            A.I[0] -= un * U[i].a; A.I[1] -= un * n1; A.I[2] -= un * n2;
-            A.H[0] -= un * U[i].l; A.H[1] -= un * f1; A.H[2] -= un * f2;
-            A.Ht[0] -= uf * U[i].a; A.Ht[1] -= uf * n1; A.Ht[2] -= uf * n2;
-            A.M[0] -= uf * U[i].l; A.M[1] -= uf * f1; A.M[2] -= uf * f2;
+            const QF un = -Wn[i].a, uf = -Wn[i].l;
+            const QF n1 = rot1(Ui.a), n2 = rot2(Ui.a), f1 = rot1(Ui.l), f2 = rot2(Ui.l);
+            A.I[0] -= un * Ui.a; A.I[1] -= un * n1; A.I[2] -= un * n2;
+            A.H[0] -= un * Ui.l; A.H[1] -= un * f1; A.H[2] -= un * f2;
+            A.Ht[0] -= uf * Ui.a; A.Ht[1] -= uf * n1; A.Ht[2] -= uf * n2;
+            A.M[0] -= uf * Ui.l; A.M[1] -= uf * f1; A.M[2] -= uf * f2;
 #endif
             if (has_acc[pj]) {
                 for (int j = 0; j < 3; j++) { acc[pj].I[j] += A.I[j]; acc[pj].H[j] += A.H[j]; acc[pj].Ht[j] += A.Ht[j]; acc[pj].M[j] += A.M[j]; }
@@ -261,12 +273,16 @@ MPPI_HD void quad_aba_solve(M &m, const QPose<T> &P, const QAbaPrep<T> &W, const
     static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
         constexpr int i = ic;
         constexpr int par = T::par[i];
-        const QSV S = {P.revolute(i) ? P.R[i].c[2] : zero, W.Sl[i]};
+        const QSV S = {P.revolute(i) ? P.R2p[i].x : zero, W.Sl[i]};
         const QSV apar = par < 0 ? a0 : a[par < 0 ? 0 : par];
+#if defined(MPPI_DPP_FMAC)
+        qoutward_fused(Wn[i].a, Wn[i].l, apar.a, apar.l, W.cb[i].a, W.cb[i].l, S.a, S.l, kk[i], qdd[i], a[i].a, a[i].l);
+#else
         const QSV ap = {apar.a + W.cb[i].a, apar.l + W.cb[i].l};
-        const QF dd = (u[i] - qdot6(U[i], ap)) * invd[i];
+        const QF dd = kk[i] + qdot6(Wn[i], apar);
         qdd[i] = dd;
         a[i] = {ap.a + dd * S.a, ap.l + dd * S.l};
+#endif
     });
 }
 
@@ -274,8 +290,9 @@ MPPI_HD void quad_aba_solve(M &m, const QPose<T> &P, const QAbaPrep<T> &W, const
 template <class T, class M>
 MPPI_HD void quad_scene_pose(M &m, const SceneState<T> &s, QPose<T> &P) {
     const M3 Rb = quat_to_R(s.base + 3);
-    P.pb = qsel(s.base[0], s.base[1], s.base[2]);
-    for (int c = 0; c < 3; c++) P.Rb.c[c] = qsel(Rb.a[c], Rb.a[3 + c], Rb.a[6 + c]);
+    QM3 Rq;
+    for (int c = 0; c < 3; c++) Rq.c[c] = qsel(Rb.a[c], Rb.a[3 + c], Rb.a[6 + c]);
+    P.set_base(Rq, qsel(s.base[0], s.base[1], s.base[2]));
     QF q[T::NB ? T::NB : 1];
     static_for<0, T::NB>([&](auto ic) MPPI_LAMBDA { q[ic] = qrep(s.q[ic]); });
     quad_fk<T>(m, q, P);
@@ -299,7 +316,7 @@ MPPI_HD void step_scene_quad(M &m0, MR &mr0, const float *root, SceneState<T> &s
         QSV vbase = {qrep(0.f), qrep(0.f)};
         if (m.floating) {
             const QF wb = qsel(s.base[10], s.base[11], s.base[12]), vb = qsel(s.base[7], s.base[8], s.base[9]);
-            vbase = {wb, vb - qcross(wb, P.pb)};
+            vbase = {wb, vb - qcross(wb, P.pos_base())};
         }
         QF qd[NBs];
         static_for<0, NB>([&](auto ic) MPPI_LAMBDA { qd[ic] = qrep(s.qd[ic]); });
@@ -311,9 +328,9 @@ MPPI_HD void step_scene_quad(M &m0, MR &mr0, const float *root, SceneState<T> &s
                 const QSV S = quad_subspace<T, i>(P);
                 const QSV vp = par < 0 ? vbase : v[par < 0 ? 0 : par];
                 v[i] = {vp.a + qd[i] * S.a, vp.l + qd[i] * S.l};
-                qframe_store(L, i, P.R[i], P.p[i], v[i]);
+                qframe_store(L, i, P.rot(i), P.pos(i), v[i]);
             });
-            qframe_store(L, NB, P.Rb, P.pb, vbase);
+            qframe_store(L, NB, P.rot_base(), P.pos_base(), vbase);
             for (int f = 0; f < kMaxFree; f++)
                 if (f < m.n_free) {
                     const float *rs = s.fr[f];
@@ -357,7 +374,7 @@ MPPI_HD void step_scene_quad(M &m0, MR &mr0, const float *root, SceneState<T> &s
             const JointLimits b = lim[i];
             QF v = qd[i] + h * qdd[i];
             // velocity limit and inelastic stops as one pair of bounds (see quad_step in mppi_quad.hpp / joint_limit)
-            const QF lo = qrep(b.lower), hi = qrep(b.upper), z = qrep(0.f), x0 = qrep(s.q[i]);
+            const QF lo = qrep(mr.b[i].k0.lower), hi = qrep(mr.b[i].k0.upper), z = qrep(0.f), x0 = qrep(s.q[i]);
             const QF vlo = qclamp((lo - x0) * inv_h, qrep(-b.vmax), z), vhi = qclamp((hi - x0) * inv_h, z, qrep(b.vmax));
             v = qclamp(v, vlo, vhi);
             const QF x = qclamp(x0 + h * v, lo, hi);

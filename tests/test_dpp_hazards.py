@@ -1,7 +1,8 @@
 """Static check of the hand-written DPP blocks (csrc/mppi_quad.hpp: rotations folded into v_fmac_f32_dpp).  On gfx9 a VGPR read
 through a DPP lane permutation must not have been written during the two preceding wait states; the compiler pads its own DPP
 instructions but does not look into inline assembly, so the blocks are spaced by construction - and this test disassembles
-every gfx950 code object of the built library and checks every DPP instruction in it (tools/check_dpp_hazards.py)."""
+every gfx950 code object of the built library and checks every DPP instruction in it (tools/check_dpp_hazards.py) - and, in the same pass, that no ordinary VALU instruction reads the result of a
+transcendental one in the next issue slot (the second hazard inline assembly can run into on gfx940+)."""
 import os
 import sys
 
@@ -20,6 +21,16 @@ def test_checker_sees_a_hazard_and_accepts_padding(tmp_path):
                    "\tv_fmac_f32_dpp v7, v1, v8 quad_perm:[1,2,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"   # v1: one wait state ago
                    "\tv_mul_f32_e32 v9, v2, v3\n\ts_nop 1\n"
                    "\tv_add_f32_dpp v4, v9, v6 quad_perm:[1,2,0,1] row_mask:0xf bank_mask:0xf\n")             # padded: fine
+    assert chk.check(str(src)) == 1
+
+
+def test_checker_sees_a_transcendental_read_too_early(tmp_path):
+    """gfx940+: the result of v_sin / v_cos / v_rcp ... must not be read by an ordinary VALU instruction in the next issue slot
+    (the packed kinematics block of quad_fk takes (cos q, sin q): it is an operand of the whole block, read six instructions in)"""
+    src = tmp_path / "t.s"
+    src.write_text("\tv_sin_f32_e32 v1, v2\n\tv_pk_mul_f32 v[4:5], v[6:7], v[0:1] op_sel_hi:[1,0]\n"      # hazard
+                   "\tv_cos_f32_e32 v8, v2\n\ts_nop 0\n\tv_mul_f32_e32 v9, v8, v8\n"                      # padded: fine
+                   "\tv_rcp_f32_e32 v10, v2\n\tv_sqrt_f32_e32 v11, v10\n")                                 # trans after trans: fine
     assert chk.check(str(src)) == 1
 
 

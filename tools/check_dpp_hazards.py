@@ -3,12 +3,16 @@
 not have been written by the previous two wait states (VALU instructions; `s_nop N` counts N + 1).  The compiler pads its own DPP
 instructions; the hand-written blocks of csrc/mppi_quad.hpp (rotations folded into v_fmac_f32_dpp) are invisible to its hazard
 recogniser, so their spacing is by construction - and verified here, over every instruction of the listing, whoever emitted it.
+Second hazard checked the same way (gfx940+, "trans forwarding"): a non-transcendental VALU instruction must not read the result
+of a transcendental one (v_sin / v_cos / v_rcp / v_rsq / v_sqrt / v_exp / v_log) in the very next issue slot - again padded by the
+compiler for its own code only (an inline-assembly block that took (cos q, sin q) right behind v_sin_f32 rotated with a stale sine).
     python tools/check_dpp_hazards.py file.s [...]      -> exit status 1 and the offending lines if a hazard is found
     python tools/check_dpp_hazards.py --library libmppi_hip.so   -> the same over the disassembly of every gfx950 code object in the
                                                                  library (llvm-objdump --offloading, then -d)"""
 import re
 import sys
 
+TRANS = re.compile(r"^v_(sin|cos|rcp|rcp_iflag|rsq|sqrt|exp|log|exp_legacy|log_legacy)_(f32|f16|bf16)")
 VREG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
 
 
@@ -25,15 +29,18 @@ def regs(tok):
 def check(path):
     bad = 0
     recent = []   # [(wait states ago, set of vgprs written)]
+    trans = set()  # vgprs written by a transcendental in the previous issue slot
     for ln, line in enumerate(open(path, errors="replace"), 1):
         code = line.split(";")[0].split("//")[0].strip()   # (hipcc -S comments with ';', llvm-objdump -d with '//')
         if not code or code.endswith(":") or code.startswith("."):
             if code.endswith(":"):
+                trans = set()
                 recent = []      # a label: control flow may come from anywhere - the compiler's own padding is trusted across blocks
             continue
         parts = code.split(None, 1)
         op, rest = parts[0], (parts[1] if len(parts) > 1 else "")
         if op == "s_nop":
+            trans = set()
             n = int(rest.strip(), 0) + 1
             recent = [(a + n, w) for a, w in recent if a + n <= 2]
             continue
@@ -46,6 +53,13 @@ def check(path):
                         print(f"{path}:{ln}: DPP read of v{r} {ago} wait state(s) after its write: {code}")
                         bad += 1
         is_valu = op.startswith("v_")
+        if is_valu and trans and not TRANS.match(op):
+            for src in ops[1:]:
+                hit = regs(src.split()[0]) & trans if src else set()
+                if hit:
+                    print(f"{path}:{ln}: v{sorted(hit)[0]} read in the issue slot after the transcendental that wrote it: {code}")
+                    bad += 1
+        trans = regs(ops[0]) if (is_valu and TRANS.match(op) and ops) else set()
         if is_valu or not op.startswith("s_"):   # every non-scalar instruction advances the wait states
             recent = [(a + 1, w) for a, w in recent if a + 1 <= 2]
         elif op.startswith("s_"):
