@@ -242,23 +242,28 @@ __device__ __forceinline__ void qrank1_fused(QF *Ia, QF *Ha, QF *Hta, QF *Ma, QF
         : "v"(sn), "v"(sf), "v"(ua), "v"(ul));
 }
 #endif
-// rotated rows of R Ic R^T - h cw^T:  X_j = Tr0 rot_j(R0) + Tr1 rot_j(R1) + Tr2 rot_j(R2) + nh rot_j(cw); j = 0 comes without
-// its h cw term (the caller adds the diagonal's |h|^2/m - h cw), which also gives the block its three plain leading instructions
-__device__ __forceinline__ void qinertia_rows_fused(const QF *Tr, const QF *Rc, QF nh, QF cw, QF &I0, QF &I1, QF &I2) {
-    QF x0, x1, x2;
-    asm("v_mul_f32 %0, %3, %6\n\t"                      // x0  = Tr0 R0
-        "v_fmac_f32 %0, %4, %7\n\t"                     // x0 += Tr1 R1
-        "v_fmac_f32 %0, %5, %8\n\t"                     // x0 += Tr2 R2
-        "v_mul_f32_dpp %1, %6, %3 " MPPI_R1 "\n\t"      // x1  = rot1(R0) Tr0
-        "v_mul_f32_dpp %2, %6, %3 " MPPI_R2 "\n\t"      // x2  = rot2(R0) Tr0
-        "v_fmac_f32_dpp %1, %7, %4 " MPPI_R1 "\n\t"
-        "v_fmac_f32_dpp %2, %7, %4 " MPPI_R2 "\n\t"
+// rotated rows of the rigid inertia about the world origin, R Ic R^T + m(|c|^2 1 - c c^T) with h = m c, cw = c:
+//   X_j = Tr0 rot_j(R0) + Tr1 rot_j(R1) + Tr2 rot_j(R2) - h rot_j(cw)   (j = 1, 2)
+//   X_0 = Tr0 R0 + Tr1 R1 + Tr2 R2 + rot1(h cw) + rot2(h cw)            (the diagonal: |h|^2/m - h_r cw_r is the sum of the
+//                                                                         OTHER two products - no cross-lane sum, no cancellation)
+__device__ __forceinline__ void qinertia_rows_fused(const QF *Tr, const QF *Rc, QF h, QF cw, QF &I0, QF &I1, QF &I2) {
+    QF x0, x1, x2, t;
+    asm("v_mul_f32 %3, %10, %11\n\t"                    //  1 t   = h cw
+        "v_mul_f32 %0, %4, %7\n\t"                      //  2 x0  = Tr0 R0
+        "v_fmac_f32 %0, %5, %8\n\t"                     //  3 x0 += Tr1 R1
+        "v_fmac_f32 %0, %6, %9\n\t"                     //  4 x0 += Tr2 R2
+        "v_mul_f32_dpp %1, %7, %4 " MPPI_R1 "\n\t"      //  5 x1  = rot1(R0) Tr0
+        "v_mul_f32_dpp %2, %7, %4 " MPPI_R2 "\n\t"      //  6 x2  = rot2(R0) Tr0
         "v_fmac_f32_dpp %1, %8, %5 " MPPI_R1 "\n\t"
         "v_fmac_f32_dpp %2, %8, %5 " MPPI_R2 "\n\t"
-        "v_fmac_f32_dpp %1, %10, %9 " MPPI_R1 "\n\t"    // x1 += rot1(cw) nh
-        "v_fmac_f32_dpp %2, %10, %9 " MPPI_R2
-        : "=&v"(x0), "=&v"(x1), "=&v"(x2)
-        : "v"(Tr[0]), "v"(Tr[1]), "v"(Tr[2]), "v"(Rc[0]), "v"(Rc[1]), "v"(Rc[2]), "v"(nh), "v"(cw));
+        "v_fmac_f32_dpp %1, %9, %6 " MPPI_R1 "\n\t"
+        "v_fmac_f32_dpp %2, %9, %6 " MPPI_R2 "\n\t"
+        "v_fmac_f32_dpp %1, %11, -%10 " MPPI_R1 "\n\t"  // 11 x1 -= rot1(cw) h
+        "v_fmac_f32_dpp %2, %11, -%10 " MPPI_R2 "\n\t"  // 12 x2 -= rot2(cw) h
+        "v_add_f32_dpp %0, %3, %0 " MPPI_R1 "\n\t"      // 13 x0 += rot1(t)          (t written at 1)
+        "v_add_f32_dpp %0, %3, %0 " MPPI_R2               // 14 x0 += rot2(t)
+        : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(t)
+        : "v"(Tr[0]), "v"(Tr[1]), "v"(Tr[2]), "v"(Rc[0]), "v"(Rc[1]), "v"(Rc[2]), "v"(h), "v"(cw));
     I0 = x0;
     I1 = x1;
     I2 = x2;
@@ -518,13 +523,12 @@ MPPI_HD void quad_aba(M &m, const QPose<T, JT> &P, const QF *qd, const QF *tau_e
         QF h, Tr[3];
         qmoments(P.R01[i], P.R2p[i], b, h, Tr);
         const QF cw = b.invm * h;
-        const QF hh = qsum(h * cw);
         const QF h1 = rot1(h), h2 = rot2(h);
         QAI A;
 #if defined(MPPI_DPP_FMAC)
-        qinertia_rows_fused(Tr, R.c, -h, cw, A.I[0], A.I[1], A.I[2]);
-        A.I[0] += hh - h * cw;
+        qinertia_rows_fused(Tr, R.c, h, cw, A.I[0], A.I[1], A.I[2]);
 #else
+        const QF hh = qsum(h * cw);
         A.I[0] = Tr[0] * R.c[0] + Tr[1] * R.c[1] + Tr[2] * R.c[2] + hh - h * cw;
         A.I[1] = Tr[0] * rot1(R.c[0]) + Tr[1] * rot1(R.c[1]) + Tr[2] * rot1(R.c[2]) - h * rot1(cw);
         A.I[2] = Tr[0] * rot2(R.c[0]) + Tr[1] * rot2(R.c[1]) + Tr[2] * rot2(R.c[2]) - h * rot2(cw);
@@ -636,29 +640,39 @@ MPPI_HD void quad_step(M &m0, QPose<T, JT> &P, QF *q, QF *qd, const QF *target) 
     for (int s = 0; s < m0.substeps; s++) {
         M &m = *launder(mp);
         const float h = m.h, kd = m.kd, inv_h = frcp(h);
-        QF tau[NB], kdh[NB], qdd[NB], ff[NB], vs[NB];
+        QF tau[NB], kdh[NB], qdd[NB];
         JointLimits lim[NB];
-        const int drive_mode = m.drive_mode;
-        static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
-            constexpr int i = ic;
-            ff[i] = drive_mode == kDriveEffort ? target[i] : qrep(0.f);
-            vs[i] = drive_mode == kDriveVelocity ? target[i] : qrep(0.f);
-            tau[i] = ff[i] + kd * (vs[i] - qd[i]);
-            kdh[i] = qrep(kd * h);
-        });
+        // joint drives (isaacgym_wrapper.py:491-507): velocity mode tau = kd (target - qd), effort mode tau = target - kd qd,
+        // both with the implicit damping kd h qdd inside the solve.  ONE uniform branch picks the mode (as selects it was four
+        // instructions per joint and substep)
+        const QF kdhq = qrep(kd * h);
+        if (m.drive_mode == kDriveVelocity) {
+            static_for<0, NB>([&](auto ic) MPPI_LAMBDA { tau[ic] = kd * (target[ic] - qd[ic]); });
+        } else {
+            static_for<0, NB>([&](auto ic) MPPI_LAMBDA { tau[ic] = target[ic] - kd * qd[ic]; });
+        }
+        static_for<0, NB>([&](auto ic) MPPI_LAMBDA { kdh[ic] = kdhq; });
         quad_aba<T>(m, P, qd, tau, kdh, qdd, lim);
-        bool any = false;
+        // URDF effort limits: a drive whose torque tau - kd h qdd leaves [-effort, effort] is held at the bound and the step is
+        // solved again without its damping.  The test is one running maximum of |torque| - effort over the joints and one
+        // branch (no limit: effort = +inf, the excess is -inf); the selects live inside the rare branch.
+        QF tt[NB];
+        QF excess = qrep(-INFINITY);
         static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
             constexpr int i = ic;
-            const QF tt = ff[i] + kd * (vs[i] - qd[i] - h * qdd[i]);
-            const QF eff = qrep(lim[i].effort);
-            if (qany_gt(qabs(tt), eff)) {  // (no limit: eff = +inf)
-                any = true;
-                tau[i] = qwhere_gt(tt, qrep(0.f), eff, -eff);
-                kdh[i] = qrep(0.f);
-            }
+            tt[i] = tau[i] - kdhq * qdd[i];
+            excess = qmax(excess, qabs(tt[i]) - qrep(lim[i].effort));
         });
-        if (any) quad_aba<T>(*launder(mp), P, qd, tau, kdh, qdd, lim);
+        if (qany_gt(excess, qrep(0.f))) {
+            static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
+                constexpr int i = ic;
+                const QF eff = qrep(lim[i].effort);
+                const bool sat = qany_gt(qabs(tt[i]), eff);
+                tau[i] = sat ? qwhere_gt(tt[i], qrep(0.f), eff, -eff) : tau[i];
+                kdh[i] = sat ? qrep(0.f) : kdh[i];
+            });
+            quad_aba<T>(*launder(mp), P, qd, tau, kdh, qdd, lim);
+        }
         static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
             constexpr int i = ic;
             const JointLimits b = lim[i];
@@ -791,8 +805,11 @@ MPPI_HD void load_controls_q(LStep &sc, const float *eps, const float *prior, in
     }
 }
 // `leader` is not consulted: the four lanes of a quad hold the same du and store it to the same address (one dword of
-// traffic either way), which replaces seven exec-mask regions per step by plain stores under uniform conditions
-template <int MAXC>
+// traffic either way), which replaces seven exec-mask regions per step by plain stores under uniform conditions.
+// PLAIN: the common case as a compile-time fact - no null-action / prior sample among the samples of this wavefront, every
+// control of the row in use (nu == MAXC), signed control cost: without the four selects per control that the general form pays
+// for them on every step (the caller picks with one uniform branch).
+template <int MAXC, bool PLAIN>
 MPPI_HD float apply_controls_q(LStep &sc, float lambda, bool abs_cost, int nu, int K, const ControlRows<MAXC> &r, int t, int k, bool is_null,
                                bool is_prior, bool /*leader*/, float *du, float *u) {
 #pragma unroll
@@ -802,15 +819,17 @@ MPPI_HD float apply_controls_q(LStep &sc, float lambda, bool abs_cost, int nu, i
 #pragma unroll
     for (int c = 0; c < MAXC; c++) {
         float v = r.Ut[c] + r.e[c];
-        if (is_null) v = 0.f;
-        if (is_prior) v = r.pr[c];
+        if constexpr (!PLAIN) {
+            if (is_null) v = 0.f;
+            if (is_prior) v = r.pr[c];
+        }
         v = clampf(v, lo.v[c], hi.v[c]);
-        const bool on = c < nu;
+        const bool on = PLAIN || c < nu;
         u[c] = on ? v : 0.f;
         const float d = v - r.Ut[c];
         if (on) du[(unsigned)(t * nu + c) * (unsigned)K + (unsigned)k] = d;
         const float term = r.Ut[c] * d * is.v[c];  // inv_sigma is zero beyond nu
-        ctrl += lambda * (abs_cost ? fabsf(term) : term);
+        ctrl += lambda * ((!PLAIN && abs_cost) ? fabsf(term) : term);
     }
     return ctrl;
 }
@@ -835,6 +854,12 @@ MPPI_HD QF quad_rollout(M &m0, CCfg &cfg0, CCost &cost0, LStep &sc, const float 
     constexpr int MAXC = NB < kMaxNu ? NB : kMaxNu;  // nu <= NB: one command per driven body at most
     ControlRows<MAXC> rows;
     load_controls_q<MAXC>(sc, eps, prior, nu, K, 0, k, rows);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const bool special_here = __builtin_amdgcn_ballot_w64(is_null || is_prior) != 0;  // wave-uniform
+#else
+    const bool special_here = is_null || is_prior;
+#endif
+    const bool plain_controls = !special_here && nu == MAXC && !abs_cost;
     QF q[NB], qd[NB], target[NB];
     static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
         constexpr int i = ic;
@@ -849,7 +874,8 @@ MPPI_HD QF quad_rollout(M &m0, CCfg &cfg0, CCost &cost0, LStep &sc, const float 
     M *mp = &m0;
     for (int t = 0; t < H; t++) {
         float u[kMaxNu];
-        ctrl += apply_controls_q<MAXC>(sc, lambda, abs_cost, nu, K, rows, t, k, is_null, is_prior, leader, du, u);
+        ctrl += plain_controls ? apply_controls_q<MAXC, true>(sc, lambda, abs_cost, nu, K, rows, t, k, is_null, is_prior, leader, du, u)
+                               : apply_controls_q<MAXC, false>(sc, lambda, abs_cost, nu, K, rows, t, k, is_null, is_prior, leader, du, u);
         // next step's rows are requested now and consumed after this step's dynamics (the last request re-reads row H-1)
         load_controls_q<MAXC>(sc, eps, prior, nu, K, t + 1 < H ? t + 1 : t, k, rows);
         if (cmd_identity) {  // fixed-base arms, the point robot: one unit-gain command per body

@@ -90,12 +90,11 @@ MPPI_HD V3 qv3_gather(QF x) { return V3{qget<0>(x), qget<1>(x), qget<2>(x)}; }
 MPPI_HD void qrigid_tail(const QM3 &R, float mass, QF h, const QF *Tr, const QSV &v, QAI &A, QSV &pA) {
     const float invm = mass > 0.f ? frcp(mass) : 0.f;
     const QF cw = invm * h;
-    const QF hh = qsum(h * cw);
     const QF h1 = rot1(h), h2 = rot2(h);
 #if defined(MPPI_DPP_FMAC)
-    qinertia_rows_fused(Tr, R.c, -h, cw, A.I[0], A.I[1], A.I[2]);   // (rotations folded into the multiply-adds, mppi_quad.hpp)
-    A.I[0] += hh - h * cw;
+    qinertia_rows_fused(Tr, R.c, h, cw, A.I[0], A.I[1], A.I[2]);   // (rotations folded into the multiply-adds, mppi_quad.hpp)
 #else
+    const QF hh = qsum(h * cw);
     A.I[0] = Tr[0] * R.c[0] + Tr[1] * R.c[1] + Tr[2] * R.c[2] + hh - h * cw;
     A.I[1] = Tr[0] * rot1(R.c[0]) + Tr[1] * rot1(R.c[1]) + Tr[2] * rot1(R.c[2]) - h * rot1(cw);
     A.I[2] = Tr[0] * rot2(R.c[0]) + Tr[1] * rot2(R.c[1]) + Tr[2] * rot2(R.c[2]) - h * rot2(cw);
