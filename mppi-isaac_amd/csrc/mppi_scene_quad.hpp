@@ -339,34 +339,40 @@ MPPI_HD void step_scene_quad(M &m0, MR &mr0, const float *root, SceneState<T> &s
         }
         MPPI_SEC(0);
         const unsigned touched = contact_forces<T, SPLIT>(m, root, L, s.acc_dirty, s.cf_dirty, split);
-        QF tau[NBs], kdh[NBs], qdd[NBs], ff[NBs], vs[NBs];
+        QF tau[NBs], kdh[NBs], qdd[NBs];
         JointLimits lim[NBs];
-        const int drive_mode = m.drive_mode;
-        static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
-            constexpr int i = ic;
-            ff[i] = qrep(drive_mode == kDriveEffort ? target[i] : 0.f);
-            vs[i] = qrep(drive_mode == kDriveVelocity ? target[i] : 0.f);
-            tau[i] = ff[i] + kd * (vs[i] - qd[i]);
-            kdh[i] = qrep(kd * h);
-        });
+        // joint drives and the effort-limit test: as in quad_step (mppi_quad.hpp) - one uniform branch for the drive mode,
+        // one running maximum for the saturation test, the selects inside the rare branch
+        const QF kdhq = qrep(kd * h);
+        if (m.drive_mode == kDriveVelocity) {
+            static_for<0, NB>([&](auto ic) MPPI_LAMBDA { tau[ic] = kd * (qrep(target[ic]) - qd[ic]); });
+        } else {
+            static_for<0, NB>([&](auto ic) MPPI_LAMBDA { tau[ic] = qrep(target[ic]) - kd * qd[ic]; });
+        }
+        static_for<0, NB>([&](auto ic) MPPI_LAMBDA { kdh[ic] = kdhq; });
         SV abase;
         QAbaPrep<T> prep;
         quad_aba_prepare<T>(mr, P, vbase, qd, L, touched, prep, lim);
         MPPI_SEC(4);
         quad_aba_solve<T>(mr, P, prep, tau, kdh, qdd, abase);
         MPPI_SEC(5);
-        bool any = false;
+        QF tt[NBs];
+        QF excess = qrep(-INFINITY);
         static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
             constexpr int i = ic;
-            const QF tt = ff[i] + kd * (vs[i] - qd[i] - h * qdd[i]);
-            const QF eff = qrep(lim[i].effort);
-            if (qany_gt(qabs(tt), eff)) {  // (no limit: eff = +inf)
-                any = true;
-                tau[i] = qwhere_gt(tt, qrep(0.f), eff, -eff);
-                kdh[i] = qrep(0.f);
-            }
+            tt[i] = tau[i] - kdhq * qdd[i];
+            excess = qmax(excess, qabs(tt[i]) - qrep(lim[i].effort));  // (no limit: effort = +inf)
         });
-        if (any) quad_aba_solve<T>(*launder(mrp), P, prep, tau, kdh, qdd, abase);
+        if (qany_gt(excess, qrep(0.f))) {
+            static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
+                constexpr int i = ic;
+                const QF eff = qrep(lim[i].effort);
+                const bool sat = qany_gt(qabs(tt[i]), eff);
+                tau[i] = sat ? qwhere_gt(tt[i], qrep(0.f), eff, -eff) : tau[i];
+                kdh[i] = sat ? qrep(0.f) : kdh[i];
+            });
+            quad_aba_solve<T>(*launder(mrp), P, prep, tau, kdh, qdd, abase);
+        }
         MPPI_SEC(6);
         static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
             constexpr int i = ic;
