@@ -313,24 +313,48 @@ __device__ __forceinline__ void qbias_force_fused(QF I0, QF I1, QF I2, QF h, QF 
         : "=&v"(pAa), "=&v"(pAl), "=&v"(n), "=&v"(f), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4)
         : "v"(I0), "v"(I1), "v"(I2), "v"(h), "v"(m), "v"(w), "v"(vl));
 }
-// the two 6-dots of a joint with their consumers: d = kdh + S.x and u = tau - S.y, summed over the quad from broadcasts in
-// every lane alike ((c + t0) + t1) + t2 - replicated scalars stay bit-identical across the quad - and interleaved so that no
-// DPP read follows the write of its operand (a dot on its own is mul, fmac, WAIT, DPP, DPP, WAIT, DPP)
+// One joint of the inward pass after U = IA S:  d = kdh + S.U,  u = tau - S.pA,  1/d,  W = -U/d.  The 6-dots are summed over
+// the quad from broadcasts, in every lane alike ((c + t0) + t1) + t2 - replicated scalars stay bit-identical across the quad -
+// and interleaved so that no DPP read follows the write of its operand (a dot on its own is mul, fmac, WAIT, DPP, DPP, WAIT,
+// DPP).  1/d is the hardware reciprocal (1 ulp; the Newton step that used to follow bought nothing the 1e-4 cost tolerance
+// sees); it sits two instructions before the end of the block, so that whatever reads it next is past the wait state a
+// transcendental's result needs (gfx940+: no VALU read in the issue slot right behind it - the compiler does not see into here).
 #define MPPI_B(k) "quad_perm:[" #k "," #k "," #k "," #k "] row_mask:0xf bank_mask:0xf bound_ctrl:1"
-__device__ __forceinline__ void qdot6_pair_fused(QF Sa, QF Sl, QF xa, QF xl, QF ya, QF yl, QF kdh, QF tau, QF &d, QF &u) {
-    QF t1, t2;
-    asm("v_mul_f32 %2, %4, %6\n\t"                       //  1 t1  = Sa xa
-        "v_fmac_f32 %2, %5, %7\n\t"                      //  2 t1 += Sl xl
-        "v_mul_f32 %3, %4, %8\n\t"                       //  3 t2  = Sa ya
-        "v_fmac_f32 %3, %5, %9\n\t"                      //  4 t2 += Sl yl
-        "v_add_f32_dpp %0, %2, %10 " MPPI_B(0) "\n\t"    //  5 d   = t1[0] + kdh      (t1 written at 2)
-        "v_add_f32_dpp %0, %2, %0 " MPPI_B(1) "\n\t"     //  6 d  += t1[1]
-        "v_subrev_f32_dpp %1, %3, %11 " MPPI_B(0) "\n\t" //  7 u   = tau - t2[0]      (t2 written at 4)
-        "v_add_f32_dpp %0, %2, %0 " MPPI_B(2) "\n\t"     //  8 d  += t1[2]
-        "v_subrev_f32_dpp %1, %3, %1 " MPPI_B(1) "\n\t"  //  9 u  -= t2[1]
-        "v_subrev_f32_dpp %1, %3, %1 " MPPI_B(2)           // 10 u  -= t2[2]
-        : "=&v"(d), "=&v"(u), "=&v"(t1), "=&v"(t2)
-        : "v"(Sa), "v"(Sl), "v"(xa), "v"(xl), "v"(ya), "v"(yl), "v"(kdh), "v"(tau));
+__device__ __forceinline__ void qjoint_fused(QF Sa, QF Sl, QF Ua, QF Ul, QF pa, QF pl, QF kdh, QF tau, QF &u, QF &invd, QF &Wa, QF &Wl) {
+    QF d, t1, t2;
+    asm("v_mul_f32 %5, %7, %9\n\t"                        //  1 t1  = Sa Ua
+        "v_fmac_f32 %5, %8, %10\n\t"                      //  2 t1 += Sl Ul
+        "v_mul_f32 %6, %7, %11\n\t"                       //  3 t2  = Sa pa
+        "v_fmac_f32 %6, %8, %12\n\t"                      //  4 t2 += Sl pl
+        "v_add_f32_dpp %4, %5, %13 " MPPI_B(0) "\n\t"     //  5 d   = t1[0] + kdh      (t1 written at 2)
+        "v_add_f32_dpp %4, %5, %4 " MPPI_B(1) "\n\t"      //  6 d  += t1[1]
+        "v_subrev_f32_dpp %0, %6, %14 " MPPI_B(0) "\n\t"  //  7 u   = tau - t2[0]      (t2 written at 4)
+        "v_add_f32_dpp %4, %5, %4 " MPPI_B(2) "\n\t"      //  8 d  += t1[2]
+        "v_subrev_f32_dpp %0, %6, %0 " MPPI_B(1) "\n\t"   //  9 u  -= t2[1]
+        "v_rcp_f32 %1, %4\n\t"                            // 10 1/d
+        "v_subrev_f32_dpp %0, %6, %0 " MPPI_B(2) "\n\t"   // 11 u  -= t2[2]
+        "v_mul_f32 %2, %9, -%1\n\t"                       // 12 Wa  = -Ua / d          (1/d written at 10)
+        "v_mul_f32 %3, %10, -%1"                           // 13 Wl  = -Ul / d
+        : "=&v"(u), "=&v"(invd), "=&v"(Wa), "=&v"(Wl), "=&v"(d), "=&v"(t1), "=&v"(t2)
+        : "v"(Sa), "v"(Sl), "v"(Ua), "v"(Ul), "v"(pa), "v"(pl), "v"(kdh), "v"(tau));
+}
+// ... and what goes on to the parent:  k = (u - U.c)/d,  pa = pA + IA c + k U  (IA c from the caller); the two sums pA + IA c
+// fill the wait between the dot's products and their first DPP read
+__device__ __forceinline__ void qbias_to_parent_fused(QF Ua, QF Ul, QF ca, QF cl, QF u, QF invd, QF pAa, QF pAl, QF Aca, QF Acl, QF &k, QF &paa,
+                                                      QF &pal) {
+    QF t;
+    asm("v_mul_f32 %3, %4, %6\n\t"                        //  1 t    = Ua ca
+        "v_fmac_f32 %3, %5, %7\n\t"                       //  2 t   += Ul cl
+        "v_add_f32 %1, %10, %12\n\t"                      //  3 paa  = pAa + (IA c).a
+        "v_add_f32 %2, %11, %13\n\t"                      //  4 pal  = pAl + (IA c).l
+        "v_subrev_f32_dpp %0, %3, %8 " MPPI_B(0) "\n\t"   //  5 k    = u - t[0]         (t written at 2)
+        "v_subrev_f32_dpp %0, %3, %0 " MPPI_B(1) "\n\t"   //  6 k   -= t[1]
+        "v_subrev_f32_dpp %0, %3, %0 " MPPI_B(2) "\n\t"   //  7 k   -= t[2]
+        "v_mul_f32 %0, %0, %9\n\t"                        //  8 k   *= 1/d
+        "v_fmac_f32 %1, %0, %4\n\t"                       //  9 paa += k Ua
+        "v_fmac_f32 %2, %0, %5"                            // 10 pal += k Ul
+        : "=&v"(k), "=&v"(paa), "=&v"(pal), "=&v"(t)
+        : "v"(Ua), "v"(Ul), "v"(ca), "v"(cl), "v"(u), "v"(invd), "v"(pAa), "v"(pAl), "v"(Aca), "v"(Acl));
 }
 // outward pass of one joint: qdd = k + W . a_parent,  a = (a_parent + c) + qdd S; the two sums a_parent + c fill the wait
 // between the dot's products and their first DPP read
@@ -490,11 +514,19 @@ MPPI_HD void quad_aba(M &m, const QPose<T, JT> &P, const QF *qd, const QF *tau_e
     bool has_acc[NB];
     const QF zero = qrep(0.f);
     // pass 1: velocities, and the two quantities both later sweeps need: S_i and c_i = v_parent x (S_i qd_i)
+    // (the linear parts p x az of all joints first, products before their common rotation: the rotation reads its operand
+    // through DPP two wait states after the write - with the other joints' products in between nobody waits)
+    QF St[NB];
+    static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
+        constexpr int i = ic;
+        const QF az = P.R2p[i].x, p = P.pos(i);
+        St[i] = P.revolute(i) ? p * rot1(az) - rot1(p) * az : az;
+    });
+    static_for<0, NB>([&](auto ic) MPPI_LAMBDA { Sl[ic] = P.revolute(ic) ? rot1(St[ic]) : St[ic]; });
     static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
         constexpr int i = ic;
         constexpr int par = T::par[i];
-        const QSV S = quad_subspace<T, i>(P);
-        Sl[i] = S.l;
+        const QSV S = {P.revolute(i) ? P.R2p[i].x : zero, Sl[i]};
         const QSV sj = {qd[i] * S.a, qd[i] * S.l};
         if constexpr (par < 0) {
             v[i] = sj;
@@ -561,24 +593,28 @@ MPPI_HD void quad_aba(M &m, const QPose<T, JT> &P, const QF *qd, const QF *tau_e
             pA = {pA.a + pacc[i].a, pA.l + pacc[i].l};
         }
         const QSV Ui = qmul(A, S);
-#if defined(MPPI_DPP_FMAC) && !defined(MPPI_NO_PAIR_DOT)
-        QF d, ui;
-        qdot6_pair_fused(S.a, S.l, Ui.a, Ui.l, pA.a, pA.l, kdh[i], tau_exp[i], d, ui);
-        const QF invd = qrcp(d);
+#if defined(MPPI_DPP_FMAC)
+        QF ui, invd;
+        qjoint_fused(S.a, S.l, Ui.a, Ui.l, pA.a, pA.l, kdh[i], tau_exp[i], ui, invd, W[i].a, W[i].l);
 #else
         const QF invd = qrcp(qdot6(S, Ui) + kdh[i]), ui = tau_exp[i] - qdot6(S, pA);
-#endif
         // what the outward pass needs of this joint: qdd_i = k_i + W_i . a_parent with W = -U/d and k = (u - U.c)/d
         // (the parent's acceleration enters through one dot; c_i is already folded into k_i here)
         const QF ninvd = -invd;
         W[i] = {Ui.a * ninvd, Ui.l * ninvd};
+#endif
         if constexpr (par < 0) kk[i] = ui * invd;
         if constexpr (par >= 0) {
             const QSV c = cb[i];
             const QSV Ac = qmul(A, c);
+#if defined(MPPI_DPP_FMAC)
+            QSV pa;
+            qbias_to_parent_fused(Ui.a, Ui.l, c.a, c.l, ui, invd, pA.a, pA.l, Ac.a, Ac.l, kk[i], pa.a, pa.l);
+#else
             const QF k = (ui - qdot6(Ui, c)) * invd;
             kk[i] = k;
             const QSV pa = {pA.a + Ac.a + k * Ui.a, pA.l + Ac.l + k * Ui.l};
+#endif
             // Ia = IA - U U^T / d  (rotated rows: X[r][(r+j)%3] += W_r * rot_j(U))
 #if defined(MPPI_DPP_FMAC)
             qrank1_fused(A.I, A.H, A.Ht, A.M, W[i].a, W[i].l, Ui.a, Ui.l);

@@ -219,21 +219,25 @@ MPPI_HD void quad_aba_solve(M &m, const QPose<T> &P, const QAbaPrep<T> &W, const
         }
         const QSV Ui = qmul(A, S);
 #if defined(MPPI_DPP_FMAC)
-        QF d, ui;
-        qdot6_pair_fused(S.a, S.l, Ui.a, Ui.l, pA.a, pA.l, kdh[i], tau_exp[i], d, ui);
-        const QF invd = qrcp(d);
+        QF ui, invd;
+        qjoint_fused(S.a, S.l, Ui.a, Ui.l, pA.a, pA.l, kdh[i], tau_exp[i], ui, invd, Wn[i].a, Wn[i].l);
 #else
         const QF invd = qrcp(qdot6(S, Ui) + kdh[i]), ui = tau_exp[i] - qdot6(S, pA);
-#endif
         const QF ninvd = -invd;
         Wn[i] = {Ui.a * ninvd, Ui.l * ninvd};
+#endif
         const QSV c = W.cb[i];
-        const QF k = (ui - qdot6(Ui, c)) * invd;
-        kk[i] = k;
         constexpr int pj = par < 0 ? NB : par;  // the base accumulator lives at index NB
         if (par >= 0 || floating) {
             const QSV Ac = qmul(A, c);
+#if defined(MPPI_DPP_FMAC)
+            QSV pa;
+            qbias_to_parent_fused(Ui.a, Ui.l, c.a, c.l, ui, invd, pA.a, pA.l, Ac.a, Ac.l, kk[i], pa.a, pa.l);
+#else
+            const QF k = (ui - qdot6(Ui, c)) * invd;
+            kk[i] = k;
             const QSV pa = {pA.a + Ac.a + k * Ui.a, pA.l + Ac.l + k * Ui.l};
+#endif
 #if defined(MPPI_DPP_FMAC)
             qrank1_fused(A.I, A.H, A.Ht, A.M, Wn[i].a, Wn[i].l, Ui.a, Ui.l);
 #else
@@ -252,6 +256,8 @@ MPPI_HD void quad_aba_solve(M &m, const QPose<T> &P, const QAbaPrep<T> &W, const
                 pacc[pj] = pa;
                 has_acc[pj] = true;
             }
+        } else {
+            kk[i] = (ui - qdot6(Ui, c)) * invd;  // (a fixed root: nothing goes on to a parent)
         }
     });
     abase = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
