@@ -439,12 +439,22 @@ MPPI_HD void qmoments(QF2 R01, QF2 R2p, const BodyK1 &b, QF &h, QF *Tr) {
 #endif
 }
 
+// all kinematic blocks are requested up front (LDS returns in order, so body i only waits for its own
+// block while the later ones stream in behind the arithmetic)
+template <class T, class M>
+MPPI_HD void quad_fk_blocks(M &m, BodyK0 *blk) {
+    static_for<0, T::NB>([&](auto ic) MPPI_LAMBDA { blk[ic] = load_block<BodyK0>(m.b[ic].k0); });
+}
+template <class T, int JT>
+MPPI_HD void quad_fk_from(const BodyK0 *blk, const QF *q, QPose<T, JT> &P);
 template <class T, class M, int JT>
 MPPI_HD void quad_fk(M &m, const QF *q, QPose<T, JT> &P) {
-    // all kinematic blocks are requested up front (LDS returns in order, so body i only waits for its own
-    // block while the later ones stream in behind the arithmetic)
     BodyK0 blk[T::NB ? T::NB : 1];
-    static_for<0, T::NB>([&](auto ic) MPPI_LAMBDA { blk[ic] = load_block<BodyK0>(m.b[ic].k0); });
+    quad_fk_blocks<T>(m, blk);
+    quad_fk_from<T, JT>(blk, q, P);
+}
+template <class T, int JT>
+MPPI_HD void quad_fk_from(const BodyK0 *blk, const QF *q, QPose<T, JT> &P) {
     static_for<0, T::NB>([&](auto ic) MPPI_LAMBDA {
         constexpr int i = ic;
         constexpr int par = T::par[i];
@@ -709,6 +719,10 @@ MPPI_HD void quad_step(M &m0, QPose<T, JT> &P, QF *q, QF *qd, const QF *target) 
             });
             quad_aba<T>(*launder(mp), P, qd, tau, kdh, qdd, lim);
         }
+        // the kinematic blocks of the NEXT pose are requested here: they carry the joint ranges the integration needs, and
+        // their round trip runs under the integration's arithmetic
+        BodyK0 blk0[NB];
+        quad_fk_blocks<T>(*launder(mp), blk0);
         static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
             constexpr int i = ic;
             const JointLimits b = lim[i];
@@ -720,7 +734,7 @@ MPPI_HD void quad_step(M &m0, QPose<T, JT> &P, QF *q, QF *qd, const QF *target) 
                 // ve = (limit - x_old) / h, never pointing back out of the range.  x_old + h v < lo is the same as v < ve_lo, so
                 // the stop is the unconditional bound v >= min(ve_lo, 0) - and the two clamps compose into one because both
                 // intervals contain 0: v in [med3(ve_lo, -vmax, 0), med3(ve_hi, 0, vmax)]
-                const QF lo = qrep(m.b[i].k0.lower), hi = qrep(m.b[i].k0.upper), z = qrep(0.f);  // (absent: -inf, +inf)
+                const QF lo = qrep(blk0[i].lower), hi = qrep(blk0[i].upper), z = qrep(0.f);  // (absent: -inf, +inf)
                 const QF vlo = qclamp((lo - q[i]) * inv_h, qrep(-b.vmax), z), vhi = qclamp((hi - q[i]) * inv_h, z, qrep(b.vmax));
                 v = qclamp(v, vlo, vhi);
                 x = qclamp(q[i] + h * v, lo, hi);
@@ -728,7 +742,7 @@ MPPI_HD void quad_step(M &m0, QPose<T, JT> &P, QF *q, QF *qd, const QF *target) 
             q[i] = x;
             qd[i] = v;
         });
-        quad_fk<T>(*launder(mp), q, P);
+        quad_fk_from<T, JT>(blk0, q, P);
     }
 }
 
