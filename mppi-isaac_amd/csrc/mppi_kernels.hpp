@@ -752,6 +752,7 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW))
     unsigned *tab = reinterpret_cast<unsigned *>(lds + (size_t)SPW * row);
     scene_table_fill(M, tab, threadIdx.x, kWave * NW);
     LMem L{lds + (lane / LPS), SPW, tab};
+    L.cm = 11 * (lane / LPS);
 #if defined(MPPI_CHECK)
     L.limit = row;  // (floats of one sample's rows: any index beyond them belongs to the wave's table or to nobody)
 #endif
@@ -888,7 +889,8 @@ __global__ __launch_bounds__(kWave) void k_sim_step_scene_quad(const DevModel *_
     const int lane4 = threadIdx.x & 3;
     const bool leader = lane4 == 0;
     const Split split{lane4, 4};
-    const LMem L{lds + (threadIdx.x >> 2), 16};
+    LMem L{lds + (threadIdx.x >> 2), 16};
+    L.cm = 11 * (int)(threadIdx.x >> 2);
     CModel &M = *(CModel *)m;
     SceneState<T> s;
     static_for<0, NB>([&](auto ic) {

@@ -70,6 +70,8 @@ struct LMem {
     int park = 0;
     // origin of the rollout's coordinates (root_relative): added back to the positions a rollout writes out
     float ox = 0.f, oy = 0.f;
+    // 11 x this sample's position in the row group (the component-minor shape-pose cache, shape_cached below)
+    int cm = 0;
 #if defined(MPPI_CHECK)
     // check build (MPPI_BUILD_VARIANT=check, tests/test_gpu_check_build.py): every access to the sample's rows is bounds-checked
     // against the row length the kernel allocated; a violation traps (the launch fails instead of corrupting a neighbour's row)
@@ -617,6 +619,40 @@ MPPI_HD ShapeW shape_world(SH &S, const float *root, const LMem &L) {
 // dealt over the lanes; static shapes are posed once per rollout, the others once per substep.
 template <class T, class M>
 MPPI_HD int shape_cache_base(M &m) { return SceneLayout<T>::kCf + 3 * m.n_rb + 5 * m.n_rnd; }
+// The cache region - rows [base, base + 12 n_shapes) of every sample of the row group - is laid out COMPONENT-MINOR, unlike the
+// sample-minor rows around it: the twelve floats of (shape i, sample s) are consecutive, at  region + (i * stride + s) * 12.
+// A pose is then three 16-byte LDS accesses instead of twelve 4-byte ones, and the lanes that look up DIFFERENT shapes at the
+// same time (dealt shape posing, dealt broad phase) no longer meet in one bank: with sample-minor rows shape i's component c of
+// sample s sits in bank (96 i + 8 c + s) mod 32 = (8 c + s) mod 32 whatever i is - an 8-way conflict for an octet whose lanes
+// hold eight shapes (the bulk of the 45 k conflict cycles per wavefront the SQ counters show for the gripper scene); here the
+// eight samples of a 16-byte access cover banks 12 s .. 12 s + 3 (mod 32), all 32 of them once.
+// (L.p points at this sample's column of the sample-minor rows: L.cm = 11 x sample turns that into the slot's address.)
+MPPI_HD float *shape_cache_slot(const LMem &L, int base, int i) { return L.p + (size_t)(base + 12 * i) * L.stride + L.cm; }
+struct Pose12 {
+    float v[12];
+};
+MPPI_HD Pose12 pose12_load(const float *o) {
+    Pose12 q;
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 a = reinterpret_cast<const f4 *>(o)[0], b = reinterpret_cast<const f4 *>(o)[1], c = reinterpret_cast<const f4 *>(o)[2];
+    q.v[0] = a.x; q.v[1] = a.y; q.v[2] = a.z; q.v[3] = a.w; q.v[4] = b.x; q.v[5] = b.y; q.v[6] = b.z; q.v[7] = b.w;
+    q.v[8] = c.x; q.v[9] = c.y; q.v[10] = c.z; q.v[11] = c.w;
+#else
+    for (int j = 0; j < 12; j++) q.v[j] = o[j];
+#endif
+    return q;
+}
+MPPI_HD void pose12_store(float *o, const Pose12 &q) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    reinterpret_cast<f4 *>(o)[0] = f4{q.v[0], q.v[1], q.v[2], q.v[3]};
+    reinterpret_cast<f4 *>(o)[1] = f4{q.v[4], q.v[5], q.v[6], q.v[7]};
+    reinterpret_cast<f4 *>(o)[2] = f4{q.v[8], q.v[9], q.v[10], q.v[11]};
+#else
+    for (int j = 0; j < 12; j++) o[j] = q.v[j];
+#endif
+}
 // TAB: the caller knows that the wave-shared table exists (octet rollout kernels) - the per-lane fetch of shape records from
 // the model is then not even compiled (its 64-bit per-lane address cost the helper-wavefront kernel a spilled register pair)
 template <class T, bool TAB = false, class M>
@@ -633,17 +669,19 @@ MPPI_HD void shape_cache_update(M &m, const float *root, const LMem &L, Split sp
             if ((S.ent < 0) != statics) continue;
             w = shape_world(S, root, L);
         }
-        const int o = base + 12 * i;
-        for (int j = 0; j < 9; j++) L[o + j] = w.R.a[j];
-        L[o + 9] = w.p.x; L[o + 10] = w.p.y; L[o + 11] = w.p.z;
+        float *o = shape_cache_slot(L, base, i);
+        Pose12 q;
+        for (int j = 0; j < 9; j++) q.v[j] = w.R.a[j];
+        q.v[9] = w.p.x; q.v[10] = w.p.y; q.v[11] = w.p.z;
+        pose12_store(o, q);
     }
 }
 template <class T, class M>
 MPPI_HD ShapeW shape_cached(M &m, int i, const LMem &L) {
-    const int o = shape_cache_base<T>(m) + 12 * i;
+    const Pose12 q = pose12_load(shape_cache_slot(L, shape_cache_base<T>(m), i));
     ShapeW w;
-    for (int j = 0; j < 9; j++) w.R.a[j] = L[o + j];
-    w.p = {L[o + 9], L[o + 10], L[o + 11]};
+    for (int j = 0; j < 9; j++) w.R.a[j] = q.v[j];
+    w.p = {q.v[9], q.v[10], q.v[11]};
     w.v = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
     return w;
 }
