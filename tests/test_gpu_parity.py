@@ -86,6 +86,37 @@ def test_sample_rollout_update_match_oracle(make, K, H, lib, oracle64):
     c.close()
 
 
+@pytest.mark.parametrize("mode", ["", "lane"])
+def test_effort_saturated_drives_match_oracle(mode, lib, oracle64, monkeypatch):
+    """The second articulated-body solve of a substep (drives held at their effort limit, quad_step's rare branch): the stock
+    panda never gets there on the reach task (the implicit damping keeps the drive torque at a sixteenth of kd times the velocity
+    error), so the URDF limits are cut to 4 N m / 2 N m here - then most substeps of most samples saturate one joint or several.
+    Quad kernel (default) and one-lane kernel against the fp64 oracle, per sample."""
+    if mode:
+        monkeypatch.setenv("MPPI_ROLLOUT", mode)
+    K, H = 512, 12
+    scene, m, cfg, cost, dof, root = panda_reach(K=K, H=H)
+    for i in range(m.n_bodies):
+        m.bodies[i].effort = 4.0 if i < 4 else 2.0
+    c = Ctx(m, cfg, cost)
+    c.call("mppi_sample", C.c_uint32(0))
+    eps = c.get("mppi_get_noise", (H, cfg.nu, K))
+    rng = np.random.default_rng(1)
+    U0 = (0.3 * rng.normal(size=(H, cfg.nu))).astype(np.float32)
+    c.set_state(dof, root)
+    c.set_U(U0)
+    c.call("mppi_rollout")
+    S = c.get("mppi_get_costs", (K,))
+    c.close()
+    So, _, _ = oracle64.rollout(m, cfg, cost, dof, root, U0, eps)
+    # the limits matter: the same rollouts with the stock limits cost something else
+    for i in range(m.n_bodies):
+        m.bodies[i].effort = 87.0
+    Sfree, _, _ = oracle64.rollout(m, cfg, cost, dof, root, U0, eps)
+    assert np.mean(np.abs(Sfree - So) > 1e-3 * np.abs(So)) > 0.7
+    np.testing.assert_allclose(S, So, rtol=2e-4)
+
+
 def test_closed_loop_matches_oracle(lib, oracle64):
     """5 closed-loop iterations: planner (K=256) + K=1 world on the device vs the same loop on the oracle."""
     scene, m, cfg, cost, dof, root = panda_reach(K=256, H=12)
