@@ -126,16 +126,21 @@ MPPI_HD void root_origin(M &m, const float *root, float &ox, float &oy) {
     ox = m.floating ? r[13 * m.robot_actor] : 0.f;
     oy = m.floating ? r[13 * m.robot_actor + 1] : 0.f;
 }
-// layout of the table: n_shapes records of kTabShape dwords (DevShape as is), then n_pairs geometry blocks of 16 dwords
+// layout of the table: n_shapes records of kTabShape dwords (DevShape as is), then n_pairs geometry blocks of 16 dwords at a
+// pitch of kTabPair = 20: the lanes of an octet read eight CONSECUTIVE blocks with 16-byte accesses (dealt broad phase), and at
+// a pitch of 16 dwords blocks j and j + 2 start in the same bank (4-way conflicts on every access); at 20 the eight accesses
+// cover the 32 banks once (20 j mod 32 = 0, 20, 8, 28, 16, 4, 24, 12)
 constexpr int kTabShape = (int)(sizeof(DevShape) / 4);
+constexpr int kTabPair = 20;
 static_assert(sizeof(DevShape) == 80 && sizeof(PairGeom) == 64 && sizeof(DevPair) == 128, "table layout");
-MPPI_HD constexpr int scene_table_dwords(int n_shapes, int n_pairs) { return kTabShape * n_shapes + 16 * n_pairs; }
+MPPI_HD constexpr int scene_table_dwords(int n_shapes, int n_pairs) { return kTabShape * n_shapes + kTabPair * n_pairs; }
 // cooperative fill by the 64 lanes of the wavefront
 template <class M>
 MPPI_HD void scene_table_fill(M &m, unsigned *tab, int lane, int lanes) {
     const int ns = m.n_shapes, np = m.n_pairs;
     for (int i = lane; i < kTabShape * ns; i += lanes) tab[i] = reinterpret_cast<const MPPI_CONST_AS unsigned *>(&m.sh[0])[i];
-    for (int i = lane; i < 16 * np; i += lanes) tab[kTabShape * ns + i] = reinterpret_cast<const MPPI_CONST_AS unsigned *>(&m.pr[i >> 4].g)[i & 15];
+    for (int i = lane; i < 16 * np; i += lanes)
+        tab[kTabShape * ns + kTabPair * (i >> 4) + (i & 15)] = reinterpret_cast<const MPPI_CONST_AS unsigned *>(&m.pr[i >> 4].g)[i & 15];
 }
 struct TabShape {  // the fields shape_world() reads, from the table
     int ent, src_actor;
@@ -153,7 +158,7 @@ MPPI_HD TabShape tab_shape(const LMem &L, int i) {
 template <class M>
 MPPI_HD PairGeom tab_pair_geom(M &m, const LMem &L, int ip) {
     PairGeom G;
-    __builtin_memcpy(&G, L.tab + kTabShape * m.n_shapes + 16 * ip, 64);
+    __builtin_memcpy(&G, L.tab + kTabShape * m.n_shapes + kTabPair * ip, 64);
     return G;
 }
 
@@ -627,6 +632,9 @@ MPPI_HD int shape_cache_base(M &m) { return SceneLayout<T>::kCf + 3 * m.n_rb + 5
 // hold eight shapes (the bulk of the 45 k conflict cycles per wavefront the SQ counters show for the gripper scene); here the
 // eight samples of a 16-byte access cover banks 12 s .. 12 s + 3 (mod 32), all 32 of them once.
 // (L.p points at this sample's column of the sample-minor rows: L.cm = 11 x sample turns that into the slot's address.)
+// The same layout for the FRAMES region (18 floats per frame, 8-byte accesses) was built and measured, round 3: 5 % fewer LDS
+// instructions in the gripper scene's kernel, -0.8 % kernel time there, +0.7 % on the pushing scene, bank conflicts unchanged
+// (22 k per wavefront: they are not the frames') - not kept.
 MPPI_HD float *shape_cache_slot(const LMem &L, int base, int i) { return L.p + (size_t)(base + 12 * i) * L.stride + L.cm; }
 struct Pose12 {
     float v[12];
