@@ -293,12 +293,25 @@ __global__ __launch_bounds__(kWave) void k_rollout_quad(const DevModel *__restri
     // every block), no SGPR spills, no constant-bus moves.
     constexpr int kModelBytes = (int)((offsetof(DevModel, fr) + 15) / 16 * 16);
     __shared__ __attribute__((aligned(64))) uint4 s_model[kModelBytes / 16];
-    for (int i = threadIdx.x; i < kModelBytes / 16; i += kWave) s_model[i] = reinterpret_cast<const uint4 *>(m)[i];
+    // (the model's loads are all requested first and written to LDS last: their round trip to memory runs under the
+    // staging of the step constants, which has round trips of its own)
+    constexpr int kModelTrips = (kModelBytes / 16 + kWave - 1) / kWave;
+    uint4 mv[kModelTrips];
+#pragma unroll
+    for (int it = 0; it < kModelTrips; it++) {
+        const int i = (int)threadIdx.x + it * kWave;
+        if (i < kModelBytes / 16) mv[it] = reinterpret_cast<const uint4 *>(m)[i];
+    }
     // ... and the step loop's own constants (control limits, nominal rows, cost target and weights)
     __shared__ __attribute__((aligned(64))) float s_step[sizeof(StepConsts) / sizeof(float)];
     {
         const int n = step_const_count(*(CCfg *)cfg);
         for (int j = threadIdx.x; j < n; j += kWave) s_step[j] = step_const_entry(*(CCfg *)cfg, *(CCost *)cost, x0_root, U, j);
+    }
+#pragma unroll
+    for (int it = 0; it < kModelTrips; it++) {
+        const int i = (int)threadIdx.x + it * kWave;
+        if (i < kModelBytes / 16) s_model[i] = mv[it];
     }
     __syncthreads();
     LModel &lm = *(LModel *)s_model;
