@@ -126,18 +126,42 @@ __device__ __forceinline__ void quad_record(CCfg &cfg, float s, bool live_leader
     MPPI_BARRIER(5);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const int nlive = K - k0 < SPW ? K - k0 : SPW;  // samples of this chunk that exist
+    if (nlive == SPW && (K & 3) == 0) {  // aligned full chunk: 16-byte loads, the rows of up to four trips requested at once
+        // (the du rows come back from L2 one round trip per trip of this loop otherwise - three of them in front of the
+        // kernel's end for the panda's 140 rows)
+        constexpr int kTrips = 4;
+        float w[SPW];
+#pragma unroll
+        for (int q = 0; q < SPW; q++) w[q] = s_w[q];
+        for (int j0 = lane; j0 < HN; j0 += kTrips * kWave) {
+            float4 v[kTrips][SPW / 4];
+#pragma unroll
+            for (int t = 0; t < kTrips; t++) {
+                const int j = j0 + t * kWave;
+                if (j < HN) {
+                    const float4 *row = reinterpret_cast<const float4 *>(du + (size_t)j * K + k0);
+#pragma unroll
+                    for (int q = 0; q < SPW / 4; q++) v[t][q] = row[q];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < kTrips; t++) {
+                const int j = j0 + t * kWave;
+                if (j < HN) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int q = 0; q < SPW / 4; q++)
+                        acc += v[t][q].x * w[4 * q] + v[t][q].y * w[4 * q + 1] + v[t][q].z * w[4 * q + 2] + v[t][q].w * w[4 * q + 3];
+                    rec[2 + j] = acc;
+                }
+            }
+        }
+        return;
+    }
     for (int j = lane; j < HN; j += kWave) {
         const float *row = du + (size_t)j * K + k0;
         float acc = 0.f;
-        if (nlive == SPW && (K & 3) == 0) {  // aligned full chunk: 16-byte loads
-            float4 v[SPW / 4];
-#pragma unroll
-            for (int q = 0; q < SPW / 4; q++) v[q] = reinterpret_cast<const float4 *>(row)[q];
-#pragma unroll
-            for (int q = 0; q < SPW / 4; q++) acc += v[q].x * s_w[4 * q] + v[q].y * s_w[4 * q + 1] + v[q].z * s_w[4 * q + 2] + v[q].w * s_w[4 * q + 3];
-        } else {
-            for (int q = 0; q < nlive; q++) acc += row[q] * s_w[q];
-        }
+        for (int q = 0; q < nlive; q++) acc += row[q] * s_w[q];
         rec[2 + j] = acc;
     }
 }
