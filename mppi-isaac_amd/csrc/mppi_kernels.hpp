@@ -303,6 +303,9 @@ __global__ __launch_bounds__(kWave) void k_rollout(const DevModel *__restrict__ 
 
 // Quad-parallel rollout (mppi_quad.hpp): 4 lanes per sample, 16 samples per wavefront.
 template <class T, bool DUMP = false>
+// (No amdgpu_waves_per_eu(1, 1) here although the kernel runs one wavefront per SIMD by construction: measured, round 3, the
+// attribute makes this kernel 20 % SLOWER (0.1175 -> 0.1415 ms, same instruction counts, 256 + 1 registers instead of 256 and
+// a few spilled loop invariants) - the register file above 256 is not free for a wavefront that could live without it.)
 __global__ __launch_bounds__(kWave) void k_rollout_quad(const DevModel *__restrict__ m, const DevCfg *__restrict__ cfg,
                                                         const DevCost *__restrict__ cost, const float *__restrict__ x0_dof,
                                                         const float *__restrict__ x0_root, const float *__restrict__ U,
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(kWave) void k_rollout_quad(const DevModel *__restri
 #pragma unroll
     for (int it = 0; it < kModelTrips; it++) {
         const int i = (int)threadIdx.x + it * kWave;
-        if (i < kModelBytes / 16) mv[it] = reinterpret_cast<const uint4 *>(m)[i];
+        mv[it] = reinterpret_cast<const uint4 *>(m)[i < kModelBytes / 16 ? i : 0];  // (unconditional: the array stays in registers)
     }
     // ... and the step loop's own constants (control limits, nominal rows, cost target and weights)
     __shared__ __attribute__((aligned(64))) float s_step[sizeof(StepConsts) / sizeof(float)];
