@@ -204,8 +204,9 @@ class Loop:
         lib, P, W, capi, env = self.lib, self.P, self.W, self.capi, self.env
         capi.check(lib, lib.mppi_rollout(P))
         if env["sharded"] and self.exchange == "mailbox":
-            capi.check(lib, lib.mppi_exchange(P))   # publish into every inbox, poll the own one (two small kernels)
-            capi.check(lib, lib.mppi_update_step_world(P, self.gathered, self.n_gathered, W))
+            # publish into every inbox, poll the own one, combine, step the world: ONE launch for the contact-free scenes
+            # (the exchange is the head of the combine + world kernel), exchange kernel + tail kernels otherwise
+            capi.check(lib, lib.mppi_exchange_update_step_world(P, W))
         elif env["sharded"]:
             if not self.inplace:
                 capi.check(lib, lib.mppi_reduce(P, ctypes.c_void_p(self.mine.data_ptr())))

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MPPI_ABI_VERSION 4
+#define MPPI_ABI_VERSION 5
 
 #define MPPI_MAX_BODIES 12   /* moving bodies (= DOF) of the articulated robot        */
 #define MPPI_MAX_LINKS 24    /* reported rigid bodies of the robot (URDF links)      */
@@ -315,6 +315,11 @@ int mppi_exchange(mppi_ctx_t *ctx);
 int mppi_exchange_publish(mppi_ctx_t *ctx);
 int mppi_exchange_wait(mppi_ctx_t *ctx);
 int mppi_exchange_status(mppi_ctx_t *ctx, int *timed_out);
+/* mppi_exchange followed by mppi_update_step_world(planner, gathered records, world) - as ONE launch where that is possible
+ * (fixed-base contact-free scenes whose rollout leaves per-wavefront records, one shard record per rank in the mailbox: the
+ * combine + world kernel starts with the reduction to the shard record, the publish and the bounded wait), so that the sharded
+ * control iteration has the two launches of the unsharded one; every other context takes the two calls in turn. */
+int mppi_exchange_update_step_world(mppi_ctx_t *planner, mppi_ctx_t *world);
 /* combine n shard records (device, [n][2+H*nu]; NULL = own record), update U, emit action, shift */
 int mppi_update(mppi_ctx_t *ctx, const float *records_dev, int n_records);
 int mppi_get_action(mppi_ctx_t *ctx, float *action_host);     /* [nu]; synchronises the stream        */

@@ -603,11 +603,42 @@ int mppi_exchange_wait(mppi_ctx_t *c) {
 }
 int mppi_exchange(mppi_ctx_t *c) {
     CTX_TRY(c);
+    // per-wavefront records of a fused rollout and a mailbox sized for ONE shard record: reduce and exchange in one launch
+    if (c->d_inbox && c->partials_valid && c->mb_nrec == 1 && !(mppi_shard_record_count(c) > 0 && mppi_shard_record_count(c) == c->mb_nrec)) {
+        bool connected = true;
+        for (void *p : c->h_peers) connected = connected && p != nullptr;
+        if (connected && !c->peers_dirty) {
+            hipLaunchKernelGGL(k_reduce_exchange, dim3(1), dim3(kCombineThreads), 0, c->stream, c->d_cfg, (const float *)c->recs_cur, c->n_partials, c->d_own_rec, c->RF,
+                               c->mb_rank, c->mb_n, (void *const *)c->d_peers, c->d_mb_seq, c->d_inbox, c->d_gathered, c->d_mb_status, 200000000ull);
+            return launch_check();
+        }
+    }
     const float *own = nullptr;
     int rc = mailbox_own_records(c, &own);
     if (rc) return rc;
     hipLaunchKernelGGL(k_mailbox_exchange, dim3(1), dim3(256), 0, c->stream, own, c->mb_nrec, c->RF, c->mb_rank, c->mb_n, (void *const *)c->d_peers, c->d_mb_seq,
                        c->d_inbox, c->d_gathered, c->d_mb_status, 200000000ull);
+    return launch_check();
+}
+/* mppi_exchange + mppi_update_step_world; ONE launch where the rollout left per-wavefront records, the mailbox carries one
+ * shard record per rank and the fused combine + world kernel exists (fixed-base contact-free scenes) */
+int mppi_exchange_update_step_world(mppi_ctx_t *c, mppi_ctx_t *world) {
+    CTX_TRY(c);
+    CTX_TRY(world);
+    bool fused = c->d_inbox && c->partials_valid && c->mb_nrec == 1 && !c->peers_dirty && c->launch_combine_world != nullptr && !c->scene && !world->scene &&
+                 world->K == 1 && world->n == c->n && world->A == c->A && world->device == c->device &&
+                 !(mppi_shard_record_count(c) > 0 && mppi_shard_record_count(c) == c->mb_nrec);
+    for (void *p : c->h_peers) fused = fused && p != nullptr;
+    if (!fused) {
+        int rc = mppi_exchange(c);
+        if (rc) return rc;
+        return mppi_update_step_world(c, c->d_gathered, c->mb_n * c->mb_nrec, world);
+    }
+    {
+        EvScope ev(c, 2);
+        c->launch_combine_world(c, nullptr, 0, world);
+    }
+    c->seq_expected++;
     return launch_check();
 }
 int mppi_exchange_status(mppi_ctx_t *c, int *timed_out) {

@@ -644,15 +644,45 @@ __global__ __launch_bounds__(256) void k_mailbox_exchange(const float *__restric
     mailbox_wait(inbox, nrec, RF, n, seq_ctr, gathered, status, max_ticks);
 }
 
+// ... and, for the rollouts that leave per-wavefront records (contact-free kernels: the in-kernel fold is off there), the
+// reduction of those records to the ONE shard record in front of it, in the same launch: one kernel boundary less per
+// sharded iteration (mppi_reduce + mppi_exchange were two launches)
+__global__ __launch_bounds__(kCombineThreads) void k_reduce_exchange(const DevCfg *__restrict__ cfg, const float *__restrict__ recs, int nrec_in,
+                                                                     float *__restrict__ own, int RF, int rank, int n, void *const *__restrict__ peers,
+                                                                     unsigned *__restrict__ seq_ctr, void *__restrict__ inbox, float *__restrict__ gathered,
+                                                                     unsigned *__restrict__ status, unsigned long long max_ticks) {
+    combine_update<kCombineThreads>(*(CCfg *)cfg, recs, nrec_in, 0, own, nullptr, nullptr, nullptr, nullptr, nullptr);
+    __syncthreads();  // (the shard record is in memory and visible to the whole workgroup)
+    mailbox_publish(own, 1, RF, rank, n, peers, seq_ctr);
+    __syncthreads();
+    mailbox_wait(inbox, 1, RF, n, seq_ctr, gathered, status, max_ticks);
+}
+
 // Closed-loop tail in ONE launch: combine + nominal update, then the K = 1 world is stepped with the new
 // action by one quad of the same workgroup and its state becomes the planner's next x0
 // (replaces k_combine + k_sim_step + k_state_from_world; fixed-base contact-free scenes only).
+// With a mailbox (mb.inbox != null; sharded runs of the contact-free scenes, mppi_exchange_update_step_world) the same launch
+// starts with this shard's part of the exchange: the per-wavefront records of the rollout are reduced to the ONE shard record,
+// published into every rank's inbox, the ranks' records awaited - and the combine then reads the gathered records.  The
+// sharded control iteration is two launches like the unsharded one.
+struct MailboxArgs {
+    const float *wave_recs = nullptr;  // this shard's per-wavefront records and their number
+    int n_wave = 0;
+    float *own = nullptr;              // [RF] the shard record
+    int RF = 0, rank = 0, n = 0;
+    void *const *peers = nullptr;
+    unsigned *seq_ctr = nullptr;
+    void *inbox = nullptr;
+    float *gathered = nullptr;
+    unsigned *status = nullptr;
+    unsigned long long max_ticks = 0;
+};
 template <class T>
 __global__ __launch_bounds__(kCombineWorldThreads) void k_combine_world(const DevCfg *__restrict__ cfg, const float *__restrict__ recs, int nrec,
                                                                    float *__restrict__ U, float *__restrict__ action, float *__restrict__ beta_eta,
                                                                    const DevModel *__restrict__ wm, const float *__restrict__ w_root,
                                                                    float *__restrict__ wq, float *__restrict__ wqd, float *__restrict__ x0_dof,
-                                                                   const float *__restrict__ filt) {
+                                                                   const float *__restrict__ filt, MailboxArgs mb) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ float s_act[MPPI_MAX_NU];
     // The world's model goes to LDS as in the rollout (in-order ds_read_b128 broadcasts instead of cold scalar-cache
@@ -663,6 +693,16 @@ __global__ __launch_bounds__(kCombineWorldThreads) void k_combine_world(const De
     if (threadIdx.x >= kCombineWorldThreads / 2)
         for (int i = threadIdx.x - kCombineWorldThreads / 2; i < kModelBytes / 16; i += kCombineWorldThreads / 2)
             s_model[i] = reinterpret_cast<const uint4 *>(wm)[i];
+    if (mb.inbox != nullptr) {
+        combine_update<kCombineWorldThreads>(*(CCfg *)cfg, mb.wave_recs, mb.n_wave, 0, mb.own, nullptr, nullptr, nullptr, nullptr, nullptr);
+        __syncthreads();  // (the shard record is in memory and visible to the whole workgroup)
+        mailbox_publish(mb.own, 1, mb.RF, mb.rank, mb.n, mb.peers, mb.seq_ctr);
+        __syncthreads();
+        mailbox_wait(mb.inbox, 1, mb.RF, mb.n, mb.seq_ctr, mb.gathered, mb.status, mb.max_ticks);
+        __syncthreads();
+        recs = mb.gathered;
+        nrec = mb.n;
+    }
     combine_update<kCombineWorldThreads>(*(CCfg *)cfg, recs, nrec, 1, nullptr, U, action, beta_eta, s_act, filt);
     __syncthreads();
     if (threadIdx.x < 4) {
@@ -1525,8 +1565,14 @@ void launch_materialise_traj_t(mppi_ctx *c, float *dof, float *root, float *rb, 
 }
 template <class T>
 void launch_combine_world_t(mppi_ctx *p, const float *recs, int n, mppi_ctx *w) {
+    MailboxArgs mb;
+    if (recs == nullptr) {  // (mppi_exchange_update_step_world: the exchange in the same launch)
+        mb.wave_recs = p->recs_cur; mb.n_wave = p->n_partials; mb.own = p->d_own_rec; mb.RF = p->RF; mb.rank = p->mb_rank; mb.n = p->mb_n;
+        mb.peers = (void *const *)p->d_peers; mb.seq_ctr = p->d_mb_seq; mb.inbox = p->d_inbox; mb.gathered = p->d_gathered; mb.status = p->d_mb_status;
+        mb.max_ticks = 200000000ull;
+    }
     hipLaunchKernelGGL(k_combine_world<T>, dim3(1), dim3(kCombineWorldThreads), 0, p->stream, p->d_cfg, recs, n, p->d_U, p->d_action, p->d_beta_eta,
-                       w->d_model, w->d_x0_root, w->d_q, w->d_qd, p->d_x0_dof, p->use_filter ? p->d_filter : nullptr);
+                       w->d_model, w->d_x0_root, w->d_q, w->d_qd, p->d_x0_dof, p->use_filter ? p->d_filter : nullptr, mb);
 }
 template <class T>
 void launch_rollout_t(mppi_ctx *c) {

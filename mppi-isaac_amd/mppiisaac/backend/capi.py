@@ -12,7 +12,7 @@ import os
 MAX_BODIES, MAX_LINKS, MAX_ACTORS, MAX_NU, MAX_H, MAX_KNOTS, MAX_COST_W = 12, 24, 8, 12, 64, 16, 16
 MAX_SHAPES, MAX_PAIRS, MAX_FREE = 40, 48, 2
 SHAPE_BOX, SHAPE_SPHERE, SHAPE_DISC = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 # error codes of include/mppi_hip.h
 MPPI_OK, MPPI_EINVAL, MPPI_EHIP, MPPI_EUNSUPPORTED, MPPI_ESTATE = 0, -1, -2, -3, -4
 
@@ -122,6 +122,7 @@ _SIGNATURES = {
     "mppi_exchange_publish": (C.c_int, [_vp]),
     "mppi_exchange_wait": (C.c_int, [_vp]),
     "mppi_exchange_status": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "mppi_exchange_update_step_world": (C.c_int, [_vp, _vp]),
     "mppi_note_graph_update": (C.c_int, [_vp, C.c_int]),
     "mppi_record_dev": (C.c_int, [_vp, C.POINTER(_vp)]),
     "mppi_update": (C.c_int, [_vp, _vp, C.c_int]),

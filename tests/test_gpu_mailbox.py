@@ -107,6 +107,50 @@ def test_mailbox_exchange_equals_single_context(make, name, K, H, G, lib):
     full.close()
 
 
+@pytest.mark.parametrize("G", [2, 4])
+def test_exchange_fused_into_the_closed_loop_tail_equals_single_context(G, lib):
+    """mppi_exchange_update_step_world: for the contact-free scenes the exchange is the head of the combine + world kernel (reduce
+    the wavefront records to the shard record, publish, bounded wait, combine the ranks' records, step the K=1 world, feed its
+    state back) - ONE launch per rank and iteration.  G shard contexts with a world each against one context with its world,
+    closed loop: the actions of later iterations depend on the fed-back state, so equal actions mean the whole tail worked."""
+    K, H = 2048, 12
+    scene, m, cfg, cost, dof, root, shards, streams = shard_contexts(panda_reach, "panda", K, H, G, lib)
+    wcfg = make_config(load_config({"defaults": [{"mppi": "panda"}]}, overrides={"mppi.num_samples": 1, "mppi.horizon": 1}).mppi)
+    nu = cfg.nu
+    full, wfull = Ctx(m, cfg, cost), Ctx(m, wcfg)
+    full.call("mppi_sample", C.c_uint32(0))
+    worlds = []
+    for i, s in enumerate(shards):
+        w = Ctx(m, wcfg)
+        w.call("mppi_set_stream", C.c_void_p(streams[i].cuda_stream))
+        worlds.append(w)
+    for c in [full, wfull] + worlds:
+        c.set_state(dof, root)
+    for w in [wfull] + worlds:
+        w.call("mppi_sim_reset")
+    torch.cuda.synchronize()
+    a_full, a = np.zeros(nu, np.float32), np.zeros(nu, np.float32)
+    for it in range(5):
+        full.call("mppi_rollout")
+        capi.check(lib, lib.mppi_update_step_world(full.ctx, None, 1, wfull.ctx))
+        full.call("mppi_wait_action", capi.fptr(a_full))
+        for s in shards:                                  # (rollouts first: every rank's tail kernel waits for all publishes)
+            s.call("mppi_rollout")
+        for s, w in zip(shards, worlds):
+            capi.check(lib, lib.mppi_exchange_update_step_world(s.ctx, w.ctx))
+        for s in shards:
+            s.call("mppi_wait_action", capi.fptr(a))
+            late = C.c_int(-1)
+            s.call("mppi_exchange_status", C.byref(late))
+            assert late.value == 0
+            np.testing.assert_allclose(a, a_full, atol=3e-6)
+        assert np.abs(a_full).max() > 0
+    info = C.create_string_buffer(256)
+    shards[0].call("mppi_kernel_info", info, 256)
+    for c in shards + worlds + [full, wfull]:
+        c.close()
+
+
 def test_mailbox_wait_is_bounded(lib):
     """a rank whose peer never publishes does not hang the device: the poll gives up after ~2 s and says so"""
     scene, m, cfg, cost, dof, root, shards, streams = shard_contexts(panda_reach, "panda", 512, 8, 2, lib)
