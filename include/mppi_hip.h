@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MPPI_ABI_VERSION 5
+#define MPPI_ABI_VERSION 6
 
 #define MPPI_MAX_BODIES 12   /* moving bodies (= DOF) of the articulated robot        */
 #define MPPI_MAX_LINKS 24    /* reported rigid bodies of the robot (URDF links)      */
@@ -304,8 +304,15 @@ int mppi_record_dev(mppi_ctx_t *ctx, float **record_dev);    /* device pointer o
  *   mppi_exchange_publish / mppi_exchange_wait   the two halves of mppi_exchange.  A caller that drives several ranks of ONE
  *                         device from one thread (tests) enqueues every rank's publish before any rank's wait: a waiting
  *                         kernel occupies its hardware queue, and streams of one process may share hardware queues
- *   mppi_exchange_status  1 if a wait ever timed out (a peer never published) */
+ *   mppi_exchange_status  1 if a wait ever timed out (a peer never published).  The records of a rank that was late are
+ *                         NEUTRAL in the gathered buffer of that iteration (eta = 0: the update runs on the ranks that did
+ *                         publish, never on stale or half-written records); callers poll the status and raise
+ *   mppi_mailbox_info     whether the inbox is fine-grained device memory (required for peers of another process / GPU:
+ *                         mppi_mailbox_ipc_handle refuses a coarse-grained inbox), records per rank, number of ranks
+ * A shard whose rollout folded no records (generic Objective mode, ragged grids) publishes ONE reduced record and neutral padding
+ * whatever the mailbox was sized for; mppi_mailbox_create is failure-atomic (a failed call leaves no mailbox behind). */
 int mppi_mailbox_create(mppi_ctx_t *ctx, int rank, int n_ranks);
+int mppi_mailbox_info(mppi_ctx_t *ctx, int *fine_grained, int *records_per_rank, int *n_ranks);
 int mppi_mailbox_ptr(mppi_ctx_t *ctx, void **inbox_dev, size_t *bytes);
 int mppi_mailbox_ipc_handle(mppi_ctx_t *ctx, void *handle64);
 int mppi_mailbox_set_peer(mppi_ctx_t *ctx, int peer_rank, void *inbox_dev);

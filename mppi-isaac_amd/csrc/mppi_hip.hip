@@ -143,8 +143,8 @@ void release_ctx(mppi_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *bufs[] = {c->d_model, c->d_cfg, c->d_cost, c->d_x0_dof, c->d_x0_root, c->d_U, c->d_eps, c->d_du, c->d_S, c->d_prior, c->d_viz,
                     c->d_partials, c->d_record, c->d_action, c->d_beta_eta, c->d_q, c->d_qd, c->d_ctrl, c->d_basis, c->d_sigma, c->d_base, c->d_fr, c->d_cf, c->d_filter,
-                    c->d_seq, c->d_fold, c->d_fold_ctr, c->d_wave_clk, c->d_traj, c->d_cost_none, c->d_inbox, c->d_peers, c->d_mb_seq, c->d_mb_status,
-                    c->d_gathered, c->d_own_rec};
+                    c->d_seq, c->d_fold, c->d_fold_ctr, c->d_wave_clk, c->d_traj, c->d_cost_none, c->d_inbox, c->d_peers, c->d_mb_seq,
+                    c->d_gathered, c->d_own_rec};  // (d_mb_status lives in the mapped host block h_action)
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (void *p : c->ipc_opened) (void)hipIpcCloseMemHandle(p);
@@ -229,7 +229,11 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
             c->launch_materialise = e->materialise_scene;
             // (large scenes - e.g. the 12-DoF mobile manipulator with table and block - do not fit the one-lane kernels' 64 rows
             // per wavefront into 160 KiB: those kernels are then simply not available, MPPI_ROLLOUT=lane is refused below)
-            if (hipSetDevice(device) == hipSuccess) lds_err = e->raise_lds(c->lds_bytes <= 160 * 1024 ? c->lds_bytes : 0, c->lds_bytes_quad + c->lds_bytes_table);
+            if (hipSetDevice(device) == hipSuccess) {
+                c->lds_bytes_static = e->static_lds();
+                if (c->lds_bytes_quad + c->lds_bytes_table + c->lds_bytes_static <= 160 * 1024)
+                    lds_err = e->raise_lds(c->lds_bytes <= 160 * 1024 ? c->lds_bytes : 0, c->lds_bytes_quad + c->lds_bytes_table);
+            }
         } else {
             // fixed-base contact-free scenes: one sample per 4-lane quad unless MPPI_ROLLOUT=lane asks for the
             // one-lane-per-sample kernel (kept for A/B measurements and as the reference arithmetic)
@@ -249,9 +253,9 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
         }
         break;
     }
-    if (ok && ((c->quad ? 0 : c->lds_bytes) > 160 * 1024 || c->lds_bytes_quad + c->lds_bytes_table > 160 * 1024)) {
+    if (ok && ((c->quad ? 0 : c->lds_bytes) > 160 * 1024 || c->lds_bytes_quad + c->lds_bytes_table + c->lds_bytes_static > 160 * 1024)) {
         delete c;
-        return fail(MPPI_EUNSUPPORTED, "contact scene needs more than 160 KiB of LDS per wavefront");
+        return fail(MPPI_EUNSUPPORTED, "contact scene needs more than 160 KiB of LDS per workgroup (dynamic rows + table + the kernels' static __shared__)");
     }
     if (ok && lds_err != hipSuccess) {
         std::string msg = std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(lds_err);
@@ -492,29 +496,59 @@ int mppi_set_record_out(mppi_ctx_t *c, float *records_dev) {
 }
 
 // ---- direct exchange of the shard records (mailbox all-gather) ------------------------------------------------
-int mppi_mailbox_create(mppi_ctx_t *c, int rank, int n_ranks) {
-    CTX_TRY(c);
-    if (n_ranks < 1 || n_ranks > 64 || rank < 0 || rank >= n_ranks) return fail(MPPI_EINVAL, "mppi_mailbox_create: need 0 <= rank < n_ranks <= 64");
-    if (c->d_inbox) return fail(MPPI_ESTATE, "mppi_mailbox_create: this context already has a mailbox");
+// frees the mailbox buffers of a context and returns it to the "no mailbox" state (failed create, see below)
+static void mailbox_release(mppi_ctx *c) {
+    void *bufs[] = {c->d_inbox, c->d_peers, c->d_mb_seq, c->d_gathered, c->d_own_rec};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    c->d_inbox = nullptr; c->d_peers = nullptr; c->d_mb_seq = nullptr; c->d_gathered = nullptr; c->d_own_rec = nullptr; c->d_mb_status = nullptr;
+    c->h_peers.clear();
+    c->mb_rank = -1; c->mb_n = 0; c->mb_nrec = 0; c->inbox_bytes = 0; c->inbox_fine = false;
+}
+static int mailbox_alloc(mppi_ctx *c, int rank, int n_ranks) {
     const int cnt = mppi_shard_record_count(c);
     c->mb_rank = rank; c->mb_n = n_ranks; c->mb_nrec = cnt > 0 ? cnt : 1;
     c->inbox_bytes = MailboxHeader::bytes(n_ranks, c->mb_nrec, c->RF);
     HIP_TRY(hipSetDevice(c->device));
     // fine-grained device memory: stores of a peer GPU become visible while this GPU's kernels run (coarse-grained memory is
-    // only guaranteed at kernel boundaries); plain device memory when the runtime refuses (single-device use needs no more)
-    if (hipExtMallocWithFlags(&c->d_inbox, c->inbox_bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+    // only guaranteed at kernel boundaries); plain device memory when the runtime refuses - good for the contexts of ONE device
+    // (tests), never handed to another process: mppi_mailbox_ipc_handle refuses a coarse-grained inbox
+    c->inbox_fine = hipExtMallocWithFlags(&c->d_inbox, c->inbox_bytes, hipDeviceMallocFinegrained) == hipSuccess;
+    if (!c->inbox_fine) {
         (void)hipGetLastError();
+        c->d_inbox = nullptr;
         HIP_TRY(hipMalloc(&c->d_inbox, c->inbox_bytes));
     }
     HIP_TRY(hipMemset(c->d_inbox, 0, c->inbox_bytes));
     ALLOC_TRY(c->d_peers, sizeof(void *) * n_ranks);
     ALLOC_TRY(c->d_mb_seq, sizeof(unsigned));
-    ALLOC_TRY(c->d_mb_status, sizeof(unsigned));
     ALLOC_TRY(c->d_gathered, sizeof(float) * (size_t)n_ranks * c->mb_nrec * c->RF);
-    ALLOC_TRY(c->d_own_rec, sizeof(float) * c->RF);
+    // this shard's records when the rollout's tail has not folded them (generic Objective mode, ragged grids, one-lane
+    // kernels): record 0 = the reduced shard record, records 1.. stay neutral (eta = 0: the combine skips them)
+    ALLOC_TRY(c->d_own_rec, sizeof(float) * (size_t)c->mb_nrec * c->RF);
+    // status word (1: a wait timed out) in the mapped host block next to the action and its sequence number: the host reads it
+    // without a copy operation
+    c->h_action[17] = 0.f;
+    c->d_mb_status = reinterpret_cast<unsigned *>(c->hc.action_mirror + 17);
     c->h_peers.assign(n_ranks, nullptr);
     c->h_peers[rank] = c->d_inbox;
     c->peers_dirty = true;
+    return MPPI_OK;
+}
+int mppi_mailbox_create(mppi_ctx_t *c, int rank, int n_ranks) {
+    CTX_TRY(c);
+    if (n_ranks < 1 || n_ranks > 64 || rank < 0 || rank >= n_ranks) return fail(MPPI_EINVAL, "mppi_mailbox_create: need 0 <= rank < n_ranks <= 64");
+    if (c->d_inbox) return fail(MPPI_ESTATE, "mppi_mailbox_create: this context already has a mailbox");
+    const int rc = mailbox_alloc(c, rank, n_ranks);
+    if (rc != MPPI_OK) mailbox_release(c);  // failure-atomic: a retry starts from scratch, nothing half-built is ever launched on
+    return rc;
+}
+int mppi_mailbox_info(mppi_ctx_t *c, int *fine_grained, int *records_per_rank, int *n_ranks) {
+    CTX_TRY(c);
+    if (!c->d_inbox) return fail(MPPI_ESTATE, "no mailbox (mppi_mailbox_create)");
+    if (fine_grained) *fine_grained = c->inbox_fine ? 1 : 0;
+    if (records_per_rank) *records_per_rank = c->mb_nrec;
+    if (n_ranks) *n_ranks = c->mb_n;
     return MPPI_OK;
 }
 int mppi_mailbox_ptr(mppi_ctx_t *c, void **inbox_dev, size_t *bytes) {
@@ -528,6 +562,11 @@ int mppi_mailbox_ipc_handle(mppi_ctx_t *c, void *handle64) {
     CTX_TRY(c);
     if (!c->d_inbox || !handle64) return fail(MPPI_ESTATE, "no mailbox (mppi_mailbox_create)");
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+    // peers of another process / GPU store into the inbox while this GPU's kernels poll it: that needs fine-grained memory
+    // (MPPI_MAILBOX_ALLOW_COARSE=1: processes that share ONE device, where a coarse-grained allocation is coherent in its L2)
+    const char *coarse_ok = std::getenv("MPPI_MAILBOX_ALLOW_COARSE");
+    if (!c->inbox_fine && !(coarse_ok && std::string(coarse_ok) == "1"))
+        return fail(MPPI_EUNSUPPORTED, "mppi_mailbox_ipc_handle: the inbox is not fine-grained device memory (hipExtMallocWithFlags refused); use the RCCL all-gather");
     hipIpcMemHandle_t h;
     HIP_TRY(hipIpcGetMemHandle(&h, c->d_inbox));
     std::memcpy(handle64, &h, 64);
@@ -577,8 +616,10 @@ static int mailbox_own_records(mppi_ctx_t *c, const float **own_out) {
     if (c->partials_valid && folded > 0 && folded == c->mb_nrec) {
         own = c->fold_out;  // the rollout's tail has folded the wave records already
     } else {
-        if (c->mb_nrec != 1) return fail(MPPI_ESTATE, "mppi_exchange: the mailbox was sized for folded records, but this rollout folded none (set the cost before mppi_mailbox_create)");
-        int rc = mppi_reduce(c, c->d_own_rec);  // ONE shard record
+        // nothing folded (generic Objective mode: S came from host-side costs; a ragged grid; the one-lane kernel of a cost
+        // program) although the mailbox may have been sized for folded records: ONE reduced shard record in slot 0, the other
+        // slots keep eta = 0 and drop out of the combine
+        int rc = mppi_reduce(c, c->d_own_rec);
         if (rc) return rc;
         own = c->d_own_rec;
     }
@@ -644,10 +685,9 @@ int mppi_exchange_update_step_world(mppi_ctx_t *c, mppi_ctx_t *world) {
 int mppi_exchange_status(mppi_ctx_t *c, int *timed_out) {
     CTX_TRY(c);
     if (!c->d_inbox || !timed_out) return fail(MPPI_ESTATE, "no mailbox (mppi_mailbox_create)");
-    unsigned s = 0;
-    HIP_TRY(hipMemcpyAsync(&s, c->d_mb_status, sizeof s, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    *timed_out = (int)s;
+    HIP_TRY(hipStreamSynchronize(c->stream));  // (the waits enqueued so far have run; the word itself is mapped host memory)
+    std::atomic_thread_fence(std::memory_order_acquire);
+    *timed_out = (int)*reinterpret_cast<const volatile unsigned *>(c->h_action + 17);
     return MPPI_OK;
 }
 

@@ -605,6 +605,7 @@ __device__ __forceinline__ void mailbox_wait(void *__restrict__ inbox, int nrec,
     }
     __syncthreads();
     const unsigned seq = s_seq;
+    bool late = false;  // thread r polls rank r's flag
     if ((int)threadIdx.x < n) {
         const unsigned *flag = reinterpret_cast<const unsigned *>(inbox) + (size_t)kMailboxFlagStride * threadIdx.x;
         const unsigned long long t0 = wall_clock64();
@@ -612,6 +613,7 @@ __device__ __forceinline__ void mailbox_wait(void *__restrict__ inbox, int nrec,
         while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
             __builtin_amdgcn_s_sleep(8);
             if (wall_clock64() - t0 > max_ticks) {
+                late = true;
                 s_late = 1;
                 break;
             }
@@ -626,6 +628,13 @@ __device__ __forceinline__ void mailbox_wait(void *__restrict__ inbox, int nrec,
     const float *src = mailbox_slot(inbox, n, nrec, RF, (int)(seq & 1u), 0);
     const int len = n * nrec * RF;
     for (int j = threadIdx.x; j < len; j += blockDim.x) gathered[j] = __builtin_nontemporal_load(src + j);
+    // a rank that never published this iteration: whatever its slot holds (an older iteration's records, or half-written ones) must
+    // not reach the update - its records become neutral (eta = 0: the combine skips them), the status word says what happened
+    if (s_late) {
+        __syncthreads();
+        if (late)
+            for (int i = 0; i < nrec; i++) gathered[((size_t)threadIdx.x * nrec + i) * RF + 1] = 0.f;
+    }
 }
 __global__ __launch_bounds__(256) void k_mailbox_publish(const float *__restrict__ own, int nrec, int RF, int rank, int n, void *const *__restrict__ peers,
                                                          unsigned *__restrict__ seq_ctr) {
@@ -1393,6 +1402,7 @@ struct mppi_ctx {
     bool scene = false;
     size_t lds_bytes = 0, lds_bytes_quad = 0;  // dynamic LDS of the lane-per-sample / quad-per-sample scene kernels
     size_t lds_bytes_table = 0;                // ... plus the wave-shared shape / pair table of the shared-lane rollout kernels
+    size_t lds_bytes_static = 0;               // ... plus the kernels' static __shared__ (hipFuncGetAttributes)
     double *d_basis = nullptr, *d_sigma = nullptr;
     const float *eps_in = nullptr;  // d_eps or an external noise buffer
     bool has_prior = false, has_cost = false, profiling = false;
@@ -1427,6 +1437,7 @@ struct mppi_ctx {
     float *d_gathered = nullptr, *d_own_rec = nullptr;
     size_t inbox_bytes = 0;
     bool peers_dirty = false;
+    bool inbox_fine = false;  // the inbox is fine-grained device memory (what peers of another GPU / process need)
 };
 
 // one row of the launch table: the kinematic tree and its kernel launchers
@@ -1453,6 +1464,7 @@ struct TopoEntry {
     void (*materialise_scene)(mppi_ctx *, float *, float *, float *, float *);
     void (*combine_world)(mppi_ctx *, const float *, int, mppi_ctx *);
     hipError_t (*raise_lds)(size_t, size_t);
+    size_t (*static_lds)();  // largest static __shared__ footprint among the contact-scene kernels (counts against the 160 KiB too)
 };
 }  // namespace mppi
 
@@ -1545,6 +1557,27 @@ hipError_t raise_lds_limit(size_t lane_bytes, size_t quad_bytes) {  // lane_byte
     return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sim_step_scene<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lane_bytes);
 }
 
+// static __shared__ of the scene kernels (staged start state, fold tickets, step constants, the wave-shared model copy): it
+// shares the 160 KiB of a workgroup with the dynamic rows, so the admission check of mppi_create has to count it
+template <class T>
+size_t static_lds_bytes_scene() {
+    size_t mx = 0;
+    auto ask = [&](const void *f) {
+        hipFuncAttributes a;
+        if (hipFuncGetAttributes(&a, f) == hipSuccess && a.sharedSizeBytes > mx) mx = a.sharedSizeBytes;
+        else (void)hipGetLastError();
+    };
+    ask(reinterpret_cast<const void *>(&k_rollout_scene_quad<T, 4>));
+    ask(reinterpret_cast<const void *>(&k_rollout_scene_quad<T, 8>));
+    ask(reinterpret_cast<const void *>(&k_rollout_scene_quad<T, 8, 1, true>));
+    if constexpr (T::NB <= 4) {
+        ask(reinterpret_cast<const void *>(&k_rollout_scene_quad<T, 8, 2>));
+        ask(reinterpret_cast<const void *>(&k_rollout_scene_quad<T, 8, 2, true>));
+    }
+    ask(reinterpret_cast<const void *>(&k_sim_step_scene_quad<T>));
+    return mx;
+}
+
 template <class T>
 void launch_rollout_quad_t(mppi_ctx *c) {
     hipLaunchKernelGGL(k_rollout_quad<T>, dim3(c->n_quads), dim3(kWave), 0, c->stream, c->d_model, c->d_cfg, c->d_cost, c->d_x0_dof, c->d_x0_root,
@@ -1625,6 +1658,7 @@ void fill_topo_entry_scene(TopoEntry &e) {
     e.materialise_scene_traj = &launch_materialise_scene_traj_t<T>;
     e.materialise_scene = &launch_materialise_scene_t<T>;
     e.raise_lds = &raise_lds_limit<T>;
+    e.static_lds = &static_lds_bytes_scene<T>;
 }
 
 }  // namespace

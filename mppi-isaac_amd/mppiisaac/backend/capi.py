@@ -12,7 +12,7 @@ import os
 MAX_BODIES, MAX_LINKS, MAX_ACTORS, MAX_NU, MAX_H, MAX_KNOTS, MAX_COST_W = 12, 24, 8, 12, 64, 16, 16
 MAX_SHAPES, MAX_PAIRS, MAX_FREE = 40, 48, 2
 SHAPE_BOX, SHAPE_SPHERE, SHAPE_DISC = 0, 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 # error codes of include/mppi_hip.h
 MPPI_OK, MPPI_EINVAL, MPPI_EHIP, MPPI_EUNSUPPORTED, MPPI_ESTATE = 0, -1, -2, -3, -4
 
@@ -113,6 +113,7 @@ _SIGNATURES = {
     "mppi_shard_record_count": (C.c_int, [_vp]),
     "mppi_set_record_out": (C.c_int, [_vp, _vp]),
     "mppi_mailbox_create": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "mppi_mailbox_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mppi_mailbox_ptr": (C.c_int, [_vp, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "mppi_mailbox_ipc_handle": (C.c_int, [_vp, _vp]),
     "mppi_mailbox_set_peer": (C.c_int, [_vp, C.c_int, _vp]),

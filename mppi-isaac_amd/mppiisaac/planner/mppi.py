@@ -321,6 +321,13 @@ class MPPIPlanner:
             capi.check(lib, lib.mppi_reduce(ctx, None))
             capi.check(lib, lib.mppi_update(ctx, None, 1))
         capi.check(lib, lib.mppi_get_action(ctx, capi.fptr(self._action)))
+        if self._shard and self._exchange == "mailbox":
+            # a peer that never published (dead, or > 2 s late): the library made its records neutral for this update and set
+            # the status word - RCCL would hang or raise in the same situation; here the caller hears about it at once
+            late = C.c_int(0)
+            capi.check(lib, lib.mppi_exchange_status(ctx, C.byref(late)))
+            if late.value:
+                raise RuntimeError("mailbox exchange: a rank did not publish its shard records in time (the update ran without them)")
         return torch.from_numpy(self._action.copy()).unsqueeze(0) if self.cfg.u_per_command > 1 else torch.from_numpy(self._action.copy())
 
     def _mailbox(self):
