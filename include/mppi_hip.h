@@ -347,6 +347,13 @@ int mppi_get_rollouts(mppi_ctx_t *ctx, float *viz_host);      /* [H][K][3], get_
 int mppi_get_perturbations(mppi_ctx_t *ctx, float *du_host);  /* [H][nu][K] effective perturbations   */
 int mppi_get_noise(mppi_ctx_t *ctx, float *eps_host);         /* [H][nu][K]                           */
 
+/* ---- parity / debug: the context's MPPI_COST_PROGRAM evaluated on the device by the interpreter the rollout kernels run, on
+ *      CALLER-GIVEN simulator answers of n envs (host arrays in the reference layouts: dof [n][2*n_dof], root [n][A][13],
+ *      rb [n][B][13], cf [n][B][3]) instead of the kernel's own kinematics -> cost [n].  What Objective.compute_cost(sim) is to
+ *      the gym getters (reference examples/<x>/planner.py compute_cost over isaacgym_wrapper.py:238-330): the golden Objective
+ *      fixtures are pushed through the HIP cost path with it (tests/test_gpu_parity.py). */
+int mppi_eval_cost(mppi_ctx_t *ctx, int n, const float *dof_host, const float *root_host, const float *rb_host, const float *cf_host, float *cost_host);
+
 /* ---- batched simulator (generic Objective mode and the K=1 "world"):
  *      replaces IsaacGymWrapper.apply_robot_cmd + step (isaacgym_wrapper.py:524-572,639-655)
  *      and the four gym state tensors (:186-199). */

@@ -205,6 +205,7 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
         for (int i = 0; i < e->nb; i++) same &= e->parents[i] == parents[i];
         if (!same) continue;
         ok = true;
+        c->launch_eval_cost = e->eval_cost;
         if (c->scene) {
             c->lds_bytes = sizeof(float) * kWave * (e->scene_lds_floats + 3 * (size_t)c->hm.n_rb + 5 * (size_t)c->hm.n_rnd);
             c->lds_bytes_quad = sizeof(float) * 16 * (e->scene_lds_floats + 3 * (size_t)c->hm.n_rb + 5 * (size_t)c->hm.n_rnd + 12 * (size_t)c->hm.n_shapes);
@@ -804,6 +805,30 @@ int mppi_get_rollouts(mppi_ctx_t *c, float *viz) {
 }
 int mppi_get_perturbations(mppi_ctx_t *c, float *du) { return d2h(c, du, c ? c->d_du : nullptr, c ? (size_t)c->HN * c->K : 0); }
 int mppi_get_noise(mppi_ctx_t *c, float *eps) { return d2h(c, eps, c ? c->eps_in : nullptr, c ? (size_t)c->HN * c->K : 0); }
+
+/* parity / debug: the context's cost program on caller-given simulator answers (host arrays, reference layouts) */
+int mppi_eval_cost(mppi_ctx_t *c, int n, const float *dof, const float *root, const float *rb, const float *cf, float *cost_out) {
+    CTX_TRY(c);
+    if (n < 1 || !dof || !root || !rb || !cf || !cost_out) return fail(MPPI_EINVAL, "mppi_eval_cost: null argument or n < 1");
+    if (!c->has_cost || c->hk.kind != kCostProgram) return fail(MPPI_ESTATE, "mppi_eval_cost: the context's cost is not a MPPI_COST_PROGRAM (mppi_set_cost)");
+    if (!c->launch_eval_cost) return fail(MPPI_EUNSUPPORTED, "mppi_eval_cost: not available for this kinematic tree");
+    const size_t sz[5] = {(size_t)n * 2 * c->n, (size_t)n * 13 * c->A, (size_t)n * 13 * c->B, (size_t)n * 3 * c->B, (size_t)n};
+    const float *src[4] = {dof, root, rb, cf};
+    float *d[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int rc = MPPI_OK;
+    for (int i = 0; i < 5 && rc == MPPI_OK; i++) rc = dev_alloc(&d[i], sizeof(float) * sz[i]);
+    for (int i = 0; i < 4 && rc == MPPI_OK; i++)
+        if (hipMemcpyAsync(d[i], src[i], sizeof(float) * sz[i], hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = fail(MPPI_EHIP, "mppi_eval_cost: upload failed");
+    if (rc == MPPI_OK) {
+        c->launch_eval_cost(c, n, d[0], d[1], d[2], d[3], d[4]);
+        rc = launch_check();
+    }
+    if (rc == MPPI_OK && (hipMemcpyAsync(cost_out, d[4], sizeof(float) * n, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess))
+        rc = fail(MPPI_EHIP, "mppi_eval_cost: download failed");
+    for (float *p : d)
+        if (p) (void)hipFree(p);
+    return rc;
+}
 
 int mppi_sim_reset(mppi_ctx_t *c) {
     CTX_TRY(c);

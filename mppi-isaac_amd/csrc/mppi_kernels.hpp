@@ -1349,6 +1349,43 @@ __global__ __launch_bounds__(kWave) void k_materialise(const DevModel *__restric
         for (int j = 0; j < 3 * B; j++) cf[(size_t)k * 3 * B + j] = 0.f;
 }
 
+// Parity / debug entry (mppi_eval_cost): the cost program of the context evaluated by the interpreter the rollout kernels run
+// (program_cost_with, mppi_device.hpp) on CALLER-GIVEN simulator answers - reference-layout rows of n envs - instead of the
+// kernel's own kinematics: link poses from the rigid-body rows (position, quaternion xyzw), actor rows from the root rows,
+// contact forces as given.  This is how the reference's golden Objective inputs (tests/golden/objective_costs.json: what the
+// gym getters returned, reference examples/*/planner.py compute_cost) reach the HIP cost path directly.
+struct GivenEnv {
+    const float *root, *cfr;
+    MPPI_HD V3 vec(int actor, int off) const { return loadv(root + 13 * actor + off); }
+    MPPI_HD void quat(int actor, float *qq) const {
+        for (int j = 0; j < 4; j++) qq[j] = root[13 * actor + 3 + j];
+    }
+    MPPI_HD float cf(int rb, int j) const { return cfr[3 * rb + j]; }
+    MPPI_HD V3 constant_point(float x, float y, float z) const { return V3{x, y, z}; }
+};
+template <class T>
+__global__ __launch_bounds__(kWave) void k_eval_cost(const DevModel *__restrict__ m_, const DevCost *__restrict__ cost_, int n, const float *__restrict__ dof,
+                                                     const float *__restrict__ root, const float *__restrict__ rb, const float *__restrict__ cf,
+                                                     float *__restrict__ out) {
+    constexpr int NB = T::NB;
+    CModel &m = *(CModel *)m_;
+    CCost &c = *(CCost *)cost_;
+    const int k = blockIdx.x * kWave + threadIdx.x;
+    if (k >= n) return;
+    float q[NB ? NB : 1], qd[NB ? NB : 1];
+    static_for<0, NB>([&](auto ic) {
+        constexpr int i = ic;
+        q[i] = dof[(size_t)k * 2 * NB + 2 * i];
+        qd[i] = dof[(size_t)k * 2 * NB + 2 * i + 1];
+    });
+    const float *rows = rb + (size_t)k * 13 * m.n_rb + 13 * m.robot_first_rb;
+    const GivenEnv env{root + (size_t)k * 13 * m.n_actors, cf + (size_t)k * 3 * m.n_rb};
+    out[k] = program_cost_with<T>(c, q, qd, [&](int l, M3 &R, V3 &p) MPPI_LAMBDA {
+        p = loadv(rows + 13 * l);
+        R = quat_to_R(rows + 13 * l + 3);
+    }, env);
+}
+
 __global__ void k_accumulate_cost(int K, float disc, const float *__restrict__ c, float *__restrict__ S) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < K) S[k] += disc * c[k];
@@ -1424,6 +1461,7 @@ struct mppi_ctx {
     void (*launch_sim_step)(mppi_ctx *, int, int, const float *) = nullptr;
     void (*launch_materialise)(mppi_ctx *, float *, float *, float *, float *) = nullptr;
     void (*launch_combine_world)(mppi_ctx *, const float *, int, mppi_ctx *) = nullptr;  // fused closed-loop tail (quad scenes)
+    void (*launch_eval_cost)(mppi_ctx *, int, const float *, const float *, const float *, const float *, float *) = nullptr;
     std::string topo;
     // closed loop: where the K = 1 world's step kernel writes the planner's next start state (mppi_update_step_world; null otherwise)
     float *fb_dof = nullptr, *fb_root = nullptr;
@@ -1463,6 +1501,7 @@ struct TopoEntry {
     void (*materialise)(mppi_ctx *, float *, float *, float *, float *);
     void (*materialise_scene)(mppi_ctx *, float *, float *, float *, float *);
     void (*combine_world)(mppi_ctx *, const float *, int, mppi_ctx *);
+    void (*eval_cost)(mppi_ctx *, int, const float *, const float *, const float *, const float *, float *);  // mppi_eval_cost
     hipError_t (*raise_lds)(size_t, size_t);
     size_t (*static_lds)();  // largest static __shared__ footprint among the contact-scene kernels (counts against the 160 KiB too)
 };
@@ -1608,6 +1647,10 @@ void launch_combine_world_t(mppi_ctx *p, const float *recs, int n, mppi_ctx *w) 
                        w->d_model, w->d_x0_root, w->d_q, w->d_qd, p->d_x0_dof, p->use_filter ? p->d_filter : nullptr, mb);
 }
 template <class T>
+void launch_eval_cost_t(mppi_ctx *c, int n, const float *dof, const float *root, const float *rb, const float *cf, float *out) {
+    hipLaunchKernelGGL(k_eval_cost<T>, dim3((n + kWave - 1) / kWave), dim3(kWave), 0, c->stream, c->d_model, c->d_cost, n, dof, root, rb, cf, out);
+}
+template <class T>
 void launch_rollout_t(mppi_ctx *c) {
     hipLaunchKernelGGL(k_rollout<T>, dim3(c->n_waves), dim3(kWave), 0, c->stream, c->d_model, c->d_cfg, c->d_cost, c->d_x0_dof, c->d_x0_root,
                        c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_S, c->cfg.want_rollouts ? c->d_viz : nullptr, c->d_partials);
@@ -1644,6 +1687,7 @@ void fill_topo_entry_free(TopoEntry &e) {
     e.materialise_traj = &launch_materialise_traj_t<T>;
     e.materialise = &launch_materialise_t<T>;
     e.combine_world = &launch_combine_world_t<T>;
+    e.eval_cost = &launch_eval_cost_t<T>;
 }
 template <class T>
 void fill_topo_entry_scene(TopoEntry &e) {

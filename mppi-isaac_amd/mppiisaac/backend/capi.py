@@ -112,6 +112,7 @@ _SIGNATURES = {
     "mppi_record_floats": (C.c_int, [_vp]),
     "mppi_shard_record_count": (C.c_int, [_vp]),
     "mppi_set_record_out": (C.c_int, [_vp, _vp]),
+    "mppi_eval_cost": (C.c_int, [_vp, C.c_int, _fp, _fp, _fp, _fp, _fp]),
     "mppi_mailbox_create": (C.c_int, [_vp, C.c_int, C.c_int]),
     "mppi_mailbox_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mppi_mailbox_ptr": (C.c_int, [_vp, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),

@@ -181,7 +181,8 @@ EXAMPLE_SCENES = {   # actors of the reference's example configs (examples/<x>/*
     "panda_pick": ["panda_gripper", "xaxis", "yaxis", "panda_pick_block", "table", "goal"], "boxer_reach": ["boxer", "wall", "goal"],
     "heijn_reach": ["heijn", "wall", "goal"], "heijn_push": ["heijn", "block", "paper_obst1", "paper_obst2", "goal"],
     "albert": ["albert", "goal"], "omni_panda_pick": ["omnipanda_effort", "xaxis", "yaxis", "block2", "table2", "goal"],
-    "panda_effort": ["panda_effort", "goal"], "panda_stick_push": ["panda_stick", "xaxis", "yaxis", "panda_push_block", "table", "goal"]}
+    "panda_effort": ["panda_effort", "goal"], "panda_stick_push": ["panda_stick", "xaxis", "yaxis", "panda_push_block", "table", "goal"],
+    "anymal": ["anymal", "goal"]}
 
 
 @pytest.mark.parametrize("case", sorted(EXAMPLE_SCENES))

@@ -1113,3 +1113,58 @@ def test_rollout_trajectory_states_match_oracle_stepping(lib, oracle64):
         c.close()
     finally:
         del os.environ["MPPI_ROLLOUT"]
+
+
+def _golden_cases():
+    from test_golden_boundary import EXAMPLE_SCENES
+    return sorted(EXAMPLE_SCENES)
+
+
+@pytest.mark.parametrize("case", _golden_cases())
+def test_golden_objective_inputs_through_the_hip_cost_program(case, lib):
+    """The reference's Objectives straight against the HIP cost path: tests/golden/objective_costs.json holds what the gym getters
+    returned (seeded random link rows, actor rows, contact forces, DOF states) and what each example planner's compute_cost made
+    of them (tools/make_golden.py imports the reference's examples/<x>/planner.py).  Those inputs go through mppi_eval_cost -
+    the cost-program interpreter the rollout kernels run (program_cost_with), on the device, fed with the given rows instead of
+    the kernel's kinematics - and must give the reference's costs.  (Until round 4 the chain was golden -> oracle on the CPU,
+    oracle -> HIP on the GPU.)"""
+    import mppiisaac.objectives as objectives
+    from mppiisaac.planner.mppi import MPPIConfig, make_config
+    from scenes import build_scene
+    from test_golden_boundary import EXAMPLE_SCENES, OBJECTIVES, gold
+    g = gold("objective_costs.json")[case]
+    scene = build_scene(EXAMPLE_SCENES[case], [[0.0, 0.0, 0.05]])
+    m = scene.to_c()
+    obj = getattr(objectives, OBJECTIVES[case])(None)
+
+    class Sim:
+        pass
+    sim = Sim()
+    sim.scene = scene
+    spec = obj.program_spec(sim)
+    cfg = make_config(MPPIConfig(num_samples=64, horizon=4, noise_sigma=np.eye(m.nu).tolist()))
+    c = Ctx(m, cfg, spec)
+    n, nd = len(g["cost"]), scene.n_dof
+    dof, root = np.zeros((n, 2 * nd), np.float32), np.zeros((n, m.n_actors, 13), np.float32)
+    rb, cf = np.zeros((n, m.n_rb, 13), np.float32), np.zeros((n, m.n_rb, 3), np.float32)
+    rb[:, :, 6] = 1.0   # (rows the objective never asks for: identity quaternions)
+    root[:, :, 6] = 1.0
+    for key, val in g["inputs"].items():
+        val = np.asarray(val, np.float32)
+        kind, *names = key.split(":")
+        if kind == "link":
+            rb[:, scene.rigid_body_index(*names)] = val
+        elif kind == "contact":
+            cf[:, scene.rigid_body_index(*names)] = val
+        elif kind == "dof_state":
+            dof[:, :] = val[:, :2 * nd]
+        else:
+            col = {"position": slice(0, 3), "orientation": slice(3, 7), "velocity": slice(7, 10)}[kind]
+            root[:, scene.actor_index(names[0]), col] = val
+    # box / sphere actors are rigid bodies too: a program that names their body reads the actor's root row
+    out = np.zeros(n, np.float32)
+    c.call("mppi_eval_cost", n, capi.fptr(dof), capi.fptr(root), capi.fptr(rb), capi.fptr(cf), capi.fptr(out))
+    c.close()
+    want = np.asarray(g["cost"])
+    print(f"{case}: HIP cost program vs reference Objective on {n} golden envs: max rel {np.max(np.abs(out - want) / np.maximum(np.abs(want), 1e-6)):.1e}")
+    np.testing.assert_allclose(out, want, rtol=2e-5, atol=2e-5)   # fp32 interpreter, hardware sqrt / rcp (1 ulp) vs the reference's torch fp32
