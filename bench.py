@@ -112,9 +112,10 @@ class Loop:
             if self.inplace:
                 capi.check(lib, lib.mppi_set_record_out(P, ctypes.c_void_p(self.mine.data_ptr())))
             self.n_records = world_size * per
-            self.exchange = "rccl"
+            self.exchange, self.exchange_why, self.probe = "rccl", "requested (MPPI_BENCH_EXCHANGE / default)", None
             if env.get("exchange") == "mailbox":
-                self.exchange = "mailbox" if self._connect_mailbox() else "rccl"
+                ok, why = self._connect_mailbox()
+                self.exchange, self.exchange_why = ("mailbox", "probe passed: " + why) if ok else ("rccl", "mailbox refused: " + why)
 
     def _connect_mailbox(self):
         """The library's own exchange of the shard records (mppi_mailbox_*: every rank stores its records into every rank's inbox
@@ -124,37 +125,43 @@ class Loop:
         torch, dist, lib, P, capi, env = self.torch, self.dist, self.lib, self.P, self.capi, self.env
         rank, world = env["rank"], env["world_size"]
         ok, why = 1, ""
+        self.probe = {"fine_grained": None, "records_per_rank": None, "iterations": 0, "late": None, "equal_per_rank": None}
         try:
             capi.check(lib, lib.mppi_mailbox_create(P, rank, world))
+            fine, nrec, nr = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+            capi.check(lib, lib.mppi_mailbox_info(P, ctypes.byref(fine), ctypes.byref(nrec), ctypes.byref(nr)))
+            self.probe.update(fine_grained=bool(fine.value), records_per_rank=nrec.value)
             h = (ctypes.c_ubyte * 64)()
-            capi.check(lib, lib.mppi_mailbox_ipc_handle(P, h))
+            capi.check(lib, lib.mppi_mailbox_ipc_handle(P, h))     # (refuses a coarse-grained inbox)
         except Exception as e:  # noqa: BLE001
-            ok, why, h = 0, f"create: {e}", (ctypes.c_ubyte * 64)()
+            ok, why, h = 0, f"create on rank {rank}: {e}", (ctypes.c_ubyte * 64)()
         handles = [None] * world
-        dist.all_gather_object(handles, (ok, bytes(h)))
-        if not all(o for o, _ in handles):
-            print(f"[bench] mailbox exchange not available ({why or 'a peer refused'}); RCCL all-gather", file=sys.stderr)
-            return False
+        dist.all_gather_object(handles, (ok, why, bytes(h)))
+        if not all(o for o, _, _ in handles):
+            why = "; ".join(w for o, w, _ in handles if not o)
+            print(f"[bench] mailbox exchange not available ({why}); RCCL all-gather", file=sys.stderr)
+            return False, why
         try:
-            for r, (_, hb) in enumerate(handles):
-                if r != rank:
+            for r, (_, _, hb) in enumerate(handles):
+                if r != rank:   # (opens the peer's inbox and checks the mapping with a copy-engine write + read-back before any kernel stores to it)
                     capi.check(lib, lib.mppi_mailbox_open(P, r, (ctypes.c_ubyte * 64).from_buffer_copy(hb)))
             gp, gn = ctypes.c_void_p(), ctypes.c_int()
             capi.check(lib, lib.mppi_mailbox_gathered(P, ctypes.byref(gp), ctypes.byref(gn)))
             self.gathered, self.n_gathered = gp, gn.value
         except Exception as e:  # noqa: BLE001
-            ok, why = 0, f"open: {e}"
+            ok, why = 0, f"open on rank {rank}: {e}"
         flags = [None] * world
-        dist.all_gather_object(flags, ok)
-        if not all(flags):
-            print(f"[bench] mailbox exchange not available ({why or 'a peer could not open an inbox'}); RCCL all-gather", file=sys.stderr)
-            return False
+        dist.all_gather_object(flags, (ok, why))
+        if not all(o for o, _ in flags):
+            why = "; ".join(w for o, w in flags if not o)
+            print(f"[bench] mailbox exchange not available ({why}); RCCL all-gather", file=sys.stderr)
+            return False, why
         # probe: same records through both exchanges
         RF = lib.mppi_record_floats(P)
         hip = ctypes.CDLL("libamdhip64.so")
         hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
         mine = torch.zeros((self.n_records, RF), dtype=torch.float32, device=self.records.device)
-        for _ in range(3):
+        for it in range(3):
             capi.check(lib, lib.mppi_rollout(P))
             if not self.inplace:
                 capi.check(lib, lib.mppi_reduce(P, ctypes.c_void_p(self.mine.data_ptr())))
@@ -175,12 +182,26 @@ class Loop:
                 torch.cuda.synchronize()
                 same = int(torch.equal(mine, self.records))
             res = [None] * world
-            dist.all_gather_object(res, same)
-            if not all(res):
-                print(f"[bench] mailbox probe failed (late={late.value}, equal per rank={res}); RCCL all-gather", file=sys.stderr)
-                return False
+            dist.all_gather_object(res, (same, late.value))
+            self.probe.update(iterations=it + 1, late=[l for _, l in res], equal_per_rank=[e for e, _ in res])
+            if not all(e for e, _ in res):
+                why = f"probe iteration {it}: late per rank {[l for _, l in res]}, gathered == all-gather per rank {[e for e, _ in res]}"
+                print(f"[bench] mailbox probe failed ({why}); RCCL all-gather", file=sys.stderr)
+                return False, why
             capi.check(lib, lib.mppi_update(P, self.gathered, self.n_gathered))
-        return True
+        return True, "3 iterations, gathered records bit-equal to the all-gather on every rank, no late rank"
+
+    def exchange_report(self):
+        """what this rank ended up doing with its shard records, for the result line (SCALE records explain themselves)"""
+        if not self.env["sharded"]:
+            return None
+        late = None
+        if self.exchange == "mailbox":
+            v = ctypes.c_int(0)
+            self.capi.check(self.lib, self.lib.mppi_exchange_status(self.P, ctypes.byref(v)))
+            late = v.value
+        return {"rank": self.env["rank"], "device": self.env["local_rank"], "selected": self.exchange, "why": self.exchange_why, "probe": self.probe,
+                "mppi_exchange_status": late, "graph": self.graph is not None}
 
     def time_exchange(self, n=50):
         """per-iteration cost of the exchange alone (same records again and again): enqueue + wait, mean over n"""
@@ -466,10 +487,11 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world_size)
-    # MPPI_BENCH_EXCHANGE: "mailbox" = the library's own exchange of the shard records (guarded by a probe against the all-gather,
-    # falls back to it), "rccl" = all-gather only.  Default: mailbox for real multi-rank RCCL jobs, rccl for the one-rank
-    # measurement of the sharded loop (MPPI_BENCH_FORCE_DIST) so that its number stays the RCCL path's
-    exchange = os.environ.get("MPPI_BENCH_EXCHANGE", "mailbox" if (world_size > 1 and backend == "nccl") else "rccl")
+    # MPPI_BENCH_EXCHANGE: "rccl" = all-gather of the shard records (default: the path that has run on multi-GPU hardware before -
+    # RCCL itself), "mailbox" = the library's own exchange (guarded by a probe against the all-gather, falls back to it).  For
+    # real multi-rank jobs the mailbox is measured as well, in an A/B pass AFTER the result line is out (below): it has never
+    # moved a byte between two GPUs, and the line the driver records must not depend on it.
+    exchange = os.environ.get("MPPI_BENCH_EXCHANGE", "rccl")
     env = dict(world_size=world_size, rank=rank, local_rank=local_rank, sharded=sharded, backend=backend, exchange=exchange,
                action_sync=os.environ.get("MPPI_BENCH_ACTION") == "sync")
     sync = not args.async_loop
@@ -480,10 +502,11 @@ def main():
     # With the mailbox exchange the captured iteration contains library kernels only, and their waits are bounded: the graph is on.
     use_graph_rccl = sharded and backend == "nccl" and os.environ.get("MPPI_BENCH_GRAPH", "1" if world_size == 1 else "0") == "1"
 
-    def measure(name, k_per_gpu, steps, warmup, shipped=False):
+    def measure(name, k_per_gpu, steps, warmup, shipped=False, env=env):
         loop = Loop(name, k_per_gpu, env, sync=sync, shipped=shipped)
         graphed = False
-        use_graph = use_graph_rccl or (sharded and getattr(loop, "exchange", "") == "mailbox" and os.environ.get("MPPI_BENCH_GRAPH", "1") == "1")
+        use_graph = (use_graph_rccl and getattr(loop, "exchange", "") != "mailbox") or \
+                    (sharded and getattr(loop, "exchange", "") == "mailbox" and os.environ.get("MPPI_BENCH_GRAPH", "1") == "1")
         if use_graph:
             for _ in range(3):
                 loop.iterate()     # lazy initialisation (RCCL channels, LDS limits) must not happen under capture
@@ -493,16 +516,37 @@ def main():
             kms = loop.profile_kernels()
         return loop, elapsed, per_iter, kms, graphed
 
+    def gather_reports(loop):
+        """every rank's exchange report on rank 0 (None when not sharded)"""
+        rep = loop.exchange_report()
+        if not sharded:
+            return None
+        out = [None] * world_size
+        dist.all_gather_object(out, rep)
+        return out
+
+    def strong_row(env=env):
+        """BASELINE configs[4] at its stated size, K_total = 65536 x H = 30 split over the ranks: the STRONG-scaling row (the
+        driver's N = 1, 2, 4, 8 lines hold the same total work), with the exchange timed on its own"""
+        kt = 65536
+        if kt % world_size:
+            return None
+        l2, e2, p2, k2, g2 = measure("panda_pick", kt // world_size, max(10, min(args.steps, 40)), min(args.warmup, 5), env=env)
+        row = {"workload": WORKLOADS["panda_pick"]["desc"].replace("8192 samples per GPU", "K_total = 65536 over all GPUs"), "scaling": "strong",
+               "K_per_gpu": l2.K, "K_total": kt, "H": l2.H, "steps": len(p2), "ms_per_step": 1e3 * e2 / len(p2), "loop_hz": len(p2) / e2,
+               "env_steps_per_s": len(p2) / e2 * kt * l2.H, "rollout_kernel_ms": k2[0], "graph": g2,
+               "exchange": getattr(l2, "exchange", None), "exchange_ms": l2.time_exchange() if sharded else None}
+        del l2
+        return row
+
     loop, elapsed, per_iter, kms, graphed = measure(args.workload, K_PER_GPU, args.steps, args.warmup)
-    # for N > 1 the 177-us panda iteration is dominated by the collective's latency; SURVEY 8e's scaling argument is made
-    # on the 8192-per-GPU panda_pick shard (BASELINE configs[4]), so that workload is timed in the same job as well
+    exchange_ms = loop.time_exchange() if sharded else None   # (every rank takes part)
+    reports = gather_reports(loop)
+    # SURVEY 8e's scaling argument is made on BASELINE configs[4] (compute >> exchange): its strong-scaling row is timed in
+    # the same job at every N, the weak row (4096 panda samples per GPU) being the line's own `value`
     second = None
-    if world_size > 1 and args.workload == "panda_reach" and os.environ.get("MPPI_BENCH_SECOND", "1") != "0":
-        del_loop = measure("panda_pick", WORKLOADS["panda_pick"]["K"], max(20, min(args.steps, 100)), min(args.warmup, 10))
-        l2, e2, p2, k2, g2 = del_loop
-        second = {"workload": WORKLOADS["panda_pick"]["desc"], "K_per_gpu": l2.K, "K_total": l2.K * world_size, "H": l2.H,
-                  "steps": len(p2), "ms_per_step": 1e3 * e2 / len(p2), "loop_hz": len(p2) / e2, "value_hz_summed_over_gpus": world_size * len(p2) / e2,
-                  "env_steps_per_s": world_size * len(p2) / e2 * l2.K * l2.H, "rollout_kernel_ms": k2[0], "graph": g2}
+    if args.workload == "panda_reach" and not args.k_total and os.environ.get("MPPI_BENCH_SECOND", "1") != "0":
+        second = strong_row()
 
     # the same workload with the conf file AS THE REFERENCE SHIPS IT (filter_u: True in conf/mppi/panda.yaml:22): the smoothing
     # operator U <- F U runs inside the same combine kernel, the iteration costs the same
@@ -522,7 +566,6 @@ def main():
         ee = world.get_actor_link_by_name("panda", "panda_ee_tip")[0, 0:3].cpu().numpy()
         dist_to_goal = float(np.linalg.norm(ee - np.asarray(wl["goal"])))
 
-    exchange_ms = loop.time_exchange() if sharded else None   # (every rank takes part)
     if rank == 0:
         loop_hz = args.steps / elapsed
         K, H, nu = loop.K, loop.H, loop.nu
@@ -558,8 +601,9 @@ def main():
                        "loop_hz": loop_hz, "env_steps_per_s": loop_hz * K * H * world_size,
                        "final_ee_to_goal_m": dist_to_goal, "final_actor_positions": final_root,
                        "exchange_ms": exchange_ms,
+                       "exchange": {"selected": loop.exchange, "why": loop.exchange_why, "exchange_ms": exchange_ms, "per_rank": reports} if sharded else None,
                        "shipped_conf": shipped,
-                       "cfg5_shard": second},
+                       "cfg5_strong": second},
             "roofline": roofline(loop, kms[0], hbm_copy_ceiling(torch), n_waves),
             "kernels_ms": {"k_rollout(+record tail)": kms[0], "k_reduce(generic mode only)": kms[1], "k_combine_update(+world step)": kms[2]},
         }
@@ -569,6 +613,32 @@ def main():
         sys.stdout.flush()
         os.dup2(stdout_fd, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
+    # ---- A/B of the library's own exchange on real peers, AFTER the result line: same workloads through the mailbox (probe first;
+    # any refusal keeps RCCL and says why).  Its numbers go to stderr and gpurun_out/ - they are evidence, not the metric.
+    if world_size > 1 and backend == "nccl" and exchange == "rccl" and os.environ.get("MPPI_BENCH_MAILBOX_AB", "1") != "0":
+        env_mb = dict(env, exchange="mailbox")
+        try:
+            lm, em, pm, km, gm = measure(args.workload, K_PER_GPU, max(20, args.steps // 2), min(args.warmup, 10), env=env_mb)
+            ab = {"n_gpus": world_size, "workload": args.workload, "K_per_gpu": K_PER_GPU, "selected": lm.exchange, "why": lm.exchange_why,
+                  "ms_per_step": 1e3 * em / len(pm), "value": world_size * len(pm) / em, "graph": gm, "exchange_ms": lm.time_exchange(),
+                  "rccl_ms_per_step": 1e3 * elapsed / args.steps, "rccl_exchange_ms": exchange_ms}
+            ab["per_rank"] = gather_reports(lm)
+            if second is not None:
+                ab["cfg5_strong"] = strong_row(env=env_mb)
+            if rank == 0:
+                print("[bench] mailbox_ab " + json.dumps(ab), file=sys.stderr, flush=True)
+                try:
+                    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                    with open(os.path.join(ROOT, "gpurun_out", f"mailbox_ab_n{world_size}.json"), "w") as f:
+                        json.dump(ab, f)
+                except OSError:
+                    pass
+        except Exception as e:  # noqa: BLE001 - the result line is out already
+            # the peers may be inside a collective of the A/B pass: leaving quietly would strand them until a watchdog fires;
+            # a non-zero exit makes the launcher end the job at once
+            print(f"[bench] mailbox A/B failed on rank {rank}: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+            os._exit(3)
     if sharded:
         dist.barrier()
         dist.destroy_process_group()

@@ -303,7 +303,9 @@ def test_full_size_properties_contact_scenes(make, K, H, nu, lib, oracle64, monk
     # and fp32 part ways at 2x per substep, oracle f32 vs f64 alike - 19 of 8192 beyond 1e-3 there): asserted are 99.5 % within
     # 1e-3, 99.8 % within 1e-2, and that the samples beyond 1e-3 carry less than 1e-3 of the softmax normaliser eta and move the
     # nominal update by less than 1e-3 |u_max| (what the controller consumes)
-    assert r["within_1e-3"] >= 0.995 and r["within_1e-2"] >= 0.998
+    # measured on MI355X (profiles/r04a_gpu_tests.txt): pushing scene 99.98 % within 1e-3, max 1.4e-3 (2 samples beyond 1e-3, weight 0);
+    # gripper scene every sample within 1.3e-6
+    assert r["within_1e-3"] >= 0.999 and r["max"] <= 1e-2
     assert r["weight_mass_outside_1e-3"] < 1e-3 and r["update_max_abs_diff"] <= 1e-3 * np.abs(umax).max()
 
 
@@ -323,7 +325,8 @@ def test_contact_rich_states_match_oracle(make, name, K, H, nu, states, lib, ora
     Round 2 measured 62 % of the samples within 1e-3 at the recorded pushing state (max 25 %): the contact law was
     discontinuous (stick friction of grazing contacts, face-to-face patches beyond the explicit stability limit, joint stops)
     and the world-frame fp32 algebra lost digits two metres from the origin.  Bounds asserted here, per state:
-    recorded: >= 98 % within 1e-3, every sample within 1e-2; derived (violent) states: >= 96 % within 1e-3, >= 99 % within 1e-2."""
+    recorded: >= 99.5 % within 1e-3, every sample within 1e-2; derived (violent) states: >= 99 % within 1e-3, >= 99.9 % within 1e-2;
+    everywhere the samples beyond 1e-3 carry < 1e-3 of eta (measured: 0 - they are the expensive, tumbling ones)."""
     from mppiisaac.planner.mppi import make_config
     from mppiisaac.utils.config_store import load_config
     Z = np.load(CLOSED_LOOP_STATES)
@@ -353,12 +356,14 @@ def test_contact_rich_states_match_oracle(make, name, K, H, nu, states, lib, ora
         if st == "recorded":
             # where the controller works: >= 98 % within 1e-3, 99.9 % within 1e-2 - and the samples beyond 1e-3 carry less than
             # 1e-3 of eta; swapping the kernel's weights for the oracle's moves the nominal update by < 1e-3 |u_max|
-            assert r["within_1e-3"] >= 0.98 and r["within_1e-2"] >= 0.995
+            # measured (profiles/r04a_gpu_tests.txt, all 8192): pushing 99.87 % within 1e-3, max 4.6e-3; gripper 99.99 %, max 1.3e-3
+            assert r["within_1e-3"] >= 0.995 and r["max"] <= 1e-2
             assert r["weight_mass_outside_1e-3"] < 1e-3 and r["update_max_abs_diff"] <= 1e-3 * umax
             assert np.mean(rl <= 1e-3) >= 0.98 and np.mean(rl <= 1e-2) >= 0.998
         else:
-            assert r["within_1e-3"] >= 0.95 and r["within_1e-2"] >= 0.99
-            assert r["weight_mass_outside_1e-3"] < 1e-2 and r["update_max_abs_diff"] <= 1e-2 * umax
+            # measured: 99.7 - 99.99 % within 1e-3, 99.96 - 100 % within 1e-2 (the tumbling samples: max 0.17 / 0.13, weight 0)
+            assert r["within_1e-3"] >= 0.99 and r["within_1e-2"] >= 0.999
+            assert r["weight_mass_outside_1e-3"] < 1e-3 and r["update_max_abs_diff"] <= 1e-2 * umax
             assert np.mean(rl <= 1e-3) >= 0.96 and np.mean(rl <= 1e-2) >= 0.99
 
 
@@ -1167,4 +1172,4 @@ def test_golden_objective_inputs_through_the_hip_cost_program(case, lib):
     c.close()
     want = np.asarray(g["cost"])
     print(f"{case}: HIP cost program vs reference Objective on {n} golden envs: max rel {np.max(np.abs(out - want) / np.maximum(np.abs(want), 1e-6)):.1e}")
-    np.testing.assert_allclose(out, want, rtol=2e-5, atol=2e-5)   # fp32 interpreter, hardware sqrt / rcp (1 ulp) vs the reference's torch fp32
+    np.testing.assert_allclose(out, want, rtol=2e-6, atol=2e-6)   # fp32 interpreter, hardware sqrt / rcp (1 ulp) vs the reference's torch fp32: measured 1.6e-7

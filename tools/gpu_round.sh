@@ -10,7 +10,7 @@ mkdir -p $OUT
 cd $REPO
 B="python bench.py --no-cpu-baseline"
 if [[ $WHAT == *tests* ]]; then
-  timeout 1200 python -m pytest tests -m gpu -q > $OUT/gpu_tests.log 2>&1; echo "pytest rc=$?" >> $OUT/gpu_tests.log
+  timeout 1500 python -m pytest tests -m gpu -q -s --durations=15 > $OUT/gpu_tests.log 2>&1; echo "pytest rc=$?" >> $OUT/gpu_tests.log
   tail -5 $OUT/gpu_tests.log
 fi
 if [[ $WHAT == *bench* ]]; then
