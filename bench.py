@@ -127,6 +127,8 @@ class Loop:
         ok, why = 1, ""
         self.probe = {"fine_grained": None, "records_per_rank": None, "iterations": 0, "late": None, "equal_per_rank": None}
         try:
+            if os.environ.get("MPPI_BENCH_TEST_REFUSE_RANK") == str(rank):   # (test hook: one rank cannot take part)
+                raise RuntimeError("refused (MPPI_BENCH_TEST_REFUSE_RANK)")
             capi.check(lib, lib.mppi_mailbox_create(P, rank, world))
             fine, nrec, nr = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
             capi.check(lib, lib.mppi_mailbox_info(P, ctypes.byref(fine), ctypes.byref(nrec), ctypes.byref(nr)))

@@ -44,7 +44,7 @@ extern "C" {
 
 enum { MPPI_OK = 0, MPPI_EINVAL = -1, MPPI_EHIP = -2, MPPI_EUNSUPPORTED = -3, MPPI_ESTATE = -4 };
 enum { MPPI_JOINT_REVOLUTE = 0, MPPI_JOINT_PRISMATIC = 1 };
-/* dof_mode of the reference's ActorWrapper (isaacgym_wrapper.py:52, drive gains :491-507) */
+/* dof_mode of the reference's ActorWrapper (isaacgym_wrapper.py:52, drive gains :491-507; position: see mppi_model_t.drive_kp) */
 enum { MPPI_DRIVE_VELOCITY = 0, MPPI_DRIVE_EFFORT = 1, MPPI_DRIVE_POSITION = 2 };
 /* ActorWrapper.type (isaacgym_wrapper.py:42-46, isaacgym_utils.py:19-54) */
 enum { MPPI_ACTOR_ROBOT = 0, MPPI_ACTOR_BOX = 1, MPPI_ACTOR_SPHERE = 2 };
@@ -177,7 +177,12 @@ typedef struct mppi_model {
     double base_Io[6];
     int32_t drive_mode;  /* MPPI_DRIVE_*                                                  */
     int32_t substeps;    /* conf/isaacgym/<x>.yaml                                        */
-    double drive_kd;     /* 600 velocity / 10 effort (isaacgym_wrapper.py:491-500)        */
+    double drive_kd;     /* 600 velocity / 10 effort / 0 position (isaacgym_wrapper.py:491-504)  */
+    /* MPPI_DRIVE_POSITION (isaacgym_wrapper.py:501-504,571-572): apply_robot_cmd OVERWRITES the DOF state with the command -
+     * q <- target, qdot <- 0 at the start of every simulator step - and the step then runs with the position drive
+     * tau = kp (target - q) - kd qdot, kp = drive_kp = 80 (treated implicitly like the other drives).  The reference never sets a
+     * position target (it would stay 0: a spring to zero behind a teleport to u); the drive here holds the commanded pose. */
+    double drive_kp;
     double dt;
     double gravity[3];   /* (0,0,-9.8) isaacgym_wrapper.py:29                             */
     /* command scatter of apply_robot_cmd (isaacgym_wrapper.py:524-572), folded into at

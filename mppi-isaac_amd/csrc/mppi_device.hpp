@@ -129,7 +129,9 @@ struct DevModel {
     float kd, h, g[3], base_m;
     int cmd_identity;  // the command map is the identity (nu == nb, one command per body, unit gain): target = u
     int all_revolute;  // every joint is revolute: the quad rollout runs its compile-time specialisation
-    float base_hb[3], base_Ic[6], pad3[3];
+    float base_hb[3], base_Ic[6];
+    float kp;  // position drive stiffness (kDrivePosition; 0 otherwise)
+    float pad3[2];
     int actor_first_rb[kMaxActors];
     int n_shapes, n_pairs, rnd_seed, n_rnd;
     int rnd_slot[kMaxActors];    // LDS slot of a noisy actor's per-sample draws (-1: nominal)
@@ -731,15 +733,21 @@ template <class T>
 MPPI_HD void step(CModel &m0, const float *root, float *q, float *qd, const float *target) {
     constexpr int NB = T::NB;
     CModel *mp = &m0;
+    // position mode (reference isaacgym_wrapper.py:571-572): apply_robot_cmd overwrites the DOF state with the command
+    if (m0.drive_mode == kDrivePosition)
+        static_for<0, NB>([&](auto ic) MPPI_LAMBDA { q[ic] = target[ic]; qd[ic] = 0.f; });
     for (int s = 0; s < m0.substeps; s++) {
         CModel &m = *launder(mp);  // re-fetch model constants per substep (see launder())
-        const float h = m.h, kd = m.kd;
+        // drives, implicit in the velocity: velocity kd (target - qd), effort target - kd qd, position kp (target - q) - kd qd with
+        // q taken at the END of the substep, which is the same form with the damping kd + h kp (oracle: drive_damping)
+        const bool pos = m.drive_mode == kDrivePosition;
+        const float h = m.h, kp = pos ? m.kp : 0.f, kd = m.kd + h * kp;
         Pose<T> P;
         forward_kinematics<T>(m, root, q, P);
         float tau[NB], kdh[NB], qdd[NB], ff[NB], vs[NB];
         static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
             constexpr int i = ic;
-            ff[i] = m.drive_mode == kDriveEffort ? target[i] : 0.f;
+            ff[i] = m.drive_mode == kDriveEffort ? target[i] : (pos ? kp * (target[i] - q[i]) : 0.f);
             vs[i] = m.drive_mode == kDriveVelocity ? target[i] : 0.f;
             tau[i] = ff[i] + kd * (vs[i] - qd[i]);
             kdh[i] = kd * h;

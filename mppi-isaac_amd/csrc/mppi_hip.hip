@@ -20,7 +20,10 @@ int fail(int code, const std::string &msg) {
 #define HIP_TRY(expr)                                                                                         \
     do {                                                                                                      \
         hipError_t e_ = (expr);                                                                               \
-        if (e_ != hipSuccess) return fail(MPPI_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+        if (e_ != hipSuccess) {                                                                               \
+            (void)hipGetLastError(); /* reported here: the next launch_check() must not find it again */      \
+            return fail(MPPI_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));                        \
+        }                                                                                                     \
     } while (0)
 
 struct EvScope {  // optional hipEvent bracket around one launch (profiling mode)
@@ -590,6 +593,17 @@ int mppi_mailbox_open(mppi_ctx_t *c, int peer_rank, const void *handle64) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
     c->ipc_opened.push_back(p);
+    // pre-flight: the mapping must take a write and give it back BEFORE any kernel stores through it (a kernel's store to an
+    // unmapped peer address is a memory fault that ends the process; a failed copy is an error code).  Word 1 of this rank's flag
+    // line in the peer's inbox is padding no kernel touches.
+    {
+        unsigned *probe_at = reinterpret_cast<unsigned *>(p) + (size_t)kMailboxFlagStride * c->mb_rank + 1;
+        const unsigned probe = 0x4d500000u + (unsigned)c->mb_rank;
+        unsigned back = 0;
+        HIP_TRY(hipMemcpy(probe_at, &probe, sizeof probe, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(&back, probe_at, sizeof back, hipMemcpyDeviceToHost));
+        if (back != probe) return fail(MPPI_EHIP, "mppi_mailbox_open: the peer's inbox does not hold what was written to it (no coherent mapping)");
+    }
     c->h_peers[peer_rank] = p;
     c->peers_dirty = true;
     return MPPI_OK;

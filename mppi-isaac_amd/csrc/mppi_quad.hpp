@@ -683,20 +683,41 @@ template <class T, class M, int JT>
 MPPI_HD void quad_step(M &m0, QPose<T, JT> &P, QF *q, QF *qd, const QF *target) {
     constexpr int NB = T::NB;
     M *mp = &m0;
+    // position mode (isaacgym_wrapper.py:571-572): apply_robot_cmd overwrites the DOF state with the command.  It lives in the
+    // GENERIC instantiation only (JT != 0; mppi_pack.hpp clears all_revolute for a position-driven robot): the all-revolute
+    // specialisation is the metric's instruction stream and carries no trace of it (measured: as a run-time branch of the
+    // common code it cost the headline kernel 3 %, 0.1203 -> 0.1240 ms)
+    if constexpr (JT != 0)
+        if (m0.drive_mode == kDrivePosition) {
+            static_for<0, NB>([&](auto ic) MPPI_LAMBDA { q[ic] = target[ic]; qd[ic] = qrep(0.f); });
+            quad_fk<T>(m0, q, P);
+        }
     for (int s = 0; s < m0.substeps; s++) {
         M &m = *launder(mp);
-        const float h = m.h, kd = m.kd, inv_h = frcp(h);
+        const float h = m.h, inv_h = frcp(h);
+        float kd = m.kd;
         QF tau[NB], kdh[NB], qdd[NB];
         JointLimits lim[NB];
         // joint drives (isaacgym_wrapper.py:491-507): velocity mode tau = kd (target - qd), effort mode tau = target - kd qd,
         // both with the implicit damping kd h qdd inside the solve.  ONE uniform branch picks the mode (as selects it was four
-        // instructions per joint and substep)
-        const QF kdhq = qrep(kd * h);
-        if (m.drive_mode == kDriveVelocity) {
-            static_for<0, NB>([&](auto ic) MPPI_LAMBDA { tau[ic] = kd * (target[ic] - qd[ic]); });
-        } else {
-            static_for<0, NB>([&](auto ic) MPPI_LAMBDA { tau[ic] = target[ic] - kd * qd[ic]; });
+        // instructions per joint and substep).  Position mode (generic instantiation): tau = kp (target - q) - (kd + h kp) qd,
+        // the spring at the end-of-substep position (mppi_device.hpp step)
+        bool driven = false;
+        if constexpr (JT != 0)
+            if (m.drive_mode == kDrivePosition) {
+                const float kp = m.kp;
+                kd += h * kp;
+                static_for<0, NB>([&](auto ic) MPPI_LAMBDA { tau[ic] = kp * (target[ic] - q[ic]) - kd * qd[ic]; });
+                driven = true;
+            }
+        if (!driven) {
+            if (m.drive_mode == kDriveVelocity) {
+                static_for<0, NB>([&](auto ic) MPPI_LAMBDA { tau[ic] = kd * (target[ic] - qd[ic]); });
+            } else {
+                static_for<0, NB>([&](auto ic) MPPI_LAMBDA { tau[ic] = target[ic] - kd * qd[ic]; });
+            }
         }
+        const QF kdhq = qrep(kd * h);
         static_for<0, NB>([&](auto ic) MPPI_LAMBDA { kdh[ic] = kdhq; });
         quad_aba<T>(m, P, qd, tau, kdh, qdd, lim);
         // URDF effort limits: a drive whose torque tau - kd h qdd leaves [-effort, effort] is held at the bound and the step is

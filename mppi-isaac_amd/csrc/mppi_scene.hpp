@@ -1590,9 +1590,14 @@ template <class T, int SPLIT = kSplitNone, class M = CModel>
 MPPI_HD void step_scene(M &m0, const float *root, SceneState<T> &s, const float *target, const LMem &L, Split split = Split{0, 1}) {
     constexpr int NB = T::NB;
     M *mp = &m0;
+    // position mode (reference isaacgym_wrapper.py:571-572): apply_robot_cmd overwrites the DOF state with the command
+    if (m0.drive_mode == kDrivePosition)
+        static_for<0, NB>([&](auto ic) MPPI_LAMBDA { s.q[ic] = target[ic]; s.qd[ic] = 0.f; });
     for (int sub = 0; sub < m0.substeps; sub++) {
         M &m = *launder(mp);
-        const float h = m.h, kd = m.kd;
+        // (position drive: the spring at the end-of-substep position = damping kd + h kp, mppi_device.hpp step)
+        const bool posmode = m.drive_mode == kDrivePosition;
+        const float h = m.h, kp = posmode ? m.kp : 0.f, kd = m.kd + h * kp;
         Pose<T> P;
         SV vbase;
         scene_frames<T>(m, root, s, P, vbase, L);
@@ -1621,7 +1626,7 @@ MPPI_HD void step_scene(M &m0, const float *root, SceneState<T> &s, const float 
         float tau[NB ? NB : 1], kdh[NB ? NB : 1], qdd[NB ? NB : 1], ff[NB ? NB : 1], vs[NB ? NB : 1];
         static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
             constexpr int i = ic;
-            ff[i] = m.drive_mode == kDriveEffort ? tgt[i] : 0.f;
+            ff[i] = m.drive_mode == kDriveEffort ? tgt[i] : (posmode ? kp * (tgt[i] - s.q[i]) : 0.f);
             vs[i] = m.drive_mode == kDriveVelocity ? tgt[i] : 0.f;
             tau[i] = ff[i] + kd * (vs[i] - s.qd[i]);
             kdh[i] = kd * h;

@@ -312,6 +312,9 @@ MPPI_HD void step_scene_quad(M &m0, MR &mr0, const float *root, SceneState<T> &s
     constexpr int NBs = NB ? NB : 1;
     M *mp = &m0;
     MR *mrp = &mr0;
+    // position mode (reference isaacgym_wrapper.py:571-572): apply_robot_cmd overwrites the DOF state with the command
+    if (m0.drive_mode == kDrivePosition)
+        static_for<0, NB>([&](auto ic) MPPI_LAMBDA { s.q[ic] = target[ic]; s.qd[ic] = 0.f; });
     for (int sub = 0; sub < m0.substeps; sub++) {
         M &m = *launder(mp);
         MR &mr = *launder(mrp);
@@ -349,12 +352,17 @@ MPPI_HD void step_scene_quad(M &m0, MR &mr0, const float *root, SceneState<T> &s
         JointLimits lim[NBs];
         // joint drives and the effort-limit test: as in quad_step (mppi_quad.hpp) - one uniform branch for the drive mode,
         // one running maximum for the saturation test, the selects inside the rare branch
-        const QF kdhq = qrep(kd * h);
+        float kde = kd;
         if (m.drive_mode == kDriveVelocity) {
             static_for<0, NB>([&](auto ic) MPPI_LAMBDA { tau[ic] = kd * (qrep(target[ic]) - qd[ic]); });
-        } else {
+        } else if (m.drive_mode == kDriveEffort) {
             static_for<0, NB>([&](auto ic) MPPI_LAMBDA { tau[ic] = qrep(target[ic]) - kd * qd[ic]; });
+        } else {  // position: the spring at the end-of-substep position (mppi_quad.hpp quad_step)
+            const float kp = m.kp;
+            kde = kd + h * kp;
+            static_for<0, NB>([&](auto ic) MPPI_LAMBDA { tau[ic] = kp * (qrep(target[ic]) - qrep(s.q[ic])) - kde * qd[ic]; });
         }
+        const QF kdhq = qrep(kde * h);
         static_for<0, NB>([&](auto ic) MPPI_LAMBDA { kdh[ic] = kdhq; });
         SV abase;
         QAbaPrep<T> prep;

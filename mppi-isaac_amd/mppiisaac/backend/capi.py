@@ -57,7 +57,7 @@ class Model(C.Structure):
     _fields_ = [("abi_version", _i), ("n_actors", _i), ("actors", Actor * MAX_ACTORS), ("robot_actor", _i),
                 ("n_bodies", _i), ("bodies", Body * MAX_BODIES), ("n_links", _i), ("n_rb", _i),
                 ("links", Link * MAX_LINKS), ("base_mass", _d), ("base_h", _d * 3), ("base_Io", _d * 6),
-                ("drive_mode", _i), ("substeps", _i), ("drive_kd", _d), ("dt", _d), ("gravity", _d * 3),
+                ("drive_mode", _i), ("substeps", _i), ("drive_kd", _d), ("drive_kp", _d), ("dt", _d), ("gravity", _d * 3),
                 ("nu", _i), ("cmd_col", (_i * 2) * MAX_BODIES), ("cmd_coef", (_d * 2) * MAX_BODIES),
                 ("n_shapes", _i), ("n_pairs", _i), ("shapes", Shape * MAX_SHAPES), ("pairs", Pair * MAX_PAIRS),
                 ("ground_friction", _d), ("contact_alpha", _d), ("contact_beta", _d), ("friction_beta", _d), ("contact_ramp_depth", _d),

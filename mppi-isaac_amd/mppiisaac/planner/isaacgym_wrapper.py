@@ -76,8 +76,8 @@ class ActorWrapper:
     noise_percentage_friction: float = 0.0
 
 
-DRIVE_GAINS = {"velocity": (capi.DRIVE_VELOCITY, 600.0), "effort": (capi.DRIVE_EFFORT, 10.0),
-               "position": (capi.DRIVE_POSITION, 0.0)}  # reference :491-507
+DRIVE_GAINS = {"velocity": (capi.DRIVE_VELOCITY, 600.0, 0.0), "effort": (capi.DRIVE_EFFORT, 10.0, 0.0),
+               "position": (capi.DRIVE_POSITION, 0.0, 80.0)}  # (mode, damping, stiffness): reference :491-507
 GRAVITY = (0.0, 0.0, -9.8)  # reference :29
 _REPORTED_DROPS = set()
 
@@ -424,7 +424,7 @@ class Scene:
         m.randomize_seed = int(self.randomize_seed)
         if self.robot.dof_mode not in DRIVE_GAINS:
             raise ValueError("Invalid dof_mode")
-        m.drive_mode, m.drive_kd = DRIVE_GAINS[self.robot.dof_mode]
+        m.drive_mode, m.drive_kd, m.drive_kp = DRIVE_GAINS[self.robot.dof_mode]
         m.substeps = int(self.cfg.substeps)
         m.dt = float(self.cfg.dt)
         for j in range(3):

@@ -298,15 +298,27 @@ static void joint_limit(real qold, real *q, real *qd, real lower, real upper, re
     if (*q > upper) { *q = upper; real ve = (upper - qold) / h; *qd = ve > 0 ? ve : 0; }
 }
 
+/* Drives (reference isaacgym_wrapper.py:491-507): velocity tau = kd (target - qd), effort tau = target - kd qd, position
+ * tau = kp (target - q) - kd qd - all implicit in the velocity: with qd+ = qd + h qdd and q+ = q + h qd+ the position drive is
+ * kp (target - q) - (kd + h kp) qd+ , i.e. the same form with the damping kde = kd + h kp.  Position mode also TELEPORTS:
+ * apply_robot_cmd overwrites the DOF state with the command (:571-572) before the step. */
+static void drive_teleport(const mppi_model_t *m, real *q, real *qd, const real *target) {
+    if (m->drive_mode != MPPI_DRIVE_POSITION) return;
+    for (int i = 0; i < m->n_bodies; i++) { q[i] = target[i]; qd[i] = 0; }
+}
+static real drive_damping(const mppi_model_t *m, real h) {
+    return (real)m->drive_kd + (m->drive_mode == MPPI_DRIVE_POSITION ? h * (real)m->drive_kp : 0);
+}
 void orc_step(const mppi_model_t *m, const real *root, real *q, real *qd, const real *target) {
     int n = m->n_bodies;
-    real h = (real)(m->dt / m->substeps), kd = (real)m->drive_kd;
+    real h = (real)(m->dt / m->substeps), kd = drive_damping(m, h), kp = m->drive_mode == MPPI_DRIVE_POSITION ? (real)m->drive_kp : 0;
+    drive_teleport(m, q, qd, target);
     for (int s = 0; s < m->substeps; s++) {
         kin_t k;
         kinematics(m, root, q, qd, &k);
         real ff[NBMAX], vs[NBMAX], tau[NBMAX], kdh[NBMAX], qdd[NBMAX];
         for (int i = 0; i < n; i++) {
-            ff[i] = m->drive_mode == MPPI_DRIVE_EFFORT ? target[i] : 0;
+            ff[i] = m->drive_mode == MPPI_DRIVE_EFFORT ? target[i] : (m->drive_mode == MPPI_DRIVE_POSITION ? kp * (target[i] - q[i]) : 0);
             vs[i] = m->drive_mode == MPPI_DRIVE_VELOCITY ? target[i] : 0;
 
             tau[i] = ff[i] + kd * (vs[i] - qd[i]);
@@ -825,7 +837,8 @@ void orc_scene_step(const mppi_model_t *m, real *root, real *q, real *qd, const 
     scene_info_t si;
     scene_info(m, &si);
     int n = m->n_bodies;
-    real h = (real)(m->dt / m->substeps), kd = (real)m->drive_kd;
+    real h = (real)(m->dt / m->substeps), kd = drive_damping(m, h), kp = m->drive_mode == MPPI_DRIVE_POSITION ? (real)m->drive_kp : 0;
+    drive_teleport(m, q, qd, target);
     frame_t *fr = (frame_t *)calloc(NFMAX, sizeof(frame_t));
     real *cf = (real *)calloc(3 * (size_t)m->n_rb + 3, sizeof(real));
     for (int s = 0; s < m->substeps; s++) {
@@ -833,7 +846,7 @@ void orc_scene_step(const mppi_model_t *m, real *root, real *q, real *qd, const 
         scene_contacts(m, &si, fr, root, cf);
         real ff[NBMAX], vs[NBMAX], tau[NBMAX], kdh[NBMAX], qdd[NBMAX], abase[6];
         for (int i = 0; i < n; i++) {
-            ff[i] = m->drive_mode == MPPI_DRIVE_EFFORT ? target[i] : 0;
+            ff[i] = m->drive_mode == MPPI_DRIVE_EFFORT ? target[i] : (m->drive_mode == MPPI_DRIVE_POSITION ? kp * (target[i] - q[i]) : 0);
             vs[i] = m->drive_mode == MPPI_DRIVE_VELOCITY ? target[i] : 0;
             tau[i] = ff[i] + kd * (vs[i] - qd[i]);
             kdh[i] = kd * h;

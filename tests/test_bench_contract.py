@@ -93,6 +93,26 @@ def test_bench_two_ranks_exchange_through_the_library_mailbox():
     assert d["n_gpus"] == 2 and "mailbox exchange" in d["config"]["parallelism"], (d["config"]["parallelism"], out.stderr[-1500:])
     assert d["value"] > 100.0 and d["config"]["final_ee_to_goal_m"] < 0.6
     assert d["config"]["exchange_ms"] is not None and d["config"]["exchange_ms"] < 5.0
+    ex = d["config"]["exchange"]                                      # the record explains itself: what ran on every rank, and why
+    assert ex["selected"] == "mailbox" and "probe passed" in ex["why"]
+    assert [r["selected"] for r in ex["per_rank"]] == ["mailbox", "mailbox"] and all(r["mppi_exchange_status"] == 0 for r in ex["per_rank"])
+    assert all(r["probe"]["equal_per_rank"] == [1, 1] and r["probe"]["late"] == [0, 0] for r in ex["per_rank"])
+
+
+def test_bench_a_rank_that_refuses_the_mailbox_sends_every_rank_to_the_all_gather():
+    """negative path of the multi-rank set-up: one rank cannot create its inbox (test hook) - every rank agrees on the all-gather,
+    nobody hangs, and the result line says which exchange ran and why, per rank"""
+    env = dict(os.environ, MPPI_BENCH_BACKEND="gloo", MPPI_BENCH_EXCHANGE="mailbox", MPPI_BENCH_SECOND="0", MPPI_BENCH_SHIPPED="0",
+               MPPI_BENCH_TEST_REFUSE_RANK="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29619", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "50", "--warmup", "5"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    ex = d["config"]["exchange"]
+    assert ex["selected"] == "rccl" and "refused" in ex["why"] and "rank 1" in ex["why"]
+    assert [r["selected"] for r in ex["per_rank"]] == ["rccl", "rccl"] and ex["exchange_ms"] is None or ex["exchange_ms"] >= 0
+    assert "all-gather" in d["config"]["parallelism"] and d["value"] > 100.0
 
 
 def test_smoke_entry_point():

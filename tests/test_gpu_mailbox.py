@@ -211,3 +211,113 @@ def test_mailbox_ipc_handle_roundtrip(lib):
     assert any(bytes(h))
     for c in shards:
         c.close()
+
+
+def test_late_rank_is_neutral_in_the_update(lib):
+    """a peer that never publishes: the wait gives up (bounded), the status word says so, and the late rank's slots reach the
+    update as NEUTRAL records (eta = 0) - the action is the one this rank's own records give, not one mixed with whatever an
+    old or half-written slot held (RCCL would hang or raise here)."""
+    K, H, G = 1024, 8, 2
+    scene, m, cfg, cost, dof, root, shards, streams = shard_contexts(panda_reach, "panda", K, H, G, lib)
+    nu, s = cfg.nu, shards[0]
+    RF = lib.mppi_record_floats(s.ctx)
+    p, n = C.c_void_p(), C.c_int()
+    s.call("mppi_mailbox_gathered", C.byref(p), C.byref(n))
+    # poison rank 1's slots first, as a stale iteration would leave them: publish from rank 1 ONCE, with absurd records
+    shards[1].call("mppi_rollout"); shards[0].call("mppi_rollout")
+    shards[1].call("mppi_exchange_publish"); shards[0].call("mppi_exchange")     # iteration 1: both publish, rank 0 gathers
+    s.call("mppi_update", p, n.value)
+    # iteration 2 and 3: rank 1 is silent (slot parity 0 was never written by rank 1; parity 1 holds its iteration-1 records)
+    for _ in range(2):
+        s.call("mppi_rollout")
+        s.call("mppi_exchange")
+        late = C.c_int(0)
+        s.call("mppi_exchange_status", C.byref(late))
+        assert late.value == 1
+        torch.cuda.synchronize()
+        rec = dev_to_host(p, n.value * RF).reshape(n.value, RF)
+        assert rec[0, 1] > 0 and rec[1, 1] == 0.0                     # own record live, the late rank's neutral
+        U = s.get("mppi_get_nominal", (H, nu))
+        own, _ = C.c_void_p(), None
+        capi.check(lib, lib.mppi_record_dev(s.ctx, C.byref(own)))     # this shard's own record
+        torch.cuda.synchronize()
+        r0 = dev_to_host(own, RF)
+        np.testing.assert_allclose(rec[0], r0, rtol=1e-6)
+        s.call("mppi_update", p, n.value)
+        a = s.get("mppi_get_action", (nu,))
+        np.testing.assert_allclose(a, U[0] + r0[2:2 + nu] / r0[1], atol=3e-6)   # the update of the ranks that did publish
+    for c in shards:
+        c.close()
+
+
+def test_mailbox_create_and_open_refusals_leave_a_usable_context(lib):
+    """negative paths of the set-up: bad arguments, a second create, a stale / foreign / garbage IPC handle - each is an error code
+    with a message, nothing half-built stays behind, and the context keeps working through the plain path afterwards"""
+    K, H = 512, 8
+    scene, m, cfg, cost, dof, root = panda_reach(K=K, H=H)
+    c = Ctx(m, cfg, cost)
+    c.call("mppi_sample", C.c_uint32(0)); c.set_state(dof, root)
+    fine, nrec, nr = C.c_int(), C.c_int(), C.c_int()
+    assert lib.mppi_mailbox_info(c.ctx, C.byref(fine), C.byref(nrec), C.byref(nr)) == capi.MPPI_ESTATE     # no mailbox yet
+    for rank, n in ((2, 2), (-1, 2), (0, 0), (0, 65)):
+        assert lib.mppi_mailbox_create(c.ctx, rank, n) == capi.MPPI_EINVAL
+        assert lib.mppi_mailbox_info(c.ctx, C.byref(fine), C.byref(nrec), C.byref(nr)) == capi.MPPI_ESTATE  # nothing left behind
+    assert lib.mppi_exchange(c.ctx) == capi.MPPI_ESTATE and lib.mppi_exchange_wait(c.ctx) == capi.MPPI_ESTATE
+    c.call("mppi_mailbox_create", 0, 2)
+    assert lib.mppi_mailbox_create(c.ctx, 0, 2) == capi.MPPI_ESTATE                                      # a second create is refused ...
+    c.call("mppi_mailbox_info", C.byref(fine), C.byref(nrec), C.byref(nr))                                # ... and the first one is intact
+    assert (nrec.value, nr.value) == (1, 2)
+    assert lib.mppi_exchange(c.ctx) == capi.MPPI_ESTATE and b"not connected" in lib.mppi_last_error()    # peer 1 was never connected
+    for blob in (bytes(64), bytes(range(64)), b"\xff" * 64):                                            # garbage handles: an error, not a crash
+        assert lib.mppi_mailbox_open(c.ctx, 1, (C.c_ubyte * 64).from_buffer_copy(blob)) == capi.MPPI_EHIP
+    assert lib.mppi_mailbox_open(c.ctx, 5, (C.c_ubyte * 64)()) == capi.MPPI_EINVAL                        # rank out of range
+    assert lib.mppi_mailbox_set_peer(c.ctx, 1, None) == capi.MPPI_EINVAL
+    a = np.zeros(cfg.nu, np.float32)
+    c.call("mppi_command", capi.fptr(a))                                                                  # the context still plans
+    assert np.isfinite(a).all() and np.abs(a).max() > 0
+    c.close()
+
+
+def test_mailbox_sized_for_folded_records_serves_generic_mode(lib):
+    """a contact scene whose rollout folds 8 records per shard sizes its mailbox for 8 - and a generic Objective
+    (host-side costs: nothing is folded) then has ONE reduced record to publish.  It goes out with neutral padding; two shards
+    through the mailbox give the single context's update."""
+    K, H, G = 4096, 6, 2
+    scene, m, cfg, cost, dof, root, shards, streams = shard_contexts(boxer_push, "boxer_push", K, H, G, lib)
+    nu = cfg.nu
+    assert lib.mppi_shard_record_count(shards[0].ctx) == 8
+    full = Ctx(m, cfg, cost)
+    full.call("mppi_sample", C.c_uint32(0)); full.set_state(dof, root)
+    host_cost = (1.0 + torch.sin(0.37 * torch.arange(K, dtype=torch.float32, device="cuda"))).contiguous()   # stands in for compute_cost(sim)
+
+    def generic_horizon(c, costs):     # the reference's loop shape (mppi_isaac.py:57-69) with a precomputed cost tensor
+        c.call("mppi_sim_reset")
+        for t in range(H):
+            c.call("mppi_sim_step_horizon", t)
+            c.call("mppi_sim_accumulate_cost", t, C.c_void_p(costs.data_ptr()))
+        c.call("mppi_sim_finish")
+    torch.cuda.synchronize()
+    generic_horizon(full, host_cost)
+    full.call("mppi_reduce", None); full.call("mppi_update", None, 1)
+    a_full, U_full = full.get("mppi_get_action", (nu,)), full.get("mppi_get_nominal", (H, nu))
+    torch.cuda.synchronize()
+    parts = [host_cost[r * K // G:(r + 1) * K // G].contiguous() for r in range(G)]
+    for s_, part in zip(shards, parts):
+        generic_horizon(s_, part)
+    torch.cuda.synchronize()
+    for s_ in shards:
+        s_.call("mppi_exchange_publish")
+    for s_ in shards:
+        s_.call("mppi_exchange_wait")
+    for s_ in shards:
+        p, n = C.c_void_p(), C.c_int()
+        s_.call("mppi_mailbox_gathered", C.byref(p), C.byref(n))
+        assert n.value == 8 * G
+        s_.call("mppi_update", p, n.value)
+        late = C.c_int(-1)
+        s_.call("mppi_exchange_status", C.byref(late))
+        assert late.value == 0
+        np.testing.assert_allclose(s_.get("mppi_get_action", (nu,)), a_full, atol=3e-6)
+        np.testing.assert_allclose(s_.get("mppi_get_nominal", (H, nu)), U_full, atol=3e-6)
+    for c in shards + [full]:
+        c.close()

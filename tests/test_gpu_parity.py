@@ -901,6 +901,10 @@ JACKAL_WHEELS = {"left_wheel_joints": ["front_left_wheel", "rear_left_wheel"], "
     (["panda_effort", "goal"], [[0.0, 0.0, 0.0]], "panda_link7", 7, 20.0, 40.0, None),      # effort mode, fixed base
     (["omnipanda", "goal"], [[0.0, 0.0, 0.0]], "panda_hand", 12, 0.2, 0.5, None),           # velocity mode, holonomic base + arm + gripper
     (["anymal", "goal"], [[0.0, 0.0, 0.62]], "base", 12, 1.0, 5.5, None),                     # quadruped on its feet: floating trunk, four legs
+    # dof_mode "position" (reference isaacgym_wrapper.py:501-504,571-572: the command overwrites the DOF state, stiffness drive):
+    (["panda_stick", "goal"], [[0.0, 0.0, 0.0]], "panda_ee_tip", 7, 0.05, 2.5, {"dof_mode": "position"}),   # quad kernel
+    (["panda_gripper", "goal"], [[0.0, 0.0, 0.0]], "panda_hand", 9, 0.02, 2.5, {"dof_mode": "position"}),   # 9-body tree
+    (["albert", "goal"], [[0.0, 0.0, 0.2]], "mmrobot_link7", 9, 0.05, 2.5, {"dof_mode": "position"}),       # contact scene (octet kernel)
 ])
 def test_more_robots_rollout(actors, init, link, nu, sigma, umax, over, lib, oracle64):
     """SURVEY 8f rank 1 robots through the HIP path: reach cost on one of their links, rollouts vs the oracle."""

@@ -100,3 +100,38 @@ def test_quad_parallel_rollout_matches_oracle(make, hostemu, oracle64):
     np.testing.assert_allclose(due, du, atol=1e-6)
     if vize is not None:
         np.testing.assert_allclose(vize, viz, atol=2e-5)
+
+
+def test_position_mode_matches_oracle(hostemu, oracle64):
+    """dof_mode "position" (teleport to the command, then the stiffness drive; reference isaacgym_wrapper.py:501-504,571-572):
+    one-lane step, one-lane and quad rollouts of the arm, and the gripper scene's contact step, against the oracle"""
+    scene = build_scene(["panda_stick", "goal"], robot_overrides={"dof_mode": "position"})
+    scene.robot.gravity = True
+    m = scene.to_c()
+    assert m.drive_mode == 2 and m.drive_kp == 80.0 and m.drive_kd == 0.0
+    dof, root = scene.initial_state()
+    rng = np.random.default_rng(11)
+    q, qd = dof[0::2].astype(np.float64), 0.3 * rng.normal(size=7)
+    qe, qde = f32(q).copy(), f32(qd).copy()
+    for _ in range(6):
+        u = dof[0::2] + rng.uniform(-0.3, 0.3, 7)                                  # commanded joint positions
+        q, qd = oracle64.step(m, root, q, qd, oracle64.cmd_map(m, u))
+        assert hostemu.emu_step(C.byref(m), fp(f32(root)), fp(qe), fp(qde), fp(f32(u))) == 0
+        assert np.abs(q - u).max() < 0.1 and np.abs(qd).max() > 1e-3               # teleported, then sagging under gravity
+        np.testing.assert_allclose(qe, q, atol=2e-5)
+        np.testing.assert_allclose(qde, qd, atol=2e-3)
+    # whole rollouts: nominal U = the start pose, noise around it (panda_reach's cost and sampler)
+    _, _, cfg, cost, _, root = panda_reach(K=64, H=8)
+    eps = oracle64.sample(cfg)
+    U = np.tile(dof[0::2], (cfg.horizon, 1))
+    for j in range(7):
+        cfg.u_min[j], cfg.u_max[j] = -3.0, 3.0
+    S, du, _ = oracle64.rollout(m, cfg, cost, dof, root, U, eps)
+    Se, due, _ = emu_rollout(hostemu, m, cfg, cost, dof, root, U, eps)
+    np.testing.assert_allclose(Se, S, rtol=5e-5)
+    Sq, duq = np.zeros(cfg.num_samples, np.float32), np.zeros_like(f32(eps))
+    assert hostemu.emu_rollout_quad(C.byref(m), C.byref(cfg), C.byref(cost), fp(f32(dof)), fp(f32(root)), fp(f32(U)), fp(f32(eps)), None,
+                                    fp(Sq), fp(duq), None) == 0
+    assert not np.isnan(Sq).any()
+    np.testing.assert_allclose(Sq, S, rtol=5e-5)
+    np.testing.assert_allclose(duq, du, atol=1e-6)

@@ -134,6 +134,51 @@ def test_pendulum_acceleration_and_period(oracle64):
     assert period == pytest.approx(2 * math.pi * math.sqrt(L / 9.8), rel=2e-3)
 
 
+def test_position_mode_teleports_then_holds_with_the_stiffness_drive(oracle64):
+    """dof_mode "position" (reference isaacgym_wrapper.py:501-504 stiffness 80 / damping 0, :571-572 apply_robot_cmd overwrites the
+    DOF state with the command): q <- target, qd <- 0 at the start of the step whatever the state was, then the step runs with the
+    drive tau = kp (target - q) treated implicitly.  Closed form for the one-link pendulum, one substep of h:
+    qdd = -m g L sin(u) / (m L^2 + h^2 kp),  qd+ = h qdd,  q+ = u + h qd+."""
+    L, mass, h, kp = 0.7, 1.3, 0.01, 80.0
+    m = pendulum_model(L=L, mass=mass, dt=h, substeps=1, kd=0.0, mode=capi.DRIVE_POSITION)
+    m.drive_kp = kp
+    for u in (0.0, 0.4, -1.1):
+        for q0, qd0 in (([2.0], [5.0]), ([-0.3], [0.0])):                         # the previous state does not matter
+            q, qd = oracle64.step(m, ROOT1, q0, qd0, [u])
+            qdd = -mass * 9.8 * L * math.sin(u) / (mass * L * L + h * h * kp)
+            assert qd[0] == pytest.approx(h * qdd, rel=1e-12, abs=1e-15)
+            assert q[0] == pytest.approx(u + h * h * qdd, rel=1e-12, abs=1e-15)
+    # without gravity the commanded pose is held exactly, and two substeps equal two half steps of the closed form
+    m.gravity[2] = 0.0
+    q, qd = oracle64.step(m, ROOT1, [1.0], [3.0], [0.25])
+    assert q[0] == 0.25 and qd[0] == 0.0
+    m.gravity[2], m.substeps = -9.8, 2
+    q, qd = oracle64.step(m, ROOT1, [0.0], [0.0], [0.4])
+    hh, I = h / 2, mass * L * L
+    kde = hh * kp
+    x, v = 0.4, 0.0
+    for _ in range(2):
+        a = (-mass * 9.8 * L * math.sin(x) + kp * (0.4 - x) - kde * v) / (I + kde * hh)
+        v += hh * a
+        x += hh * v
+    assert q[0] == pytest.approx(x, rel=1e-12) and qd[0] == pytest.approx(v, rel=1e-12)
+    # the state is overwritten EVERY step: 200 steps with the same command end where one step ends; over one long step
+    # (50 substeps of 40 ms) the spring works against gravity, and a stiffer drive sags less
+    m.drive_kp = 80.0
+    (q1,), (qd1,) = oracle64.step(m, ROOT1, [0.0], [0.0], [0.9])
+    q, qd = 0.3, -2.0
+    for _ in range(200):
+        (q,), (qd,) = oracle64.step(m, ROOT1, [q], [qd], [0.9])
+    assert (q, qd) == (q1, qd1) and 0.0 < 0.9 - q1 < 1e-2
+    m.substeps, m.dt = 50, 2.0
+    sag = []
+    for k in (80.0, 8000.0):
+        m.drive_kp = k
+        (q,), _ = oracle64.step(m, ROOT1, [0.0], [0.0], [0.9])
+        sag.append(0.9 - q)
+    assert 0.0 < sag[1] < 0.1 * sag[0] < 0.09
+
+
 def test_double_pendulum_energy_drift(oracle64):
     L, mass = 0.5, 1.3
     m = pendulum_model(n_links=2, L=L, mass=mass, dt=0.0005)
