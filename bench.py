@@ -430,14 +430,17 @@ def roofline(loop, kms, hbm_measured, n_waves):
                      "issue_cycles_frac": k.get("issue_cycles_frac"), "wait_cycles_frac": k.get("wait_cycles_frac"),
                      "lds_bank_conflict_per_wave": k.get("SQ_LDS_BANK_CONFLICT_per_wave"),
                      "source": f"profiles/{sq.get('tag')}_sq_summary.json (rocprofv3 --pmc SQ_* passes of this command; kernel_ms live)"}
-    lane = os.environ.get("MPPI_ROLLOUT") == "lane"
-    scene = loop.name in ("boxer_push", "panda_pick")
-    lps = 1 if lane else (4 if (not scene or os.environ.get("MPPI_ROLLOUT") == "quad") else 8)
+    info = ctypes.create_string_buffer(256)
+    loop.capi.check(loop.lib, loop.lib.mppi_kernel_info(loop.P, info, 256))
+    kind = dict(kv.split("=") for kv in info.value.decode().split())["rollout"]   # lane | quad | oct | scene | scene-quad | scene-oct | scene-oct-pair
+    lane = kind in ("lane", "scene")
+    scene = kind.startswith("scene")
+    lps = 1 if lane else (8 if "oct" in kind else 4)
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "traffic_source": traffic_src, "kernel": ("k_rollout_scene" if scene else "k_rollout") + ("" if lane else "_quad"),
+            "traffic": traffic, "traffic_source": traffic_src, "kernel": ("k_rollout_scene" if scene else "k_rollout") + ("" if lane else "_quad") + ("<.., 8> (octet layout)" if (lps == 8 and not scene) else ""),
             "peak_measured": hbm_measured, "kernel_ms": kms, "bytes_alg_per_launch": bytes_alg, "wavefronts": n_waves, "lanes_per_sample": lps,
             "issue": issue,
-            "note": "instruction-issue-bound path (SURVEY 8d; DESIGN.md 5-6): one sample per 4-lane quad (contact scenes: 8-lane octet) = K/16 (K/8) wavefronts on 1024 SIMDs; "
+            "note": "instruction-issue-bound path (SURVEY 8d; DESIGN.md 5-6): one sample per 8-lane octet (MPPI_ROLLOUT=quad: 4-lane quad) = K/8 (K/16) wavefronts on 1024 SIMDs; "
                     "`issue` restates the kernel against the fp32 vector issue rate from the committed SQ counters; "
                     "peak_measured = device-to-device copy of 256 MiB (read + write bytes / time) on this GPU"}
 

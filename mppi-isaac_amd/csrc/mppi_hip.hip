@@ -85,7 +85,9 @@ int create_buffers(mppi_ctx *c, const mppi_config_t *cfg) {
     c->n = c->hm.nb; c->A = c->hm.n_actors; c->B = c->hm.n_rb; c->K = cfg->num_samples; c->H = cfg->horizon; c->nu = cfg->nu;
     c->HN = c->H * c->nu; c->RF = 2 + c->HN; c->n_waves = (c->K + kWave - 1) / kWave;
     {
-        const int spw = c->lanes_per_sample == 8 ? 8 : 16;  // samples per wavefront of the rollout kernel that shares lanes
+        // samples per workgroup (= per record) of the rollout kernel that shares lanes: 16, contact scenes in the octet layout 8
+        // (the contact-free octet kernel runs two wavefronts of eight samples per workgroup)
+        const int spw = (c->lanes_per_sample == 8 && c->scene) ? 8 : 16;
         c->n_quads = (c->K + spw - 1) / spw;
     }
     const size_t K = c->K;
@@ -241,13 +243,16 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
         } else {
             // fixed-base contact-free scenes: one sample per 4-lane quad unless MPPI_ROLLOUT=lane asks for the
             // one-lane-per-sample kernel (kept for A/B measurements and as the reference arithmetic)
+            // ... and, by default, with the articulated-body solve in the OCTET layout (mppi_oct.hpp: 8 lanes per sample, angular /
+            // linear halves of every spatial quantity in two quads, K/8 wavefronts); MPPI_ROLLOUT=quad keeps 4 lanes per sample
             const char *mode = std::getenv("MPPI_ROLLOUT");
             c->quad = !(mode && std::string(mode) == "lane");
-            c->lanes_per_sample = c->quad ? 4 : 1;
-            c->launch_rollout = c->quad ? e->rollout_quad : e->rollout;
+            const bool oct = c->quad && !(mode && std::string(mode) == "quad") && cfg->num_samples >= 8;
+            c->lanes_per_sample = c->quad ? (oct ? 8 : 4) : 1;
+            c->launch_rollout = c->quad ? (oct ? e->rollout_oct : e->rollout_quad) : e->rollout;
             c->launch_rollout_lane = e->rollout;  // cost programs on contact-free scenes run on the one-lane kernel
             if (c->quad) {
-                c->launch_rollout_traj = e->rollout_traj;
+                c->launch_rollout_traj = oct ? e->rollout_oct_traj : e->rollout_traj;
                 c->launch_materialise_traj = e->materialise_traj;
             }
             c->launch_combine_world = e->combine_world;
@@ -952,7 +957,7 @@ int mppi_kernel_ms(mppi_ctx_t *c, int which, float *ms) {
 }
 int mppi_kernel_info(mppi_ctx_t *c, char *buf, int buflen) {
     CTX_TRY(c);
-    std::snprintf(buf, buflen, "topology=%s rollout=%s K=%d H=%d nu=%d waves=%d block=%d bytes_alg=%zu", c->topo.c_str(), c->scene ? (c->helper_wave ? "scene-oct-pair" : (c->lanes_per_sample == 8 ? "scene-oct" : (c->quad ? "scene-quad" : "scene"))) : (c->quad ? "quad" : "lane"), c->K, c->H, c->nu, c->quad ? c->n_quads : c->n_waves, kWave,
+    std::snprintf(buf, buflen, "topology=%s rollout=%s K=%d H=%d nu=%d waves=%d block=%d bytes_alg=%zu", c->topo.c_str(), c->scene ? (c->helper_wave ? "scene-oct-pair" : (c->lanes_per_sample == 8 ? "scene-oct" : (c->quad ? "scene-quad" : "scene"))) : (c->quad ? (c->lanes_per_sample == 8 ? "oct" : "quad") : "lane"), c->K, c->H, c->nu, c->quad ? c->n_quads * ((c->lanes_per_sample == 8 && !c->scene) ? 2 : 1) : c->n_waves, kWave,
                   (size_t)4 * (3 * (size_t)c->K * c->HN + 2 * (size_t)c->K + c->HN));
     return MPPI_OK;
 }

@@ -28,6 +28,7 @@
 #include "mppi_pack.hpp"
 #include "mppi_scene.hpp"
 #include "mppi_quad.hpp"
+#include "mppi_oct.hpp"
 #include "mppi_scene_quad.hpp"
 
 using namespace mppi;
@@ -101,9 +102,11 @@ __device__ __forceinline__ void wave_record(CCfg &cfg, float s, bool live, const
 // weights are broadcast through LDS, the du values of a row are one contiguous 64- or 32-byte read.
 // `owner` = false: a helper wavefront of the workgroup (k_rollout_scene_quad with NW = 2) - it owns no samples and only keeps
 // the workgroup barrier company (every wavefront of a workgroup must reach every __syncthreads()).
+// `slot` >= 0: the sample slot (0 .. SPW-1) this lane belongs to, for kernels whose samples are not laid out as consecutive lane
+// groups (the octet layout of the contact-free rollout, mppi_oct.hpp: two samples interleaved in every 16-lane row).
 template <int SPW = 16>
 __device__ __forceinline__ void quad_record(CCfg &cfg, float s, bool live_leader, const float *__restrict__ du, int k0, float *__restrict__ rec,
-                                            bool owner = true) {
+                                            bool owner = true, int slot = -1) {
     constexpr int LPS = kWave / SPW;
     __shared__ float s_w[SPW];
     if (!owner) {
@@ -116,7 +119,9 @@ __device__ __forceinline__ void quad_record(CCfg &cfg, float s, bool live_leader
     const float beta = wave_min(fin ? s : INFINITY);
     const float w = fin ? __expf(-(s - beta) * cfg.inv_lambda) : 0.f;
     const float eta = wave_sum(w);
-    if ((lane & (LPS - 1)) == 0) s_w[lane / LPS] = w;  // non-leader lanes carry w = 0 and are not stored
+    if (slot >= 0) {
+        if ((lane & 3) == 0 && ((lane >> 3) & 1) == 0) s_w[slot] = w;  // the leader lane of every slot (w = 0 when its sample does not exist)
+    } else if ((lane & (LPS - 1)) == 0) s_w[lane / LPS] = w;  // non-leader lanes carry w = 0 and are not stored
     if (lane == 0) {
         rec[0] = beta;
         rec[1] = eta;
@@ -159,6 +164,71 @@ __device__ __forceinline__ void quad_record(CCfg &cfg, float s, bool live_leader
         return;
     }
     for (int j = lane; j < HN; j += kWave) {
+        const float *row = du + (size_t)j * K + k0;
+        float acc = 0.f;
+        for (int q = 0; q < nlive; q++) acc += row[q] * s_w[q];
+        rec[2 + j] = acc;
+    }
+}
+
+// The record of a WORKGROUP of two wavefronts that own eight samples each (the octet layout of the contact-free rollout, LAY = 8):
+// 16 consecutive samples -> ONE record, as many records per launch as the quad layout leaves (the combine kernel's time follows
+// their number: 512 records cost it 22.7 us, 256 18.9 us).  beta and eta go through LDS (one barrier each); the rows are summed
+// by the 128 threads as in quad_record<16>.  `slot`: sample slot 0..7 of this lane in its wavefront (oct_slot()).
+__device__ __forceinline__ void oct_record2(CCfg &cfg, float s, bool live_leader, const float *__restrict__ du, int k0, float *__restrict__ rec, int slot) {
+    constexpr int NT = 2 * kWave, SPG = 16;
+    __shared__ float s_w[SPG], s_b[2], s_e[2];
+    const int K = cfg.K, HN = cfg.H * cfg.nu;
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+    const bool fin = live_leader && isfinite(s);
+    const float bw = wave_min(fin ? s : INFINITY);
+    if (lane == 0) s_b[wv] = bw;
+    MPPI_BARRIER(5);
+    const float beta = fminf(s_b[0], s_b[1]);
+    const float w = fin ? __expf(-(s - beta) * cfg.inv_lambda) : 0.f;
+    const float ew = wave_sum(w);
+    if (lane == 0) s_e[wv] = ew;
+    if ((lane & 3) == 0 && ((lane >> 3) & 1) == 0) s_w[wv * 8 + slot] = w;  // the leader lane of every slot (w = 0: no such sample)
+    // this workgroup's own du stores must be visible to all of its lanes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    MPPI_BARRIER(6);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (threadIdx.x == 0) {
+        rec[0] = beta;
+        rec[1] = s_e[0] + s_e[1];
+    }
+    const int nlive = K - k0 < SPG ? K - k0 : SPG;
+    if (nlive == SPG && (K & 3) == 0) {  // aligned full group: 16-byte loads, both trips of a thread requested at once
+        constexpr int kTrips = 2;
+        float wq[SPG];
+#pragma unroll
+        for (int q = 0; q < SPG; q++) wq[q] = s_w[q];
+        for (int j0 = threadIdx.x; j0 < HN; j0 += kTrips * NT) {
+            float4 v[kTrips][SPG / 4];
+#pragma unroll
+            for (int t = 0; t < kTrips; t++) {
+                const int j = j0 + t * NT;
+                if (j < HN) {
+                    const float4 *row = reinterpret_cast<const float4 *>(du + (size_t)j * K + k0);
+#pragma unroll
+                    for (int q = 0; q < SPG / 4; q++) v[t][q] = row[q];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < kTrips; t++) {
+                const int j = j0 + t * NT;
+                if (j < HN) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int q = 0; q < SPG / 4; q++)
+                        acc += v[t][q].x * wq[4 * q] + v[t][q].y * wq[4 * q + 1] + v[t][q].z * wq[4 * q + 2] + v[t][q].w * wq[4 * q + 3];
+                    rec[2 + j] = acc;
+                }
+            }
+        }
+        return;
+    }
+    for (int j = threadIdx.x; j < HN; j += NT) {
         const float *row = du + (size_t)j * K + k0;
         float acc = 0.f;
         for (int q = 0; q < nlive; q++) acc += row[q] * s_w[q];
@@ -302,11 +372,14 @@ __global__ __launch_bounds__(kWave) void k_rollout(const DevModel *__restrict__ 
 }
 
 // Quad-parallel rollout (mppi_quad.hpp): 4 lanes per sample, 16 samples per wavefront.
-template <class T, bool DUMP = false>
+// LAY = 8: the OCTET layout of the articulated-body solve (mppi_oct.hpp) - 8 lanes per sample, the angular half of every spatial
+// quantity in one quad and the linear half in the other, 8 samples per wavefront (two per 16-lane row): the same step / rollout
+// code around a solve with ~15 % fewer issue slots (tools/exp/oct_aba_proto.hip), K/8 wavefronts.
+template <class T, bool DUMP = false, int LAY = 4>
 // (No amdgpu_waves_per_eu(1, 1) here although the kernel runs one wavefront per SIMD by construction: measured, round 3, the
 // attribute makes this kernel 20 % SLOWER (0.1175 -> 0.1415 ms, same instruction counts, 256 + 1 registers instead of 256 and
 // a few spilled loop invariants) - the register file above 256 is not free for a wavefront that could live without it.)
-__global__ __launch_bounds__(kWave) void k_rollout_quad(const DevModel *__restrict__ m, const DevCfg *__restrict__ cfg,
+__global__ __launch_bounds__(LAY == 8 ? 2 * kWave : kWave) void k_rollout_quad(const DevModel *__restrict__ m, const DevCfg *__restrict__ cfg,
                                                         const DevCost *__restrict__ cost, const float *__restrict__ x0_dof,
                                                         const float *__restrict__ x0_root, const float *__restrict__ U,
                                                         const float *__restrict__ eps, const float *__restrict__ prior,
@@ -318,27 +391,40 @@ __global__ __launch_bounds__(kWave) void k_rollout_quad(const DevModel *__restri
     // Stage the robot model (header + body + link blocks, ~4 KB) in LDS once per wavefront: constants are then
     // fetched with in-order ds_read_b128 broadcasts into VGPRs - no SMEM round trip (s_waitcnt lgkmcnt(0) on
     // every block), no SGPR spills, no constant-bus moves.
+    // (LAY = 8: a workgroup is TWO wavefronts of eight samples each - 16 consecutive samples, one record, one staged model)
+    constexpr int NT = LAY == 8 ? 2 * kWave : kWave;
     constexpr int kModelBytes = (int)((offsetof(DevModel, fr) + 15) / 16 * 16);
     __shared__ __attribute__((aligned(64))) uint4 s_model[kModelBytes / 16];
     // (the model's loads are all requested first and written to LDS last: their round trip to memory runs under the
     // staging of the step constants, which has round trips of its own)
-    constexpr int kModelTrips = (kModelBytes / 16 + kWave - 1) / kWave;
+    constexpr int kModelTrips = (kModelBytes / 16 + NT - 1) / NT;
     uint4 mv[kModelTrips];
 #pragma unroll
     for (int it = 0; it < kModelTrips; it++) {
-        const int i = (int)threadIdx.x + it * kWave;
+        const int i = (int)threadIdx.x + it * NT;
         mv[it] = reinterpret_cast<const uint4 *>(m)[i < kModelBytes / 16 ? i : 0];  // (unconditional: the array stays in registers)
     }
     // ... and the step loop's own constants (control limits, nominal rows, cost target and weights)
     __shared__ __attribute__((aligned(64))) float s_step[sizeof(StepConsts) / sizeof(float)];
     {
         const int n = step_const_count(*(CCfg *)cfg);
-        for (int j = threadIdx.x; j < n; j += kWave) s_step[j] = step_const_entry(*(CCfg *)cfg, *(CCost *)cost, x0_root, U, j);
+        for (int j = threadIdx.x; j < n; j += NT) s_step[j] = step_const_entry(*(CCfg *)cfg, *(CCost *)cost, x0_root, U, j);
     }
 #pragma unroll
     for (int it = 0; it < kModelTrips; it++) {
-        const int i = (int)threadIdx.x + it * kWave;
+        const int i = (int)threadIdx.x + it * NT;
         if (i < kModelBytes / 16) s_model[i] = mv[it];
+    }
+    // octet layout: the linear lanes read the bodies' inertia blocks from a copy whose inertia tensors and 1/m are zero
+    // (mppi_oct.hpp oct_lin_view); lane i stages body i
+    constexpr int kLinBodies = (LAY == 8 && T::NB > 0) ? T::NB : 1;
+    __shared__ __attribute__((aligned(64))) DevBody s_lin[kLinBodies];
+    if constexpr (LAY == 8) {
+        if ((int)threadIdx.x < T::NB) {
+            DevBody b = ((const DevModel *)m)->b[threadIdx.x];
+            b.k1 = oct_lin_view(b.k1);
+            s_lin[threadIdx.x] = b;
+        }
     }
     __syncthreads();
     LModel &lm = *(LModel *)s_model;
@@ -348,20 +434,31 @@ __global__ __launch_bounds__(kWave) void k_rollout_quad(const DevModel *__restri
     // mapping the two halves of each line are fetched by two different L2s (measured: 2x the algorithmic
     // read traffic).  Chunks are therefore dealt so that chunks 2i and 2i+1 land on the same XCD.
     const int nb = gridDim.x;
-    const int chunk = (nb % 16 == 0) ? (int)(blockIdx.x % 8) * (nb / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
-    const int k = chunk * 16 + (threadIdx.x >> 2);
+    const int chunk = (nb % 16 == 0) ? (int)(blockIdx.x % 8) * (nb / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;   // 16 samples either way
+    const int k = chunk * 16 + (LAY == 8 ? (int)(threadIdx.x >> 6) * 8 + oct_slot() : (int)(threadIdx.x >> 2));
     const int lane4 = threadIdx.x & 3;
-    const bool live = k < cfg->K;        // the four lanes of a quad share k
-    const bool leader = lane4 == 0;
+    const bool live = k < cfg->K;        // the lanes of a sample share k
+    const bool leader = lane4 == 0 && (LAY == 4 || oct_half() == 0);
     float s = INFINITY;
     if (live) {
         // one wave-uniform branch picks the instruction stream specialised for an all-revolute tree
-        if (((CModel *)m)->all_revolute) s = quad_rollout<T, 0, DUMP>(lm, *(CCfg *)cfg, *(CCost *)cost, sc, x0_dof, x0_root, eps, prior, du, viz, k, leader, quad_row(), lane4 < 3, traj);
-        else s = quad_rollout<T, -1, DUMP>(lm, *(CCfg *)cfg, *(CCost *)cost, sc, x0_dof, x0_root, eps, prior, du, viz, k, leader, quad_row(), lane4 < 3, traj);
+        if constexpr (LAY == 8) {
+            const OctAba ab{oct_bodies(&lm.b[0], (const MPPI_LDS_AS DevBody *)s_lin), oct_lane()};
+            if (((CModel *)m)->all_revolute) s = quad_rollout<T, 0, DUMP>(lm, *(CCfg *)cfg, *(CCost *)cost, sc, x0_dof, x0_root, eps, prior, du, viz, k, leader, quad_row(), lane4 < 3, traj, ab);
+            else s = quad_rollout<T, -1, DUMP>(lm, *(CCfg *)cfg, *(CCost *)cost, sc, x0_dof, x0_root, eps, prior, du, viz, k, leader, quad_row(), lane4 < 3, traj, ab);
+        } else {
+            if (((CModel *)m)->all_revolute) s = quad_rollout<T, 0, DUMP>(lm, *(CCfg *)cfg, *(CCost *)cost, sc, x0_dof, x0_root, eps, prior, du, viz, k, leader, quad_row(), lane4 < 3, traj);
+            else s = quad_rollout<T, -1, DUMP>(lm, *(CCfg *)cfg, *(CCost *)cost, sc, x0_dof, x0_root, eps, prior, du, viz, k, leader, quad_row(), lane4 < 3, traj);
+        }
         if (leader) S[k] = s;
     }
-    quad_record(*(CCfg *)cfg, s, live && leader, du, chunk * 16, partials + (size_t)chunk * (2 + cfg->H * cfg->nu));
-    fold_after_record(*(CCfg *)cfg, partials, fold_ctr, fold_out);
+    if constexpr (LAY == 8) {
+        oct_record2(*(CCfg *)cfg, s, live && leader, du, chunk * 16, partials + (size_t)chunk * (2 + cfg->H * cfg->nu), oct_slot());
+        fold_after_record<2>(*(CCfg *)cfg, partials, fold_ctr, fold_out);
+    } else {
+        quad_record(*(CCfg *)cfg, s, live && leader, du, chunk * 16, partials + (size_t)chunk * (2 + cfg->H * cfg->nu));
+        fold_after_record(*(CCfg *)cfg, partials, fold_ctr, fold_out);
+    }
     if (wave_clk != nullptr && threadIdx.x == 0) {  // instrumentation (mppi_set_wave_clock): this wavefront's residency
         wave_clk[2 * chunk] = clk0;
         wave_clk[2 * chunk + 1] = wall_clock64();
@@ -1486,6 +1583,8 @@ struct TopoEntry {
     size_t scene_lds_floats;  // per-lane LDS floats of the contact-scene kernels, excluding 3 * n_rb
     void (*rollout)(mppi_ctx *);
     void (*rollout_quad)(mppi_ctx *);
+    void (*rollout_oct)(mppi_ctx *);        // contact-free scenes, octet layout of the solve (8 lanes per sample)
+    void (*rollout_oct_traj)(mppi_ctx *);
     void (*rollout_scene)(mppi_ctx *);
     void (*rollout_scene_quad)(mppi_ctx *);
     void (*rollout_scene_oct)(mppi_ctx *);  // 8 lanes per sample
@@ -1623,6 +1722,19 @@ void launch_rollout_quad_t(mppi_ctx *c) {
                        c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_S, c->cfg.want_rollouts ? c->d_viz : nullptr, c->d_partials,
                        c->fold ? c->d_fold_ctr : nullptr, c->fold_out, c->wave_clk_on ? c->d_wave_clk : nullptr);
 }
+// the same rollout with the articulated-body solve in the octet layout (8 lanes per sample, K/8 wavefronts; mppi_oct.hpp)
+template <class T>
+void launch_rollout_oct_t(mppi_ctx *c) {
+    hipLaunchKernelGGL((k_rollout_quad<T, false, 8>), dim3(c->n_quads), dim3(2 * kWave), 0, c->stream, c->d_model, c->d_cfg, c->d_cost, c->d_x0_dof, c->d_x0_root,
+                       c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_S, c->cfg.want_rollouts ? c->d_viz : nullptr, c->d_partials,
+                       c->fold ? c->d_fold_ctr : nullptr, c->fold_out, c->wave_clk_on ? c->d_wave_clk : nullptr);
+}
+template <class T>
+void launch_rollout_oct_traj_t(mppi_ctx *c) {
+    hipLaunchKernelGGL((k_rollout_quad<T, true, 8>), dim3(c->n_quads), dim3(2 * kWave), 0, c->stream, c->d_model, c->d_cfg, c->d_cost_none, c->d_x0_dof, c->d_x0_root,
+                       c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_S, (float *)nullptr, c->d_partials,
+                       (unsigned *)nullptr, c->fold_out, (unsigned long long *)nullptr, c->d_traj);
+}
 template <class T>
 void launch_rollout_traj_t(mppi_ctx *c) {
     hipLaunchKernelGGL((k_rollout_quad<T, true>), dim3(c->n_quads), dim3(kWave), 0, c->stream, c->d_model, c->d_cfg, c->d_cost_none, c->d_x0_dof, c->d_x0_root,
@@ -1681,6 +1793,8 @@ void fill_topo_entry_free(TopoEntry &e) {
     for (int i = 0; i < T::NB; i++) e.parents[i] = T::par[i];
     e.rollout = &launch_rollout_t<T>;
     e.rollout_quad = &launch_rollout_quad_t<T>;
+    e.rollout_oct = &launch_rollout_oct_t<T>;
+    e.rollout_oct_traj = &launch_rollout_oct_traj_t<T>;
     e.sim_step = &launch_sim_step_t<T>;
     e.sim_step_quad = &launch_sim_step_quad_t<T>;
     e.rollout_traj = &launch_rollout_traj_t<T>;

@@ -667,6 +667,15 @@ MPPI_HD void quad_aba(M &m, const QPose<T, JT> &P, const QF *qd, const QF *tau_e
     });
 }
 
+// How a step solves the articulated body: the quad layout's solve above, or the octet layout's (mppi_oct.hpp OctAba: one
+// sample per two quads) - the step / rollout code around the solve is the same for both.
+struct QuadAba {
+    template <class T, class M, int JT>
+    MPPI_HD void aba(M &m, const QPose<T, JT> &P, const QF *qd, const QF *tau_exp, const QF *kdh, QF *qdd, JointLimits *lim) const {
+        quad_aba<T>(m, P, qd, tau_exp, kdh, qdd, lim);
+    }
+};
+
 // base pose of the (fixed) robot from its root row, distributed over the quad
 template <class T, class M, int JT>
 MPPI_HD void quad_base(M &m, const float *root, QPose<T, JT> &P) {
@@ -679,8 +688,8 @@ MPPI_HD void quad_base(M &m, const float *root, QPose<T, JT> &P) {
 
 // One simulator step.  P must hold the forward kinematics of q on entry (base pose included) and holds the
 // forward kinematics of the NEW q on exit: the pose computed for the cost / next step is never recomputed.
-template <class T, class M, int JT>
-MPPI_HD void quad_step(M &m0, QPose<T, JT> &P, QF *q, QF *qd, const QF *target) {
+template <class T, class M, int JT, class AB = QuadAba>
+MPPI_HD void quad_step(M &m0, QPose<T, JT> &P, QF *q, QF *qd, const QF *target, const AB &ab = AB{}) {
     constexpr int NB = T::NB;
     M *mp = &m0;
     // position mode (isaacgym_wrapper.py:571-572): apply_robot_cmd overwrites the DOF state with the command.  It lives in the
@@ -719,7 +728,7 @@ MPPI_HD void quad_step(M &m0, QPose<T, JT> &P, QF *q, QF *qd, const QF *target) 
         }
         const QF kdhq = qrep(kd * h);
         static_for<0, NB>([&](auto ic) MPPI_LAMBDA { kdh[ic] = kdhq; });
-        quad_aba<T>(m, P, qd, tau, kdh, qdd, lim);
+        ab.template aba<T>(m, P, qd, tau, kdh, qdd, lim);
         // URDF effort limits: a drive whose torque tau - kd h qdd leaves [-effort, effort] is held at the bound and the step is
         // solved again without its damping.  The test is one running maximum of |torque| - effort over the joints and one
         // branch (no limit: effort = +inf, the excess is -inf); the selects live inside the rare branch.
@@ -738,7 +747,7 @@ MPPI_HD void quad_step(M &m0, QPose<T, JT> &P, QF *q, QF *qd, const QF *target) 
                 tau[i] = sat ? qwhere_gt(tt[i], qrep(0.f), eff, -eff) : tau[i];
                 kdh[i] = sat ? qrep(0.f) : kdh[i];
             });
-            quad_aba<T>(*launder(mp), P, qd, tau, kdh, qdd, lim);
+            ab.template aba<T>(*launder(mp), P, qd, tau, kdh, qdd, lim);
         }
         // the kinematic blocks of the NEXT pose are requested here: they carry the joint ranges the integration needs, and
         // their round trip runs under the integration's arithmetic
@@ -909,9 +918,10 @@ MPPI_HD float apply_controls_q(LStep &sc, float lambda, bool abs_cost, int nu, i
 // `leader` is true in exactly one lane of the quad (it performs the du store); lanes 0..2 store viz.
 // DUMP: the state after every step goes to `traj` as well (q rows [NB][H*K], then qd rows: column t*K + k) - the generic
 // Objective mode evaluates Python costs on the materialised trajectory (mppi_rollout_trajectory).
-template <class T, int JT, bool DUMP = false, class M = void>
+template <class T, int JT, bool DUMP = false, class M = void, class AB = QuadAba>
 MPPI_HD QF quad_rollout(M &m0, CCfg &cfg0, CCost &cost0, LStep &sc, const float *dof0, const float *root, const float *eps,
-                        const float *prior, float *du, float *viz, int k, bool leader, int row, bool viz_lane, float *traj = nullptr) {
+                        const float *prior, float *du, float *viz, int k, bool leader, int row, bool viz_lane, float *traj = nullptr,
+                        const AB &ab = AB{}) {
     constexpr int NB = T::NB;
     // read once, kept in SGPRs across the horizon (not laundered)
     const int K = cfg0.K, nu = cfg0.nu, H = cfg0.H, kind = cost0.kind, link = cost0.link[0], viz_link = cfg0.viz_link;
@@ -962,7 +972,7 @@ MPPI_HD QF quad_rollout(M &m0, CCfg &cfg0, CCost &cost0, LStep &sc, const float 
                 target[i] = qrep(tg);
             });
         }
-        quad_step<T>(*mp, P, q, qd, target);
+        quad_step<T>(*mp, P, q, qd, target, ab);
         if constexpr (DUMP) {  // (the four lanes of a quad hold the same values: same-address stores, as for du)
             const unsigned HK = (unsigned)H * (unsigned)K, col = (unsigned)t * (unsigned)K + (unsigned)k;
             static_for<0, NB>([&](auto ic) MPPI_LAMBDA {

@@ -625,10 +625,10 @@ def test_error_paths(lib):
     assert lib.mppi_rollout(c.ctx) == -4 and b"no fused cost" in lib.mppi_last_error()      # MPPI_ESTATE
     assert lib.mppi_set_cost(c.ctx, C.byref(bad)) == -3                                       # MPPI_EUNSUPPORTED
     c.close()
-    m.drive_mode = capi.DRIVE_POSITION
+    m.drive_mode, m.drive_kp = capi.DRIVE_POSITION, -1.0                                      # a position drive needs a stiffness
     assert lib.mppi_create(C.byref(m), C.byref(cfg), 0, C.byref(ctx)) == -1
     assert b"position" in lib.mppi_last_error()
-    m.drive_mode = capi.DRIVE_VELOCITY
+    m.drive_mode, m.drive_kp = capi.DRIVE_VELOCITY, 0.0
     cfg.lambda_ = 0.0
     assert lib.mppi_create(C.byref(m), C.byref(cfg), 0, C.byref(ctx)) == -1
 
