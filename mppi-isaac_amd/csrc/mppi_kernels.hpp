@@ -921,8 +921,11 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW))
         hwdbg = (unsigned long long)s_hw[0] | ((unsigned long long)s_hw[1] << 32);
     }
 #endif
-    const int k = chunk * SPW + (lane / LPS);
-    const int sub = lane & (LPS - 1);
+    // lanes of a sample: a quad (LPS = 4), or two quads 8 lanes apart inside a 16-lane row (LPS = 8: the octet lane map of
+    // mppi_oct.hpp - row_ror:8 reaches the partner quad); `sub` numbers them 0 .. LPS - 1
+    const int slot = LPS == 8 ? oct_slot() : lane / LPS;
+    const int k = chunk * SPW + slot;
+    const int sub = LPS == 8 ? (lane & 3) + 4 * oct_half() : lane & (LPS - 1);
     const bool live = k < ((CCfg *)cfg)->K;  // (constant address space: a scalar load, not a register per lane)
     // instrumentation (mppi_set_wave_clock): the start stamp goes out now instead of occupying a register pair for the whole rollout
     if (wave_clk != nullptr && threadIdx.x == 0) {
@@ -937,8 +940,8 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW))
     const int row = scene_row_floats<T>(M) + (NW == 2 ? scene_pair_floats<T>(M) : 0);
     unsigned *tab = reinterpret_cast<unsigned *>(lds + (size_t)SPW * row);
     scene_table_fill(M, tab, threadIdx.x, kWave * NW);
-    LMem L{lds + (lane / LPS), SPW, tab};
-    L.cm = 11 * (lane / LPS);
+    LMem L{lds + slot, SPW, tab};
+    L.cm = 11 * slot;
 #if defined(MPPI_CHECK)
     L.limit = row;  // (floats of one sample's rows: any index beyond them belongs to the wave's table or to nobody)
 #endif
@@ -965,7 +968,7 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW))
                 }
             }
             // the record tail's barriers are the workgroup's: the helper reaches them too and does none of the work
-            quad_record<SPW>(*(CCfg *)cfg, INFINITY, false, du, chunk * SPW, partials, false);
+            quad_record<SPW>(*(CCfg *)cfg, INFINITY, false, du, chunk * SPW, partials, false, LPS == 8 ? slot : -1);
             fold_after_record<NW>(*(CCfg *)cfg, partials, fold_ctr, fold_out);
             return;
         }
@@ -975,7 +978,7 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW))
         s = rollout_scene<T, kSplit, DUMP>(M, lm, *(CCfg *)cfg, *(CCost *)cost, x0_dof, s_root, U, eps, prior, du, viz, k, L, Split{sub, LPS}, traj);
         if (sub == 0) S[(unsigned)k] = s;
     }
-    quad_record<SPW>(*(CCfg *)cfg, s, live && sub == 0, du, chunk * SPW, partials + (size_t)chunk * (2 + cfg->H * cfg->nu));
+    quad_record<SPW>(*(CCfg *)cfg, s, live && sub == 0, du, chunk * SPW, partials + (size_t)chunk * (2 + cfg->H * cfg->nu), true, LPS == 8 ? slot : -1);
     fold_after_record<NW>(*(CCfg *)cfg, partials, fold_ctr, fold_out);
     MPPI_SEC(10);
     if (wave_clk != nullptr && lane == 0) {  // instrumentation (mppi_set_wave_clock): this wavefront's residency

@@ -449,18 +449,19 @@ __device__ __forceinline__ unsigned quad_allor(unsigned x) {
     return x;
 }
 // sum / or over the lanes that share a sample, identical in all of them.  Octet: the quad totals (already identical within
-// each quad) are exchanged with row_half_mirror (lane i <-> 7 - i of every 8 lanes): q0 + q1 in one quad, q1 + q0 in the
-// other - the same bits.
+// each quad) are exchanged with row_ror:8 - the two quads of a sample sit 8 lanes apart inside a 16-lane row (the lane map of
+// mppi_oct.hpp, shared with the octet layout of the articulated-body solve): q0 + q1 in one quad, q1 + q0 in the other - the
+// same bits.  (Until round 4 the quads of a sample were neighbours and this was row_half_mirror.)
 template <int SPLIT>
 __device__ __forceinline__ float group_allsum(float x) {
     x = quad_allsum(x);
-    if constexpr (split_octet(SPLIT)) x += scene_dpp<0x141>(x);
+    if constexpr (split_octet(SPLIT)) x += scene_dpp<0x128>(x);
     return x;
 }
 template <int SPLIT>
 __device__ __forceinline__ unsigned group_allor(unsigned x) {
     x = quad_allor(x);
-    if constexpr (split_octet(SPLIT)) x |= (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0x141, 0xf, 0xf, true);
+    if constexpr (split_octet(SPLIT)) x |= (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0x128, 0xf, 0xf, true);
     return x;
 }
 template <int SPLIT>
