@@ -30,6 +30,7 @@
 #include "mppi_quad.hpp"
 #include "mppi_oct.hpp"
 #include "mppi_scene_quad.hpp"
+#include "mppi_scene_oct.hpp"
 
 using namespace mppi;
 
@@ -876,7 +877,8 @@ __global__ __launch_bounds__(kWave) void k_rollout_scene(const DevModel *__restr
 #else
 #define MPPI_SCENE_OCCUPANCY
 #endif
-template <class T, int LPS, int NW = 1, bool DUMP = false>
+// OSOLVE: the articulated-body solve in the octet layout too (mppi_scene_oct.hpp: fixed-base trees of more than four bodies)
+template <class T, int LPS, int NW = 1, bool DUMP = false, bool OSOLVE = false>
 __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW))) MPPI_SCENE_OCCUPANCY void k_rollout_scene_quad(const DevModel *__restrict__ m, const DevCfg *__restrict__ cfg,
                                                               const DevCost *__restrict__ cost, const float *__restrict__ x0_dof,
                                                               const float *__restrict__ x0_root, const float *__restrict__ U,
@@ -888,7 +890,8 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW))
     static_assert(LPS == 4 || LPS == 8, "4 or 8 lanes per sample");
     static_assert(NW == 1 || (NW == 2 && LPS == 8 && T::NB <= 4), "helper wavefront: octet layout of the short trees only");
     constexpr int SPW = kWave / LPS;
-    constexpr int kSplit = NW == 2 ? kSplitOctPair : (LPS == 8 ? kSplitOct : kSplitQuad);
+    static_assert(!OSOLVE || (LPS == 8 && NW == 1 && T::NB > 4), "octet solve: octet kernel of the longer trees");
+    constexpr int kSplit = NW == 2 ? kSplitOctPair : (LPS == 8 ? (OSOLVE ? kSplitOctSolve : kSplitOct) : kSplitQuad);
     const unsigned long long clk0 = wave_clk != nullptr ? wall_clock64() : 0ull;
 #if defined(MPPI_SECTION_CLOCKS)
     if (threadIdx.x <= kSections) section_counters()[threadIdx.x] = threadIdx.x == kSections ? __builtin_readcyclecounter() : 0ull;
@@ -942,6 +945,19 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW))
     scene_table_fill(M, tab, threadIdx.x, kWave * NW);
     LMem L{lds + slot, SPW, tab};
     L.cm = 11 * slot;
+    // octet layout of the solve (mppi_scene_oct.hpp): the linear lanes read the bodies' inertia blocks from a copy without inertia
+    // tensors; lane i stages body i
+    constexpr bool kOctSolve = OSOLVE;
+    __shared__ __attribute__((aligned(64))) DevBody s_lin[kOctSolve ? T::NB : 1];
+    if constexpr (kOctSolve) {
+        if ((int)threadIdx.x < T::NB) {
+            DevBody b = M.b[threadIdx.x];
+            b.k1 = oct_lin_view(b.k1);
+            s_lin[threadIdx.x] = b;
+        }
+        const MPPI_LDS_AS DevBody *mine = oct_half() ? (const MPPI_LDS_AS DevBody *)s_lin : &lm.b[0];
+        L.oct_bodies = (unsigned)(unsigned long)mine;
+    }
 #if defined(MPPI_CHECK)
     L.limit = row;  // (floats of one sample's rows: any index beyond them belongs to the wave's table or to nobody)
 #endif
@@ -1617,8 +1633,24 @@ void launch_rollout_scene_t(mppi_ctx *c) {
                        c->d_x0_root, c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_S, c->cfg.want_rollouts ? c->d_viz : nullptr,
                        c->d_partials);
 }
+// the octet kernel of a fixed-base tree of more than four bodies runs the solve in the octet layout as well (MPPI_SCENE_SOLVE=quad:
+// the quad-layout solve in both quads, for A/B measurements)
+template <class T>
+constexpr bool kHasOctSolve = (T::NB > 4);
+inline bool scene_oct_solve(const mppi_ctx *c) {
+    const char *e = std::getenv("MPPI_SCENE_SOLVE");
+    return c->hm.floating == 0 && !(e && std::string(e) == "quad");
+}
 template <class T, int LPS>
 void launch_rollout_scene_quad_t(mppi_ctx *c) {
+    if constexpr (LPS == 8 && kHasOctSolve<T>) {
+        if (scene_oct_solve(c)) {
+            hipLaunchKernelGGL((k_rollout_scene_quad<T, 8, 1, false, true>), dim3(c->n_quads), dim3(kWave), c->lds_bytes_quad * (kWave / LPS) / 16 + c->lds_bytes_table, c->stream, c->d_model, c->d_cfg, c->d_cost, c->d_x0_dof,
+                               c->d_x0_root, c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_S, c->cfg.want_rollouts ? c->d_viz : nullptr,
+                               c->d_partials, c->fold ? c->d_fold_ctr : nullptr, c->fold_out, c->wave_clk_on ? c->d_wave_clk : nullptr);
+            return;
+        }
+    }
     hipLaunchKernelGGL((k_rollout_scene_quad<T, LPS>), dim3(c->n_quads), dim3(kWave), c->lds_bytes_quad * (kWave / LPS) / 16 + c->lds_bytes_table, c->stream, c->d_model, c->d_cfg, c->d_cost, c->d_x0_dof,
                        c->d_x0_root, c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_S, c->cfg.want_rollouts ? c->d_viz : nullptr,
                        c->d_partials, c->fold ? c->d_fold_ctr : nullptr, c->fold_out, c->wave_clk_on ? c->d_wave_clk : nullptr);
@@ -1646,6 +1678,14 @@ void launch_rollout_scene_traj_t(mppi_ctx *c) {
             const size_t row = c->lds_bytes_quad / 16 + sizeof(float) * ((size_t)SceneLayout<T>::NF * 27 + 3 * (size_t)c->hm.n_rb + 2 + 6 * kMaxFree + scene_park_floats<T>());
             hipLaunchKernelGGL((k_rollout_scene_quad<T, 8, 2, true>), dim3(c->n_quads), dim3(2 * kWave), row * (kWave / 8) + c->lds_bytes_table, c->stream, c->d_model, c->d_cfg, c->d_cost_none,
                                c->d_x0_dof, c->d_x0_root, c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_S, (float *)nullptr,
+                               c->d_partials, (unsigned *)nullptr, c->fold_out, (unsigned long long *)nullptr, c->d_traj);
+            return;
+        }
+    }
+    if constexpr (kHasOctSolve<T>) {
+        if (scene_oct_solve(c)) {
+            hipLaunchKernelGGL((k_rollout_scene_quad<T, 8, 1, true, true>), dim3(c->n_quads), dim3(kWave), c->lds_bytes_quad * (kWave / 8) / 16 + c->lds_bytes_table, c->stream, c->d_model, c->d_cfg, c->d_cost_none, c->d_x0_dof,
+                               c->d_x0_root, c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_S, (float *)nullptr,
                                c->d_partials, (unsigned *)nullptr, c->fold_out, (unsigned long long *)nullptr, c->d_traj);
             return;
         }
@@ -1685,6 +1725,12 @@ hipError_t raise_lds_limit(size_t lane_bytes, size_t quad_bytes) {  // lane_byte
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rollout_scene_quad<T, 8, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)quad_bytes);
     if (e != hipSuccess) return e;
+    if constexpr (kHasOctSolve<T>) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rollout_scene_quad<T, 8, 1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)quad_bytes);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rollout_scene_quad<T, 8, 1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)quad_bytes);
+        if (e != hipSuccess) return e;
+    }
     if constexpr (T::NB <= 4) {  // (+ the helper's accumulator set: bounded by the quad kernel's 16-sample figure)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rollout_scene_quad<T, 8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)quad_bytes);
         if (e != hipSuccess) return e;
@@ -1711,6 +1757,10 @@ size_t static_lds_bytes_scene() {
     ask(reinterpret_cast<const void *>(&k_rollout_scene_quad<T, 4>));
     ask(reinterpret_cast<const void *>(&k_rollout_scene_quad<T, 8>));
     ask(reinterpret_cast<const void *>(&k_rollout_scene_quad<T, 8, 1, true>));
+    if constexpr (kHasOctSolve<T>) {
+        ask(reinterpret_cast<const void *>(&k_rollout_scene_quad<T, 8, 1, false, true>));
+        ask(reinterpret_cast<const void *>(&k_rollout_scene_quad<T, 8, 1, true, true>));
+    }
     if constexpr (T::NB <= 4) {
         ask(reinterpret_cast<const void *>(&k_rollout_scene_quad<T, 8, 2>));
         ask(reinterpret_cast<const void *>(&k_rollout_scene_quad<T, 8, 2, true>));

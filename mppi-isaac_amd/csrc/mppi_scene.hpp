@@ -72,6 +72,10 @@ struct LMem {
     float ox = 0.f, oy = 0.f;
     // 11 x this sample's position in the row group (the component-minor shape-pose cache, shape_cached below)
     int cm = 0;
+    // octet layout of the articulated-body solve (mppi_scene_oct.hpp; rollout kernels of fixed-base trees of more than four bodies):
+    // LDS address of THIS lane's view of the model's body blocks (angular lanes: the staged model's own, linear lanes: the copy
+    // without inertia tensors); 0: the kernel has none - quad-layout solve
+    unsigned oct_bodies = 0;
 #if defined(MPPI_CHECK)
     // check build (MPPI_BUILD_VARIANT=check, tests/test_gpu_check_build.py): every access to the sample's rows is bounds-checked
     // against the row length the kernel allocated; a violation traps (the launch fails instead of corrupting a neighbour's row)
@@ -425,9 +429,10 @@ MPPI_HD void pair_add(PairAcc &a, const PairAcc &b) {
 // half of the shape poses), accumulating into a row set of its own; the first wavefront adds that set to its own after the
 // barrier, in a fixed order (deterministic), and goes on alone with the solve.  Two resident wavefronts per SIMD overlap
 // where one only waits: measured 1.3x the time for 2x the wavefronts (tools/exp/w2_overlap.sh).
-enum { kSplitNone = 0, kSplitQuad = 1, kSplitEmulate = 2, kSplitOct = 3, kSplitOctPair = 4 };
-constexpr bool split_on_device(int split) { return split == kSplitQuad || split == kSplitOct || split == kSplitOctPair; }
-constexpr bool split_octet(int split) { return split == kSplitOct || split == kSplitOctPair; }
+// kSplitOctSolve: kSplitOct with the articulated-body solve itself in the octet layout (mppi_scene_oct.hpp; fixed-base trees)
+enum { kSplitNone = 0, kSplitQuad = 1, kSplitEmulate = 2, kSplitOct = 3, kSplitOctPair = 4, kSplitOctSolve = 5 };
+constexpr bool split_on_device(int split) { return split == kSplitQuad || split == kSplitOct || split == kSplitOctPair || split == kSplitOctSolve; }
+constexpr bool split_octet(int split) { return split == kSplitOct || split == kSplitOctPair || split == kSplitOctSolve; }
 struct Split {
     int sub, n;
     int wave = 0;  // kSplitOctPair: 0 = the wavefront that owns the sample state, 1 = its helper
@@ -1797,13 +1802,26 @@ template <class T, class M, class MR>
 MPPI_HD float step_tail_scene_quad(M &m, MR &mr, CCfg &cfg, CCost &c, const float *root, const SceneState<T> &s, const LMem &L, float *viz, int t, int k,
                                    bool leader);
 
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class T, int SPLIT, class M, class MR>
+__device__ __forceinline__ void step_scene_oct(M &m0, MR &mr0, const float *root, SceneState<T> &s, const float *target, const LMem &L, Split split);
+#endif
 // One step of a contact scene in the layout the kernel runs in.  The quad layout of the robot algebra pays from a handful
 // of bodies on (measured: gripper arm, 9 bodies, 5.11 -> 4.43 ms; boxer, 2 wheels on a floating base, 1.64 -> 1.87 ms):
 // short trees keep the replicated one-lane algebra.
 template <class T, int SPLIT, class M, class MR>
 MPPI_HD void step_scene_any(M &m, MR &mr, const float *root, SceneState<T> &s, const float *target, const LMem &L, Split split) {
     if constexpr (SPLIT == kSplitNone || T::NB <= 4) step_scene<T, SPLIT>(m, root, s, target, L, split);
-    else step_scene_quad<T, SPLIT>(m, mr, root, s, target, L, split);
+    else {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // fixed-base trees in the octet kernel: the solve with the angular / linear halves of every spatial quantity in the two
+        // quads of the sample (mppi_scene_oct.hpp) instead of the quad-layout solve computed by both quads alike - a kernel
+        // instantiation of its own (both solves in one kernel cost the register allocation of the larger plus spills)
+        if constexpr (SPLIT == kSplitOctSolve) step_scene_oct<T, SPLIT>(m, mr, root, s, target, L, split);
+        else
+#endif
+            step_scene_quad<T, SPLIT>(m, mr, root, s, target, L, split);
+    }
 }
 
 // mr0: view of the same model for the robot algebra of the quad path (an LDS copy of the model prefix in the kernel)
