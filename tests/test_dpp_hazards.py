@@ -34,6 +34,18 @@ def test_checker_sees_a_transcendental_read_too_early(tmp_path):
     assert chk.check(str(src)) == 1
 
 
+def test_checker_flags_hand_written_dpp_right_behind_a_label(tmp_path):
+    """the write history ends at a label (control flow may arrive from a block that has just written the operand).  The
+    compiler's own DPP instructions are trusted there; the forms only the inline-assembly blocks emit (v_fmac_f32_dpp, row_ror:8
+    exchanges) are not - within two wait states of a label they are reported unless padded"""
+    src = tmp_path / "l.s"
+    src.write_text(".LBB0_1:\n\tv_fmac_f32_dpp v7, v1, v8 quad_perm:[1,2,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"     # hazard
+                   ".LBB0_2:\n\tv_mul_f32_e32 v9, v2, v3\n\tv_mov_b32_dpp v4, v5 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"   # 1 slot: hazard
+                   ".LBB0_3:\n\ts_nop 1\n\tv_fmac_f32_dpp v7, v1, v8 quad_perm:[1,2,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"   # padded: fine
+                   ".LBB0_4:\n\tv_add_f32_dpp v4, v9, v6 quad_perm:[1,2,0,1] row_mask:0xf bank_mask:0xf\n")                              # compiler form: trusted
+    assert chk.check(str(src)) == 2
+
+
 def test_built_library_has_no_dpp_hazard():
     lib = os.path.join(ROOT, "mppi-isaac_amd", "csrc", "libmppi_hip.so")
     if not os.path.exists(OBJDUMP):
