@@ -418,9 +418,12 @@ __global__ __launch_bounds__(LAY == 8 ? 2 * kWave : kWave) void k_rollout_quad(c
     }
     // octet layout: the linear lanes read the bodies' inertia blocks from a copy whose inertia tensors and 1/m are zero
     // (mppi_oct.hpp oct_lin_view); lane i stages body i
-    constexpr int kLinBodies = (LAY == 8 && T::NB > 0) ? T::NB : 1;
-    __shared__ __attribute__((aligned(64))) DevBody s_lin[kLinBodies];
+    __shared__ __attribute__((aligned(256))) uint4 s_lin_raw[(LAY == 8 ? oct_lin_raw_bytes(T::NB) : 16) / 16];
+    LModel &lm = *(LModel *)s_model;
+    LStep &sc = *(LStep *)s_step;
+    MPPI_LDS_AS DevBody *s_lin = nullptr;
     if constexpr (LAY == 8) {
+        s_lin = oct_lin_place((MPPI_LDS_AS void *)s_lin_raw, &lm.b[0]);   // (bank-disjoint from the model's own blocks)
         if ((int)threadIdx.x < T::NB) {
             DevBody b = ((const DevModel *)m)->b[threadIdx.x];
             b.k1 = oct_lin_view(b.k1);
@@ -428,8 +431,6 @@ __global__ __launch_bounds__(LAY == 8 ? 2 * kWave : kWave) void k_rollout_quad(c
         }
     }
     __syncthreads();
-    LModel &lm = *(LModel *)s_model;
-    LStep &sc = *(LStep *)s_step;
     // XCD-aware chunk mapping: a wavefront owns 16 consecutive samples = 64 B of every sample-minor row, i.e.
     // half a 128-B line.  Workgroup b runs on XCD b % 8 and the XCD L2s are private, so with the identity
     // mapping the two halves of each line are fetched by two different L2s (measured: 2x the algorithmic
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(LAY == 8 ? 2 * kWave : kWave) void k_rollout_quad(c
     if (live) {
         // one wave-uniform branch picks the instruction stream specialised for an all-revolute tree
         if constexpr (LAY == 8) {
-            const OctAba ab{oct_bodies(&lm.b[0], (const MPPI_LDS_AS DevBody *)s_lin), oct_lane()};
+            const OctAba ab{oct_bodies(&lm.b[0], s_lin), oct_lane()};
             if (((CModel *)m)->all_revolute) s = quad_rollout<T, 0, DUMP>(lm, *(CCfg *)cfg, *(CCost *)cost, sc, x0_dof, x0_root, eps, prior, du, viz, k, leader, quad_row(), lane4 < 3, traj, ab);
             else s = quad_rollout<T, -1, DUMP>(lm, *(CCfg *)cfg, *(CCost *)cost, sc, x0_dof, x0_root, eps, prior, du, viz, k, leader, quad_row(), lane4 < 3, traj, ab);
         } else {
@@ -948,8 +949,9 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW))
     // octet layout of the solve (mppi_scene_oct.hpp): the linear lanes read the bodies' inertia blocks from a copy without inertia
     // tensors; lane i stages body i
     constexpr bool kOctSolve = OSOLVE;
-    __shared__ __attribute__((aligned(64))) DevBody s_lin[kOctSolve ? T::NB : 1];
+    __shared__ __attribute__((aligned(256))) uint4 s_lin_raw[(kOctSolve ? oct_lin_raw_bytes(T::NB) : 16) / 16];
     if constexpr (kOctSolve) {
+        MPPI_LDS_AS DevBody *s_lin = oct_lin_place((MPPI_LDS_AS void *)s_lin_raw, &lm.b[0]);   // (bank-disjoint from the model's own blocks)
         if ((int)threadIdx.x < T::NB) {
             DevBody b = M.b[threadIdx.x];
             b.k1 = oct_lin_view(b.k1);

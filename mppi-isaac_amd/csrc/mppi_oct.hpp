@@ -416,6 +416,15 @@ __device__ __forceinline__ OctBodies oct_bodies(const MPPI_LDS_AS DevBody *model
     asm volatile("" : "+v"(p));
     return p;
 }
+// Where the linear lanes' copy of the body blocks goes inside a raw LDS array with 256 bytes of slack: 128 bytes (mod 256) away
+// from the model's own blocks.  A ds_read_b128 serves angular and linear lanes in the same lane group, i.e. TWO addresses per
+// group; 64 banks x 4 B = 256 B, so copies at the same offset mod 256 would hit the same banks on every block read (measured
+// with the copy placed by the compiler: 4.5 k SQ_LDS_BANK_CONFLICT cycles per wavefront where the quad layout has none).
+constexpr int oct_lin_raw_bytes(int nb) { return nb * (int)sizeof(DevBody) + 256; }
+__device__ __forceinline__ MPPI_LDS_AS DevBody *oct_lin_place(MPPI_LDS_AS void *raw, const MPPI_LDS_AS DevBody *model_bodies) {
+    const unsigned r = (unsigned)(unsigned long)raw, b = (unsigned)(unsigned long)model_bodies;
+    return (MPPI_LDS_AS DevBody *)(unsigned long)(r + ((b + 128u - r) & 255u));
+}
 // the solve policy of quad_step / quad_rollout (mppi_quad.hpp QuadAba) for the octet layout
 struct OctAba {
     OctBodies bodies;
