@@ -71,7 +71,7 @@ def make_world(name, cfg):
     return sim
 
 
-def run_world(name, cfg, planner, steps, report=True):
+def run_world(name, cfg, planner, steps, report=True, hook=None):
     """the loop of the reference's world.py: world state -> planner (bytes) -> action -> apply + step.  Returns the stage cost of
     the world's state (the example's own Objective evaluated on the K=1 world) before and after."""
     sim = make_world(name, cfg)
@@ -82,6 +82,8 @@ def run_world(name, cfg, planner, steps, report=True):
         action = bytes_to_torch(planner.compute_action_tensor(torch_to_bytes(sim._dof_state), torch_to_bytes(sim._root_state)))
         sim.apply_robot_cmd(action.to(sim.device).reshape(1, -1))
         sim.step()
+        if hook is not None:
+            hook(i, sim)
         if report and i % 25 == 0:
             print(f"step {i:4d}  stage cost of the world state = {float(objective.compute_cost(sim)[0]):.4f}")
     rate = steps / (time.perf_counter() - t0)

@@ -224,6 +224,7 @@ class Scene:
         (isaacgym_wrapper.py:441), no robot self-collision; wheels/casters collide with the ground only."""
         shapes = []
         self.dropped_pairs = []  # (shape, shape) candidates the contact model leaves out on purpose
+        self.dropped_pair_shapes = []  # the same candidates as indices into the shape list (tests measure their clearance)
         # (a scene in which no candidate pair survives the filter below - e.g. a fixed-base arm and a collision-free goal -
         # is contact-free: the contact-free kernels run it.  A FIXED-base robot still moves its links into static geometry:
         # heijn_reach's base against the wall, an arm against a fixed obstacle sphere)
@@ -257,13 +258,15 @@ class Scene:
                         # with each other, like the links of one robot)
                         shapes.append(dict(actor=self.robot_idx, body=l["body"], type=kind, rb=self.first_rb[self.robot_idx] + li, size=size,
                                            R=Rl @ Rc, p=Rl @ pc + pl, friction=0.0 if l["name"] in casters else a.friction,
-                                           fixed=bool(a.fixed), link=l["name"]))
+                                           fixed=bool(a.fixed), link=l["name"], R_in_link=Rc, p_in_link=pc))
             elif a.type == "box":
                 shapes.append(dict(actor=ai, body=-1, type=capi.SHAPE_BOX, rb=self.first_rb[ai], size=[0.5 * v for v in a.size],
-                                   R=np.eye(3), p=np.zeros(3), friction=a.friction, fixed=bool(a.fixed), link="box"))
+                                   R=np.eye(3), p=np.zeros(3), friction=a.friction, fixed=bool(a.fixed), link="box",
+                                   R_in_link=np.eye(3), p_in_link=np.zeros(3)))
             elif a.type == "sphere":
                 shapes.append(dict(actor=ai, body=-1, type=capi.SHAPE_SPHERE, rb=self.first_rb[ai], size=[a.size[0], 0.0, 0.0],
-                                   R=np.eye(3), p=np.zeros(3), friction=a.friction, fixed=bool(a.fixed), link="sphere"))
+                                   R=np.eye(3), p=np.zeros(3), friction=a.friction, fixed=bool(a.fixed), link="sphere",
+                                   R_in_link=np.eye(3), p_in_link=np.zeros(3)))
         pairs = []
         for i, si in enumerate(shapes):
             robot_i = self.env_cfg[si["actor"]].type == "robot"
@@ -282,8 +285,10 @@ class Scene:
                 if capi.SHAPE_DISC in kinds:
                     # modelling decision: wheels and casters are rim contacts against the ground plane only
                     self.dropped_pairs.append(names)
+                    self.dropped_pair_shapes.append((i, j))
                     continue
                 pairs.append((i, j))
+        self.all_shapes = shapes  # (kept when the scene turns out contact-free, for the clearance tests)
         if not pairs:
             return [], []  # nothing can come into contact with anything that reacts
         if len(shapes) > capi.MAX_SHAPES or len(pairs) > capi.MAX_PAIRS:

@@ -416,3 +416,66 @@ def test_two_robots_in_one_env(lib, oracle64, tmp_path):
     assert np.linalg.norm(p1 - [1.5, 1.0]) < 0.45 and np.linalg.norm(p2 - [-1.0, 1.0]) < 0.6, (p1, p2)
     with pytest.raises(NotImplementedError, match="compiled forest"):
         world.set_actor_position_by_robot_index([0.0, 0.0, 0.05], 1)
+
+
+def _disc_box_clearance(disc, box, rb):
+    """smallest distance between the points of a disc (rim, a half-radius ring and the centre, 64 per ring) and a box
+    (positive outside); rb: the world's rigid-body rows [B,13] (position, quaternion xyzw)"""
+    def pose(shape):
+        row = rb[shape["rb"]]
+        x, y, z, w = row[3:7]
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                      [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        # (rb is the row of the LINK that carries the shape; shape["R"], shape["p"] are relative to the moving body instead)
+        return R @ np.asarray(shape["R_in_link"]), R @ np.asarray(shape["p_in_link"]) + row[0:3]
+    Rd, pd = pose(disc)
+    Rb, pb = pose(box)
+    a = np.linspace(0.0, 2 * np.pi, 64, endpoint=False)
+    ring = np.stack([np.cos(a), np.sin(a), np.zeros_like(a)], 1)       # a disc lies in its shape frame's xy plane (axis z)
+    pts = np.concatenate([disc["size"][0] * ring, 0.5 * disc["size"][0] * ring, np.zeros((1, 3))]) @ Rd.T + pd
+    loc = (pts - pb) @ Rb
+    d = np.abs(loc) - np.asarray(box["size"])
+    outside = np.linalg.norm(np.maximum(d, 0.0), axis=1)
+    inside = np.minimum(d.max(axis=1), 0.0)
+    return float((outside + inside).min())
+
+
+def test_wheel_and_caster_pairs_left_out_of_the_contact_model_stay_clear(lib):
+    """wheels and casters (disc shapes) are tested against the ground only; the candidate pairs with boxes of
+    other actors are listed in Scene.dropped_pair_shapes.  Over the closed loop of every example with such pairs (planner +
+    K=1 world, 300 control iterations - the pushing scene reaches and pushes its block in that time) no left-out pair comes
+    within the reference's contact offset (conf/isaacgym: contact_offset 0.01): the modelling cut changes no force there."""
+    import importlib.util
+    import os
+    from mppiisaac.backend import capi
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mppi-isaac_amd", "examples", "run.py")
+    spec = importlib.util.spec_from_file_location("examples_run", path)
+    run = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(run)
+    checked = 0
+    for name in sorted(run.EXAMPLES):
+        cfg = run.config(name, filter_u=False)
+        planner = run.make_planner(name, cfg)
+        sc = planner.sim.scene
+        if not sc.dropped_pair_shapes:
+            planner.sim.stop_sim()
+            continue
+        closest = {}
+
+        def hook(i, sim, sc=sc, closest=closest):
+            rb = sim._rigid_body_state[0].cpu().numpy().astype(np.float64)
+            for (i0, i1), names in zip(sc.dropped_pair_shapes, sc.dropped_pairs):
+                a, b = sc.all_shapes[i0], sc.all_shapes[i1]
+                disc, other = (a, b) if a["type"] == capi.SHAPE_DISC else (b, a)
+                if other["type"] != capi.SHAPE_BOX:
+                    continue
+                closest[names] = min(closest.get(names, np.inf), _disc_box_clearance(disc, other, rb))
+        first, last, _ = run.run_world(name, cfg, planner, 300, report=False, hook=hook)
+        planner.sim.stop_sim()
+        assert closest, name
+        worst = min(closest, key=closest.get)
+        print(f"\n{name}: {len(closest)} wheel/caster-box pairs, closest {worst[0]} / {worst[1]} {closest[worst]:.4f} m; stage cost {first:.3f} -> {last:.3f}")
+        assert closest[worst] > 0.01, (name, worst, closest[worst])
+        checked += 1
+    assert checked >= 1
