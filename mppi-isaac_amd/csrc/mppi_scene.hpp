@@ -998,13 +998,10 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
     // prefetch at all next to LDS work, see load_block_vmem; their integer fields go back to SGPRs for the scalar branches.
     // Measured alternatives at equal state, pushing scene: scalar loads requested one pair ahead 1.358 ms, vector loads one
     // pair ahead 1.324 ms, the records from the wavefront's LDS table one pair ahead 1.375 ms)
-#if defined(MPPI_PAIR_VMEM_RECORDS)   // experiment builds: the helper-wavefront kernel with vector-memory record prefetch as well
+    // (round 4: the kernel with a helper wavefront as well.  Until its scratch traffic was removed in round 3 the 16 registers of
+    // the NEXT pair's record did not fit its 256-register budget - 17 more values went to scratch; now they do: same scratch size,
+    // 7 % fewer instructions in the listing, pushing scene 1.0625 -> 1.0499 ms at equal state, bit-identical costs)
     constexpr bool kVmemRecords = split_on_device(SPLIT) && !dealt_broad_phase<T>(SPLIT);
-#else
-    // (not the kernel with a helper wavefront: 16 registers for the record of the NEXT pair across the whole pair body is what
-    // its 256-register budget does not have - with them the kernel keeps 17 values in scratch memory)
-    constexpr bool kVmemRecords = split_on_device(SPLIT) && !dealt_broad_phase<T>(SPLIT) && !kPair;
-#endif
     // (the kernel with a helper wavefront runs on half the register file: the contact-law block of the pairs that survive the
     // broad phase is fetched when it is needed instead of occupying 16 registers across the whole pair)
     constexpr bool kLazyGains = kPair;
@@ -1133,6 +1130,7 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
         MPPI_SEC(12);  // broad-phase arithmetic
         if (apart) continue;
         // contact law of the survivors: second block of the pair (already here: requested one pair ahead)
+        // (requested through the vector memory path in front of the broad phase instead: measured the same, 1.0427 vs 1.0396 ms)
         if constexpr (kLazyGains) Cg = load_block<PairGain>(m.pr[ip].c);
         Gains P = {G.mode, Cg.mu, Cg.k, Cg.cn, Cg.ct, Cg.kh, Cg.inv_d0, Cg.npts};
         if (G.rnd) {  // per-sample friction (min of the two) and contact gains scaled with the per-sample reacting mass
