@@ -247,7 +247,15 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
             // linear halves of every spatial quantity in two quads, K/8 wavefronts); MPPI_ROLLOUT=quad keeps 4 lanes per sample
             const char *mode = std::getenv("MPPI_ROLLOUT");
             c->quad = !(mode && std::string(mode) == "lane");
-            const bool oct = c->quad && !(mode && std::string(mode) == "quad") && cfg->num_samples >= 8;
+            // The octet kernel needs 257 registers: ONE wavefront per SIMD.  Up to K = 8 x SIMDs (8192 on the MI355X) that is all
+            // it ever gets; beyond, its second wavefront per SIMD queues behind the first (measured, profiles/
+            // r04h_wave_count_scan_oct.txt: 5.09 us per horizon step at K = 8192, 9.95 at 16384) while the 256-register quad
+            // kernel co-hosts two (5.61 us at K = 16384): larger K keeps 4 lanes per sample.  MPPI_ROLLOUT=oct forces the octet.
+            int cus = 256;
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+            (void)hipGetLastError();
+            const bool oct_fits = (cfg->num_samples + 7) / 8 <= 4 * cus || (mode && std::string(mode) == "oct");
+            const bool oct = c->quad && !(mode && std::string(mode) == "quad") && cfg->num_samples >= 8 && oct_fits;
             c->lanes_per_sample = c->quad ? (oct ? 8 : 4) : 1;
             c->launch_rollout = c->quad ? (oct ? e->rollout_oct : e->rollout_quad) : e->rollout;
             c->launch_rollout_lane = e->rollout;  // cost programs on contact-free scenes run on the one-lane kernel

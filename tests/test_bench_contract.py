@@ -42,7 +42,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     lat = d["latency_ms"]
     assert lat["p5"] <= lat["median"] <= lat["p95"] and lat["median"] == pytest.approx(d["ms_per_step"], rel=0.25)
     i = r["issue"]                                              # instruction-issue view from the committed SQ counters
-    assert i is None or (0 < i["frac_of_fp32_issue_peak"] < 1 and i["waves"] == 256)
+    assert i is None or (0 < i["frac_of_fp32_issue_peak"] < 1 and i["waves"] == r["wavefronts"])   # the committed SQ counters belong to the kernel layout that ran
     assert d["config"]["final_ee_to_goal_m"] < 0.6              # the closed loop moves towards the goal
 
 
