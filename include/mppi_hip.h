@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MPPI_ABI_VERSION 6
+#define MPPI_ABI_VERSION 7
 
 #define MPPI_MAX_BODIES 12   /* moving bodies (= DOF) of the articulated robot        */
 #define MPPI_MAX_LINKS 24    /* reported rigid bodies of the robot (URDF links)      */
@@ -41,6 +41,7 @@ extern "C" {
 #define MPPI_MAX_SHAPES 40   /* collision primitives per env (anymal: 37)                 */
 #define MPPI_MAX_PAIRS 48    /* candidate contact pairs per env                           */
 #define MPPI_MAX_FREE 2      /* free (non-fixed) box/sphere actors per env                */
+#define MPPI_MAX_EXTRA_BASES 3 /* moving-base robots per env beyond the first (ABI 7)         */
 
 enum { MPPI_OK = 0, MPPI_EINVAL = -1, MPPI_EHIP = -2, MPPI_EUNSUPPORTED = -3, MPPI_ESTATE = -4 };
 enum { MPPI_JOINT_REVOLUTE = 0, MPPI_JOINT_PRISMATIC = 1 };
@@ -209,6 +210,17 @@ typedef struct mppi_model {
      * < 0: nominal values in every sample */
     int32_t randomize_seed;
     int32_t pad2_;
+    /* ABI 7 - several MOVING-base robots in one env (reference isaacgym_wrapper.py:101-106,534-559, conf/mppi/multi-jackal.yaml).
+     * The robots form one articulated forest (bodies, links and DOFs follow one another in env order, like the fixed-base
+     * forests); base 0 is `robot_actor` with base_mass / base_h / base_Io above, base r > 0 is extra_base_*[r - 1].  A body whose
+     * `parent`, a link or a shape whose `body` is -1 - r hangs off base r (r = 0: the -1 of every single-robot model).  All
+     * robots of an env are either fixed or moving.  Every base has its own root row (root_state[actor]) and its own 6x6 base
+     * system in the articulated-body solve; the robots do not collide with each other (one forest = one robot's links). */
+    int32_t n_extra_bases;
+    int32_t extra_base_actor[MPPI_MAX_EXTRA_BASES];
+    double extra_base_mass[MPPI_MAX_EXTRA_BASES];
+    double extra_base_h[MPPI_MAX_EXTRA_BASES][3];
+    double extra_base_Io[MPPI_MAX_EXTRA_BASES][6];
 } mppi_model_t;
 
 /* mppi_torch.MPPIConfig fields (reference conf/mppi/ + benchmarks/point_robot/setup/mppi.yaml:5-37) */

@@ -24,6 +24,7 @@
 #pragma once
 #include <math.h>
 #include <stdint.h>
+#include <initializer_list>
 
 #if defined(__HIPCC__)
 #define MPPI_HD __host__ __device__ __forceinline__
@@ -40,6 +41,7 @@ constexpr int kMaxNu = 12;
 constexpr int kMaxShapes = 40;
 constexpr int kMaxPairs = 48;
 constexpr int kMaxFree = 2;
+constexpr int kMaxExtraBases = 3;  // MPPI_MAX_EXTRA_BASES (checked in mppi_pack.hpp)
 
 // ---- device-side model (fp32, z-framed) ------------------------------------------------
 struct CmdBlock {
@@ -142,6 +144,11 @@ struct DevModel {
     DevFree fr[kMaxFree];
     DevShape sh[kMaxShapes];
     DevPair pr[kMaxPairs];
+    // the further moving bases of the env (ABI 7; behind everything else: no offset of the single-robot models moves): base r > 0
+    // is xbase_*[r - 1], base 0 is robot_actor / base_m / base_hb / base_Ic above.  Read by the one-lane scene kernels only.
+    int n_bases;
+    int xbase_actor[kMaxExtraBases];
+    float xbase_m[kMaxExtraBases], xbase_hb[kMaxExtraBases][3], xbase_Ic[kMaxExtraBases][6];
 };
 struct CtrlBlock {  // one 64-byte block per quantity: fetched with a single s_load_dwordx16
     float v[16];
@@ -258,10 +265,20 @@ enum { kCostNone = 0, kCostPointReach = 1, kCostPandaReach = 2, kCostBoxerPush =
 enum { kDriveVelocity = 0, kDriveEffort = 1, kDrivePosition = 2 };
 
 // ---- compile-time kinematic tree -------------------------------------------------------
+// A parent index -1 - r names base r of the forest: r = 0 for every single-robot model and for the fixed-base forests, r > 0 for
+// the further robots of an env of MOVING-base robots (mppi_hip.h, ABI 7: one floating base per tree) - so the number of bases,
+// like the tree, is a compile-time fact and the instantiations of the existing trees do not change.
+constexpr int topo_nbase(std::initializer_list<int> parents) {
+    int n = 1;
+    for (int p : parents)
+        if (p < 0 && -p > n) n = -p;
+    return n;
+}
 template <int... P>
 struct Topo {
     static constexpr int NB = sizeof...(P);
     static constexpr int par[sizeof...(P) ? sizeof...(P) : 1] = {P...};
+    static constexpr int NBASE = topo_nbase({P...});
 };
 template <int I>
 struct IC {
@@ -526,7 +543,17 @@ struct Pose {
     int jt[T::NB ? T::NB : 1];  // joint types (wave-uniform), cached with the pose
     M3 Rb;
     V3 pb;
+    M3 Rx[T::NBASE > 1 ? T::NBASE - 1 : 1];  // bases 1.. of a forest of moving-base robots (base 0: Rb, pb)
+    V3 px[T::NBASE > 1 ? T::NBASE - 1 : 1];
+    template <int r> MPPI_HD const M3 &base_R() const { if constexpr (r == 0) return Rb; else return Rx[r - 1]; }
+    template <int r> MPPI_HD const V3 &base_p() const { if constexpr (r == 0) return pb; else return px[r - 1]; }
+    template <int r> MPPI_HD M3 &base_R() { if constexpr (r == 0) return Rb; else return Rx[r - 1]; }
+    template <int r> MPPI_HD V3 &base_p() { if constexpr (r == 0) return pb; else return px[r - 1]; }
 };
+// base r of the model: root row, composite inertia of the root-link cluster
+template <int r, class M> MPPI_HD int base_actor(M &m) { if constexpr (r == 0) return m.robot_actor; else return m.xbase_actor[r - 1]; }
+template <int r, class M> MPPI_HD float base_mass(M &m) { if constexpr (r == 0) return m.base_m; else return m.xbase_m[r - 1]; }
+constexpr int base_of_parent(int par) { return par < 0 ? -1 - par : 0; }
 
 #define MPPI_LAMBDA __attribute__((always_inline))
 
@@ -553,9 +580,12 @@ MPPI_HD void forward_kinematics_base(M &m, const float *q, Pose<T> &P);
 
 template <class T, class M>
 MPPI_HD void forward_kinematics(M &m, const float *root, const float *q, Pose<T> &P) {
-    const float *rs = root + 13 * m.robot_actor;
-    P.pb = loadv(rs);
-    P.Rb = quat_to_R(rs + 3);
+    static_for<0, T::NBASE>([&](auto rc) MPPI_LAMBDA {
+        constexpr int r = rc;
+        const float *rs = root + 13 * base_actor<r>(m);
+        P.template base_p<r>() = loadv(rs);
+        P.template base_R<r>() = quat_to_R(rs + 3);
+    });
     forward_kinematics_base<T>(m, q, P);
 }
 
@@ -567,8 +597,8 @@ MPPI_HD void forward_kinematics_base(M &m, const float *q, Pose<T> &P) {
         constexpr int par = T::par[i];
         const BodyK0 b = load_block<BodyK0>(m.b[i].k0);
         P.jt[i] = b.jtype;
-        const M3 &Rp = par < 0 ? P.Rb : P.R[par < 0 ? 0 : par];
-        const V3 pp = par < 0 ? P.pb : P.p[par < 0 ? 0 : par];
+        const M3 &Rp = par < 0 ? P.template base_R<base_of_parent(par)>() : P.R[par < 0 ? 0 : par];
+        const V3 pp = par < 0 ? P.template base_p<base_of_parent(par)>() : P.p[par < 0 ? 0 : par];
         M3 Rt0;
         for (int j = 0; j < 9; j++) Rt0.a[j] = b.rt(j);
         M3 RT = mul(Rp, Rt0);
@@ -787,7 +817,7 @@ template <class T, class M>
 MPPI_HD void link_pose(M &m, const Pose<T> &P, int l, M3 &R, V3 &p) {
     auto &L = m.l[l];
     const int body = L.body;
-    float wb = body < 0 ? 1.f : 0.f;
+    float wb = (T::NBASE > 1 ? body == -1 : body < 0) ? 1.f : 0.f;
     M3 Rb;
     for (int j = 0; j < 9; j++) Rb.a[j] = wb * P.Rb.a[j];
     V3 pb = wb * P.pb;
@@ -797,6 +827,13 @@ MPPI_HD void link_pose(M &m, const Pose<T> &P, int l, M3 &R, V3 &p) {
         for (int j = 0; j < 9; j++) Rb.a[j] += w * P.R[i].a[j];
         pb = pb + w * P.p[i];
     });
+    if constexpr (T::NBASE > 1)   // links welded to a further base of the forest (body = -1 - r)
+        static_for<1, T::NBASE>([&](auto rc) MPPI_LAMBDA {
+            constexpr int r = rc;
+            const float w = body == -1 - r ? 1.f : 0.f;
+            for (int j = 0; j < 9; j++) Rb.a[j] += w * P.Rx[r - 1].a[j];
+            pb = pb + w * P.px[r - 1];
+        });
     R = mul(Rb, load3(L.R));
     p = pb + mul(Rb, loadv(L.p));
 }

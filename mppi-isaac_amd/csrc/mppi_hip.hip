@@ -112,7 +112,7 @@ int create_buffers(mppi_ctx *c, const mppi_config_t *cfg) {
     ALLOC_TRY(c->d_q, sizeof(float) * c->n * K);
     ALLOC_TRY(c->d_qd, sizeof(float) * c->n * K);
     ALLOC_TRY(c->d_ctrl, sizeof(float) * K);
-    ALLOC_TRY(c->d_base, sizeof(float) * 13 * K);
+    ALLOC_TRY(c->d_base, sizeof(float) * 13 * (size_t)c->hm.n_bases * K);   // (one block of 13 rows per moving base of the env)
     ALLOC_TRY(c->d_fr, sizeof(float) * kMaxFree * 13 * K);
     ALLOC_TRY(c->d_cf, sizeof(float) * 3 * c->B * K);
     ALLOC_TRY(c->d_filter, sizeof(float) * c->H * c->H);
@@ -218,6 +218,9 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
             // rollouts: 4 lanes per sample (contact points dealt over the quad) unless MPPI_ROLLOUT=lane
             const char *mode = std::getenv("MPPI_ROLLOUT");
             c->quad = !(mode && std::string(mode) == "lane");
+            // several moving-base robots in one env (ABI 7: one floating base per tree): the one-lane kernels carry them - the
+            // shared-lane kernels keep ONE base (conf/mppi/multi-jackal.yaml asks for 100 samples: two wavefronts either way)
+            if (c->hm.n_bases > 1) c->quad = false;
             // contact scenes: 8 lanes per sample (contact work dealt over an octet, K/8 wavefronts) unless MPPI_ROLLOUT=quad
             // (4 lanes per sample, the round-1 kernel) or =lane; one-sample contexts (the K = 1 world) keep the quad
             const bool oct = c->quad && !(mode && std::string(mode) == "quad") && cfg->num_samples >= 8;

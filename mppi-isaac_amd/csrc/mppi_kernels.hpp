@@ -1028,7 +1028,10 @@ __global__ __launch_bounds__(kWave) void k_sim_step_scene(const DevModel *__rest
         s.q[i] = q_[(size_t)i * K + k];
         s.qd[i] = qd_[(size_t)i * K + k];
     });
-    for (int j = 0; j < 13; j++) s.base[j] = base_[(size_t)j * K + k];
+    static_for<0, T::NBASE>([&](auto rc) {   // (rows r * 13 + j: one block of 13 per base of the forest)
+        constexpr int r = rc;
+        for (int j = 0; j < 13; j++) s.template base_row<r>()[j] = base_[(size_t)(13 * r + j) * K + k];
+    });
     for (int f = 0; f < kMaxFree; f++)
         for (int j = 0; j < 13; j++) s.fr[f][j] = fr_[(size_t)(f * 13 + j) * K + k];
     float target[NB ? NB : 1], u[kMaxNu];
@@ -1063,7 +1066,10 @@ __global__ __launch_bounds__(kWave) void k_sim_step_scene(const DevModel *__rest
         q_[(size_t)i * K + k] = s.q[i];
         qd_[(size_t)i * K + k] = s.qd[i];
     });
-    for (int j = 0; j < 13; j++) base_[(size_t)j * K + k] = s.base[j];
+    static_for<0, T::NBASE>([&](auto rc) {
+        constexpr int r = rc;
+        for (int j = 0; j < 13; j++) base_[(size_t)(13 * r + j) * K + k] = s.template base_row<r>()[j];
+    });
     for (int f = 0; f < kMaxFree; f++)
         for (int j = 0; j < 13; j++) fr_[(size_t)(f * 13 + j) * K + k] = s.fr[f][j];
     for (int j = 0; j < 3 * M.n_rb; j++) cf_[(size_t)j * K + k] = L[SceneLayout<T>::kCf + j];
@@ -1181,7 +1187,10 @@ __global__ __launch_bounds__(kWave) void k_materialise_scene(const DevModel *__r
             dof[(size_t)k * 2 * NB + 2 * i + 1] = s.qd[i];
         }
     });
-    for (int j = 0; j < 13; j++) s.base[j] = base_[(size_t)j * K + k];
+    static_for<0, T::NBASE>([&](auto rc) {
+        constexpr int r = rc;
+        for (int j = 0; j < 13; j++) s.template base_row<r>()[j] = base_[(size_t)(13 * r + j) * K + k];
+    });
     for (int f = 0; f < kMaxFree; f++)
         for (int j = 0; j < 13; j++) s.fr[f][j] = fr_[(size_t)(f * 13 + j) * K + k];
     const int A = M.n_actors, B = M.n_rb;
@@ -1196,7 +1205,10 @@ __global__ void k_sim_reset_scene(const DevModel *__restrict__ m, int K, const f
                                   float *__restrict__ fr_, float *__restrict__ cf_) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
-    for (int j = 0; j < 13; j++) base_[(size_t)j * K + k] = x0_root[13 * m->robot_actor + j];
+    for (int r = 0; r < m->n_bases; r++) {
+        const int actor = r == 0 ? m->robot_actor : m->xbase_actor[r - 1];
+        for (int j = 0; j < 13; j++) base_[(size_t)(13 * r + j) * K + k] = x0_root[13 * actor + j];
+    }
     for (int f = 0; f < kMaxFree; f++)
         for (int j = 0; j < 13; j++) fr_[(size_t)(f * 13 + j) * K + k] = f < m->n_free ? x0_root[13 * m->fr[f].actor + j] : 0.f;
     for (int j = 0; j < 3 * m->n_rb; j++) cf_[(size_t)j * K + k] = 0.f;
@@ -1205,7 +1217,7 @@ __global__ void k_sim_reset_scene(const DevModel *__restrict__ m, int K, const f
 __global__ void k_root_from_world(const DevModel *__restrict__ m, const float *__restrict__ wbase, const float *__restrict__ wfr, float *__restrict__ x0_root) {
     const int j = threadIdx.x;
     if (j < 13) {
-        x0_root[13 * m->robot_actor + j] = wbase[j];
+        for (int r = 0; r < m->n_bases; r++) x0_root[13 * (r == 0 ? m->robot_actor : m->xbase_actor[r - 1]) + j] = wbase[13 * r + j];
         for (int f = 0; f < kMaxFree; f++)
             if (f < m->n_free) x0_root[13 * m->fr[f].actor + j] = wfr[f * 13 + j];
     }

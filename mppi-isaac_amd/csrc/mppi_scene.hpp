@@ -168,7 +168,7 @@ MPPI_HD PairGeom tab_pair_geom(M &m, const LMem &L, int ip) {
 
 template <class T>
 struct SceneLayout {
-    static constexpr int NF = T::NB + 1 + kMaxFree;  // dynamic frames
+    static constexpr int NF = T::NB + T::NBASE + kMaxFree;  // dynamic frames: bodies, bases (one per tree of a moving-base forest), free actors
     static constexpr int kFrame = 0;                 // [NF][18]: R(9) p(3) w(3) vO(3)
     static constexpr int kAcc = NF * 18;             // [NF][27]: f(6) C(21)
     static constexpr int kCf = kAcc + NF * 27;       // [n_rb][3] net contact force
@@ -252,10 +252,16 @@ MPPI_HD int scene_pair_floats(M &m) { return SceneLayout<T>::NF * 27 + 3 * m.n_r
 
 constexpr int scene_floats_max(int nb) { return (nb + 1 + kMaxFree) * 45 + 3 * (kMaxLinks + kMaxActors); }
 
+// dynamic frame of free actor f / of base r
+template <class T>
+constexpr int free_frame(int f) { return T::NB + T::NBASE + f; }
 template <class T>
 struct SceneState {
     float q[T::NB ? T::NB : 1], qd[T::NB ? T::NB : 1];
     float base[13];           // robot root row: pos, quat xyzw, linvel, angvel
+    float xbase[T::NBASE > 1 ? T::NBASE - 1 : 1][13];  // ... of the further moving-base robots of the env (one-lane kernels only)
+    template <int r> MPPI_HD float *base_row() { if constexpr (r == 0) return base; else return xbase[r - 1]; }
+    template <int r> MPPI_HD const float *base_row() const { if constexpr (r == 0) return base; else return xbase[r - 1]; }
     float fr[kMaxFree][13];   // free actors' root rows
     // accumulator rows (per dynamic frame) and net-contact-force rows (per rigid body, when there are <= 32 of them)
     // that the previous contact pass wrote: only those are cleared by the next pass.  All ones = "clear everything"
@@ -1331,18 +1337,25 @@ MPPI_HD void root_integrate(float *rs, const SV &a, float h) {
     rs[10] = w.x; rs[11] = w.y; rs[12] = w.z;
 }
 
+// spatial velocity / acceleration of the bases of the forest (one: every model but an env of several moving-base robots)
+template <class T>
+struct BaseSV {
+    SV r[T::NBASE];
+};
 // Articulated-body solve of the robot with external wrenches f_i and implicit dampings C_i per frame
-// (from contact_forces), explicit gravity, optional floating base.  Returns qdd and the base acceleration.
+// (from contact_forces), explicit gravity, optional floating base - one 6x6 base system per tree of a forest of moving-base
+// robots (a root body's parent -1 - r names its base, mppi_device.hpp Topo).  Returns qdd and the base accelerations.
 template <class T, class M>
-MPPI_HD void aba_scene(M &m, const Pose<T> &P, const SV &vbase, const float *qd, const float *tau_exp, const float *kdh,
-                       const LMem &L, float *qdd, SV &abase) {
+MPPI_HD void aba_scene(M &m, const Pose<T> &P, const BaseSV<T> &vbase, const float *qd, const float *tau_exp, const float *kdh,
+                       const LMem &L, float *qdd, BaseSV<T> &abase) {
     constexpr int NB = T::NB;
     using Lay = SceneLayout<T>;
     constexpr int NBs = NB ? NB : 1;
-    SV v[NBs], U[NBs], pacc[NBs + 1];
-    AI acc[NBs + 1];
+    constexpr int NX = T::NBASE;  // bases: accumulators NB .. NB + NX - 1
+    SV v[NBs], U[NBs], pacc[NBs + NX];
+    AI acc[NBs + NX];
     float invd[NBs], u[NBs];
-    bool has_acc[NBs + 1];
+    bool has_acc[NBs + NX];
     const float h = m.h;
     const V3 g = m.gravity_on ? V3{m.g[0], m.g[1], m.g[2]} : V3{0.f, 0.f, 0.f};
     static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
@@ -1350,11 +1363,11 @@ MPPI_HD void aba_scene(M &m, const Pose<T> &P, const SV &vbase, const float *qd,
         constexpr int par = T::par[i];
         SV S = joint_subspace<T, i>(m, P);
         SV sj = {qd[i] * S.a, qd[i] * S.l};
-        if constexpr (par < 0) v[i] = vbase + sj;
+        if constexpr (par < 0) v[i] = vbase.r[base_of_parent(par)] + sj;
         else v[i] = v[par < 0 ? 0 : par] + sj;
         has_acc[i] = false;
     });
-    has_acc[NB] = false;
+    static_for<0, NX>([&](auto rc) MPPI_LAMBDA { has_acc[NB + rc] = false; });
     static_rfor<0, NB>([&](auto ic) MPPI_LAMBDA {
         constexpr int i = ic;
         constexpr int par = T::par[i];
@@ -1382,14 +1395,14 @@ MPPI_HD void aba_scene(M &m, const Pose<T> &P, const SV &vbase, const float *qd,
         float d = dot(S, U[i]) + kdh[i];
         invd[i] = frcp(d);
         u[i] = tau_exp[i] - dot(S, pA);
-        const SV vp = par < 0 ? vbase : v[par < 0 ? 0 : par];
+        const SV vp = par < 0 ? vbase.r[base_of_parent(par)] : v[par < 0 ? 0 : par];
         SV sj = {qd[i] * S.a, qd[i] * S.l};
         SV c = {cross(vp.a, sj.a), cross(vp.a, sj.l) + cross(vp.l, sj.a)};
         SV Ic_ = mul(A, c);
         float k = (u[i] - dot(U[i], c)) * invd[i];
         SV pa = {pA.a + Ic_.a + k * U[i].a, pA.l + Ic_.l + k * U[i].l};
         rank1_sub(A, U[i], invd[i]);
-        constexpr int pj = par < 0 ? NB : par;  // base accumulator at index NB
+        constexpr int pj = par < 0 ? NB + base_of_parent(par) : par;  // base accumulators at NB ..
         if (has_acc[pj]) {
             add_to(acc[pj], A);
             pacc[pj] = pacc[pj] + pa;
@@ -1399,36 +1412,41 @@ MPPI_HD void aba_scene(M &m, const Pose<T> &P, const SV &vbase, const float *qd,
             has_acc[pj] = true;
         }
     });
-    abase = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    static_for<0, NX>([&](auto rc) MPPI_LAMBDA { abase.r[rc] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}; });
     if (m.floating) {
-        AI A;
-        SV pA;
-        V3 hw;
-        rigid_world(P.Rb, P.pb, m.base_m, loadv(m.base_hb), m.base_Ic, vbase, A, pA, hw);
-        SV fe;
-        AI C;
-        acc_load(L, Lay::kAcc, NB, fe, C);
-        SV Cv = mul(C, vbase);
-        pA = {pA.a + Cv.a - fe.a - cross(hw, g), pA.l + Cv.l - fe.l - m.base_m * g};
-        A.I.xx += h * C.I.xx; A.I.xy += h * C.I.xy; A.I.xz += h * C.I.xz; A.I.yy += h * C.I.yy; A.I.yz += h * C.I.yz; A.I.zz += h * C.I.zz;
-        for (int j = 0; j < 9; j++) A.H[j] += h * C.H[j];
-        A.M.xx += h * C.M.xx; A.M.xy += h * C.M.xy; A.M.xz += h * C.M.xz; A.M.yy += h * C.M.yy; A.M.yz += h * C.M.yz; A.M.zz += h * C.M.zz;
-        if (has_acc[NB]) {
-            add_to(A, acc[NB]);
-            pA = pA + pacc[NB];
-        }
-        SV rhs = {{-pA.a.x, -pA.a.y, -pA.a.z}, {-pA.l.x, -pA.l.y, -pA.l.z}};
-        abase = solve6(A, rhs);
+        static_for<0, NX>([&](auto rc) MPPI_LAMBDA {
+            constexpr int r = rc;
+            AI A;
+            SV pA;
+            V3 hw;
+            const float bm = base_mass<r>(m);
+            if constexpr (r == 0) rigid_world(P.Rb, P.pb, bm, loadv(m.base_hb), m.base_Ic, vbase.r[0], A, pA, hw);
+            else rigid_world(P.Rx[r - 1], P.px[r - 1], bm, loadv(m.xbase_hb[r - 1]), m.xbase_Ic[r - 1], vbase.r[r], A, pA, hw);
+            SV fe;
+            AI C;
+            acc_load(L, Lay::kAcc, NB + r, fe, C);
+            SV Cv = mul(C, vbase.r[r]);
+            pA = {pA.a + Cv.a - fe.a - cross(hw, g), pA.l + Cv.l - fe.l - bm * g};
+            A.I.xx += h * C.I.xx; A.I.xy += h * C.I.xy; A.I.xz += h * C.I.xz; A.I.yy += h * C.I.yy; A.I.yz += h * C.I.yz; A.I.zz += h * C.I.zz;
+            for (int j = 0; j < 9; j++) A.H[j] += h * C.H[j];
+            A.M.xx += h * C.M.xx; A.M.xy += h * C.M.xy; A.M.xz += h * C.M.xz; A.M.yy += h * C.M.yy; A.M.yz += h * C.M.yz; A.M.zz += h * C.M.zz;
+            if (has_acc[NB + r]) {
+                add_to(A, acc[NB + r]);
+                pA = pA + pacc[NB + r];
+            }
+            SV rhs = {{-pA.a.x, -pA.a.y, -pA.a.z}, {-pA.l.x, -pA.l.y, -pA.l.z}};
+            abase.r[r] = solve6(A, rhs);
+        });
     }
     SV a[NBs];
     static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
         constexpr int i = ic;
         constexpr int par = T::par[i];
         SV S = joint_subspace<T, i>(m, P);
-        const SV vp = par < 0 ? vbase : v[par < 0 ? 0 : par];
+        const SV vp = par < 0 ? vbase.r[base_of_parent(par)] : v[par < 0 ? 0 : par];
         SV sj = {qd[i] * S.a, qd[i] * S.l};
         SV c = {cross(vp.a, sj.a), cross(vp.a, sj.l) + cross(vp.l, sj.a)};
-        SV ap = (par < 0 ? abase : a[par < 0 ? 0 : par]) + c;
+        SV ap = (par < 0 ? abase.r[base_of_parent(par)] : a[par < 0 ? 0 : par]) + c;
         float dd = (u[i] - dot(U[i], ap)) * invd[i];
         qdd[i] = dd;
         a[i] = {ap.a + dd * S.a, ap.l + dd * S.l};
@@ -1437,30 +1455,41 @@ MPPI_HD void aba_scene(M &m, const Pose<T> &P, const SV &vbase, const float *qd,
 
 // kinematics of the whole scene for the current state: robot poses + dynamic frames into L
 template <class T, class M>
-MPPI_HD void scene_frames(M &m, const float *root, const SceneState<T> &s, Pose<T> &P, SV &vbase, const LMem &L) {
+MPPI_HD void scene_frames(M &m, const float *root, const SceneState<T> &s, Pose<T> &P, BaseSV<T> &vbase, const LMem &L) {
     constexpr int NB = T::NB;
-    // the robot row of `root` is replaced by the sample's own base state
-    P.pb = loadv(s.base);
-    P.Rb = quat_to_R(s.base + 3);
+    // the robot rows of `root` are replaced by the sample's own base states
+    static_for<0, T::NBASE>([&](auto rc) MPPI_LAMBDA {
+        constexpr int r = rc;
+        const float *bs = s.template base_row<r>();
+        P.template base_p<r>() = loadv(bs);
+        P.template base_R<r>() = quat_to_R(bs + 3);
+    });
     forward_kinematics_base<T>(m, s.q, P);
-    V3 wb = loadv(s.base + 10), vb = loadv(s.base + 7);
-    vbase = m.floating ? SV{wb, vb - cross(wb, P.pb)} : SV{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    static_for<0, T::NBASE>([&](auto rc) MPPI_LAMBDA {
+        constexpr int r = rc;
+        const float *bs = s.template base_row<r>();
+        V3 wb = loadv(bs + 10), vb = loadv(bs + 7);
+        vbase.r[r] = m.floating ? SV{wb, vb - cross(wb, P.template base_p<r>())} : SV{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    });
     SV v[NB ? NB : 1];
     static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
         constexpr int i = ic;
         constexpr int par = T::par[i];
         SV S = joint_subspace<T, i>(m, P);
         SV sj = {s.qd[i] * S.a, s.qd[i] * S.l};
-        if constexpr (par < 0) v[i] = vbase + sj;
+        if constexpr (par < 0) v[i] = vbase.r[base_of_parent(par)] + sj;
         else v[i] = v[par < 0 ? 0 : par] + sj;
         frame_store(L, i, P.R[i], P.p[i], v[i]);
     });
-    frame_store(L, NB, P.Rb, P.pb, vbase);
+    static_for<0, T::NBASE>([&](auto rc) MPPI_LAMBDA {
+        constexpr int r = rc;
+        frame_store(L, NB + r, P.template base_R<r>(), P.template base_p<r>(), vbase.r[r]);
+    });
     for (int f = 0; f < kMaxFree; f++)
         if (f < m.n_free) {
             const float *rs = s.fr[f];
             V3 p = loadv(rs), w = loadv(rs + 10), vl = loadv(rs + 7);
-            frame_store(L, NB + 1 + f, quat_to_R(rs + 3), p, SV{w, vl - cross(w, p)});
+            frame_store(L, free_frame<T>(f), quat_to_R(rs + 3), p, SV{w, vl - cross(w, p)});
         }
 }
 
@@ -1474,7 +1503,7 @@ MPPI_HD SV free_body_accel(M &m, int f, const LMem &L, float h, int set1 = 0) {
     M3 R;
     V3 p;
     SV v;
-    frame_load(L, NB + 1 + f, R, p, v);
+    frame_load(L, free_frame<T>(f), R, p, v);
     float fm = F.m, Ic6[6] = {F.Ic[0], 0.f, 0.f, F.Ic[1], 0.f, F.Ic[2]};
     if (m.rnd_slot[F.actor] >= 0) {  // this sample's own mass and size
         const ActorDraw dr = actor_draw<T>(m, F.actor, L);
@@ -1494,11 +1523,11 @@ MPPI_HD SV free_body_accel(M &m, int f, const LMem &L, float h, int set1 = 0) {
     rigid_world(R, p, fm, V3{0.f, 0.f, 0.f}, Ic6, v, A, pA, hw);
     SV fe;
     AI C;
-    acc_load(L, SceneLayout<T>::kAcc, NB + 1 + f, fe, C);
+    acc_load(L, SceneLayout<T>::kAcc, free_frame<T>(f), fe, C);
     if (set1 > 0) {  // (fixed order: owner's set + helper's set, as the owner's merge does for the robot's rows)
         SV fe1;
         AI C1;
-        acc_load(L, set1, NB + 1 + f, fe1, C1);
+        acc_load(L, set1, free_frame<T>(f), fe1, C1);
         fe = fe + fe1;
         add_to(C, C1);
     }
@@ -1576,7 +1605,7 @@ MPPI_HD void state_unpark(SceneState<T> &s, int n_free, const LMem &L) {
 }
 // link poses and base velocity back from the frames of this substep (what scene_frames stored)
 template <class T, class M>
-MPPI_HD void pose_from_frames(M &m, const LMem &L, Pose<T> &P, SV &vbase) {
+MPPI_HD void pose_from_frames(M &m, const LMem &L, Pose<T> &P, BaseSV<T> &vbase) {
     constexpr int NB = T::NB;
     static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
         constexpr int i = ic;
@@ -1585,8 +1614,8 @@ MPPI_HD void pose_from_frames(M &m, const LMem &L, Pose<T> &P, SV &vbase) {
         P.p[i] = {L[o + 9], L[o + 10], L[o + 11]};
     });
     SV vb;
-    frame_load(L, NB, P.Rb, P.pb, vb);
-    vbase = m.floating ? vb : SV{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    frame_load(L, NB, P.Rb, P.pb, vb);   // (the helper-wavefront kernel: one base - several bases run on the one-lane kernels)
+    vbase.r[0] = m.floating ? vb : SV{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
 }
 
 // One simulator step of a contact scene (dt = substeps * h).  `root` carries the static actors.
@@ -1603,7 +1632,7 @@ MPPI_HD void step_scene(M &m0, const float *root, SceneState<T> &s, const float 
         const bool posmode = m.drive_mode == kDrivePosition;
         const float h = m.h, kp = posmode ? m.kp : 0.f, kd = m.kd + h * kp;
         Pose<T> P;
-        SV vbase;
+        BaseSV<T> vbase;
         scene_frames<T>(m, root, s, P, vbase, L);
         MPPI_SEC(0);
 #if defined(MPPI_NO_PARK)
@@ -1635,7 +1664,7 @@ MPPI_HD void step_scene(M &m0, const float *root, SceneState<T> &s, const float 
             tau[i] = ff[i] + kd * (vs[i] - s.qd[i]);
             kdh[i] = kd * h;
         });
-        SV abase;
+        BaseSV<T> abase;
         aba_scene<T>(m, P, vbase, s.qd, tau, kdh, L, qdd, abase);
         MPPI_SEC(5);
         bool any = false;
@@ -1662,7 +1691,8 @@ MPPI_HD void step_scene(M &m0, const float *root, SceneState<T> &s, const float 
             s.q[i] = x;
             s.qd[i] = v;
         });
-        if (m.floating) root_integrate(s.base, abase, h);
+        if (m.floating)
+            static_for<0, T::NBASE>([&](auto rc) MPPI_LAMBDA { root_integrate(s.template base_row<(int)rc>(), abase.r[rc], h); });
 #if defined(__HIP_DEVICE_COMPILE__)
         if constexpr (SPLIT == kSplitOctPair) {
             // the helper wavefront has solved the free actors while this one solved the robot (helper_free_bodies)
@@ -1688,7 +1718,10 @@ MPPI_HD void scene_init(M &m, const float *dof0, const float *root, SceneState<T
         s.q[i] = dof0[2 * i];
         s.qd[i] = dof0[2 * i + 1];
     });
-    for (int j = 0; j < 13; j++) s.base[j] = root[13 * m.robot_actor + j];
+    static_for<0, T::NBASE>([&](auto rc) MPPI_LAMBDA {
+        constexpr int r = rc;
+        for (int j = 0; j < 13; j++) s.template base_row<r>()[j] = root[13 * base_actor<r>(m) + j];
+    });
     for (int f = 0; f < kMaxFree; f++)
         for (int j = 0; j < 13; j++) s.fr[f][j] = f < m.n_free ? root[13 * m.fr[f].actor + j] : 0.f;
 }
@@ -1747,6 +1780,8 @@ struct SceneEnv {
     MPPI_HD float at(int actor, int j) const {
         float v = root[13 * actor + j];
         if (actor == m.robot_actor && m.floating) v = s.base[j];
+        if constexpr (T::NBASE > 1)
+            static_for<1, T::NBASE>([&](auto rc) MPPI_LAMBDA { if (actor == m.xbase_actor[rc - 1]) v = s.xbase[rc - 1][j]; });
         for (int f = 0; f < kMaxFree; f++)
             if (f < m.n_free && m.fr[f].actor == actor) v = s.fr[f][j];
         return v;
@@ -1754,6 +1789,8 @@ struct SceneEnv {
     MPPI_HD V3 vec(int actor, int off) const {
         V3 o = loadv(root + 13 * actor + off);
         if (actor == m.robot_actor && m.floating) o = loadv(s.base + off);
+        if constexpr (T::NBASE > 1)
+            static_for<1, T::NBASE>([&](auto rc) MPPI_LAMBDA { if (actor == m.xbase_actor[rc - 1]) o = loadv(s.xbase[rc - 1] + off); });
         for (int f = 0; f < kMaxFree; f++)
             if (f < m.n_free && m.fr[f].actor == actor) o = loadv(s.fr[f] + off);
         return o;
@@ -1762,6 +1799,11 @@ struct SceneEnv {
         for (int j = 0; j < 4; j++) qq[j] = root[13 * actor + 3 + j];
         if (actor == m.robot_actor && m.floating)
             for (int j = 0; j < 4; j++) qq[j] = s.base[3 + j];
+        if constexpr (T::NBASE > 1)
+            static_for<1, T::NBASE>([&](auto rc) MPPI_LAMBDA {
+                if (actor == m.xbase_actor[rc - 1])
+                    for (int j = 0; j < 4; j++) qq[j] = s.xbase[rc - 1][3 + j];
+            });
         for (int f = 0; f < kMaxFree; f++)
             if (f < m.n_free && m.fr[f].actor == actor)
                 for (int j = 0; j < 4; j++) qq[j] = s.fr[f][3 + j];
@@ -1770,11 +1812,20 @@ struct SceneEnv {
     MPPI_HD V3 constant_point(float x, float y, float z) const { return V3{x - L.ox, y - L.oy, z}; }  // (rollout coordinates, see root_relative)
 };
 
+// base poses of the sample's own state into P (what forward_kinematics_base starts from)
+template <class T>
+MPPI_HD void pose_bases(const SceneState<T> &s, Pose<T> &P) {
+    static_for<0, T::NBASE>([&](auto rc) MPPI_LAMBDA {
+        constexpr int r = rc;
+        const float *bs = s.template base_row<r>();
+        P.template base_p<r>() = loadv(bs);
+        P.template base_R<r>() = quat_to_R(bs + 3);
+    });
+}
 template <class T, class M>
 MPPI_HD float stage_cost_scene(M &m, CCost &c, const float *root, const SceneState<T> &s, const LMem &L) {
     Pose<T> P;
-    P.pb = loadv(s.base);
-    P.Rb = quat_to_R(s.base + 3);
+    pose_bases<T>(s, P);
     if (c.kind == kCostProgram) {
         forward_kinematics_base<T>(m, s.q, P);
         return program_cost<T>(m, c, s.q, s.qd, P, SceneEnv<T, M>{m, root, s, L});
@@ -1861,8 +1912,7 @@ MPPI_HD float rollout_scene(M &m0, MR &mr0, CCfg &cfg0, CCost &cost0, const floa
             if (cfg.want_rollouts && viz != nullptr && leader) {
                 M &m = *launder(mp);
                 Pose<T> P;
-                P.pb = loadv(s.base);
-                P.Rb = quat_to_R(s.base + 3);
+                pose_bases<T>(s, P);
                 forward_kinematics_base<T>(m, s.q, P);
                 M3 R;
                 V3 p;
@@ -1908,29 +1958,37 @@ MPPI_HD void scene_materialise(M &m, const float *root, const SceneState<T> &s, 
     // root rows: static actors from x0, robot and free actors from the env state
     if (root_out != nullptr) {
         for (int j = 0; j < 13 * m.n_actors; j++) root_out[j] = root[j];
-        for (int j = 0; j < 13; j++) root_out[13 * m.robot_actor + j] = s.base[j];
+        static_for<0, T::NBASE>([&](auto rc) MPPI_LAMBDA {
+            constexpr int r = rc;
+            for (int j = 0; j < 13; j++) root_out[13 * base_actor<r>(m) + j] = s.template base_row<r>()[j];
+        });
         for (int f = 0; f < kMaxFree; f++)
             if (f < m.n_free)
                 for (int j = 0; j < 13; j++) root_out[13 * m.fr[f].actor + j] = s.fr[f][j];
     }
     if (rb != nullptr) {
         Pose<T> P;
-        P.pb = loadv(s.base);
-        P.Rb = quat_to_R(s.base + 3);
+        pose_bases<T>(s, P);
         forward_kinematics_base<T>(m, s.q, P);
-        V3 wb = loadv(s.base + 10), vb = loadv(s.base + 7);
-        const SV vbase = m.floating ? SV{wb, vb - cross(wb, P.pb)} : SV{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+        BaseSV<T> vbase;
+        static_for<0, T::NBASE>([&](auto rc) MPPI_LAMBDA {
+            constexpr int r = rc;
+            const float *bs = s.template base_row<r>();
+            V3 wb = loadv(bs + 10), vb = loadv(bs + 7);
+            vbase.r[r] = m.floating ? SV{wb, vb - cross(wb, P.template base_p<r>())} : SV{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+        });
         SV v[NB ? NB : 1];
         static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
             constexpr int i = ic;
             constexpr int par = T::par[i];
             SV S = joint_subspace<T, i>(m, P);
             SV sj = {s.qd[i] * S.a, s.qd[i] * S.l};
-            if constexpr (par < 0) v[i] = vbase + sj;
+            if constexpr (par < 0) v[i] = vbase.r[base_of_parent(par)] + sj;
             else v[i] = v[par < 0 ? 0 : par] + sj;
         });
         for (int a = 0; a < m.n_actors; a++) {
             if (a == m.robot_actor) continue;
+            if (T::NBASE > 1 && m.actor_first_rb[a] >= m.robot_first_rb && m.actor_first_rb[a] < m.robot_first_rb + m.nl) continue;  // (a further robot of the forest: its links' rows are written below)
             float *o = rb + 13 * m.actor_first_rb[a];
             for (int j = 0; j < 13; j++) o[j] = root[13 * a + j];
         }
@@ -1943,8 +2001,12 @@ MPPI_HD void scene_materialise(M &m, const float *root, const SceneState<T> &s, 
             M3 R;
             V3 p;
             link_pose<T>(m, P, l, R, p);
-            const float w0 = m.l[l].body < 0 ? 1.f : 0.f;
-            SV vl = {w0 * vbase.a, w0 * vbase.l};
+            SV vl = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+            static_for<0, T::NBASE>([&](auto rc) MPPI_LAMBDA {
+                constexpr int r = rc;
+                const float w0 = (T::NBASE > 1 ? m.l[l].body == -1 - r : m.l[l].body < 0) ? 1.f : 0.f;
+                vl = {vl.a + w0 * vbase.r[r].a, vl.l + w0 * vbase.r[r].l};
+            });
             static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
                 constexpr int i = ic;
                 const float w = m.l[l].body == i ? 1.f : 0.f;

@@ -105,26 +105,40 @@ def _quat_to_R(q) -> np.ndarray:
                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
 
 
-def merge_fixed_base_robots(env_cfg: List["ActorWrapper"], robots: List[int], models: List[dict]):
+def merge_robots(env_cfg: List["ActorWrapper"], robots: List[int], models: List[dict]):
     """Several robots in one env (reference isaacgym_wrapper.py:101-106,220-236,534-559,574-612: commands, joint states and
     initial joint poses of the robots are concatenated in env order).  Fixed-base robots are independent trees hanging off the
     world, so together they are ONE articulated forest: the compiled models are concatenated, every later robot's root joints
-    and base-welded links carry its base pose relative to the first robot's.  -> (merged model, actor index per link)"""
+    and base-welded links carry its base pose relative to the first robot's.  Moving-base robots (multi-jackal) form a forest
+    with one floating base per tree (mppi_hip.h, ABI 7).  -> (merged model, actor index per link)"""
+    moving = [not env_cfg[i].fixed for i in robots]
+    if any(moving) and not all(moving):
+        raise NotImplementedError("several robots per env: the robots of an env are either all fixed or all moving")
     for i in robots:
         a = env_cfg[i]
-        if not a.fixed or a.differential_drive:
-            raise NotImplementedError(f"several robots per env: only fixed-base robots can share an env ('{a.name}' has a moving base: "
-                                      "the engine carries one floating base per env)")
         if a.dof_mode != env_cfg[robots[0]].dof_mode:
             raise ValueError("All robots must have the same dof_mode")        # (reference :541-542)
     if robots != list(range(robots[0], robots[0] + len(robots))):
         raise NotImplementedError("several robots per env: list the robot actors next to each other (their rigid-body rows form one block)")
+    if all(moving) and len(robots) > 1 + capi.MAX_EXTRA_BASES:
+        raise ValueError(f"several robots per env: at most {1 + capi.MAX_EXTRA_BASES} moving bases (MPPI_MAX_EXTRA_BASES)")
+    if sum(len(m["links"]) for m in models) > capi.MAX_LINKS:
+        # more URDF links than reported rigid-body rows exist (two jackals: 2 x 14): report the links somebody can observe - base
+        # link, collision geometry, visualize_link - as for the ANYmal's 78 (urdf_compile.prune_links; links are addressed by name)
+        from mppiisaac.backend.urdf_compile import prune_links
+        models = [prune_links(m, keep=[env_cfg[i].visualize_link] if env_cfg[i].visualize_link else ()) for i, m in zip(robots, models)]
+        logging.getLogger("mppiisaac").warning("several robots per env: %d links without collision geometry are not reported as rigid bodies "
+                                               "(MPPI_MAX_LINKS = %d)", sum(m["pruned_links"] for m in models), capi.MAX_LINKS)
     first = env_cfg[robots[0]]
     R0, p0 = _quat_to_R(first.init_ori), np.asarray(first.init_pos, float)
     merged = {"format": models[0]["format"], "name": "+".join(m["name"] for m in models), "root_link": models[0]["root_link"],
               "links": [], "bodies": [], "base": models[0]["base"]}
+    # MOVING bases (ABI 7; reference conf/mppi/multi-jackal.yaml): every robot keeps its own root row and its own 6x6 base system;
+    # a root body's parent and a base link's body index name the base they hang off as -1 - r.  No relative poses: the bases move
+    merged["bases"] = [dict(actor=i, inertia=m["base"]["inertia"], own_inertia=m["links"][0]["own_inertia"]) for i, m in zip(robots, models)] \
+        if all(moving) else None
     owner = []
-    for i, m in zip(robots, models):
+    for r, (i, m) in enumerate(zip(robots, models)):
         a = env_cfg[i]
         R_rel = R0.T @ _quat_to_R(a.init_ori)
         p_rel = R0.T @ (np.asarray(a.init_pos, float) - p0)
@@ -132,8 +146,11 @@ def merge_fixed_base_robots(env_cfg: List["ActorWrapper"], robots: List[int], mo
         for b in m["bodies"]:
             nb = dict(b)
             if b["parent"] < 0:
-                nb["R_tree"] = (R_rel @ np.asarray(b["R_tree"])).tolist()
-                nb["p_tree"] = (R_rel @ np.asarray(b["p_tree"]) + p_rel).tolist()
+                if all(moving):
+                    nb["parent"] = -1 - r
+                else:
+                    nb["R_tree"] = (R_rel @ np.asarray(b["R_tree"])).tolist()
+                    nb["p_tree"] = (R_rel @ np.asarray(b["p_tree"]) + p_rel).tolist()
             else:
                 nb["parent"] = b["parent"] + boff
             merged["bodies"].append(nb)
@@ -141,8 +158,11 @@ def merge_fixed_base_robots(env_cfg: List["ActorWrapper"], robots: List[int], mo
             nl = dict(l)
             nl["parent_link"] = l["parent_link"] + loff if l["parent_link"] >= 0 else -1
             if l["body"] < 0:
-                nl["R"] = (R_rel @ np.asarray(l["R"])).tolist()
-                nl["p"] = (R_rel @ np.asarray(l["p"]) + p_rel).tolist()
+                if all(moving):
+                    nl["body"] = -1 - r
+                else:
+                    nl["R"] = (R_rel @ np.asarray(l["R"])).tolist()
+                    nl["p"] = (R_rel @ np.asarray(l["p"]) + p_rel).tolist()
             else:
                 nl["body"] = l["body"] + boff
             merged["links"].append(nl)
@@ -167,7 +187,7 @@ class Scene:
         if len(robots) > 1:   # robot_model: one compiled model per robot actor, in env order
             if not isinstance(robot_model, (list, tuple)) or len(robot_model) != len(robots):
                 raise ValueError("several robots per env: pass one compiled model per robot actor")
-            robot_model, self.link_owner = merge_fixed_base_robots(env_cfg, robots, list(robot_model))
+            robot_model, self.link_owner = merge_robots(env_cfg, robots, list(robot_model))
         else:
             robot_model = robot_model[0] if isinstance(robot_model, (list, tuple)) else robot_model
             self.link_owner = [self.robot_idx] * len(robot_model["links"])
@@ -189,25 +209,39 @@ class Scene:
         self.randomize_seed = -1  # >= 0: per-sample size/mass/friction draws of the noisy box/sphere actors
 
     def _command_map(self):
-        """apply_robot_cmd's scatter (reference :524-559) as <=2 (column, coefficient) terms per DOF."""
-        a = self.robot
+        """apply_robot_cmd's scatter (reference :524-559) as <=2 (column, coefficient) terms per DOF.  Several robots: their DOFs
+        follow one another and take the next commands in turn - a diff-drive robot its own (v, yaw rate) pair.  (The reference's
+        loop hands EVERY diff-drive robot the first two commands and writes through actor-local DOF indices, :545-559: with two
+        jackals the second one's columns stay zero.  Restated as what `u_desired_idx += 2` says it means.)"""
         idx, terms = 0, []
-        if a.differential_drive:
-            if not a.left_wheel_joints or not a.right_wheel_joints:
-                # e.g. the shipped conf/actors/jackal.yaml: the reference evaluates `name in None` here and raises
-                # TypeError (isaacgym_wrapper.py:552-555); fail with a message instead
-                raise ValueError(f"actor '{a.name}': differential_drive needs left_wheel_joints and right_wheel_joints")
-            idx = 2
-        # (several fixed-base robots: their DOFs follow one another and take the next commands in turn, reference :534-559)
-        for name in self.dof_names:
-            if a.differential_drive and name in (a.left_wheel_joints or []):
-                terms.append(((0, 1.0 / a.wheel_radius), (1, -a.wheel_base / (2 * a.wheel_radius))))
-            elif a.differential_drive and name in (a.right_wheel_joints or []):
-                terms.append(((0, 1.0 / a.wheel_radius), (1, a.wheel_base / (2 * a.wheel_radius))))
-            else:
-                terms.append(((idx, 1.0), (0, 0.0)))
-                idx += 1
+        owner_of_dof = [self._actor_of_body(b) for b in range(self.n_dof)]
+        for ai in self.robot_ids:
+            a = self.env_cfg[ai]
+            base = idx
+            if a.differential_drive:
+                if not a.left_wheel_joints or not a.right_wheel_joints:
+                    # e.g. the shipped conf/actors/jackal.yaml: the reference evaluates `name in None` here and raises
+                    # TypeError (isaacgym_wrapper.py:552-555); fail with a message instead
+                    raise ValueError(f"actor '{a.name}': differential_drive needs left_wheel_joints and right_wheel_joints")
+                idx += 2
+            for b, name in enumerate(self.dof_names):
+                if owner_of_dof[b] != ai:
+                    continue
+                if a.differential_drive and name in (a.left_wheel_joints or []):
+                    terms.append(((base, 1.0 / a.wheel_radius), (base + 1, -a.wheel_base / (2 * a.wheel_radius))))
+                elif a.differential_drive and name in (a.right_wheel_joints or []):
+                    terms.append(((base, 1.0 / a.wheel_radius), (base + 1, a.wheel_base / (2 * a.wheel_radius))))
+                else:
+                    terms.append(((idx, 1.0), (0, 0.0)))
+                    idx += 1
         return terms, idx
+
+    def _actor_of_body(self, body: int) -> int:
+        """robot actor that owns moving body `body` (the owner of the links welded to it)"""
+        for l, o in zip(self.robot_model["links"], self.link_owner):
+            if l["body"] == body:
+                return o
+        return self.robot_idx
 
     # contact parameters of the penalty model (build-normative, DESIGN.md section 3; no reference counterpart)
     CONTACT_ALPHA, CONTACT_BETA, FRICTION_BETA, GROUND_FRICTION = 0.8, 0.8, 1.0, 1.0
@@ -307,7 +341,8 @@ class Scene:
         if link["body"] < 0:
             return False
         b = self.robot_model["bodies"][link["body"]]
-        wheels = (self.robot.left_wheel_joints or []) + (self.robot.right_wheel_joints or [])
+        owner = self.env_cfg[self._actor_of_body(link["body"])]
+        wheels = (owner.left_wheel_joints or []) + (owner.right_wheel_joints or [])
         return b["joint"] in wheels and abs(float(np.dot(R_shape[:, 2], np.asarray(b["axis"])))) > 0.99
 
     def viz_link_index(self) -> int:
@@ -400,17 +435,26 @@ class Scene:
                 cl.R[j] = l["R"][j // 3][j % 3]
             for j in range(3):
                 cl.p[j] = l["p"][j]
-        bi = rm["base"]["inertia"]
         # the reference overwrites the mass of rigid body 0 of every actor with ActorWrapper.mass
         # (isaacgym_wrapper.py:450-456); the inertia tensor is left as imported.  Only matters for floating bases.
-        own = rm["links"][0]["own_inertia"]
-        dm = float(self.robot.mass) - own["mass"]
-        c0 = np.asarray(own["h"]) / own["mass"] if own["mass"] > 0 else np.zeros(3)
-        m.base_mass = bi["mass"] + dm
+        def base_inertia(bi, own, actor):
+            dm = float(actor.mass) - own["mass"]
+            c0 = np.asarray(own["h"]) / own["mass"] if own["mass"] > 0 else np.zeros(3)
+            return bi["mass"] + dm, [bi["h"][j] + dm * c0[j] for j in range(3)], list(bi["Io"])
+        bases = rm.get("bases") or [dict(actor=self.robot_idx, inertia=rm["base"]["inertia"], own_inertia=rm["links"][0]["own_inertia"])]
+        m.base_mass, bh, bI = base_inertia(bases[0]["inertia"], bases[0]["own_inertia"], self.env_cfg[bases[0]["actor"]])
         for j in range(3):
-            m.base_h[j] = bi["h"][j] + dm * c0[j]
+            m.base_h[j] = bh[j]
         for j in range(6):
-            m.base_Io[j] = bi["Io"][j]
+            m.base_Io[j] = bI[j]
+        m.n_extra_bases = len(bases) - 1            # several moving-base robots (ABI 7): base r > 0
+        for r, b in enumerate(bases[1:]):
+            m.extra_base_actor[r] = b["actor"]
+            m.extra_base_mass[r], bh, bI = base_inertia(b["inertia"], b["own_inertia"], self.env_cfg[b["actor"]])
+            for j in range(3):
+                m.extra_base_h[r][j] = bh[j]
+            for j in range(6):
+                m.extra_base_Io[r][j] = bI[j]
         m.n_shapes, m.n_pairs = len(self.shapes), len(self.pairs)
         for i, sh in enumerate(self.shapes):
             cs = m.shapes[i]
@@ -832,7 +876,7 @@ class IsaacGymWrapper:
 
     # setters of the reference (:359-397): the root row of one actor in every env; takes effect for the next rollout / step
     def _set_root_columns(self, actor_idx, lo: int, hi: int, value) -> None:
-        if len(self.scene.robot_ids) > 1 and self._as_index(actor_idx) in self.scene.robot_ids:
+        if len(self.scene.robot_ids) > 1 and self._as_index(actor_idx) in self.scene.robot_ids and self.scene.robot.fixed:
             raise NotImplementedError("the fixed bases of several robots in one env are part of the compiled forest: place them "
                                       "with initial_actor_positions")
         root = self._root_state[0].clone()

@@ -45,6 +45,7 @@
 typedef REAL real;
 
 #define NBMAX MPPI_MAX_BODIES
+#define NBASEMAX (1 + MPPI_MAX_EXTRA_BASES)
 
 /* ------------------------------------------------------------------ small linear algebra */
 static void m3_mul(const real *A, const real *B, real *C) { /* C = A B */
@@ -169,21 +170,35 @@ static void crf(const real *v, const real *f, real *out) { /* v x* f (force) */
 typedef struct {
     real Rj[NBMAX][9], pj[NBMAX][3]; /* child->parent transform of each body            */
     real Rw[NBMAX][9], pw[NBMAX][3]; /* body->world                                      */
-    real Rb[9], pb[3];               /* base->world                                      */
-    real vb[6];                      /* base spatial velocity, base coordinates          */
+    real Rb[NBASEMAX][9], pb[NBASEMAX][3]; /* base r -> world (r > 0: the further moving-base robots of an env, ABI 7) */
+    real vb[NBASEMAX][6];            /* base spatial velocity, base coordinates          */
     real X[NBMAX][36];               /* Plucker parent->child                            */
     real S[NBMAX][6];
     real v[NBMAX][6];                /* spatial velocity, body coordinates               */
     real c[NBMAX][6];
 } kin_t;
 
+/* the moving bases of an env (mppi_hip.h, ABI 7): base 0 = robot_actor, base r > 0 = extra_base_*[r - 1]; a body's parent / a
+ * link's or shape's body index -1 - r names base r */
+static int n_bases(const mppi_model_t *m) { return 1 + m->n_extra_bases; }
+static int base_actor(const mppi_model_t *m, int r) { return r == 0 ? m->robot_actor : m->extra_base_actor[r - 1]; }
+static real base_mass_of(const mppi_model_t *m, int r) { return (real)(r == 0 ? m->base_mass : m->extra_base_mass[r - 1]); }
+static const double *base_h_of(const mppi_model_t *m, int r) { return r == 0 ? m->base_h : m->extra_base_h[r - 1]; }
+static const double *base_Io_of(const mppi_model_t *m, int r) { return r == 0 ? m->base_Io : m->extra_base_Io[r - 1]; }
+static int base_of_body(const mppi_model_t *m, int i) {
+    while (m->bodies[i].parent >= 0) i = m->bodies[i].parent;
+    return -1 - m->bodies[i].parent;
+}
+
 static void kinematics(const mppi_model_t *m, const real *root, const real *q, const real *qd, kin_t *k) {
-    const real *rs = root + 13 * m->robot_actor;
-    k->pb[0] = rs[0]; k->pb[1] = rs[1]; k->pb[2] = rs[2];
-    quat_to_R(rs + 3, k->Rb);
-    /* base spatial velocity in base coordinates (zero for a fixed base) */
-    for (int j = 0; j < 6; j++) k->vb[j] = 0;
-    if (!m->actors[m->robot_actor].fixed) { m3_tvec(k->Rb, rs + 10, k->vb); m3_tvec(k->Rb, rs + 7, k->vb + 3); }
+    for (int r = 0; r < n_bases(m); r++) {
+        const real *rs = root + 13 * base_actor(m, r);
+        k->pb[r][0] = rs[0]; k->pb[r][1] = rs[1]; k->pb[r][2] = rs[2];
+        quat_to_R(rs + 3, k->Rb[r]);
+        /* base spatial velocity in base coordinates (zero for a fixed base) */
+        for (int j = 0; j < 6; j++) k->vb[r][j] = 0;
+        if (!m->actors[base_actor(m, r)].fixed) { m3_tvec(k->Rb[r], rs + 10, k->vb[r]); m3_tvec(k->Rb[r], rs + 7, k->vb[r] + 3); }
+    }
     for (int i = 0; i < m->n_bodies; i++) {
         const mppi_body_t *b = &m->bodies[i];
         real Rt[9], pt[3], ax[3];
@@ -203,8 +218,8 @@ static void kinematics(const mppi_model_t *m, const real *root, const real *q, c
             for (int j = 0; j < 3; j++) { k->S[i][j] = 0; k->S[i][3 + j] = ax[j]; }
         }
         plucker(k->Rj[i], k->pj[i], k->X[i]);
-        const real *Rp = b->parent < 0 ? k->Rb : k->Rw[b->parent];
-        const real *pp = b->parent < 0 ? k->pb : k->pw[b->parent];
+        const real *Rp = b->parent < 0 ? k->Rb[-1 - b->parent] : k->Rw[b->parent];
+        const real *pp = b->parent < 0 ? k->pb[-1 - b->parent] : k->pw[b->parent];
         real t[3];
         m3_mul(Rp, k->Rj[i], k->Rw[i]);
         m3_vec(Rp, k->pj[i], t);
@@ -212,7 +227,7 @@ static void kinematics(const mppi_model_t *m, const real *root, const real *q, c
         /* v_i = X v_parent + S qd ; c_i = v_i x (S qd)    (base is fixed: v_base = 0) */
         real vj[6];
         for (int j = 0; j < 6; j++) vj[j] = k->S[i][j] * qd[i];
-        m6_vec(k->X[i], b->parent < 0 ? k->vb : k->v[b->parent], k->v[i]);
+        m6_vec(k->X[i], b->parent < 0 ? k->vb[-1 - b->parent] : k->v[b->parent], k->v[i]);
         for (int j = 0; j < 6; j++) k->v[i][j] += vj[j];
         crm(k->v[i], vj, k->c[i]);
     }
@@ -255,7 +270,7 @@ static void aba_solve(const mppi_model_t *m, const kin_t *k, const real *tau_exp
     real a0[6] = {0, 0, 0, 0, 0, 0};
     if (m->actors[m->robot_actor].gravity) {
         real g[3] = {(real)m->gravity[0], (real)m->gravity[1], (real)m->gravity[2]}, gb[3];
-        m3_tvec(k->Rb, g, gb);
+        m3_tvec(k->Rb[0], g, gb);   /* (fixed-base trees and forests: ONE base frame, mppi_hip.h; several bases move and are scenes) */
         a0[3] = -gb[0]; a0[4] = -gb[1]; a0[5] = -gb[2];
     }
     for (int i = 0; i < n; i++) {
@@ -356,7 +371,8 @@ void orc_rigid_body_state(const mppi_model_t *m, const real *root, const real *q
     for (int a = 0; a < m->n_actors; a++) {
         const mppi_actor_t *A = &m->actors[a];
         if (a != m->robot_actor) { /* box / sphere: its single body is the root body */
-            memcpy(rb + 13 * A->first_rb, root + 13 * a, 13 * sizeof(real));
+            /* (the further robots of a forest: their links' rows are written with the first robot's, the rows follow one another) */
+            if (A->type != MPPI_ACTOR_ROBOT) memcpy(rb + 13 * A->first_rb, root + 13 * a, 13 * sizeof(real));
             continue;
         }
         for (int l = 0; l < m->n_links; l++) {
@@ -364,13 +380,13 @@ void orc_rigid_body_state(const mppi_model_t *m, const real *root, const real *q
             real Rl[9], pl[3], Rw[9], pw[3], t[3], quat[4], wv[3] = {0, 0, 0}, lv[3] = {0, 0, 0};
             for (int j = 0; j < 9; j++) Rl[j] = (real)L->R[j];
             for (int j = 0; j < 3; j++) pl[j] = (real)L->p[j];
-            const real *Rbw = L->body < 0 ? k.Rb : k.Rw[L->body];
-            const real *pbw = L->body < 0 ? k.pb : k.pw[L->body];
+            const real *Rbw = L->body < 0 ? k.Rb[-1 - L->body] : k.Rw[L->body];
+            const real *pbw = L->body < 0 ? k.pb[-1 - L->body] : k.pw[L->body];
             m3_mul(Rbw, Rl, Rw);
             m3_vec(Rbw, pl, t);
             for (int j = 0; j < 3; j++) pw[j] = pbw[j] + t[j];
             { /* velocity of the link origin: R_w (v + w x p_l) */
-                const real *v = L->body >= 0 ? k.v[L->body] : k.vb;
+                const real *v = L->body >= 0 ? k.v[L->body] : k.vb[-1 - L->body];
                 real wxp[3], vl[3];
                 cross3(v, pl, wxp);
                 for (int j = 0; j < 3; j++) vl[j] = v[3 + j] + wxp[j];
@@ -394,7 +410,7 @@ void orc_rigid_body_state(const mppi_model_t *m, const real *root, const real *q
  * shape properties, isaacgym_utils.py:61-68 ground plane); PARITY UNPINNED - this is the build-normative
  * model, checked by physics known-answer tests (tests/test_scene_kat.py).
  * Formulation: dense 6x6 spatial algebra in WORLD coordinates about the world origin, double precision. */
-#define NFMAX (NBMAX + 1 + MPPI_MAX_FREE)
+#define NFMAX (NBMAX + NBASEMAX + MPPI_MAX_FREE)
 
 typedef struct {
     real R[9], p[3];   /* pose */
@@ -406,16 +422,18 @@ typedef struct {
 
 typedef struct {
     int is_scene, floating, n_free, free_actor[MPPI_MAX_FREE];
-    real robot_mass;
+    int nb;                      /* bases of the forest (1 + n_extra_bases): dynamic frames n_bodies .. n_bodies + nb - 1 */
+    real robot_mass[NBASEMAX];   /* mass of the tree that hangs off base r (contact gains scale with the reacting robot's mass) */
 } scene_info_t;
 
 static void scene_info(const mppi_model_t *m, scene_info_t *si) {
     si->floating = !m->actors[m->robot_actor].fixed;
     si->n_free = 0;
     for (int a = 0; a < m->n_actors; a++)
-        if (a != m->robot_actor && !m->actors[a].fixed && si->n_free < MPPI_MAX_FREE) si->free_actor[si->n_free++] = a;
-    si->robot_mass = (real)m->base_mass;
-    for (int i = 0; i < m->n_bodies; i++) si->robot_mass += (real)m->bodies[i].mass;
+        if (m->actors[a].type != MPPI_ACTOR_ROBOT && !m->actors[a].fixed && si->n_free < MPPI_MAX_FREE) si->free_actor[si->n_free++] = a;
+    si->nb = n_bases(m);
+    for (int r = 0; r < si->nb; r++) si->robot_mass[r] = base_mass_of(m, r);
+    for (int i = 0; i < m->n_bodies; i++) si->robot_mass[base_of_body(m, i)] += (real)m->bodies[i].mass;
     si->is_scene = si->floating || si->n_free > 0 || m->n_pairs > 0;
 }
 int orc_is_scene(const mppi_model_t *m) { scene_info_t si; scene_info(m, &si); return si.is_scene; }
@@ -591,18 +609,18 @@ static void sphere_sphere(int mode, real mu, real k, real cn, real ct, real kh, 
 static int shape_entity(const mppi_model_t *m, const scene_info_t *si, const mppi_shape_t *S, real *mass) {
     *mass = -1;
     if (S->actor == m->robot_actor) {
-        if (S->body >= 0) { *mass = si->robot_mass; return S->body; }
-        if (si->floating) { *mass = si->robot_mass; return m->n_bodies; }
+        if (S->body >= 0) { *mass = si->robot_mass[base_of_body(m, S->body)]; return S->body; }
+        if (si->floating) { *mass = si->robot_mass[-1 - S->body]; return m->n_bodies + (-1 - S->body); }
         return -1;
     }
     for (int f = 0; f < si->n_free; f++)
-        if (si->free_actor[f] == S->actor) { *mass = (real)m->actors[S->actor].mass; return m->n_bodies + 1 + f; }
+        if (si->free_actor[f] == S->actor) { *mass = (real)m->actors[S->actor].mass; return m->n_bodies + si->nb + f; }
     return -1;
 }
 
 static void scene_contacts(const mppi_model_t *m, const scene_info_t *si, frame_t *fr, const real *root, real *cf) {
     real h = (real)(m->dt / m->substeps);
-    int nf = m->n_bodies + 1 + MPPI_MAX_FREE;
+    int nf = m->n_bodies + si->nb + MPPI_MAX_FREE;
     g_ramp_depth = (real)m->contact_ramp_depth;
     for (int e = 0; e < nf; e++) { memset(fr[e].f, 0, sizeof fr[e].f); memset(fr[e].C, 0, sizeof fr[e].C); }
     for (int j = 0; j < 3 * m->n_rb; j++) cf[j] = 0;
@@ -746,19 +764,21 @@ static void root_frame(const real *rs, frame_t *f) {
 
 /* World-frame dense ABA of the robot with external wrenches / implicit dampings per frame. */
 static void scene_aba(const mppi_model_t *m, const scene_info_t *si, frame_t *fr, const real *qd, const real *tau_exp, const real *kdh,
-                      real *qdd, real *abase) {
-    int n = m->n_bodies;
+                      real *qdd, real (*abase)[6]) {
+    int n = m->n_bodies, nb = si->nb;
     real h = (real)(m->dt / m->substeps);
-    real g[3] = {0, 0, 0};
-    if (m->actors[m->robot_actor].gravity) for (int j = 0; j < 3; j++) g[j] = (real)m->gravity[j];
-    real S[NBMAX][6], c[NBMAX][6], IA[NBMAX + 1][36], pA[NBMAX + 1][6], U[NBMAX][6], d[NBMAX], u[NBMAX], a[NBMAX][6];
-    const real *vb = fr[n].v;
-    for (int i = 0; i <= n; i++) {
+    real gr[NBASEMAX][3];   /* gravity per tree (ActorWrapper.gravity of the robot that owns it) */
+    for (int r = 0; r < nb; r++)
+        for (int j = 0; j < 3; j++) gr[r][j] = m->actors[base_actor(m, r)].gravity ? (real)m->gravity[j] : 0;
+    real S[NBMAX][6], c[NBMAX][6], IA[NBMAX + NBASEMAX][36], pA[NBMAX + NBASEMAX][6], U[NBMAX][6], d[NBMAX], u[NBMAX], a[NBMAX][6];
+    for (int i = 0; i < n + nb; i++) {
         const frame_t *F = &fr[i];
+        const int r = i < n ? base_of_body(m, i) : i - n;
+        const real *g = gr[r];
         real hw[3];
         if (i < n) world_inertia(F->R, F->p, (real)m->bodies[i].mass, m->bodies[i].h, m->bodies[i].Io, IA[i], hw);
-        else world_inertia(F->R, F->p, (real)m->base_mass, m->base_h, m->base_Io, IA[i], hw);
-        real mass = i < n ? (real)m->bodies[i].mass : (real)m->base_mass;
+        else world_inertia(F->R, F->p, base_mass_of(m, r), base_h_of(m, r), base_Io_of(m, r), IA[i], hw);
+        real mass = i < n ? (real)m->bodies[i].mass : base_mass_of(m, r);
         real Iv[6], Cv[6], fg[6], t3[3];
         m6_vec(IA[i], F->v, Iv);
         crf(F->v, Iv, pA[i]);
@@ -773,7 +793,7 @@ static void scene_aba(const mppi_model_t *m, const scene_info_t *si, frame_t *fr
             m3_vec(F->R, ax, aw);
             if (b->jtype == MPPI_JOINT_REVOLUTE) { cross3(F->p, aw, t); for (int j = 0; j < 3; j++) { S[i][j] = aw[j]; S[i][3 + j] = t[j]; } }
             else for (int j = 0; j < 3; j++) { S[i][j] = 0; S[i][3 + j] = aw[j]; }
-            const real *vp = b->parent < 0 ? vb : fr[b->parent].v;
+            const real *vp = b->parent < 0 ? fr[n + (-1 - b->parent)].v : fr[b->parent].v;
             real sj[6];
             for (int j = 0; j < 6; j++) sj[j] = S[i][j] * qd[i];
             crm(vp, sj, c[i]);
@@ -785,25 +805,27 @@ static void scene_aba(const mppi_model_t *m, const scene_info_t *si, frame_t *fr
         for (int j = 0; j < 6; j++) { sd += S[i][j] * U[i][j]; sp += S[i][j] * pA[i][j]; }
         d[i] = sd + kdh[i];
         u[i] = tau_exp[i] - sp;
-        int par = m->bodies[i].parent < 0 ? n : m->bodies[i].parent;
+        int par = m->bodies[i].parent < 0 ? n + (-1 - m->bodies[i].parent) : m->bodies[i].parent;
         real Ia[36], t6[6];
         for (int r = 0; r < 6; r++) for (int cc = 0; cc < 6; cc++) Ia[6 * r + cc] = IA[i][6 * r + cc] - U[i][r] * U[i][cc] / d[i];
         m6_vec(Ia, c[i], t6);
         for (int j = 0; j < 6; j++) pA[par][j] += pA[i][j] + t6[j] + U[i][j] * (u[i] / d[i]);
         for (int j = 0; j < 36; j++) IA[par][j] += Ia[j];
     }
-    for (int j = 0; j < 6; j++) abase[j] = 0;
-    if (si->floating) {
-        real A[36], b6[6];
-        memcpy(A, IA[n], sizeof A);
-        for (int j = 0; j < 6; j++) b6[j] = -pA[n][j];
-        solve6(A, b6);
-        memcpy(abase, b6, sizeof b6);
+    for (int r = 0; r < nb; r++) {   /* one 6x6 base system per tree */
+        for (int j = 0; j < 6; j++) abase[r][j] = 0;
+        if (si->floating) {
+            real A[36], b6[6];
+            memcpy(A, IA[n + r], sizeof A);
+            for (int j = 0; j < 6; j++) b6[j] = -pA[n + r][j];
+            solve6(A, b6);
+            memcpy(abase[r], b6, sizeof b6);
+        }
     }
     for (int i = 0; i < n; i++) {
         int par = m->bodies[i].parent;
         real ap[6], ua = 0;
-        for (int j = 0; j < 6; j++) ap[j] = (par < 0 ? abase[j] : a[par][j]) + c[i][j];
+        for (int j = 0; j < 6; j++) ap[j] = (par < 0 ? abase[-1 - par][j] : a[par][j]) + c[i][j];
         for (int j = 0; j < 6; j++) ua += U[i][j] * ap[j];
         qdd[i] = (u[i] - ua) / d[i];
         for (int j = 0; j < 6; j++) a[i][j] = ap[j] + S[i][j] * qdd[i];
@@ -815,8 +837,10 @@ static void scene_frames(const mppi_model_t *m, const scene_info_t *si, const re
     int n = m->n_bodies;
     kin_t k;
     kinematics(m, root, q, qd, &k);  /* poses only are taken from the body-frame kinematics */
-    root_frame(root + 13 * m->robot_actor, &fr[n]);
-    if (!si->floating) memset(fr[n].v, 0, sizeof fr[n].v);
+    for (int r = 0; r < si->nb; r++) {
+        root_frame(root + 13 * base_actor(m, r), &fr[n + r]);
+        if (!si->floating) memset(fr[n + r].v, 0, sizeof fr[n + r].v);
+    }
     for (int i = 0; i < n; i++) {
         const mppi_body_t *b = &m->bodies[i];
         memcpy(fr[i].R, k.Rw[i], sizeof fr[i].R);
@@ -825,10 +849,10 @@ static void scene_frames(const mppi_model_t *m, const scene_info_t *si, const re
         m3_vec(fr[i].R, ax, aw);
         if (b->jtype == MPPI_JOINT_REVOLUTE) { cross3(fr[i].p, aw, t); for (int j = 0; j < 3; j++) { Sw[j] = aw[j]; Sw[3 + j] = t[j]; } }
         else for (int j = 0; j < 3; j++) { Sw[j] = 0; Sw[3 + j] = aw[j]; }
-        const real *vp = b->parent < 0 ? fr[n].v : fr[b->parent].v;
+        const real *vp = b->parent < 0 ? fr[n + (-1 - b->parent)].v : fr[b->parent].v;
         for (int j = 0; j < 6; j++) fr[i].v[j] = vp[j] + Sw[j] * qd[i];
     }
-    for (int f = 0; f < si->n_free; f++) root_frame(root + 13 * si->free_actor[f], &fr[n + 1 + f]);
+    for (int f = 0; f < si->n_free; f++) root_frame(root + 13 * si->free_actor[f], &fr[n + si->nb + f]);
 }
 
 /* One simulator step of a contact scene; root [A][13] (robot base + free actors) is updated in place.
@@ -844,7 +868,7 @@ void orc_scene_step(const mppi_model_t *m, real *root, real *q, real *qd, const 
     for (int s = 0; s < m->substeps; s++) {
         scene_frames(m, &si, root, q, qd, fr);
         scene_contacts(m, &si, fr, root, cf);
-        real ff[NBMAX], vs[NBMAX], tau[NBMAX], kdh[NBMAX], qdd[NBMAX], abase[6];
+        real ff[NBMAX], vs[NBMAX], tau[NBMAX], kdh[NBMAX], qdd[NBMAX], abase[NBASEMAX][6];
         for (int i = 0; i < n; i++) {
             ff[i] = m->drive_mode == MPPI_DRIVE_EFFORT ? target[i] : (m->drive_mode == MPPI_DRIVE_POSITION ? kp * (target[i] - q[i]) : 0);
             vs[i] = m->drive_mode == MPPI_DRIVE_VELOCITY ? target[i] : 0;
@@ -870,11 +894,12 @@ void orc_scene_step(const mppi_model_t *m, real *root, real *q, real *qd, const 
             q[i] += h * qd[i];
             if (b->limited) joint_limit(qold, &q[i], &qd[i], (real)b->lower, (real)b->upper, h);
         }
-        if (si.floating) root_integrate(root + 13 * m->robot_actor, abase, h);
+        if (si.floating)
+            for (int r = 0; r < si.nb; r++) root_integrate(root + 13 * base_actor(m, r), abase[r], h);
         for (int f = 0; f < si.n_free; f++) {
             int a = si.free_actor[f];
             const mppi_actor_t *A = &m->actors[a];
-            const frame_t *F = &fr[n + 1 + f];
+            const frame_t *F = &fr[n + si.nb + f];
             double Io6[6] = {0, 0, 0, 0, 0, 0}, h0[3] = {0, 0, 0};
             if (A->type == MPPI_ACTOR_BOX) {
                 double x = A->size[0], y = A->size[1], z = A->size[2];

@@ -11,8 +11,9 @@ from mppiisaac.utils.isaacgym_utils import load_actor_cfgs, load_asset
 def build_scene(actors, init_positions=None, isaacgym="normal", overrides=None, robot_overrides=None):
     env_cfg = load_actor_cfgs(actors)
     robots = [a for a in env_cfg if a.type == "robot"]
-    for k, v in (robot_overrides or {}).items():
-        setattr(robots[0], k, v)
+    for k, v in (robot_overrides or {}).items():   # (every robot of the env: the multi-robot scenes repeat one robot type)
+        for r in robots:
+            setattr(r, k, v)
     if init_positions:
         for p, a in zip(init_positions, robots):
             a.init_pos = list(p)

@@ -479,3 +479,77 @@ def test_wheel_and_caster_pairs_left_out_of_the_contact_model_stay_clear(lib):
         assert closest[worst] > 0.01, (name, worst, closest[worst])
         checked += 1
     assert checked >= 1
+
+
+def test_two_moving_base_robots_in_one_env(lib, oracle64, tmp_path):
+    """several MOVING-base robots per env (reference conf/mppi/multi-jackal.yaml: two jackals, nu = 4, 100 samples, horizon 20;
+    isaacgym_wrapper.py:534-559): one floating base per tree of the forest (mppi_hip.h ABI 7), every robot its own (v, yaw rate)
+    pair of commands.  Through the planner facade with the reference's MPPI parameters and a cost program that sends each robot
+    to its own target: the one-lane scene kernels carry the forest - rollouts vs the fp64 oracle on every sample, the K = 1 world
+    in closed loop (both robots arrive), root rows of BOTH robots settable (they are states, not part of the compiled model)"""
+    import yaml
+    from mppiisaac.objectives import ProgramObjective, Term, actor
+    from mppiisaac.planner.isaacgym_wrapper import IsaacGymWrapper
+    from mppiisaac.planner.mppi import make_config
+    from mppiisaac.planner.mppi_isaac import MPPIisaacPlanner
+    from mppiisaac.utils.config_store import load_config
+    from mppiisaac.utils.transport import bytes_to_torch, torch_to_bytes
+    # (the shipped jackal.yaml names no wheel joints - the reference raises TypeError on it, isaacgym_wrapper.py:552-555)
+    wheels = {"left_wheel_joints": ["front_left_wheel", "rear_left_wheel"], "right_wheel_joints": ["front_right_wheel", "rear_right_wheel"]}
+    jackal = {"type": "robot", "differential_drive": True, "friction": 0.8, "mass": 40.0, "urdf_file": "jackal/jackal.urdf", "wheel_base": 0.4,
+              "wheel_count": 4, "wheel_radius": 0.14, **wheels}
+    first, second = tmp_path / "jackal1.yaml", tmp_path / "jackal2.yaml"
+    first.write_text(yaml.safe_dump({**jackal, "name": "jackal1"}))
+    second.write_text(yaml.safe_dump({**jackal, "name": "jackal2"}))
+    cfg = load_config({"defaults": [{"mppi": "multi-jackal"}, {"isaacgym": "normal"}], "actors": [str(first), str(second), "goal"],
+                       "initial_actor_positions": [[0.0, 0.0, 0.1], [0.5, -2.0, 0.1]], "nx": 8}, overrides={"mppi.filter_u": False})
+    K, H = cfg.mppi.num_samples, cfg.mppi.horizon
+    assert (K, H) == (100, 20)
+    T1, T2 = (2.0, 1.0, 0.0), (-1.0, -3.0, 0.0)
+
+    class TwoReach(ProgramObjective):
+        WEIGHTS = {"first": 1.0, "second": 1.0}
+
+        def terms(self):
+            return [Term("first", "dist", (actor("jackal1"), T1, 2)), Term("second", "dist", (actor("jackal2"), T2, 2))]
+    planner = MPPIisaacPlanner(cfg, TwoReach(cfg))
+    sim = planner.sim
+    m = sim._c_model
+    assert sim.scene.nu == 4 and sim.scene.n_dof == 8 and m.n_extra_bases == 1 and planner.mppi._fused_cost is not None
+    assert [m.bodies[i].parent for i in range(8)] == [-1] * 4 + [-2] * 4
+    info = C.create_string_buffer(512)
+    lib.mppi_kernel_info(sim._ctx, info, 512)
+    assert "rollout=scene " in info.value.decode() and "topology=[-1,-1,-1,-1,-2,-2,-2,-2]" in info.value.decode()
+    world = IsaacGymWrapper(cfg.isaacgym, actors=cfg.actors, init_positions=cfg.initial_actor_positions, num_envs=1)
+    assert world.num_robots == 2
+    for _ in range(20):   # both settle on their wheels
+        world.apply_robot_cmd(torch.zeros(1, 4, device=world.device))
+        world.step()
+    a = bytes_to_torch(planner.compute_action_tensor(torch_to_bytes(world._dof_state.cpu()), torch_to_bytes(world._root_state.cpu()))).numpy()
+    assert a.shape == (4,) and np.isfinite(a).all()
+    # rollouts vs the oracle, every sample (same cost program, the kernel's own noise)
+    S = planner.mppi.get_costs().numpy()
+    eps = np.zeros((H, 4, K), np.float32)
+    capi.check(lib, lib.mppi_get_noise(sim._ctx, capi.fptr(eps)))
+    dof, root = world._dof_state[0].cpu().numpy(), world._root_state[0].cpu().numpy()
+    spec = planner.objective.fused_spec(sim)
+    So, _, _ = oracle64.rollout(m, make_config(cfg.mppi, viz_link=sim.scene.viz_link_index()), spec, dof, root, np.zeros((H, 4)), eps)
+    rel = np.abs(S - So) / np.abs(So)
+    print(f"\ntwo jackals {K}x{H} vs fp64 oracle: within 1e-4 {np.mean(rel <= 1e-4):.3f} 1e-3 {np.mean(rel <= 1e-3):.3f} max {rel.max():.1e}")
+    assert np.mean(rel <= 1e-4) >= 0.97 and rel.max() <= 1e-2
+    d0 = (np.linalg.norm(root[0, :2] - T1[:2]), np.linalg.norm(root[1, :2] - T2[:2]))
+    for _ in range(220):
+        a = bytes_to_torch(planner.compute_action_tensor(torch_to_bytes(world._dof_state.cpu()), torch_to_bytes(world._root_state.cpu())))
+        world.apply_robot_cmd(a.to(world.device).reshape(1, -1))
+        world.step()
+    p = world._root_state[0, :2, 0:2].cpu().numpy()
+    d1 = (np.linalg.norm(p[0] - T1[:2]), np.linalg.norm(p[1] - T2[:2]))
+    print(f"distances to the targets {d0[0]:.2f}, {d0[1]:.2f} -> {d1[0]:.2f}, {d1[1]:.2f}")
+    assert d1[0] < 0.5 and d1[1] < 0.5, (d0, d1)
+    # rigid-body rows of the second robot follow its own base
+    b2 = world.get_actor_link_by_name("jackal2", "base_link")[0, 0:2].cpu().numpy()
+    np.testing.assert_allclose(b2, p[1], atol=1e-5)
+    world.set_actor_position_by_robot_index([4.0, 4.0, 0.1], 1)      # a moving base is state: it can be placed
+    assert np.allclose(world._root_state[0, 1, 0:2].cpu().numpy(), [4.0, 4.0])
+    planner.sim.stop_sim()
+    world.stop_sim()
