@@ -122,7 +122,7 @@ typedef struct mppi_pair {
 /* One moving body = one 1-DOF joint + the links welded to its child link.
  * Transform convention: x_parent = R * x_child + p (R row-major 3x3). */
 typedef struct mppi_body {
-    int32_t parent;      /* moving-body index, -1 = robot base                           */
+    int32_t parent;      /* moving-body index, -1 = robot base (-1 - r: base r of a forest, ABI 7) */
     int32_t jtype;       /* MPPI_JOINT_*                                                 */
     double axis[3];      /* unit joint axis in the body (child) frame                    */
     double R_tree[9];    /* joint frame in the parent body frame at q = 0                */
@@ -162,7 +162,8 @@ typedef struct mppi_actor {
     double noise_percentage_friction; /* friction += U(-p, p) * friction                 */
 } mppi_actor_t;
 
-/* Scene of one env: one articulated robot + simple actors, in env_cfg (= root_state) order. */
+/* Scene of one env: one articulated robot - or a forest of robots, fixed-base (merged into one tree set hanging off the world)
+ * or moving-base (one floating base per tree, ABI 7 fields at the end) - + simple actors, in env_cfg (= root_state) order. */
 typedef struct mppi_model {
     int32_t abi_version;
     int32_t n_actors;

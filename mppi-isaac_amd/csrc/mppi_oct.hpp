@@ -307,6 +307,8 @@ __device__ __forceinline__ void obody_root_fused(const OctBodyIn &b, const OctLa
     }
 }
 // ---- outward pass of one joint: qdd = k + W . a_parent,  a = a_parent + c + qdd S --------------------------------------------------------
+// (left to the compiler - the same nine operations in C++, DPP moves folded into the adds by its combiner - the substep loop grows
+// from 1003 to 1012 instructions with 29 instead of 25 s_nop: it does not fill the wait slots with the integration's work either)
 __device__ __forceinline__ void ooutward_fused(OF W, OF ap, OF cb, OF S, OF k, OF &dd, OF &a) {
     OF t;
     asm("v_mul_f32 %[t], %[W], %[ap]\n\t"                             //  1 t   = W ap
@@ -321,14 +323,35 @@ __device__ __forceinline__ void ooutward_fused(OF W, OF ap, OF cb, OF S, OF k, O
         : [dd] "=&v"(dd), [a] "=&v"(a), [t] "=&v"(t)
         : [W] "v"(W), [ap] "v"(ap), [cb] "v"(cb), [S] "v"(S), [k] "v"(k));
 }
+// ... with the block's three wait slots FILLED with the drive-limit test of the PREVIOUS joint (quad_step: torque of the implicit
+// drive tt = tau - kdh qdd, running maximum of |tt| - effort): three independent instructions that otherwise follow the pass as
+// code of their own, here in the slots the DPP hazards leave empty - the same operations, the same results
+__device__ __forceinline__ void ooutward_fused_check(OF W, OF ap, OF cb, OF S, OF k, OF &dd, OF &a, OF tau_p, OF kdh_p, OF dd_p, OF eff_p, OF &tt_p,
+                                                     OF &excess) {
+    OF t, e;
+    asm("v_mul_f32 %[t], %[W], %[ap]\n\t"                             //  1 t   = W ap
+        "v_add_f32 %[a], %[ap], %[cb]\n\t"                            //  2 a   = ap + c
+        "v_fma_f32 %[ttp], -%[kdhp], %[ddp], %[taup]\n\t"             //  3 tt' = tau' - kdh' qdd'        (previous joint)
+        "v_add_f32_dpp %[t], %[t], %[t] " MPPI_SW "\n\t"              //  4 t  += swap(t)          (t written at 1)
+        "v_sub_f32 %[e], |%[ttp]|, %[effp]\n\t"                       //  5 e   = |tt'| - effort'
+        "v_max_f32 %[ex], %[ex], %[e]\n\t"                            //  6 excess = max(excess, e)
+        "v_add_f32_dpp %[dd], %[t], %[k] " MPPI_B(0) "\n\t"           //  7 dd  = t[0] + k         (t written at 4: two slots)
+        "v_add_f32_dpp %[dd], %[t], %[dd] " MPPI_B(1) "\n\t"          //  8 dd += t[1]
+        "v_add_f32_dpp %[dd], %[t], %[dd] " MPPI_B(2) "\n\t"          //  9 dd += t[2]
+        "v_fmac_f32 %[a], %[dd], %[S]"                                // 10 a  += dd S
+        : [dd] "=&v"(dd), [a] "=&v"(a), [t] "=&v"(t), [e] "=&v"(e), [ttp] "=&v"(tt_p), [ex] "+v"(excess)
+        : [W] "v"(W), [ap] "v"(ap), [cb] "v"(cb), [S] "v"(S), [k] "v"(k), [taup] "v"(tau_p), [kdhp] "v"(kdh_p), [ddp] "v"(dd_p), [effp] "v"(eff_p));
+}
 
 // Articulated-body solve, octet-parallel: same interface and arithmetic as quad_aba (mppi_quad.hpp) up to the association of
 // the sums.  `bodies`: this LANE's view of the model's body blocks - the angular lanes read the model's own, the linear lanes a
 // copy whose inertia tensors and 1/m are zero (oct_lin_view), so that the rigid-inertia rows come out as I in one half and
 // zero in the other without a select.  tau / kdh / qd / qdd: replicated scalars (same in all eight lanes of a sample).
-template <class T, class BP, class M, int JT>
+// CHECK: the drive-limit test of quad_step rides in the wait slots of the outward pass (ooutward_fused_check): tt[i] = tau_exp[i] -
+// kdh[i] qdd[i] and excess = max_i(|tt[i]| - effort_i) come back with the accelerations
+template <class T, bool CHECK = false, class BP, class M, int JT>
 __device__ __forceinline__ void oct_aba(M &m, BP bodies, const OctLane &ol, const QPose<T, JT> &P, const OF *qd, const OF *tau_exp, const OF *kdh, OF *qdd,
-                                        JointLimits *lim) {
+                                        JointLimits *lim, OF *tt = nullptr, OF *excess_out = nullptr) {
     constexpr int NB = T::NB;
     OF v[NB], w[NB], S[NB], cb[NB], W[NB], kk[NB], pacc[NB];
     OAI acc[NB];
@@ -399,12 +422,20 @@ __device__ __forceinline__ void oct_aba(M &m, BP bodies, const OctLane &ol, cons
     OF a[NB];
     OF a0 = zero;
     if (m.gravity_on) a0 = ol.lin * qsel(-m.g[0], -m.g[1], -m.g[2]);
+    OF excess = -INFINITY;
     static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
         constexpr int i = ic;
         constexpr int par = T::par[i];
         const OF apar = par >= 0 ? a[par < 0 ? 0 : par] : a0;
-        ooutward_fused(W[i], apar, cb[i], S[i], kk[i], qdd[i], a[i]);
+        if constexpr (CHECK && i > 0)
+            ooutward_fused_check(W[i], apar, cb[i], S[i], kk[i], qdd[i], a[i], tau_exp[i - 1], kdh[i - 1], qdd[i - 1], OF(lim[i - 1].effort), tt[i - 1], excess);
+        else
+            ooutward_fused(W[i], apar, cb[i], S[i], kk[i], qdd[i], a[i]);
     });
+    if constexpr (CHECK) {  // (the last joint's test has no block behind it)
+        tt[NB - 1] = tau_exp[NB - 1] - kdh[NB - 1] * qdd[NB - 1];
+        *excess_out = qmax(excess, qabs(tt[NB - 1]) - OF(lim[NB - 1].effort));
+    }
 }
 
 // this lane's view of the body blocks (angular lanes: the model's own, linear lanes: the copy staged with oct_lin_view).  The
@@ -429,9 +460,16 @@ __device__ __forceinline__ MPPI_LDS_AS DevBody *oct_lin_place(MPPI_LDS_AS void *
 struct OctAba {
     OctBodies bodies;
     OctLane ol;
+    static constexpr bool kFusedLimitCheck = true;
     template <class T, class M, int JT>
     __device__ __forceinline__ void aba(M &m, const QPose<T, JT> &P, const QF *qd, const QF *tau_exp, const QF *kdh, QF *qdd, JointLimits *lim) const {
         oct_aba<T>(m, bodies, ol, P, qd, tau_exp, kdh, qdd, lim);
+    }
+    // ... and the drive-limit test of quad_step with it: tt[i] = tau_exp[i] - kdh[i] qdd[i], excess = max_i(|tt[i]| - effort_i)
+    template <class T, class M, int JT>
+    __device__ __forceinline__ void aba_checked(M &m, const QPose<T, JT> &P, const QF *qd, const QF *tau_exp, const QF *kdh, QF *qdd, JointLimits *lim,
+                                                QF *tt, QF &excess) const {
+        oct_aba<T, true>(m, bodies, ol, P, qd, tau_exp, kdh, qdd, lim, tt, &excess);
     }
 };
 

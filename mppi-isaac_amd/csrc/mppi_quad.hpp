@@ -670,6 +670,7 @@ MPPI_HD void quad_aba(M &m, const QPose<T, JT> &P, const QF *qd, const QF *tau_e
 // How a step solves the articulated body: the quad layout's solve above, or the octet layout's (mppi_oct.hpp OctAba: one
 // sample per two quads) - the step / rollout code around the solve is the same for both.
 struct QuadAba {
+    static constexpr bool kFusedLimitCheck = false;
     template <class T, class M, int JT>
     MPPI_HD void aba(M &m, const QPose<T, JT> &P, const QF *qd, const QF *tau_exp, const QF *kdh, QF *qdd, JointLimits *lim) const {
         quad_aba<T>(m, P, qd, tau_exp, kdh, qdd, lim);
@@ -728,17 +729,21 @@ MPPI_HD void quad_step(M &m0, QPose<T, JT> &P, QF *q, QF *qd, const QF *target, 
         }
         const QF kdhq = qrep(kd * h);
         static_for<0, NB>([&](auto ic) MPPI_LAMBDA { kdh[ic] = kdhq; });
-        ab.template aba<T>(m, P, qd, tau, kdh, qdd, lim);
         // URDF effort limits: a drive whose torque tau - kd h qdd leaves [-effort, effort] is held at the bound and the step is
         // solved again without its damping.  The test is one running maximum of |torque| - effort over the joints and one
         // branch (no limit: effort = +inf, the excess is -inf); the selects live inside the rare branch.
         QF tt[NB];
         QF excess = qrep(-INFINITY);
-        static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
-            constexpr int i = ic;
-            tt[i] = tau[i] - kdhq * qdd[i];
-            excess = qmax(excess, qabs(tt[i]) - qrep(lim[i].effort));
-        });
+        if constexpr (AB::kFusedLimitCheck) {   // (octet layout: the test rides in the wait slots of the solve's outward pass)
+            ab.template aba_checked<T>(m, P, qd, tau, kdh, qdd, lim, tt, excess);
+        } else {
+            ab.template aba<T>(m, P, qd, tau, kdh, qdd, lim);
+            static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
+                constexpr int i = ic;
+                tt[i] = tau[i] - kdhq * qdd[i];
+                excess = qmax(excess, qabs(tt[i]) - qrep(lim[i].effort));
+            });
+        }
         if (qany_gt(excess, qrep(0.f))) {
             static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
                 constexpr int i = ic;

@@ -264,13 +264,83 @@ def test_two_fixed_base_robots_form_one_forest(oracle64, tmp_path):
         rbk, _ = oracle64.rigid_body_state(s[1], s[2], s[3], s[4])
         np.testing.assert_allclose(rb[k * n1:(k + 1) * n1], rbk[:n1], atol=1e-12)
     np.testing.assert_allclose(rb[2 * n1], root[2])                            # the goal's row follows the two robots
-    # refused: a moving base among several robots; robot actors that are not listed next to each other
+    # refused: a moving base next to a fixed one; robot actors that are not listed next to each other
     boxer = load_actor_cfgs(["boxer", "point_robot", "goal"])
-    with pytest.raises(NotImplementedError, match="moving base"):
+    with pytest.raises(NotImplementedError, match="either all fixed or all moving"):
         Scene(boxer, ig, [load_asset(boxer[0]), load_asset(boxer[1])])
     apart = load_actor_cfgs(["point_robot", "goal", str(second)])
     with pytest.raises(NotImplementedError, match="next to each other"):
         Scene(apart, ig, [load_asset(apart[0]), load_asset(apart[2])])
+
+
+JACKAL = {"type": "robot", "differential_drive": True, "friction": 0.8, "mass": 40.0, "urdf_file": "jackal/jackal.urdf", "wheel_base": 0.4,
+          "wheel_count": 4, "wheel_radius": 0.14, "left_wheel_joints": ["front_left_wheel", "rear_left_wheel"],
+          "right_wheel_joints": ["front_right_wheel", "rear_right_wheel"]}
+
+
+def test_two_moving_base_robots_form_a_forest_with_a_base_per_tree(oracle64, hostemu, tmp_path):
+    """several MOVING-base robots per env (reference conf/mppi/multi-jackal.yaml; mppi_hip.h ABI 7): the forest carries one
+    floating base per tree - a root body's parent and a base link's body index -1 - r name base r -, every robot takes its own
+    (v, yaw rate) pair of commands, and on the oracle both robots move bit for bit like each robot on its own; the device
+    arithmetic of the one-lane scene kernels (host build) follows the oracle step by step"""
+    import ctypes as C
+    import yaml
+    from mppiisaac.planner.isaacgym_wrapper import Scene
+    from mppiisaac.utils.config_store import load_config
+    from mppiisaac.utils.isaacgym_utils import load_actor_cfgs, load_asset
+    paths = []
+    for k in (1, 2):
+        p = tmp_path / f"jackal{k}.yaml"
+        p.write_text(yaml.safe_dump({**JACKAL, "name": f"jackal{k}"}))
+        paths.append(str(p))
+    ig = load_config({"defaults": [{"isaacgym": "normal"}]}).isaacgym
+    env = load_actor_cfgs(paths + ["goal"])
+    env[0].init_pos, env[1].init_pos = [0.0, 0.0, 0.1], [3.0, 1.0, 0.1]
+    scene = Scene(env, ig, [load_asset(env[0]), load_asset(env[1])])
+    m = scene.to_c()
+    assert scene.n_dof == 8 and scene.nu == 4 and [b["parent"] for b in scene.robot_model["bodies"]] == [-1] * 4 + [-2] * 4
+    assert m.n_extra_bases == 1 and m.extra_base_actor[0] == 1 and m.extra_base_mass[0] == pytest.approx(m.base_mass)
+    assert [(t[0][0], t[1][0]) for t in scene.cmd_terms] == [(0, 1)] * 4 + [(2, 3)] * 4        # (v, yaw rate) per robot
+    # 2 x 14 URDF links exceed MPPI_MAX_LINKS: the links nobody can observe are not reported (as for the ANYmal)
+    assert scene.n_rb == 13 and scene.rigid_body_index("jackal2", "base_link") == 6
+    assert {l["body"] for l, o in zip(scene.robot_model["links"], scene.link_owner) if o == 1} == {-2, 4, 5, 6, 7}
+    dof, root = scene.initial_state()
+    q, qd, ro = dof[0::2].astype(float), dof[1::2].astype(float), root.astype(float)
+    singles = []
+    for k in (0, 1):
+        e = load_actor_cfgs([paths[k], "goal"])
+        e[0].init_pos = list(env[k].init_pos)
+        s = Scene(e, ig, load_asset(e[0]))
+        d, r = s.initial_state()
+        singles.append([s.to_c(), r.astype(float), d[0::2].astype(float), d[1::2].astype(float)])
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    rb, cf = np.zeros((m.n_rb, 13), np.float32), np.zeros((m.n_rb, 3), np.float32)
+    hostemu.emu_set_scene_split(1)
+    for t in range(50):
+        u = np.array([0.5, 0.3, -0.3, -0.5]) if t >= 20 else np.zeros(4)
+        de = np.zeros(16, np.float32)
+        de[0::2], de[1::2] = q, qd
+        re = f32(ro).copy()
+        assert hostemu.emu_scene_step(C.byref(m), fp(de), fp(re.reshape(-1)), fp(f32(u)), fp(rb), fp(cf)) == 0
+        ro, q, qd, _ = oracle64.scene_step(m, ro, q, qd, oracle64.cmd_map(m, u))
+        for k, s in enumerate(singles):
+            s[1], s[2], s[3], _ = oracle64.scene_step(s[0], s[1], s[2], s[3], oracle64.cmd_map(s[0], u[2 * k:2 * k + 2]))
+        np.testing.assert_allclose(re[:, 0:7], ro[:, 0:7], atol=5e-5)                         # device arithmetic vs oracle
+        np.testing.assert_allclose(re[:, 7:13], ro[:, 7:13], atol=5e-3)
+        np.testing.assert_allclose(de[0::2], q, atol=5e-5)
+        np.testing.assert_allclose(rb[[0, 6], 0:3], ro[0:2, 0:3], atol=5e-5)                  # base links follow their own base
+    for k, s in enumerate(singles):                                                          # each robot exactly as on its own
+        np.testing.assert_array_equal(ro[k], s[1][0])
+        np.testing.assert_array_equal(q[4 * k:4 * k + 4], s[2])
+    assert np.linalg.norm(ro[0, 0:2]) > 0.3 and np.linalg.norm(ro[1, 0:2] - [3.0, 1.0]) > 0.15    # and they drive
+    # the library side refuses what the forest cannot be: a base that names a fixed or a non-robot actor
+    m.extra_base_actor[0] = 2
+    assert hostemu.emu_scene_step(C.byref(m), fp(de), fp(re.reshape(-1)), fp(f32(u)), fp(rb), fp(cf)) != 0
+    # refused on the host: more moving bases than the ABI carries
+    many = load_actor_cfgs([paths[0]] * 5 + ["goal"])
+    with pytest.raises(ValueError, match="moving bases"):
+        Scene(many, ig, [load_asset(a) for a in many[:5]])
 
 
 def test_pruned_link_list_keeps_what_can_be_observed():
