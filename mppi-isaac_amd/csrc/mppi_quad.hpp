@@ -873,6 +873,11 @@ MPPI_HD QF quad_stage_cost(int kind, LStep &sc, const QF *q, const QM3 &R, QF p)
     return qrep(0.f);
 }
 
+// element `byte_off / 4` of a sample-minor buffer: uniform base pointer + 32-bit BYTE offset = the scalar-base form of the global
+// load / store (`global_load_dword v, v_off, s[base]`: one add for the offset) instead of a 64-bit address per element (an add and
+// a 64-bit shift-add); mppi_pack.hpp keeps H nu K below 2^30 elements
+MPPI_HD float ld32(const float *base, unsigned byte_off) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off); }
+MPPI_HD void st32(float *base, unsigned byte_off, float v) { *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + byte_off) = v; }
 // control rows of step t: the nominal row from the staged copy, this sample's noise from HBM (requested one step ahead)
 template <int MAXC>
 MPPI_HD void load_controls_q(LStep &sc, const float *eps, const float *prior, int nu, int K, int t, int k, ControlRows<MAXC> &r) {
@@ -881,7 +886,7 @@ MPPI_HD void load_controls_q(LStep &sc, const float *eps, const float *prior, in
     for (int c = 0; c < MAXC; c++) {
         const int cc = c < nu ? c : nu - 1;
         r.Ut[c] = ur.v[c];
-        r.e[c] = eps[(unsigned)(t * nu + cc) * (unsigned)K + (unsigned)k];
+        r.e[c] = ld32(eps, ((unsigned)(t * nu + cc) * (unsigned)K + (unsigned)k) * 4u);
         r.pr[c] = 0.f;
     }
     if (prior != nullptr) {  // ONE uniform branch for the whole row (rare: use_priors)
@@ -912,7 +917,7 @@ MPPI_HD float apply_controls_q(LStep &sc, float lambda, bool abs_cost, int nu, i
         const bool on = PLAIN || c < nu;
         u[c] = on ? v : 0.f;
         const float d = v - r.Ut[c];
-        if (on) du[(unsigned)(t * nu + c) * (unsigned)K + (unsigned)k] = d;
+        if (on) st32(du, ((unsigned)(t * nu + c) * (unsigned)K + (unsigned)k) * 4u, d);
         const float term = r.Ut[c] * d * is.v[c];  // inv_sigma is zero beyond nu
         ctrl += lambda * ((!PLAIN && abs_cost) ? fabsf(term) : term);
     }
