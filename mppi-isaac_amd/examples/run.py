@@ -47,6 +47,10 @@ EXAMPLES = {
     # from it there); the runner supplies one - joint velocity noise of 1 (rad/s)^2 on the twelve leg joints
     "anymal": dict(mppi="anymal", isaacgym="push", actors=["anymal", "goal"], init=[[0.0, 2.0, 1.2]], nx=24, objective="AnymalWalkObjective",
                    goal=[2.0, 2.0, 0.5], overrides={"noise_sigma": [[1.0 if i == j else 0.0 for j in range(12)] for i in range(12)]}),
+    # reference conf/mppi/multi-jackal.yaml (two jackals, nu = 4; no example script of the reference uses it): every robot drives to
+    # its own target.  conf/actors/jackal_a.yaml / jackal_b.yaml are named copies of jackal.yaml with the wheel joints filled in
+    "multi_jackal": dict(mppi="multi-jackal", isaacgym="normal", actors=["jackal_a", "jackal_b", "goal"], init=[[0.0, 0.0, 0.1], [0.5, -2.0, 0.1]], nx=8,
+                         objective="MultiJackalObjective", goal=[2.0, 1.0, 0.1]),
 }
 
 

@@ -445,3 +445,18 @@ class AnymalWalkObjective(ProgramObjective):
         out = [Term("robot_to_goal", "dist", (link(self.robot, "base"), actor(self.goal), 3))]
         out += [Term("robot_off_ground", "abs_dz", (link(self.robot, n), self.TRUNK_HEIGHT)) for n in self.TRUNK_LINKS]
         return out + [Term("knees_off_ground", "abs_dz", (link(self.robot, n), self.KNEE_HEIGHT)) for n in self.KNEE_LINKS]
+
+
+class MultiJackalObjective(ProgramObjective):
+    """several moving-base robots in one env (reference conf/mppi/multi-jackal.yaml; no planner of the reference uses it): every
+    robot drives to its own target - the first to the goal actor, the others to fixed points"""
+    WEIGHTS = {"robot_to_goal": 1.0}
+
+    def __init__(self, cfg=None, robots=("jackal_a", "jackal_b"), goal="goal", targets=((-1.0, -3.0, 0.0),)):
+        self.robots, self.goal, self.targets = tuple(robots), goal, tuple(targets)
+        super().__init__(cfg)
+
+    def terms(self):
+        out = [Term("robot_to_goal", "dist", (actor(self.robots[0]), actor(self.goal), 2))]
+        return out + [Term("robot_to_goal", "dist", (actor(r), t, 2)) for r, t in zip(self.robots[1:], self.targets)]
+

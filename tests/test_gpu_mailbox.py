@@ -94,8 +94,8 @@ def test_mailbox_exchange_equals_single_context(make, name, K, H, G, lib):
             late = C.c_int(-1)
             s.call("mppi_exchange_status", C.byref(late))
             assert late.value == 0
-            np.testing.assert_allclose(s.get("mppi_get_action", (nu,)), a_full, atol=3e-6)
-            np.testing.assert_allclose(s.get("mppi_get_nominal", (H, nu)), U_full, atol=3e-6)
+            np.testing.assert_allclose(s.get("mppi_get_action", (nu,)), a_full, rtol=3e-6, atol=3e-6)   # (fp32 sums of the shard records in another order: measured 1.4e-6 relative on an action of 3.03)
+            np.testing.assert_allclose(s.get("mppi_get_nominal", (H, nu)), U_full, rtol=3e-6, atol=3e-6)
         # all ranks hold the same gathered records, bit for bit
         torch.cuda.synchronize()
         ref = dev_to_host(gathered[0][0], gathered[0][1] * RF)
@@ -181,7 +181,7 @@ def test_exchange_fused_into_the_closed_loop_tail_equals_single_context(G, lib):
             late = C.c_int(-1)
             s.call("mppi_exchange_status", C.byref(late))
             assert late.value == 0
-            np.testing.assert_allclose(a, a_full, atol=3e-6)
+            np.testing.assert_allclose(a, a_full, rtol=3e-6, atol=3e-6)
         assert np.abs(a_full).max() > 0
     info = C.create_string_buffer(256)
     shards[0].call("mppi_kernel_info", info, 256)
@@ -317,7 +317,7 @@ def test_mailbox_sized_for_folded_records_serves_generic_mode(lib):
         late = C.c_int(-1)
         s_.call("mppi_exchange_status", C.byref(late))
         assert late.value == 0
-        np.testing.assert_allclose(s_.get("mppi_get_action", (nu,)), a_full, atol=3e-6)
-        np.testing.assert_allclose(s_.get("mppi_get_nominal", (H, nu)), U_full, atol=3e-6)
+        np.testing.assert_allclose(s_.get("mppi_get_action", (nu,)), a_full, rtol=3e-6, atol=3e-6)
+        np.testing.assert_allclose(s_.get("mppi_get_nominal", (H, nu)), U_full, rtol=3e-6, atol=3e-6)
     for c in shards + [full]:
         c.close()
