@@ -112,8 +112,8 @@ def make_config(cfg: MPPIConfig, *, k_offset: int = 0, k_local: Optional[int] = 
         raise NotImplementedError("update_lambda=True is not supported (False in every shipped conf/mppi file)")
     if cfg.mppi_mode not in ("halton-spline", "simple") or cfg.sampling_method not in ("halton", "random"):
         raise ValueError(f"unknown mppi_mode / sampling_method: {cfg.mppi_mode!r} / {cfg.sampling_method!r}")
-    if cfg.u_per_command != 1:
-        raise NotImplementedError("u_per_command != 1 is not supported")
+    if not 1 <= int(cfg.u_per_command) <= int(cfg.horizon):
+        raise ValueError("u_per_command must lie in [1, horizon]")
     if cfg.noise_sigma is None:
         raise ValueError("noise_sigma is required: its size defines the control dimension")
     sigma = np.atleast_2d(np.asarray(cfg.noise_sigma, dtype=np.float64))
@@ -328,7 +328,13 @@ class MPPIPlanner:
             capi.check(lib, lib.mppi_exchange_status(ctx, C.byref(late)))
             if late.value:
                 raise RuntimeError("mailbox exchange: a rank did not publish its shard records in time (the update ran without them)")
-        return torch.from_numpy(self._action.copy()).unsqueeze(0) if self.cfg.u_per_command > 1 else torch.from_numpy(self._action.copy())
+        n = int(self.cfg.u_per_command)
+        if n > 1:
+            # mppi_torch: `action = U[:u_per_command]` of the updated (and, with filter_u, smoothed) nominal, which is then shifted by
+            # ONE step as always [RECALLED: pytorch_mppi's command(); SURVEY.md A].  Row 0 is the action the update kernel publishes,
+            # rows 1 .. n-1 are the first rows of the shifted nominal: [n, nu]
+            return torch.cat((torch.from_numpy(self._action.copy()).unsqueeze(0), self.U[: n - 1]), dim=0)
+        return torch.from_numpy(self._action.copy())
 
     def _mailbox(self):
         """(gathered records pointer, count) of this rank's mailbox; created and connected on first use - after the cost is set,

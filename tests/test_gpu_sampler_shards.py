@@ -553,3 +553,28 @@ def test_two_moving_base_robots_in_one_env(lib, oracle64, tmp_path):
     assert np.allclose(world._root_state[0, 1, 0:2].cpu().numpy(), [4.0, 4.0])
     planner.sim.stop_sim()
     world.stop_sim()
+
+
+def test_u_per_command_returns_the_first_rows_of_the_updated_nominal(lib):
+    """mppi_torch's `u_per_command` (reference benchmarks/point_robot/setup/mppi.yaml:5-37 lists it; 1 in every shipped conf):
+    command() returns the first n rows of the updated nominal - row 0 is the action of u_per_command = 1, the nominal is shifted
+    by ONE step as always - as [n, nu]; the same noise set gives the same first row either way, with and without filter_u"""
+    from mppiisaac.objectives import PandaReachObjective
+    from mppiisaac.planner.mppi_isaac import MPPIisaacPlanner
+    q = [0.0, -0.94, 0.0, -2.8, 0.0, 1.8675, 0.0]
+    for filt in (False, True):
+        out = {}
+        for n in (1, 3):
+            cfg = _panda_cfg(u_per_command=n, filter_u=filt)
+            pl = MPPIisaacPlanner(cfg, PandaReachObjective(cfg))
+            pl.sim.set_actor_position_by_name([0.5, -0.4, 0.3], "goal")
+            a = pl.compute_action(q, [0.0] * 7)
+            out[n] = (a.numpy(), pl.mppi.U.numpy())
+            pl.sim.stop_sim()
+        a1, U1 = out[1]
+        a3, U3 = out[3]
+        assert a1.shape == (7,) and a3.shape == (3, 7)
+        np.testing.assert_array_equal(a3[0], a1)
+        np.testing.assert_array_equal(a3[1:], U3[:2])          # rows 1, 2 of the updated nominal = rows 0, 1 of the shifted one
+        np.testing.assert_array_equal(U1, U3)                  # shifted by one step either way
+        assert np.abs(a3[1:]).max() > 0
