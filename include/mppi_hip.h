@@ -361,6 +361,10 @@ int mppi_note_graph_update(mppi_ctx_t *ctx, int n);
 int mppi_command(mppi_ctx_t *ctx, float *action_host);        /* rollout+reduce+update+get_action     */
 int mppi_get_costs(mppi_ctx_t *ctx, float *S_host);           /* [K] total trajectory costs           */
 int mppi_get_weights_stats(mppi_ctx_t *ctx, float *beta_eta_host); /* [2]                             */
+/* mppi_torch's `update_lambda` (MPPIConfig.update_lambda / eta_u_bound / eta_l_bound; False in every shipped conf): the caller
+ * reads eta with mppi_get_weights_stats after an update and sets the temperature of the NEXT iteration (stream-ordered; takes
+ * effect for the next rollout's control cost and the next update's weights).  lambda > 0. */
+int mppi_set_lambda(mppi_ctx_t *ctx, double lambda);
 int mppi_get_rollouts(mppi_ctx_t *ctx, float *viz_host);      /* [H][K][3], get_rollouts mppi_isaac.py:118-124 */
 int mppi_get_perturbations(mppi_ctx_t *ctx, float *du_host);  /* [H][nu][K] effective perturbations   */
 int mppi_get_noise(mppi_ctx_t *ctx, float *eps_host);         /* [H][nu][K]                           */

@@ -427,6 +427,17 @@ int mppi_set_filter(mppi_ctx_t *c, const float *F) {
     }
     return MPPI_OK;
 }
+int mppi_set_lambda(mppi_ctx_t *c, double lambda) {
+    CTX_TRY(c);
+    if (!(lambda > 0) || !std::isfinite(lambda)) return fail(MPPI_EINVAL, "mppi_set_lambda: lambda must be positive and finite");
+    c->cfg.lambda_ = lambda;
+    c->hc.lambda = (float)lambda;
+    c->hc.inv_lambda = (float)(1.0 / lambda);
+    // (stream-ordered: the kernels of the iteration in flight keep the value they were launched with)
+    HIP_TRY(hipMemcpyAsync(c->d_cfg, &c->hc, sizeof(DevCfg), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MPPI_OK;
+}
 int mppi_get_nominal(mppi_ctx_t *c, float *U) {
     CTX_TRY(c);
     HIP_TRY(hipMemcpyAsync(U, c->d_U, sizeof(float) * c->HN, hipMemcpyDeviceToHost, c->stream));

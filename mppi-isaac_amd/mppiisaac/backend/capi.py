@@ -101,6 +101,7 @@ _SIGNATURES = {
     "mppi_set_state_dev": (C.c_int, [_vp, _vp, _vp]),
     "mppi_get_state": (C.c_int, [_vp, _fp, _fp]),
     "mppi_set_cost": (C.c_int, [_vp, C.POINTER(Cost)]),
+    "mppi_set_lambda": (C.c_int, [_vp, C.c_double]),
     "mppi_sample": (C.c_int, [_vp, C.c_uint32]),
     "mppi_sample_normal": (C.c_int, [_vp, C.c_uint32]),
     "mppi_set_noise_dev": (C.c_int, [_vp, _vp]),

@@ -106,10 +106,8 @@ def make_config(cfg: MPPIConfig, *, k_offset: int = 0, k_local: Optional[int] = 
     """MPPIConfig -> C-ABI mppi_config_t for the shard [k_offset, k_offset + k_local)."""
     if cfg.update_cov:
         raise NotImplementedError("update_cov=True is not supported (False in every shipped conf/mppi file)")
-    if cfg.update_lambda:
-        # mppi_torch's adaptation factors are not visible from the reference tree (SURVEY.md A) and every shipped
-        # conf/mppi file sets it False: refuse instead of silently ignoring it
-        raise NotImplementedError("update_lambda=True is not supported (False in every shipped conf/mppi file)")
+    if cfg.update_lambda and not (cfg.eta_u_bound > cfg.eta_l_bound > 0):
+        raise ValueError("update_lambda needs eta_u_bound > eta_l_bound > 0")
     if cfg.mppi_mode not in ("halton-spline", "simple") or cfg.sampling_method not in ("halton", "random"):
         raise ValueError(f"unknown mppi_mode / sampling_method: {cfg.mppi_mode!r} / {cfg.sampling_method!r}")
     if not 1 <= int(cfg.u_per_command) <= int(cfg.horizon):
@@ -328,6 +326,8 @@ class MPPIPlanner:
             capi.check(lib, lib.mppi_exchange_status(ctx, C.byref(late)))
             if late.value:
                 raise RuntimeError("mailbox exchange: a rank did not publish its shard records in time (the update ran without them)")
+        if self.cfg.update_lambda:
+            self._adapt_lambda()
         n = int(self.cfg.u_per_command)
         if n > 1:
             # mppi_torch: `action = U[:u_per_command]` of the updated (and, with filter_u, smoothed) nominal, which is then shifted by
@@ -335,6 +335,25 @@ class MPPIPlanner:
             # rows 1 .. n-1 are the first rows of the shifted nominal: [n, nu]
             return torch.cat((torch.from_numpy(self._action.copy()).unsqueeze(0), self.U[: n - 1]), dim=0)
         return torch.from_numpy(self._action.copy())
+
+    # mppi_torch's `update_lambda` (False in every shipped conf; its code is not in the reference tree).  Restated from the MPPI
+    # it derives from (STORM's mppi: beta_lm = 0.9, beta_um = 1.2) [RECALLED - unpinned, SURVEY.md A]: the normaliser eta = sum of
+    # the weights measures how many samples carry weight; above eta_u_bound the temperature is too soft -> lambda *= 0.9, below
+    # eta_l_bound too greedy -> lambda *= 1.2.  Every rank sees the same eta after the combine, so shards stay in step.
+    LAMBDA_DOWN, LAMBDA_UP = 0.9, 1.2
+
+    def _adapt_lambda(self):
+        stats = np.zeros(2, np.float32)
+        capi.check(self._lib, self._lib.mppi_get_weights_stats(self._ctx, capi.fptr(stats)))
+        eta = float(stats[1])
+        lam = self.lambda_
+        if eta > self.cfg.eta_u_bound:
+            lam *= self.LAMBDA_DOWN
+        elif eta < self.cfg.eta_l_bound:
+            lam *= self.LAMBDA_UP
+        if lam != self.lambda_:
+            self.lambda_ = lam
+            capi.check(self._lib, self._lib.mppi_set_lambda(self._ctx, C.c_double(lam)))
 
     def _mailbox(self):
         """(gathered records pointer, count) of this rank's mailbox; created and connected on first use - after the cost is set,

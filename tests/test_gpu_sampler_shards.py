@@ -578,3 +578,32 @@ def test_u_per_command_returns_the_first_rows_of_the_updated_nominal(lib):
         np.testing.assert_array_equal(a3[1:], U3[:2])          # rows 1, 2 of the updated nominal = rows 0, 1 of the shifted one
         np.testing.assert_array_equal(U1, U3)                  # shifted by one step either way
         assert np.abs(a3[1:]).max() > 0
+
+
+def test_update_lambda_adapts_the_temperature_between_commands(lib):
+    """mppi_torch's `update_lambda` (eta_u_bound / eta_l_bound; False in every shipped conf, factors restated from STORM's MPPI,
+    unpinned): after a command whose weight normaliser eta lies above eta_u_bound the temperature shrinks by 0.9, below eta_l_bound
+    it grows by 1.2, inside the band it stays - and the NEXT command's weights (eta, checked against the costs on the host) and
+    control cost are computed with the new lambda (mppi_set_lambda)"""
+    from mppiisaac.objectives import PandaReachObjective
+    from mppiisaac.planner.mppi_isaac import MPPIisaacPlanner
+    q = [0.0, -0.94, 0.0, -2.8, 0.0, 1.8675, 0.0]
+    cfg = _panda_cfg(update_lambda=True, eta_u_bound=20.0, eta_l_bound=10.0, lambda_=0.5)
+    pl = MPPIisaacPlanner(cfg, PandaReachObjective(cfg))
+    pl.sim.set_actor_position_by_name([0.5, -0.4, 0.3], "goal")
+    lam, seen = 0.5, []
+    for it in range(12):
+        pl.compute_action(q, [0.0] * 7)
+        S = pl.mppi.get_costs().numpy().astype(np.float64)
+        stats = np.zeros(2, np.float32)
+        capi.check(lib, lib.mppi_get_weights_stats(pl.sim._ctx, capi.fptr(stats)))
+        eta_host = np.exp(-(S - S.min()) / lam).sum()                     # with the lambda this command ran with
+        assert stats[1] == pytest.approx(eta_host, rel=1e-4), (it, lam)
+        want = lam * 0.9 if stats[1] > 20.0 else (lam * 1.2 if stats[1] < 10.0 else lam)
+        assert pl.mppi.lambda_ == pytest.approx(want, rel=1e-12)
+        seen.append((lam, float(stats[1])))
+        lam = pl.mppi.lambda_
+    assert seen[0][1] > 20.0 and seen[-1][0] < 0.5                        # lambda = 0.5 is far too soft for 256 samples: it came down
+    assert any(10.0 <= e <= 20.0 for _, e in seen[1:]) or seen[-1][1] < seen[0][1]
+    assert lib.mppi_set_lambda(pl.sim._ctx, C.c_double(0.0)) == capi.MPPI_EINVAL
+    pl.sim.stop_sim()

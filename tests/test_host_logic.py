@@ -174,9 +174,10 @@ def test_every_reference_mppi_file_is_restated_and_builds():
 
 def test_unsupported_mppi_switches_are_refused_not_ignored():
     from mppiisaac.planner.mppi import MPPIConfig, make_config
-    for kw in ({"update_lambda": True}, {"update_cov": True}):
-        with pytest.raises(NotImplementedError):
-            make_config(MPPIConfig(noise_sigma=[[1.0]], **kw))
+    with pytest.raises(NotImplementedError):
+        make_config(MPPIConfig(noise_sigma=[[1.0]], update_cov=True))
+    with pytest.raises(ValueError, match="eta_u_bound"):   # update_lambda: a band of the weight normaliser, upper above lower
+        make_config(MPPIConfig(noise_sigma=[[1.0]], update_lambda=True, eta_u_bound=3.0, eta_l_bound=5.0))
     for n in (0, 99):                                   # u_per_command: the first n rows of the updated nominal, 1 <= n <= horizon
         with pytest.raises(ValueError, match="u_per_command"):
             make_config(MPPIConfig(noise_sigma=[[1.0]], horizon=12, u_per_command=n))
