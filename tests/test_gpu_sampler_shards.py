@@ -537,6 +537,14 @@ def test_two_moving_base_robots_in_one_env(lib, oracle64, tmp_path):
     rel = np.abs(S - So) / np.abs(So)
     print(f"\ntwo jackals {K}x{H} vs fp64 oracle: within 1e-4 {np.mean(rel <= 1e-4):.3f} 1e-3 {np.mean(rel <= 1e-3):.3f} max {rel.max():.1e}")
     assert np.mean(rel <= 1e-4) >= 0.97 and rel.max() <= 1e-2
+    # the same objective as an unmodified reference-style Python Objective (generic mode: the one-lane step / materialise kernels)
+
+    class Generic(TwoReach):
+        fused_spec = None
+    gen = MPPIisaacPlanner(cfg, Generic(cfg))
+    gen.compute_action_tensor(torch_to_bytes(world._dof_state.cpu()), torch_to_bytes(world._root_state.cpu()))
+    np.testing.assert_allclose(gen.mppi.get_costs().numpy(), S, rtol=2e-4)
+    gen.sim.stop_sim()
     d0 = (np.linalg.norm(root[0, :2] - T1[:2]), np.linalg.norm(root[1, :2] - T2[:2]))
     for _ in range(220):
         a = bytes_to_torch(planner.compute_action_tensor(torch_to_bytes(world._dof_state.cpu()), torch_to_bytes(world._root_state.cpu())))
