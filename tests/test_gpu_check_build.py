@@ -60,3 +60,25 @@ def test_check_build_finds_nothing(make, K, H, kernel):
     rel = np.abs(Sc - Sp) / np.abs(Sp)
     # (the check build's extra branches change how products and sums are contracted: last-bit differences, amplified by contact)
     assert np.median(rel) < 1e-5 and (rel <= 1e-3).mean() >= 0.99, (np.median(rel), rel.max())
+
+
+def test_check_build_on_a_forest_of_moving_bases():
+    """two jackals in one env (mppi_hip.h ABI 7: one floating base per tree; the one-lane scene kernels with NB + 2 base frames and
+    accumulators per sample): every LDS row access of the rollout inside the rows the kernel allocated, costs as the product build's"""
+    from mppiisaac.objectives import MultiJackalObjective, compile_program
+    from mppiisaac.planner.mppi import MPPIConfig, make_config
+    from scenes import build_scene
+    assert os.path.exists(CHECK_LIB)
+    chk, prod = capi.load_library(CHECK_LIB), capi.load_library()
+    scene = build_scene(["jackal_a", "jackal_b", "goal"], [[0.0, 0.0, 0.1], [0.5, -2.0, 0.1]])
+    m = scene.to_c()
+    cfg = make_config(MPPIConfig(num_samples=100, horizon=10, noise_sigma=np.eye(4).tolist(), lambda_=0.01, u_min=[-1.5], u_max=[1.5],
+                                 sample_null_action=True), viz_link=scene.viz_link_index())
+    obj = MultiJackalObjective()
+    cost = compile_program(obj.terms(), obj.weights, scene)
+    dof, root = scene.initial_state()
+    Sc, info = costs(chk, m, cfg, cost, dof, root)
+    Sp, _ = costs(prod, m, cfg, cost, dof, root)
+    assert "rollout=scene " in info and "-2,-2,-2,-2]" in info, info
+    assert np.isfinite(Sc).all()
+    np.testing.assert_allclose(Sc, Sp, rtol=1e-4)
