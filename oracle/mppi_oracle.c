@@ -526,12 +526,15 @@ static void shape_world(const mppi_model_t *m, const mppi_shape_t *S, int ent, c
 /* Penetration depth and push-out direction of a point inside a box, continuous everywhere in the interior: with the
  * distances dx, dy, dz > 0 to the three nearest faces, depth = (dx^-2 + dy^-2 + dz^-2)^-1/2 - a smooth minimum that vanishes
  * on every face, equals the nearest-face distance next to a face and blends near edges and corners - and the normal is the
- * unit vector along its gradient, sum_i (depth/d_i)^3 n_i.  (The nearest-face rule switched the direction of the force by 90
+ * unit vector along sum_i max(0, depth/d_i - 1/5)^3 n_i (the gradient's direction with the far faces cut off).  (The nearest-face rule switched the direction of the force by 90
  * degrees where two distances tie; a point leaving through a side face kept its front-face force until the last moment.) */
 static void box_interior(real dx, real dy, real dz, const real *y, real *nl, real *depth) {
     real ix = 1 / dx, iy = 1 / dy, iz = 1 / dz;
     real ds = 1 / (real)sqrt((double)(ix * ix + iy * iy + iz * iz));
-    real wx = ds * ix, wy = ds * iy, wz = ds * iz;
+    /* compact support (round 4): a face further away than five times the depth has NO share in the direction - (depth/d_i)^3 leaked
+     * 3e-5 of the side faces' directions into the normal of a block resting 8 mm deep on a 0.5-m table (a creep of 1 um/s) */
+    real wx = ds * ix - (real)0.2, wy = ds * iy - (real)0.2, wz = ds * iz - (real)0.2;
+    wx = wx > 0 ? wx : 0; wy = wy > 0 ? wy : 0; wz = wz > 0 ? wz : 0;
     wx = wx * wx * wx; wy = wy * wy * wy; wz = wz * wz * wz;
     real nn = 1 / (real)sqrt((double)(wx * wx + wy * wy + wz * wz));
     nl[0] = (y[0] > 0 ? wx : -wx) * nn; nl[1] = (y[1] > 0 ? wy : -wy) * nn; nl[2] = (y[2] > 0 ? wz : -wz) * nn;
