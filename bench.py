@@ -326,7 +326,7 @@ def hbm_copy_ceiling(torch, min_ms=0.0):
     """measured HBM ceiling next to the 8 TB/s spec: read + write of a 256 MiB device-to-device copy, best of the
     batches of 10 copies that fit into `min_ms` (at least one: the first batch on a device that has just been opened reads
     5.1-5.3 TB/s, later ones 5.5-5.6).  Taken between the construction of the loop and its timed run.  (Measured, round 4: neither
-    this load nor up to 2000 extra iterations in front of the warm-up change what the driver's short command - 5 warm-up + 20
+    this load, nor 1000 launches of the fp64 sampler, nor up to 2000 extra iterations in front of the warm-up change what the driver's short command - 5 warm-up + 20
     timed iterations, 3 ms in all - reports: 7840-7950 Hz against 7925-7983 Hz over 200-2000 iterations; the spread between
     boxes is larger than that)"""
     a = torch.empty(64 << 20, dtype=torch.float32, device="cuda")

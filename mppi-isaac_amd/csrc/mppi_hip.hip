@@ -958,6 +958,15 @@ int mppi_set_profiling(mppi_ctx_t *c, int on) {
     c->profiling = on != 0;
     c->profile_period = on > 1 ? on : 1;
     for (int w = 0; w < 3; w++) c->ev_used[w] = c->ev_seen[w] = 0;
+    // the event pairs of the first brackets are created HERE, not inside the profiled region (EvScope grows the pool on demand
+    // beyond them): two hipEventCreate per bracket and kernel sat between the launches of a closed loop that waits for every action
+    if (on)
+        for (int w = 0; w < 3; w++)
+            while (c->ev[w].size() < 512) {
+                hipEvent_t a, b;
+                if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { (void)hipGetLastError(); break; }
+                c->ev[w].emplace_back(a, b);
+            }
     return MPPI_OK;
 }
 /* average hipEvent duration (ms) of the launches of kernel `which` since mppi_set_profiling(ctx,1) */
