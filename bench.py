@@ -202,7 +202,11 @@ class Loop:
             v = ctypes.c_int(0)
             self.capi.check(self.lib, self.lib.mppi_exchange_status(self.P, ctypes.byref(v)))
             late = v.value
-        return {"rank": self.env["rank"], "device": self.env["local_rank"], "selected": self.exchange, "why": self.exchange_why, "probe": self.probe,
+        # (what the collective library itself says about the job: world size and backend as torch.distributed sees them, the device
+        # this rank computes on)
+        return {"rank": self.env["rank"], "device": self.env["local_rank"], "device_name": self.torch.cuda.get_device_name(self.env["local_rank"]),
+                "dist_world_size": self.dist.get_world_size(), "dist_rank": self.dist.get_rank(), "dist_backend": str(self.dist.get_backend()),
+                "selected": self.exchange, "why": self.exchange_why, "probe": self.probe,
                 "mppi_exchange_status": late, "graph": self.graph is not None}
 
     def time_exchange(self, n=50):
@@ -413,6 +417,108 @@ def cpu_baseline(loop, budget_s=24.0):
             "rows": rows}
 
 
+class ReferenceStyleReach(object):
+    """A Python Objective written the way the reference's examples write theirs (examples/panda/planner.py:10-40: weights dict,
+    reset(), compute_cost(sim) over the gym getters with torch; pytorch3d's two rotation helpers come from mppiisaac.utils.conversions
+    because pytorch3d is not in the image).  It declares nothing else - no cost program, no fused_spec, no graph_safe - so the
+    planner runs it in GENERIC mode: horizon simulated by the HIP kernels, cost evaluated by this Python code."""
+
+    def __init__(self, cfg=None):
+        self.weights = {"robot_to_goal": 1.0, "robot_ori": 0.5}
+        self.reset()
+
+    def reset(self):
+        pass
+
+    def compute_cost(self, sim):
+        import torch
+        from mppiisaac.utils.conversions import matrix_to_euler_angles, quaternion_to_matrix
+        ee = sim.get_actor_link_by_name("panda", "panda_ee_tip")
+        goal = sim.get_actor_position_by_name("goal")
+        to_goal = torch.linalg.norm(ee[:, 0:3] - goal[:, 0:3], axis=1)
+        tilt = torch.linalg.norm(matrix_to_euler_angles(quaternion_to_matrix(ee[:, 3:7]), "ZYX")[:, 0:2], axis=1)
+        return self.weights["robot_to_goal"] * to_goal + self.weights["robot_ori"] * tilt
+
+
+class ReferenceStyleReachGraphSafe(ReferenceStyleReach):
+    """the same Objective with the one-line opt-in `graph_safe = True` (a pure tensor program of sim tensors and .weights): the
+    planner may capture its evaluation over the horizon into a HIP graph (planner/mppi.py)"""
+    graph_safe = True
+
+
+def facade_loop(wl_name, objective, device, steps, warmup, profile_to=None):
+    """The loop a user of the REFERENCE runs (examples/panda/world.py:32-50 + planner.py:43-48, both in one process): a K = 1
+    IsaacGymWrapper world, an MPPIisaacPlanner, state and action exchanged as torch.save blobs through
+    `compute_action_tensor(dof_bytes, root_bytes)`, the world stepped from Python with `apply_robot_cmd(action); step()`.
+    Every iteration waits for its action on the host by construction (the action is the payload of the returned blob).
+    -> (Hz, ms per iteration, final end-effector distance to the goal)"""
+    import torch
+    from mppiisaac.planner.isaacgym_wrapper import IsaacGymWrapper
+    from mppiisaac.planner.mppi_isaac import MPPIisaacPlanner
+    from mppiisaac.utils.transport import bytes_to_torch, torch_to_bytes
+    wl = WORKLOADS[wl_name]
+    cfg = make_cfg(wl, wl["K"])
+    cfg.mppi.device = device
+    planner = MPPIisaacPlanner(cfg, objective)
+    world = IsaacGymWrapper(cfg.isaacgym, actors=cfg.actors, init_positions=cfg.initial_actor_positions, num_envs=1, device=device)
+    if wl["goal"] is not None:
+        for sim in (planner.sim, world):
+            sim.set_actor_position_by_name(wl["goal"], "goal")
+    if wl["q0"] is not None:
+        dof0 = world._dof_state[0].cpu().numpy().copy()
+        dof0[0::2] = wl["q0"]
+        world._push_single_state(dof0, world._root_state[0].cpu().numpy())
+
+    def iterate():
+        action = bytes_to_torch(planner.compute_action_tensor(torch_to_bytes(world._dof_state), torch_to_bytes(world._root_state)))
+        world.apply_robot_cmd(action)
+        world.step()
+    for _ in range(warmup):
+        iterate()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        iterate()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    dist = None
+    if wl_name == "panda_reach":
+        ee = world.get_actor_link_by_name("panda", "panda_ee_tip")[0, 0:3].cpu().numpy()
+        dist = float(np.linalg.norm(ee - np.asarray(wl["goal"])))
+    if profile_to is not None:
+        import cProfile
+        import io
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        for _ in range(steps):
+            iterate()
+        torch.cuda.synchronize()
+        pr.disable()
+        buf = io.StringIO()
+        pstats.Stats(pr, stream=buf).sort_stats("cumulative").print_stats(40)
+        with open(profile_to, "a") as f:
+            f.write(f"==== {type(objective).__name__}: {1 / dt:.0f} Hz, {dt * 1e3:.4f} ms / iteration (un-profiled), cProfile of {steps} iterations\n")
+            f.write(buf.getvalue())
+    del planner, world
+    return 1.0 / dt, dt * 1e3, dist
+
+
+def facade_rows(wl_name, device):
+    """`value_facade` / `value_generic_objective` of the result line: the reference-API loop on the metric's workload"""
+    import mppiisaac.objectives as objectives
+    n, w = int(os.environ.get("MPPI_BENCH_FACADE_STEPS", "400")), 30
+    prof = os.environ.get("MPPI_BENCH_FACADE_PROFILE")
+    rows = {}
+    for key, obj in (("fused", getattr(objectives, WORKLOADS[wl_name]["objective"])(None)), ("generic", ReferenceStyleReach()),
+                     ("generic_graph_safe", ReferenceStyleReachGraphSafe())):
+        if key != "fused" and wl_name != "panda_reach":
+            continue
+        hz, ms, dist = facade_loop(wl_name, obj, device, n, w, profile_to=prof)
+        rows[key] = {"value": hz, "ms_per_step": ms, "steps": n, "final_ee_to_goal_m": dist}
+    return rows
+
+
 def roofline(loop, kms, hbm_measured, n_waves):
     """HBM view (north_star's yardstick) and instruction-issue view (the bound that matters here) of the rollout kernel"""
     K, H, nu = loop.K, loop.H, loop.nu
@@ -446,7 +552,11 @@ def roofline(loop, kms, hbm_measured, n_waves):
     lane = kind in ("lane", "scene")
     scene = kind.startswith("scene")
     lps = 1 if lane else (8 if "oct" in kind else 4)
-    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+    # `bound`: what limits this kernel - instruction ISSUE of lone wavefronts, not HBM; achieved / peak / unit / frac keep
+    # the HBM view the contract defines (algorithmic bytes per launch / kernel time against 8 TB/s), `issue_frac` is the same kernel
+    # against the fp32 vector issue peak
+    return {"bound": "issue", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "hbm_frac": achieved / HBM_PEAK_GBS, "issue_frac": issue["frac_of_fp32_issue_peak"] if issue else None,
             "traffic": traffic, "traffic_source": traffic_src, "kernel": ("k_rollout_scene" if scene else "k_rollout") + ("" if lane else "_quad") + ("<.., 8> (octet layout)" if (lps == 8 and not scene) else ""),
             "peak_measured": hbm_measured, "kernel_ms": kms, "bytes_alg_per_launch": bytes_alg, "wavefronts": n_waves, "lanes_per_sample": lps,
             "issue": issue,
@@ -461,6 +571,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)     # 20 warm-up + 200 timed iterations
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-facade", action="store_true", help="skip the reference-API loops (value_facade, value_generic_objective)")
     ap.add_argument("--async-loop", action="store_true", help="do not wait for the action on the host every iteration")
     ap.add_argument("--workload", default="panda_reach", choices=sorted(WORKLOADS), help="BASELINE config (default: the metric's)")
     ap.add_argument("--k-total", type=int, default=0,
@@ -472,6 +583,18 @@ def main():
     import torch
     import torch.distributed as dist
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher - one rank per GPU through torch.distributed.run on
+        # 127.0.0.1, rank 0's result line on this stdout, the launcher's exit code handed on
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print(f"[bench] --gpus {args.gpus} without WORLD_SIZE: launching {' '.join(cmd[1:9])} ...", file=sys.stderr, flush=True)
+        raise SystemExit(subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))).returncode)
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -584,6 +707,22 @@ def main():
     if args.workload == "panda_reach":
         ee = world.get_actor_link_by_name("panda", "panda_ee_tip")[0, 0:3].cpu().numpy()
         dist_to_goal = float(np.linalg.norm(ee - np.asarray(wl["goal"])))
+    # task outcome of the contact workloads (what their Objectives drive down: examples/boxer_push/planner.py:26-67,
+    # examples/panda_pick/planner.py:24-53) after the warm-up + timed iterations of this run
+    outcome = None
+    if args.workload in ("boxer_push", "panda_pick"):
+        o = loop.objective
+        pos = lambda name: world.get_actor_position_by_name(name)[0, 0:3].cpu().numpy()
+        ee = world.get_actor_link_by_name(o.robot, o.link)[0, 0:3].cpu().numpy()
+        nd = 2 if args.workload == "boxer_push" else 3
+        outcome = {"final_block_to_goal_m": float(np.linalg.norm((pos(o.block) - pos(o.goal))[:nd])),
+                   "final_ee_to_block_m": float(np.linalg.norm((ee - pos(o.block))[:nd])),
+                   "iterations": args.steps + args.warmup, "dims": nd}
+    # the loop a user of the reference runs (MPPIisaacPlanner.compute_action_tensor with torch.save blobs, a K = 1 world stepped from
+    # Python): with the example's Objective fused, and with a reference-style Python compute_cost (generic mode)
+    facade = None
+    if world_size == 1 and not args.no_facade and os.environ.get("MPPI_BENCH_FACADE", "1") != "0":
+        facade = facade_rows(args.workload, loop.cfg.mppi.device)
 
     if rank == 0:
         loop_hz = args.steps / elapsed
@@ -599,6 +738,8 @@ def main():
                       else f"MPPI control-loop Hz, {args.workload} K={K} H={H} (not the BASELINE metric)",
             "value": loop_hz * world_size,
             "value_shipped_conf": shipped["value"] if shipped else None,
+            "value_facade": facade["fused"]["value"] if facade else None,
+            "value_generic_objective": facade["generic"]["value"] if facade and "generic" in facade else None,
             "unit": f"Hz ({K}-sample x {H}-step control iterations per second, summed over GPUs)",
             "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
@@ -618,7 +759,13 @@ def main():
                        "noise": ("fixed halton-spline set, sampled once at construction (k_sample %.1f us, outside the loop)" % (1e3 * sampler_ms))
                                 if sampler_ms is not None else "gaussian, redrawn on the device every iteration",
                        "loop_hz": loop_hz, "env_steps_per_s": loop_hz * K * H * world_size,
-                       "final_ee_to_goal_m": dist_to_goal, "final_actor_positions": final_root,
+                       "final_ee_to_goal_m": dist_to_goal, "final_actor_positions": final_root, "task_outcome": outcome,
+                       "facade": {"what": "the reference's own loop (examples/<x>/world.py:32-50): torch.save blobs through "
+                                          "MPPIisaacPlanner.compute_action_tensor, K = 1 IsaacGymWrapper world stepped from Python with apply_robot_cmd + step; "
+                                          "`fused`: the example's Objective as an in-kernel cost; `generic`: a reference-style Python compute_cost(sim) "
+                                          "(bench.py ReferenceStyleReach) evaluated by torch on the kernel-simulated horizon; `generic_graph_safe`: the same "
+                                          "Objective with the `graph_safe = True` opt-in",
+                                  **facade} if facade else None,
                        "exchange_ms": exchange_ms,
                        "exchange": {"selected": loop.exchange, "why": loop.exchange_why, "exchange_ms": exchange_ms, "per_rank": reports} if sharded else None,
                        "shipped_conf": shipped,

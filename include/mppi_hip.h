@@ -29,18 +29,19 @@
 extern "C" {
 #endif
 
-#define MPPI_ABI_VERSION 7
+#define MPPI_ABI_VERSION 8
 
 #define MPPI_MAX_BODIES 12   /* moving bodies (= DOF) of the articulated robot        */
 #define MPPI_MAX_LINKS 24    /* reported rigid bodies of the robot (URDF links)      */
-#define MPPI_MAX_ACTORS 8    /* actors per env (robot + boxes/spheres)               */
+#define MPPI_MAX_ACTORS 12   /* actors per env (robot + boxes/spheres; reference IsaacGymConfig.num_obstacles = 10, isaacgym_wrapper.py:16) */
 #define MPPI_MAX_NU 12       /* control dimension                                    */
 #define MPPI_MAX_H 64        /* horizon                                              */
 #define MPPI_MAX_KNOTS 16    /* spline knots of the halton-spline sampler            */
 #define MPPI_MAX_COST_W 16
-#define MPPI_MAX_SHAPES 40   /* collision primitives per env (anymal: 37)                 */
-#define MPPI_MAX_PAIRS 48    /* candidate contact pairs per env                           */
-#define MPPI_MAX_FREE 2      /* free (non-fixed) box/sphere actors per env                */
+#define MPPI_MAX_SHAPES 56   /* collision primitives per env (anymal: 37; an arm + ten obstacle spheres)  */
+#define MPPI_MAX_PAIRS 96    /* candidate contact pairs per env                           */
+#define MPPI_MAX_FREE 4      /* free (non-fixed) box/sphere actors per env (the shipped kernels carry 2 slots; scenes with
+                              * 3-4 free actors get their kernels built on demand, see mppi_create)          */
 #define MPPI_MAX_EXTRA_BASES 3 /* moving-base robots per env beyond the first (ABI 7)         */
 
 enum { MPPI_OK = 0, MPPI_EINVAL = -1, MPPI_EHIP = -2, MPPI_EUNSUPPORTED = -3, MPPI_ESTATE = -4 };
@@ -268,7 +269,15 @@ int mppi_device_count(int *count);
 /* ---- lifetime: replaces IsaacGymWrapper.__init__/start_sim (isaacgym_wrapper.py:84-236)
  *      + MPPIPlanner(cfg.mppi, ...) construction (mppi_isaac.py:43-49).  Allocates all
  *      device buffers on `device`.  `stream` is a hipStream_t (NULL = default stream).   */
+/*      Kinematic trees: the rollout kernels are templates over the tree.  The library ships the instantiations of the robots under
+ *      assets/compiled/; ANY OTHER tree (what gym.load_asset accepts: whatever URDF the actor YAML names, isaacgym_utils.py:14-29)
+ *      is built on demand at mppi_create - hipcc compiles the two generated units of that tree into a plugin library that is cached
+ *      on disk (MPPI_JIT_CACHE, default ~/.cache/mppi_hip; keyed by tree, flags and the kernel sources), loaded and appended to the
+ *      launch table; so are the contact-scene kernels with four free-actor slots for envs of 3-4 free actors.  MPPI_JIT=0 switches
+ *      the builds off (unknown trees are refused with MPPI_EUNSUPPORTED), HIPCC names the compiler.  mppi_jit_info: what the last
+ *      on-demand build did ("built <plugin> in 34.1 s" / "cached <plugin> in 0.0 s"; empty string: none so far).            */
 int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device, mppi_ctx_t **out);
+int mppi_jit_info(char *buf, int buflen);
 int mppi_destroy(mppi_ctx_t *ctx);
 int mppi_set_stream(mppi_ctx_t *ctx, void *hip_stream);
 int mppi_synchronize(mppi_ctx_t *ctx);
@@ -276,6 +285,8 @@ int mppi_synchronize(mppi_ctx_t *ctx);
 /* ---- state in: replaces reset_rollout_sim (mppi_isaac.py:87-105): ONE env state
  *      (dof_state [2n] interleaved q,qdot; root_state [A][13] pos,quat xyzw,linvel,angvel)
  *      is broadcast to all K samples inside the kernel (no [K,..] copy is written). */
+/*      (ABI 8: the host state rides as kernel arguments of a one-wavefront launch - stream-ordered, no copy operation, no
+ *      synchronise; the host buffers are free again when the call returns.) */
 int mppi_set_state(mppi_ctx_t *ctx, const float *dof_state_host, const float *root_state_host);
 int mppi_set_state_dev(mppi_ctx_t *ctx, const float *dof_state_dev, const float *root_state_dev);
 int mppi_get_state(mppi_ctx_t *ctx, float *dof_state_host, float *root_state_host);
@@ -322,9 +333,10 @@ int mppi_record_dev(mppi_ctx_t *ctx, float **record_dev);    /* device pointer o
  *   mppi_exchange_publish / mppi_exchange_wait   the two halves of mppi_exchange.  A caller that drives several ranks of ONE
  *                         device from one thread (tests) enqueues every rank's publish before any rank's wait: a waiting
  *                         kernel occupies its hardware queue, and streams of one process may share hardware queues
- *   mppi_exchange_status  1 if a wait ever timed out (a peer never published).  The records of a rank that was late are
- *                         NEUTRAL in the gathered buffer of that iteration (eta = 0: the update runs on the ranks that did
- *                         publish, never on stale or half-written records); callers poll the status and raise
+ *   mppi_exchange_status  1 if a wait timed out (a peer never published) SINCE THE LAST CALL of this function (read-and-clear,
+ *                         ABI 8: a transient stall is reported once, for the iterations it affected).  The records of a rank
+ *                         that was late are NEUTRAL in the gathered buffer of that iteration (eta = 0: the update runs on the
+ *                         ranks that did publish, never on stale or half-written records); callers poll the status and warn
  *   mppi_mailbox_info     whether the inbox is fine-grained device memory (required for peers of another process / GPU:
  *                         mppi_mailbox_ipc_handle refuses a coarse-grained inbox), records per rank, number of ranks
  * A shard whose rollout folded no records (generic Objective mode, ragged grids) publishes ONE reduced record and neutral padding
@@ -382,6 +394,16 @@ int mppi_eval_cost(mppi_ctx_t *ctx, int n, const float *dof_host, const float *r
 int mppi_sim_reset(mppi_ctx_t *ctx);                       /* all K envs <- current x0              */
 int mppi_sim_step(mppi_ctx_t *ctx, const float *u_dev, int u_is_shared); /* u [K][nu] (AoS) or [nu] */
 int mppi_sim_step_horizon(mppi_ctx_t *ctx, int t);         /* u = clamp(U[t]+eps[t]) per sample     */
+/* (ABI 8) the host side of the reference's world loop (examples/<x>/world.py:35-44: torch_to_bytes(sim._dof_state),
+ * torch_to_bytes(sim._root_state) -> planner -> sim.apply_robot_cmd(action); sim.step()) without copy operations:
+ *   mppi_sim_step_host   one command [nu] for every env by HOST pointer (written into a ring slot of the context's mapped host
+ *                        block; the step kernel reads it through the mapped pointer)
+ *   mppi_mirror_state    K = 1: the dof [2n] / root [A][13] device tensors (what mppi_sim_materialise wrote) are copied into the
+ *                        mapped host block by a one-wavefront kernel that publishes a sequence number behind them
+ *   mppi_mirror_wait     polls that number and copies the mirrored state out: no device-to-host copy, no stream synchronise */
+int mppi_sim_step_host(mppi_ctx_t *ctx, const float *u_host);
+int mppi_mirror_state(mppi_ctx_t *ctx, const float *dof_dev, const float *root_dev);
+int mppi_mirror_wait(mppi_ctx_t *ctx, float *dof_host, float *root_host);
 /* reference-layout tensors: dof [K][2n], root [K][A][13], rb [K][B][13], cf [K][B][3]; NULL = skip */
 int mppi_sim_materialise(mppi_ctx_t *ctx, float *dof_dev, float *root_dev, float *rb_dev, float *cf_dev);
 int mppi_sim_accumulate_cost(mppi_ctx_t *ctx, int t, const float *cost_dev); /* S += gamma^t c      */

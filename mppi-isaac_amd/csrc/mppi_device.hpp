@@ -36,11 +36,20 @@ namespace mppi {
 
 constexpr int kMaxBodies = 12;
 constexpr int kMaxLinks = 24;
-constexpr int kMaxActors = 8;
+constexpr int kMaxActors = 12;
 constexpr int kMaxNu = 12;
-constexpr int kMaxShapes = 40;
-constexpr int kMaxPairs = 48;
-constexpr int kMaxFree = 2;
+constexpr int kMaxShapes = 56;
+constexpr int kMaxPairs = 96;
+constexpr int kMaxFree = 4;        // free actors a MODEL may hold (MPPI_MAX_FREE)
+// free-actor slots the contact-scene KERNELS of this build carry (state rows, frames, LDS rows are sized by it): 2 in the shipped
+// library - every example scene of the reference has at most two free actors, and two more slots cost the register-bound scene
+// kernels 26 state values and two frames per sample -; a scene with 3 or 4 free actors gets its kernels from an on-demand
+// build with -DMPPI_FREE_SLOTS=4 (mppi_hip.hip: jit_topology)
+#ifndef MPPI_FREE_SLOTS
+#define MPPI_FREE_SLOTS 2
+#endif
+constexpr int kFreeSlots = MPPI_FREE_SLOTS;
+static_assert(kFreeSlots >= 1 && kFreeSlots <= kMaxFree, "MPPI_FREE_SLOTS out of range");
 constexpr int kMaxExtraBases = 3;  // MPPI_MAX_EXTRA_BASES (checked in mppi_pack.hpp)
 
 // ---- device-side model (fp32, z-framed) ------------------------------------------------

@@ -3,8 +3,17 @@
 // the generated topo_<i>.hip units and found through topo_table.inc.
 #include <atomic>
 #include <chrono>
+#include <fstream>
 #include <mutex>
+#include <sstream>
 #include <unordered_set>
+
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <spawn.h>
+#include <sys/stat.h>
+#include <sys/wait.h>
+#include <unistd.h>
 
 #include "mppi_kernels.hpp"
 #include "topo_table.inc"  // generated: extern "C" const TopoEntry *mppi_topo_entry_<i>(); kTopoEntries[]
@@ -113,7 +122,7 @@ int create_buffers(mppi_ctx *c, const mppi_config_t *cfg) {
     ALLOC_TRY(c->d_qd, sizeof(float) * c->n * K);
     ALLOC_TRY(c->d_ctrl, sizeof(float) * K);
     ALLOC_TRY(c->d_base, sizeof(float) * 13 * (size_t)c->hm.n_bases * K);   // (one block of 13 rows per moving base of the env)
-    ALLOC_TRY(c->d_fr, sizeof(float) * kMaxFree * 13 * K);
+    ALLOC_TRY(c->d_fr, sizeof(float) * c->free_slots * 13 * K);
     ALLOC_TRY(c->d_cf, sizeof(float) * 3 * c->B * K);
     ALLOC_TRY(c->d_filter, sizeof(float) * c->H * c->H);
     ALLOC_TRY(c->d_basis, sizeof(double) * MPPI_MAX_H * MPPI_MAX_KNOTS);
@@ -131,6 +140,9 @@ int create_buffers(mppi_ctx *c, const mppi_config_t *cfg) {
     std::memset(c->h_action, 0, sizeof(float) * 32);
     HIP_TRY(hipHostGetDevicePointer((void **)&c->hc.action_mirror, c->h_action, 0));
     c->hc.seq_host = reinterpret_cast<unsigned *>(c->hc.action_mirror + 16);
+    HIP_TRY(hipHostMalloc((void **)&c->h_io, sizeof(float) * kIoFloats, hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(c->h_io, 0, sizeof(float) * kIoFloats);
+    HIP_TRY(hipHostGetDevicePointer((void **)&c->d_io, c->h_io, 0));
     ALLOC_TRY(c->d_seq, sizeof(unsigned));
     c->hc.seq_dev = c->d_seq;
     HIP_TRY(hipMemcpy(c->d_cfg, &c->hc, sizeof(DevCfg), hipMemcpyHostToDevice));
@@ -154,6 +166,7 @@ void release_ctx(mppi_ctx *c) {
         if (b) (void)hipFree(b);
     for (void *p : c->ipc_opened) (void)hipIpcCloseMemHandle(p);
     if (c->h_action) (void)hipHostFree(c->h_action);
+    if (c->h_io) (void)hipHostFree(c->h_io);
     for (auto &v : c->ev)
         for (auto &p : v) {
             (void)hipEventDestroy(p.first);
@@ -168,6 +181,246 @@ int launch_check() {
     return MPPI_OK;
 }
 
+// ---- host hand-over without copy operations (ABI 8: the bytes API of the reference hands ONE env state in and takes one
+// action out per control iteration, < 1 KB either way - a hipMemcpyAsync + synchronise per tensor cost more than the data) ----
+// the state travels as KERNEL ARGUMENTS of a one-wavefront launch: no copy operation, no synchronisation, and the caller's
+// buffers are free again when the call returns (the runtime copies kernel arguments at launch)
+struct X0Args {
+    float v[2 * MPPI_MAX_BODIES + 13 * MPPI_MAX_ACTORS];
+};
+__global__ void k_set_x0(X0Args a, int n_dof, int n_root, float *__restrict__ x0_dof, float *__restrict__ x0_root) {
+    for (int i = threadIdx.x; i < n_dof; i += blockDim.x) x0_dof[i] = a.v[i];
+    for (int i = threadIdx.x; i < n_root; i += blockDim.x) x0_root[i] = a.v[2 * MPPI_MAX_BODIES + i];
+}
+// K = 1 world: dof / root state tensors -> mapped host memory, then the sequence number behind a system-scope release
+// (mppi_mirror_wait polls it: no device-to-host copy operation, no stream synchronise)
+__global__ void k_mirror_state(const float *__restrict__ dof, const float *__restrict__ root, int n_dof, int n_root, float *__restrict__ mirror,
+                               unsigned *__restrict__ seq_host, unsigned seq) {
+    for (int i = threadIdx.x; i < n_dof; i += blockDim.x) mirror[i] = dof[i];
+    for (int i = threadIdx.x; i < n_root; i += blockDim.x) mirror[kIoDofFloats + i] = root[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(seq_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+}  // namespace
+
+
+// ------------------------------------------------------------------------------ kinematic trees built on demand
+// The rollout kernels are templates over the kinematic tree (every per-body array index static: mppi_device.hpp), so a tree has to
+// be INSTANTIATED before it can run.  The library ships the instantiations of the robots under assets/compiled/; any other tree -
+// what the reference gets from gym.load_asset for whatever URDF the actor YAML names (isaacgym_utils.py:14-29,
+// isaacgym_wrapper.py:429-447) - is built HERE at mppi_create: the two generated units of that tree (exactly what
+// __graft_entry__.generate_sources writes per tree) are compiled with hipcc for gfx950 into a small plugin library, cached on
+// disk under a key of the tree, the build flags and the contents of the kernel headers, dlopen'ed and appended to the launch
+// table.  The first planner of a new robot pays the compile (tens of seconds, like a convex decomposition in the reference's
+// asset import); every later one finds the plugin in the cache.  MPPI_JIT=0 switches this off (unknown trees are then refused),
+// MPPI_JIT_CACHE names the cache directory, HIPCC the compiler.
+extern "C" int mppi_create(const mppi_model_t *, const mppi_config_t *, int, mppi_ctx_t **);
+extern "C" char **environ;
+namespace {
+
+std::mutex g_plugin_mu;
+std::vector<const TopoEntry *> g_plugins;   // entries of the plugins loaded so far (never unloaded)
+std::string g_jit_log;                        // what the last on-demand build did (mppi_jit_info)
+
+const char *const kJitFlags[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize"};   // = __graft_entry__.HIPCC_FLAGS
+const char *const kJitFreeFlags[] = {"-mllvm", "-amdgpu-sched-strategy=max-ilp"};                                     // = ILP_FLAGS (contact-free units)
+constexpr int kDppLeadWaitFrom = 9;                                                                                    // = DPP_LEAD_WAIT_FROM
+
+bool entry_matches(const TopoEntry *e, int nb, const int *parents, bool scene, int n_free) {
+    if (e->nb != nb) return false;
+    for (int i = 0; i < nb; i++)
+        if (e->parents[i] != parents[i]) return false;
+    if (!e->rollout) return false;
+    if (scene && (!e->rollout_scene || e->free_slots < n_free)) return false;
+    return true;
+}
+const TopoEntry *find_entry(int nb, const int *parents, bool scene, int n_free) {
+    for (const TopoEntryFn fn : kTopoEntries)
+        if (entry_matches(fn(), nb, parents, scene, n_free)) return fn();
+    std::lock_guard<std::mutex> lk(g_plugin_mu);
+    for (const TopoEntry *e : g_plugins)
+        if (entry_matches(e, nb, parents, scene, n_free)) return e;
+    return nullptr;
+}
+
+std::string lib_dir() {   // directory of this library = the directory of the kernel headers (csrc/)
+    Dl_info info;
+    if (dladdr((void *)&mppi_create, &info) == 0 || !info.dli_fname) return "";
+    std::string p = info.dli_fname;
+    const size_t k = p.rfind('/');
+    return k == std::string::npos ? "." : p.substr(0, k);
+}
+bool file_exists(const std::string &p) {
+    struct stat st;
+    return stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode);
+}
+bool mkdir_p(const std::string &dir) {
+    for (size_t i = 1; i <= dir.size(); i++)
+        if (i == dir.size() || dir[i] == '/') {
+            const std::string d = dir.substr(0, i);
+            if (mkdir(d.c_str(), 0755) != 0 && errno != EEXIST) return false;
+        }
+    return true;
+}
+// FNV-1a over the kernel headers and the ABI header: a plugin is only ever loaded next to the sources it was built from
+bool source_key(const std::string &dir, uint64_t &key, std::string &err) {
+    const char *files[] = {"mppi_kernels.hpp", "mppi_device.hpp", "mppi_quad.hpp", "mppi_oct.hpp", "mppi_scene.hpp", "mppi_scene_quad.hpp", "mppi_scene_oct.hpp",
+                           "mppi_pack.hpp", "topologies.inc", "../../include/mppi_hip.h"};
+    uint64_t h = 1469598103934665603ull;
+    for (const char *f : files) {
+        std::ifstream in(dir + "/" + f, std::ios::binary);
+        if (!in) { err = "kernel sources not found next to the library (" + dir + "/" + f + ")"; return false; }
+        char buf[1 << 16];
+        while (in.read(buf, sizeof buf) || in.gcount() > 0) {
+            for (std::streamsize i = 0; i < in.gcount(); i++) h = (h ^ (unsigned char)buf[i]) * 1099511628211ull;
+            if (!in) break;
+        }
+    }
+    for (const char *f : kJitFlags)
+        for (const char *q = f; *q; q++) h = (h ^ (unsigned char)*q) * 1099511628211ull;
+    key = h;
+    return true;
+}
+std::string cache_dir() {
+    if (const char *e = std::getenv("MPPI_JIT_CACHE")) return e;
+    if (const char *e = std::getenv("XDG_CACHE_HOME")) return std::string(e) + "/mppi_hip";
+    if (const char *e = std::getenv("HOME")) return std::string(e) + "/.cache/mppi_hip";
+    return "/tmp/mppi_hip_" + std::to_string((long)getuid());
+}
+std::string find_hipcc() {
+    if (const char *e = std::getenv("HIPCC")) return e;
+    for (const char *p : {"/opt/rocm/bin/hipcc", "/usr/bin/hipcc", "/usr/local/bin/hipcc"})
+        if (access(p, X_OK) == 0) return p;
+    return "";
+}
+// runs one compiler process, stderr + stdout into `log`; returns its pid (-1: could not start)
+pid_t spawn_to_log(const std::vector<std::string> &argv, const std::string &log) {
+    std::vector<char *> av;
+    for (const std::string &a : argv) av.push_back(const_cast<char *>(a.c_str()));
+    av.push_back(nullptr);
+    posix_spawn_file_actions_t fa;
+    posix_spawn_file_actions_init(&fa);
+    posix_spawn_file_actions_addopen(&fa, 1, log.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    posix_spawn_file_actions_adddup2(&fa, 1, 2);
+    pid_t pid = -1;
+    const int rc = posix_spawn(&pid, av[0], &fa, nullptr, av.data(), environ);
+    posix_spawn_file_actions_destroy(&fa);
+    return rc == 0 ? pid : -1;
+}
+bool wait_ok(pid_t pid) {
+    int st = 0;
+    while (waitpid(pid, &st, 0) < 0)
+        if (errno != EINTR) return false;
+    return WIFEXITED(st) && WEXITSTATUS(st) == 0;
+}
+std::string tail_of(const std::string &path, size_t n = 1500) {
+    std::ifstream in(path);
+    std::stringstream ss;
+    ss << in.rdbuf();
+    std::string t = ss.str();
+    return t.size() > n ? t.substr(t.size() - n) : t;
+}
+
+// builds (or finds in the cache) and loads the plugin of one kinematic tree; `with_scene`: the contact-scene kernels as well
+// (the long compile), `free_slots`: free-actor slots of those kernels
+const TopoEntry *jit_topology(int nb, const int *parents, bool with_scene, int free_slots, std::string &err) {
+    const char *sw = std::getenv("MPPI_JIT");
+    if (sw && std::string(sw) == "0") { err = "on-demand builds are switched off (MPPI_JIT=0)"; return nullptr; }
+    const std::string dir = lib_dir();
+    uint64_t key = 0;
+    if (dir.empty() || !source_key(dir, key, err)) { if (err.empty()) err = "cannot locate the library on disk"; return nullptr; }
+    std::string name = "topo";
+    for (int i = 0; i < nb; i++) name += (parents[i] < 0 ? "_m" : "_") + std::to_string(parents[i] < 0 ? -parents[i] : parents[i]);
+    char kbuf[32];
+    std::snprintf(kbuf, sizeof kbuf, "%016llx", (unsigned long long)key);
+    name += std::string(with_scene ? "_scene" + std::to_string(free_slots) : "_free") + "_abi" + std::to_string(MPPI_ABI_VERSION) + "_" + kbuf;
+    const std::string cdir = cache_dir();
+    if (!mkdir_p(cdir)) { err = "cannot create the plugin cache directory " + cdir + " (MPPI_JIT_CACHE)"; return nullptr; }
+    const std::string so = cdir + "/" + name + ".so";
+    const auto t0 = std::chrono::steady_clock::now();
+    bool built = false;
+    if (!file_exists(so)) {
+        const std::string hipcc = find_hipcc();
+        if (hipcc.empty()) { err = "no hipcc found (HIPCC, /opt/rocm/bin/hipcc): cannot build the kernels of this tree"; return nullptr; }
+        std::string args;
+        for (int i = 0; i < nb; i++) args += (i ? ", " : "") + std::to_string(parents[i]);
+        const std::string tmp = cdir + "/" + name + "." + std::to_string((long)getpid());
+        const std::string inc = "#include \"" + dir + "/mppi_kernels.hpp\"\n";
+        {
+            std::ofstream f(tmp + "_free.hip");
+            f << "// GENERATED by libmppi_hip.so (jit_topology): contact-free kernels of the kinematic tree [" << args << "]\n"
+              << (nb > kDppLeadWaitFrom ? "#define MPPI_DPP_LEAD_WAIT 1\n" : "") << inc
+              << (with_scene ? "extern \"C\" void mppi_plugin_fill_scene(mppi::TopoEntry *e);\n" : "")
+              << "extern \"C\" const mppi::TopoEntry *mppi_plugin_entry() {\n    static const mppi::TopoEntry e = [] {\n        mppi::TopoEntry x{};\n"
+              << "        fill_topo_entry_free<mppi::Topo<" << args << ">>(x);\n"
+              << (with_scene ? "        mppi_plugin_fill_scene(&x);\n" : "") << "        return x;\n    }();\n    return &e;\n}\n"
+              << "extern \"C\" void mppi_plugin_sizes(size_t *out) { out[0] = sizeof(mppi_ctx); out[1] = sizeof(mppi::DevModel); out[2] = sizeof(mppi::TopoEntry); out[3] = sizeof(mppi::DevCfg); }\n";
+        }
+        std::vector<std::pair<pid_t, std::string>> jobs;
+        std::vector<std::string> objs = {tmp + "_free.o"};
+        std::vector<std::string> cmd = {hipcc};
+        for (const char *f : kJitFlags) cmd.push_back(f);
+        std::vector<std::string> cfree = cmd;
+        for (const char *f : kJitFreeFlags) cfree.push_back(f);
+        cfree.insert(cfree.end(), {"-c", "-o", tmp + "_free.o", tmp + "_free.hip"});
+        std::fprintf(stderr, "[mppi_hip] building the kernels of kinematic tree [%s]%s with %s (one-off: cached as %s)\n", args.c_str(),
+                     with_scene ? " incl. the contact-scene kernels" : "", hipcc.c_str(), so.c_str());
+        jobs.emplace_back(spawn_to_log(cfree, tmp + "_free.log"), tmp + "_free.log");
+        if (with_scene) {
+            std::ofstream f(tmp + "_scene.hip");
+            f << "// GENERATED by libmppi_hip.so (jit_topology): contact-scene kernels of the kinematic tree [" << args << "]\n#define MPPI_DPP_LEAD_WAIT 1\n"
+              << inc << "extern \"C\" void mppi_plugin_fill_scene(mppi::TopoEntry *e) { fill_topo_entry_scene<mppi::Topo<" << args << ">>(*e); }\n";
+            f.close();
+            std::vector<std::string> cs = cmd;
+            cs.insert(cs.end(), {"-DMPPI_FREE_SLOTS=" + std::to_string(free_slots), "-c", "-o", tmp + "_scene.o", tmp + "_scene.hip"});
+            objs.push_back(tmp + "_scene.o");
+            jobs.emplace_back(spawn_to_log(cs, tmp + "_scene.log"), tmp + "_scene.log");
+        }
+        bool ok = true;
+        std::string why;
+        for (auto &j : jobs) {
+            if (j.first < 0 || !wait_ok(j.first)) {
+                ok = false;
+                why += "\n--- " + j.second + "\n" + tail_of(j.second);
+            }
+        }
+        if (ok) {
+            std::vector<std::string> link = {hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp + ".so"};
+            link.insert(link.end(), objs.begin(), objs.end());
+            const pid_t lp = spawn_to_log(link, tmp + "_link.log");
+            if (lp < 0 || !wait_ok(lp)) { ok = false; why += "\n--- link\n" + tail_of(tmp + "_link.log"); }
+        }
+        for (const char *sfx : {"_free.hip", "_free.o", "_scene.hip", "_scene.o"}) (void)unlink((tmp + sfx).c_str());
+        if (!ok) { err = "building the kernels of tree [" + args + "] failed:" + why; return nullptr; }
+        for (const char *sfx : {"_free.log", "_scene.log", "_link.log"}) (void)unlink((tmp + sfx).c_str());
+        if (rename((tmp + ".so").c_str(), so.c_str()) != 0) { err = "cannot move the built plugin into " + so; return nullptr; }   // (atomic: ranks may race)
+        built = true;
+    }
+    void *h = dlopen(so.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!h) { err = std::string("dlopen of the plugin failed: ") + dlerror(); return nullptr; }
+    auto entry = (const TopoEntry *(*)())dlsym(h, "mppi_plugin_entry");
+    auto sizes = (void (*)(size_t *))dlsym(h, "mppi_plugin_sizes");
+    size_t sz[4] = {0, 0, 0, 0};
+    if (sizes) sizes(sz);
+    if (!entry || sz[0] != sizeof(mppi_ctx) || sz[1] != sizeof(DevModel) || sz[2] != sizeof(TopoEntry) || sz[3] != sizeof(DevCfg)) {
+        err = "the plugin " + so + " does not match this library (rebuild: delete it)";
+        dlclose(h);
+        return nullptr;
+    }
+    const TopoEntry *e = entry();
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    {
+        std::lock_guard<std::mutex> lk(g_plugin_mu);
+        g_plugins.push_back(e);
+        char buf[64];
+        std::snprintf(buf, sizeof buf, "%.1f", secs);
+        g_jit_log = std::string(built ? "built " : "cached ") + so + " in " + buf + " s";
+    }
+    return e;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------ C-ABI
@@ -175,6 +428,13 @@ extern "C" {
 
 const char *mppi_last_error(void) { return g_err.c_str(); }
 int mppi_abi_version(void) { return MPPI_ABI_VERSION; }
+/* what the last on-demand build of a kinematic tree did ("built <plugin> in 34.1 s" / "cached ..."); empty: none so far */
+int mppi_jit_info(char *buf, int buflen) {
+    if (!buf || buflen < 1) return fail(MPPI_EINVAL, "null buffer");
+    std::lock_guard<std::mutex> lk(g_plugin_mu);
+    std::snprintf(buf, buflen, "%s", g_jit_log.c_str());
+    return MPPI_OK;
+}
 int mppi_device_count(int *count) {
     if (!count) return fail(MPPI_EINVAL, "null count");
     HIP_TRY(hipGetDeviceCount(count));
@@ -203,13 +463,13 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
     c->scene = is_scene(c->hm);
     hipError_t lds_err = hipSuccess;
     bool ok = false;
-    for (const TopoEntryFn fn : kTopoEntries) {
-        const TopoEntry *e = fn();
-        if (e->nb != c->hm.nb) continue;
-        bool same = true;
-        for (int i = 0; i < e->nb; i++) same &= e->parents[i] == parents[i];
-        if (!same) continue;
+    // the launch-table row of this tree: shipped instantiations first, then plugins loaded earlier, then an on-demand build
+    const TopoEntry *found = find_entry(c->hm.nb, parents, c->scene, c->hm.n_free);
+    std::string jit_err;
+    if (!found) found = jit_topology(c->hm.nb, parents, c->scene, c->hm.n_free > 2 ? kMaxFree : 2, jit_err);
+    for (const TopoEntry *e = found; e != nullptr;) {
         ok = true;
+        c->free_slots = e->free_slots > 0 ? e->free_slots : 2;
         c->launch_eval_cost = e->eval_cost;
         if (c->scene) {
             c->lds_bytes = sizeof(float) * kWave * (e->scene_lds_floats + 3 * (size_t)c->hm.n_rb + 5 * (size_t)c->hm.n_rnd);
@@ -285,9 +545,7 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
     if (!ok) {
         std::string t = c->topo;
         delete c;
-        return fail(MPPI_EUNSUPPORTED, "kinematic tree " + t +
-                                           " is not instantiated in this build: add its compiled model under assets/compiled/ and "
-                                           "re-run __graft_entry__.build()");
+        return fail(MPPI_EUNSUPPORTED, "kinematic tree " + t + " is not instantiated in this library and could not be built on demand: " + jit_err);
     }
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) {
@@ -338,10 +596,14 @@ int mppi_synchronize(mppi_ctx_t *c) {
 
 int mppi_set_state(mppi_ctx_t *c, const float *dof, const float *root) {
     CTX_TRY(c);
-    if (dof) HIP_TRY(hipMemcpyAsync(c->d_x0_dof, dof, sizeof(float) * 2 * c->n, hipMemcpyHostToDevice, c->stream));
-    if (root) HIP_TRY(hipMemcpyAsync(c->d_x0_root, root, sizeof(float) * 13 * c->A, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));  // the host buffers may be reused by the caller right away
-    return MPPI_OK;
+    // (ABI 8) the < 1 KB of state ride as kernel arguments of a one-wavefront launch, stream-ordered like the copies they
+    // replace: no copy operation, no synchronise; the host buffers may be reused by the caller right away
+    X0Args a;
+    const int nd = dof ? 2 * c->n : 0, nr = root ? 13 * c->A : 0;
+    if (nd) std::memcpy(a.v, dof, sizeof(float) * nd);
+    if (nr) std::memcpy(a.v + 2 * MPPI_MAX_BODIES, root, sizeof(float) * nr);
+    if (nd || nr) hipLaunchKernelGGL(k_set_x0, dim3(1), dim3(64), 0, c->stream, a, nd, nr, c->d_x0_dof, c->d_x0_root);
+    return launch_check();
 }
 int mppi_set_state_dev(mppi_ctx_t *c, const float *dof, const float *root) {
     CTX_TRY(c);
@@ -473,7 +735,7 @@ int mppi_rollout_trajectory(mppi_ctx_t *c) {
         return fail(MPPI_EUNSUPPORTED, "mppi_rollout_trajectory: this context runs a kernel without the trajectory dump (MPPI_ROLLOUT=lane, or a contact scene with fewer than 8 samples); use the mppi_sim_* steps");
     const size_t HK = (size_t)c->H * c->K;
     if (!c->d_traj) {
-        const size_t rows = c->scene ? 2 * (size_t)c->n + 13 + 13 * (size_t)kMaxFree + 3 * (size_t)c->hm.n_rb : 2 * (size_t)c->n;
+        const size_t rows = c->scene ? 2 * (size_t)c->n + 13 + 13 * (size_t)c->free_slots + 3 * (size_t)c->hm.n_rb : 2 * (size_t)c->n;
         if (!c->d_cost_none) {
             ALLOC_TRY(c->d_cost_none, sizeof(DevCost));
             HIP_TRY(hipMemsetAsync(c->d_cost_none, 0, sizeof(DevCost), c->stream));  // kind = MPPI_COST_NONE
@@ -729,7 +991,12 @@ int mppi_exchange_status(mppi_ctx_t *c, int *timed_out) {
     if (!c->d_inbox || !timed_out) return fail(MPPI_ESTATE, "no mailbox (mppi_mailbox_create)");
     HIP_TRY(hipStreamSynchronize(c->stream));  // (the waits enqueued so far have run; the word itself is mapped host memory)
     std::atomic_thread_fence(std::memory_order_acquire);
-    *timed_out = (int)*reinterpret_cast<const volatile unsigned *>(c->h_action + 17);
+    volatile unsigned *word = reinterpret_cast<volatile unsigned *>(c->h_action + 17);
+    *timed_out = (int)*word;
+    // read-and-clear: the word reports the waits since the LAST call - one transient stall (a first-iteration graph capture, a
+    // debugger pause on a peer) must not mark every later iteration late; the stream is idle here, nobody else writes the word
+    *word = 0u;
+    std::atomic_thread_fence(std::memory_order_release);
     return MPPI_OK;
 }
 
@@ -884,6 +1151,47 @@ int mppi_sim_step(mppi_ctx_t *c, const float *u_dev, int u_is_shared) {
     if (!u_dev) return fail(MPPI_EINVAL, "null command");
     c->launch_sim_step(c, u_is_shared ? 1 : 0, 0, u_dev);
     return launch_check();
+}
+/* (ABI 8) one command for every env, handed over by HOST pointer: it is written into a ring slot of the context's mapped host
+ * block and the step kernel reads it through the mapped pointer - what apply_robot_cmd + step of a K = 1 world need per control
+ * iteration (reference examples/<x>/world.py:42-44), without a host-to-device copy operation */
+int mppi_sim_step_host(mppi_ctx_t *c, const float *u_host) {
+    CTX_TRY(c);
+    if (!u_host) return fail(MPPI_EINVAL, "null command");
+    const unsigned slot = c->io_cmd_next++ % kIoCmdSlots;
+    std::memcpy(c->h_io + kIoCmd + 16 * slot, u_host, sizeof(float) * c->nu);
+    std::atomic_thread_fence(std::memory_order_release);
+    c->launch_sim_step(c, 1, 0, c->d_io + kIoCmd + 16 * slot);
+    return launch_check();
+}
+/* (ABI 8) K = 1 world: the dof [2n] and root [A][13] state tensors (device, e.g. what mppi_sim_materialise just wrote) are
+ * mirrored into the context's mapped host block by a one-wavefront kernel that publishes a sequence number behind them;
+ * mppi_mirror_wait polls the number and copies them out - the `torch_to_bytes(sim._dof_state)` of the reference's world loop
+ * (examples/<x>/world.py:35-39) without a device-to-host copy operation or a stream synchronise */
+int mppi_mirror_state(mppi_ctx_t *c, const float *dof_dev, const float *root_dev) {
+    CTX_TRY(c);
+    if (!dof_dev || !root_dev) return fail(MPPI_EINVAL, "mppi_mirror_state: null tensor");
+    c->io_mirror_seq++;
+    hipLaunchKernelGGL(k_mirror_state, dim3(1), dim3(64), 0, c->stream, dof_dev, root_dev, 2 * c->n, 13 * c->A, c->d_io + kIoDof,
+                       reinterpret_cast<unsigned *>(c->d_io), c->io_mirror_seq);
+    return launch_check();
+}
+int mppi_mirror_wait(mppi_ctx_t *c, float *dof_host, float *root_host) {
+    CTX_TRY(c);
+    if (c->io_mirror_seq == 0) return fail(MPPI_ESTATE, "mppi_mirror_wait: nothing mirrored (mppi_mirror_state)");
+    const volatile unsigned *seq = reinterpret_cast<const volatile unsigned *>(c->h_io);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0; *seq != c->io_mirror_seq; spins++) {
+        if ((spins & 0xFFFF) == 0xFFFF && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) {
+            hipError_t e = hipStreamSynchronize(c->stream);  // a kernel fault surfaces here
+            if (e != hipSuccess) return fail(MPPI_EHIP, std::string("mppi_mirror_wait: ") + hipGetErrorString(e));
+            if (*seq != c->io_mirror_seq) return fail(MPPI_ESTATE, "mppi_mirror_wait: the mirror kernel never published");
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (dof_host) std::memcpy(dof_host, c->h_io + kIoDof, sizeof(float) * 2 * c->n);
+    if (root_host) std::memcpy(root_host, c->h_io + kIoDof + kIoDofFloats, sizeof(float) * 13 * c->A);
+    return MPPI_OK;
 }
 int mppi_sim_step_horizon(mppi_ctx_t *c, int t) {
     CTX_TRY(c);

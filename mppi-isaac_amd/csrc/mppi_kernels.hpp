@@ -973,7 +973,7 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW))
         // unsigned immediate offset and costs a register per row - the compiler spilled those to scratch)
         L.set1 = scene_row_floats<T>(M);
         L.xch = L.set1 + SceneLayout<T>::NF * 27 + 3 * M.n_rb;
-        L.park = L.xch + 2 + 6 * kMaxFree;
+        L.park = L.xch + 2 + 6 * kFreeSlots;
         if (wave != 0) {
             // HELPER WAVEFRONT: its half of the shape poses and candidate pairs of every substep, out of and into LDS (see
             // kSplitOctPair); the barriers inside contact_forces pair with those of the first wavefront's calls
@@ -1008,7 +1008,7 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW))
 #endif
 }
 
-// env state of contact scenes in HBM (sample-minor): base [13][K], free [kMaxFree*13][K], cf [n_rb*3][K]
+// env state of contact scenes in HBM (sample-minor): base [13][K], free [kFreeSlots*13][K], cf [n_rb*3][K]
 template <class T>
 __global__ __launch_bounds__(kWave) void k_sim_step_scene(const DevModel *__restrict__ m, const DevCfg *__restrict__ cfg, int mode, int t,
                                                           const float *__restrict__ u_ext, const float *__restrict__ x0_root,
@@ -1032,7 +1032,7 @@ __global__ __launch_bounds__(kWave) void k_sim_step_scene(const DevModel *__rest
         constexpr int r = rc;
         for (int j = 0; j < 13; j++) s.template base_row<r>()[j] = base_[(size_t)(13 * r + j) * K + k];
     });
-    for (int f = 0; f < kMaxFree; f++)
+    for (int f = 0; f < kFreeSlots; f++)
         for (int j = 0; j < 13; j++) s.fr[f][j] = fr_[(size_t)(f * 13 + j) * K + k];
     float target[NB ? NB : 1], u[kMaxNu];
     const int g = cfg->k_offset + k;
@@ -1070,7 +1070,7 @@ __global__ __launch_bounds__(kWave) void k_sim_step_scene(const DevModel *__rest
         constexpr int r = rc;
         for (int j = 0; j < 13; j++) base_[(size_t)(13 * r + j) * K + k] = s.template base_row<r>()[j];
     });
-    for (int f = 0; f < kMaxFree; f++)
+    for (int f = 0; f < kFreeSlots; f++)
         for (int j = 0; j < 13; j++) fr_[(size_t)(f * 13 + j) * K + k] = s.fr[f][j];
     for (int j = 0; j < 3 * M.n_rb; j++) cf_[(size_t)j * K + k] = L[SceneLayout<T>::kCf + j];
 }
@@ -1112,7 +1112,7 @@ __global__ __launch_bounds__(kWave) void k_sim_step_scene_quad(const DevModel *_
         s.qd[i] = qd_[(size_t)i * K + k];
     });
     for (int j = 0; j < 13; j++) s.base[j] = base_[(size_t)j * K + k];
-    for (int f = 0; f < kMaxFree; f++)
+    for (int f = 0; f < kFreeSlots; f++)
         for (int j = 0; j < 13; j++) s.fr[f][j] = fr_[(size_t)(f * 13 + j) * K + k];
     float target[NB ? NB : 1], u[kMaxNu];
     const int g = cfg->k_offset + k;
@@ -1149,7 +1149,7 @@ __global__ __launch_bounds__(kWave) void k_sim_step_scene_quad(const DevModel *_
             qd_[(size_t)i * K + k] = s.qd[i];
         });
         for (int j = 0; j < 13; j++) base_[(size_t)j * K + k] = s.base[j];
-        for (int f = 0; f < kMaxFree; f++)
+        for (int f = 0; f < kFreeSlots; f++)
             for (int j = 0; j < 13; j++) fr_[(size_t)(f * 13 + j) * K + k] = s.fr[f][j];
         for (int j = 0; j < 3 * M.n_rb; j++) cf_[(size_t)j * K + k] = L[SceneLayout<T>::kCf + j];
         if (fb_dof != nullptr && k == 0) {
@@ -1160,7 +1160,7 @@ __global__ __launch_bounds__(kWave) void k_sim_step_scene_quad(const DevModel *_
             });
             for (int j = 0; j < 13 * M.n_actors; j++) fb_root[j] = x0_root[j];   // static actors: as the world holds them
             for (int j = 0; j < 13; j++) fb_root[13 * M.robot_actor + j] = s.base[j];
-            for (int f = 0; f < kMaxFree; f++)
+            for (int f = 0; f < kFreeSlots; f++)
                 if (f < M.n_free)
                     for (int j = 0; j < 13; j++) fb_root[13 * M.fr[f].actor + j] = s.fr[f][j];
         }
@@ -1191,7 +1191,7 @@ __global__ __launch_bounds__(kWave) void k_materialise_scene(const DevModel *__r
         constexpr int r = rc;
         for (int j = 0; j < 13; j++) s.template base_row<r>()[j] = base_[(size_t)(13 * r + j) * K + k];
     });
-    for (int f = 0; f < kMaxFree; f++)
+    for (int f = 0; f < kFreeSlots; f++)
         for (int j = 0; j < 13; j++) s.fr[f][j] = fr_[(size_t)(f * 13 + j) * K + k];
     const int A = M.n_actors, B = M.n_rb;
     scene_materialise<T>(M, x0_root, s, nullptr, root != nullptr ? root + (size_t)k * 13 * A : nullptr,
@@ -1209,7 +1209,7 @@ __global__ void k_sim_reset_scene(const DevModel *__restrict__ m, int K, const f
         const int actor = r == 0 ? m->robot_actor : m->xbase_actor[r - 1];
         for (int j = 0; j < 13; j++) base_[(size_t)(13 * r + j) * K + k] = x0_root[13 * actor + j];
     }
-    for (int f = 0; f < kMaxFree; f++)
+    for (int f = 0; f < kFreeSlots; f++)
         for (int j = 0; j < 13; j++) fr_[(size_t)(f * 13 + j) * K + k] = f < m->n_free ? x0_root[13 * m->fr[f].actor + j] : 0.f;
     for (int j = 0; j < 3 * m->n_rb; j++) cf_[(size_t)j * K + k] = 0.f;
 }
@@ -1218,7 +1218,7 @@ __global__ void k_root_from_world(const DevModel *__restrict__ m, const float *_
     const int j = threadIdx.x;
     if (j < 13) {
         for (int r = 0; r < m->n_bases; r++) x0_root[13 * (r == 0 ? m->robot_actor : m->xbase_actor[r - 1]) + j] = wbase[13 * r + j];
-        for (int f = 0; f < kMaxFree; f++)
+        for (int f = 0; f < kFreeSlots; f++)
             if (f < m->n_free) x0_root[13 * m->fr[f].actor + j] = wfr[f * 13 + j];
     }
 }
@@ -1535,9 +1535,18 @@ __global__ void k_state_from_world(int n, const float *__restrict__ wq, const fl
 
 }  // namespace
 
+// host hand-over block of a context (mapped pinned memory, ABI 8): [0] sequence number of the state mirror, [kIoCmd ...] a
+// ring of kIoCmdSlots commands of 16 floats (mppi_sim_step_host: the step kernel reads its command through the mapped pointer),
+// [kIoDof ...] the mirrored dof state (2n <= kIoDofFloats) followed by the root state (13 A) of a K = 1 world
+constexpr int kIoCmd = 16, kIoCmdSlots = 64, kIoDof = kIoCmd + 16 * kIoCmdSlots, kIoDofFloats = 32;
+constexpr int kIoFloats = kIoDof + kIoDofFloats + 13 * MPPI_MAX_ACTORS + 12;
+
 // ------------------------------------------------------------------------------ context
 struct mppi_ctx {
     int device = 0;
+    float *h_io = nullptr, *d_io = nullptr;  // the hand-over block and its device address
+    int free_slots = 2;  // free-actor slots of the scene kernels this context launches (TopoEntry.free_slots): sizes d_fr and the trajectory rows
+    unsigned io_cmd_next = 0, io_mirror_seq = 0;
     hipStream_t stream = nullptr;
     mppi_model_t model;
     mppi_config_t cfg;
@@ -1614,6 +1623,7 @@ struct TopoEntry {
     int nb;
     int parents[MPPI_MAX_BODIES];
     size_t scene_lds_floats;  // per-lane LDS floats of the contact-scene kernels, excluding 3 * n_rb
+    int free_slots;           // free-actor slots of the contact-scene kernels (kFreeSlots of the unit that filled them; 0: none filled)
     void (*rollout)(mppi_ctx *);
     void (*rollout_quad)(mppi_ctx *);
     void (*rollout_oct)(mppi_ctx *);        // contact-free scenes, octet layout of the solve (8 lanes per sample)
@@ -1672,7 +1682,7 @@ void launch_rollout_scene_quad_t(mppi_ctx *c) {
 // octet layout with a helper wavefront per sample group (short trees: kSplitOctPair)
 template <class T>
 size_t pair_lds_bytes(const mppi_ctx *c) {
-    const size_t row = c->lds_bytes_quad / 16 + sizeof(float) * ((size_t)SceneLayout<T>::NF * 27 + 3 * (size_t)c->hm.n_rb + 2 + 6 * kMaxFree + scene_park_floats<T>());
+    const size_t row = c->lds_bytes_quad / 16 + sizeof(float) * ((size_t)SceneLayout<T>::NF * 27 + 3 * (size_t)c->hm.n_rb + 2 + 6 * kFreeSlots + scene_park_floats<T>());
     return row * (kWave / 8) + c->lds_bytes_table;
 }
 template <class T>
@@ -1689,7 +1699,7 @@ template <class T>
 void launch_rollout_scene_traj_t(mppi_ctx *c) {
     if constexpr (T::NB <= 4) {  // short trees: the kernel with the helper wavefront (pair_lds_bytes is defined below)
         if (c->helper_wave) {
-            const size_t row = c->lds_bytes_quad / 16 + sizeof(float) * ((size_t)SceneLayout<T>::NF * 27 + 3 * (size_t)c->hm.n_rb + 2 + 6 * kMaxFree + scene_park_floats<T>());
+            const size_t row = c->lds_bytes_quad / 16 + sizeof(float) * ((size_t)SceneLayout<T>::NF * 27 + 3 * (size_t)c->hm.n_rb + 2 + 6 * kFreeSlots + scene_park_floats<T>());
             hipLaunchKernelGGL((k_rollout_scene_quad<T, 8, 2, true>), dim3(c->n_quads), dim3(2 * kWave), row * (kWave / 8) + c->lds_bytes_table, c->stream, c->d_model, c->d_cfg, c->d_cost_none,
                                c->d_x0_dof, c->d_x0_root, c->d_U, c->eps_in, c->has_prior ? c->d_prior : nullptr, c->d_du, c->d_S, (float *)nullptr,
                                c->d_partials, (unsigned *)nullptr, c->fold_out, (unsigned long long *)nullptr, c->d_traj);
@@ -1711,7 +1721,7 @@ void launch_rollout_scene_traj_t(mppi_ctx *c) {
 template <class T>
 void launch_materialise_scene_traj_t(mppi_ctx *c, float *dof, float *root, float *rb, float *cf) {
     const size_t HK = (size_t)c->H * c->K;
-    float *q = c->d_traj, *qd = q + (size_t)T::NB * HK, *base = qd + (size_t)T::NB * HK, *fr = base + 13 * HK, *cfr = fr + (size_t)13 * kMaxFree * HK;
+    float *q = c->d_traj, *qd = q + (size_t)T::NB * HK, *base = qd + (size_t)T::NB * HK, *fr = base + 13 * HK, *cfr = fr + (size_t)13 * kFreeSlots * HK;
     hipLaunchKernelGGL(k_materialise_scene<T>, dim3((unsigned)((HK + kWave - 1) / kWave)), dim3(kWave), 0, c->stream, c->d_model, (int)HK, c->d_x0_root, q, qd, base,
                        fr, cfr, dof, root, rb, cf);
 }
@@ -1873,6 +1883,7 @@ void fill_topo_entry_free(TopoEntry &e) {
 template <class T>
 void fill_topo_entry_scene(TopoEntry &e) {
     e.scene_lds_floats = (size_t)SceneLayout<T>::kCf;
+    e.free_slots = kFreeSlots;
     e.rollout_scene = &launch_rollout_scene_t<T>;
     e.rollout_scene_quad = &launch_rollout_scene_quad_t<T, 4>;
     e.rollout_scene_oct = &launch_rollout_scene_quad_t<T, 8>;

@@ -168,7 +168,7 @@ MPPI_HD PairGeom tab_pair_geom(M &m, const LMem &L, int ip) {
 
 template <class T>
 struct SceneLayout {
-    static constexpr int NF = T::NB + T::NBASE + kMaxFree;  // dynamic frames: bodies, bases (one per tree of a moving-base forest), free actors
+    static constexpr int NF = T::NB + T::NBASE + kFreeSlots;  // dynamic frames: bodies, bases (one per tree of a moving-base forest), free actors
     static constexpr int kFrame = 0;                 // [NF][18]: R(9) p(3) w(3) vO(3)
     static constexpr int kAcc = NF * 18;             // [NF][27]: f(6) C(21)
     static constexpr int kCf = kAcc + NF * 27;       // [n_rb][3] net contact force
@@ -246,11 +246,11 @@ MPPI_HD int scene_row_floats(M &m) { return SceneLayout<T>::floats(m.n_rb, m.n_r
 // the accelerations of the free actors it solves (6 each, at xch + 2)
 // ... and the region in which the owner parks the sample's state during the pair walk (q, qd, base row, free actors' rows)
 template <class T>
-constexpr int scene_park_floats() { return 2 * T::NB + 13 + 13 * kMaxFree + (T::NB ? T::NB : 1) + 3; }  // + drive targets, + S / ctrl / disc of the rollout
+constexpr int scene_park_floats() { return 2 * T::NB + 13 + 13 * kFreeSlots + (T::NB ? T::NB : 1) + 3; }  // + drive targets, + S / ctrl / disc of the rollout
 template <class T, class M>
-MPPI_HD int scene_pair_floats(M &m) { return SceneLayout<T>::NF * 27 + 3 * m.n_rb + 2 + 6 * kMaxFree + scene_park_floats<T>(); }
+MPPI_HD int scene_pair_floats(M &m) { return SceneLayout<T>::NF * 27 + 3 * m.n_rb + 2 + 6 * kFreeSlots + scene_park_floats<T>(); }
 
-constexpr int scene_floats_max(int nb) { return (nb + 1 + kMaxFree) * 45 + 3 * (kMaxLinks + kMaxActors); }
+constexpr int scene_floats_max(int nb) { return (nb + 1 + kFreeSlots) * 45 + 3 * (kMaxLinks + kMaxActors); }
 
 // dynamic frame of free actor f / of base r
 template <class T>
@@ -262,7 +262,7 @@ struct SceneState {
     float xbase[T::NBASE > 1 ? T::NBASE - 1 : 1][13];  // ... of the further moving-base robots of the env (one-lane kernels only)
     template <int r> MPPI_HD float *base_row() { if constexpr (r == 0) return base; else return xbase[r - 1]; }
     template <int r> MPPI_HD const float *base_row() const { if constexpr (r == 0) return base; else return xbase[r - 1]; }
-    float fr[kMaxFree][13];   // free actors' root rows
+    float fr[kFreeSlots][13];   // free actors' root rows
     // accumulator rows (per dynamic frame) and net-contact-force rows (per rigid body, when there are <= 32 of them)
     // that the previous contact pass wrote: only those are cleared by the next pass.  All ones = "clear everything"
     // (fresh LDS: start of a rollout, every launch of the step kernels).
@@ -1488,7 +1488,7 @@ MPPI_HD void scene_frames(M &m, const float *root, const SceneState<T> &s, Pose<
         constexpr int r = rc;
         frame_store(L, NB + r, P.template base_R<r>(), P.template base_p<r>(), vbase.r[r]);
     });
-    for (int f = 0; f < kMaxFree; f++)
+    for (int f = 0; f < kFreeSlots; f++)
         if (f < m.n_free) {
             const float *rs = s.fr[f];
             V3 p = loadv(rs), w = loadv(rs + 10), vl = loadv(rs + 7);
@@ -1549,7 +1549,7 @@ MPPI_HD SV free_body_accel(M &m, int f, const LMem &L, float h, int set1 = 0) {
 template <class T, class M>
 __device__ __forceinline__ void helper_free_bodies(M &m, const LMem &L, Split split) {
     const float h = m.h;
-    for (int f = 0; f < kMaxFree; f++)
+    for (int f = 0; f < kFreeSlots; f++)
         if (f < m.n_free) {
             const SV a = free_body_accel<T>(m, f, L, h, L.set1);
             if (split.sub == 0) {
@@ -1562,7 +1562,7 @@ __device__ __forceinline__ void helper_free_bodies(M &m, const LMem &L, Split sp
 #endif
 template <class T, class M>
 MPPI_HD void step_free_bodies(M &m, SceneState<T> &s, const LMem &L, float h) {
-    for (int f = 0; f < kMaxFree; f++)
+    for (int f = 0; f < kFreeSlots; f++)
         if (f < m.n_free) root_integrate(s.fr[f], free_body_accel<T>(m, f, L, h), h);
 }
 
@@ -1586,7 +1586,7 @@ MPPI_HD void state_park(const SceneState<T> &s, int n_free, const LMem &L, bool 
     o += 2 * NB;
     for (int j = 0; j < 13; j++) L[o + j] = s.base[j];
     o += 13;
-    for (int f = 0; f < kMaxFree; f++)
+    for (int f = 0; f < kFreeSlots; f++)
         if (f < n_free)
             for (int j = 0; j < 13; j++) L[o + 13 * f + j] = s.fr[f][j];
 }
@@ -1602,7 +1602,7 @@ MPPI_HD void state_unpark(SceneState<T> &s, int n_free, const LMem &L) {
     o += 2 * NB;
     for (int j = 0; j < 13; j++) s.base[j] = L[o + j];
     o += 13;
-    for (int f = 0; f < kMaxFree; f++)
+    for (int f = 0; f < kFreeSlots; f++)
         if (f < n_free)
             for (int j = 0; j < 13; j++) s.fr[f][j] = L[o + 13 * f + j];
 }
@@ -1643,7 +1643,7 @@ MPPI_HD void step_scene(M &m0, const float *root, SceneState<T> &s, const float 
 #else
         constexpr bool kPark = SPLIT == kSplitOctPair;
 #endif
-        constexpr int kParkTarget = 2 * NB + 13 + 13 * kMaxFree;  // (behind the state, see scene_park_floats)
+        constexpr int kParkTarget = 2 * NB + 13 + 13 * kFreeSlots;  // (behind the state, see scene_park_floats)
         float tgt[NB ? NB : 1];
         if constexpr (kPark) {
             state_park<T>(s, m.n_free, L, split.sub == 0);
@@ -1700,7 +1700,7 @@ MPPI_HD void step_scene(M &m0, const float *root, SceneState<T> &s, const float 
         if constexpr (SPLIT == kSplitOctPair) {
             // the helper wavefront has solved the free actors while this one solved the robot (helper_free_bodies)
             MPPI_BARRIER(4);
-            for (int f = 0; f < kMaxFree; f++)
+            for (int f = 0; f < kFreeSlots; f++)
                 if (f < m.n_free) {
                     const int o = L.xch + 2 + 6 * f;
                     root_integrate(s.fr[f], SV{{L[o], L[o + 1], L[o + 2]}, {L[o + 3], L[o + 4], L[o + 5]}}, h);
@@ -1725,7 +1725,7 @@ MPPI_HD void scene_init(M &m, const float *dof0, const float *root, SceneState<T
         constexpr int r = rc;
         for (int j = 0; j < 13; j++) s.template base_row<r>()[j] = root[13 * base_actor<r>(m) + j];
     });
-    for (int f = 0; f < kMaxFree; f++)
+    for (int f = 0; f < kFreeSlots; f++)
         for (int j = 0; j < 13; j++) s.fr[f][j] = f < m.n_free ? root[13 * m.fr[f].actor + j] : 0.f;
 }
 
@@ -1744,7 +1744,7 @@ MPPI_HD float stage_cost_scene_link(M &m, CCost &c, const float *root, const Sce
     if (c.kind == kCostBoxerPush) {
         // block = free actor (looked up by actor id), goal = static actor
         float bx = 0.f, by = 0.f, bvx = 0.f, bvy = 0.f, byaw = 0.f;
-        for (int f = 0; f < kMaxFree; f++)
+        for (int f = 0; f < kFreeSlots; f++)
             if (f < m.n_free && m.fr[f].actor == c.actor[0]) {
                 bx = s.fr[f][0]; by = s.fr[f][1]; bvx = s.fr[f][7]; bvy = s.fr[f][8];
                 byaw = quat_yaw(s.fr[f] + 3);
@@ -1762,7 +1762,7 @@ MPPI_HD float stage_cost_scene_link(M &m, CCost &c, const float *root, const Sce
     // PANDA_PICK, examples/panda_pick/planner.py:24-53: link[0] = panda_ee, link[1] = table rigid body, actor[0] = block,
     // actor[1] = goal; w = {robot_to_block, block_to_goal, collision, robot_ori}
     V3 b = {0.f, 0.f, 0.f};
-    for (int f = 0; f < kMaxFree; f++)
+    for (int f = 0; f < kFreeSlots; f++)
         if (f < m.n_free && m.fr[f].actor == c.actor[0]) b = loadv(s.fr[f]);
     const V3 g = loadv(root + 13 * c.actor[1]);
     const V3 drb = r - b, dbg = b - g;
@@ -1785,7 +1785,7 @@ struct SceneEnv {
         if (actor == m.robot_actor && m.floating) v = s.base[j];
         if constexpr (T::NBASE > 1)
             static_for<1, T::NBASE>([&](auto rc) MPPI_LAMBDA { if (actor == m.xbase_actor[rc - 1]) v = s.xbase[rc - 1][j]; });
-        for (int f = 0; f < kMaxFree; f++)
+        for (int f = 0; f < kFreeSlots; f++)
             if (f < m.n_free && m.fr[f].actor == actor) v = s.fr[f][j];
         return v;
     }
@@ -1794,7 +1794,7 @@ struct SceneEnv {
         if (actor == m.robot_actor && m.floating) o = loadv(s.base + off);
         if constexpr (T::NBASE > 1)
             static_for<1, T::NBASE>([&](auto rc) MPPI_LAMBDA { if (actor == m.xbase_actor[rc - 1]) o = loadv(s.xbase[rc - 1] + off); });
-        for (int f = 0; f < kMaxFree; f++)
+        for (int f = 0; f < kFreeSlots; f++)
             if (f < m.n_free && m.fr[f].actor == actor) o = loadv(s.fr[f] + off);
         return o;
     }
@@ -1807,7 +1807,7 @@ struct SceneEnv {
                 if (actor == m.xbase_actor[rc - 1])
                     for (int j = 0; j < 4; j++) qq[j] = s.xbase[rc - 1][3 + j];
             });
-        for (int f = 0; f < kMaxFree; f++)
+        for (int f = 0; f < kFreeSlots; f++)
             if (f < m.n_free && m.fr[f].actor == actor)
                 for (int j = 0; j < 4; j++) qq[j] = s.fr[f][3 + j];
     }
@@ -1878,7 +1878,7 @@ MPPI_HD void step_scene_any(M &m, MR &mr, const float *root, SceneState<T> &s, c
 
 // mr0: view of the same model for the robot algebra of the quad path (an LDS copy of the model prefix in the kernel)
 // DUMP: the env state after every step goes to `traj` as well, in the sample-minor layout of the simulator's state arrays with
-// H*K columns (column t*K + k): q [NB], qd [NB], base [13], free actors [kMaxFree*13], net contact forces [3*n_rb] - the generic
+// H*K columns (column t*K + k): q [NB], qd [NB], base [13], free actors [kFreeSlots*13], net contact forces [3*n_rb] - the generic
 // Objective mode evaluates Python costs on the materialised trajectory (mppi_rollout_trajectory).
 template <class T, int SPLIT = kSplitNone, bool DUMP = false, class M = CModel, class MR = CModel>
 MPPI_HD float rollout_scene(M &m0, MR &mr0, CCfg &cfg0, CCost &cost0, const float *dof0, const float *root, const float *U, const float *eps,
@@ -1905,7 +1905,7 @@ MPPI_HD float rollout_scene(M &m0, MR &mr0, CCfg &cfg0, CCost &cost0, const floa
         else cmd_map<T>(mr0, u, target);  // (the kernel's LDS copy of the robot part: no scalar-cache round trips)
         MPPI_SEC(8);
         constexpr bool kParkSums = SPLIT == kSplitOctPair;  // (the helper-wavefront kernel: everything that idles during a step is parked)
-        constexpr int kParkSumsAt = 2 * NB + 13 + 13 * kMaxFree + (NB ? NB : 1);
+        constexpr int kParkSumsAt = 2 * NB + 13 + 13 * kFreeSlots + (NB ? NB : 1);
         if constexpr (kParkSums)
             if (leader) { L[L.park + kParkSumsAt] = S; L[L.park + kParkSumsAt + 1] = ctrl; L[L.park + kParkSumsAt + 2] = disc; }
         step_scene_any<T, SPLIT>(*mp, mr0, root, s, target, L, split);
@@ -1940,9 +1940,9 @@ MPPI_HD float rollout_scene(M &m0, MR &mr0, CCfg &cfg0, CCost &cost0, const floa
                 o += (size_t)2 * NB * HK;
                 for (int j = 0; j < 13; j++) o[(size_t)j * HK] = s.base[j] + (j == 0 ? L.ox : (j == 1 ? L.oy : 0.f));
                 o += (size_t)13 * HK;
-                for (int f = 0; f < kMaxFree; f++)
+                for (int f = 0; f < kFreeSlots; f++)
                     for (int j = 0; j < 13; j++) o[(size_t)(f * 13 + j) * HK] = s.fr[f][j] + (j == 0 ? L.ox : (j == 1 ? L.oy : 0.f));
-                o += (size_t)13 * kMaxFree * HK;
+                o += (size_t)13 * kFreeSlots * HK;
                 const int n_cf = 3 * launder(mp)->n_rb;
                 for (int j = 0; j < n_cf; j++) o[(size_t)j * HK] = L[SceneLayout<T>::kCf + j];
             }
@@ -1965,7 +1965,7 @@ MPPI_HD void scene_materialise(M &m, const float *root, const SceneState<T> &s, 
             constexpr int r = rc;
             for (int j = 0; j < 13; j++) root_out[13 * base_actor<r>(m) + j] = s.template base_row<r>()[j];
         });
-        for (int f = 0; f < kMaxFree; f++)
+        for (int f = 0; f < kFreeSlots; f++)
             if (f < m.n_free)
                 for (int j = 0; j < 13; j++) root_out[13 * m.fr[f].actor + j] = s.fr[f][j];
     }
@@ -1995,7 +1995,7 @@ MPPI_HD void scene_materialise(M &m, const float *root, const SceneState<T> &s, 
             float *o = rb + 13 * m.actor_first_rb[a];
             for (int j = 0; j < 13; j++) o[j] = root[13 * a + j];
         }
-        for (int f = 0; f < kMaxFree; f++)
+        for (int f = 0; f < kFreeSlots; f++)
             if (f < m.n_free) {
                 float *o = rb + 13 * m.fr[f].rb;
                 for (int j = 0; j < 13; j++) o[j] = s.fr[f][j];

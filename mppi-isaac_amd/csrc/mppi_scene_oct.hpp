@@ -298,7 +298,7 @@ __device__ __forceinline__ void step_scene_oct(M &m0, MR &mr0, const float *root
             });
             const QSV vb0 = {qrep(0.f), qrep(0.f)};
             qframe_store(L, NB, P.rot_base(), P.pos_base(), vb0);
-            for (int f = 0; f < kMaxFree; f++)
+            for (int f = 0; f < kFreeSlots; f++)
                 if (f < m.n_free) {
                     const float *rs = s.fr[f];
                     V3 p = loadv(rs), w3 = loadv(rs + 10), vl = loadv(rs + 7);

@@ -339,7 +339,7 @@ MPPI_HD void step_scene_quad(M &m0, MR &mr0, const float *root, SceneState<T> &s
                 qframe_store(L, i, P.rot(i), P.pos(i), v[i]);
             });
             qframe_store(L, NB, P.rot_base(), P.pos_base(), vbase);
-            for (int f = 0; f < kMaxFree; f++)
+            for (int f = 0; f < kFreeSlots; f++)
                 if (f < m.n_free) {
                     const float *rs = s.fr[f];
                     V3 p = loadv(rs), w = loadv(rs + 10), vl = loadv(rs + 7);

@@ -9,10 +9,10 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-MAX_BODIES, MAX_LINKS, MAX_ACTORS, MAX_NU, MAX_H, MAX_KNOTS, MAX_COST_W = 12, 24, 8, 12, 64, 16, 16
-MAX_SHAPES, MAX_PAIRS, MAX_FREE, MAX_EXTRA_BASES = 40, 48, 2, 3
+MAX_BODIES, MAX_LINKS, MAX_ACTORS, MAX_NU, MAX_H, MAX_KNOTS, MAX_COST_W = 12, 24, 12, 12, 64, 16, 16
+MAX_SHAPES, MAX_PAIRS, MAX_FREE, MAX_EXTRA_BASES = 56, 96, 4, 3
 SHAPE_BOX, SHAPE_SPHERE, SHAPE_DISC = 0, 1, 2
-ABI_VERSION = 7
+ABI_VERSION = 8
 # error codes of include/mppi_hip.h
 MPPI_OK, MPPI_EINVAL, MPPI_EHIP, MPPI_EUNSUPPORTED, MPPI_ESTATE = 0, -1, -2, -3, -4
 
@@ -94,6 +94,7 @@ _SIGNATURES = {
     "mppi_abi_version": (C.c_int, []),
     "mppi_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "mppi_create": (C.c_int, [C.POINTER(Model), C.POINTER(Config), C.c_int, C.POINTER(_vp)]),
+    "mppi_jit_info": (C.c_int, [C.c_char_p, C.c_int]),
     "mppi_destroy": (C.c_int, [_vp]),
     "mppi_set_stream": (C.c_int, [_vp, _vp]),
     "mppi_synchronize": (C.c_int, [_vp]),
@@ -143,6 +144,9 @@ _SIGNATURES = {
     "mppi_sim_reset": (C.c_int, [_vp]),
     "mppi_sim_step": (C.c_int, [_vp, _vp, C.c_int]),
     "mppi_sim_step_horizon": (C.c_int, [_vp, C.c_int]),
+    "mppi_sim_step_host": (C.c_int, [_vp, _fp]),
+    "mppi_mirror_state": (C.c_int, [_vp, _vp, _vp]),
+    "mppi_mirror_wait": (C.c_int, [_vp, _fp, _fp]),
     "mppi_sim_materialise": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "mppi_sim_accumulate_cost": (C.c_int, [_vp, C.c_int, _vp]),
     "mppi_sim_finish": (C.c_int, [_vp]),

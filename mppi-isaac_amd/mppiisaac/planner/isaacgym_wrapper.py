@@ -118,6 +118,10 @@ def merge_robots(env_cfg: List["ActorWrapper"], robots: List[int], models: List[
         a = env_cfg[i]
         if a.dof_mode != env_cfg[robots[0]].dof_mode:
             raise ValueError("All robots must have the same dof_mode")        # (reference :541-542)
+        if bool(a.gravity) != bool(env_cfg[robots[0]].gravity):
+            # the kernels apply gravity to the whole forest from ONE flag (DevModel.gravity_on, the first robot's); the reference
+            # sets disable_gravity per actor (isaacgym_utils.py:17-18) - refused rather than silently different
+            raise NotImplementedError("several robots per env: the robots of an env must agree on `gravity`")
     if robots != list(range(robots[0], robots[0] + len(robots))):
         raise NotImplementedError("several robots per env: list the robot actors next to each other (their rigid-body rows form one block)")
     if all(moving) and len(robots) > 1 + capi.MAX_EXTRA_BASES:
@@ -205,6 +209,7 @@ class Scene:
                 self.rb_names.append((a.name, a.type))  # primitive bodies are named "box"/"sphere"
         self.n_rb = len(self.rb_names)
         self.cmd_terms, self.nu = self._command_map()
+        self._report_deviations()
         self.shapes, self.pairs = self._contact_scene()
         self.randomize_seed = -1  # >= 0: per-sample size/mass/friction draws of the noisy box/sphere actors
 
@@ -235,6 +240,22 @@ class Scene:
                     terms.append(((idx, 1.0), (0, 0.0)))
                     idx += 1
         return terms, idx
+
+    def _report_deviations(self):
+        """behaviour that differs from what the reference's code literally does ("Known deviations"): said once
+        per process and kind, like the pruned links of merge_robots"""
+        notes = []
+        if sum(1 for i in self.robot_ids if self.env_cfg[i].differential_drive) > 1:
+            notes.append(("multi-diff-drive", "several differential-drive robots in one env: every robot takes its OWN (v, yaw rate) pair of the command; the "
+                                              "reference hands u[:, :2] to each of them (isaacgym_wrapper.py:545-559)"))
+        if self.robot.dof_mode == "position":
+            notes.append(("position-mode", "dof_mode 'position': the command overwrites q (qd <- 0) at every step and is then HELD by a stiffness drive "
+                                           "(kp = 80); the reference writes a half-size tensor with set_dof_state_tensor and sets no position target "
+                                           "(isaacgym_wrapper.py:501-504,571-572)"))
+        for key, text in notes:
+            if key not in _REPORTED_DROPS:
+                _REPORTED_DROPS.add(key)
+                logging.getLogger("mppiisaac").warning("known deviation from the reference: %s", text)
 
     def _actor_of_body(self, body: int) -> int:
         """robot actor that owns moving body `body` (the owner of the links welded to it)"""
@@ -558,6 +579,7 @@ class IsaacGymWrapper:
         # compute_action_tensor is set_state -> rollout with no [K, ...] tensor written
         self._state_t = {"dof": torch.zeros((K, 2 * n), **f32), "root": torch.zeros((K, A, 13), **f32),
                          "rb": torch.zeros((K, B, 13), **f32), "cf": torch.zeros((K, B, 3), **f32)}
+        self._state_t_own = self._state_t
         self._stale, self._needs_reset = True, False
         self._visualize_link_present = sc.viz_link_index() >= 0
         self.visualize_link_buffer = []
@@ -567,9 +589,24 @@ class IsaacGymWrapper:
         self.obstacle_indices = torch.tensor(
             [i for i, a in enumerate(self.env_cfg) if (a.type in ["sphere", "box"] and a.name != "dummy")], device=self.device)
         self._pending_cmd = None
+        self._pending_host = None
+        # The K = 1 "world" (reference examples/<x>/world.py) hands its state to the planner as torch.save blobs every control
+        # iteration: the library mirrors dof / root into mapped host memory right behind the kernel that materialises them, and
+        # `torch_to_bytes(sim._dof_state)` takes its payload from there - no device-to-host copy, no synchronise (utils/transport.py)
+        self._mirror = None
+        if self.num_envs == 1:
+            from mppiisaac.utils.transport import register_host_mirror
+            self._mirror = {"dof": np.zeros(2 * n, np.float32), "root": np.zeros(13 * A, np.float32), "fresh": False, "versions": None}
+            register_host_mirror(self._state_t["dof"], lambda: self._mirrored("dof"))
+            register_host_mirror(self._state_t["root"], lambda: self._mirrored("root"))
         self.reset_to_initial_poses()
 
     def stop_sim(self):
+        if getattr(self, "_mirror", None) is not None:
+            from mppiisaac.utils.transport import unregister_host_mirror
+            for k in ("dof", "root"):
+                unregister_host_mirror(self._state_t[k])
+            self._mirror = None
         if getattr(self, "_ctx", None):
             self._lib.mppi_destroy(self._ctx)
             self._ctx = None
@@ -602,6 +639,21 @@ class IsaacGymWrapper:
         t = self._state_t
         capi.check(self._lib, self._lib.mppi_sim_materialise(self._ctx, _dev_ptr(t["dof"]), _dev_ptr(t["root"]), _dev_ptr(t["rb"]), _dev_ptr(t["cf"])))
         self._stale = False
+        m = self._mirror
+        if m is not None and t is self._state_t_own:
+            capi.check(self._lib, self._lib.mppi_mirror_state(self._ctx, _dev_ptr(t["dof"]), _dev_ptr(t["root"])))
+            m["fresh"], m["versions"] = False, (t["dof"]._version, t["root"]._version)
+
+    def _mirrored(self, key):
+        """host copy of the K = 1 world's dof / root state tensor as the last materialise left it (None: the tensor has been
+        written to since - the caller copies it from the device instead)"""
+        m, t = self._mirror, self._state_t_own
+        if m is None or m["versions"] != (t["dof"]._version, t["root"]._version):
+            return None
+        if not m["fresh"]:
+            capi.check(self._lib, self._lib.mppi_mirror_wait(self._ctx, capi.fptr(m["dof"]), capi.fptr(m["root"])))
+            m["fresh"] = True
+        return m[key]
 
     def _fresh(self, key):
         if self._stale:
@@ -635,8 +687,9 @@ class IsaacGymWrapper:
     def set_state_from_env0(self, dof_state: torch.Tensor, root_state: torch.Tensor):
         """reset_rollout_sim path (reference mppi_isaac.py:87-99): a [1,2n] / [1,A,13] world state is
         broadcast to every env.  Only the single state crosses to the device."""
-        self._push_single_state(dof_state.detach().reshape(-1)[: 2 * self.scene.n_dof].cpu().numpy(),
-                                root_state.detach().reshape(-1, 13)[: len(self.env_cfg)].cpu().numpy())
+        if isinstance(dof_state, torch.Tensor):
+            dof_state, root_state = dof_state.detach().cpu().numpy(), root_state.detach().cpu().numpy()
+        self._push_single_state(dof_state.reshape(-1)[: 2 * self.scene.n_dof], root_state.reshape(-1)[: 13 * len(self.env_cfg)])
 
     def reset_robot_state(self, q, qdot):
         """reference :574-619 (urdfenvs compatibility): q, qdot lists -> interleaved DOF state in all envs."""
@@ -690,12 +743,20 @@ class IsaacGymWrapper:
     def apply_robot_cmd(self, u_desired: torch.Tensor):
         """Latch the command for the next step().  [nu] applies to all envs, [K,nu] per env.  The
         scatter to DOF targets incl. the diff-drive map happens in the step kernel (reference :524-572)."""
+        if not (isinstance(u_desired, torch.Tensor) and u_desired.is_cuda):
+            # ONE command that lives on the host (what the world loop of the reference's examples applies: the planner's action as it
+            # came off the wire, examples/<x>/world.py:42): it stays there - step() hands it to the step kernel through the
+            # context's mapped host block instead of a host-to-device copy
+            h = np.ascontiguousarray(u_desired.detach().numpy() if isinstance(u_desired, torch.Tensor) else u_desired, dtype=np.float32)
+            if h.size == self.scene.nu and h.ndim <= 2:
+                self._pending_host, self._pending_cmd = h.reshape(-1), None
+                return
         u = torch.as_tensor(u_desired, dtype=torch.float32, device=self.device)
         if u.dim() == 1:
             u = u.unsqueeze(0)
         if u.shape[-1] != self.scene.nu:
             raise ValueError(f"command has {u.shape[-1]} entries, expected {self.scene.nu}")
-        self._pending_cmd = u.contiguous()
+        self._pending_cmd, self._pending_host = u.contiguous(), None
 
     # per-DOF targets set directly (reference :402-406; used by examples/*/tuning.py and examples/anymal/world.py).  The step
     # kernels take COMMANDS (nu columns, scattered by the command map), so these are available where one command drives
@@ -715,6 +776,13 @@ class IsaacGymWrapper:
         self._latch_dof_targets(u, "effort")
 
     def step(self):
+        if self._pending_host is not None:   # one command for every env, still on the host
+            self._reset_envs_if_needed()
+            capi.check(self._lib, self._lib.mppi_sim_step_host(self._ctx, capi.fptr(self._pending_host)))
+            self._stale = True
+            if self._visualize_link_present:
+                self.visualize_link_buffer.append(self.visualize_link_pos.clone())
+            return
         u = self._pending_cmd
         if u is None:
             u = torch.zeros((1, self.scene.nu), dtype=torch.float32, device=self.device)

@@ -9,7 +9,7 @@ import torch
 
 from mppiisaac.planner.isaacgym_wrapper import IsaacGymWrapper
 from mppiisaac.planner.mppi import MPPIPlanner, make_config
-from mppiisaac.utils.transport import bytes_to_torch, torch_to_bytes
+from mppiisaac.utils.transport import bytes_to_array, torch_to_bytes
 
 
 class MPPIisaacPlanner(object):
@@ -85,7 +85,8 @@ class MPPIisaacPlanner(object):
 
     def reset_rollout_sim(self, dof_state_tensor, root_state_tensor, rigid_body_state_tensor=None):
         self.sim.visualize_link_buffer = []
-        self.sim.set_state_from_env0(bytes_to_torch(dof_state_tensor, map_location="cpu"), bytes_to_torch(root_state_tensor, map_location="cpu"))
+        # (only the numbers are needed: the payloads are viewed in place, nothing is restored onto the device the blob names)
+        self.sim.set_state_from_env0(bytes_to_array(dof_state_tensor), bytes_to_array(root_state_tensor))
 
     def compute_action_tensor(self, dof_state_tensor, root_state_tensor):
         self.objective.reset()

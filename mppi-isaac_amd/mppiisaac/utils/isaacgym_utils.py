@@ -29,8 +29,27 @@ def load_actor_cfgs(actors: List[str]) -> List[ActorWrapper]:
     return actor_cfgs
 
 
+_COMPILED_AT_RUN_TIME = {}   # (urdf path, mtime) -> compiled model
+
+
+def _find_urdf(urdf_file: str):
+    """where gym.load_asset would look (reference isaacgym_utils.py:14-29: asset root <repo>/assets/urdf + urdf_file): an absolute
+    path, $MPPI_URDF_ROOT/<urdf_file>, <package>/assets/urdf/<urdf_file>"""
+    if not urdf_file:
+        return None
+    for cand in (urdf_file if os.path.isabs(urdf_file) else None,
+                 os.path.join(os.environ["MPPI_URDF_ROOT"], urdf_file) if os.environ.get("MPPI_URDF_ROOT") else None,
+                 os.path.join(PKG_ROOT, "assets", "urdf", urdf_file)):
+        if cand and os.path.isfile(cand):
+            return cand
+    return None
+
+
 def load_asset(actor_cfg: ActorWrapper) -> dict:
-    """Compiled model of a robot actor, looked up by its `urdf_file`."""
+    """Model of a robot actor from its `urdf_file` - the counterpart of gym.load_asset (reference isaacgym_utils.py:14-29): the
+    compiled fixture under assets/compiled/ when there is one for that URDF, otherwise the URDF itself is compiled HERE, at run
+    time (mppiisaac.backend.urdf_compile: tree, frames, inertias from <inertial> or collision hulls, collision primitives).  The
+    kernels of a kinematic tree the library has not seen are built on demand by mppi_create (include/mppi_hip.h)."""
     if actor_cfg.type != "robot":
         raise NotImplementedError("only robot actors have a compiled asset; boxes/spheres are described by the actor cfg")
     for path in sorted(glob.glob(os.path.join(COMPILED_DIR, "*.json"))):
@@ -38,9 +57,21 @@ def load_asset(actor_cfg: ActorWrapper) -> dict:
             model = json.load(f)
         if model.get("urdf_file") == actor_cfg.urdf_file:
             return model
-    raise FileNotFoundError(
-        f"no compiled model for urdf_file='{actor_cfg.urdf_file}' under {COMPILED_DIR}; compile it with "
-        "mppiisaac.backend.urdf_compile.compile_urdf (tools/compile_models.py) and rebuild the HIP library")
+    urdf = _find_urdf(actor_cfg.urdf_file)
+    if urdf is None:
+        raise FileNotFoundError(
+            f"urdf_file='{actor_cfg.urdf_file}': no compiled model under {COMPILED_DIR} and no such URDF (absolute path, "
+            "$MPPI_URDF_ROOT/<urdf_file>, <package>/assets/urdf/<urdf_file>)")
+    key = (urdf, os.path.getmtime(urdf))
+    if key not in _COMPILED_AT_RUN_TIME:
+        from mppiisaac.backend import capi
+        from mppiisaac.backend.urdf_compile import compile_urdf, prune_links
+        model = compile_urdf(urdf)
+        if len(model["links"]) > capi.MAX_LINKS:   # more URDF links than reported rigid-body rows: keep the observable ones
+            model = prune_links(model, keep=[actor_cfg.visualize_link] if actor_cfg.visualize_link else ())
+        model["urdf_file"] = actor_cfg.urdf_file
+        _COMPILED_AT_RUN_TIME[key] = model
+    return _COMPILED_AT_RUN_TIME[key]
 
 
 def add_ground_plane(gym=None, sim=None) -> None:

@@ -52,7 +52,11 @@ try:  # pragma: no cover - not present in this image
 except ImportError:
     _zerorpc = None
 
-MAX_FRAME = 1 << 31
+MAX_FRAME = 1 << 28        # 256 MiB: far above the largest real payload (torch.save blobs of state / rollout tensors), far below what
+                           # an unauthenticated peer may make this process allocate with a nine-byte header
+FRAME_TIMEOUT = 30.0       # [s] a frame whose first byte has arrived must arrive whole within this time (half-sent frames do not pin memory)
+MAX_CONNECTIONS = 32       # concurrent peers of one server (one thread each)
+_CHUNK = 1 << 20
 HEARTBEAT = 5.0        # zerorpc's default heartbeat period [s]
 
 # ---------------------------------------------------------------------------------------------- ZMTP 3.0
@@ -119,10 +123,13 @@ class ZmtpConnection:
 
     # -- raw
     def _recv_exact(self, n: int) -> bytes:
-        buf = bytearray(n)
-        view, got = memoryview(buf), 0
+        # the buffer GROWS with the bytes received (1 MiB at a time): the announced length alone allocates nothing
+        buf = bytearray(min(n, _CHUNK))
+        got = 0
         while got < n:
-            r = self.sock.recv_into(view[got:], n - got)
+            if got == len(buf):
+                buf.extend(bytes(min(n - got, _CHUNK)))
+            r = self.sock.recv_into(memoryview(buf)[got:], len(buf) - got)
             if r == 0:
                 raise ConnectionError("peer closed the connection")
             got += r
@@ -136,10 +143,19 @@ class ZmtpConnection:
         flags = self._recv_exact(1)[0]
         if flags & ~(FLAG_MORE | FLAG_LONG | FLAG_COMMAND):
             raise ProtocolError(f"reserved frame flag bits set: {flags:#04x}")
-        n = struct.unpack("!Q", self._recv_exact(8))[0] if flags & FLAG_LONG else self._recv_exact(1)[0]
-        if n > MAX_FRAME:
-            raise ProtocolError(f"frame of {n} bytes exceeds the limit")
-        return flags, self._recv_exact(n)
+        # between messages a peer may stay silent for as long as it likes; once a frame has started, the rest of it is due
+        idle = self.sock.gettimeout()
+        if idle is None or idle > FRAME_TIMEOUT:
+            self.sock.settimeout(FRAME_TIMEOUT)
+        try:
+            n = struct.unpack("!Q", self._recv_exact(8))[0] if flags & FLAG_LONG else self._recv_exact(1)[0]
+            if n > MAX_FRAME:
+                raise ProtocolError(f"frame of {n} bytes exceeds the limit")
+            return flags, self._recv_exact(n)
+        except socket.timeout as e:
+            raise ConnectionError("a frame stalled half-way") from e
+        finally:
+            self.sock.settimeout(idle)
 
     # -- handshake
     def handshake(self):
@@ -340,6 +356,9 @@ class ZmtpServer:
                     continue
                 except OSError:
                     break
+                if len(self._conns) >= MAX_CONNECTIONS:       # (one thread and up to MAX_FRAME of buffer per peer)
+                    s.close()
+                    continue
                 conn = ZmtpConnection(s, b"ROUTER")
                 self._conns.append(conn)
                 threading.Thread(target=self._serve, args=(conn,), daemon=True).start()

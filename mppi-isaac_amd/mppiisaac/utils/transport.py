@@ -11,17 +11,34 @@ STORED (not compressed), so for a given (dtype, shape) everything but the raw st
   * `bytes_to_torch` recognises a blob by its pickle member (which spells dtype, shape, strides and device tag), checks the
     payload's CRC and views the payload directly.
 
-Anything unusual (non-contiguous or non-CPU tensors to save; unknown layouts, several storages, a device tag that has to be
-honoured on load) takes the plain torch path."""
+A device tensor (what the reference's world loop hands over: `torch_to_bytes(sim._dof_state)`, examples/<x>/world.py:35-39) is
+saved under its own template - the pickle member carries its device tag, so a stock peer restores it where it came from - with
+the payload fetched either by `.cpu()` or, for tensors a simulator has registered (`register_host_mirror`: the K = 1 world keeps
+a copy of its state in mapped host memory, written by the kernel that produces it), without any device-to-host copy.
+
+Anything unusual (non-contiguous tensors to save; unknown layouts, several storages, a device tag that has to be honoured on
+load) takes the plain torch path."""
 import io
 import struct
 import zipfile
 import zlib
 
+import numpy as np
 import torch
 
-_SAVE_TEMPLATES = {}   # (dtype, shape) -> (bytearray blob, payload offset, nbytes, crc offsets)
+_SAVE_TEMPLATES = {}   # (dtype, shape, device) -> (bytearray blob, payload offset, nbytes, crc offsets)
+_HOST_MIRRORS = {}     # data_ptr of a device tensor -> (shape, dtype, getter() -> contiguous numpy array or None)
 _LOAD_LAYOUTS = {}     # pickle-member bytes -> (dtype, shape, payload offset, nbytes, descriptor crc offset, on_cpu)
+
+
+def register_host_mirror(t: torch.Tensor, getter) -> None:
+    """`getter()` returns the CURRENT contents of device tensor `t` as a contiguous numpy array without a device-to-host copy
+    (or None when it cannot vouch for them - e.g. the tensor was written in place -: `torch_to_bytes` then copies)."""
+    _HOST_MIRRORS[t.data_ptr()] = (tuple(t.shape), t.dtype, getter)
+
+
+def unregister_host_mirror(t: torch.Tensor) -> None:
+    _HOST_MIRRORS.pop(t.data_ptr(), None)
 
 
 def _locate_payload(blob: bytes):
@@ -72,10 +89,11 @@ def _slow_save(t: torch.Tensor) -> bytes:
 
 
 def torch_to_bytes(t: torch.Tensor) -> bytes:
-    if not (isinstance(t, torch.Tensor) and t.device.type == "cpu" and t.is_contiguous() and not t.requires_grad
-            and t.layout == torch.strided and t.numel() > 0 and type(t) is torch.Tensor):
+    if not (isinstance(t, torch.Tensor) and t.is_contiguous() and not t.requires_grad
+            and t.layout == torch.strided and t.numel() > 0 and type(t) is torch.Tensor and t.device.type in ("cpu", "cuda")):
         return _slow_save(t)
-    key = (t.dtype, tuple(t.shape))
+    on_device = t.device.type != "cpu"
+    key = (t.dtype, tuple(t.shape), str(t.device))
     tpl = _SAVE_TEMPLATES.get(key)
     if tpl is None:
         blob = _slow_save(t.detach().clone())   # (a fresh storage: the archive then holds exactly this tensor's bytes)
@@ -88,7 +106,14 @@ def torch_to_bytes(t: torch.Tensor) -> bytes:
     if tpl is False:
         return _slow_save(t)
     blob, off, n, crc_offsets = tpl
-    payload = t.detach().numpy().tobytes()
+    host = None
+    if on_device:
+        m = _HOST_MIRRORS.get(t.data_ptr())
+        if m is not None and m[0] == key[1] and m[1] == t.dtype:
+            host = m[2]()
+        payload = host.tobytes() if host is not None else t.detach().cpu().numpy().tobytes()
+    else:
+        payload = t.detach().numpy().tobytes()
     out = bytearray(blob)
     out[off:off + n] = payload
     crc = struct.pack("<I", zlib.crc32(payload) & 0xFFFFFFFF)
@@ -119,3 +144,18 @@ def bytes_to_torch(b: bytes, map_location=None) -> torch.Tensor:
     if not want_cpu or len(b) < off + n or zlib.crc32(b[off:off + n]) & 0xFFFFFFFF != struct.unpack("<I", b[crc_off:crc_off + 4])[0]:
         return torch.load(io.BytesIO(b), map_location=map_location)   # honour the device tag / let torch report the damage
     return torch.frombuffer(bytearray(b[off:off + n]), dtype=dtype).reshape(shape)
+
+
+_NP_DTYPES = {torch.float32: np.float32, torch.float64: np.float64, torch.int32: np.int32, torch.int64: np.int64}
+
+
+def bytes_to_array(b: bytes) -> np.ndarray:
+    """the payload of a blob as a numpy array (read-only view of `b` when its layout is known, CRC checked) - for receivers that
+    only want the numbers, like the planner taking the world state in (`reset_rollout_sim`, reference mppi_isaac.py:87-99)"""
+    second = b.find(b"PK\x03\x04", 4) if b[:4] == b"PK\x03\x04" else -1
+    lay = _LOAD_LAYOUTS.get(b[:second]) if second > 0 else None
+    if lay is not None and lay[0] in _NP_DTYPES:
+        dtype, shape, off, n, crc_off, _ = lay
+        if len(b) >= off + n and zlib.crc32(memoryview(b)[off:off + n]) & 0xFFFFFFFF == struct.unpack_from("<I", b, crc_off)[0]:
+            return np.frombuffer(b, dtype=_NP_DTYPES[dtype], count=n // np.dtype(_NP_DTYPES[dtype]).itemsize, offset=off).reshape(shape)
+    return bytes_to_torch(b, map_location="cpu").detach().numpy()

@@ -206,11 +206,13 @@ def test_transport_fast_path_is_byte_compatible_with_torch_save_and_load():
             back = T.bytes_to_torch(blob, map_location="cpu")
             assert torch.equal(back, t) and back.dtype == dtype and tuple(back.shape) == shape
             back += 1                                                        # a private, writable copy
-    assert (torch.float32, (1, 14)) in T._SAVE_TEMPLATES and len(T._LOAD_LAYOUTS) >= 6
+    assert (torch.float32, (1, 14), "cpu") in T._SAVE_TEMPLATES and len(T._LOAD_LAYOUTS) >= 6
+    a = T.bytes_to_array(T.torch_to_bytes(torch.arange(14, dtype=torch.float32).reshape(1, 14)))   # the numbers only, viewed in place
+    assert a.dtype == np.float32 and a.shape == (1, 14) and (a[0] == np.arange(14)).all()
     # a payload that does not match its CRC is not served from the fast path: torch.load decides what happens with it
     t = torch.arange(14, dtype=torch.float32).reshape(1, 14)
     blob = bytearray(T.torch_to_bytes(t))
-    off = T._SAVE_TEMPLATES[(torch.float32, (1, 14))][1]
+    off = T._SAVE_TEMPLATES[(torch.float32, (1, 14), "cpu")][1]
     blob[off + 1] ^= 0x40
     calls = []
     orig = torch.load
@@ -373,3 +375,37 @@ def test_pruned_link_list_keeps_what_can_be_observed():
     assert 0 <= tip["parent_link"] < kept.index("panda_ee_tip")
     total = sum(b["inertia"]["mass"] for b in m["bodies"]) + m["base"]["inertia"]["mass"]
     assert total == pytest.approx(81.51, abs=0.01)        # every URDF inertial is still in the bodies, whatever the link list says
+
+
+def test_unseen_kinematic_tree_is_built_on_demand_without_a_gpu(tmp_path, monkeypatch):
+    """reference gym.load_asset takes any URDF (isaacgym_utils.py:14-29).  Here: a URDF nobody compiled before is compiled at run
+    time by load_asset, and mppi_create BUILDS the kernels of its tree (hipcc cross-compiles without a GPU) into a cached plugin
+    and loads it - on this box the call then stops at the first device call, after the build.  (GPU side:
+    tests/test_gpu_runtime_tree.py plans on it.)"""
+    import ctypes as C
+    import test_gpu_runtime_tree as T
+    from mppiisaac.planner.isaacgym_wrapper import Scene
+    from mppiisaac.utils.isaacgym_utils import load_actor_cfgs, load_asset
+    urdf, actor = str(tmp_path / "b5.urdf"), str(tmp_path / "arm5.yaml")
+    T.write_branched_urdf(urdf)
+    T.actor_yaml(actor, urdf)
+    monkeypatch.setenv("MPPI_JIT_CACHE", str(tmp_path / "jit"))
+    env = load_actor_cfgs([actor, "goal"])
+    sc = Scene(env, load_config({"defaults": [{"isaacgym": "normal"}]}).isaacgym, [load_asset(a) for a in env if a.type == "robot"])
+    assert [b["parent"] for b in sc.robot_model["bodies"]] == [-1, 0, 1, 0, 3] and sc.link_names[-1] == "tool"
+    m, cfg = sc.to_c(), make_config(MPPIConfig(num_samples=64, horizon=8, noise_sigma=np.eye(5).tolist()), viz_link=-1)
+    lib = capi.load_library()
+    ctx = C.c_void_p()
+    monkeypatch.setenv("MPPI_JIT", "0")
+    assert lib.mppi_create(C.byref(m), C.byref(cfg), 0, C.byref(ctx)) == capi.MPPI_EUNSUPPORTED and b"MPPI_JIT=0" in lib.mppi_last_error()
+    monkeypatch.delenv("MPPI_JIT")
+    rc = lib.mppi_create(C.byref(m), C.byref(cfg), 0, C.byref(ctx))
+    info = C.create_string_buffer(512)
+    assert lib.mppi_jit_info(info, 512) == 0
+    assert info.value.decode().startswith("built ") and "topo_m1_0_1_0_3_free" in info.value.decode(), (rc, lib.mppi_last_error(), info.value)
+    built = os.listdir(str(tmp_path / "jit"))
+    assert len(built) == 1 and built[0].endswith(".so")           # sources, objects and logs of the build are gone
+    if rc != 0:                                                    # (no GPU here: the build went through, the device call did not)
+        assert rc == capi.MPPI_EHIP and b"not instantiated" not in lib.mppi_last_error()
+    else:
+        lib.mppi_destroy(ctx)

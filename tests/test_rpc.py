@@ -275,6 +275,61 @@ def test_handshake_refusals():
         lst.close()
 
 
+def test_frames_are_bounded_and_stalled_frames_are_dropped(monkeypatch):
+    """an unauthenticated peer cannot pin memory: a long frame beyond MAX_FRAME is refused from its nine-byte header, the buffer
+    of an accepted frame grows with the bytes that arrive (the announced length allocates nothing), a frame that stalls half-way
+    ends the connection, and the server caps its concurrent connections"""
+    if rpc.BACKEND == "zerorpc":
+        pytest.skip("real zerorpc")
+    monkeypatch.setattr(rpc, "FRAME_TIMEOUT", 0.5)
+    srv, url, t = serve(FakePlanner())
+    port = int(url.rsplit(":", 1)[1])
+
+    def handshaken():
+        s = socket.create_connection(("127.0.0.1", port), timeout=5)
+        s.sendall(RFC_GREETING + RFC_READY_DEALER)
+        got = b""
+        while len(got) < 64 + len(READY_ROUTER):
+            got += s.recv(4096)
+        return s
+    # (1) a LONG frame that announces 1 TiB: the connection is closed at once
+    s = handshaken()
+    s.sendall(bytes([0x02]) + struct.pack("!Q", 1 << 40))
+    s.settimeout(5)
+    assert s.recv(16) == b""
+    s.close()
+    # (2) a frame that announces 200 MiB and sends 10 bytes: dropped after FRAME_TIMEOUT, and nothing of that size was allocated
+    import tracemalloc
+    tracemalloc.start()
+    s = handshaken()
+    s.sendall(bytes([0x02]) + struct.pack("!Q", 200 << 20) + b"x" * 10)
+    s.settimeout(5)
+    t0 = time.time()
+    assert s.recv(16) == b""
+    assert time.time() - t0 < 4
+    peak = tracemalloc.get_traced_memory()[1]
+    tracemalloc.stop()
+    assert peak < (16 << 20), peak
+    s.close()
+    # (3) the server still serves
+    c = rpc.Client(url, timeout=5)
+    assert c.add_to_env([1, 2, 3]) == 3
+    c.close()
+    # (4) connection cap
+    monkeypatch.setattr(rpc, "MAX_CONNECTIONS", 2)
+    time.sleep(0.3)
+    keep = [handshaken() for _ in range(2)]
+    extra = socket.create_connection(("127.0.0.1", port), timeout=5)
+    extra.settimeout(3)
+    try:
+        assert extra.recv(16) == b""     # closed without a greeting
+    except ConnectionError:
+        pass
+    for k in keep + [extra]:
+        k.close()
+    srv.stop()
+
+
 def test_endpoint_validation():
     if rpc.BACKEND == "zerorpc":
         pytest.skip("real zerorpc")
