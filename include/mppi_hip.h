@@ -398,11 +398,11 @@ int mppi_sim_step_horizon(mppi_ctx_t *ctx, int t);         /* u = clamp(U[t]+eps
  * torch_to_bytes(sim._root_state) -> planner -> sim.apply_robot_cmd(action); sim.step()) without copy operations:
  *   mppi_sim_step_host   one command [nu] for every env by HOST pointer (written into a ring slot of the context's mapped host
  *                        block; the step kernel reads it through the mapped pointer)
- *   mppi_mirror_state    K = 1: the dof [2n] / root [A][13] device tensors (what mppi_sim_materialise wrote) are copied into the
- *                        mapped host block by a one-wavefront kernel that publishes a sequence number behind them
+ *   mppi_sim_materialise_mirror   K = 1: mppi_sim_materialise whose kernel also writes env 0's dof [2n] / root [A][13] rows into
+ *                        the mapped host block and publishes a sequence number behind them
  *   mppi_mirror_wait     polls that number and copies the mirrored state out: no device-to-host copy, no stream synchronise */
 int mppi_sim_step_host(mppi_ctx_t *ctx, const float *u_host);
-int mppi_mirror_state(mppi_ctx_t *ctx, const float *dof_dev, const float *root_dev);
+int mppi_sim_materialise_mirror(mppi_ctx_t *ctx, float *dof_dev, float *root_dev, float *rb_dev, float *cf_dev);
 int mppi_mirror_wait(mppi_ctx_t *ctx, float *dof_host, float *root_host);
 /* reference-layout tensors: dof [K][2n], root [K][A][13], rb [K][B][13], cf [K][B][3]; NULL = skip */
 int mppi_sim_materialise(mppi_ctx_t *ctx, float *dof_dev, float *root_dev, float *rb_dev, float *cf_dev);

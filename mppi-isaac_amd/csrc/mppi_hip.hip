@@ -192,19 +192,7 @@ __global__ void k_set_x0(X0Args a, int n_dof, int n_root, float *__restrict__ x0
     for (int i = threadIdx.x; i < n_dof; i += blockDim.x) x0_dof[i] = a.v[i];
     for (int i = threadIdx.x; i < n_root; i += blockDim.x) x0_root[i] = a.v[2 * MPPI_MAX_BODIES + i];
 }
-// K = 1 world: dof / root state tensors -> mapped host memory, then the sequence number behind a system-scope release
-// (mppi_mirror_wait polls it: no device-to-host copy operation, no stream synchronise)
-__global__ void k_mirror_state(const float *__restrict__ dof, const float *__restrict__ root, int n_dof, int n_root, float *__restrict__ mirror,
-                               unsigned *__restrict__ seq_host, unsigned seq) {
-    for (int i = threadIdx.x; i < n_dof; i += blockDim.x) mirror[i] = dof[i];
-    for (int i = threadIdx.x; i < n_root; i += blockDim.x) mirror[kIoDofFloats + i] = root[i];
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(seq_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
 }  // namespace
-
 
 // ------------------------------------------------------------------------------ kinematic trees built on demand
 // The rollout kernels are templates over the kinematic tree (every per-body array index static: mppi_device.hpp), so a tree has to
@@ -528,7 +516,11 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
             }
             c->launch_combine_world = e->combine_world;
             // many envs: quad step kernel; the K = 1 world (and tiny K) keeps the one-lane kernel
-            c->launch_sim_step = (c->quad && cfg->num_samples >= 64) ? e->sim_step_quad : e->sim_step;
+            // ... and, since round 5, the quad kernel again (one quad steps the world in ~4 us, the lone lane took ~12: the world loop of
+            // the reference's examples waits for this kernel every control iteration); MPPI_WORLD_STEP=lane keeps the one-lane kernel
+            const char *ws = std::getenv("MPPI_WORLD_STEP");
+            const bool world_quad = cfg->num_samples == 1 && !(ws && std::string(ws) == "lane");
+            c->launch_sim_step = (c->quad && (cfg->num_samples >= 64 || world_quad)) ? e->sim_step_quad : e->sim_step;
             c->launch_materialise = e->materialise;
         }
         break;
@@ -1164,21 +1156,22 @@ int mppi_sim_step_host(mppi_ctx_t *c, const float *u_host) {
     c->launch_sim_step(c, 1, 0, c->d_io + kIoCmd + 16 * slot);
     return launch_check();
 }
-/* (ABI 8) K = 1 world: the dof [2n] and root [A][13] state tensors (device, e.g. what mppi_sim_materialise just wrote) are
- * mirrored into the context's mapped host block by a one-wavefront kernel that publishes a sequence number behind them;
- * mppi_mirror_wait polls the number and copies them out - the `torch_to_bytes(sim._dof_state)` of the reference's world loop
- * (examples/<x>/world.py:35-39) without a device-to-host copy operation or a stream synchronise */
-int mppi_mirror_state(mppi_ctx_t *c, const float *dof_dev, const float *root_dev) {
+/* (ABI 8) K = 1 world: mppi_sim_materialise whose kernel ALSO mirrors env 0's dof [2n] and root [A][13] rows into the context's
+ * mapped host block and publishes a sequence number behind them; mppi_mirror_wait polls the number and copies them out - the
+ * `torch_to_bytes(sim._dof_state)` of the reference's world loop (examples/<x>/world.py:35-39) without a device-to-host copy
+ * operation or a stream synchronise */
+int mppi_sim_materialise_mirror(mppi_ctx_t *c, float *dof, float *root, float *rb, float *cf) {
     CTX_TRY(c);
-    if (!dof_dev || !root_dev) return fail(MPPI_EINVAL, "mppi_mirror_state: null tensor");
+    if (c->K != 1 || !dof || !root) return fail(MPPI_EINVAL, "mppi_sim_materialise_mirror: a K = 1 context and its dof / root tensors");
     c->io_mirror_seq++;
-    hipLaunchKernelGGL(k_mirror_state, dim3(1), dim3(64), 0, c->stream, dof_dev, root_dev, 2 * c->n, 13 * c->A, c->d_io + kIoDof,
-                       reinterpret_cast<unsigned *>(c->d_io), c->io_mirror_seq);
+    c->mirror_armed = true;
+    c->launch_materialise(c, dof, root, rb, cf);
+    c->mirror_armed = false;
     return launch_check();
 }
 int mppi_mirror_wait(mppi_ctx_t *c, float *dof_host, float *root_host) {
     CTX_TRY(c);
-    if (c->io_mirror_seq == 0) return fail(MPPI_ESTATE, "mppi_mirror_wait: nothing mirrored (mppi_mirror_state)");
+    if (c->io_mirror_seq == 0) return fail(MPPI_ESTATE, "mppi_mirror_wait: nothing mirrored (mppi_sim_materialise_mirror)");
     const volatile unsigned *seq = reinterpret_cast<const volatile unsigned *>(c->h_io);
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 0; *seq != c->io_mirror_seq; spins++) {

@@ -1168,11 +1168,26 @@ __global__ __launch_bounds__(kWave) void k_sim_step_scene_quad(const DevModel *_
 #endif
 }
 
+// K = 1 world (ABI 8, mppi_sim_materialise with the state mirror armed): env 0's dof / root rows, just written to the state tensors,
+// also go into the context's mapped host block, followed by the sequence number behind a system-scope release - the host takes
+// its torch.save payloads from there (mppi_mirror_wait), no device-to-host copy
+constexpr int kIoMirrorRoot = 32;  // = kIoDofFloats (mppi_ctx hand-over block): the root rows follow the dof rows at this offset
+__device__ __forceinline__ void mirror_env0(float *__restrict__ mirror, unsigned *__restrict__ mirror_seq, unsigned seq, int k, const float *__restrict__ dof,
+                                            const float *__restrict__ root, int n_dof, int n_root) {
+    if (mirror == nullptr || k != 0 || dof == nullptr || root == nullptr) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // this lane's own stores to dof / root are what it reads back
+    for (int i = 0; i < n_dof; i++) mirror[i] = dof[i];
+    for (int i = 0; i < n_root; i++) mirror[kIoMirrorRoot + i] = root[i];
+    __threadfence_system();
+    __hip_atomic_store(mirror_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 template <class T>
 __global__ __launch_bounds__(kWave) void k_materialise_scene(const DevModel *__restrict__ m, int K, const float *__restrict__ x0_root,
                                                              const float *__restrict__ q_, const float *__restrict__ qd_, const float *__restrict__ base_,
                                                              const float *__restrict__ fr_, const float *__restrict__ cf_, float *__restrict__ dof,
-                                                             float *__restrict__ root, float *__restrict__ rb, float *__restrict__ cf) {
+                                                             float *__restrict__ root, float *__restrict__ rb, float *__restrict__ cf,
+                                                             float *__restrict__ mirror = nullptr, unsigned *__restrict__ mirror_seq = nullptr, unsigned seq = 0) {
     constexpr int NB = T::NB;
     const int k = blockIdx.x * kWave + threadIdx.x;
     if (k >= K) return;
@@ -1198,6 +1213,7 @@ __global__ __launch_bounds__(kWave) void k_materialise_scene(const DevModel *__r
                          rb != nullptr ? rb + (size_t)k * 13 * B : nullptr, nullptr);
     if (cf != nullptr)
         for (int j = 0; j < 3 * B; j++) cf[(size_t)k * 3 * B + j] = cf_[(size_t)j * K + k];
+    mirror_env0(mirror, mirror_seq, seq, k, dof, root, 2 * NB, 13 * A);
 }
 
 // all envs <- x0 (root rows of the robot base and the free actors)
@@ -1457,7 +1473,8 @@ __global__ __launch_bounds__(kWave) void k_sim_step_quad(const DevModel *__restr
 template <class T>
 __global__ __launch_bounds__(kWave) void k_materialise(const DevModel *__restrict__ m, int K, const float *__restrict__ x0_root,
                                                        const float *__restrict__ q_, const float *__restrict__ qd_, float *__restrict__ dof,
-                                                       float *__restrict__ root, float *__restrict__ rb, float *__restrict__ cf) {
+                                                       float *__restrict__ root, float *__restrict__ rb, float *__restrict__ cf,
+                                                       float *__restrict__ mirror = nullptr, unsigned *__restrict__ mirror_seq = nullptr, unsigned seq = 0) {
     constexpr int NB = T::NB;
     const int k = blockIdx.x * kWave + threadIdx.x;
     if (k >= K) return;
@@ -1477,6 +1494,7 @@ __global__ __launch_bounds__(kWave) void k_materialise(const DevModel *__restric
     if (rb != nullptr) rigid_body_state<T>(*(CModel *)m, x0_root, q, qd, rb + (size_t)k * 13 * B, cf != nullptr ? cf + (size_t)k * 3 * B : nullptr);
     else if (cf != nullptr)
         for (int j = 0; j < 3 * B; j++) cf[(size_t)k * 3 * B + j] = 0.f;
+    mirror_env0(mirror, mirror_seq, seq, k, dof, root, 2 * NB, 13 * A);
 }
 
 // Parity / debug entry (mppi_eval_cost): the cost program of the context evaluated by the interpreter the rollout kernels run
@@ -1539,6 +1557,7 @@ __global__ void k_state_from_world(int n, const float *__restrict__ wq, const fl
 // ring of kIoCmdSlots commands of 16 floats (mppi_sim_step_host: the step kernel reads its command through the mapped pointer),
 // [kIoDof ...] the mirrored dof state (2n <= kIoDofFloats) followed by the root state (13 A) of a K = 1 world
 constexpr int kIoCmd = 16, kIoCmdSlots = 64, kIoDof = kIoCmd + 16 * kIoCmdSlots, kIoDofFloats = 32;
+static_assert(kIoDofFloats == kIoMirrorRoot, "mirror layout");
 constexpr int kIoFloats = kIoDof + kIoDofFloats + 13 * MPPI_MAX_ACTORS + 12;
 
 // ------------------------------------------------------------------------------ context
@@ -1547,6 +1566,7 @@ struct mppi_ctx {
     float *h_io = nullptr, *d_io = nullptr;  // the hand-over block and its device address
     int free_slots = 2;  // free-actor slots of the scene kernels this context launches (TopoEntry.free_slots): sizes d_fr and the trajectory rows
     unsigned io_cmd_next = 0, io_mirror_seq = 0;
+    bool mirror_armed = false;  // the next materialise launch also mirrors env 0 into h_io (mppi_sim_materialise_mirror)
     hipStream_t stream = nullptr;
     mppi_model_t model;
     mppi_config_t cfg;
@@ -1739,7 +1759,7 @@ void launch_sim_step_scene_quad_t(mppi_ctx *c, int mode, int t, const float *u_e
 template <class T>
 void launch_materialise_scene_t(mppi_ctx *c, float *dof, float *root, float *rb, float *cf) {
     hipLaunchKernelGGL(k_materialise_scene<T>, dim3(c->n_waves), dim3(kWave), 0, c->stream, c->d_model, c->K, c->d_x0_root, c->d_q, c->d_qd, c->d_base,
-                       c->d_fr, c->d_cf, dof, root, rb, cf);
+                       c->d_fr, c->d_cf, dof, root, rb, cf, c->mirror_armed ? c->d_io + kIoDof : nullptr, reinterpret_cast<unsigned *>(c->d_io), c->io_mirror_seq);
 }
 template <class T>
 hipError_t raise_lds_limit(size_t lane_bytes, size_t quad_bytes) {  // lane_bytes == 0: the one-lane kernels are not used
@@ -1857,7 +1877,7 @@ void launch_sim_step_quad_t(mppi_ctx *c, int mode, int t, const float *u_ext) {
 template <class T>
 void launch_materialise_t(mppi_ctx *c, float *dof, float *root, float *rb, float *cf) {
     hipLaunchKernelGGL(k_materialise<T>, dim3(c->n_waves), dim3(kWave), 0, c->stream, c->d_model, c->K, c->d_x0_root, c->d_q, c->d_qd, dof, root,
-                       rb, cf);
+                       rb, cf, c->mirror_armed ? c->d_io + kIoDof : nullptr, reinterpret_cast<unsigned *>(c->d_io), c->io_mirror_seq);
 }
 
 // The launch-table row of a kinematic tree is filled by TWO translation units (generated: topo_<i>.hip, topo_<i>_scene.hip):

@@ -145,7 +145,7 @@ _SIGNATURES = {
     "mppi_sim_step": (C.c_int, [_vp, _vp, C.c_int]),
     "mppi_sim_step_horizon": (C.c_int, [_vp, C.c_int]),
     "mppi_sim_step_host": (C.c_int, [_vp, _fp]),
-    "mppi_mirror_state": (C.c_int, [_vp, _vp, _vp]),
+    "mppi_sim_materialise_mirror": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "mppi_mirror_wait": (C.c_int, [_vp, _fp, _fp]),
     "mppi_sim_materialise": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "mppi_sim_accumulate_cost": (C.c_int, [_vp, C.c_int, _vp]),

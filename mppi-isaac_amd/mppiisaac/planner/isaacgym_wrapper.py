@@ -580,6 +580,7 @@ class IsaacGymWrapper:
         self._state_t = {"dof": torch.zeros((K, 2 * n), **f32), "root": torch.zeros((K, A, 13), **f32),
                          "rb": torch.zeros((K, B, 13), **f32), "cf": torch.zeros((K, B, 3), **f32)}
         self._state_t_own = self._state_t
+        self._state_ptrs = tuple(_dev_ptr(self._state_t[k]) for k in ("dof", "root", "rb", "cf"))
         self._stale, self._needs_reset = True, False
         self._visualize_link_present = sc.viz_link_index() >= 0
         self.visualize_link_buffer = []
@@ -637,12 +638,13 @@ class IsaacGymWrapper:
     def _materialise(self):
         self._reset_envs_if_needed()
         t = self._state_t
-        capi.check(self._lib, self._lib.mppi_sim_materialise(self._ctx, _dev_ptr(t["dof"]), _dev_ptr(t["root"]), _dev_ptr(t["rb"]), _dev_ptr(t["cf"])))
-        self._stale = False
         m = self._mirror
-        if m is not None and t is self._state_t_own:
-            capi.check(self._lib, self._lib.mppi_mirror_state(self._ctx, _dev_ptr(t["dof"]), _dev_ptr(t["root"])))
+        if m is not None and t is self._state_t_own:   # K = 1 world: the same kernel mirrors dof / root into mapped host memory
+            capi.check(self._lib, self._lib.mppi_sim_materialise_mirror(self._ctx, *self._state_ptrs))
             m["fresh"], m["versions"] = False, (t["dof"]._version, t["root"]._version)
+        else:
+            capi.check(self._lib, self._lib.mppi_sim_materialise(self._ctx, _dev_ptr(t["dof"]), _dev_ptr(t["root"]), _dev_ptr(t["rb"]), _dev_ptr(t["cf"])))
+        self._stale = False
 
     def _mirrored(self, key):
         """host copy of the K = 1 world's dof / root state tensor as the last materialise left it (None: the tensor has been

@@ -429,10 +429,52 @@ class MPPIPlanner:
                 else:
                     warnings.warn("the Objective's cost of a whole horizon evaluated in one call differs from its per-step costs "
                                   "(it depends on more than the sim tensors): keeping one compute_cost call per horizon step")
+        elif single and self._cost_graph_wanted():
+            S_add = self._horizon_costs_graph(state, b, sig)
         else:
             S_add = self._horizon_costs(state, b, single=single)
         capi.check(self._lib, self._lib.mppi_sim_accumulate_cost(self._ctx, 0, C_void(S_add)))
         return True
+
+    def _cost_graph_wanted(self) -> bool:
+        """the adopted one-call evaluation as a captured HIP graph: for Objectives that declare `graph_safe = True` (compute_cost is
+        a pure tensor program of sim tensors and `.weights` - the same opt-in as _replay_horizon), or any Objective with
+        MPPI_GENERIC_GRAPH=1.  A reference-style compute_cost is ~60 small torch kernels; launching them costs the host ~5 us
+        each, a replay costs one launch."""
+        if self._graph_state == "off" or getattr(self, "_cost_graph", None) is False:
+            return False
+        if self._graph_state == "on":
+            return True
+        obj = getattr(self._running_cost, "__self__", None)
+        obj = getattr(obj, "objective", obj)
+        return bool(getattr(obj, "graph_safe", False))
+
+    def _horizon_costs_graph(self, state, b, sig) -> torch.Tensor:
+        g = getattr(self, "_cost_graph", None)
+        if g is not None and g[2] != sig:
+            g = None                                   # another Objective / other weights: capture again
+        if g is None:
+            try:
+                S = self._horizon_costs(state, b, single=True)     # (this command's costs, and the warm-up of the capture)
+                viz0 = list(self.sim.visualize_link_buffer)
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    S_static = self._horizon_costs(state, b, single=True)
+                viz = self.sim.visualize_link_buffer[len(viz0):]
+                self.sim.visualize_link_buffer = viz0
+                self._cost_graph = (graph, S_static, sig, viz)
+                return S
+            except Exception as e:  # noqa: BLE001 - host synchronisation inside compute_cost etc.: the eager call stays
+                warnings.warn(f"the Objective's horizon evaluation is not graph-capturable ({type(e).__name__}: {e}); evaluating it eagerly")
+                self._cost_graph = False
+                torch.cuda.synchronize()
+                return self._horizon_costs(state, b, single=True)
+        graph, S_static, _, viz = g
+        graph.replay()
+        if self.sim._visualize_link_present:
+            self.sim.visualize_link_buffer.extend(viz)
+        return S_static
 
     def _simulate_horizon(self) -> dict:
         """the envs' state after every horizon step as reference-layout tensors [H*K, ...] (row t*K + k)"""
@@ -492,7 +534,7 @@ class MPPIPlanner:
         """S_add [K] = sum_t gamma^t c_t from ONE compute_cost over the [H*K]-env view, or from H calls on its [K]-row blocks"""
         sim, H, K = self.sim, self.T, self.K
         if single:
-            with sim._horizon_view(b, H * K):
+            with sim._horizon_view(b, H * K), torch.no_grad():
                 c = self._running_cost(state)
                 if sim._visualize_link_present:
                     viz = sim.visualize_link_pos.reshape(H, K, 3)
@@ -506,7 +548,8 @@ class MPPIPlanner:
             with sim._horizon_view({k: v[t * K:(t + 1) * K] for k, v in b.items()}, K):
                 if sim._visualize_link_present:
                     sim.visualize_link_buffer.append(sim.visualize_link_pos.clone())
-                c = self._running_cost(state).to(dtype=torch.float32, device=sim.device)
+                with torch.no_grad():
+                    c = self._running_cost(state).to(dtype=torch.float32, device=sim.device)
             if c.shape != (K,):
                 raise ValueError(f"compute_cost must return a [{K}] tensor, got {tuple(c.shape)}")
             S += self._batch_gamma[t] * c

@@ -32,7 +32,7 @@ JOINT = """  <joint name="{name}" type="{type}">
 """
 
 
-def write_branched_urdf(path):
+def write_branched_urdf(path, tail=True):
     """base - j1 -> l1 - j2 -> l2 - j4 (prismatic) -> l4 ;  l1 - j3 -> l3 - j5 -> l5 (+ a tool link welded to l5)"""
     links = "".join(LINK.format(name=n, cx=0.01 * i, cy=-0.005 * i, cz=0.1 + 0.01 * i, m=1.5 - 0.2 * i, ixx=0.02 + 0.002 * i, iyy=0.018 + 0.001 * i, izz=0.006 + 0.001 * i,
                                 lz=0.2 + 0.01 * i) for i, n in enumerate(["base", "l1", "l2", "l3", "l4", "l5"]))
@@ -42,8 +42,10 @@ def write_branched_urdf(path):
          ("j4", "prismatic", "l2", "l4", "0 0 0.2", "0 0.1 0", "0 0 1", -0.1, 0.15, 80, 0.5),
          ("j3", "revolute", "l1", "l3", "-0.05 0.04 0.2", "0 -0.4 0.1", "1 0 0", -2.0, 2.0, 40, 2.5),
          ("j5", "continuous", "l3", "l5", "0 0 0.24", "0 0 0", "0 0.6 0.8", 0, 0, 20, 3.0)]
+    if not tail:   # a second unseen tree, [-1, 0, 1, 0]: without l5 (the tool is welded to l3)
+        links, J = links.replace(LINK.format(name="l5", cx=0.05, cy=-0.025, cz=0.15, m=0.5, ixx=0.03, iyy=0.023, izz=0.011, lz=0.25), ""), J[:-1]
     joints = "".join(JOINT.format(name=n, type=t, parent=p, child=c, xyz=xyz, rpy=rpy, axis=ax, lo=lo, hi=hi, effort=e, vel=v) for n, t, p, c, xyz, rpy, ax, lo, hi, e, v in J)
-    joints += '  <joint name="weld" type="fixed"><parent link="l5"/><child link="tool"/><origin xyz="0 0 0.3" rpy="0 0.2 0"/></joint>\n'
+    joints += '  <joint name="weld" type="fixed"><parent link="%s"/><child link="tool"/><origin xyz="0 0 0.3" rpy="0 0.2 0"/></joint>\n' % ("l5" if tail else "l3")
     with open(path, "w") as f:
         f.write('<?xml version="1.0"?>\n<robot name="branched5">\n' + links + joints + "</robot>\n")
 
@@ -151,13 +153,14 @@ def test_unseen_branched_urdf_is_compiled_built_and_planned_on(tmp_path, monkeyp
 
 
 def test_on_demand_builds_can_be_switched_off(tmp_path, monkeypatch):
-    urdf = str(tmp_path / "branched5.urdf")
-    write_branched_urdf(urdf)
-    actor = str(tmp_path / "arm5.yaml")
-    actor_yaml(actor, urdf)
+    urdf = str(tmp_path / "branched4.urdf")
+    write_branched_urdf(urdf, tail=False)       # (a tree no earlier test of this process has loaded a plugin for)
+    actor = str(tmp_path / "arm4.yaml")
+    actor_yaml(actor, urdf, init_joint_pose=[0.0] * 8)
     monkeypatch.setenv("MPPI_JIT_CACHE", str(tmp_path / "jit_off"))
     monkeypatch.setenv("MPPI_JIT", "0")
     icfg = load_config({"defaults": [{"isaacgym": "normal"}]}).isaacgym
     with pytest.raises(capi.MppiHipError, match="could not be built on demand.*MPPI_JIT=0"):
         IsaacGymWrapper(icfg, actors=[actor, "goal"], num_envs=64,
-                        mppi_config=lambda scene: make_config(MPPIConfig(num_samples=64, horizon=8, noise_sigma=np.eye(5).tolist()), viz_link=-1))
+                        mppi_config=lambda scene: make_config(MPPIConfig(num_samples=64, horizon=8, noise_sigma=np.eye(4).tolist()), viz_link=-1))
+    assert not os.path.exists(str(tmp_path / "jit_off")) or not os.listdir(str(tmp_path / "jit_off"))
