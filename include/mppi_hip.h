@@ -416,6 +416,11 @@ int mppi_sim_finish(mppi_ctx_t *ctx);                      /* S += control cost 
  * MPPI_EUNSUPPORTED for contexts that run the one-lane kernels or a contact scene with fewer than 8 samples. */
 int mppi_rollout_trajectory(mppi_ctx_t *ctx);
 int mppi_materialise_trajectory(mppi_ctx_t *ctx, float *dof_dev, float *root_dev, float *rb_dev, float *cf_dev);
+/* (ABI 8) ... and the other end of that horizon in ONE launch: cost_dev [H][K] = the stage costs of all env-steps as the host-side
+ * Objective returned them (row t*K + k); S_k += sum_t gamma^t c_t[k] + control cost, then the per-wavefront records (what
+ * mppi_sim_accumulate_cost, mppi_sim_finish and mppi_reduce do in three); record_out_dev as in mppi_reduce.  MPPI_EUNSUPPORTED
+ * for contexts of the one-lane kernels. */
+int mppi_reduce_horizon_costs(mppi_ctx_t *ctx, const float *cost_dev, float *record_out_dev);
 /* device-resident closed loop: step a K=1 world with the planner's action, feed its state back */
 int mppi_world_step_from(mppi_ctx_t *world, mppi_ctx_t *planner);
 int mppi_set_state_from_world(mppi_ctx_t *planner, mppi_ctx_t *world);

@@ -767,6 +767,26 @@ int mppi_reduce(mppi_ctx_t *c, float *record_out_dev) {
                            c->d_beta_eta, (const float *)nullptr);
     return launch_check();
 }
+/* (ABI 8) generic Objective mode with the whole horizon evaluated at once (mppi_rollout_trajectory + mppi_materialise_trajectory):
+ * cost_dev [H][K] holds the stage costs of all env-steps (row t*K + k = env k after step t); S_k += sum_t gamma^t c_t[k] (+ the
+ * control cost) and the per-wavefront records in ONE launch - instead of mppi_sim_accumulate_cost, mppi_sim_finish and mppi_reduce */
+int mppi_reduce_horizon_costs(mppi_ctx_t *c, const float *cost_dev, float *record_out_dev) {
+    CTX_TRY(c);
+    if (!cost_dev) return fail(MPPI_EINVAL, "null cost");
+    const int n16 = (c->K + 15) / 16;
+    if (n16 > c->n_quads) return fail(MPPI_EUNSUPPORTED, "mppi_reduce_horizon_costs: this context keeps per-wavefront records of 64 samples (one-lane kernels); use mppi_sim_accumulate_cost + mppi_reduce");
+    {
+        EvScope ev(c, 1);
+        hipLaunchKernelGGL(k_horizon_reduce_quad, dim3(n16), dim3(kWave), 0, c->stream, c->d_cfg, cost_dev, c->d_ctrl, c->d_S, c->d_du, c->d_partials);
+    }
+    c->n_partials = n16;
+    c->partials_valid = true;
+    c->recs_cur = c->d_partials;
+    if (record_out_dev)
+        hipLaunchKernelGGL(k_combine, dim3(1), dim3(kCombineThreads), 0, c->stream, c->d_cfg, c->recs_cur, c->n_partials, 0, record_out_dev, c->d_U, c->d_action,
+                           c->d_beta_eta, (const float *)nullptr);
+    return launch_check();
+}
 int mppi_shard_record_count(const mppi_ctx_t *c) {
     // (a cost program on a contact-free scene runs the one-lane kernel, which leaves per-wave records and folds nothing:
     // callers that asked before mppi_set_cost ask again after it)

@@ -353,6 +353,26 @@ __global__ __launch_bounds__(kWave) void k_reduce_quad(const DevCfg *__restrict_
     quad_record<16>(*(CCfg *)cfg, live ? S[k] : INFINITY, live && (threadIdx.x & 3) == 0, du, k0, partials + (size_t)blockIdx.x * (2 + cfg->H * cfg->nu));
 }
 
+// generic Objective mode, whole horizon at once (ABI 8): the host-side stage costs of all H*K env-steps come as ONE array
+// c[t*K + k]; S_k += sum_t gamma^t c[t][k] and the per-wavefront records in the same launch - what `(c.view(H, K) * disc).sum(0)`
+// (two torch kernels), mppi_sim_accumulate_cost, mppi_sim_finish and mppi_reduce did in five
+__global__ __launch_bounds__(kWave) void k_horizon_reduce_quad(const DevCfg *__restrict__ cfg, const float *__restrict__ c, const float *__restrict__ ctrl,
+                                                               float *__restrict__ S, const float *__restrict__ du, float *__restrict__ partials) {
+    const int K = cfg->K, H = cfg->H;
+    const int k0 = blockIdx.x * 16, k = k0 + (int)(threadIdx.x >> 2);
+    const bool live = k < K;
+    float s = INFINITY;
+    if (live) {
+        float acc = 0.f, disc = 1.f;
+        for (int t = 0; t < H; t++) {
+            acc = fmaf(disc, c[(size_t)t * K + k], acc);
+            disc *= cfg->gamma;
+        }
+        s = S[k] + acc + ctrl[k];
+        if ((threadIdx.x & 3) == 0) S[k] = s;
+    }
+    quad_record<16>(*(CCfg *)cfg, s, live && (threadIdx.x & 3) == 0, du, k0, partials + (size_t)blockIdx.x * (2 + H * cfg->nu));
+}
 
 template <class T>
 __global__ __launch_bounds__(kWave) void k_rollout(const DevModel *__restrict__ m, const DevCfg *__restrict__ cfg,

@@ -660,18 +660,23 @@ class IsaacGymWrapper:
     def _fresh(self, key):
         if self._stale:
             self._materialise()
+        if self._view_lazy is not None:   # horizon view of the planner: a state tensor is produced when somebody reads it
+            self._view_lazy(key)
         return self._state_t[key]
 
+    _view_lazy = None
+
     @contextlib.contextmanager
-    def _horizon_view(self, tensors: dict, n_rows: int):
+    def _horizon_view(self, tensors: dict, n_rows: int, lazy=None):
         """the four state tensors replaced by [H*K, ...] blocks (row block t = the envs after horizon step t) and num_envs by
-        H*K, for ONE compute_cost call over a whole horizon (planner/mppi.py: _horizon_batched)"""
+        H*K, for ONE compute_cost call over a whole horizon (planner/mppi.py: _horizon_batched).  `lazy(key)`: called before a
+        tensor is handed out - the planner materialises only the tensors an Objective actually reads"""
         saved = (self._state_t, self.num_envs, self._stale)
-        self._state_t, self.num_envs, self._stale = tensors, int(n_rows), False
+        self._state_t, self.num_envs, self._stale, self._view_lazy = tensors, int(n_rows), False, lazy
         try:
             yield self
         finally:
-            self._state_t, self.num_envs, self._stale = saved[0], saved[1], True
+            self._state_t, self.num_envs, self._stale, self._view_lazy = saved[0], saved[1], True, None
 
     _dof_state = property(lambda self: self._fresh("dof"))
     _root_state = property(lambda self: self._fresh("root"))

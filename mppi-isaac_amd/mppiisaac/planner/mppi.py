@@ -295,11 +295,16 @@ class MPPIPlanner:
         if self._fused_cost is not None:
             capi.check(lib, lib.mppi_rollout(ctx))
         else:
+            # generic mode.  _horizon_batched returns "reduced" when the whole horizon went through the library in four launches
+            # (rollout with the states kept -> materialise what the Objective reads -> [Objective] -> costs folded and reduced):
+            # the control-cost finish and the separate reduce of the step-by-step bookkeeping are part of the last one
             capi.check(lib, lib.mppi_sim_reset(ctx))
             self.sim._needs_reset = False
-            if not self._horizon_batched(state) and not self._replay_horizon(state):
-                self._horizon_eager(state)
-            capi.check(lib, lib.mppi_sim_finish(ctx))
+            done = self._horizon_batched(state)
+            if done != "reduced":
+                if not done and not self._replay_horizon(state):
+                    self._horizon_eager(state)
+                capi.check(lib, lib.mppi_sim_finish(ctx))
             self.sim._stale = True
         if self._shard and self._exchange == "mailbox":
             # the library's own exchange (include/mppi_hip.h mppi_mailbox_*): every rank stores its records into every rank's
@@ -432,7 +437,14 @@ class MPPIPlanner:
         elif single and self._cost_graph_wanted():
             S_add = self._horizon_costs_graph(state, b, sig)
         else:
-            S_add = self._horizon_costs(state, b, single=single)
+            S_add = self._horizon_costs(state, b, single=single, fold=False if single else None)
+        if S_add.shape[0] == self.T * self.K:   # the stage costs of all H*K env-steps: folded over the horizon and reduced in ONE launch
+            rc = self._lib.mppi_reduce_horizon_costs(self._ctx, C_void(S_add), None)
+            if rc == capi.MPPI_OK:
+                return "reduced"
+            if rc != capi.MPPI_EUNSUPPORTED:
+                capi.check(self._lib, rc)
+            S_add = (S_add.view(self.T, self.K) * self._batch_disc).sum(0).contiguous()
         capi.check(self._lib, self._lib.mppi_sim_accumulate_cost(self._ctx, 0, C_void(S_add)))
         return True
 
@@ -455,12 +467,12 @@ class MPPIPlanner:
             g = None                                   # another Objective / other weights: capture again
         if g is None:
             try:
-                S = self._horizon_costs(state, b, single=True)     # (this command's costs, and the warm-up of the capture)
+                S = self._horizon_costs(state, b, single=True, fold=False)     # (this command's costs, and the warm-up of the capture)
                 viz0 = list(self.sim.visualize_link_buffer)
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
-                    S_static = self._horizon_costs(state, b, single=True)
+                    S_static = self._horizon_costs(state, b, single=True, fold=False)
                 viz = self.sim.visualize_link_buffer[len(viz0):]
                 self.sim.visualize_link_buffer = viz0
                 self._cost_graph = (graph, S_static, sig, viz)
@@ -469,7 +481,7 @@ class MPPIPlanner:
                 warnings.warn(f"the Objective's horizon evaluation is not graph-capturable ({type(e).__name__}: {e}); evaluating it eagerly")
                 self._cost_graph = False
                 torch.cuda.synchronize()
-                return self._horizon_costs(state, b, single=True)
+                return self._horizon_costs(state, b, single=True, fold=False)
         graph, S_static, _, viz = g
         graph.replay()
         if self.sim._visualize_link_present:
@@ -488,6 +500,7 @@ class MPPIPlanner:
             self._batch_disc = torch.tensor(self._batch_gamma, **f32)[:, None].contiguous()
             self._batch_graph = None
             self._batch_fused = None   # None: not tried yet; True / False: the library's whole-horizon rollout is / is not available
+            self._batch_want, self._batch_done = set(), set()
         b = self._batch_buf
         # the whole horizon in two launches: the fused rollout kernel (no cost, per-step states kept), then one materialise
         # over all H*K env-steps; contexts without that kernel simulate step by step below
@@ -499,8 +512,13 @@ class MPPIPlanner:
                 capi.check(lib, rc)         # (any other failure - a hipMalloc of the trajectory buffer, a launch error - is an error)
                 self._batch_fused = True
         if self._batch_fused:
-            capi.check(lib, lib.mppi_materialise_trajectory(ctx, C_void(b["dof"]), C_void(b["root"]), C_void(b["rb"]), C_void(b["cf"])))
+            # only the tensors the Objective read at the last command are produced up front (one launch); any other one is
+            # materialised when it is asked for (_lazy_materialise through IsaacGymWrapper._fresh)
+            self._batch_done = set(self._batch_want)
+            if self._batch_done:
+                capi.check(lib, lib.mppi_materialise_trajectory(ctx, *[C_void(b[k]) if k in self._batch_done else None for k in ("dof", "root", "rb", "cf")]))
             return b
+        self._batch_done = {"dof", "root", "rb", "cf"}
 
         def simulate():
             for t in range(H):
@@ -530,11 +548,22 @@ class MPPIPlanner:
             simulate()
         return b
 
-    def _horizon_costs(self, state, b, single: bool) -> torch.Tensor:
-        """S_add [K] = sum_t gamma^t c_t from ONE compute_cost over the [H*K]-env view, or from H calls on its [K]-row blocks"""
+    def _lazy_materialise(self, key):
+        """a state tensor of the horizon view is about to be read: produce it now if this command has not yet (and up front from the
+        next command on)"""
+        if key in self._batch_done:
+            return
+        b = self._batch_buf
+        capi.check(self._lib, self._lib.mppi_materialise_trajectory(self._ctx, *[C_void(b[k]) if k == key else None for k in ("dof", "root", "rb", "cf")]))
+        self._batch_done.add(key)
+        self._batch_want.add(key)
+
+    def _horizon_costs(self, state, b, single: bool, fold=None) -> torch.Tensor:
+        """S_add [K] = sum_t gamma^t c_t from ONE compute_cost over the [H*K]-env view, or from H calls on its [K]-row blocks;
+        fold=False (single call only): the un-discounted stage costs [H*K] themselves, for mppi_reduce_horizon_costs"""
         sim, H, K = self.sim, self.T, self.K
         if single:
-            with sim._horizon_view(b, H * K), torch.no_grad():
+            with sim._horizon_view(b, H * K, lazy=self._lazy_materialise), torch.no_grad():
                 c = self._running_cost(state)
                 if sim._visualize_link_present:
                     viz = sim.visualize_link_pos.reshape(H, K, 3)
@@ -542,10 +571,10 @@ class MPPIPlanner:
             c = c.to(dtype=torch.float32, device=sim.device)
             if c.shape != (H * K,):
                 raise ValueError(f"compute_cost must return one cost per env ([{H * K}] over the horizon view), got {tuple(c.shape)}")
-            return (c.view(H, K) * self._batch_disc).sum(0).contiguous()
+            return c.contiguous() if fold is False else (c.view(H, K) * self._batch_disc).sum(0).contiguous()
         S = torch.zeros(K, dtype=torch.float32, device=sim.device)
         for t in range(H):
-            with sim._horizon_view({k: v[t * K:(t + 1) * K] for k, v in b.items()}, K):
+            with sim._horizon_view({k: v[t * K:(t + 1) * K] for k, v in b.items()}, K, lazy=self._lazy_materialise):
                 if sim._visualize_link_present:
                     sim.visualize_link_buffer.append(sim.visualize_link_pos.clone())
                 with torch.no_grad():
