@@ -416,6 +416,10 @@ int mppi_sim_finish(mppi_ctx_t *ctx);                      /* S += control cost 
  * MPPI_EUNSUPPORTED for contexts that run the one-lane kernels or a contact scene with fewer than 8 samples. */
 int mppi_rollout_trajectory(mppi_ctx_t *ctx);
 int mppi_materialise_trajectory(mppi_ctx_t *ctx, float *dof_dev, float *root_dev, float *rb_dev, float *cf_dev);
+/* (ABI 8) one rigid body of all H*K env-steps as dense rows [H*K][13]: what `sim.get_actor_link_by_name(actor, link)` of an
+ * Objective reads (reference isaacgym_wrapper.py:302-308) without the whole [H*K][B][13] tensor.  MPPI_EUNSUPPORTED for contact
+ * scenes and for rigid bodies that are no robot link: callers take the full tensor. */
+int mppi_materialise_trajectory_link(mppi_ctx_t *ctx, int rb_index, float *out_dev);
 /* (ABI 8) ... and the other end of that horizon in ONE launch: cost_dev [H][K] = the stage costs of all env-steps as the host-side
  * Objective returned them (row t*K + k); S_k += sum_t gamma^t c_t[k] + control cost, then the per-wavefront records (what
  * mppi_sim_accumulate_cost, mppi_sim_finish and mppi_reduce do in three); record_out_dev as in mppi_reduce.  MPPI_EUNSUPPORTED

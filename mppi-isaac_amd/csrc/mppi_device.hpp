@@ -1056,4 +1056,35 @@ MPPI_HD void rigid_body_state(CModel &m, const float *root, const float *q, cons
         for (int j = 0; j < 3 * m.n_rb; j++) cf[j] = 0.f;
 }
 
+// the rigid-body row (position, quaternion xyzw, linear and angular velocity: 13 floats) of ONE robot link of one env
+template <class T>
+MPPI_HD void rigid_body_link(CModel &m, const float *root, const float *q, const float *qd, int l, float *o) {
+    constexpr int NB = T::NB;
+    Pose<T> P;
+    forward_kinematics<T>(m, root, q, P);
+    SV v[NB ? NB : 1];
+    static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
+        constexpr int i = ic;
+        constexpr int par = T::par[i];
+        SV S = joint_subspace<T, i>(m, P);
+        SV sj = {qd[i] * S.a, qd[i] * S.l};
+        if constexpr (par < 0) v[i] = sj;
+        else v[i] = v[par < 0 ? 0 : par] + sj;
+    });
+    M3 R;
+    V3 p;
+    link_pose<T>(m, P, l, R, p);
+    SV vb = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
+        constexpr int i = ic;
+        const float w = m.l[l].body == i ? 1.f : 0.f;
+        vb = {vb.a + w * v[i].a, vb.l + w * v[i].l};
+    });
+    V3 lv = vb.l + cross(vb.a, p);
+    o[0] = p.x; o[1] = p.y; o[2] = p.z;
+    R_to_quat(R, o + 3);
+    o[7] = lv.x; o[8] = lv.y; o[9] = lv.z;
+    o[10] = vb.a.x; o[11] = vb.a.y; o[12] = vb.a.z;
+}
+
 }  // namespace mppi

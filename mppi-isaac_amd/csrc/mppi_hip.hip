@@ -513,6 +513,7 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
             if (c->quad) {
                 c->launch_rollout_traj = oct ? e->rollout_oct_traj : e->rollout_traj;
                 c->launch_materialise_traj = e->materialise_traj;
+                c->launch_materialise_traj_link = e->materialise_traj_link;
             }
             c->launch_combine_world = e->combine_world;
             // many envs: quad step kernel; the K = 1 world (and tiny K) keeps the one-lane kernel
@@ -745,6 +746,19 @@ int mppi_materialise_trajectory(mppi_ctx_t *c, float *dof, float *root, float *r
     CTX_TRY(c);
     if (!c->launch_materialise_traj || !c->d_traj) return fail(MPPI_ESTATE, "mppi_materialise_trajectory: no trajectory (mppi_rollout_trajectory)");
     c->launch_materialise_traj(c, dof, root, rb, cf);
+    return launch_check();
+}
+/* (ABI 8) one rigid body of all H*K env-steps of the last mppi_rollout_trajectory as dense rows [H*K][13] - what
+ * `sim.get_actor_link_by_name(actor, link)` of an Objective needs over the horizon, without the [H*K][n_rb][13] tensor around it.
+ * MPPI_EUNSUPPORTED: contact scenes and rigid bodies that are no robot link (callers take the full tensor instead) */
+int mppi_materialise_trajectory_link(mppi_ctx_t *c, int rb_index, float *out_dev) {
+    CTX_TRY(c);
+    if (!c->launch_materialise_traj || !c->d_traj) return fail(MPPI_ESTATE, "mppi_materialise_trajectory_link: no trajectory (mppi_rollout_trajectory)");
+    if (!out_dev) return fail(MPPI_EINVAL, "null output");
+    const int l = rb_index - c->hm.robot_first_rb;
+    if (!c->launch_materialise_traj_link || c->scene || l < 0 || l >= c->hm.nl)
+        return fail(MPPI_EUNSUPPORTED, "mppi_materialise_trajectory_link: a robot link of a contact-free scene");
+    c->launch_materialise_traj_link(c, l, out_dev);
     return launch_check();
 }
 int mppi_reduce(mppi_ctx_t *c, float *record_out_dev) {

@@ -1517,6 +1517,33 @@ __global__ __launch_bounds__(kWave) void k_materialise(const DevModel *__restric
     mirror_env0(mirror, mirror_seq, seq, k, dof, root, 2 * NB, 13 * A);
 }
 
+// one robot link of N envs as dense rows [N][13] (generic Objective mode: `sim.get_actor_link_by_name(..)` over the horizon view needs
+// the rows of the ONE link it names, not the [N][n_rb][13] tensor - 68 us of kinematics and scattered stores for the panda's 11
+// links against ~15 for one).  Each wavefront's 64 rows x 13 floats are 832 consecutive floats: staged in LDS, stored coalesced.
+template <class T>
+__global__ __launch_bounds__(kWave) void k_materialise_link(const DevModel *__restrict__ m, int N, const float *__restrict__ x0_root, const float *__restrict__ q_,
+                                                            const float *__restrict__ qd_, int link, float *__restrict__ out) {
+    constexpr int NB = T::NB;
+    __shared__ float s_row[kWave * 13];
+    const int k = blockIdx.x * kWave + threadIdx.x;
+    if (k < N) {
+        float q[NB ? NB : 1], qd[NB ? NB : 1], o[13];
+        static_for<0, NB>([&](auto ic) {
+            constexpr int i = ic;
+            q[i] = q_[(size_t)i * N + k];
+            qd[i] = qd_[(size_t)i * N + k];
+        });
+        rigid_body_link<T>(*(CModel *)m, x0_root, q, qd, link, o);
+        for (int j = 0; j < 13; j++) s_row[threadIdx.x * 13 + j] = o[j];
+    }
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * kWave * 13, end = (size_t)N * 13;
+    for (int j = 0; j < 13; j++) {
+        const size_t at = base + (size_t)j * kWave + threadIdx.x;
+        if (at < end) out[at] = s_row[j * kWave + threadIdx.x];
+    }
+}
+
 // Parity / debug entry (mppi_eval_cost): the cost program of the context evaluated by the interpreter the rollout kernels run
 // (program_cost_with, mppi_device.hpp) on CALLER-GIVEN simulator answers - reference-layout rows of n envs - instead of the
 // kernel's own kinematics: link poses from the rigid-body rows (position, quaternion xyzw), actor rows from the root rows,
@@ -1600,6 +1627,7 @@ struct mppi_ctx {
     DevCost *d_cost_none = nullptr;    // a zero cost for those rollouts
     void (*launch_rollout_traj)(mppi_ctx *) = nullptr;
     void (*launch_materialise_traj)(mppi_ctx *, float *, float *, float *, float *) = nullptr;
+    void (*launch_materialise_traj_link)(mppi_ctx *, int, float *) = nullptr;  // one robot link of all H*K env-steps (contact-free scenes)
     bool helper_wave = false;  // octet rollout kernel with a second wavefront per sample group for half of the contact pairs
     int n_partials = 0;   // records currently held by d_partials
     bool quad = false;
@@ -1675,6 +1703,7 @@ struct TopoEntry {
     void (*rollout_traj)(mppi_ctx *);        // fused rollouts with the per-step states dumped (generic Objective mode)
     void (*rollout_scene_traj)(mppi_ctx *);
     void (*materialise_traj)(mppi_ctx *, float *, float *, float *, float *);
+    void (*materialise_traj_link)(mppi_ctx *, int, float *);
     void (*materialise_scene_traj)(mppi_ctx *, float *, float *, float *, float *);
     void (*sim_step)(mppi_ctx *, int, int, const float *);
     void (*sim_step_quad)(mppi_ctx *, int, int, const float *);
@@ -1865,6 +1894,12 @@ void launch_materialise_traj_t(mppi_ctx *c, float *dof, float *root, float *rb, 
                        c->d_traj + (size_t)T::NB * HK, dof, root, rb, cf);
 }
 template <class T>
+void launch_materialise_traj_link_t(mppi_ctx *c, int link, float *out) {
+    const size_t HK = (size_t)c->H * c->K;
+    hipLaunchKernelGGL(k_materialise_link<T>, dim3((unsigned)((HK + kWave - 1) / kWave)), dim3(kWave), 0, c->stream, c->d_model, (int)HK, c->d_x0_root, c->d_traj,
+                       c->d_traj + (size_t)T::NB * HK, link, out);
+}
+template <class T>
 void launch_combine_world_t(mppi_ctx *p, const float *recs, int n, mppi_ctx *w) {
     MailboxArgs mb;
     if (recs == nullptr) {  // (mppi_exchange_update_step_world: the exchange in the same launch)
@@ -1916,6 +1951,7 @@ void fill_topo_entry_free(TopoEntry &e) {
     e.sim_step_quad = &launch_sim_step_quad_t<T>;
     e.rollout_traj = &launch_rollout_traj_t<T>;
     e.materialise_traj = &launch_materialise_traj_t<T>;
+    e.materialise_traj_link = &launch_materialise_traj_link_t<T>;
     e.materialise = &launch_materialise_t<T>;
     e.combine_world = &launch_combine_world_t<T>;
     e.eval_cost = &launch_eval_cost_t<T>;

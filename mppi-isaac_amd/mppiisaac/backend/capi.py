@@ -153,6 +153,7 @@ _SIGNATURES = {
     "mppi_rollout_trajectory": (C.c_int, [_vp]),
     "mppi_materialise_trajectory": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "mppi_reduce_horizon_costs": (C.c_int, [_vp, _vp, _vp]),
+    "mppi_materialise_trajectory_link": (C.c_int, [_vp, C.c_int, _vp]),
     "mppi_world_step_from": (C.c_int, [_vp, _vp]),
     "mppi_set_state_from_world": (C.c_int, [_vp, _vp]),
     "mppi_update_step_world": (C.c_int, [_vp, _vp, C.c_int, _vp]),

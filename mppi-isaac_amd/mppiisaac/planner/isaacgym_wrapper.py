@@ -665,27 +665,39 @@ class IsaacGymWrapper:
         return self._state_t[key]
 
     _view_lazy = None
+    _view_link = None
 
     @contextlib.contextmanager
-    def _horizon_view(self, tensors: dict, n_rows: int, lazy=None):
+    def _horizon_view(self, tensors: dict, n_rows: int, lazy=None, link=None):
         """the four state tensors replaced by [H*K, ...] blocks (row block t = the envs after horizon step t) and num_envs by
         H*K, for ONE compute_cost call over a whole horizon (planner/mppi.py: _horizon_batched).  `lazy(key)`: called before a
-        tensor is handed out - the planner materialises only the tensors an Objective actually reads"""
+        tensor is handed out - the planner materialises only the tensors an Objective actually reads; `link(rb_index)`: dense
+        [n_rows, 13] rows of ONE rigid body (or None) - what get_actor_link_by_name hands out instead of a slice of the whole
+        rigid-body tensor"""
         saved = (self._state_t, self.num_envs, self._stale)
-        self._state_t, self.num_envs, self._stale, self._view_lazy = tensors, int(n_rows), False, lazy
+        self._state_t, self.num_envs, self._stale, self._view_lazy, self._view_link = tensors, int(n_rows), False, lazy, link
         try:
             yield self
         finally:
-            self._state_t, self.num_envs, self._stale, self._view_lazy = saved[0], saved[1], True, None
+            self._state_t, self.num_envs, self._stale, self._view_lazy, self._view_link = saved[0], saved[1], True, None, None
 
     _dof_state = property(lambda self: self._fresh("dof"))
     _root_state = property(lambda self: self._fresh("root"))
     _rigid_body_state = property(lambda self: self._fresh("rb"))
     _net_contact_force = property(lambda self: self._fresh("cf"))
 
+    def _rigid_body_rows(self, rb_index: int):
+        """[num_envs, 13] rows of one rigid body: a slice of the rigid-body tensor, or - over the planner's horizon view - the dense
+        rows of just that body (the whole [H*K, B, 13] tensor is then never produced)"""
+        if self._view_link is not None:
+            rows = self._view_link(rb_index)
+            if rows is not None:
+                return rows
+        return self._rigid_body_state[:, rb_index, :]
+
     @property
     def visualize_link_pos(self):
-        return self._rigid_body_state[:, self.robot_rigid_body_viz_idx, 0:3]
+        return self._rigid_body_rows(self.robot_rigid_body_viz_idx)[:, 0:3]
 
     def reset_to_initial_poses(self):
         dof, root = self.scene.initial_state()
@@ -855,7 +867,7 @@ class IsaacGymWrapper:
         return self.get_actor_orientation_by_actor_index(self._get_actor_index_by_robot_index(robot_idx))
 
     def get_rigid_body_by_rigid_body_index(self, rigid_body_idx):
-        return self._rigid_body_state[:, self._as_index(rigid_body_idx), :]
+        return self._rigid_body_rows(self._as_index(rigid_body_idx))
 
     def get_actor_position_by_name(self, name: str):
         return self._root_state[:, self.scene.actor_index(name), 0:3]
@@ -867,7 +879,7 @@ class IsaacGymWrapper:
         return self._root_state[:, self.scene.actor_index(name), 3:7]
 
     def get_actor_link_by_name(self, actor_name: str, link_name: str):
-        return self._rigid_body_state[:, self.scene.rigid_body_index(actor_name, link_name), :]
+        return self._rigid_body_rows(self.scene.rigid_body_index(actor_name, link_name))
 
     def get_actor_contact_forces_by_name(self, actor_name: str, link_name: str):
         return self._net_contact_force[:, self.scene.rigid_body_index(actor_name, link_name)]

@@ -501,6 +501,7 @@ class MPPIPlanner:
             self._batch_graph = None
             self._batch_fused = None   # None: not tried yet; True / False: the library's whole-horizon rollout is / is not available
             self._batch_want, self._batch_done = set(), set()
+            self._batch_links, self._batch_links_want, self._batch_links_done = {}, set(), set()   # dense rows of single rigid bodies
         b = self._batch_buf
         # the whole horizon in two launches: the fused rollout kernel (no cost, per-step states kept), then one materialise
         # over all H*K env-steps; contexts without that kernel simulate step by step below
@@ -517,8 +518,14 @@ class MPPIPlanner:
             self._batch_done = set(self._batch_want)
             if self._batch_done:
                 capi.check(lib, lib.mppi_materialise_trajectory(ctx, *[C_void(b[k]) if k in self._batch_done else None for k in ("dof", "root", "rb", "cf")]))
+            self._batch_links_done = set()
+            if "rb" not in self._batch_done:
+                for idx in self._batch_links_want:
+                    capi.check(lib, lib.mppi_materialise_trajectory_link(ctx, idx, C_void(self._batch_links[idx])))
+                    self._batch_links_done.add(idx)
             return b
         self._batch_done = {"dof", "root", "rb", "cf"}
+        self._batch_links_done = set()
 
         def simulate():
             for t in range(H):
@@ -558,12 +565,31 @@ class MPPIPlanner:
         self._batch_done.add(key)
         self._batch_want.add(key)
 
+    def _lazy_link(self, idx: int):
+        """dense [H*K, 13] rows of rigid body `idx` over the horizon (None: take the slice of the full rigid-body tensor - it exists
+        already, or this body / scene has no single-body kernel)"""
+        if "rb" in self._batch_done or not self._batch_fused or self._batch_links.get(idx, 0) is None:
+            return None
+        if idx not in self._batch_links_done:
+            buf = self._batch_links.get(idx)
+            if buf is None:
+                buf = torch.zeros((self.T * self.K, 13), dtype=torch.float32, device=self.sim.device)
+            rc = self._lib.mppi_materialise_trajectory_link(self._ctx, idx, C_void(buf))
+            if rc == capi.MPPI_EUNSUPPORTED:
+                self._batch_links[idx] = None      # (remembered: no second attempt)
+                return None
+            capi.check(self._lib, rc)
+            self._batch_links[idx] = buf
+            self._batch_links_done.add(idx)
+            self._batch_links_want.add(idx)
+        return self._batch_links[idx]
+
     def _horizon_costs(self, state, b, single: bool, fold=None) -> torch.Tensor:
         """S_add [K] = sum_t gamma^t c_t from ONE compute_cost over the [H*K]-env view, or from H calls on its [K]-row blocks;
         fold=False (single call only): the un-discounted stage costs [H*K] themselves, for mppi_reduce_horizon_costs"""
         sim, H, K = self.sim, self.T, self.K
         if single:
-            with sim._horizon_view(b, H * K, lazy=self._lazy_materialise), torch.no_grad():
+            with sim._horizon_view(b, H * K, lazy=self._lazy_materialise, link=self._lazy_link), torch.no_grad():
                 c = self._running_cost(state)
                 if sim._visualize_link_present:
                     viz = sim.visualize_link_pos.reshape(H, K, 3)
@@ -574,7 +600,8 @@ class MPPIPlanner:
             return c.contiguous() if fold is False else (c.view(H, K) * self._batch_disc).sum(0).contiguous()
         S = torch.zeros(K, dtype=torch.float32, device=sim.device)
         for t in range(H):
-            with sim._horizon_view({k: v[t * K:(t + 1) * K] for k, v in b.items()}, K, lazy=self._lazy_materialise):
+            rows_of = lambda idx, t=t: (lambda r: None if r is None else r[t * K:(t + 1) * K])(self._lazy_link(idx))
+            with sim._horizon_view({k: v[t * K:(t + 1) * K] for k, v in b.items()}, K, lazy=self._lazy_materialise, link=rows_of):
                 if sim._visualize_link_present:
                     sim.visualize_link_buffer.append(sim.visualize_link_pos.clone())
                 with torch.no_grad():
