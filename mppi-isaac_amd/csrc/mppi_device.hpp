@@ -39,7 +39,7 @@ constexpr int kMaxLinks = 24;
 constexpr int kMaxActors = 12;
 constexpr int kMaxNu = 12;
 constexpr int kMaxShapes = 56;
-constexpr int kMaxPairs = 96;
+constexpr int kMaxPairs = 64;
 constexpr int kMaxFree = 4;        // free actors a MODEL may hold (MPPI_MAX_FREE)
 // free-actor slots the contact-scene KERNELS of this build carry (state rows, frames, LDS rows are sized by it): 2 in the shipped
 // library - every example scene of the reference has at most two free actors, and two more slots cost the register-bound scene

@@ -823,6 +823,51 @@ MPPI_HD void sphere_in_box(const Gains &P, V3 ps, float r, const ShapeW &Y, cons
     contact_point(P, pw, sign * mul(Y.R, nl), depth, vA, vB, acc);
 }
 
+// disc (thin wheel / caster cylinder: centre pc, unit axis ax, radius r) against box Y - round 5: the wheels and casters of a
+// mobile base meet the boxes of OTHER actors too (reference: everything in an env shares one collision group,
+// isaacgym_wrapper.py:436-442), not just the ground.  ONE analytic point, like the disc's rim point against the ground: from the
+// disc centre a ray runs IN THE DISC'S PLANE towards the box (towards the box's closest point to the centre); the box covers the
+// stretch [t_in, t_out] of it (slab test), the disc the stretch [0, r].  The contact point is the deepest point of the disc along
+// that ray: the rim point, t = r, when the box reaches beyond the rim - or the middle of the box's stretch when the box is thinner
+// than the disc reaches (t = min(r, (t_in + t_out) / 2): continuous in every parameter).  Depth and normal are those of a point
+// inside a box (box_interior).  A box over the disc's flat side (no direction in the plane) is met by the disc centre.
+// sign = +1 when the disc is shape A.
+MPPI_HD void disc_in_box(const Gains &P, V3 pc, V3 ax, float r, const ShapeW &Y, const float *hy, float sign, const SV &vA, const SV &vB, PairAcc &acc) {
+    const V3 d0 = pc - Y.p;
+    const V3 yc = {Y.R.a[0] * d0.x + Y.R.a[3] * d0.y + Y.R.a[6] * d0.z, Y.R.a[1] * d0.x + Y.R.a[4] * d0.y + Y.R.a[7] * d0.z,
+                   Y.R.a[2] * d0.x + Y.R.a[5] * d0.y + Y.R.a[8] * d0.z};           // disc centre in the box frame
+    const V3 cl = {fminf(fmaxf(yc.x, -hy[0]), hy[0]), fminf(fmaxf(yc.y, -hy[1]), hy[1]), fminf(fmaxf(yc.z, -hy[2]), hy[2])};
+    const V3 al = {Y.R.a[0] * ax.x + Y.R.a[3] * ax.y + Y.R.a[6] * ax.z, Y.R.a[1] * ax.x + Y.R.a[4] * ax.y + Y.R.a[7] * ax.z,
+                   Y.R.a[2] * ax.x + Y.R.a[5] * ax.y + Y.R.a[8] * ax.z};           // disc axis in the box frame
+    V3 e = cl - yc;                                  // from the disc centre to the box's closest point ...
+    e = e - dot(e, al) * al;                         // ... within the disc's plane
+    const float l2 = dot(e, e);
+    V3 y = yc;
+    if (l2 > 1e-12f) {
+        const V3 u = frsqrt(l2) * e;                 // ray direction; the box's stretch of the ray by the slab test
+        float t_in = 0.f, t_out = r + r + hy[0] + hy[1] + hy[2];
+        const float uc[3] = {u.x, u.y, u.z}, oc[3] = {yc.x, yc.y, yc.z};
+        bool miss = false;
+        for (int j = 0; j < 3; j++) {
+            if (fabsf(uc[j]) > 1e-6f) {
+                const float inv = frcp(uc[j]), t1 = (-hy[j] - oc[j]) * inv, t2 = (hy[j] - oc[j]) * inv;
+                t_in = fmaxf(t_in, fminf(t1, t2));
+                t_out = fminf(t_out, fmaxf(t1, t2));
+            } else {
+                miss = miss || fabsf(oc[j]) >= hy[j];
+            }
+        }
+        if (miss || t_in >= fminf(t_out, r)) return;
+        y = yc + fminf(r, 0.5f * (t_in + t_out)) * u;
+    }
+    const float dx = hy[0] - fabsf(y.x), dy = hy[1] - fabsf(y.y), dz = hy[2] - fabsf(y.z);
+    if (!(dx > 0.f && dy > 0.f && dz > 0.f)) return;
+    V3 nl;
+    float depth;
+    box_interior(dx, dy, dz, y, nl, depth);
+    contact_point(P, Y.p + mul(Y.R, y), sign * mul(Y.R, nl), depth, vA, vB, acc);
+}
+
 // two spheres: normal along the line of centres (from B to A), contact point in the middle of the overlap; coincident centres
 // push apart along +z (sphere obstacles of the plannerbenchmark adapters against sphere-shaped links,
 // reference benchmarks/panda_arm/mppi_planner/mppi_planner_wrapper.py:58-79)
@@ -902,7 +947,7 @@ MPPI_HD bool pair_broad_phase(M &m, int ip, const PairGeom &G, const float *root
             // base hovers within its bounding sphere's reach of the ground for ever), a sphere by its radius
             apart = typeA == 0 ? wa.p.z - (fabsf(wa.R.a[6]) * hA[0] + fabsf(wa.R.a[7]) * hA[1] + fabsf(wa.R.a[8]) * hA[2]) > kMargin
                                : (typeA != 2 && wa.p.z > rA + kMargin);
-        } else if (typeA != 2 && typeB != 2) {
+        } else {   // (a disc against another shape: culled like a sphere of its radius)
             const float rB = typeB == 0 ? fsqrt(hB[0] * hB[0] + hB[1] * hB[1] + hB[2] * hB[2]) * 1.000001f : hB[0];
             const V3 d = wa.p - wb.p;
             if (typeB == 0) {
@@ -1104,7 +1149,7 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
                 // base hovers within its bounding sphere's reach of the ground for ever), a sphere by its radius
                 apart = typeA == 0 ? wa.p.z - (fabsf(wa.R.a[6]) * hA[0] + fabsf(wa.R.a[7]) * hA[1] + fabsf(wa.R.a[8]) * hA[2]) > kMargin
                                    : (typeA != 2 && wa.p.z > rA + kMargin);
-            } else if (typeA != 2 && typeB != 2) {
+            } else {   // (a disc against another shape: culled like a sphere of its radius)
                 const float rB = typeB == 0 ? fsqrt(hB[0] * hB[0] + hB[1] * hB[1] + hB[2] * hB[2]) * 1.000001f : hB[0];
                 const V3 d = wa.p - wb.p;
                 if (typeB == 0) {
@@ -1194,6 +1239,8 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
                 if (typeA == 1 && typeB == 0) sphere_in_box(P, wa.p, hA[0], wb, hB, 1.f, wa.v, wb.v, out);
                 else if (typeA == 0 && typeB == 1) sphere_in_box(P, wb.p, hB[0], wa, hA, -1.f, wa.v, wb.v, out);
                 else if (typeA == 1 && typeB == 1) sphere_sphere(P, wa.p, hA[0], wb.p, hB[0], wa.v, wb.v, out);
+                else if (typeA == 2 && typeB == 0) disc_in_box(P, wa.p, V3{wa.R.a[2], wa.R.a[5], wa.R.a[8]}, hA[0], wb, hB, 1.f, wa.v, wb.v, out);
+                else if (typeA == 0 && typeB == 2) disc_in_box(P, wb.p, V3{wb.R.a[2], wb.R.a[5], wb.R.a[8]}, hB[0], wa, hA, -1.f, wa.v, wb.v, out);
             }
         };
         MPPI_SEC(13);  // contact law, velocities

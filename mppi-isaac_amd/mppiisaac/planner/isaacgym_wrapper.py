@@ -269,6 +269,10 @@ class Scene:
     # depth over which the damper and the implicit spring term of a contact ramp in (None: the static sag |g| h^2 / alpha of a
     # body resting on its contact patch - 7.7 mm at h = 25 ms -, so a body at rest sees the full law; 0: no ramp)
     CONTACT_RAMP_DEPTH = None
+    # wheel / caster discs against the boxes of other actors (round 5; False restores the ground-only wheels of rounds 1-4: an A/B
+    # switch for measurements - MPPI_WHEEL_BOX_PAIRS=0 in the environment does the same)
+    import os as _os
+    WHEEL_BOX_PAIRS = _os.environ.get("MPPI_WHEEL_BOX_PAIRS", "1") != "0"
 
     def _contact_scene(self):
         """Collision primitives and candidate pairs of one env.
@@ -337,8 +341,14 @@ class Scene:
                     continue
                 kinds = {si["type"], sj["type"]}
                 names = (f'{self.env_cfg[si["actor"]].name}:{si["link"]}', f'{self.env_cfg[sj["actor"]].name}:{sj["link"]}')
-                if capi.SHAPE_DISC in kinds:
-                    # modelling decision: wheels and casters are rim contacts against the ground plane only
+                if capi.SHAPE_DISC in kinds and kinds != {capi.SHAPE_DISC, capi.SHAPE_BOX}:
+                    # round 5: wheels and casters meet the BOXES of other actors (block, obstacles, walls, table: every non-robot
+                    # shape of the reference's examples but the obstacle spheres of the benchmark adapters) as well as the ground;
+                    # what is still left out - a wheel against a sphere or another wheel - is listed here and logged
+                    self.dropped_pairs.append(names)
+                    self.dropped_pair_shapes.append((i, j))
+                    continue
+                if capi.SHAPE_DISC in kinds and not self.WHEEL_BOX_PAIRS:
                     self.dropped_pairs.append(names)
                     self.dropped_pair_shapes.append((i, j))
                     continue
@@ -353,8 +363,8 @@ class Scene:
             if key not in _REPORTED_DROPS:  # once per distinct scene and process
                 _REPORTED_DROPS.add(key)
                 logging.getLogger("mppiisaac").warning(
-                    "contact model: %d wheel/caster pairs collide with the ground only and are not tested against other "
-                    "shapes (e.g. %s / %s); see Scene.dropped_pairs", len(key), *key[0])
+                    "contact model: %d wheel/caster pairs are not tested (a wheel against a sphere or another wheel%s; e.g. %s / %s); "
+                    "see Scene.dropped_pairs", len(key), "" if self.WHEEL_BOX_PAIRS else ", and - MPPI_WHEEL_BOX_PAIRS=0 - against boxes", *key[0])
         return shapes, pairs
 
     def _is_wheel(self, link: dict, R_shape: np.ndarray) -> bool:

@@ -593,6 +593,53 @@ static void sphere_in_box(int mode, real mu, real k, real cn, real ct, real kh, 
     contact_point(mode, mu, k, cn, ct, kh, pw, n, depth, vA, vB, acc);
 }
 
+/* disc (wheel / caster: centre pc, unit axis ax, radius r) against box Y - round 5, the reference's "everything in an env
+ * collides" (isaacgym_wrapper.py:436-442) for the wheels and casters of the mobile bases.  One analytic point: a ray
+ * from the disc centre, in the disc's plane, towards the box's closest point; the box covers [t_in, t_out] of it (slab test), the
+ * disc [0, r]; contact point at t = min(r, (t_in + t_out) / 2) - the rim point, or the middle of a box thinner than the disc
+ * reaches -, depth and normal of a point inside a box.  A box over the flat side is met by the disc centre. */
+static void disc_in_box(int mode, real mu, real k, real cn, real ct, real kh, const real *pc, const real *ax, real r, const shape_w_t *Y, const double *hy,
+                        real sign, const real *vA, const real *vB, pair_acc_t *acc) {
+    real d[3], yc[3], al[3], cl[3], e[3], y[3];
+    for (int j = 0; j < 3; j++) d[j] = pc[j] - Y->p[j];
+    m3_tvec(Y->R, d, yc);
+    m3_tvec(Y->R, ax, al);
+    real ea = 0, l2 = 0;
+    for (int j = 0; j < 3; j++) {
+        cl[j] = yc[j] < -(real)hy[j] ? -(real)hy[j] : (yc[j] > (real)hy[j] ? (real)hy[j] : yc[j]);
+        e[j] = cl[j] - yc[j];
+        ea += e[j] * al[j];
+    }
+    for (int j = 0; j < 3; j++) { e[j] -= ea * al[j]; l2 += e[j] * e[j]; }
+    for (int j = 0; j < 3; j++) y[j] = yc[j];
+    if (l2 > (real)1e-12) {
+        real il = 1 / (real)sqrt((double)l2), t_in = 0, t_out = r + r + (real)(hy[0] + hy[1] + hy[2]);
+        int miss = 0;
+        for (int j = 0; j < 3; j++) {
+            real u = e[j] * il;
+            if (fabs((double)u) > 1e-6) {
+                real t1 = (-(real)hy[j] - yc[j]) / u, t2 = ((real)hy[j] - yc[j]) / u;
+                real lo = t1 < t2 ? t1 : t2, hi = t1 < t2 ? t2 : t1;
+                if (lo > t_in) t_in = lo;
+                if (hi < t_out) t_out = hi;
+            } else if (fabs((double)yc[j]) >= hy[j]) miss = 1;
+        }
+        real end = t_out < r ? t_out : r;
+        if (miss || t_in >= end) return;
+        real t = (real)0.5 * (t_in + t_out); if (t > r) t = r;
+        for (int j = 0; j < 3; j++) y[j] = yc[j] + t * e[j] * il;
+    }
+    real dx = (real)hy[0] - (real)fabs((double)y[0]), dy = (real)hy[1] - (real)fabs((double)y[1]), dz = (real)hy[2] - (real)fabs((double)y[2]);
+    if (!(dx > 0 && dy > 0 && dz > 0)) return;
+    real nl[3], depth, pw[3], n[3], t3[3];
+    box_interior(dx, dy, dz, y, nl, &depth);
+    m3_vec(Y->R, y, t3);
+    for (int j = 0; j < 3; j++) pw[j] = Y->p[j] + t3[j];
+    m3_vec(Y->R, nl, n);
+    for (int j = 0; j < 3; j++) n[j] *= sign;
+    contact_point(mode, mu, k, cn, ct, kh, pw, n, depth, vA, vB, acc);
+}
+
 /* two spheres: normal along the line of centres (from B to A), contact point in the middle of the overlap; coincident centres
  * push apart along +z.  (The plannerbenchmark adapters add sphere obstacles next to sphere-shaped robot links,
  * benchmarks/panda_arm/mppi_planner/mppi_planner_wrapper.py:58-79.) */
@@ -688,6 +735,12 @@ static void scene_contacts(const mppi_model_t *m, const scene_info_t *si, frame_
                 sphere_in_box(mode, mu, k, cn, ct, kh, wb.p, (real)B->size[0], &wa, A->size, -1, wa.v, wb.v, &acc);
             } else if (A->type == MPPI_SHAPE_SPHERE && B->type == MPPI_SHAPE_SPHERE) {
                 sphere_sphere(mode, mu, k, cn, ct, kh, wa.p, (real)A->size[0], wb.p, (real)B->size[0], wa.v, wb.v, &acc);
+            } else if (A->type == MPPI_SHAPE_DISC && B->type == MPPI_SHAPE_BOX) {
+                real ax[3] = {wa.R[2], wa.R[5], wa.R[8]};
+                disc_in_box(mode, mu, k, cn, ct, kh, wa.p, ax, (real)A->size[0], &wb, B->size, 1, wa.v, wb.v, &acc);
+            } else if (A->type == MPPI_SHAPE_BOX && B->type == MPPI_SHAPE_DISC) {
+                real ax[3] = {wb.R[2], wb.R[5], wb.R[8]};
+                disc_in_box(mode, mu, k, cn, ct, kh, wb.p, ax, (real)B->size[0], &wa, A->size, -1, wa.v, wb.v, &acc);
             }
         }
         if (!acc.any) continue;

@@ -1,8 +1,17 @@
 """Parity of the HIP path (through the C-ABI, libmppi_hip.so) with the CPU oracle on a real MI355X.
 
-Tolerances (fp32 device arithmetic vs the fp64 oracle): sampled noise 1e-6 absolute,
-trajectory cost 1e-4 relative, effective perturbation 1e-6, action 1e-3 * |u_max|, joint position
-1e-4 rad after a 20-step rollout."""
+Tolerances (fp32 device arithmetic vs the fp64 oracle), AS ASSERTED below:
+
+* sampler, update, contact-FREE rollouts (point robot, panda and the other fixed-base arms), per sample: sampled noise 1e-6
+  absolute, trajectory cost 1e-4 relative, effective perturbation 1e-6, action 1e-3 * |u_max|, joint position 1e-4 rad after a
+  20-step rollout - every one of the K samples (test_full_size_properties: all 4096).
+* CONTACT scenes (BASELINE configs 4 and 5) - a STATISTICAL bound plus a bound on what the controller consumes, not a per-sample
+  tolerance: a rollout through contact amplifies a last-bit difference by up to 2x per substep (fp64 vs fp32 builds of the oracle
+  part ways on as many samples), so over all K = 8192 samples: at the initial states >= 99.9 % within 1e-3 and max <= 1e-2; at
+  the recorded closed-loop states >= 99.5 % within 1e-3 and >= 99.9 % within 1e-2; at states derived from violent rollouts
+  >= 99 % / 99.9 %; EVERYWHERE the samples beyond 1e-3 carry < 1e-3 of the softmax normaliser eta (measured: 0 - they are the
+  expensive, tumbling ones) and replacing the kernel's costs by the oracle's moves the nominal update by <= 1e-3 |u_max|.
+  Where along the horizon a sample leaves the oracle: tests/test_gpu_state_parity.py (per-step states of all K samples)."""
 import ctypes as C
 import os
 

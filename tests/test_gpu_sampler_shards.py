@@ -418,34 +418,11 @@ def test_two_robots_in_one_env(lib, oracle64, tmp_path):
         world.set_actor_position_by_robot_index([0.0, 0.0, 0.05], 1)
 
 
-def _disc_box_clearance(disc, box, rb):
-    """smallest distance between the points of a disc (rim, a half-radius ring and the centre, 64 per ring) and a box
-    (positive outside); rb: the world's rigid-body rows [B,13] (position, quaternion xyzw)"""
-    def pose(shape):
-        row = rb[shape["rb"]]
-        x, y, z, w = row[3:7]
-        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
-                      [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
-                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
-        # (rb is the row of the LINK that carries the shape; shape["R"], shape["p"] are relative to the moving body instead)
-        return R @ np.asarray(shape["R_in_link"]), R @ np.asarray(shape["p_in_link"]) + row[0:3]
-    Rd, pd = pose(disc)
-    Rb, pb = pose(box)
-    a = np.linspace(0.0, 2 * np.pi, 64, endpoint=False)
-    ring = np.stack([np.cos(a), np.sin(a), np.zeros_like(a)], 1)       # a disc lies in its shape frame's xy plane (axis z)
-    pts = np.concatenate([disc["size"][0] * ring, 0.5 * disc["size"][0] * ring, np.zeros((1, 3))]) @ Rd.T + pd
-    loc = (pts - pb) @ Rb
-    d = np.abs(loc) - np.asarray(box["size"])
-    outside = np.linalg.norm(np.maximum(d, 0.0), axis=1)
-    inside = np.minimum(d.max(axis=1), 0.0)
-    return float((outside + inside).min())
-
-
-def test_wheel_and_caster_pairs_left_out_of_the_contact_model_stay_clear(lib):
-    """wheels and casters (disc shapes) are tested against the ground only; the candidate pairs with boxes of
-    other actors are listed in Scene.dropped_pair_shapes.  Over the closed loop of every example with such pairs (planner +
-    K=1 world, 300 control iterations - the pushing scene reaches and pushes its block in that time) no left-out pair comes
-    within the reference's contact offset (conf/isaacgym: contact_offset 0.01): the modelling cut changes no force there."""
+def test_no_candidate_pair_is_left_out_of_any_example_scene(lib):
+    """rounds 1-4 tested wheels and casters against the ground only and measured how close the left-out pairs came (16 mm in the
+    pushing scene).  Round 5: disc-box pairs are part of the contact model (csrc/mppi_scene.hpp disc_in_box) - in every example
+    scene of the reference every candidate pair the collision filter allows is now tested (Scene.dropped_pairs is empty), and the
+    pushing scene carries the twelve wheel / caster pairs against block and obstacles."""
     import importlib.util
     import os
     from mppiisaac.backend import capi
@@ -453,32 +430,15 @@ def test_wheel_and_caster_pairs_left_out_of_the_contact_model_stay_clear(lib):
     spec = importlib.util.spec_from_file_location("examples_run", path)
     run = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(run)
-    checked = 0
+    disc_pairs = {}
     for name in sorted(run.EXAMPLES):
         cfg = run.config(name, filter_u=False)
         planner = run.make_planner(name, cfg)
         sc = planner.sim.scene
-        if not sc.dropped_pair_shapes:
-            planner.sim.stop_sim()
-            continue
-        closest = {}
-
-        def hook(i, sim, sc=sc, closest=closest):
-            rb = sim._rigid_body_state[0].cpu().numpy().astype(np.float64)
-            for (i0, i1), names in zip(sc.dropped_pair_shapes, sc.dropped_pairs):
-                a, b = sc.all_shapes[i0], sc.all_shapes[i1]
-                disc, other = (a, b) if a["type"] == capi.SHAPE_DISC else (b, a)
-                if other["type"] != capi.SHAPE_BOX:
-                    continue
-                closest[names] = min(closest.get(names, np.inf), _disc_box_clearance(disc, other, rb))
-        first, last, _ = run.run_world(name, cfg, planner, 300, report=False, hook=hook)
+        assert not sc.dropped_pairs, (name, sc.dropped_pairs[:2])
+        disc_pairs[name] = sum(1 for a, b in sc.pairs if b >= 0 and capi.SHAPE_DISC in (sc.shapes[a]["type"], sc.shapes[b]["type"]))
         planner.sim.stop_sim()
-        assert closest, name
-        worst = min(closest, key=closest.get)
-        print(f"\n{name}: {len(closest)} wheel/caster-box pairs, closest {worst[0]} / {worst[1]} {closest[worst]:.4f} m; stage cost {first:.3f} -> {last:.3f}")
-        assert closest[worst] > 0.01, (name, worst, closest[worst])
-        checked += 1
-    assert checked >= 1
+    assert disc_pairs["boxer_push"] == 12 and disc_pairs["boxer_reach"] == 4, disc_pairs
 
 
 def test_two_moving_base_robots_in_one_env(lib, oracle64, tmp_path):

@@ -1,0 +1,78 @@
+"""Full-K, PER-STEP state parity of the contact scenes (VERDICT r4 "what's weak" 2): where, along the horizon, does a sample of the
+HIP rollout leave the fp64 oracle?  The trajectory-dumping rollout kernels (mppi_rollout_trajectory + mppi_materialise_trajectory:
+the env state after EVERY horizon step, all K samples) against the oracle's batched env step (orc_envs_step, fp64, OpenMP over the
+envs, the same per-sample actor randomisation) driven with the same commands u_t = clamp(U_t + eps_t).
+
+What is asserted (and printed as a table per state): after the FIRST steps - before contact dynamics had time to amplify the last
+bits - every sample agrees to 1e-4 (joint positions [rad | m] and actor positions [m]); further on the fraction inside each
+tolerance band falls off as the chaotic samples (tumbling block, chassis on its side) part ways, and the test reports
+the horizon step at which each band is left by more than 0.1 % of the samples."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from mppiisaac.backend import capi
+from scenes import boxer_push, panda_pick
+from test_gpu_parity import CLOSED_LOOP_STATES, Ctx
+
+pytestmark = pytest.mark.gpu
+BANDS = (1e-5, 1e-4, 1e-3, 1e-2)
+
+
+def oracle_states(o, m, cfg, dof0, root0, U, eps, n_steps):
+    """[n_steps][K] joint positions / actor positions of the oracle's envs after every step"""
+    K, nu, n, A, B = cfg.num_samples, cfg.nu, m.n_bodies, m.n_actors, m.n_rb
+    f = o.dtype
+    dof = np.tile(np.asarray(dof0, f).reshape(1, -1), (K, 1))
+    root = np.tile(np.asarray(root0, f).reshape(1, A, 13), (K, 1, 1))
+    rb, cf = np.zeros((K, B, 13), f), np.zeros((K, B, 3), f)
+    umin, umax = np.array([cfg.u_min[j] for j in range(nu)]), np.array([cfg.u_max[j] for j in range(nu)])
+    qs, ps = [], []
+    for t in range(n_steps):
+        u = np.clip(np.asarray(U[t], np.float64)[None, :] + eps[t].T.astype(np.float64), umin, umax)
+        if cfg.sample_null_action and cfg.k_offset + K == cfg.k_total:
+            u[-1] = np.clip(np.zeros(nu), umin, umax)
+        u = np.ascontiguousarray(u, f)
+        o.lib.orc_envs_step(C.byref(m), C.c_int(K), C.c_int(cfg.k_offset), o.p(u), o.p(dof), o.p(root), o.p(rb), o.p(cf))
+        qs.append(dof[:, 0::2].copy())
+        ps.append(root[:, :, 0:3].copy())
+    return np.stack(qs), np.stack(ps)
+
+
+@pytest.mark.parametrize("make,name,K,H,nu,first_steps", [(boxer_push, "boxer_push", 8192, 25, 2, 2), (panda_pick, "panda_pick", 8192, 30, 9, 2)])
+def test_per_step_states_of_all_samples_against_the_oracle(make, name, K, H, nu, first_steps, oracle64):
+    Z = np.load(CLOSED_LOOP_STATES)
+    scene, m, cfg, cost, dof0, root0 = make(K=K, H=H)
+    n_cmp = 12
+    for st in ("initial", "recorded"):
+        dof, root = (dof0, root0) if st == "initial" else (Z[f"{name}_recorded_dof"], Z[f"{name}_recorded_root"])
+        U = Z[f"{name}_recorded_U"] if st == "recorded" and f"{name}_recorded_U" in Z.files else np.zeros((H, nu), np.float32)
+        c = Ctx(m, cfg, cost)
+        c.call("mppi_sample", C.c_uint32(0)); c.set_state(dof, root); c.set_U(U)
+        eps = c.get("mppi_get_noise", (H, nu, K))
+        c.call("mppi_rollout_trajectory")
+        f32 = dict(dtype=torch.float32, device="cuda")
+        t_dof, t_root = torch.zeros((H * K, 2 * m.n_bodies), **f32), torch.zeros((H * K, m.n_actors, 13), **f32)
+        c.call("mppi_materialise_trajectory", C.c_void_p(t_dof.data_ptr()), C.c_void_p(t_root.data_ptr()), None, None)
+        torch.cuda.synchronize()
+        q_hip = t_dof.cpu().numpy().reshape(H, K, -1)[:n_cmp, :, 0::2]
+        p_hip = t_root.cpu().numpy().reshape(H, K, m.n_actors, 13)[:n_cmp, :, :, 0:3]
+        c.close()
+        q_orc, p_orc = oracle_states(oracle64, m, cfg, dof, root, U, eps, n_cmp)
+        err = np.maximum(np.abs(q_hip - q_orc).max(-1), np.abs(p_hip - p_orc).reshape(n_cmp, K, -1).max(-1))    # [n_cmp][K]
+        assert np.isfinite(err).all()
+        frac = np.array([[np.mean(err[t] <= b) for b in BANDS] for t in range(n_cmp)])
+        left = {b: next((t for t in range(n_cmp) if frac[t, i] < 0.999), None) for i, b in enumerate(BANDS)}
+        print(f"\n{name}, {st} state: per-step state error of all {K} samples vs the fp64 oracle (max over joint and actor positions)")
+        print("   step | within 1e-5   1e-4     1e-3     1e-2   | median    max")
+        for t in range(n_cmp):
+            print(f"   {t + 1:4d} |  {frac[t, 0]:.4f}   {frac[t, 1]:.4f}   {frac[t, 2]:.4f}   {frac[t, 3]:.4f} | {np.median(err[t]):.1e}  {err[t].max():.1e}")
+        print("   more than 0.1 % of the samples outside a band from step: " + ", ".join(f"{b:g}: {'never (12 steps)' if s is None else s + 1}" for b, s in left.items()))
+        # before the chaotic regime: EVERY sample within 1e-4 over the first steps, the typical sample within 1e-5 for all twelve
+        assert err[:first_steps].max() <= 1e-4, err[:first_steps].max()
+        assert np.median(err[-1]) <= 1e-4
+        # ... and no cliff: 99 % of the samples stay within 1e-2 for the twelve steps
+        assert frac[:, 3].min() >= 0.99

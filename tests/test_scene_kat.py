@@ -405,3 +405,77 @@ def test_sphere_rolls_off_sphere_device_arithmetic_matches_oracle(hostemu, oracl
         np.testing.assert_allclose(re[:, 7:13], r[:, 7:13], atol=2e-3)
         np.testing.assert_allclose(cfe, cf, atol=5e-3 * max(1.0, np.abs(cf).max()))
     assert r[2, 0] > 1.15 and r[2, 2] < 0.1                                   # it has left the top and sits on the ground
+
+
+def _without_pairs(m, drop):
+    """copy of the model without the candidate pairs for which drop(shape a, shape b) holds"""
+    import copy
+    m2 = copy.deepcopy(m) if False else type(m).from_buffer_copy(bytes(m))
+    keep = [(m.pairs[i].a, m.pairs[i].b) for i in range(m.n_pairs) if not drop(m.pairs[i].a, m.pairs[i].b)]
+    for i, (a, b) in enumerate(keep):
+        m2.pairs[i].a, m2.pairs[i].b = a, b
+    m2.n_pairs = len(keep)
+    return m2
+
+
+def test_a_caster_driven_into_a_block_pushes_it(oracle64, open_floor):
+    """round 5: wheels and casters meet the boxes of other actors (reference: one collision group per env,
+    isaacgym_wrapper.py:436-442), not the ground only.  The chassis-block pair is taken OUT of the model here, so the only
+    shapes of the robot that can touch the block are its casters (front: y = -0.274 in the chassis, radius 0.062, heading -y)
+    and wheels: driving forward, the casters' rims reach the block's face and push it along - the face stays at the rims, a
+    millimetre or two inside the penalty layer; with the disc-box pairs removed as well (the model of rounds 1-4) the robot
+    drives straight through the block."""
+    from mppiisaac.backend import capi
+    scene, m, q0, qd0, root0 = open_floor
+    shapes = scene.shapes
+    chassis = next(i for i, s in enumerate(shapes) if s["link"] == "chassis_link")
+    block = next(i for i, s in enumerate(shapes) if scene.env_cfg[s["actor"]].name == "block")
+    discs = {i for i, s in enumerate(shapes) if s["type"] == capi.SHAPE_DISC}
+    assert sum(1 for i in range(m.n_pairs) if m.pairs[i].a in discs and m.pairs[i].b == block) == 4      # two wheels, two casters
+    assert not scene.dropped_pairs                                                                       # nothing is left out
+    only_discs = _without_pairs(m, lambda a, b: {a, b} == {chassis, block})
+    nothing = _without_pairs(m, lambda a, b: b == block and (a == chassis or a in discs))
+    bi, rb_block = scene.actor_index("block"), scene.rigid_body_index("block", "box")
+    res = {}
+    for name, mm in (("discs", only_discs), ("none", nothing)):
+        root = root0.copy()
+        root[bi, 0:3] = [0.0, 2.5 - 0.336 - 0.15 - 0.04, 0.1]        # block face 4 cm in front of the casters' rims
+        root, q, qd, _ = settle(oracle64, mm, root, q0.copy(), qd0.copy(), 10)
+        y0, peak = root[bi, 1], 0.0
+        for _ in range(30):
+            root, q, qd, cf = oracle64.scene_step(mm, root, q, qd, oracle64.cmd_map(mm, (0.5, 0.0)))
+            peak = max(peak, abs(cf[rb_block, 1]))
+        res[name] = (y0 - root[bi, 1], peak, (root[scene.robot_idx, 1] - 0.336) - (root[bi, 1] + 0.15), root[bi, 8])
+    pushed, force, gap, vy = res["discs"]
+    assert pushed > 0.6 and force > 1.0 and vy == pytest.approx(-0.5, abs=0.02), res      # 1.5 s at 0.5 m/s, minus the 4 cm of approach
+    assert -0.005 < gap < 0.0005, res                                     # the block's face rides on the casters' rims
+    assert abs(res["none"][0]) < 1e-6 and res["none"][1] < 1e-9, res      # nothing touches the block without the pairs
+
+
+def test_disc_box_contact_device_arithmetic_matches_oracle(hostemu, oracle64, open_floor):
+    """the disc-box narrow phase of csrc/mppi_scene.hpp (disc_in_box) against the oracle's, with the contact ACTIVE: chassis-block
+    pair out of the model, the robot drives its casters into the block and then turns with a wheel against it; host build of the
+    device functions vs the fp64 oracle, re-synchronised every step"""
+    scene, m, q0, qd0, root0 = open_floor
+    shapes = scene.shapes
+    chassis = next(i for i, s in enumerate(shapes) if s["link"] == "chassis_link")
+    block = next(i for i, s in enumerate(shapes) if scene.env_cfg[s["actor"]].name == "block")
+    mm = _without_pairs(m, lambda a, b: {a, b} == {chassis, block})
+    bi, rbb = scene.actor_index("block"), scene.rigid_body_index("block", "box")
+    root = root0.copy()
+    root[bi, 0:3] = [0.02, 2.5 - 0.336 - 0.15 - 0.01, 0.1]
+    q, qd = q0.copy(), qd0.copy()
+    rb, cf = np.zeros((m.n_rb, 13), np.float32), np.zeros((m.n_rb, 3), np.float32)
+    active, worst = 0, 0.0
+    for u, n in (((0.0, 0.0), 8), ((0.5, 0.0), 14), ((0.3, 1.2), 14), ((0.4, -1.0), 10)):
+        for _ in range(n):
+            de = np.zeros(2 * scene.n_dof, np.float32)
+            de[0::2], de[1::2] = q, qd
+            re = f32(root).copy()
+            assert hostemu.emu_scene_step(C.byref(mm), fp(de), fp(re.reshape(-1)), fp(f32(u)), fp(rb), fp(cf)) == 0
+            root, q, qd, cfo = oracle64.scene_step(mm, root, q, qd, oracle64.cmd_map(mm, u))
+            np.testing.assert_allclose(re[:, 0:7], root[:, 0:7], atol=2e-5)
+            np.testing.assert_allclose(re[:, 7:13], root[:, 7:13], atol=2e-3)
+            active += int(np.abs(cfo[rbb, 0:2]).max() > 0.1)
+            worst = max(worst, np.abs(cf - cfo).max() / max(1.0, np.abs(cfo).max()))
+    assert active >= 15 and worst < 5e-3, (active, worst)
