@@ -825,13 +825,13 @@ MPPI_HD void sphere_in_box(const Gains &P, V3 ps, float r, const ShapeW &Y, cons
 
 // disc (thin wheel / caster cylinder: centre pc, unit axis ax, radius r) against box Y - round 5: the wheels and casters of a
 // mobile base meet the boxes of OTHER actors too (reference: everything in an env shares one collision group,
-// isaacgym_wrapper.py:436-442), not just the ground.  ONE analytic point, like the disc's rim point against the ground: from the
-// disc centre a ray runs IN THE DISC'S PLANE towards the box (towards the box's closest point to the centre); the box covers the
-// stretch [t_in, t_out] of it (slab test), the disc the stretch [0, r].  The contact point is the deepest point of the disc along
-// that ray: the rim point, t = r, when the box reaches beyond the rim - or the middle of the box's stretch when the box is thinner
-// than the disc reaches (t = min(r, (t_in + t_out) / 2): continuous in every parameter).  Depth and normal are those of a point
-// inside a box (box_interior).  A box over the disc's flat side (no direction in the plane) is met by the disc centre.
-// sign = +1 when the disc is shape A.
+// isaacgym_wrapper.py:436-442), not just the ground.  ONE analytic point, like the disc's rim point against the ground - the
+// deepest point of the disc in the box: with e the direction from the disc centre INTO the box (towards the box's closest point
+// while the centre is outside; against the push-out normal of box_interior once it is inside - the two agree on the surface) and
+// e_p its part in the disc's plane, the point is  centre + r e_p / |e|:  the rim point when the box lies in the disc's plane, the
+// centre when it lies over the flat side, everything in between continuously; a box thinner than the disc reaches along that
+// ray is met in the middle of its stretch [t_in, t_out] (slab test) instead.  Depth and normal are those of a point inside a
+// box (box_interior).  sign = +1 when the disc is shape A.
 MPPI_HD void disc_in_box(const Gains &P, V3 pc, V3 ax, float r, const ShapeW &Y, const float *hy, float sign, const SV &vA, const SV &vB, PairAcc &acc) {
     const V3 d0 = pc - Y.p;
     const V3 yc = {Y.R.a[0] * d0.x + Y.R.a[3] * d0.y + Y.R.a[6] * d0.z, Y.R.a[1] * d0.x + Y.R.a[4] * d0.y + Y.R.a[7] * d0.z,
@@ -839,26 +839,32 @@ MPPI_HD void disc_in_box(const Gains &P, V3 pc, V3 ax, float r, const ShapeW &Y,
     const V3 cl = {fminf(fmaxf(yc.x, -hy[0]), hy[0]), fminf(fmaxf(yc.y, -hy[1]), hy[1]), fminf(fmaxf(yc.z, -hy[2]), hy[2])};
     const V3 al = {Y.R.a[0] * ax.x + Y.R.a[3] * ax.y + Y.R.a[6] * ax.z, Y.R.a[1] * ax.x + Y.R.a[4] * ax.y + Y.R.a[7] * ax.z,
                    Y.R.a[2] * ax.x + Y.R.a[5] * ax.y + Y.R.a[8] * ax.z};           // disc axis in the box frame
-    V3 e = cl - yc;                                  // from the disc centre to the box's closest point ...
-    e = e - dot(e, al) * al;                         // ... within the disc's plane
-    const float l2 = dot(e, e);
+    V3 e = cl - yc;                                  // into the box: towards its closest point ...
+    const float cx = hy[0] - fabsf(yc.x), cy = hy[1] - fabsf(yc.y), cz = hy[2] - fabsf(yc.z);
+    if (cx > 0.f && cy > 0.f && cz > 0.f) {          // ... or, with the centre inside, against the push-out direction
+        V3 nc;
+        float dc;
+        box_interior(cx, cy, cz, yc, nc, dc);
+        e = -1.f * nc;
+    }
+    const float le2 = dot(e, e);
+    if (!(le2 > 1e-20f)) return;                     // (centre exactly on the surface: no direction - and no depth)
+    const V3 ep = e - dot(e, al) * al;               // its part in the disc's plane
+    const float ile = frsqrt(le2), lp2 = dot(ep, ep);
+    float t = r * fsqrt(lp2) * ile;                  // distance of the contact point from the centre: r sin(angle between e and the axis)
     V3 y = yc;
-    if (l2 > 1e-12f) {
-        const V3 u = frsqrt(l2) * e;                 // ray direction; the box's stretch of the ray by the slab test
-        float t_in = 0.f, t_out = r + r + hy[0] + hy[1] + hy[2];
+    if (lp2 > 1e-12f * le2) {
+        const V3 u = frsqrt(lp2) * ep;               // ray direction; the box's stretch of the ray by the slab test
+        float t_in = -1e30f, t_out = 1e30f;
         const float uc[3] = {u.x, u.y, u.z}, oc[3] = {yc.x, yc.y, yc.z};
-        bool miss = false;
-        for (int j = 0; j < 3; j++) {
+        for (int j = 0; j < 3; j++)
             if (fabsf(uc[j]) > 1e-6f) {
                 const float inv = frcp(uc[j]), t1 = (-hy[j] - oc[j]) * inv, t2 = (hy[j] - oc[j]) * inv;
                 t_in = fmaxf(t_in, fminf(t1, t2));
                 t_out = fminf(t_out, fmaxf(t1, t2));
-            } else {
-                miss = miss || fabsf(oc[j]) >= hy[j];
             }
-        }
-        if (miss || t_in >= fminf(t_out, r)) return;
-        y = yc + fminf(r, 0.5f * (t_in + t_out)) * u;
+        if (t_out < 1e29f && t_in > -1e29f) t = fminf(t, 0.5f * (fmaxf(t_in, 0.f) + t_out));
+        y = yc + t * u;
     }
     const float dx = hy[0] - fabsf(y.x), dy = hy[1] - fabsf(y.y), dz = hy[2] - fabsf(y.z);
     if (!(dx > 0.f && dy > 0.f && dz > 0.f)) return;

@@ -594,40 +594,51 @@ static void sphere_in_box(int mode, real mu, real k, real cn, real ct, real kh, 
 }
 
 /* disc (wheel / caster: centre pc, unit axis ax, radius r) against box Y - round 5, the reference's "everything in an env
- * collides" (isaacgym_wrapper.py:436-442) for the wheels and casters of the mobile bases.  One analytic point: a ray
- * from the disc centre, in the disc's plane, towards the box's closest point; the box covers [t_in, t_out] of it (slab test), the
- * disc [0, r]; contact point at t = min(r, (t_in + t_out) / 2) - the rim point, or the middle of a box thinner than the disc
- * reaches -, depth and normal of a point inside a box.  A box over the flat side is met by the disc centre. */
+ * collides" (isaacgym_wrapper.py:436-442) for the wheels and casters of the mobile bases.  One analytic point, the
+ * deepest point of the disc in the box: e = direction from the disc centre into the box (to the box's closest point; with the
+ * centre inside: against box_interior's push-out normal), e_p its part in the disc's plane, contact point = centre + r e_p / |e|
+ * (rim point for a box in the disc's plane, centre for a box over the flat side); a box thinner than the disc reaches along that
+ * ray is met in the middle of its stretch (slab test).  Depth and normal of a point inside a box. */
 static void disc_in_box(int mode, real mu, real k, real cn, real ct, real kh, const real *pc, const real *ax, real r, const shape_w_t *Y, const double *hy,
                         real sign, const real *vA, const real *vB, pair_acc_t *acc) {
-    real d[3], yc[3], al[3], cl[3], e[3], y[3];
+    real d[3], yc[3], al[3], e[3], ep[3], y[3], c3[3];
     for (int j = 0; j < 3; j++) d[j] = pc[j] - Y->p[j];
     m3_tvec(Y->R, d, yc);
     m3_tvec(Y->R, ax, al);
-    real ea = 0, l2 = 0;
+    int inside = 1;
     for (int j = 0; j < 3; j++) {
-        cl[j] = yc[j] < -(real)hy[j] ? -(real)hy[j] : (yc[j] > (real)hy[j] ? (real)hy[j] : yc[j]);
-        e[j] = cl[j] - yc[j];
-        ea += e[j] * al[j];
+        real cl = yc[j] < -(real)hy[j] ? -(real)hy[j] : (yc[j] > (real)hy[j] ? (real)hy[j] : yc[j]);
+        e[j] = cl - yc[j];
+        c3[j] = (real)hy[j] - (real)fabs((double)yc[j]);
+        if (!(c3[j] > 0)) inside = 0;
     }
-    for (int j = 0; j < 3; j++) { e[j] -= ea * al[j]; l2 += e[j] * e[j]; }
+    if (inside) {
+        real nc[3], dc;
+        box_interior(c3[0], c3[1], c3[2], yc, nc, &dc);
+        for (int j = 0; j < 3; j++) e[j] = -nc[j];
+    }
+    real le2 = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+    if (!(le2 > (real)1e-20)) return;
+    real ea = e[0] * al[0] + e[1] * al[1] + e[2] * al[2], lp2 = 0;
+    for (int j = 0; j < 3; j++) { ep[j] = e[j] - ea * al[j]; lp2 += ep[j] * ep[j]; }
+    real t = r * (real)sqrt((double)(lp2 / le2));
     for (int j = 0; j < 3; j++) y[j] = yc[j];
-    if (l2 > (real)1e-12) {
-        real il = 1 / (real)sqrt((double)l2), t_in = 0, t_out = r + r + (real)(hy[0] + hy[1] + hy[2]);
-        int miss = 0;
+    if (lp2 > (real)1e-12 * le2) {
+        real il = 1 / (real)sqrt((double)lp2), t_in = (real)-1e30, t_out = (real)1e30;
         for (int j = 0; j < 3; j++) {
-            real u = e[j] * il;
+            real u = ep[j] * il;
             if (fabs((double)u) > 1e-6) {
                 real t1 = (-(real)hy[j] - yc[j]) / u, t2 = ((real)hy[j] - yc[j]) / u;
                 real lo = t1 < t2 ? t1 : t2, hi = t1 < t2 ? t2 : t1;
                 if (lo > t_in) t_in = lo;
                 if (hi < t_out) t_out = hi;
-            } else if (fabs((double)yc[j]) >= hy[j]) miss = 1;
+            }
         }
-        real end = t_out < r ? t_out : r;
-        if (miss || t_in >= end) return;
-        real t = (real)0.5 * (t_in + t_out); if (t > r) t = r;
-        for (int j = 0; j < 3; j++) y[j] = yc[j] + t * e[j] * il;
+        if (t_out < (real)1e29 && t_in > (real)-1e29) {
+            real mid = (real)0.5 * ((t_in > 0 ? t_in : 0) + t_out);
+            if (mid < t) t = mid;
+        }
+        for (int j = 0; j < 3; j++) y[j] = yc[j] + t * ep[j] * il;
     }
     real dx = (real)hy[0] - (real)fabs((double)y[0]), dy = (real)hy[1] - (real)fabs((double)y[1]), dz = (real)hy[2] - (real)fabs((double)y[2]);
     if (!(dx > 0 && dy > 0 && dz > 0)) return;
