@@ -158,7 +158,20 @@ struct DevModel {
     int n_bases;
     int xbase_actor[kMaxExtraBases];
     float xbase_m[kMaxExtraBases], xbase_hb[kMaxExtraBases][3], xbase_Ic[kMaxExtraBases][6];
+    // pair groups (round 5; shared-lane scene kernels): all candidate pairs between the ROBOT's shapes and one shape of another
+    // actor form a group; when that shape is further from the robot's anchor shape than the robot can reach - in every sample of
+    // the wavefront - none of the group's pairs is visited (contact_forces: a culled pair still costs its record, two shape poses
+    // and the broad-phase arithmetic, ~350 issue slots; the pushing scene has 15 robot-block / robot-obstacle pairs since the
+    // wheels and casters meet boxes).  Conservative like the broad phase: a skipped pair is one the broad phase would have culled.
+    int n_groups, grp_pad;
+    struct Group {
+        int anchor, other;          // shapes whose cached centres are compared: a robot shape welded to base 0, the other actor's shape
+        unsigned mask_lo, mask_hi;  // the group's pairs
+        float reach2;               // (robot reach about the anchor's centre + bounding radius of the other shape + margins)^2
+        float pad[3];
+    } grp[8];
 };
+constexpr int kMaxGroups = 8;
 struct CtrlBlock {  // one 64-byte block per quantity: fetched with a single s_load_dwordx16
     float v[16];
 };

@@ -1031,6 +1031,40 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
         }
     }
 #endif
+    // Pair groups (DevModel::Group): the robot's pairs against one shape of another actor are skipped TOGETHER when that shape is
+    // out of the robot's reach in every sample of this wavefront - one distance test per group and substep instead of a record
+    // fetch, two pose reads and the broad-phase arithmetic per pair.  The verdict is wave-uniform (the pair loop is), so the masks
+    // live in scalar registers; conservative like the broad phase (a skipped pair is one it would have culled).
+    unsigned dead_lo = 0u, dead_hi = 0u;
+    if constexpr (kCached) {
+        for (int g = 0; g < m.n_groups; g++) {
+            const V3 d = shape_cached<T>(m, m.grp[g].anchor, L).p - shape_cached<T>(m, m.grp[g].other, L).p;
+            bool far = dot(d, d) > m.grp[g].reach2;
+#if defined(__HIP_DEVICE_COMPILE__)
+            far = __all(far) != 0;
+#endif
+            if (far) { dead_lo |= m.grp[g].mask_lo; dead_hi |= m.grp[g].mask_hi; }
+        }
+#if defined(__HIP_DEVICE_COMPILE__)
+        dead_lo = (unsigned)uniform((int)dead_lo);
+        dead_hi = (unsigned)uniform((int)dead_hi);
+#endif
+        alive_lo &= ~dead_lo;
+        alive_hi &= ~dead_hi;
+    }
+    auto is_dead = [&](int ip) MPPI_LAMBDA { return (((ip < 32 ? dead_lo : dead_hi) >> (ip & 31)) & 1u) != 0u; };
+    // owner / helper wavefront (kSplitOctPair): the pairs that are left are dealt ALTERNATELY in their order - by the parity of the
+    // pair index the work of the two wavefronts would depend on which groups happen to be out of reach
+    unsigned long long mine = 0ull;
+    if constexpr (kPair) {
+        unsigned long long rest = ~((unsigned long long)dead_lo | ((unsigned long long)dead_hi << 32));
+        if (m.n_pairs < 64) rest &= (1ull << m.n_pairs) - 1ull;
+        for (int ord = 0; rest != 0ull; ord++) {
+            const unsigned long long low = rest & (0ull - rest);
+            if ((ord & 1) == split.wave) mine |= low;
+            rest ^= low;
+        }
+    }
     MPPI_SEC(2);
     // The loop visits the pairs that are alive (all of them without the dealt pass).  Both 64-byte blocks of the NEXT pair
     // are requested while the current one is worked on: measured with the section clocks (tools/exp/section_clocks.py), a
@@ -1043,7 +1077,8 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
             if (MPPI_PAIR_SPLIT == 2) return split.wave ? from : (int)m.n_pairs;
             if (MPPI_PAIR_SPLIT == 3) return split.wave ? (int)m.n_pairs : from;
 #endif
-            return from + ((from ^ split.wave) & 1);  // pairs of this wavefront's parity
+            const unsigned long long rest = from < 64 ? mine >> from : 0ull;   // this wavefront's share of the pairs that are left
+            return rest != 0ull ? from + (int)__builtin_ctzll(rest) : (int)m.n_pairs;
         }
         if constexpr (dealt_broad_phase<T>(SPLIT)) {
             if (m.n_pairs > kDealtBroadPhaseMin) {
@@ -1052,6 +1087,7 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
                 return rest != 0ull ? from + (int)__builtin_ctzll(rest) : (int)m.n_pairs;
             }
         }
+        while (from < m.n_pairs && is_dead(from)) from++;
         return from;
     };
     // (small trees walk all pairs in order: wave-uniform records, which the compiler would fetch with scalar loads - no

@@ -164,3 +164,56 @@ def test_on_demand_builds_can_be_switched_off(tmp_path, monkeypatch):
         IsaacGymWrapper(icfg, actors=[actor, "goal"], num_envs=64,
                         mppi_config=lambda scene: make_config(MPPIConfig(num_samples=64, horizon=8, noise_sigma=np.eye(4).tolist()), viz_link=-1))
     assert not os.path.exists(str(tmp_path / "jit_off")) or not os.listdir(str(tmp_path / "jit_off"))
+
+
+def test_three_free_actors_get_kernels_with_four_free_slots(tmp_path, monkeypatch, oracle64):
+    """MPPI_MAX_FREE = 4: the shipped scene kernels carry two free-actor slots (every example of the reference has at most two free
+    actors; two more slots cost the register-bound scene kernels 26 state values per sample); an env with THREE free boxes gets the
+    scene kernels of its tree built on demand with -DMPPI_FREE_SLOTS=4 - here the boxer with three blocks: rollouts of the octet
+    kernel (helper wavefront) and the K = 1 world's step against the fp64 oracle."""
+    import yaml
+    from mppiisaac.utils.isaacgym_utils import CONF_DIR
+    from scenes import boxer_push
+    monkeypatch.setenv("MPPI_JIT_CACHE", str(tmp_path / "jit"))
+    blocks = []
+    base = yaml.safe_load(open(os.path.join(CONF_DIR, "actors", "block.yaml")))
+    for i, pos in enumerate(([0.3, 1.6, 0.1], [-0.5, 1.9, 0.1], [0.1, 3.3, 0.1])):
+        cfgb = dict(base, name=f"block{i}", init_pos=pos, noise_sigma_size=[0.0, 0.0, 0.0], noise_percentage_mass=0.0, noise_percentage_friction=0.0)
+        path = str(tmp_path / f"block{i}.yaml")
+        with open(path, "w") as f:
+            yaml.safe_dump(cfgb, f)
+        blocks.append(path)
+    K, H = 256, 10
+    mc = MPPIConfig(num_samples=K, horizon=H, lambda_=0.1, u_min=[-0.8, -1.5], u_max=[0.8, 1.5], noise_sigma=[[0.3, 0.0], [0.0, 0.8]], sample_null_action=True)
+    icfg = load_config({"defaults": [{"isaacgym": "normal"}]}).isaacgym
+    sim = IsaacGymWrapper(icfg, actors=["boxer"] + blocks + ["goal"], init_positions=[[0.0, 2.5, 0.05]], num_envs=K,
+                          mppi_config=lambda scene: make_config(mc, viz_link=scene.viz_link_index()))
+    lib = sim._lib
+    info = C.create_string_buffer(512)
+    capi.check(lib, lib.mppi_jit_info(info, 512))
+    assert "topo_m1_m1_scene4" in info.value.decode(), info.value
+    assert sim._c_model.n_actors == 5 and sum(1 for a in sim.env_cfg if a.type == "box" and not a.fixed) == 3
+    cost = capi.Cost()
+    cost.kind, cost.n_terms = capi.COST_PROGRAM, 3
+    for j in range(3):
+        t = cost.terms[j]
+        t.op, t.n, t.w = capi.OP_DIST, 2, 1.0 + j
+        t.src[0], t.idx[0] = capi.SRC_ACTOR, sim.scene.actor_index(f"block{j}")
+        t.src[1], t.idx[1] = capi.SRC_ACTOR, sim.scene.actor_index("goal")
+    capi.check(lib, lib.mppi_set_cost(sim._ctx, C.byref(cost)))
+    dof, root = sim._dof_state[0].cpu().numpy().copy(), sim._root_state[0].cpu().numpy().copy()
+    capi.check(lib, lib.mppi_sample(sim._ctx, C.c_uint32(0)))
+    rng = np.random.default_rng(3)
+    U = (0.4 * rng.normal(size=(H, 2))).astype(np.float32)
+    U[:, 0] = np.abs(U[:, 0]) + 0.3                       # drive into the blocks
+    capi.check(lib, lib.mppi_set_nominal(sim._ctx, capi.fptr(U)))
+    capi.check(lib, lib.mppi_rollout(sim._ctx))
+    S, eps = np.zeros(K, np.float32), np.zeros((H, 2, K), np.float32)
+    capi.check(lib, lib.mppi_get_costs(sim._ctx, capi.fptr(S)))
+    capi.check(lib, lib.mppi_get_noise(sim._ctx, capi.fptr(eps)))
+    So, _, _ = oracle64.rollout(sim._c_model, sim._mppi_config, cost, dof, root, U, eps)
+    rel = np.abs(S - So) / np.abs(So)
+    print(f"\n[three free actors] {info.value.decode()}; rollouts vs fp64 oracle: within 1e-4 {np.mean(rel <= 1e-4):.4f}, 1e-3 {np.mean(rel <= 1e-3):.4f}, max {rel.max():.1e}")
+    assert np.mean(rel <= 1e-3) >= 0.99 and np.median(rel) < 1e-5
+    assert np.abs(So - So[0]).max() > 1e-3                # (the rollouts differ: the blocks are pushed around)
+    sim.stop_sim()

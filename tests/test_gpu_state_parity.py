@@ -76,3 +76,27 @@ def test_per_step_states_of_all_samples_against_the_oracle(make, name, K, H, nu,
         assert np.median(err[-1]) <= 1e-4
         # ... and no cliff: 99 % of the samples stay within 1e-2 for the twelve steps
         assert frac[:, 3].min() >= 0.99
+
+
+@pytest.mark.parametrize("make,name,K,H,nu", [(boxer_push, "boxer_push", 8192, 25, 2), (panda_pick, "panda_pick", 2048, 30, 9)])
+def test_group_cull_of_candidate_pairs_changes_no_cost(make, name, K, H, nu, monkeypatch):
+    """pair groups (DevModel::Group, csrc/mppi_scene.hpp contact_forces): the robot's pairs against one shape of another actor are
+    skipped together when that shape is out of the robot's reach in every sample of a wavefront.  Conservative like the broad
+    phase: with the groups switched off (MPPI_GROUP_CULL=0) every pair is visited - and the costs are the same to the last bit
+    wherever the alternate dealing of the pairs over owner / helper wavefront does not reorder a sum (contact-free samples), and
+    within 1e-5 everywhere else; at the initial and at the recorded closed-loop state."""
+    Z = np.load(CLOSED_LOOP_STATES)
+    scene, m, cfg, cost, dof0, root0 = make(K=K, H=H)
+    for st in ("initial", "recorded"):
+        dof, root = (dof0, root0) if st == "initial" else (Z[f"{name}_recorded_dof"], Z[f"{name}_recorded_root"])
+        U = Z[f"{name}_recorded_U"] if st == "recorded" and f"{name}_recorded_U" in Z.files else np.zeros((H, nu), np.float32)
+        S = {}
+        for sw in ("1", "0"):
+            monkeypatch.setenv("MPPI_GROUP_CULL", sw)
+            c = Ctx(m, cfg, cost)
+            c.call("mppi_sample", C.c_uint32(0)); c.set_state(dof, root); c.set_U(U); c.call("mppi_rollout")
+            S[sw] = c.get("mppi_get_costs", (K,))
+            c.close()
+        rel = np.abs(S["1"] - S["0"]) / np.abs(S["0"])
+        print(f"\n{name} {st}: group cull on vs off: bit-equal costs {np.mean(S['1'] == S['0']):.4f}, max rel diff {rel.max():.1e}")
+        assert np.percentile(rel, 99) <= 1e-5 and np.mean(rel <= 1e-3) >= 0.995
