@@ -1169,7 +1169,7 @@ int mppi_sim_reset(mppi_ctx_t *c) {
     c->partials_valid = false;
     hipLaunchKernelGGL(k_sim_reset, dim3((c->K + 255) / 256), dim3(256), 0, c->stream, c->K, c->n, c->d_x0_dof, c->d_q, c->d_qd, c->d_S, c->d_ctrl);
     if (c->scene)
-        hipLaunchKernelGGL(k_sim_reset_scene, dim3((c->K + 255) / 256), dim3(256), 0, c->stream, c->d_model, c->K, c->d_x0_root, c->d_base, c->d_fr, c->d_cf);
+        hipLaunchKernelGGL(k_sim_reset_scene, dim3((c->K + 255) / 256), dim3(256), 0, c->stream, c->d_model, c->K, c->d_x0_root, c->d_base, c->d_fr, c->d_cf, c->free_slots);
     return launch_check();
 }
 int mppi_sim_step(mppi_ctx_t *c, const float *u_dev, int u_is_shared) {

@@ -1237,15 +1237,17 @@ __global__ __launch_bounds__(kWave) void k_materialise_scene(const DevModel *__r
 }
 
 // all envs <- x0 (root rows of the robot base and the free actors)
+// (free_slots: the free-actor slots of the context's scene kernels - TopoEntry.free_slots -, NOT this unit's kFreeSlots: the
+// kernels of a tree built on demand may carry four, mppi_hip.hip jit_topology)
 __global__ void k_sim_reset_scene(const DevModel *__restrict__ m, int K, const float *__restrict__ x0_root, float *__restrict__ base_,
-                                  float *__restrict__ fr_, float *__restrict__ cf_) {
+                                  float *__restrict__ fr_, float *__restrict__ cf_, int free_slots) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
     for (int r = 0; r < m->n_bases; r++) {
         const int actor = r == 0 ? m->robot_actor : m->xbase_actor[r - 1];
         for (int j = 0; j < 13; j++) base_[(size_t)(13 * r + j) * K + k] = x0_root[13 * actor + j];
     }
-    for (int f = 0; f < kFreeSlots; f++)
+    for (int f = 0; f < free_slots; f++)
         for (int j = 0; j < 13; j++) fr_[(size_t)(f * 13 + j) * K + k] = f < m->n_free ? x0_root[13 * m->fr[f].actor + j] : 0.f;
     for (int j = 0; j < 3 * m->n_rb; j++) cf_[(size_t)j * K + k] = 0.f;
 }
@@ -1254,8 +1256,7 @@ __global__ void k_root_from_world(const DevModel *__restrict__ m, const float *_
     const int j = threadIdx.x;
     if (j < 13) {
         for (int r = 0; r < m->n_bases; r++) x0_root[13 * (r == 0 ? m->robot_actor : m->xbase_actor[r - 1]) + j] = wbase[13 * r + j];
-        for (int f = 0; f < kFreeSlots; f++)
-            if (f < m->n_free) x0_root[13 * m->fr[f].actor + j] = wfr[f * 13 + j];
+        for (int f = 0; f < m->n_free; f++) x0_root[13 * m->fr[f].actor + j] = wfr[f * 13 + j];
     }
 }
 

@@ -1053,18 +1053,6 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
         alive_hi &= ~dead_hi;
     }
     auto is_dead = [&](int ip) MPPI_LAMBDA { return (((ip < 32 ? dead_lo : dead_hi) >> (ip & 31)) & 1u) != 0u; };
-    // owner / helper wavefront (kSplitOctPair): the pairs that are left are dealt ALTERNATELY in their order - by the parity of the
-    // pair index the work of the two wavefronts would depend on which groups happen to be out of reach
-    unsigned long long mine = 0ull;
-    if constexpr (kPair) {
-        unsigned long long rest = ~((unsigned long long)dead_lo | ((unsigned long long)dead_hi << 32));
-        if (m.n_pairs < 64) rest &= (1ull << m.n_pairs) - 1ull;
-        for (int ord = 0; rest != 0ull; ord++) {
-            const unsigned long long low = rest & (0ull - rest);
-            if ((ord & 1) == split.wave) mine |= low;
-            rest ^= low;
-        }
-    }
     MPPI_SEC(2);
     // The loop visits the pairs that are alive (all of them without the dealt pass).  Both 64-byte blocks of the NEXT pair
     // are requested while the current one is worked on: measured with the section clocks (tools/exp/section_clocks.py), a
@@ -1077,8 +1065,11 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
             if (MPPI_PAIR_SPLIT == 2) return split.wave ? from : (int)m.n_pairs;
             if (MPPI_PAIR_SPLIT == 3) return split.wave ? (int)m.n_pairs : from;
 #endif
-            const unsigned long long rest = from < 64 ? mine >> from : 0ull;   // this wavefront's share of the pairs that are left
-            return rest != 0ull ? from + (int)__builtin_ctzll(rest) : (int)m.n_pairs;
+            from += (from ^ split.wave) & 1;                        // pairs of this wavefront's parity ...
+            while (from < m.n_pairs && is_dead(from)) from += 2;    // ... that no group verdict has removed
+            return from < m.n_pairs ? from : (int)m.n_pairs;
+            // (dealing the pairs that are left alternately in their ORDER instead - so that the split does not depend on which
+            // groups are out of reach - measured 4 % slower on the pushing scene with every group in reach: 1.268 vs 1.221 ms)
         }
         if constexpr (dealt_broad_phase<T>(SPLIT)) {
             if (m.n_pairs > kDealtBroadPhaseMin) {
