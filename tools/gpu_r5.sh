@@ -38,4 +38,9 @@ if [[ $WHAT == *prof* ]]; then
   WORKLOAD=panda_reach STEPS=300 bash tools/profile_bench.sh ${TAG} > $OUT/prof_reach.log 2>&1
   WORKLOAD=boxer_push STEPS=100 bash tools/profile_bench.sh ${TAG}_boxer > $OUT/prof_boxer.log 2>&1
   WORKLOAD=panda_pick STEPS=60 bash tools/profile_bench.sh ${TAG}_pick > $OUT/prof_pick.log 2>&1
+  WORKLOAD=panda_reach STEPS=100 bash tools/pmc_sq.sh ${TAG} > $OUT/sq_reach.log 2>&1
+  WORKLOAD=boxer_push STEPS=60 bash tools/pmc_sq.sh ${TAG}_boxer > $OUT/sq_boxer.log 2>&1
+  WORKLOAD=panda_pick STEPS=40 bash tools/pmc_sq.sh ${TAG}_pick > $OUT/sq_pick.log 2>&1
+  cd $REPO; for t in ${TAG} ${TAG}_boxer ${TAG}_pick; do python tools/summarise_profile.py $t > /dev/null 2>&1; done
+  mkdir -p $OUT/profiles && cp profiles/${TAG}* $OUT/profiles/ 2>/dev/null; cp profiles/pmc_latest.json profiles/sq_latest.json $OUT/profiles/ 2>/dev/null
 fi

@@ -14,7 +14,7 @@ WORKLOAD=${WORKLOAD:-panda_reach}
 STEPS=${STEPS:-300}
 EXTRA=""
 if [ -n "${KTOTAL:-}" ]; then EXTRA="--k-total $KTOTAL"; fi
-CMD="env MPPI_BENCH_SECOND=0 python $REPO/bench.py --workload $WORKLOAD --steps $STEPS --warmup 30 --no-cpu-baseline $EXTRA"
+CMD="env MPPI_BENCH_SECOND=0 python $REPO/bench.py --workload $WORKLOAD --steps $STEPS --warmup 30 --no-cpu-baseline --no-facade $EXTRA"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace_bench.json 2> $OUT/trace.err
 if [ -z "${STATS_ONLY:-}" ]; then
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $CMD > $OUT/pmc_fetch_bench.json 2> $OUT/pmc_fetch.err
