@@ -473,14 +473,26 @@ def facade_loop(wl_name, objective, device, steps, warmup, profile_to=None):
         action = bytes_to_torch(planner.compute_action_tensor(torch_to_bytes(world._dof_state), torch_to_bytes(world._root_state)))
         world.apply_robot_cmd(action)
         world.step()
+    import gc
     for _ in range(warmup):
         iterate()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        iterate()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    # (as timeit does: no cyclic garbage collection inside the timed region - a generation-2 pass over what the earlier phases of a
+    # bench run left behind costs milliseconds, the loop itself allocates a few dozen short-lived objects per iteration)
+    gc.collect()
+    gc.disable()
+    stamps = np.zeros(steps + 1)
+    try:
+        stamps[0] = t0 = time.perf_counter()
+        for i in range(steps):
+            iterate()
+            stamps[i + 1] = time.perf_counter()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+    finally:
+        gc.enable()
+    facade_loop.last_latency_ms = {"median": float(np.median(np.diff(stamps)) * 1e3), "p5": float(np.percentile(np.diff(stamps), 5) * 1e3),
+                                   "p95": float(np.percentile(np.diff(stamps), 95) * 1e3), "max": float(np.diff(stamps).max() * 1e3)}
     dist = None
     if wl_name == "panda_reach":
         ee = world.get_actor_link_by_name("panda", "panda_ee_tip")[0, 0:3].cpu().numpy()
@@ -515,7 +527,7 @@ def facade_rows(wl_name, device):
         if key != "fused" and wl_name != "panda_reach":
             continue
         hz, ms, dist = facade_loop(wl_name, obj, device, n, w, profile_to=prof)
-        rows[key] = {"value": hz, "ms_per_step": ms, "steps": n, "final_ee_to_goal_m": dist}
+        rows[key] = {"value": hz, "ms_per_step": ms, "steps": n, "final_ee_to_goal_m": dist, "latency_ms": facade_loop.last_latency_ms}
     return rows
 
 

@@ -96,6 +96,17 @@ def test_group_cull_of_candidate_pairs_changes_no_cost(make, name, K, H, nu, mon
             c.call("mppi_sample", C.c_uint32(0)); c.set_state(dof, root); c.set_U(U); c.call("mppi_rollout")
             S[sw] = c.get("mppi_get_costs", (K,))
             c.close()
+        if make is boxer_push and st == "recorded":       # ... and with every sample simulating its own block size (the groups' reach covers the draws)
+            scene.randomize_seed = 3
+            mr = scene.to_c()
+            scene.randomize_seed = -1
+            for sw in ("1", "0"):
+                monkeypatch.setenv("MPPI_GROUP_CULL", sw)
+                c = Ctx(mr, cfg, cost)
+                c.call("mppi_sample", C.c_uint32(0)); c.set_state(dof, root); c.set_U(U); c.call("mppi_rollout")
+                S["r" + sw] = c.get("mppi_get_costs", (K,))
+                c.close()
+            assert np.array_equal(S["r1"], S["r0"]) and not np.array_equal(S["r1"], S["1"])
         rel = np.abs(S["1"] - S["0"]) / np.abs(S["0"])
         print(f"\n{name} {st}: group cull on vs off: bit-equal costs {np.mean(S['1'] == S['0']):.4f}, max rel diff {rel.max():.1e}")
         assert np.mean(S["1"] == S["0"]) == 1.0, "a skipped pair is one the broad phase would have culled: bit-identical costs"
