@@ -313,7 +313,7 @@ std::string tail_of(const std::string &path, size_t n = 1500) {
 
 // builds (or finds in the cache) and loads the plugin of one kinematic tree; `with_scene`: the contact-scene kernels as well
 // (the long compile), `free_slots`: free-actor slots of those kernels
-const TopoEntry *jit_topology(int nb, const int *parents, bool with_scene, int free_slots, std::string &err) {
+const TopoEntry *jit_topology(int nb, const int *parents, bool with_scene, int free_slots, std::string &err, bool retried = false) {
     const char *sw = std::getenv("MPPI_JIT");
     if (sw && std::string(sw) == "0") { err = "on-demand builds are switched off (MPPI_JIT=0)"; return nullptr; }
     const std::string dir = lib_dir();
@@ -387,14 +387,19 @@ const TopoEntry *jit_topology(int nb, const int *parents, bool with_scene, int f
         built = true;
     }
     void *h = dlopen(so.c_str(), RTLD_NOW | RTLD_LOCAL);
-    if (!h) { err = std::string("dlopen of the plugin failed: ") + dlerror(); return nullptr; }
-    auto entry = (const TopoEntry *(*)())dlsym(h, "mppi_plugin_entry");
-    auto sizes = (void (*)(size_t *))dlsym(h, "mppi_plugin_sizes");
+    auto entry = h ? (const TopoEntry *(*)())dlsym(h, "mppi_plugin_entry") : nullptr;
+    auto sizes = h ? (void (*)(size_t *))dlsym(h, "mppi_plugin_sizes") : nullptr;
     size_t sz[4] = {0, 0, 0, 0};
     if (sizes) sizes(sz);
     if (!entry || sz[0] != sizeof(mppi_ctx) || sz[1] != sizeof(DevModel) || sz[2] != sizeof(TopoEntry) || sz[3] != sizeof(DevCfg)) {
-        err = "the plugin " + so + " does not match this library (rebuild: delete it)";
-        dlclose(h);
+        const std::string why = h ? "does not match this library" : std::string("cannot be loaded (") + dlerror() + ")";
+        if (h) dlclose(h);
+        if (!built && !retried) {   // a damaged or foreign file in the cache: thrown away and built afresh, once
+            std::fprintf(stderr, "[mppi_hip] cached plugin %s %s: rebuilding\n", so.c_str(), why.c_str());
+            (void)unlink(so.c_str());
+            return jit_topology(nb, parents, with_scene, free_slots, err, true);
+        }
+        err = "the plugin " + so + " " + why;
         return nullptr;
     }
     const TopoEntry *e = entry();

@@ -409,3 +409,19 @@ def test_unseen_kinematic_tree_is_built_on_demand_without_a_gpu(tmp_path, monkey
         assert rc == capi.MPPI_EHIP and b"not instantiated" not in lib.mppi_last_error()
     else:
         lib.mppi_destroy(ctx)
+    # a damaged file in the cache (a torn copy, another library's plugin) is thrown away and built afresh - seen by a tree this process
+    # has not loaded yet: the same URDF without its last link, [-1, 0, 1, 0]
+    urdf4, actor4 = str(tmp_path / "b4.urdf"), str(tmp_path / "arm4.yaml")
+    T.write_branched_urdf(urdf4, tail=False)
+    T.actor_yaml(actor4, urdf4, init_joint_pose=[0.0] * 8)
+    env4 = load_actor_cfgs([actor4, "goal"])
+    sc4 = Scene(env4, load_config({"defaults": [{"isaacgym": "normal"}]}).isaacgym, [load_asset(a) for a in env4 if a.type == "robot"])
+    m4, cfg4 = sc4.to_c(), make_config(MPPIConfig(num_samples=64, horizon=8, noise_sigma=np.eye(4).tolist()), viz_link=-1)
+    name4 = built[0].replace("topo_m1_0_1_0_3_free", "topo_m1_0_1_0_free")
+    with open(os.path.join(str(tmp_path / "jit"), name4), "wb") as f:
+        f.write(b"not a shared object")
+    rc = lib.mppi_create(C.byref(m4), C.byref(cfg4), 0, C.byref(ctx))
+    assert lib.mppi_jit_info(info, 512) == 0 and info.value.decode().startswith("built ") and name4 in info.value.decode(), (rc, lib.mppi_last_error(), info.value)
+    assert os.path.getsize(os.path.join(str(tmp_path / "jit"), name4)) > 100000
+    if rc == 0:
+        lib.mppi_destroy(ctx)
