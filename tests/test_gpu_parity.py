@@ -379,6 +379,53 @@ def test_contact_rich_states_match_oracle(make, name, K, H, nu, states, lib, ora
             assert np.mean(rl <= 1e-3) >= 0.96 and np.mean(rl <= 1e-2) >= 0.99
 
 
+def test_single_call_evaluation_is_revalidated_and_dropped_when_the_objective_drifts(lib, monkeypatch):
+    """generic mode evaluates a reference-style Objective ONCE per command over the whole horizon after checking, on the first
+    command, that this equals H calls on the [K]-row blocks.  An Objective whose Python-side state starts to matter LATER (here: a
+    call counter that scales the cost from the 60th call on) would go stale silently: every BATCH_RECHECK-th command two row blocks
+    are evaluated on their own and compared with the single call's rows (planner/mppi.py _revalidate_single) - the drift is caught,
+    the full check runs, and the planner goes back to one call per horizon step with a warning."""
+    import warnings
+    from mppiisaac.objectives import PandaReachObjective
+    from mppiisaac.planner.mppi import MPPIPlanner
+    from mppiisaac.planner.mppi_isaac import MPPIisaacPlanner
+    from mppiisaac.utils.config_store import load_config
+
+    class Drifting:
+        def __init__(self):
+            self.inner, self.calls = PandaReachObjective(None), 0
+
+        def reset(self):
+            pass
+
+        def compute_cost(self, sim):
+            self.calls += 1
+            c = self.inner.compute_cost(sim)
+            return c * (1.0 + 0.01 * self.calls) if self.calls >= 60 else c
+    monkeypatch.setattr(MPPIPlanner, "BATCH_RECHECK", 4)
+    H = 10
+    cfg = load_config({"defaults": [{"mppi": "panda"}, {"isaacgym": "normal"}], "actors": ["panda_stick", "goal"],
+                       "initial_actor_positions": [[0.0, 0.0, 0.0]], "nx": 14},
+                      overrides={"mppi.num_samples": 256, "mppi.horizon": H, "mppi.filter_u": False})
+    obj = Drifting()
+    planner = MPPIisaacPlanner(cfg, obj)
+    planner.sim.set_actor_position_by_name([0.5, -0.4, 0.3], "goal")
+    q = [0.0, -0.94, 0.0, -2.8, 0.0, 1.8675, 0.0]
+    per_command = []
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter("always")
+        for _ in range(40):
+            before = obj.calls
+            planner.compute_action(q, [0.0] * 7)
+            per_command.append(obj.calls - before)
+    assert per_command[0] == H + 1                       # first command: the single call checked against H calls
+    assert per_command[1:4] == [1, 1, 1]                 # adopted: one call per command
+    assert 4 in per_command[4:12]                        # a re-validation that passes: the single call, two row blocks, the command's own call
+    assert per_command[-1] == H and per_command[-5:] == [H] * 5      # after the drift: the reference's call pattern, for good
+    assert any("differs from its per-step costs" in str(w.message) for w in seen)
+    planner.sim.stop_sim()
+
+
 def test_generic_objective_mode_equals_fused(lib):
     """Objective contract (compute_cost(sim) per horizon step, reference mppi_isaac.py:57-69) == fused kernel."""
     from mppiisaac.objectives import PandaReachObjective, PointReachObjective
@@ -719,11 +766,12 @@ def test_randomised_actors_per_sample(lib, oracle64):
     print(f"randomised actors: within 1e-4 {np.mean(np.abs(S - So) <= 1e-4 * np.abs(So)):.4f} 1e-3 {agree:.4f} max {np.max(np.abs(S - So) / np.abs(So)):.2e}")
     assert np.median(S) == pytest.approx(np.median(So), rel=1e-4)
     # round 3: every sample within 3.3e-4 (round 2: 95-96 % within 1e-3, worst 3.9 %).  Round 5: the wheels and casters meet the
-    # block and the obstacles too - the few samples that drive the robot INTO an obstacle (cost 600 - 9000 against a median of 27:
-    # softmax weight zero) tumble and part from the oracle by up to 4 %; everything the controller weighs stays within 1e-3
+    # block and the obstacles too - a few samples that bump into the block or an obstacle with a wheel (cost 75 - 9000 against a
+    # median of 27: softmax weight zero) part from the oracle by 1-4 %; what the controller weighs stays within 1e-3
     rel = np.abs(S - So) / np.abs(So)
     far = rel > 1e-2
-    assert agree > 0.98 and far.mean() < 0.02 and (So[far] > 5 * np.median(So)).all(), (agree, far.sum(), So[far])
+    r = agreement(S, So, cfg.lambda_)
+    assert agree > 0.98 and far.mean() < 0.02 and rel.max() < 0.1 and r["weight_mass_outside_1e-3"] < 1e-3, (agree, far.sum(), So[far], r)
     assert agree > (np.abs(S - So_nom) <= 1e-2 * np.abs(So_nom)).mean() + 0.1   # and it is THIS seed's worlds that it follows
     ex = load_config({"defaults": [{"mppi": "boxer_push"}, {"isaacgym": "normal"}]}, overrides={"mppi.num_samples": K, "mppi.horizon": H})
     for r in range(2):
