@@ -617,8 +617,9 @@ class MPPIPlanner:
             with sim._horizon_view(b, H * K, lazy=self._lazy_materialise, link=self._lazy_link), torch.no_grad():
                 c = self._running_cost(state)
                 if sim._visualize_link_present:
-                    viz = sim.visualize_link_pos.reshape(H, K, 3)
-                    sim.visualize_link_buffer.extend(viz[t] for t in range(H))
+                    # the whole horizon as ONE [H, K, 3] block (H per-step views cost the host 18 us per command;
+                    # MPPIisaacPlanner.get_rollouts concatenates blocks and per-step entries alike)
+                    sim.visualize_link_buffer.append(sim.visualize_link_pos.reshape(H, K, 3))
             c = c.to(dtype=torch.float32, device=sim.device)
             if c.shape != (H * K,):
                 raise ValueError(f"compute_cost must return one cost per env ([{H * K}] over the horizon view), got {tuple(c.shape)}")

@@ -106,7 +106,9 @@ class MPPIisaacPlanner(object):
             return torch_to_bytes(torch.zeros((1, 1, 1)))
         if self.mppi._fused_cost is not None:
             return torch_to_bytes(self.mppi.get_rollouts())
-        return torch_to_bytes(torch.stack(self.sim.visualize_link_buffer))
+        # entries: [K, 3] per simulator step (reference isaacgym_wrapper.py:651-652) or one [H, K, 3] block per simulated horizon
+        buf = self.sim.visualize_link_buffer
+        return torch_to_bytes(torch.cat([b if b.dim() == 3 else b.unsqueeze(0) for b in buf]))
 
     def update_weights(self, weights):
         self.objective.weights = weights
