@@ -38,8 +38,9 @@ extern "C" {
 #define MPPI_MAX_H 64        /* horizon                                              */
 #define MPPI_MAX_KNOTS 16    /* spline knots of the halton-spline sampler            */
 #define MPPI_MAX_COST_W 16
-#define MPPI_MAX_SHAPES 56   /* collision primitives per env (anymal: 37; an arm + ten obstacle spheres)  */
-#define MPPI_MAX_PAIRS 64    /* candidate contact pairs per env (the dealt broad phase keeps one verdict bit per pair) */
+#define MPPI_MAX_SHAPES 64   /* collision primitives per env (anymal: 37; an arm + ten obstacle spheres)  */
+#define MPPI_MAX_PAIRS 128   /* candidate contact pairs per env (one verdict bit per pair in four mask words; the ten-link arm
+                              * among the reference's ten obstacle spheres - IsaacGymConfig.num_obstacles - has 100)        */
 #define MPPI_MAX_FREE 4      /* free (non-fixed) box/sphere actors per env (the shipped kernels carry 2 slots; scenes with
                               * 3-4 free actors get their kernels built on demand, see mppi_create)          */
 #define MPPI_MAX_EXTRA_BASES 3 /* moving-base robots per env beyond the first (ABI 7)         */

@@ -38,8 +38,8 @@ constexpr int kMaxBodies = 12;
 constexpr int kMaxLinks = 24;
 constexpr int kMaxActors = 12;
 constexpr int kMaxNu = 12;
-constexpr int kMaxShapes = 56;
-constexpr int kMaxPairs = 64;
+constexpr int kMaxShapes = 64;
+constexpr int kMaxPairs = 128;
 constexpr int kMaxFree = 4;        // free actors a MODEL may hold (MPPI_MAX_FREE)
 // free-actor slots the contact-scene KERNELS of this build carry (state rows, frames, LDS rows are sized by it): 2 in the shipped
 // library - every example scene of the reference has at most two free actors, and two more slots cost the register-bound scene
@@ -166,9 +166,10 @@ struct DevModel {
     int n_groups, grp_pad;
     struct Group {
         int anchor, other;          // shapes whose cached centres are compared: a robot shape welded to base 0, the other actor's shape
-        unsigned mask_lo, mask_hi;  // the group's pairs
+        unsigned mask_lo, mask_hi;  // the group's pairs (0-31, 32-63)
         float reach2;               // (robot reach about the anchor's centre + bounding radius of the other shape + margins)^2
-        float pad[3];
+        unsigned mask_2, mask_3;    // ... pairs 64-95, 96-127
+        float pad;
     } grp[8];
 };
 constexpr int kMaxGroups = 8;

@@ -874,6 +874,27 @@ MPPI_HD void disc_in_box(const Gains &P, V3 pc, V3 ax, float r, const ShapeW &Y,
     contact_point(P, Y.p + mul(Y.R, y), sign * mul(Y.R, nl), depth, vA, vB, acc);
 }
 
+// disc (centre pc, unit axis ax, radius r) against a sphere (centre ps, radius rs): the disc's point nearest to the sphere centre -
+// the centre's projection into the disc's plane, pulled back onto the disc - against the sphere's surface; sign = +1 when the disc
+// is shape A (the normal points from B to A).  (Round 5: wheels of a mobile base against the sphere obstacles of the benchmark
+// adapters, reference benchmarks/point_robot/mppi_planner/mppi_planner_wrapper.py:58-79.)
+MPPI_HD void disc_sphere(const Gains &P, V3 pc, V3 ax, float r, V3 ps, float rs, float sign, const SV &vA, const SV &vB, PairAcc &acc) {
+    V3 e = ps - pc;
+    e = e - dot(e, ax) * ax;                               // the sphere centre's offset within the disc's plane
+    const float l2 = dot(e, e);
+    const V3 q = pc + (l2 > r * r ? r * frsqrt(l2) : 1.f) * e;   // the disc's nearest point
+    const V3 d = q - ps;
+    const float d2 = dot(d, d);
+    if (d2 >= rs * rs) return;
+    V3 n = ax;                                             // (the sphere centre ON the disc: push along the axis)
+    float dist = 0.f;
+    if (d2 > 1e-12f) {
+        dist = fsqrt(d2);
+        n = frcp(dist) * d;                                // from the sphere towards the disc
+    }
+    contact_point(P, q, sign * n, rs - dist, vA, vB, acc);
+}
+
 // two spheres: normal along the line of centres (from B to A), contact point in the middle of the overlap; coincident centres
 // push apart along +z (sphere obstacles of the plannerbenchmark adapters against sphere-shaped links,
 // reference benchmarks/panda_arm/mppi_planner/mppi_planner_wrapper.py:58-79)
@@ -1010,11 +1031,12 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
     // loop then visits only the survivors.  pair_broad_phase() restates the test of the loop body term by term - the
     // verdicts must agree bit for bit (tests/test_gpu_parity.py compares contact scenes with the oracle either way).
     // Pays when most pairs are apart in every sample of a wavefront: 23-pair gripper scene -17 % away from contact.
-    unsigned alive_lo = ~0u, alive_hi = ~0u;
+    // (one verdict bit per candidate pair: 128 pairs = four words; the reference's ten obstacle spheres around a ten-link arm are 100)
+    unsigned alive_lo = ~0u, alive_hi = ~0u, alive_2 = ~0u, alive_3 = ~0u;
 #if defined(__HIP_DEVICE_COMPILE__)
     if constexpr (dealt_broad_phase<T>(SPLIT)) {
         if (m.n_pairs > kDealtBroadPhaseMin) {
-            alive_lo = alive_hi = 0u;
+            alive_lo = alive_hi = alive_2 = alive_3 = 0u;
             const int trips = (m.n_pairs + split.n - 1) / split.n;
             for (int it = 0; it < trips; it++) {
                 const int ip = it * split.n + split.sub;
@@ -1023,11 +1045,18 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
                 PairPose pp;
                 const bool apart = pair_broad_phase<T, true>(m, ic, G, root, L, pp);
                 const unsigned bit = (!apart && ip < m.n_pairs) ? 1u << (ip & 31) : 0u;
-                alive_lo |= ip < 32 ? bit : 0u;
-                alive_hi |= ip < 32 ? 0u : bit;
+                const int w = ip >> 5;
+                alive_lo |= w == 0 ? bit : 0u;
+                alive_hi |= w == 1 ? bit : 0u;
+                alive_2 |= w == 2 ? bit : 0u;
+                alive_3 |= w == 3 ? bit : 0u;
             }
             alive_lo = group_allor<SPLIT>(alive_lo);
             alive_hi = group_allor<SPLIT>(alive_hi);
+            if (m.n_pairs > 64) {
+                alive_2 = group_allor<SPLIT>(alive_2);
+                alive_3 = group_allor<SPLIT>(alive_3);
+            }
         }
     }
 #endif
@@ -1035,7 +1064,7 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
     // out of the robot's reach in every sample of this wavefront - one distance test per group and substep instead of a record
     // fetch, two pose reads and the broad-phase arithmetic per pair.  The verdict is wave-uniform (the pair loop is), so the masks
     // live in scalar registers; conservative like the broad phase (a skipped pair is one it would have culled).
-    unsigned dead_lo = 0u, dead_hi = 0u;
+    unsigned dead_lo = 0u, dead_hi = 0u, dead_2 = 0u, dead_3 = 0u;
     if constexpr (kCached) {
         for (int g = 0; g < m.n_groups; g++) {
             const V3 d = shape_cached<T>(m, m.grp[g].anchor, L).p - shape_cached<T>(m, m.grp[g].other, L).p;
@@ -1043,16 +1072,23 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
 #if defined(__HIP_DEVICE_COMPILE__)
             far = __all(far) != 0;
 #endif
-            if (far) { dead_lo |= m.grp[g].mask_lo; dead_hi |= m.grp[g].mask_hi; }
+            if (far) { dead_lo |= m.grp[g].mask_lo; dead_hi |= m.grp[g].mask_hi; dead_2 |= m.grp[g].mask_2; dead_3 |= m.grp[g].mask_3; }
         }
 #if defined(__HIP_DEVICE_COMPILE__)
         dead_lo = (unsigned)uniform((int)dead_lo);
         dead_hi = (unsigned)uniform((int)dead_hi);
+        dead_2 = (unsigned)uniform((int)dead_2);
+        dead_3 = (unsigned)uniform((int)dead_3);
 #endif
         alive_lo &= ~dead_lo;
         alive_hi &= ~dead_hi;
+        alive_2 &= ~dead_2;
+        alive_3 &= ~dead_3;
     }
-    auto is_dead = [&](int ip) MPPI_LAMBDA { return (((ip < 32 ? dead_lo : dead_hi) >> (ip & 31)) & 1u) != 0u; };
+    auto is_dead = [&](int ip) MPPI_LAMBDA {
+        const unsigned wd = ip < 64 ? (ip < 32 ? dead_lo : dead_hi) : (ip < 96 ? dead_2 : dead_3);
+        return ((wd >> (ip & 31)) & 1u) != 0u;
+    };
     MPPI_SEC(2);
     // The loop visits the pairs that are alive (all of them without the dealt pass).  Both 64-byte blocks of the NEXT pair
     // are requested while the current one is worked on: measured with the section clocks (tools/exp/section_clocks.py), a
@@ -1075,7 +1111,14 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
             if (m.n_pairs > kDealtBroadPhaseMin) {
                 const unsigned long long alive = (unsigned long long)alive_lo | ((unsigned long long)alive_hi << 32);
                 const unsigned long long rest = from < 64 ? alive >> from : 0ull;
-                return rest != 0ull ? from + (int)__builtin_ctzll(rest) : (int)m.n_pairs;
+                if (rest != 0ull) return from + (int)__builtin_ctzll(rest);
+                if (m.n_pairs > 64) {
+                    const unsigned long long upper = (unsigned long long)alive_2 | ((unsigned long long)alive_3 << 32);
+                    const int f2 = from > 64 ? from - 64 : 0;
+                    const unsigned long long rest2 = f2 < 64 ? upper >> f2 : 0ull;
+                    if (rest2 != 0ull) return 64 + f2 + (int)__builtin_ctzll(rest2);
+                }
+                return (int)m.n_pairs;
             }
         }
         while (from < m.n_pairs && is_dead(from)) from++;
@@ -1274,6 +1317,8 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
                 else if (typeA == 1 && typeB == 1) sphere_sphere(P, wa.p, hA[0], wb.p, hB[0], wa.v, wb.v, out);
                 else if (typeA == 2 && typeB == 0) disc_in_box(P, wa.p, V3{wa.R.a[2], wa.R.a[5], wa.R.a[8]}, hA[0], wb, hB, 1.f, wa.v, wb.v, out);
                 else if (typeA == 0 && typeB == 2) disc_in_box(P, wb.p, V3{wb.R.a[2], wb.R.a[5], wb.R.a[8]}, hB[0], wa, hA, -1.f, wa.v, wb.v, out);
+                else if (typeA == 2 && typeB == 1) disc_sphere(P, wa.p, V3{wa.R.a[2], wa.R.a[5], wa.R.a[8]}, hA[0], wb.p, hB[0], 1.f, wa.v, wb.v, out);
+                else if (typeA == 1 && typeB == 2) disc_sphere(P, wb.p, V3{wb.R.a[2], wb.R.a[5], wb.R.a[8]}, hB[0], wa.p, hA[0], -1.f, wa.v, wb.v, out);
             }
         };
         MPPI_SEC(13);  // contact law, velocities

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 MAX_BODIES, MAX_LINKS, MAX_ACTORS, MAX_NU, MAX_H, MAX_KNOTS, MAX_COST_W = 12, 24, 12, 12, 64, 16, 16
-MAX_SHAPES, MAX_PAIRS, MAX_FREE, MAX_EXTRA_BASES = 56, 64, 4, 3
+MAX_SHAPES, MAX_PAIRS, MAX_FREE, MAX_EXTRA_BASES = 64, 128, 4, 3
 SHAPE_BOX, SHAPE_SPHERE, SHAPE_DISC = 0, 1, 2
 ABI_VERSION = 8
 # error codes of include/mppi_hip.h

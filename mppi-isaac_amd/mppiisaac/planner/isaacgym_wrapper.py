@@ -341,10 +341,10 @@ class Scene:
                     continue
                 kinds = {si["type"], sj["type"]}
                 names = (f'{self.env_cfg[si["actor"]].name}:{si["link"]}', f'{self.env_cfg[sj["actor"]].name}:{sj["link"]}')
-                if capi.SHAPE_DISC in kinds and kinds != {capi.SHAPE_DISC, capi.SHAPE_BOX}:
-                    # round 5: wheels and casters meet the BOXES of other actors (block, obstacles, walls, table: every non-robot
-                    # shape of the reference's examples but the obstacle spheres of the benchmark adapters) as well as the ground;
-                    # what is still left out - a wheel against a sphere or another wheel - is listed here and logged
+                if kinds == {capi.SHAPE_DISC}:
+                    # round 5: wheels and casters meet the boxes and spheres of other actors (block, obstacles, walls, table, the
+                    # obstacle spheres of the benchmark adapters) as well as the ground; what is still left out - a wheel against
+                    # another wheel - is listed here and logged
                     self.dropped_pairs.append(names)
                     self.dropped_pair_shapes.append((i, j))
                     continue
@@ -363,8 +363,8 @@ class Scene:
             if key not in _REPORTED_DROPS:  # once per distinct scene and process
                 _REPORTED_DROPS.add(key)
                 logging.getLogger("mppiisaac").warning(
-                    "contact model: %d wheel/caster pairs are not tested (a wheel against a sphere or another wheel%s; e.g. %s / %s); "
-                    "see Scene.dropped_pairs", len(key), "" if self.WHEEL_BOX_PAIRS else ", and - MPPI_WHEEL_BOX_PAIRS=0 - against boxes", *key[0])
+                    "contact model: %d wheel/caster pairs are not tested (a wheel against another wheel%s; e.g. %s / %s); "
+                    "see Scene.dropped_pairs", len(key), "" if self.WHEEL_BOX_PAIRS else ", and - MPPI_WHEEL_BOX_PAIRS=0 - against boxes and spheres", *key[0])
         return shapes, pairs
 
     def _is_wheel(self, link: dict, R_shape: np.ndarray) -> bool:

@@ -651,6 +651,23 @@ static void disc_in_box(int mode, real mu, real k, real cn, real ct, real kh, co
     contact_point(mode, mu, k, cn, ct, kh, pw, n, depth, vA, vB, acc);
 }
 
+/* disc against a sphere (round 5: wheels against the sphere obstacles of the benchmark adapters): the disc's point nearest to the
+ * sphere centre (its projection into the disc's plane, pulled back onto the disc) against the sphere's surface */
+static void disc_sphere(int mode, real mu, real k, real cn, real ct, real kh, const real *pc, const real *ax, real r, const real *ps, real rs,
+                        real sign, const real *vA, const real *vB, pair_acc_t *acc) {
+    real e[3], q[3], d[3], n[3], ea = 0, l2 = 0, d2 = 0;
+    for (int j = 0; j < 3; j++) { e[j] = ps[j] - pc[j]; ea += e[j] * ax[j]; }
+    for (int j = 0; j < 3; j++) { e[j] -= ea * ax[j]; l2 += e[j] * e[j]; }
+    real sc = l2 > r * r ? r / (real)sqrt((double)l2) : 1;
+    for (int j = 0; j < 3; j++) { q[j] = pc[j] + sc * e[j]; d[j] = q[j] - ps[j]; d2 += d[j] * d[j]; }
+    if (d2 >= rs * rs) return;
+    real dist = 0;
+    for (int j = 0; j < 3; j++) n[j] = ax[j];
+    if (d2 > (real)1e-12) { dist = (real)sqrt((double)d2); for (int j = 0; j < 3; j++) n[j] = d[j] / dist; }
+    for (int j = 0; j < 3; j++) n[j] *= sign;
+    contact_point(mode, mu, k, cn, ct, kh, q, n, rs - dist, vA, vB, acc);
+}
+
 /* two spheres: normal along the line of centres (from B to A), contact point in the middle of the overlap; coincident centres
  * push apart along +z.  (The plannerbenchmark adapters add sphere obstacles next to sphere-shaped robot links,
  * benchmarks/panda_arm/mppi_planner/mppi_planner_wrapper.py:58-79.) */
@@ -752,6 +769,12 @@ static void scene_contacts(const mppi_model_t *m, const scene_info_t *si, frame_
             } else if (A->type == MPPI_SHAPE_BOX && B->type == MPPI_SHAPE_DISC) {
                 real ax[3] = {wb.R[2], wb.R[5], wb.R[8]};
                 disc_in_box(mode, mu, k, cn, ct, kh, wb.p, ax, (real)B->size[0], &wa, A->size, -1, wa.v, wb.v, &acc);
+            } else if (A->type == MPPI_SHAPE_DISC && B->type == MPPI_SHAPE_SPHERE) {
+                real ax[3] = {wa.R[2], wa.R[5], wa.R[8]};
+                disc_sphere(mode, mu, k, cn, ct, kh, wa.p, ax, (real)A->size[0], wb.p, (real)B->size[0], 1, wa.v, wb.v, &acc);
+            } else if (A->type == MPPI_SHAPE_SPHERE && B->type == MPPI_SHAPE_DISC) {
+                real ax[3] = {wb.R[2], wb.R[5], wb.R[8]};
+                disc_sphere(mode, mu, k, cn, ct, kh, wb.p, ax, (real)B->size[0], wa.p, (real)A->size[0], -1, wa.v, wb.v, &acc);
             }
         }
         if (!acc.any) continue;

@@ -110,3 +110,56 @@ def test_group_cull_of_candidate_pairs_changes_no_cost(make, name, K, H, nu, mon
         rel = np.abs(S["1"] - S["0"]) / np.abs(S["0"])
         print(f"\n{name} {st}: group cull on vs off: bit-equal costs {np.mean(S['1'] == S['0']):.4f}, max rel diff {rel.max():.1e}")
         assert np.mean(S["1"] == S["0"]) == 1.0, "a skipped pair is one the broad phase would have culled: bit-identical costs"
+
+
+def test_an_arm_among_ten_obstacle_spheres(oracle64):
+    """reference `IsaacGymConfig.num_obstacles: int = 10` (isaacgym_wrapper.py:16) and the obstacle lists of compute_action
+    (mppi_isaac.py:75-81, isaacgym_wrapper.py:695-742): the panda with its gripper among TEN fixed spheres = 12 actors, 100 candidate
+    pairs (MPPI_MAX_ACTORS 12 / MPPI_MAX_PAIRS 128 since ABI 8; 8 / 48 before, when this scene was refused).  Three of the
+    spheres stand where the arm's links reach them: rollouts of the contact-scene kernel against the fp64 oracle on every sample,
+    and the contact forces on the obstacles are felt."""
+    from mppiisaac.planner.isaacgym_wrapper import ActorWrapper, Scene
+    from mppiisaac.planner.mppi import make_config
+    from mppiisaac.utils.config_store import load_config
+    from mppiisaac.utils.isaacgym_utils import load_actor_cfgs, load_asset
+    K, H = 1024, 15
+    env = load_actor_cfgs(["panda_gripper", "goal"])
+    rng = np.random.default_rng(5)
+    spots = [[0.45, 0.0, 0.55], [0.3, 0.25, 0.75], [0.35, -0.2, 0.35]] + [[float(v) for v in rng.uniform([0.9, -1.0, 0.1], [1.6, 1.0, 1.2])] for _ in range(7)]
+    for i, p in enumerate(spots):
+        env.append(ActorWrapper(type="sphere", name=f"sphere{i}", size=[0.08], fixed=True, init_pos=p))
+    ex = load_config({"defaults": [{"mppi": "panda_pick"}, {"isaacgym": "normal"}]}, overrides={"mppi.num_samples": K, "mppi.horizon": H})
+    scene = Scene(env, ex.isaacgym, load_asset(env[0]))
+    m = scene.to_c()
+    assert m.n_actors == 12 and m.n_pairs == 100 and m.n_shapes == 21, (m.n_actors, m.n_pairs, m.n_shapes)
+    cfg = make_config(ex.mppi, viz_link=scene.viz_link_index())
+    nu = cfg.nu
+    cost = capi.Cost()
+    cost.kind, cost.n_terms = capi.COST_PROGRAM, 4
+    t = cost.terms[0]
+    t.op, t.n, t.w = capi.OP_DIST, 3, 10.0
+    t.src[0], t.idx[0] = capi.SRC_RB, scene.rigid_body_index("panda", "panda_ee")
+    t.src[1], t.idx[1] = capi.SRC_ACTOR, scene.actor_index("goal")
+    for j in range(3):
+        t = cost.terms[1 + j]
+        t.op, t.n, t.w = capi.OP_FORCE_L1, 3, 0.05
+        t.src[0], t.idx[0] = capi.SRC_RB, scene.rigid_body_index(f"sphere{j}", "sphere")
+    dof, root = scene.initial_state()
+    root[scene.actor_index("goal"), 0:3] = [0.5, 0.1, 0.5]
+    c = Ctx(m, cfg, cost)
+    c.call("mppi_sample", C.c_uint32(0)); c.set_state(dof, root)
+    U = np.zeros((H, nu), np.float32)
+    U[:, 1], U[:, 3] = 0.6, 0.5                      # lean the arm forward, into the first spheres
+    c.set_U(U); c.call("mppi_rollout")
+    S, eps = c.get("mppi_get_costs", (K,)), c.get("mppi_get_noise", (H, nu, K))
+    c.close()
+    So, _, _ = oracle64.rollout(m, cfg, cost, dof, root, U, eps)
+    rel = np.abs(S - So) / np.abs(So)
+    m0 = scene.to_c()
+    m0.n_pairs = 0
+    S_free, _, _ = oracle64.rollout(m0, cfg, cost, dof, root, U, eps)
+    touched = np.mean(np.abs(So - S_free) > 1e-3 * np.abs(S_free))
+    print(f"\narm among ten spheres, {m.n_pairs} pairs: all {K} samples vs fp64 oracle within 1e-4 {np.mean(rel <= 1e-4):.4f} 1e-3 {np.mean(rel <= 1e-3):.4f} max {rel.max():.1e}; "
+          f"{touched:.2f} of the rollouts touch an obstacle")
+    assert np.isfinite(S).all() and touched > 0.2
+    assert np.mean(rel <= 1e-3) >= 0.99 and np.mean(rel <= 1e-2) >= 0.998

@@ -479,3 +479,53 @@ def test_disc_box_contact_device_arithmetic_matches_oracle(hostemu, oracle64, op
             active += int(np.abs(cfo[rbb, 0:2]).max() > 0.1)
             worst = max(worst, np.abs(cf - cfo).max() / max(1.0, np.abs(cfo).max()))
     assert active >= 15 and worst < 5e-3, (active, worst)
+
+
+def test_a_wheel_meets_a_sphere_obstacle(oracle64, hostemu):
+    """round 5: disc-sphere pairs (csrc/mppi_scene.hpp disc_sphere) - the wheels of a mobile base against the sphere obstacles the
+    benchmark adapters place (reference benchmarks/point_robot/mppi_planner/mppi_planner_wrapper.py:58-79).  With the chassis-sphere
+    pair out of the model a fixed sphere in the path of the boxer's front casters stops the robot at their rims; oracle, and the
+    host build of the device function stepwise against it with the contact active."""
+    from mppiisaac.backend import capi
+    from mppiisaac.planner.isaacgym_wrapper import ActorWrapper, Scene
+    from mppiisaac.utils.config_store import load_config
+    from mppiisaac.utils.isaacgym_utils import load_actor_cfgs, load_asset
+    env = load_actor_cfgs(["boxer", "goal"])
+    env[0].init_pos = [0.0, 2.5, 0.05]
+    env.append(ActorWrapper(type="sphere", name="sphere0", size=[0.15], fixed=True, init_pos=[0.177, 2.5 - 0.336 - 0.15 - 0.05, 0.06]))
+    scene = Scene(env, load_config({"defaults": [{"isaacgym": "normal"}]}).isaacgym, load_asset(env[0]))
+    assert not scene.dropped_pairs                       # wheels against spheres are tested; only wheel-wheel pairs would be listed
+    m = scene.to_c()
+    shapes = scene.shapes
+    chassis = next(i for i, s in enumerate(shapes) if s["link"] == "chassis_link")
+    sph = next(i for i, s in enumerate(shapes) if s["type"] == capi.SHAPE_SPHERE)
+    discs = [i for i, s in enumerate(shapes) if s["type"] == capi.SHAPE_DISC]
+    assert sum(1 for i in range(m.n_pairs) if m.pairs[i].a in discs and m.pairs[i].b == sph) == 4
+    mm = _without_pairs(m, lambda a, b: {a, b} == {chassis, sph})
+    dof, root = scene.initial_state()
+    q, qd, root = dof[0::2].astype(float), dof[1::2].astype(float), root.astype(float)
+    root, q, qd, _ = settle(oracle64, mm, root, q, qd, 10)
+    rb, cf = np.zeros((m.n_rb, 13), np.float32), np.zeros((m.n_rb, 3), np.float32)
+    rbs = scene.rigid_body_index("sphere0", "sphere")
+    active, worst = 0, 0.0
+    for t in range(40):
+        u = (0.5, 0.0)
+        de = np.zeros(2 * scene.n_dof, np.float32)
+        de[0::2], de[1::2] = q, qd
+        re = f32(root).copy()
+        assert hostemu.emu_scene_step(C.byref(mm), fp(de), fp(re.reshape(-1)), fp(f32(u)), fp(rb), fp(cf)) == 0
+        root, q, qd, cfo = oracle64.scene_step(mm, root, q, qd, oracle64.cmd_map(mm, u))
+        np.testing.assert_allclose(re[:, 0:7], root[:, 0:7], atol=3e-5)
+        np.testing.assert_allclose(re[:, 7:13], root[:, 7:13], atol=3e-3)
+        active += int(np.abs(cfo[rbs]).max() > 0.1)
+        worst = max(worst, np.abs(cf - cfo).max() / max(1.0, np.abs(cfo).max()))
+    # the right caster's rim (0.336 ahead of the chassis centre, at x = 0.177) runs into the sphere: for half a dozen steps the sphere
+    # pushes back (kilonewtons on a 274-kg robot), the robot is turned aside and passes the obstacle
+    assert active >= 4 and worst < 5e-3, (active, worst)
+    assert yaw_of(root[0, 3:7]) > 0.15 and root[0, 0] > 0.1, (yaw_of(root[0, 3:7]), root[0, 0:3])
+    # without the pair it would have driven straight through
+    nothing = _without_pairs(mm, lambda a, b: b == sph and a in discs)
+    r2, q2, qd2 = f32(scene.initial_state()[1]).astype(float), dof[0::2].astype(float), dof[1::2].astype(float)
+    r2, q2, qd2, _ = settle(oracle64, nothing, r2, q2, qd2, 10)
+    r2, q2, qd2, _ = settle(oracle64, nothing, r2, q2, qd2, 40, u=(0.5, 0.0))
+    assert abs(yaw_of(r2[0, 3:7])) < 1e-3 and abs(r2[0, 0]) < 1e-3
