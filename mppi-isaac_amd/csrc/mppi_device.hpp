@@ -40,6 +40,7 @@ constexpr int kMaxActors = 12;
 constexpr int kMaxNu = 12;
 constexpr int kMaxShapes = 64;
 constexpr int kMaxPairs = 128;
+constexpr int kPairKernelMaxPairs = 64;  // the helper-wavefront scene kernel: two mask words (mppi_scene.hpp, pair groups)
 constexpr int kMaxFree = 4;        // free actors a MODEL may hold (MPPI_MAX_FREE)
 // free-actor slots the contact-scene KERNELS of this build carry (state rows, frames, LDS rows are sized by it): 2 in the shipped
 // library - every example scene of the reference has at most two free actors, and two more slots cost the register-bound scene

@@ -480,7 +480,8 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
             c->lanes_per_sample = !c->quad ? 1 : (oct ? 8 : 4);
             c->launch_rollout = c->quad ? (oct ? e->rollout_scene_oct : e->rollout_scene_quad) : e->rollout_scene;
             // short trees: the octet kernel with a helper wavefront per sample group (kSplitOctPair) unless MPPI_ROLLOUT=oct
-            c->helper_wave = oct && e->rollout_scene_pair != nullptr && !(mode && std::string(mode) == "oct");
+            // (its dead-pair masks are two words, mppi_scene.hpp: a larger candidate list goes to the one-wavefront octet kernel)
+            c->helper_wave = oct && e->rollout_scene_pair != nullptr && !(mode && std::string(mode) == "oct") && c->hm.n_pairs <= kPairKernelMaxPairs;
             if (c->helper_wave) c->launch_rollout = e->rollout_scene_pair;
             if (oct) {  // (whole-horizon trajectories for host-side costs: the octet kernel)
                 c->launch_rollout_traj = e->rollout_scene_traj;

@@ -1064,6 +1064,10 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
     // out of the robot's reach in every sample of this wavefront - one distance test per group and substep instead of a record
     // fetch, two pose reads and the broad-phase arithmetic per pair.  The verdict is wave-uniform (the pair loop is), so the masks
     // live in scalar registers; conservative like the broad phase (a skipped pair is one it would have culled).
+    // (the kernel with a helper wavefront keeps TWO words: its 256-register budget is full, and the two scalar registers of the upper
+    // words came out of it as 48 B more scratch per lane, pushing scene 1.19 -> 1.33 ms; mppi_create gives a scene with more than
+    // kPairKernelMaxPairs candidate pairs the one-wavefront kernel instead)
+    constexpr bool kWide = !kPair;
     unsigned dead_lo = 0u, dead_hi = 0u, dead_2 = 0u, dead_3 = 0u;
     if constexpr (kCached) {
         for (int g = 0; g < m.n_groups; g++) {
@@ -1072,22 +1076,33 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
 #if defined(__HIP_DEVICE_COMPILE__)
             far = __all(far) != 0;
 #endif
-            if (far) { dead_lo |= m.grp[g].mask_lo; dead_hi |= m.grp[g].mask_hi; dead_2 |= m.grp[g].mask_2; dead_3 |= m.grp[g].mask_3; }
+            if (far) {
+                dead_lo |= m.grp[g].mask_lo; dead_hi |= m.grp[g].mask_hi;
+                if constexpr (kWide) { dead_2 |= m.grp[g].mask_2; dead_3 |= m.grp[g].mask_3; }
+            }
         }
 #if defined(__HIP_DEVICE_COMPILE__)
         dead_lo = (unsigned)uniform((int)dead_lo);
         dead_hi = (unsigned)uniform((int)dead_hi);
-        dead_2 = (unsigned)uniform((int)dead_2);
-        dead_3 = (unsigned)uniform((int)dead_3);
+        if constexpr (kWide) {
+            dead_2 = (unsigned)uniform((int)dead_2);
+            dead_3 = (unsigned)uniform((int)dead_3);
+        }
 #endif
         alive_lo &= ~dead_lo;
         alive_hi &= ~dead_hi;
-        alive_2 &= ~dead_2;
-        alive_3 &= ~dead_3;
+        if constexpr (kWide) {
+            alive_2 &= ~dead_2;
+            alive_3 &= ~dead_3;
+        }
     }
     auto is_dead = [&](int ip) MPPI_LAMBDA {
-        const unsigned wd = ip < 64 ? (ip < 32 ? dead_lo : dead_hi) : (ip < 96 ? dead_2 : dead_3);
-        return ((wd >> (ip & 31)) & 1u) != 0u;
+        if constexpr (kWide) {
+            const unsigned wd = ip < 64 ? (ip < 32 ? dead_lo : dead_hi) : (ip < 96 ? dead_2 : dead_3);
+            return ((wd >> (ip & 31)) & 1u) != 0u;
+        } else {
+            return (((ip < 32 ? dead_lo : dead_hi) >> (ip & 31)) & 1u) != 0u;
+        }
     };
     MPPI_SEC(2);
     // The loop visits the pairs that are alive (all of them without the dealt pass).  Both 64-byte blocks of the NEXT pair

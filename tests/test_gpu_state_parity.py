@@ -163,3 +163,57 @@ def test_an_arm_among_ten_obstacle_spheres(oracle64):
           f"{touched:.2f} of the rollouts touch an obstacle")
     assert np.isfinite(S).all() and touched > 0.2
     assert np.mean(rel <= 1e-3) >= 0.99 and np.mean(rel <= 1e-2) >= 0.998
+
+
+def test_a_mobile_base_among_nine_boxes_takes_the_one_wavefront_kernel(oracle64):
+    """The pushing scene's kernel with a helper wavefront keeps two words of dead-pair masks (its register budget is full:
+    mppi_scene.hpp, pair groups) - a scene with more than 64 candidate pairs (boxer: chassis, two wheels, two casters and the
+    block against NINE obstacle boxes = 12 actors, 65 pairs; reference isaacgym_wrapper.py:16 `num_obstacles = 10`) is given the one-wavefront octet kernel by
+    mppi_create; costs against the fp64 oracle either way."""
+    from mppiisaac.planner.isaacgym_wrapper import ActorWrapper, Scene
+    from mppiisaac.planner.mppi import make_config
+    from mppiisaac.utils.config_store import load_config
+    from mppiisaac.utils.isaacgym_utils import load_actor_cfgs, load_asset
+    K, H = 1024, 20
+    for n_obst, kernel in ((9, "scene-oct"), (4, "scene-oct-pair")):
+        env = load_actor_cfgs(["boxer", "block", "goal"])
+        rng = np.random.default_rng(11)
+        spots = [[0.85, 0.05, 0.15], [0.3, -0.75, 0.15], [0.1, 0.8, 0.15]] + [[float(v) for v in rng.uniform([-2.0, -2.0, 0.15], [2.5, 2.0, 0.15])] for _ in range(n_obst - 3)]
+        for i, p in enumerate(spots):
+            env.append(ActorWrapper(type="box", name=f"obst{i}", size=[0.3, 0.3, 0.3], fixed=True, init_pos=p))
+        ex = load_config({"defaults": [{"mppi": "boxer_push"}, {"isaacgym": "normal"}]}, overrides={"mppi.num_samples": K, "mppi.horizon": H})
+        scene = Scene(env, ex.isaacgym, load_asset(env[0]))
+        m = scene.to_c()
+        assert (m.n_pairs > 64) == (n_obst == 9), m.n_pairs
+        cfg = make_config(ex.mppi, viz_link=scene.viz_link_index())
+        cost = capi.Cost()
+        cost.kind, cost.n_terms = capi.COST_PROGRAM, 3
+        t = cost.terms[0]
+        t.op, t.n, t.w = capi.OP_DIST, 2, 1.0
+        t.src[0], t.idx[0] = capi.SRC_ACTOR, scene.actor_index("block")
+        t.src[1], t.idx[1] = capi.SRC_ACTOR, scene.actor_index("goal")
+        for j in range(2):
+            t = cost.terms[1 + j]
+            t.op, t.n, t.w = capi.OP_FORCE_L1, 3, 0.001
+            t.src[0], t.idx[0] = capi.SRC_RB, scene.rigid_body_index(f"obst{j}", "box")
+        dof, root = scene.initial_state()
+        c = Ctx(m, cfg, cost)
+        buf = C.create_string_buffer(256)
+        c.call("mppi_kernel_info", buf, C.c_int(256))
+        assert f"rollout={kernel} " in buf.value.decode(), buf.value
+        c.call("mppi_sample", C.c_uint32(0)); c.set_state(dof, root)
+        U = np.zeros((H, cfg.nu), np.float32)
+        U[:, 0] = 1.2                                # straight at the first boxes
+        c.set_U(U); c.call("mppi_rollout")
+        S, eps = c.get("mppi_get_costs", (K,)), c.get("mppi_get_noise", (H, cfg.nu, K))
+        c.close()
+        So, _, _ = oracle64.rollout(m, cfg, cost, dof, root, U, eps)
+        rel = np.abs(S - So) / np.abs(So)
+        m0 = scene.to_c()
+        m0.n_pairs = 0
+        S_free, _, _ = oracle64.rollout(m0, cfg, cost, dof, root, U, eps)
+        touched = np.mean(np.abs(So - S_free) > 1e-3 * np.abs(S_free))
+        print(f"\nboxer among {n_obst} boxes, {m.n_pairs} pairs, {kernel}: vs fp64 oracle within 1e-4 {np.mean(rel <= 1e-4):.4f} 1e-3 {np.mean(rel <= 1e-3):.4f} 1e-2 {np.mean(rel <= 1e-2):.4f} max {rel.max():.1e}; "
+              f"{touched:.2f} of the rollouts differ from the scene without contacts")
+        assert np.isfinite(S).all() and touched > 0.2
+        assert np.mean(rel <= 1e-3) >= 0.97 and np.mean(rel <= 1e-2) >= 0.99
