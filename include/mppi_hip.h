@@ -41,6 +41,7 @@ extern "C" {
 #define MPPI_MAX_SHAPES 64   /* collision primitives per env (anymal: 37; an arm + ten obstacle spheres)  */
 #define MPPI_MAX_PAIRS 128   /* candidate contact pairs per env (one verdict bit per pair in four mask words; the ten-link arm
                               * among the reference's ten obstacle spheres - IsaacGymConfig.num_obstacles - has 100)        */
+#define MPPI_CONTACT_POINT_NORMALS 1
 #define MPPI_MAX_FREE 4      /* free (non-fixed) box/sphere actors per env (the shipped kernels carry 2 slots; scenes with
                               * 3-4 free actors get their kernels built on demand, see mppi_create)          */
 #define MPPI_MAX_EXTRA_BASES 3 /* moving-base robots per env beyond the first (ABI 7)         */
@@ -212,13 +213,18 @@ typedef struct mppi_model {
      * hash of (seed, g, actor) - the seeded counterpart of the reference's unseeded np.random draws per env;
      * < 0: nominal values in every sample */
     int32_t randomize_seed;
-    int32_t pad2_;
+    /* bit 0 (MPPI_CONTACT_POINT_NORMALS): two DYNAMIC boxes keep the law of ABI <= 7 - every feature point pushed towards the nearest
+     * face of the other box.  Default (0): ONE normal per pair from the 15-axis separating-axis test, every point's depth measured
+     * along it, and a patch its points under-sample (a lone corner, crossing edges) filled up to half the nominal stiffness by one
+     * contact of the separating-axis depth */
+    int32_t contact_flags;
     /* ABI 7 - several MOVING-base robots in one env (reference isaacgym_wrapper.py:101-106,534-559, conf/mppi/multi-jackal.yaml).
      * The robots form one articulated forest (bodies, links and DOFs follow one another in env order, like the fixed-base
      * forests); base 0 is `robot_actor` with base_mass / base_h / base_Io above, base r > 0 is extra_base_*[r - 1].  A body whose
      * `parent`, a link or a shape whose `body` is -1 - r hangs off base r (r = 0: the -1 of every single-robot model).  All
      * robots of an env are either fixed or moving.  Every base has its own root row (root_state[actor]) and its own 6x6 base
-     * system in the articulated-body solve; the robots do not collide with each other (one forest = one robot's links). */
+     * system in the articulated-body solve; pairs between shapes of DIFFERENT trees are allowed (the host lists chassis against
+     * chassis: round 5), pairs within one tree are not. */
     int32_t n_extra_bases;
     int32_t extra_base_actor[MPPI_MAX_EXTRA_BASES];
     double extra_base_mass[MPPI_MAX_EXTRA_BASES];

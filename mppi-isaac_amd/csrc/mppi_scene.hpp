@@ -798,6 +798,155 @@ MPPI_HD void box_points_in_box(const Gains &P, V3 yc, const V3 *col, const Shape
     }
 }
 
+// Two DYNAMIC boxes (mode 0, round 5): ONE normal for the whole pair, from the separating-axis test, instead of a push-out
+// direction per feature point.  The per-point rule (box_interior: towards the nearest face of the OTHER box) fails where it
+// matters for two robots - two equal chassis meeting squarely: every corner and edge midpoint of one lies on a face plane of the
+// other (only the face centres are inside: half the nominal stiffness), and as soon as the boxes pitch a little the points of
+// the top edge are nearer to the other box's TOP face than to its front: they are pushed up, one chassis climbs the other and
+// the two end up inside each other.  Here (oracle: box_pair_sat / corners_along):
+//   - 15-axis separating-axis test; an axis that separates: no contact.  depth = the smallest overlap;
+//   - n = blend of the six face axes with weights max(0, o_min / o_a - 1/2)^3 - a pure face normal unless two overlaps are
+//     within a factor two of each other -, oriented from B to A;
+//   - every feature point inside the other box is pushed along n, its depth = the distance it has to travel along n to leave
+//     that box (ray exit: continuous in the point and in n): box_points_along;
+//   - a patch that its points under-sample (a lone corner; two edges that cross: NO feature point inside) is filled up to HALF the
+//     nominal stiffness: the share npts / 2 - sum of ramps goes to one more contact of the separating-axis depth at p = the
+//     incident box's support point (smoothed over +-0.05 in the direction cosine: a face lying flat gives its centre, a tilted
+//     one its deepest corner) clamped onto the reference face: box_pair_fill, called with the pair's TOTAL wsum.  Half, not all of
+//     it: the stability bound of the explicit law (alpha + 2 beta < 4) is per BODY, and a block held between two fingers sees two
+//     patches - filled to the full nominal stiffness the recorded gripper state lost 0.8 % of its 8192 rollouts to fp32 rounding.
+// A = X of `rel` (rel.R[3 i + j] = b_i . a_j, rel.t = centre of A in B's frame).  Every lane of a sample computes the same bits.
+MPPI_HD V3 tmul3(const M3 &A, V3 v) {  // A^T v
+    return {A.a[0] * v.x + A.a[3] * v.y + A.a[6] * v.z, A.a[1] * v.x + A.a[4] * v.y + A.a[7] * v.z, A.a[2] * v.x + A.a[5] * v.y + A.a[8] * v.z};
+}
+struct BoxSat {
+    V3 n, p;
+    float depth;
+    bool hit;
+};
+MPPI_HD BoxSat box_pair_sat(const BoxRel &rel, const ShapeW &wa, const float *hA, const ShapeW &wb, const float *hB) {
+    BoxSat out;
+    out.hit = false;
+    out.n = out.p = {0.f, 0.f, 0.f};
+    out.depth = 0.f;
+    const float *Cm = rel.R;
+    float aC[9];
+    for (int j = 0; j < 9; j++) aC[j] = fabsf(Cm[j]);
+    const float t[3] = {rel.t.x, rel.t.y, rel.t.z};
+    float tA[3], oA[3], oB[3];
+    float omin = 1e30f;
+    bool apart = false;
+    for (int i = 0; i < 3; i++) {
+        tA[i] = t[0] * Cm[i] + t[1] * Cm[3 + i] + t[2] * Cm[6 + i];
+        oB[i] = hB[i] + aC[3 * i] * hA[0] + aC[3 * i + 1] * hA[1] + aC[3 * i + 2] * hA[2] - fabsf(t[i]);
+        oA[i] = hA[i] + aC[i] * hB[0] + aC[3 + i] * hB[1] + aC[6 + i] * hB[2] - fabsf(tA[i]);
+        apart = apart || !(oB[i] > 0.f) || !(oA[i] > 0.f);
+        omin = fminf(omin, fminf(oB[i], oA[i]));
+    }
+    float odepth = omin;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {  // edge axes b_i x a_j (nearly parallel edges: the face axes cover that direction)
+            const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+            const float l2 = 1.f - Cm[3 * i + j] * Cm[3 * i + j];
+            const float o = hB[i1] * aC[3 * i2 + j] + hB[i2] * aC[3 * i1 + j] + hA[j1] * aC[3 * i + j2] + hA[j2] * aC[3 * i + j1] -
+                            fabsf(t[i2] * Cm[3 * i1 + j] - t[i1] * Cm[3 * i2 + j]);
+            const bool used = l2 >= 1e-3f;
+            apart = apart || (used && !(o > 0.f));
+            odepth = used ? fminf(odepth, o * frsqrt(fmaxf(l2, 1e-3f))) : odepth;
+        }
+    if (apart) return out;
+    constexpr float kInvTau = 20.f;
+    auto sat1 = [](float x) MPPI_LAMBDA { return fminf(1.f, fmaxf(-1.f, x)); };
+    float nB[3] = {0.f, 0.f, 0.f}, nA[3] = {0.f, 0.f, 0.f}, yB[3] = {0.f, 0.f, 0.f}, xA[3] = {0.f, 0.f, 0.f};
+    float WB = 0.f, WA = 0.f;
+    for (int i = 0; i < 3; i++) {  // B's face i is the reference, A the incident box: in B's frame
+        float w = fmaxf(0.f, omin * frcp(oB[i]) - 0.5f);
+        if (!(w > 0.f)) continue;  // (usually five of the six axes: adding their zeros changes no bit)
+        w = w * w * w;
+        const float sg = t[i] > 0.f ? 1.f : -1.f;
+        float y[3] = {t[0], t[1], t[2]};
+        for (int j = 0; j < 3; j++) {
+            const float sj = hA[j] * sat1(sg * Cm[3 * i + j] * kInvTau);
+            for (int l = 0; l < 3; l++) y[l] -= sj * Cm[3 * l + j];
+        }
+        for (int l = 0; l < 3; l++) y[l] = fminf(hB[l], fmaxf(-hB[l], y[l]));
+        y[i] = sg * (hB[i] - 0.5f * oB[i]);
+        nB[i] += w * sg;
+        for (int l = 0; l < 3; l++) yB[l] += w * y[l];
+        WB += w;
+    }
+    for (int j = 0; j < 3; j++) {  // A's face j is the reference, B the incident box: in A's frame
+        float w = fmaxf(0.f, omin * frcp(oA[j]) - 0.5f);
+        if (!(w > 0.f)) continue;
+        w = w * w * w;
+        const float sg = tA[j] > 0.f ? 1.f : -1.f;
+        float x[3] = {-tA[0], -tA[1], -tA[2]};  // centre of B in A's frame
+        for (int i = 0; i < 3; i++) {
+            const float si = hB[i] * sat1(sg * Cm[3 * i + j] * kInvTau);
+            for (int l = 0; l < 3; l++) x[l] += si * Cm[3 * i + l];
+        }
+        for (int l = 0; l < 3; l++) x[l] = fminf(hA[l], fmaxf(-hA[l], x[l]));
+        x[j] = -sg * (hA[j] - 0.5f * oA[j]);
+        nA[j] += w * sg;
+        for (int l = 0; l < 3; l++) xA[l] += w * x[l];
+        WA += w;
+    }
+    const V3 n = mul(wb.R, V3{nB[0], nB[1], nB[2]}) + mul(wa.R, V3{nA[0], nA[1], nA[2]});
+    const float nn2 = dot(n, n);
+    if (!(nn2 > 1e-12f)) return out;  // (opposite face normals of equal weight cancel: no direction to push in)
+    out.n = frsqrt(nn2) * n;
+    out.p = frcp(WA + WB) * (WB * wb.p + mul(wb.R, V3{yB[0], yB[1], yB[2]}) + WA * wa.p + mul(wa.R, V3{xA[0], xA[1], xA[2]}));
+    out.depth = odepth;
+    out.hit = true;
+    return out;
+}
+MPPI_HD void box_pair_fill(const Gains &P, const BoxSat &sat, const SV &vA, const SV &vB, PairAcc &acc) {
+    const float deficit = 0.5f * P.npts - acc.wsum;  // (HALF the nominal patch, see above)
+    if (!(deficit > 0.f)) return;
+    PairAcc one;
+    one.f = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    one.rep = {0.f, 0.f, 0.f};
+    one.wsum = 0.f;
+    one.any = false;
+    contact_point(P, sat.p, sat.n, sat.depth, vA, vB, one);  // (mode 0: touches f, rep, wsum only)
+    acc.f = {acc.f.a + deficit * one.f.a, acc.f.l + deficit * one.f.l};
+    acc.rep = acc.rep + deficit * one.rep;
+    acc.wsum += deficit * one.wsum;
+    acc.any = true;
+}
+// box_points_in_box with the pair's normal: n (world, from B to A), nl = the direction in which the points of X leave Y, in Y's
+// frame (+-R_Y^T n)
+MPPI_HD void box_points_along(const Gains &P, V3 yc, const V3 *col, const ShapeW &Y, const float *hy, V3 nl, V3 n, const SV &vA, const SV &vB,
+                              Split sp, PairAcc &acc) {
+    const V3 inv = {frcp(fmaxf(fabsf(nl.x), 1e-9f)), frcp(fmaxf(fabsf(nl.y), 1e-9f)), frcp(fmaxf(fabsf(nl.z), 1e-9f))};  // (a face the ray runs parallel to is never its exit)
+    auto point = [&](int c, V3 &y) MPPI_LAMBDA {
+        const int c3 = c / 3, c9 = c / 9;
+        const float s0 = (float)(c - 3 * c3 - 1), s1 = (float)(c3 - 3 * c9 - 1), s2 = (float)(c9 - 1);
+        y = yc + s0 * col[0] + s1 * col[1] + s2 * col[2];
+        return c != 13 && hy[0] - fabsf(y.x) > 0.f && hy[1] - fabsf(y.y) > 0.f && hy[2] - fabsf(y.z) > 0.f;
+    };
+    unsigned hits = 0;
+    const int trips = (27 + sp.n - 1) / sp.n;
+    for (int it = 0; it < trips; it++) {
+        const int c = sp.sub + it * sp.n;
+        V3 y;
+        if (point(c, y) && c < 27) hits |= 1u << it;
+    }
+    while (hits != 0) {
+        const int j = __builtin_ctz(hits);
+        hits &= hits - 1;
+        V3 y;
+        point(sp.sub + j * sp.n, y);
+        // ray exit from Y along nl, capped at four times the distance to the NEAREST face: a point that enters through a side face (a
+        // finger sliding over the block) starts at depth 0 and gains four times its distance from that face until the exit along n
+        // takes over - with the plain ray exit its depth jumped to the pair's penetration the moment it was inside
+        const float near = fminf(fminf(hy[0] - fabsf(y.x), hy[1] - fabsf(y.y)), hy[2] - fabsf(y.z));
+        const float depth = fminf(fminf(fminf((hy[0] - (nl.x > 0.f ? y.x : -y.x)) * inv.x, (hy[1] - (nl.y > 0.f ? y.y : -y.y)) * inv.y),
+                                        (hy[2] - (nl.z > 0.f ? y.z : -y.z)) * inv.z), 4.f * near);
+        contact_point(P, Y.p + mul(Y.R, y), n, depth, vA, vB, acc);
+    }
+}
+
 // sphere (centre ps, radius r) against box Y: closest point of the box to the centre; sign = +1 when the
 // sphere is shape A (normal from B = box to A = sphere)
 MPPI_HD void sphere_in_box(const Gains &P, V3 ps, float r, const ShapeW &Y, const float *hy, float sign, const SV &vA, const SV &vB, PairAcc &acc) {
@@ -1294,6 +1443,11 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
             wa.v = frame_velocity(L, G.entA);
             if (has_b) wb.v = frame_velocity(L, entB);
         }
+        // two dynamic boxes: one normal for the pair (box_pair_sat), unless the model asks for the law of ABI <= 7
+        const bool pair_normal = G.mode == 0 && has_b && typeA == 0 && typeB == 0 && m.face_fill != 0;
+        BoxSat sat;
+        sat.hit = false;
+        if (pair_normal) sat = box_pair_sat(rel, wa, hA, wb, hB);
         auto points = [&](Split sp, PairAcc &out) MPPI_LAMBDA {
             if (!has_b) {  // ground plane z = 0, normal +z (from ground to A)
                 if (typeA == 0) {
@@ -1320,12 +1474,20 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
                 // A's points in B: centre t, columns of Rrel; B's points in A: centre -Rrel^T t, columns = rows of Rrel
                 const V3 colA[3] = {{hA[0] * rel.R[0], hA[0] * rel.R[3], hA[0] * rel.R[6]}, {hA[1] * rel.R[1], hA[1] * rel.R[4], hA[1] * rel.R[7]},
                                     {hA[2] * rel.R[2], hA[2] * rel.R[5], hA[2] * rel.R[8]}};
-                box_points_in_box(P, rel.t, colA, wb, hB, 1.f, wa.v, wb.v, sp, out);
+                if (pair_normal) {
+                    if (sat.hit) box_points_along(P, rel.t, colA, wb, hB, tmul3(wb.R, sat.n), sat.n, wa.v, wb.v, sp, out);
+                } else {
+                    box_points_in_box(P, rel.t, colA, wb, hB, 1.f, wa.v, wb.v, sp, out);
+                }
                 const V3 tb = {-(rel.R[0] * rel.t.x + rel.R[3] * rel.t.y + rel.R[6] * rel.t.z), -(rel.R[1] * rel.t.x + rel.R[4] * rel.t.y + rel.R[7] * rel.t.z),
                                -(rel.R[2] * rel.t.x + rel.R[5] * rel.t.y + rel.R[8] * rel.t.z)};
                 const V3 colB[3] = {{hB[0] * rel.R[0], hB[0] * rel.R[1], hB[0] * rel.R[2]}, {hB[1] * rel.R[3], hB[1] * rel.R[4], hB[1] * rel.R[5]},
                                     {hB[2] * rel.R[6], hB[2] * rel.R[7], hB[2] * rel.R[8]}};
-                box_points_in_box(P, tb, colB, wa, hA, -1.f, wa.v, wb.v, sp, out);
+                if (pair_normal) {
+                    if (sat.hit) box_points_along(P, tb, colB, wa, hA, -1.f * tmul3(wa.R, sat.n), sat.n, wa.v, wb.v, sp, out);
+                } else {
+                    box_points_in_box(P, tb, colB, wa, hA, -1.f, wa.v, wb.v, sp, out);
+                }
             } else if (sp.sub == 0) {
                 if (typeA == 1 && typeB == 0) sphere_in_box(P, wa.p, hA[0], wb, hB, 1.f, wa.v, wb.v, out);
                 else if (typeA == 0 && typeB == 1) sphere_in_box(P, wb.p, hB[0], wa, hA, -1.f, wa.v, wb.v, out);
@@ -1378,6 +1540,7 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
         }
 #endif
         MPPI_SEC(14);  // feature points + cross-lane sum
+        if (pair_normal && sat.hit) box_pair_fill(P, sat, wa.v, wb.v, acc);
         if (G.mode == 0 && acc.any) pair_normalise(P, acc);
         if (acc.any) {
             const SV neg = {{-acc.f.a.x, -acc.f.a.y, -acc.f.a.z}, {-acc.f.l.x, -acc.f.l.y, -acc.f.l.z}};

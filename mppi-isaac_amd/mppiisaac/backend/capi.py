@@ -12,6 +12,7 @@ import os
 MAX_BODIES, MAX_LINKS, MAX_ACTORS, MAX_NU, MAX_H, MAX_KNOTS, MAX_COST_W = 12, 24, 12, 12, 64, 16, 16
 MAX_SHAPES, MAX_PAIRS, MAX_FREE, MAX_EXTRA_BASES = 64, 128, 4, 3
 SHAPE_BOX, SHAPE_SPHERE, SHAPE_DISC = 0, 1, 2
+CONTACT_POINT_NORMALS = 1  # Model.contact_flags bit 0
 ABI_VERSION = 8
 # error codes of include/mppi_hip.h
 MPPI_OK, MPPI_EINVAL, MPPI_EHIP, MPPI_EUNSUPPORTED, MPPI_ESTATE = 0, -1, -2, -3, -4
@@ -61,7 +62,7 @@ class Model(C.Structure):
                 ("nu", _i), ("cmd_col", (_i * 2) * MAX_BODIES), ("cmd_coef", (_d * 2) * MAX_BODIES),
                 ("n_shapes", _i), ("n_pairs", _i), ("shapes", Shape * MAX_SHAPES), ("pairs", Pair * MAX_PAIRS),
                 ("ground_friction", _d), ("contact_alpha", _d), ("contact_beta", _d), ("friction_beta", _d), ("contact_ramp_depth", _d),
-                ("randomize_seed", _i), ("pad2_", _i),
+                ("randomize_seed", _i), ("contact_flags", _i),
                 ("n_extra_bases", _i), ("extra_base_actor", _i * MAX_EXTRA_BASES), ("extra_base_mass", _d * MAX_EXTRA_BASES),
                 ("extra_base_h", (_d * 3) * MAX_EXTRA_BASES), ("extra_base_Io", (_d * 6) * MAX_EXTRA_BASES)]
 

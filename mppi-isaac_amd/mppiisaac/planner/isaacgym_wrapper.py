@@ -273,6 +273,11 @@ class Scene:
     # switch for measurements - MPPI_WHEEL_BOX_PAIRS=0 in the environment does the same)
     import os as _os
     WHEEL_BOX_PAIRS = _os.environ.get("MPPI_WHEEL_BOX_PAIRS", "1") != "0"
+    # round 5: the moving-base robots of one env meet each other (chassis against chassis); two dynamic boxes whose feature points
+    # under-sample the contact patch get the rest of the nominal stiffness from the separating-axis test (DESIGN.md 3,
+    # mppi_model_t.contact_flags).  Switches for measurements and for the known-answer tests of the laws before round 5
+    ROBOT_ROBOT_PAIRS = _os.environ.get("MPPI_ROBOT_ROBOT_PAIRS", "1") != "0"
+    BOX_PAIR_NORMAL = _os.environ.get("MPPI_BOX_PAIR_NORMAL", "1") != "0"
 
     def _contact_scene(self):
         """Collision primitives and candidate pairs of one env.
@@ -317,7 +322,7 @@ class Scene:
                         # with each other, like the links of one robot)
                         shapes.append(dict(actor=self.robot_idx, body=l["body"], type=kind, rb=self.first_rb[self.robot_idx] + li, size=size,
                                            R=Rl @ Rc, p=Rl @ pc + pl, friction=0.0 if l["name"] in casters else a.friction,
-                                           fixed=bool(a.fixed), link=l["name"], R_in_link=Rc, p_in_link=pc))
+                                           fixed=bool(a.fixed), link=l["name"], R_in_link=Rc, p_in_link=pc, owner=ai))
             elif a.type == "box":
                 shapes.append(dict(actor=ai, body=-1, type=capi.SHAPE_BOX, rb=self.first_rb[ai], size=[0.5 * v for v in a.size],
                                    R=np.eye(3), p=np.zeros(3), friction=a.friction, fixed=bool(a.fixed), link="box",
@@ -337,10 +342,21 @@ class Scene:
                 sj = shapes[j]
                 robot_j = self.env_cfg[sj["actor"]].type == "robot"
                 static_j = sj["fixed"] and (not robot_j or sj["body"] < 0)
-                if si["actor"] == sj["actor"] or (static_i and static_j):
+                if static_i and static_j:
                     continue
                 kinds = {si["type"], sj["type"]}
-                names = (f'{self.env_cfg[si["actor"]].name}:{si["link"]}', f'{self.env_cfg[sj["actor"]].name}:{sj["link"]}')
+                if si["actor"] == sj["actor"]:
+                    # the links of ONE robot never meet (the reference's self-collision filter, isaacgym_wrapper.py:441).  Two
+                    # MOVING-base robots of an env do (round 5; one collision group per env): their boxes and spheres against each
+                    # other - chassis against chassis; a wheel reaches the other robot's chassis only after its own chassis has
+                    # (the wheels of the jackal, the boxer, the heijn sit inside the chassis' outline lengthwise), left out
+                    if not (robot_i and si.get("owner") != sj.get("owner") and not si["fixed"] and not sj["fixed"]):
+                        continue
+                    if capi.SHAPE_DISC in kinds or not self.ROBOT_ROBOT_PAIRS:
+                        self.dropped_pairs.append((f'{self.env_cfg[si["owner"]].name}:{si["link"]}', f'{self.env_cfg[sj["owner"]].name}:{sj["link"]}'))
+                        self.dropped_pair_shapes.append((i, j))
+                        continue
+                names = (f'{self.env_cfg[si.get("owner", si["actor"])].name}:{si["link"]}', f'{self.env_cfg[sj.get("owner", sj["actor"])].name}:{sj["link"]}')
                 if kinds == {capi.SHAPE_DISC}:
                     # round 5: wheels and casters meet the boxes and spheres of other actors (block, obstacles, walls, table, the
                     # obstacle spheres of the benchmark adapters) as well as the ground; what is still left out - a wheel against
@@ -363,7 +379,7 @@ class Scene:
             if key not in _REPORTED_DROPS:  # once per distinct scene and process
                 _REPORTED_DROPS.add(key)
                 logging.getLogger("mppiisaac").warning(
-                    "contact model: %d wheel/caster pairs are not tested (a wheel against another wheel%s; e.g. %s / %s); "
+                    "contact model: %d wheel/caster pairs are not tested (a wheel against another wheel or against another robot%s; e.g. %s / %s); "
                     "see Scene.dropped_pairs", len(key), "" if self.WHEEL_BOX_PAIRS else ", and - MPPI_WHEEL_BOX_PAIRS=0 - against boxes and spheres", *key[0])
         return shapes, pairs
 
@@ -500,6 +516,7 @@ class Scene:
         m.ground_friction = self.GROUND_FRICTION
         m.contact_alpha, m.contact_beta, m.friction_beta = self.CONTACT_ALPHA, self.CONTACT_BETA, self.FRICTION_BETA
         hsub = float(self.cfg.dt) / int(self.cfg.substeps)
+        m.contact_flags = 0 if self.BOX_PAIR_NORMAL else capi.CONTACT_POINT_NORMALS
         m.contact_ramp_depth = (abs(GRAVITY[2]) * hsub * hsub / self.CONTACT_ALPHA) if self.CONTACT_RAMP_DEPTH is None else float(self.CONTACT_RAMP_DEPTH)
         m.randomize_seed = int(self.randomize_seed)
         if self.robot.dof_mode not in DRIVE_GAINS:

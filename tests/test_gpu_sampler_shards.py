@@ -435,7 +435,14 @@ def test_no_candidate_pair_is_left_out_of_any_example_scene(lib):
         cfg = run.config(name, filter_u=False)
         planner = run.make_planner(name, cfg)
         sc = planner.sim.scene
-        assert not sc.dropped_pairs, (name, sc.dropped_pairs[:2])
+        # (left out on purpose: the WHEELS of one moving-base robot against another robot - its chassis meets the other chassis
+        # first, and every further pair between the same two bodies would add a nominal stiffness of its own to the explicit law)
+        left = [(a, b) for a, b in sc.dropped_pair_shapes
+                if not (capi.SHAPE_DISC in (sc.shapes[a]["type"], sc.shapes[b]["type"]) and sc.shapes[a].get("owner", -1) != sc.shapes[b].get("owner", -2)
+                        and "owner" in sc.shapes[a] and "owner" in sc.shapes[b])]
+        assert not left, (name, left[:2])
+        if name == "multi_jackal":   # the robots of an env meet each other: chassis against chassis
+            assert sum(1 for a, b in sc.pairs if b >= 0 and sc.shapes[a].get("owner") is not None and sc.shapes[b].get("owner") not in (None, sc.shapes[a]["owner"])) == 1
         disc_pairs[name] = sum(1 for a, b in sc.pairs if b >= 0 and capi.SHAPE_DISC in (sc.shapes[a]["type"], sc.shapes[b]["type"]))
         planner.sim.stop_sim()
     assert disc_pairs["boxer_push"] == 12 and disc_pairs["boxer_reach"] == 4, disc_pairs

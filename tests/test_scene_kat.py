@@ -529,3 +529,140 @@ def test_a_wheel_meets_a_sphere_obstacle(oracle64, hostemu):
     r2, q2, qd2, _ = settle(oracle64, nothing, r2, q2, qd2, 10)
     r2, q2, qd2, _ = settle(oracle64, nothing, r2, q2, qd2, 40, u=(0.5, 0.0))
     assert abs(yaw_of(r2[0, 3:7])) < 1e-3 and abs(r2[0, 0]) < 1e-3
+
+
+def _two_jackals(tmp_path, offset, pair_normal=True):
+    import yaml
+    from mppiisaac.planner.isaacgym_wrapper import Scene
+    from mppiisaac.utils.config_store import load_config
+    from mppiisaac.utils.isaacgym_utils import load_actor_cfgs, load_asset
+    from test_host_logic import JACKAL
+    paths = []
+    for k in (1, 2):
+        p = tmp_path / f"jackal{k}.yaml"
+        p.write_text(yaml.safe_dump({**JACKAL, "name": f"jackal{k}"}))
+        paths.append(str(p))
+    ig = load_config({"defaults": [{"isaacgym": "normal"}]}).isaacgym
+    env = load_actor_cfgs(paths + ["goal"])
+    env[0].init_pos, env[1].init_pos = [0.0, 0.0, 0.1], [1.2, offset, 0.1]
+    env[1].init_ori = [0.0, 0.0, 1.0, 0.0]                               # facing the first one
+    scene = Scene(env, ig, [load_asset(env[0]), load_asset(env[1])])
+    m = scene.to_c()
+    if not pair_normal:
+        from mppiisaac.backend import capi
+        m.contact_flags = capi.CONTACT_POINT_NORMALS
+    return scene, m
+
+
+def test_two_jackals_head_on_stop_instead_of_interpenetrating(oracle64, hostemu, tmp_path):
+    """round 5: the moving-base robots of one env meet each other - chassis box against chassis box
+    (reference: one collision group per env, isaacgym_wrapper.py:436-442) - and two DYNAMIC boxes get ONE normal per pair from the
+    15-axis separating-axis test (oracle box_pair_sat).  Two jackals (46.5 kg, chassis 0.42 m long) driven at each
+    other at 0.5 m/s commanded each, squarely and 5 / 15 cm off the line: they meet at a centre distance of 0.42 m, stay within
+    4 cm of it and on the ground.  With the per-point normals of rounds 1-4 (`MPPI_CONTACT_POINT_NORMALS`) the pair that is
+    5 cm off the line ends up INSIDE each other, one chassis lifted onto the other: the corners of the front's top edge are nearer
+    to the other chassis' top face than to its front as soon as the robots pitch, and are pushed up.  The host build of the device
+    function follows the oracle through the collision."""
+    scene, m = _two_jackals(tmp_path, 0.0)
+    shapes = scene.shapes
+    chassis = [i for i, s in enumerate(shapes) if s["link"] == "chassis_link"]
+    assert len(chassis) == 2 and shapes[chassis[0]]["owner"] != shapes[chassis[1]]["owner"]
+    cross = [(m.pairs[i].a, m.pairs[i].b) for i in range(m.n_pairs) if m.pairs[i].b >= 0]
+    assert cross == [tuple(chassis)], cross                              # one pair between the robots; wheels meet the ground only
+    assert len(scene.dropped_pair_shapes) == 24 and all(2 in (shapes[a]["type"], shapes[b]["type"]) for a, b in scene.dropped_pair_shapes)   # 4 x 4 wheels, 2 x 4 wheel-chassis: listed
+
+    def drive(m, steps=100, v=0.5, emu=False):
+        dof, root = scene.initial_state()
+        ro, q, qd = root.astype(float), dof[0::2].astype(float), dof[1::2].astype(float)
+        dist, z, worst = [], [], 0.0
+        rb, cf = np.zeros((m.n_rb, 13), np.float32), np.zeros((m.n_rb, 3), np.float32)
+        for _ in range(steps):
+            u = np.array([v, 0.0, v, 0.0])
+            if emu:
+                de = np.zeros(16, np.float32)
+                de[0::2], de[1::2] = q, qd
+                re = f32(ro).copy()
+                assert hostemu.emu_scene_step(C.byref(m), fp(de), fp(re.reshape(-1)), fp(f32(u)), fp(rb), fp(cf)) == 0
+            ro, q, qd, _ = oracle64.scene_step(m, ro, q, qd, oracle64.cmd_map(m, u))
+            if emu:
+                worst = max(worst, float(np.abs(re[:, 0:7] - ro[:, 0:7]).max()))
+            dist.append(float(np.hypot(*(ro[1, 0:2] - ro[0, 0:2]))))
+            z.append(float(max(ro[0, 2], ro[1, 2])))
+        return min(dist), dist[-1], max(z), worst
+
+    for off in (0.0, 0.05, 0.15):
+        scene, m = _two_jackals(tmp_path, off)
+        closest, final, top, _ = drive(m)
+        assert closest > 0.38 and final > 0.38 and top < 0.1, (off, closest, final, top)     # 0.42 = touching; at rest z = 0.06
+    scene, m_old = _two_jackals(tmp_path, 0.05, pair_normal=False)
+    closest, final, top, _ = drive(m_old)
+    assert closest < 0.05 and top > 0.2, (closest, final, top)            # rounds 1-4: through each other, one on top
+    hostemu.emu_set_scene_split(1)
+    scene, m = _two_jackals(tmp_path, 0.05)
+    closest, _, _, worst = drive(m, steps=60, emu=True)
+    assert closest < 0.42 and worst < 5e-5, (closest, worst)              # device arithmetic through the collision
+
+
+def test_pair_normal_law_of_two_dynamic_boxes(oracle64):
+    """box_pair_sat of the oracle on configurations with known answers (two free boxes cannot be posed without a robot in a scene:
+    the boxer's chassis - half extents 0.275 x 0.37 x 0.0695, 274 kg - against a free 4-kg box), one substep at rest, no gravity:
+    (i) squarely face to face with EQUAL cross sections - every corner and edge midpoint on a face plane of the other box, the
+    degenerate case of the feature-point model: the two face centres carry k d / 2 along the approach axis, nothing sideways or
+    vertical (k = alpha m_eff / h^2); (ii) a BAR sunk 1 cm into the chassis' top face, lying ACROSS it - no feature point of
+    either box inside the other, the boxes intersect: the separating-axis contact carries it with HALF the nominal stiffness,
+    straight up; with the per-point law of rounds 1-4 it feels nothing and falls through; (iii) a crate turned 45 degrees whose
+    vertical edge stands 1 cm off the chassis' vertical edge - all six face axes overlap, the edge-edge axis separates: no force."""
+    from mppiisaac.backend import capi
+    from mppiisaac.planner.isaacgym_wrapper import ActorWrapper, Scene
+    from mppiisaac.utils.config_store import load_config
+    from mppiisaac.utils.isaacgym_utils import load_actor_cfgs, load_asset
+    ig = load_config({"defaults": [{"isaacgym": "normal"}]}).isaacgym
+
+    def scene_with(size):
+        env = load_actor_cfgs(["boxer", "goal"])
+        env.append(ActorWrapper(type="box", name="crate", size=size, fixed=False, mass=4.0, init_pos=[0.0, 0.0, 1.0]))
+        scene = Scene(env, ig, load_asset(env[0]))
+        dof, root0 = scene.initial_state()
+        return scene, dof[0::2].astype(float), dof[1::2].astype(float), root0.astype(float), scene.actor_index("crate"), scene.rigid_body_index("crate", "box")
+
+    def force_on_crate(scene, q, qd, root0, ci, rbc, pos, quat=(0.0, 0.0, 0.0, 1.0), law="pair"):
+        m = scene.to_c()
+        m.gravity[2] = 0.0                                                # (nothing but the pair acts on the crate)
+        m.substeps = 1                                                    # (the reported force is the step's LAST substep's: the first one, at rest)
+        if law == "points":
+            m.contact_flags = capi.CONTACT_POINT_NORMALS
+        M = float(sum(m.bodies[i].mass for i in range(m.n_bodies)) + m.base_mass)
+        k = m.contact_alpha * (M * 4.0 / (M + 4.0)) / m.dt ** 2
+        root = root0.copy()
+        root[scene.robot_idx, 0:3] = [0.0, 0.0, 2.0]                      # both far above the ground, at rest
+        root[ci, 0:3], root[ci, 3:7] = pos, quat
+        _, _, _, cf = oracle64.scene_step(m, root, q, qd, oracle64.cmd_map(m, (0.0, 0.0)))
+        return cf[rbc].copy(), k
+
+    d = 0.012                                                             # 12 mm deep (beyond the ramp depth: full gains)
+    # (i) crate of the chassis' cross-section squarely in front of it (chassis centre 0.0695 above the base, heading -y)
+    sc = scene_with([0.55, 0.3, 0.139])
+    for law in ("pair", "points"):
+        f, k = force_on_crate(*sc, pos=[0.0, -(0.37 + 0.15) + d, 2.0 + 0.0695], law=law)
+        # (the per-point law measures the face centres' depth as the smooth minimum over three face distances: 1.5 % less)
+        assert f[1] < 0 and abs(f[1]) == pytest.approx(0.5 * k * d, rel=1e-5 if law == "pair" else 0.03) and np.abs(f[[0, 2]]).max() < 1e-6 * k * d, (law, f, k * d)
+    # (ii) a bar 1.2 m long, 4 cm thick, along x: centre 0.3 m to the side (its middle and both ends outside the chassis'
+    # footprint), 0.1 m off the chassis' centre line (the chassis' own top-face points outside the bar), 1 cm into the top face
+    sb = scene_with([1.2, 0.04, 0.04])
+    top = 2.0 + 2 * 0.0695
+    f, k = force_on_crate(*sb, pos=[0.3, 0.1, top + 0.02 - 0.01])
+    assert f[2] == pytest.approx(0.5 * k * 0.01, rel=1e-5) and np.abs(f[0:2]).max() < 1e-6 * k * 0.01, (f, k * 0.01)
+    f_old, _ = force_on_crate(*sb, pos=[0.3, 0.1, top + 0.02 - 0.01], law="points")
+    assert np.abs(f_old).max() == 0.0, f_old
+    # (iii) the crate of (i) turned 45 degrees about the vertical, the vertical edge that points at the chassis 1 cm off the
+    # chassis' front-right vertical edge (0.275, -0.37), along the diagonal
+    c, s_ = np.cos(np.pi / 8), np.sin(np.pi / 8)
+    R = np.array([[np.cos(np.pi / 4), -np.sin(np.pi / 4)], [np.sin(np.pi / 4), np.cos(np.pi / 4)]])
+    corners = [R @ np.array([sx * 0.275, sy * 0.15]) for sx in (-1, 1) for sy in (-1, 1)]
+    inward = np.array([-1.0, 1.0]) / np.sqrt(2)                           # from outside the chassis' corner towards it
+    tip = max(corners, key=lambda v: float(v @ inward))                   # the crate's edge that points at the chassis
+    centre = np.array([0.275, -0.37]) - 0.01 * inward - tip
+    f, _ = force_on_crate(*sc, pos=[centre[0], centre[1], 2.0 + 0.0695], quat=(0.0, 0.0, s_, c))
+    assert np.abs(f).max() == 0.0, f
+    f_in, k = force_on_crate(*sc, pos=[centre[0] + 0.02 * inward[0], centre[1] + 0.02 * inward[1], 2.0 + 0.0695], quat=(0.0, 0.0, s_, c))
+    assert np.linalg.norm(f_in) > 0.2 * k * 0.01 and f_in @ np.array([inward[0], inward[1], 0.0]) < 0, f_in   # 1 cm inside: pushed back out
