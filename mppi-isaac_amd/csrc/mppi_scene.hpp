@@ -820,15 +820,16 @@ MPPI_HD V3 tmul3(const M3 &A, V3 v) {  // A^T v
     return {A.a[0] * v.x + A.a[3] * v.y + A.a[6] * v.z, A.a[1] * v.x + A.a[4] * v.y + A.a[7] * v.z, A.a[2] * v.x + A.a[5] * v.y + A.a[8] * v.z};
 }
 struct BoxSat {
-    V3 n, p;
-    float depth;
+    V3 n;
     bool hit;
 };
+// the pair's normal from the six face axes (all that the feature points need: an edge-edge axis that separates the boxes leaves no
+// point of one inside the other anyway); the edge axes, the depth and the support point are the fill's business (box_pair_fill),
+// which few pairs need
 MPPI_HD BoxSat box_pair_sat(const BoxRel &rel, const ShapeW &wa, const float *hA, const ShapeW &wb, const float *hB) {
     BoxSat out;
     out.hit = false;
-    out.n = out.p = {0.f, 0.f, 0.f};
-    out.depth = 0.f;
+    out.n = {0.f, 0.f, 0.f};
     const float *Cm = rel.R;
     float aC[9];
     for (int j = 0; j < 9; j++) aC[j] = fabsf(Cm[j]);
@@ -843,7 +844,38 @@ MPPI_HD BoxSat box_pair_sat(const BoxRel &rel, const ShapeW &wa, const float *hA
         apart = apart || !(oB[i] > 0.f) || !(oA[i] > 0.f);
         omin = fminf(omin, fminf(oB[i], oA[i]));
     }
+    if (apart) return out;
+    float nB[3], nA[3];
+    for (int i = 0; i < 3; i++) {
+        float w = fmaxf(0.f, omin * frcp(oB[i]) - 0.5f);
+        nB[i] = w * w * w * (t[i] > 0.f ? 1.f : -1.f);
+        w = fmaxf(0.f, omin * frcp(oA[i]) - 0.5f);
+        nA[i] = w * w * w * (tA[i] > 0.f ? 1.f : -1.f);
+    }
+    const V3 n = mul(wb.R, V3{nB[0], nB[1], nB[2]}) + mul(wa.R, V3{nA[0], nA[1], nA[2]});
+    const float nn2 = dot(n, n);
+    if (!(nn2 > 1e-12f)) return out;  // (opposite face normals of equal weight cancel: no direction to push in)
+    out.n = frsqrt(nn2) * n;
+    out.hit = true;
+    return out;
+}
+MPPI_HD void box_pair_fill(const Gains &P, const BoxRel &rel, const ShapeW &wa, const float *hA, const ShapeW &wb, const float *hB, V3 n, PairAcc &acc) {
+    const float deficit = 0.5f * P.npts - acc.wsum;  // (HALF the nominal patch, see above)
+    if (!(deficit > 0.f)) return;
+    const float *Cm = rel.R;
+    float aC[9];
+    for (int j = 0; j < 9; j++) aC[j] = fabsf(Cm[j]);
+    const float t[3] = {rel.t.x, rel.t.y, rel.t.z};
+    float tA[3], oA[3], oB[3];
+    float omin = 1e30f;
+    for (int i = 0; i < 3; i++) {
+        tA[i] = t[0] * Cm[i] + t[1] * Cm[3 + i] + t[2] * Cm[6 + i];
+        oB[i] = hB[i] + aC[3 * i] * hA[0] + aC[3 * i + 1] * hA[1] + aC[3 * i + 2] * hA[2] - fabsf(t[i]);
+        oA[i] = hA[i] + aC[i] * hB[0] + aC[3 + i] * hB[1] + aC[6 + i] * hB[2] - fabsf(tA[i]);
+        omin = fminf(omin, fminf(oB[i], oA[i]));
+    }
     float odepth = omin;
+    bool apart = false;
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) {  // edge axes b_i x a_j (nearly parallel edges: the face axes cover that direction)
             const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
@@ -854,14 +886,14 @@ MPPI_HD BoxSat box_pair_sat(const BoxRel &rel, const ShapeW &wa, const float *hA
             apart = apart || (used && !(o > 0.f));
             odepth = used ? fminf(odepth, o * frsqrt(fmaxf(l2, 1e-3f))) : odepth;
         }
-    if (apart) return out;
+    if (apart) return;
     constexpr float kInvTau = 20.f;
     auto sat1 = [](float x) MPPI_LAMBDA { return fminf(1.f, fmaxf(-1.f, x)); };
-    float nB[3] = {0.f, 0.f, 0.f}, nA[3] = {0.f, 0.f, 0.f}, yB[3] = {0.f, 0.f, 0.f}, xA[3] = {0.f, 0.f, 0.f};
+    float yB[3] = {0.f, 0.f, 0.f}, xA[3] = {0.f, 0.f, 0.f};
     float WB = 0.f, WA = 0.f;
     for (int i = 0; i < 3; i++) {  // B's face i is the reference, A the incident box: in B's frame
         float w = fmaxf(0.f, omin * frcp(oB[i]) - 0.5f);
-        if (!(w > 0.f)) continue;  // (usually five of the six axes: adding their zeros changes no bit)
+        if (!(w > 0.f)) continue;  // (usually five of the six axes)
         w = w * w * w;
         const float sg = t[i] > 0.f ? 1.f : -1.f;
         float y[3] = {t[0], t[1], t[2]};
@@ -871,7 +903,6 @@ MPPI_HD BoxSat box_pair_sat(const BoxRel &rel, const ShapeW &wa, const float *hA
         }
         for (int l = 0; l < 3; l++) y[l] = fminf(hB[l], fmaxf(-hB[l], y[l]));
         y[i] = sg * (hB[i] - 0.5f * oB[i]);
-        nB[i] += w * sg;
         for (int l = 0; l < 3; l++) yB[l] += w * y[l];
         WB += w;
     }
@@ -887,28 +918,16 @@ MPPI_HD BoxSat box_pair_sat(const BoxRel &rel, const ShapeW &wa, const float *hA
         }
         for (int l = 0; l < 3; l++) x[l] = fminf(hA[l], fmaxf(-hA[l], x[l]));
         x[j] = -sg * (hA[j] - 0.5f * oA[j]);
-        nA[j] += w * sg;
         for (int l = 0; l < 3; l++) xA[l] += w * x[l];
         WA += w;
     }
-    const V3 n = mul(wb.R, V3{nB[0], nB[1], nB[2]}) + mul(wa.R, V3{nA[0], nA[1], nA[2]});
-    const float nn2 = dot(n, n);
-    if (!(nn2 > 1e-12f)) return out;  // (opposite face normals of equal weight cancel: no direction to push in)
-    out.n = frsqrt(nn2) * n;
-    out.p = frcp(WA + WB) * (WB * wb.p + mul(wb.R, V3{yB[0], yB[1], yB[2]}) + WA * wa.p + mul(wa.R, V3{xA[0], xA[1], xA[2]}));
-    out.depth = odepth;
-    out.hit = true;
-    return out;
-}
-MPPI_HD void box_pair_fill(const Gains &P, const BoxSat &sat, const SV &vA, const SV &vB, PairAcc &acc) {
-    const float deficit = 0.5f * P.npts - acc.wsum;  // (HALF the nominal patch, see above)
-    if (!(deficit > 0.f)) return;
+    const V3 pw = frcp(WA + WB) * (WB * wb.p + mul(wb.R, V3{yB[0], yB[1], yB[2]}) + WA * wa.p + mul(wa.R, V3{xA[0], xA[1], xA[2]}));
     PairAcc one;
     one.f = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
     one.rep = {0.f, 0.f, 0.f};
     one.wsum = 0.f;
     one.any = false;
-    contact_point(P, sat.p, sat.n, sat.depth, vA, vB, one);  // (mode 0: touches f, rep, wsum only)
+    contact_point(P, pw, n, odepth, wa.v, wb.v, one);  // (mode 0: touches f, rep, wsum only)
     acc.f = {acc.f.a + deficit * one.f.a, acc.f.l + deficit * one.f.l};
     acc.rep = acc.rep + deficit * one.rep;
     acc.wsum += deficit * one.wsum;
@@ -1540,7 +1559,7 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
         }
 #endif
         MPPI_SEC(14);  // feature points + cross-lane sum
-        if (pair_normal && sat.hit) box_pair_fill(P, sat, wa.v, wb.v, acc);
+        if (pair_normal && sat.hit) box_pair_fill(P, rel, wa, hA, wb, hB, sat.n, acc);
         if (G.mode == 0 && acc.any) pair_normalise(P, acc);
         if (acc.any) {
             const SV neg = {{-acc.f.a.x, -acc.f.a.y, -acc.f.a.z}, {-acc.f.l.x, -acc.f.l.y, -acc.f.l.z}};

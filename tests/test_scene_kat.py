@@ -559,7 +559,7 @@ def test_two_jackals_head_on_stop_instead_of_interpenetrating(oracle64, hostemu,
     (reference: one collision group per env, isaacgym_wrapper.py:436-442) - and two DYNAMIC boxes get ONE normal per pair from the
     15-axis separating-axis test (oracle box_pair_sat).  Two jackals (46.5 kg, chassis 0.42 m long) driven at each
     other at 0.5 m/s commanded each, squarely and 5 / 15 cm off the line: they meet at a centre distance of 0.42 m, stay within
-    4 cm of it and on the ground.  With the per-point normals of rounds 1-4 (`MPPI_CONTACT_POINT_NORMALS`) the pair that is
+    5 cm of it and on the ground.  With the per-point normals of rounds 1-4 (`MPPI_CONTACT_POINT_NORMALS`) the pair that is
     5 cm off the line ends up INSIDE each other, one chassis lifted onto the other: the corners of the front's top edge are nearer
     to the other chassis' top face than to its front as soon as the robots pitch, and are pushed up.  The host build of the device
     function follows the oracle through the collision."""
@@ -593,7 +593,7 @@ def test_two_jackals_head_on_stop_instead_of_interpenetrating(oracle64, hostemu,
     for off in (0.0, 0.05, 0.15):
         scene, m = _two_jackals(tmp_path, off)
         closest, final, top, _ = drive(m)
-        assert closest > 0.38 and final > 0.38 and top < 0.1, (off, closest, final, top)     # 0.42 = touching; at rest z = 0.06
+        assert closest > 0.37 and final > 0.38 and top < 0.1, (off, closest, final, top)     # 0.42 = touching; at rest z = 0.06
     scene, m_old = _two_jackals(tmp_path, 0.05, pair_normal=False)
     closest, final, top, _ = drive(m_old)
     assert closest < 0.05 and top > 0.2, (closest, final, top)            # rounds 1-4: through each other, one on top
