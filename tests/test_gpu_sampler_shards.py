@@ -582,3 +582,67 @@ def test_update_lambda_adapts_the_temperature_between_commands(lib):
     assert any(10.0 <= e <= 20.0 for _, e in seen[1:]) or seen[-1][1] < seen[0][1]
     assert lib.mppi_set_lambda(pl.sim._ctx, C.c_double(0.0)) == capi.MPPI_EINVAL
     pl.sim.stop_sim()
+
+
+def test_two_jackals_meet_inside_the_rollouts(lib, oracle64, tmp_path):
+    """round 5: the moving-base robots of an env meet each other (chassis against chassis, one normal per pair from the
+    separating-axis test: DESIGN.md 3).  Two jackals 0.75 m apart, facing each other, nominal plan "both full ahead": the chassis
+    meet within the first steps of most of the 256 rollouts - the one-lane scene kernels (the forest's kernels) against the fp64
+    oracle on every sample, and against the same rollouts with the pair taken out (the robots would pass through each other)."""
+    import yaml
+    from mppiisaac.planner.isaacgym_wrapper import Scene
+    from mppiisaac.planner.mppi import make_config
+    from mppiisaac.utils.config_store import load_config
+    from mppiisaac.utils.isaacgym_utils import load_actor_cfgs, load_asset
+    from test_gpu_parity import Ctx
+    from test_host_logic import JACKAL
+    paths = []
+    for k in (1, 2):
+        p = tmp_path / f"jackal{k}.yaml"
+        p.write_text(yaml.safe_dump({**JACKAL, "name": f"jackal{k}"}))
+        paths.append(str(p))
+    K, H = 256, 20
+    ex = load_config({"defaults": [{"mppi": "multi-jackal"}, {"isaacgym": "normal"}]}, overrides={"mppi.num_samples": K, "mppi.horizon": H})
+    env = load_actor_cfgs(paths + ["goal"])
+    env[0].init_pos, env[1].init_pos = [0.0, 0.0, 0.06], [0.75, 0.04, 0.06]
+    env[1].init_ori = [0.0, 0.0, 1.0, 0.0]
+    scene = Scene(env, ex.isaacgym, [load_asset(env[0]), load_asset(env[1])])
+    m = scene.to_c()
+    assert sum(1 for i in range(m.n_pairs) if m.pairs[i].b >= 0) == 1
+    cfg = make_config(ex.mppi, viz_link=scene.viz_link_index())
+    cost = capi.Cost()
+    cost.kind, cost.n_terms = capi.COST_PROGRAM, 3
+    for j, (name, tgt) in enumerate((("jackal1", (2.0, 0.0)), ("jackal2", (-1.5, 0.0)))):
+        t = cost.terms[j]
+        t.op, t.n, t.w = capi.OP_DIST, 2, 1.0
+        t.src[0], t.idx[0] = capi.SRC_ACTOR, scene.actor_index(name)
+        t.src[1] = capi.SRC_CONST
+        t.p[0], t.p[1], t.p[2] = tgt[0], tgt[1], 0.0
+    t = cost.terms[2]
+    t.op, t.n, t.w = capi.OP_FORCE_L1, 3, 0.001
+    t.src[0], t.idx[0] = capi.SRC_RB, scene.rigid_body_index("jackal1", "chassis_link")
+    dof, root = scene.initial_state()
+    c = Ctx(m, cfg, cost)
+    info = C.create_string_buffer(512)
+    c.call("mppi_kernel_info", info, C.c_int(512))
+    assert "rollout=scene " in info.value.decode(), info.value
+    c.call("mppi_sample", C.c_uint32(0)); c.set_state(dof, root)
+    U = np.zeros((H, cfg.nu), np.float32)
+    U[:, 0], U[:, 2] = 0.6, 0.6
+    c.set_U(U); c.call("mppi_rollout")
+    S, eps = c.get("mppi_get_costs", (K,)), c.get("mppi_get_noise", (H, cfg.nu, K))
+    c.close()
+    So, _, _ = oracle64.rollout(m, cfg, cost, dof, root, U, eps)
+    m0 = scene.to_c()
+    for i in range(m0.n_pairs):
+        if m0.pairs[i].b >= 0:
+            m0.pairs[i] = m0.pairs[m0.n_pairs - 1]
+            m0.n_pairs -= 1
+            break
+    S_through, _, _ = oracle64.rollout(m0, cfg, cost, dof, root, U, eps)
+    rel = np.abs(S - So) / np.abs(So)
+    met = np.mean(np.abs(So - S_through) > 1e-3 * np.abs(S_through))
+    print(f"\ntwo jackals meeting, {K}x{H}: one-lane scene kernel vs fp64 oracle within 1e-4 {np.mean(rel <= 1e-4):.4f} 1e-3 {np.mean(rel <= 1e-3):.4f} 1e-2 {np.mean(rel <= 1e-2):.4f} "
+          f"max {rel.max():.1e}; the chassis meet in {met:.2f} of the rollouts")
+    assert np.isfinite(S).all() and met > 0.5
+    assert np.mean(rel <= 1e-3) >= 0.97 and np.mean(rel <= 1e-2) >= 0.99
