@@ -15,6 +15,7 @@ from __future__ import annotations
 import contextlib
 import ctypes
 import logging
+import math
 from dataclasses import dataclass, field
 from enum import Enum
 from typing import List, Optional
@@ -241,6 +242,22 @@ class Scene:
                     idx += 1
         return terms, idx
 
+    def substeps(self) -> int:
+        """integration steps per control interval: cfg.substeps, multiplied up in contact scenes until a step is no longer than
+        MAX_CONTACT_SUBSTEP (see there)"""
+        n = int(self.cfg.substeps)
+        h = float(self.cfg.dt) / n
+        if self.pairs and self.MAX_CONTACT_SUBSTEP > 0 and h > self.MAX_CONTACT_SUBSTEP * (1 + 1e-9):
+            k = int(math.ceil(h / self.MAX_CONTACT_SUBSTEP - 1e-9))
+            if "contact-substep" not in _REPORTED_DROPS:
+                _REPORTED_DROPS.add("contact-substep")
+                logging.getLogger("mppiisaac").warning(
+                    "known deviation from the reference: contact scene with dt / substeps = %.3f s: integrated with %d x %d substeps of %.4f s "
+                    "(the penalty contact carries a body within |g| h^2 / alpha of the surface: %.0f mm at the configured step, %.1f mm now)",
+                    h, n, k, h / k, 1e3 * abs(GRAVITY[2]) * h * h / self.CONTACT_ALPHA, 1e3 * abs(GRAVITY[2]) * (h / k) ** 2 / self.CONTACT_ALPHA)
+            n *= k
+        return n
+
     def _report_deviations(self):
         """behaviour that differs from what the reference's code literally does ("Known deviations"): said once
         per process and kind, like the pruned links of merge_robots"""
@@ -278,6 +295,12 @@ class Scene:
     # mppi_model_t.contact_flags).  Switches for measurements and for the known-answer tests of the laws before round 5
     ROBOT_ROBOT_PAIRS = _os.environ.get("MPPI_ROBOT_ROBOT_PAIRS", "1") != "0"
     BOX_PAIR_NORMAL = _os.environ.get("MPPI_BOX_PAIR_NORMAL", "1") != "0"
+    # The penalty contact's stiffness is tied to the integration step, k = alpha m / h^2 (what an explicit step of length h can carry):
+    # a body at rest sags |g| h^2 / alpha into what it rests on - 7.7 mm at the 25 ms of conf/isaacgym/normal.yaml, 12 CENTIMETRES at
+    # the 100 ms of conf/isaacgym/push.yaml (dt 0.1, substeps 1: fine for PhysX's implicit solver; here the block of heijn_push sank
+    # into the floor until the robot's bumper passed over it).  Contact scenes therefore never integrate with a longer step than
+    # this: the configured substeps are multiplied up (push.yaml: 1 -> 4), dt - what one control interval is - stays.  0 = off.
+    MAX_CONTACT_SUBSTEP = float(_os.environ.get("MPPI_MAX_CONTACT_SUBSTEP", "0.025"))
 
     def _contact_scene(self):
         """Collision primitives and candidate pairs of one env.
@@ -515,14 +538,15 @@ class Scene:
             m.pairs[i].a, m.pairs[i].b = a, b
         m.ground_friction = self.GROUND_FRICTION
         m.contact_alpha, m.contact_beta, m.friction_beta = self.CONTACT_ALPHA, self.CONTACT_BETA, self.FRICTION_BETA
-        hsub = float(self.cfg.dt) / int(self.cfg.substeps)
+        substeps = self.substeps()
+        hsub = float(self.cfg.dt) / substeps
         m.contact_flags = 0 if self.BOX_PAIR_NORMAL else capi.CONTACT_POINT_NORMALS
         m.contact_ramp_depth = (abs(GRAVITY[2]) * hsub * hsub / self.CONTACT_ALPHA) if self.CONTACT_RAMP_DEPTH is None else float(self.CONTACT_RAMP_DEPTH)
         m.randomize_seed = int(self.randomize_seed)
         if self.robot.dof_mode not in DRIVE_GAINS:
             raise ValueError("Invalid dof_mode")
         m.drive_mode, m.drive_kd, m.drive_kp = DRIVE_GAINS[self.robot.dof_mode]
-        m.substeps = int(self.cfg.substeps)
+        m.substeps = substeps
         m.dt = float(self.cfg.dt)
         for j in range(3):
             m.gravity[j] = GRAVITY[j]

@@ -666,3 +666,39 @@ def test_pair_normal_law_of_two_dynamic_boxes(oracle64):
     assert np.abs(f).max() == 0.0, f
     f_in, k = force_on_crate(*sc, pos=[centre[0] + 0.02 * inward[0], centre[1] + 0.02 * inward[1], 2.0 + 0.0695], quat=(0.0, 0.0, s_, c))
     assert np.linalg.norm(f_in) > 0.2 * k * 0.01 and f_in @ np.array([inward[0], inward[1], 0.0]) < 0, f_in   # 1 cm inside: pushed back out
+
+
+def test_contact_scenes_never_integrate_with_a_step_the_contact_cannot_carry(oracle64):
+    """conf/isaacgym/push.yaml (reference: dt 0.1, substeps 1 - heijn_push, anymal) asks for 100-ms steps.  The penalty contact's
+    stiffness is tied to the step, k = alpha m / h^2: a body at rest sags |g| h^2 / alpha into what it rests on - 12 cm at 100 ms,
+    the block of heijn_push sank into the floor until the robot's bumper passed over it (block 1.58 m from its goal after 1500
+    iterations; 0.51 m - against the obstacle that covers the goal - with the cap, `profiles/r05v_task_outcomes.txt`).  Contact
+    scenes multiply the configured substeps up until a step is at most 25 ms (Scene.substeps); dt stays."""
+    from mppiisaac.planner.isaacgym_wrapper import Scene
+    from mppiisaac.utils.config_store import load_config
+    from mppiisaac.utils.isaacgym_utils import load_actor_cfgs, load_asset
+    ig = load_config({"defaults": [{"isaacgym": "push"}]}).isaacgym
+    assert (ig.dt, ig.substeps) == (0.1, 1)
+    env = load_actor_cfgs(["heijn", "block", "paper_obst1", "paper_obst2", "goal"])
+    env[0].init_pos = [0.0, 1.5, 0.05]
+    scene = Scene(env, ig, load_asset(env[0]))
+    m = scene.to_c()
+    assert m.substeps == 4 and m.dt == pytest.approx(0.1) and m.contact_ramp_depth == pytest.approx(9.8 * 0.025 ** 2 / 0.8)
+    bi = scene.actor_index("block")
+    half = 0.5 * scene.env_cfg[bi].size[2]
+    res = {}
+    for cap in (Scene.MAX_CONTACT_SUBSTEP, 0.0):
+        old = Scene.MAX_CONTACT_SUBSTEP
+        try:
+            Scene.MAX_CONTACT_SUBSTEP = cap
+            mm = scene.to_c()
+        finally:
+            Scene.MAX_CONTACT_SUBSTEP = old
+        dof, root = scene.initial_state()
+        root, q, qd, _ = settle(oracle64, mm, root.astype(float), dof[0::2].astype(float), dof[1::2].astype(float), 40)
+        res[cap] = (mm.substeps, half - root[bi, 2])
+    assert res[Scene.MAX_CONTACT_SUBSTEP][0] == 4 and 0.004 < res[Scene.MAX_CONTACT_SUBSTEP][1] < 0.012, res      # sag |g| h^2 / alpha = 7.7 mm
+    assert res[0.0][0] == 1 and res[0.0][1] > 0.1, res                                                             # 12 cm at the configured step
+    # a contact-free scene keeps its configured steps (the golden fixtures of the contact-free paths were made with them)
+    arm = load_actor_cfgs(["panda", "goal"])
+    assert Scene(arm, ig, load_asset(arm[0])).to_c().substeps == 1
