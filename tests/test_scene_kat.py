@@ -695,7 +695,7 @@ def test_contact_scenes_never_integrate_with_a_step_the_contact_cannot_carry(ora
         finally:
             Scene.MAX_CONTACT_SUBSTEP = old
         dof, root = scene.initial_state()
-        root, q, qd, _ = settle(oracle64, mm, root.astype(float), dof[0::2].astype(float), dof[1::2].astype(float), 40)
+        root, q, qd, _ = settle(oracle64, mm, root.astype(float), dof[0::2].astype(float), dof[1::2].astype(float), 40, u=(0.0,) * scene.nu)
         res[cap] = (mm.substeps, half - root[bi, 2])
     assert res[Scene.MAX_CONTACT_SUBSTEP][0] == 4 and 0.004 < res[Scene.MAX_CONTACT_SUBSTEP][1] < 0.012, res      # sag |g| h^2 / alpha = 7.7 mm
     assert res[0.0][0] == 1 and res[0.0][1] > 0.1, res                                                             # 12 cm at the configured step
