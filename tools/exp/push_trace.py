@@ -23,6 +23,6 @@ def hook(i, sim):
                 r = rs[names.index(n)]
                 out.append(f"{n} ({r[0]:.3f}, {r[1]:.3f}, z {r[2]:.3f}, yaw {yaw(r[3:7]):.2f})")
         cf = sim.get_actor_contact_forces_by_name("block", "box")[0].cpu().numpy() if "block" in names else None
-        print(f"  it {i:4d}: " + "; ".join(out) + f"; dof q {np.round(dofs[0::2][:4], 2)}; force on block {np.round(cf, 1) if cf is not None else ''}")
+        print(f"  it {i:4d}: " + "; ".join(out) + f"; dof q {np.round(dofs[0::2], 2)}; force on block {np.round(cf, 1) if cf is not None else ''}")
 first, last, rate = run.run_world(name, cfg, planner, steps, report=False, hook=hook)
 print(f"{name}: stage cost {first:.3f} -> {last:.3f}, {rate:.0f} Hz")
