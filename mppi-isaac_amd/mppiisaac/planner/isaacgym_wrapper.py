@@ -369,11 +369,12 @@ class Scene:
                     continue
                 kinds = {si["type"], sj["type"]}
                 if si["actor"] == sj["actor"]:
-                    # the links of ONE robot never meet (the reference's self-collision filter, isaacgym_wrapper.py:441).  Two
-                    # MOVING-base robots of an env do (round 5; one collision group per env): their boxes and spheres against each
-                    # other - chassis against chassis; a wheel reaches the other robot's chassis only after its own chassis has
-                    # (the wheels of the jackal, the boxer, the heijn sit inside the chassis' outline lengthwise), left out
-                    if not (robot_i and si.get("owner") != sj.get("owner") and not si["fixed"] and not sj["fixed"]):
+                    # the links of ONE robot never meet (the reference's self-collision filter, isaacgym_wrapper.py:441).  The
+                    # robots of an env do (round 5; one collision group per env) - moving bases and the moving links of fixed-base
+                    # robots alike: their boxes and spheres against each other - chassis against chassis; a wheel reaches the
+                    # other robot's chassis only after its own chassis has (the wheels of the jackal, the boxer, the heijn sit
+                    # inside the chassis' outline lengthwise), left out
+                    if not (robot_i and si.get("owner") != sj.get("owner")):
                         continue
                     if capi.SHAPE_DISC in kinds or not self.ROBOT_ROBOT_PAIRS:
                         self.dropped_pairs.append((f'{self.env_cfg[si["owner"]].name}:{si["link"]}', f'{self.env_cfg[sj["owner"]].name}:{sj["link"]}'))

@@ -675,3 +675,57 @@ def test_two_jackals_meet_inside_the_rollouts(lib, oracle64, tmp_path):
           f"max {rel.max():.1e}; the chassis meet in {met:.2f} of the rollouts")
     assert np.isfinite(S).all() and met > 0.5
     assert np.mean(rel <= 1e-3) >= 0.97 and np.mean(rel <= 1e-2) >= 0.99
+
+
+def test_two_point_robots_meet_inside_the_rollouts(lib, oracle64, tmp_path):
+    """round 5: the robots of an env meet each other - FIXED-base robots too (reference conf/mppi/multi-pointbot.yaml: two point
+    robots; one collision group per env, isaacgym_wrapper.py:436-442): the moving links of different robots form candidate pairs
+    (the point robot's base cylinder is a box here: 0.4 m across).  Two point robots 0.6 m apart with the nominal plan "at each
+    other": the bodies meet in most of the 512 rollouts - shared-lane contact-scene kernels of the six-body forest against the fp64
+    oracle on every sample, and against the same rollouts with the pairs taken out (the robots pass through each other)."""
+    import yaml
+    from mppiisaac.planner.isaacgym_wrapper import Scene
+    from mppiisaac.planner.mppi import make_config
+    from mppiisaac.utils.config_store import load_config
+    from mppiisaac.utils.isaacgym_utils import load_actor_cfgs, load_asset
+    from test_gpu_parity import Ctx
+    second = tmp_path / "point_robot2.yaml"
+    second.write_text(yaml.safe_dump({"type": "robot", "name": "point_robot2", "fixed": True, "urdf_file": "point_robot.urdf"}))
+    K, H = 512, 20
+    ex = load_config({"defaults": [{"mppi": "multi-pointbot"}, {"isaacgym": "normal"}]}, overrides={"mppi.num_samples": K, "mppi.horizon": H, "mppi.use_priors": False})
+    env = load_actor_cfgs(["point_robot", str(second), "goal"])
+    env[0].init_pos, env[1].init_pos = [0.0, 0.0, 0.05], [0.6, 0.05, 0.05]
+    scene = Scene(env, ex.isaacgym, [load_asset(env[0]), load_asset(env[1])])
+    m = scene.to_c()
+    cross = [(scene.shapes[m.pairs[i].a]["link"], scene.shapes[m.pairs[i].b]["link"]) for i in range(m.n_pairs)]
+    assert ("base_link", "base_link") in cross and all(scene.shapes[m.pairs[i].a]["owner"] != scene.shapes[m.pairs[i].b]["owner"] for i in range(m.n_pairs)), cross
+    cfg = make_config(ex.mppi, viz_link=scene.viz_link_index())
+    cost = capi.Cost()
+    cost.kind, cost.n_terms = capi.COST_PROGRAM, 2
+    for j, (name, tgt) in enumerate((("point_robot", (1.5, 0.0)), ("point_robot2", (-1.0, 0.0)))):
+        t = cost.terms[j]
+        t.op, t.n, t.w = capi.OP_DIST, 2, 1.0
+        t.src[0], t.idx[0] = capi.SRC_RB, scene.rigid_body_index(name, "base_link")
+        t.src[1] = capi.SRC_CONST
+        t.p[0], t.p[1], t.p[2] = tgt[0], tgt[1], 0.0
+    dof, root = scene.initial_state()
+    c = Ctx(m, cfg, cost)
+    info = C.create_string_buffer(512)
+    c.call("mppi_kernel_info", info, C.c_int(512))
+    assert "rollout=scene" in info.value.decode() and "topology=[-1,0,1,-1,3,4]" in info.value.decode(), info.value
+    c.call("mppi_sample", C.c_uint32(0)); c.set_state(dof, root)
+    U = np.zeros((H, cfg.nu), np.float32)
+    U[:, 0], U[:, 3] = 0.4, -0.4
+    c.set_U(U); c.call("mppi_rollout")
+    S, eps = c.get("mppi_get_costs", (K,)), c.get("mppi_get_noise", (H, cfg.nu, K))
+    c.close()
+    So, _, _ = oracle64.rollout(m, cfg, cost, dof, root, U, eps)
+    m0 = scene.to_c()
+    m0.n_pairs = 0
+    S_through, _, _ = oracle64.rollout(m0, cfg, cost, dof, root, U, eps)
+    rel = np.abs(S - So) / np.abs(So)
+    met = np.mean(np.abs(So - S_through) > 1e-3 * np.abs(S_through))
+    print(f"\ntwo point robots meeting, {K}x{H}: contact-scene kernel vs fp64 oracle within 1e-4 {np.mean(rel <= 1e-4):.4f} 1e-3 {np.mean(rel <= 1e-3):.4f} 1e-2 {np.mean(rel <= 1e-2):.4f} "
+          f"max {rel.max():.1e}; the robots meet in {met:.2f} of the rollouts")
+    assert np.isfinite(S).all() and met > 0.3
+    assert np.mean(rel <= 1e-3) >= 0.97 and np.mean(rel <= 1e-2) >= 0.99

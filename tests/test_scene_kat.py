@@ -702,3 +702,31 @@ def test_contact_scenes_never_integrate_with_a_step_the_contact_cannot_carry(ora
     # a contact-free scene keeps its configured steps (the golden fixtures of the contact-free paths were made with them)
     arm = load_actor_cfgs(["panda", "goal"])
     assert Scene(arm, ig, load_asset(arm[0])).to_c().substeps == 1
+
+
+def test_two_fixed_base_robots_of_an_env_meet_each_other(oracle64, tmp_path):
+    """round 5: the moving links of different FIXED-base robots form candidate pairs too (reference conf/mppi/multi-pointbot.yaml, one
+    collision group per env).  Two point robots (base cylinder as a box 0.4 m across, joints x / y / yaw of one forest) commanded at
+    each other at 0.5 m/s stop 0.4 m apart - 4 mm into the penalty layer - instead of passing through each other."""
+    import yaml
+    from mppiisaac.planner.isaacgym_wrapper import Scene
+    from mppiisaac.utils.config_store import load_config
+    from mppiisaac.utils.isaacgym_utils import load_actor_cfgs, load_asset
+    second = tmp_path / "point_robot2.yaml"
+    second.write_text(yaml.safe_dump({"type": "robot", "name": "point_robot2", "fixed": True, "urdf_file": "point_robot.urdf"}))
+    ig = load_config({"defaults": [{"isaacgym": "normal"}]}).isaacgym
+    for off in (0.0, 0.1):
+        env = load_actor_cfgs(["point_robot", str(second), "goal"])
+        env[0].init_pos, env[1].init_pos = [0.0, 0.0, 0.05], [1.0, off, 0.05]
+        scene = Scene(env, ig, [load_asset(env[0]), load_asset(env[1])])
+        m = scene.to_c()
+        assert m.n_pairs == 4 and all(scene.shapes[m.pairs[i].a]["owner"] != scene.shapes[m.pairs[i].b]["owner"] for i in range(4))
+        dof, root = scene.initial_state()
+        ro, q, qd = root.astype(float), dof[0::2].astype(float), dof[1::2].astype(float)
+        gap = []
+        for _ in range(80):
+            ro, q, qd, cf = oracle64.scene_step(m, ro, q, qd, oracle64.cmd_map(m, np.array([0.5, 0.0, 0.0, -0.5, 0.0, 0.0])))
+            gap.append((1.0 + q[3]) - q[0])
+        assert 0.38 < min(gap) and 0.39 < gap[-1] < 0.4005, (off, min(gap), gap[-1])
+        f1, f2 = cf[scene.rigid_body_index("point_robot", "base_link")], cf[scene.rigid_body_index("point_robot2", "base_link")]
+        assert f1[0] < -1.0 and np.allclose(f1, -f2, atol=1e-9), (f1, f2)      # pushed apart, equal and opposite
