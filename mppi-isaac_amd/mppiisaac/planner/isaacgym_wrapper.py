@@ -308,7 +308,9 @@ class Scene:
         Robot links contribute their URDF <collision> geometry (meshes as their AABB box, thin cylinders
         as discs); box/sphere actors their own shape (reference isaacgym_utils.py:26-52).  Pairs follow the
         reference's collision filter: same env only, both actors `collision: true`
-        (isaacgym_wrapper.py:441), no robot self-collision; wheels/casters collide with the ground only."""
+        (isaacgym_wrapper.py:441), no self-collision of one robot; the robots of an env meet each other (boxes and spheres of their
+        moving links); wheels / casters meet the ground and the boxes and spheres of OTHER actors, not other wheels or other robots
+        (those candidates are listed in `dropped_pairs`)."""
         shapes = []
         self.dropped_pairs = []  # (shape, shape) candidates the contact model leaves out on purpose
         self.dropped_pair_shapes = []  # the same candidates as indices into the shape list (tests measure their clearance)
