@@ -730,6 +730,16 @@ def main():
         outcome = {"final_block_to_goal_m": float(np.linalg.norm((pos(o.block) - pos(o.goal))[:nd])),
                    "final_ee_to_block_m": float(np.linalg.norm((ee - pos(o.block))[:nd])),
                    "iterations": args.steps + args.warmup, "dims": nd}
+        if args.workload == "boxer_push":
+            # the goal of the reference's pushing examples sits INSIDE the footprint of paper_obst1 (both at (1, 1): reference
+            # examples/boxer_push/config_boxer_push.yaml, conf/actors/paper_obst1.yaml): the block is done when it rests against that
+            # obstacle - the distance it can reach is the obstacle's and its own half extent, not zero (tools/task_outcomes.py)
+            obst = next((a for a in world.scene.env_cfg if a.name == o.obstacles[0]), None)
+            blk = next((a for a in world.scene.env_cfg if a.name == o.block), None)
+            d = pos(o.goal)[:2] - pos(o.obstacles[0])[:2]
+            if obst is not None and blk is not None and abs(d[0]) < 0.5 * obst.size[0] and abs(d[1]) < 0.5 * obst.size[1]:
+                outcome["goal_is_inside_the_footprint_of"] = o.obstacles[0]
+                outcome["closest_the_block_can_get_m"] = float(0.5 * min(obst.size[0], obst.size[1]) + 0.5 * min(blk.size[0], blk.size[1]))
     # the loop a user of the reference runs (MPPIisaacPlanner.compute_action_tensor with torch.save blobs, a K = 1 world stepped from
     # Python): with the example's Objective fused, and with a reference-style Python compute_cost (generic mode)
     facade = None
