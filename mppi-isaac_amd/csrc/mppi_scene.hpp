@@ -827,31 +827,43 @@ struct BoxSat {
 // the pair's normal from the six face axes (all that the feature points need: an edge-edge axis that separates the boxes leaves no
 // point of one inside the other anyway); the edge axes, the depth and the support point are the fill's business (box_pair_fill),
 // which few pairs need
+// the six face-axis overlaps of two boxes (o > 0 on every axis: no face axis separates them) and what they are made from
+struct BoxOverlaps {
+    float aC[9];   // |b_i . a_j|
+    float t[3];    // centre of A in B's frame
+    float tA[3];   // a_j . (pA - pB)
+    float oA[3], oB[3];
+    float omin;
+    bool apart;
+};
+MPPI_HD BoxOverlaps box_overlaps(const BoxRel &rel, const float *hA, const float *hB) {
+    BoxOverlaps v;
+    const float *Cm = rel.R;
+    for (int j = 0; j < 9; j++) v.aC[j] = fabsf(Cm[j]);
+    v.t[0] = rel.t.x; v.t[1] = rel.t.y; v.t[2] = rel.t.z;
+    v.omin = 1e30f;
+    v.apart = false;
+    for (int i = 0; i < 3; i++) {
+        v.tA[i] = v.t[0] * Cm[i] + v.t[1] * Cm[3 + i] + v.t[2] * Cm[6 + i];
+        v.oB[i] = hB[i] + v.aC[3 * i] * hA[0] + v.aC[3 * i + 1] * hA[1] + v.aC[3 * i + 2] * hA[2] - fabsf(v.t[i]);
+        v.oA[i] = hA[i] + v.aC[i] * hB[0] + v.aC[3 + i] * hB[1] + v.aC[6 + i] * hB[2] - fabsf(v.tA[i]);
+        v.apart = v.apart || !(v.oB[i] > 0.f) || !(v.oA[i] > 0.f);
+        v.omin = fminf(v.omin, fminf(v.oB[i], v.oA[i]));
+    }
+    return v;
+}
 MPPI_HD BoxSat box_pair_sat(const BoxRel &rel, const ShapeW &wa, const float *hA, const ShapeW &wb, const float *hB) {
     BoxSat out;
     out.hit = false;
     out.n = {0.f, 0.f, 0.f};
-    const float *Cm = rel.R;
-    float aC[9];
-    for (int j = 0; j < 9; j++) aC[j] = fabsf(Cm[j]);
-    const float t[3] = {rel.t.x, rel.t.y, rel.t.z};
-    float tA[3], oA[3], oB[3];
-    float omin = 1e30f;
-    bool apart = false;
-    for (int i = 0; i < 3; i++) {
-        tA[i] = t[0] * Cm[i] + t[1] * Cm[3 + i] + t[2] * Cm[6 + i];
-        oB[i] = hB[i] + aC[3 * i] * hA[0] + aC[3 * i + 1] * hA[1] + aC[3 * i + 2] * hA[2] - fabsf(t[i]);
-        oA[i] = hA[i] + aC[i] * hB[0] + aC[3 + i] * hB[1] + aC[6 + i] * hB[2] - fabsf(tA[i]);
-        apart = apart || !(oB[i] > 0.f) || !(oA[i] > 0.f);
-        omin = fminf(omin, fminf(oB[i], oA[i]));
-    }
-    if (apart) return out;
+    const BoxOverlaps v = box_overlaps(rel, hA, hB);
+    if (v.apart) return out;
     float nB[3], nA[3];
     for (int i = 0; i < 3; i++) {
-        float w = fmaxf(0.f, omin * frcp(oB[i]) - 0.5f);
-        nB[i] = w * w * w * (t[i] > 0.f ? 1.f : -1.f);
-        w = fmaxf(0.f, omin * frcp(oA[i]) - 0.5f);
-        nA[i] = w * w * w * (tA[i] > 0.f ? 1.f : -1.f);
+        float w = fmaxf(0.f, v.omin * frcp(v.oB[i]) - 0.5f);
+        nB[i] = w * w * w * (v.t[i] > 0.f ? 1.f : -1.f);
+        w = fmaxf(0.f, v.omin * frcp(v.oA[i]) - 0.5f);
+        nA[i] = w * w * w * (v.tA[i] > 0.f ? 1.f : -1.f);
     }
     const V3 n = mul(wb.R, V3{nB[0], nB[1], nB[2]}) + mul(wa.R, V3{nA[0], nA[1], nA[2]});
     const float nn2 = dot(n, n);
@@ -864,17 +876,9 @@ MPPI_HD void box_pair_fill(const Gains &P, const BoxRel &rel, const ShapeW &wa, 
     const float deficit = 0.5f * P.npts - acc.wsum;  // (HALF the nominal patch, see above)
     if (!(deficit > 0.f)) return;
     const float *Cm = rel.R;
-    float aC[9];
-    for (int j = 0; j < 9; j++) aC[j] = fabsf(Cm[j]);
-    const float t[3] = {rel.t.x, rel.t.y, rel.t.z};
-    float tA[3], oA[3], oB[3];
-    float omin = 1e30f;
-    for (int i = 0; i < 3; i++) {
-        tA[i] = t[0] * Cm[i] + t[1] * Cm[3 + i] + t[2] * Cm[6 + i];
-        oB[i] = hB[i] + aC[3 * i] * hA[0] + aC[3 * i + 1] * hA[1] + aC[3 * i + 2] * hA[2] - fabsf(t[i]);
-        oA[i] = hA[i] + aC[i] * hB[0] + aC[3 + i] * hB[1] + aC[6 + i] * hB[2] - fabsf(tA[i]);
-        omin = fminf(omin, fminf(oB[i], oA[i]));
-    }
+    const BoxOverlaps v = box_overlaps(rel, hA, hB);
+    const float *aC = v.aC, *t = v.t, *tA = v.tA, *oA = v.oA, *oB = v.oB;
+    const float omin = v.omin;
     float odepth = omin;
     bool apart = false;
     for (int i = 0; i < 3; i++)
