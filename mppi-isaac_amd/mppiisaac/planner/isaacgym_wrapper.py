@@ -290,9 +290,9 @@ class Scene:
     # switch for measurements - MPPI_WHEEL_BOX_PAIRS=0 in the environment does the same)
     import os as _os
     WHEEL_BOX_PAIRS = _os.environ.get("MPPI_WHEEL_BOX_PAIRS", "1") != "0"
-    # round 5: the moving-base robots of one env meet each other (chassis against chassis); two dynamic boxes whose feature points
-    # under-sample the contact patch get the rest of the nominal stiffness from the separating-axis test (DESIGN.md 3,
-    # mppi_model_t.contact_flags).  Switches for measurements and for the known-answer tests of the laws before round 5
+    # round 5: the robots of one env meet each other (the boxes and spheres of their moving links: chassis against chassis); two
+    # dynamic boxes get ONE normal per pair from a separating-axis test (mppi_model_t.contact_flags).  Switches for
+    # measurements and for the known-answer tests of the laws before round 5
     ROBOT_ROBOT_PAIRS = _os.environ.get("MPPI_ROBOT_ROBOT_PAIRS", "1") != "0"
     BOX_PAIR_NORMAL = _os.environ.get("MPPI_BOX_PAIR_NORMAL", "1") != "0"
     # The penalty contact's stiffness is tied to the integration step, k = alpha m / h^2 (what an explicit step of length h can carry):
@@ -343,8 +343,8 @@ class Scene:
                             pc = pc + Rc @ (0.5 * (hi + lo))
                         else:
                             continue
-                        # (several robots form one articulated forest: their link shapes all belong to it - and do not collide
-                        # with each other, like the links of one robot)
+                        # (several robots form one articulated forest: their link shapes all belong to it; `owner` says whose
+                        # they are - the links of ONE robot do not meet, those of different robots do: pair filter below)
                         shapes.append(dict(actor=self.robot_idx, body=l["body"], type=kind, rb=self.first_rb[self.robot_idx] + li, size=size,
                                            R=Rl @ Rc, p=Rl @ pc + pl, friction=0.0 if l["name"] in casters else a.friction,
                                            fixed=bool(a.fixed), link=l["name"], R_in_link=Rc, p_in_link=pc, owner=ai))
@@ -373,9 +373,10 @@ class Scene:
                 if si["actor"] == sj["actor"]:
                     # the links of ONE robot never meet (the reference's self-collision filter, isaacgym_wrapper.py:441).  The
                     # robots of an env do (round 5; one collision group per env) - moving bases and the moving links of fixed-base
-                    # robots alike: their boxes and spheres against each other - chassis against chassis; a wheel reaches the
-                    # other robot's chassis only after its own chassis has (the wheels of the jackal, the boxer, the heijn sit
-                    # inside the chassis' outline lengthwise), left out
+                    # robots alike: their boxes and spheres against each other - chassis against chassis.  The WHEELS of one robot
+                    # against another robot are left out and listed: every further pair between the same two bodies adds a nominal
+                    # stiffness of its own to the explicit law ("several robots per env"; the jackal's tyres stand
+                    # 2 cm proud of its chassis: two jackals meet that much later than their tyres would)
                     if not (robot_i and si.get("owner") != sj.get("owner")):
                         continue
                     if capi.SHAPE_DISC in kinds or not self.ROBOT_ROBOT_PAIRS:
