@@ -165,7 +165,7 @@ struct DevModel {
     // and the broad-phase arithmetic, ~350 issue slots; the pushing scene has 15 robot-block / robot-obstacle pairs since the
     // wheels and casters meet boxes).  Conservative like the broad phase: a skipped pair is one the broad phase would have culled.
     int n_groups;
-    int face_fill;  // two dynamic boxes: one normal per pair from the separating-axis test (box_pair_sat); 0: the per-point law of ABI <= 7
+    int pair_normal;  // two dynamic boxes: one normal per pair from the separating-axis test (box_pair_sat); 0: the per-point law of ABI <= 7
     struct Group {
         int anchor, other;          // shapes whose cached centres are compared: a robot shape welded to base 0, the other actor's shape
         unsigned mask_lo, mask_hi;  // the group's pairs (0-31, 32-63)

@@ -1468,7 +1468,7 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
             if (has_b) wb.v = frame_velocity(L, entB);
         }
         // two dynamic boxes: one normal for the pair (box_pair_sat), unless the model asks for the law of ABI <= 7
-        const bool pair_normal = G.mode == 0 && has_b && typeA == 0 && typeB == 0 && m.face_fill != 0;
+        const bool pair_normal = G.mode == 0 && has_b && typeA == 0 && typeB == 0 && m.pair_normal != 0;
         BoxSat sat;
         sat.hit = false;
         if (pair_normal) sat = box_pair_sat(rel, wa, hA, wb, hB);
