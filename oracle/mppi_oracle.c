@@ -570,7 +570,7 @@ static void corners_in_box(int mode, real mu, real k, real cn, real ct, real kh,
  * edge are nearer to the other box's TOP face than to its front: they are pushed up, one chassis climbs the other and the two
  * end up inside each other.  Here (csrc/mppi_scene.hpp::box_pair_sat / box_points_along are the same arithmetic):
  *   - 15-axis separating-axis test; an axis that separates: no contact.  depth_sat = the smallest overlap;
- *   - n = blend of the six face axes with weights max(0, o_min / o_a - 1/2)^3 - a pure face normal unless two overlaps are
+ *   - n = blend of the six face axes with weights max(0, 2 - o_a / o_min)^3 - a pure face normal unless two overlaps are
  *     within a factor two of each other -, oriented from B to A;
  *   - every feature point inside the other box is pushed along n; its depth = the distance it has to travel along n to leave
  *     that box (ray exit: continuous in the point and in n);
@@ -615,7 +615,7 @@ static void box_pair_sat(const shape_w_t *A, const double *hA_, const shape_w_t 
     const real itau = 20;
     real nB[3] = {0, 0, 0}, nA[3] = {0, 0, 0}, yB[3] = {0, 0, 0}, xA[3] = {0, 0, 0}, WB = 0, WA = 0;
     for (int i = 0; i < 3; i++) {   /* B's face i is the reference, A the incident box: everything in B's frame */
-        real w = omin / oB[i] - (real)0.5;
+        real w = 2 - oB[i] / omin;
         w = w > 0 ? w * w * w : 0;
         const real sg = t[i] > 0 ? (real)1 : (real)-1;
         real y[3] = {t[0], t[1], t[2]};
@@ -630,7 +630,7 @@ static void box_pair_sat(const shape_w_t *A, const double *hA_, const shape_w_t 
         WB += w;
     }
     for (int j = 0; j < 3; j++) {   /* A's face j is the reference, B the incident box: everything in A's frame */
-        real w = omin / oA[j] - (real)0.5;
+        real w = 2 - oA[j] / omin;
         w = w > 0 ? w * w * w : 0;
         const real sg = tA[j] > 0 ? (real)1 : (real)-1;
         real x[3] = {-tA[0], -tA[1], -tA[2]};   /* centre of B in A's frame */
