@@ -53,6 +53,11 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
 def test_bench_other_workloads_and_the_sharded_code_path():
     d = run_bench("--workload", "boxer_push", "--no-cpu-baseline")
     assert "boxer_push" in d["metric"] and d["roofline"]["kernel"] == "k_rollout_scene_quad" and d["value"] > 10
+    # the contact workloads' lines carry their task outcome, and what the numbers mean: the goal of the pushing scene lies inside an
+    # obstacle's footprint (the block is done when it rests against it)
+    o = d["config"]["task_outcome"]
+    assert o["goal_is_inside_the_footprint_of"] == "paper_obst1" and 0.3 < o["closest_the_block_can_get_m"] < 0.6
+    assert 0.0 < o["final_block_to_goal_m"] < 2.0 and o["iterations"] > 0
     env = dict(os.environ, MPPI_BENCH_FORCE_DIST="1", MASTER_PORT="29547")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "60", "--warmup", "10", "--no-cpu-baseline"],
                          capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
