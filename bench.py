@@ -512,6 +512,13 @@ def facade_loop(wl_name, objective, device, steps, warmup, profile_to=None):
         with open(profile_to, "a") as f:
             f.write(f"==== {type(objective).__name__}: {1 / dt:.0f} Hz, {dt * 1e3:.4f} ms / iteration (un-profiled), cProfile of {steps} iterations\n")
             f.write(buf.getvalue())
+    # which path ran: the in-kernel cost kind the planner bound (a traced Objective says so), or generic mode
+    fc = planner.mppi._fused_cost
+    facade_loop.last_mode = ("generic (torch on the simulated horizon)" if fc is None else
+                             ("traced -> " if getattr(planner.mppi, "_trace_guard", None) is not None else "declared -> ") + f"in-kernel cost kind {fc.kind}")
+    # (the K = 1 wrapper registers host mirrors that hold it alive - stop it explicitly, `del` alone leaks the context)
+    world.stop_sim()
+    planner.sim.stop_sim()
     del planner, world
     return 1.0 / dt, dt * 1e3, dist
 
@@ -522,12 +529,21 @@ def facade_rows(wl_name, device):
     n, w = int(os.environ.get("MPPI_BENCH_FACADE_STEPS", "400")), 30
     prof = os.environ.get("MPPI_BENCH_FACADE_PROFILE")
     rows = {}
-    for key, obj in (("fused", getattr(objectives, WORKLOADS[wl_name]["objective"])(None)), ("generic", ReferenceStyleReach()),
-                     ("generic_graph_safe", ReferenceStyleReachGraphSafe())):
+    # `generic`: the reference-style Objective as the planner runs it by default since round 6 - traced once into a cost program
+    # (mppiisaac/trace.py), validated against the Python code on the first command and every 64th; `generic_untraced` /
+    # `generic_graph_safe`: the same Objective with MPPI_TRACE_OBJECTIVE=0 - torch evaluates it on the kernel-simulated horizon
+    for key, obj, traced in (("fused", getattr(objectives, WORKLOADS[wl_name]["objective"])(None), True), ("generic", ReferenceStyleReach(), True),
+                             ("generic_untraced", ReferenceStyleReach(), False), ("generic_graph_safe", ReferenceStyleReachGraphSafe(), False)):
         if key != "fused" and wl_name != "panda_reach":
             continue
-        hz, ms, dist = facade_loop(wl_name, obj, device, n, w, profile_to=prof)
-        rows[key] = {"value": hz, "ms_per_step": ms, "steps": n, "final_ee_to_goal_m": dist, "latency_ms": facade_loop.last_latency_ms}
+        if not traced:
+            os.environ["MPPI_TRACE_OBJECTIVE"] = "0"
+        try:
+            hz, ms, dist = facade_loop(wl_name, obj, device, n, w, profile_to=prof)
+        finally:
+            os.environ.pop("MPPI_TRACE_OBJECTIVE", None)
+        rows[key] = {"value": hz, "ms_per_step": ms, "steps": n, "final_ee_to_goal_m": dist, "latency_ms": facade_loop.last_latency_ms,
+                     "mode": facade_loop.last_mode}
     return rows
 
 
@@ -766,6 +782,7 @@ def main():
             "value_shipped_conf": shipped["value"] if shipped else None,
             "value_facade": facade["fused"]["value"] if facade else None,
             "value_generic_objective": facade["generic"]["value"] if facade and "generic" in facade else None,
+            "value_generic_objective_untraced": facade["generic_untraced"]["value"] if facade and "generic_untraced" in facade else None,
             "unit": f"Hz ({K}-sample x {H}-step control iterations per second, summed over GPUs)",
             "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
@@ -789,8 +806,10 @@ def main():
                        "facade": {"what": "the reference's own loop (examples/<x>/world.py:32-50): torch.save blobs through "
                                           "MPPIisaacPlanner.compute_action_tensor, K = 1 IsaacGymWrapper world stepped from Python with apply_robot_cmd + step; "
                                           "`fused`: the example's Objective as an in-kernel cost; `generic`: a reference-style Python compute_cost(sim) "
-                                          "(bench.py ReferenceStyleReach) evaluated by torch on the kernel-simulated horizon; `generic_graph_safe`: the same "
-                                          "Objective with the `graph_safe = True` opt-in",
+                                          "(bench.py ReferenceStyleReach, nothing declared) as the planner runs it by default - traced once into a cost program, "
+                                          "validated against the Python code on the first command and every 64th (the validations are inside the timed loop); "
+                                          "`generic_untraced`: the same Objective with MPPI_TRACE_OBJECTIVE=0, evaluated by torch on the kernel-simulated horizon "
+                                          "(what `generic` was until round 5); `generic_graph_safe`: that with the `graph_safe = True` opt-in",
                                   **facade} if facade else None,
                        "exchange_ms": exchange_ms,
                        "exchange": {"selected": loop.exchange, "why": loop.exchange_why, "exchange_ms": exchange_ms, "per_rank": reports} if sharded else None,

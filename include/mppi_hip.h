@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MPPI_ABI_VERSION 8
+#define MPPI_ABI_VERSION 9
 
 #define MPPI_MAX_BODIES 12   /* moving bodies (= DOF) of the articulated robot        */
 #define MPPI_MAX_LINKS 24    /* reported rigid bodies of the robot (URDF links)      */
@@ -42,6 +42,12 @@ extern "C" {
 #define MPPI_MAX_PAIRS 128   /* candidate contact pairs per env (one verdict bit per pair in four mask words; the ten-link arm
                               * among the reference's ten obstacle spheres - IsaacGymConfig.num_obstacles - has 100)        */
 #define MPPI_CONTACT_POINT_NORMALS 1
+#define MPPI_CONTACT_EXPLICIT_LIGHT 2   /* contact_flags bit 1, see mppi_model_t */
+/* ABI 9: a free actor of at most MPPI_LIGHT_BODY_MASS kg that is at least MPPI_LIGHT_BODY_RATIO times lighter than the robot whose link it
+ * touches is held IMPLICITLY (mppi_model_t.contact_flags); the ramp depth of such a pair is contact_ramp_depth / MPPI_LIGHT_RAMP_DIV */
+#define MPPI_LIGHT_BODY_MASS 0.25
+#define MPPI_LIGHT_BODY_RATIO 100
+#define MPPI_LIGHT_RAMP_DIV 16
 #define MPPI_MAX_FREE 4      /* free (non-fixed) box/sphere actors per env (the shipped kernels carry 2 slots; scenes with
                               * 3-4 free actors get their kernels built on demand, see mppi_create)          */
 #define MPPI_MAX_EXTRA_BASES 3 /* moving-base robots per env beyond the first (ABI 7)         */
@@ -216,7 +222,13 @@ typedef struct mppi_model {
     /* bit 0 (MPPI_CONTACT_POINT_NORMALS): two DYNAMIC boxes keep the law of ABI <= 7 - every feature point pushed towards the nearest
      * face of the other box.  Default (0): ONE normal per pair from the 15-axis separating-axis test, every point's depth measured
      * along it, and a patch its points under-sample (a lone corner, crossing edges) filled up to half the nominal stiffness by one
-     * contact of the separating-axis depth */
+     * contact of the separating-axis depth
+     * bit 1 (MPPI_CONTACT_EXPLICIT_LIGHT), ABI 9: a LIGHT free actor (MPPI_LIGHT_BODY_MASS, MPPI_LIGHT_BODY_RATIO) against a robot link keeps the
+     * explicit law of two dynamic bodies, whose stiffness alpha m / h^2 is what the lighter body can carry in an explicit step - 1.3 N/m
+     * for the 1-gram block of the reference's conf/actors/panda_pick_block.yaml: a gripper closes through it.  Default (0): such a pair
+     * is implicit on BOTH bodies with the robot's gains - the link sees the light body as a wall moving with its start-of-substep
+     * velocity, the light body is solved after the robot against the link's end-of-substep velocity (DESIGN.md 3 "light bodies") -
+     * what PhysX's implicit solver does for examples/panda_pick and examples/omni_panda_pick (isaacgym_wrapper.py:29-36) */
     int32_t contact_flags;
     /* ABI 7 - several MOVING-base robots in one env (reference isaacgym_wrapper.py:101-106,534-559, conf/mppi/multi-jackal.yaml).
      * The robots form one articulated forest (bodies, links and DOFs follow one another in env order, like the fixed-base

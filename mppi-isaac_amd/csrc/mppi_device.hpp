@@ -111,7 +111,8 @@ struct DevShape {
 // is fetched for the pairs that survive it.
 struct PairGeom {
     int a, b;        // shapes; b = -1: ground plane
-    int mode;        // 0: both dynamic (explicit penalty), 1: a dynamic / b static (implicit), 2: b dynamic / a static
+    int mode;        // 0: both dynamic (explicit penalty), 1: a dynamic / b static (implicit), 2: b dynamic / a static,
+                     // 3 / 4: both dynamic, b / a a LIGHT free actor held implicitly by the robot link a / b (mppi_scene.hpp)
     int rnd;         // a noisy actor takes part: size / friction / mass scale are per sample
     int typeA, typeB, entA, entB;  // MPPI_SHAPE_* (typeB = -1: ground), dynamic frame (-1: static)
     float hA[3], hB[3];            // nominal half extents | radius in [0]
@@ -143,7 +144,10 @@ struct DevModel {
     int all_revolute;  // every joint is revolute: the quad rollout runs its compile-time specialisation
     float base_hb[3], base_Ic[6];
     float kp;  // position drive stiffness (kDrivePosition; 0 otherwise)
-    float pad3[2];
+    // round 6: candidate pairs between a robot link and a free actor at least MPPI_LIGHT_BODY_RATIO times lighter than the robot
+    // (PairGeom::mode 3 / 4: implicit on both bodies, mppi_scene.hpp "light bodies"), and the free slots (bit f) such an actor sits in
+    int n_light_pairs;
+    unsigned light_free;
     int actor_first_rb[kMaxActors];
     int n_shapes, n_pairs, rnd_seed, n_rnd;
     int rnd_slot[kMaxActors];    // LDS slot of a noisy actor's per-sample draws (-1: nominal)

@@ -466,7 +466,9 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
         c->launch_eval_cost = e->eval_cost;
         if (c->scene) {
             c->lds_bytes = sizeof(float) * kWave * (e->scene_lds_floats + 3 * (size_t)c->hm.n_rb + 5 * (size_t)c->hm.n_rnd);
-            c->lds_bytes_quad = sizeof(float) * 16 * (e->scene_lds_floats + 3 * (size_t)c->hm.n_rb + 5 * (size_t)c->hm.n_rnd + 12 * (size_t)c->hm.n_shapes);
+            // (+ the records of the light bodies' pairs, mppi_scene.hpp scene_row_floats; the one-lane kernels keep them per lane)
+            c->lds_bytes_quad = sizeof(float) * 16 * (e->scene_lds_floats + 3 * (size_t)c->hm.n_rb + 5 * (size_t)c->hm.n_rnd + 12 * (size_t)c->hm.n_shapes +
+                                                      (c->hm.n_light_pairs != 0 ? (size_t)kLightFloats : 0));
             c->lds_bytes_table = sizeof(unsigned) * (size_t)scene_table_dwords(c->hm.n_shapes, c->hm.n_pairs);
             // rollouts: 4 lanes per sample (contact points dealt over the quad) unless MPPI_ROLLOUT=lane
             const char *mode = std::getenv("MPPI_ROLLOUT");
@@ -481,7 +483,10 @@ int mppi_create(const mppi_model_t *model, const mppi_config_t *cfg, int device,
             c->launch_rollout = c->quad ? (oct ? e->rollout_scene_oct : e->rollout_scene_quad) : e->rollout_scene;
             // short trees: the octet kernel with a helper wavefront per sample group (kSplitOctPair) unless MPPI_ROLLOUT=oct
             // (its dead-pair masks are two words, mppi_scene.hpp: a larger candidate list goes to the one-wavefront octet kernel)
-            c->helper_wave = oct && e->rollout_scene_pair != nullptr && !(mode && std::string(mode) == "oct") && c->hm.n_pairs <= kPairKernelMaxPairs;
+            // (... and a scene with a light body's pairs - implicit on both bodies, mppi_scene.hpp "light bodies" - as well: the free
+            // actors are solved AFTER the robot there, not next to it)
+            c->helper_wave = oct && e->rollout_scene_pair != nullptr && !(mode && std::string(mode) == "oct") && c->hm.n_pairs <= kPairKernelMaxPairs &&
+                             c->hm.n_light_pairs == 0;
             if (c->helper_wave) c->launch_rollout = e->rollout_scene_pair;
             if (oct) {  // (whole-horizon trajectories for host-side costs: the octet kernel)
                 c->launch_rollout_traj = e->rollout_scene_traj;
@@ -1191,6 +1196,14 @@ int mppi_sim_step_host(mppi_ctx_t *c, const float *u_host) {
     CTX_TRY(c);
     if (!u_host) return fail(MPPI_EINVAL, "null command");
     const unsigned slot = c->io_cmd_next++ % kIoCmdSlots;
+    // back-pressure: a slot is written again only after the kernels of the previous lap have read theirs - a caller that steps without
+    // ever reading state (many envs, contact scenes with multiplied substeps) could otherwise get more than kIoCmdSlots launches
+    // ahead of the stream, and steps would silently run with later commands.  One wait per lap; the loops that read the state
+    // every iteration (the reference's world loop) find the stream idle
+    if (slot == 0 && c->io_cmd_next > 1) {
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return fail(MPPI_EHIP, std::string("mppi_sim_step_host: ") + hipGetErrorString(e));
+    }
     std::memcpy(c->h_io + kIoCmd + 16 * slot, u_host, sizeof(float) * c->nu);
     std::atomic_thread_fence(std::memory_order_release);
     c->launch_sim_step(c, 1, 0, c->d_io + kIoCmd + 16 * slot);

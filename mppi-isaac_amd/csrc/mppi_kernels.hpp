@@ -875,6 +875,10 @@ __global__ __launch_bounds__(kWave) void k_rollout_scene(const DevModel *__restr
     const int k = blockIdx.x * kWave + threadIdx.x;
     const bool live = k < cfg->K;
     LMem L{lds + threadIdx.x, kWave};  // lane-minor rows: conflict-free ds_read/ds_write
+    // (records of the light bodies' pairs, mppi_scene.hpp "light bodies": a per-lane array here - 64 rows of a large scene fill the LDS)
+    float light_rec[kLightFloats];
+    L.lp = light_rec;
+    L.lstride = 1;
     // start state in rollout coordinates (relative to the robot's start position, mppi_scene.hpp root_relative)
     __shared__ float s_root[13 * kMaxActors];
     root_origin(*(CModel *)m, x0_root, L.ox, L.oy);
@@ -966,6 +970,10 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW))
     scene_table_fill(M, tab, threadIdx.x, kWave * NW);
     LMem L{lds + slot, SPW, tab};
     L.cm = 11 * slot;
+    if (M.n_light_pairs != 0) {   // records of the light bodies' pairs: the tail of the sample's rows (scene_row_floats)
+        L.lp = lds + slot + (size_t)scene_light_base<T>(M) * SPW;
+        L.lstride = SPW;
+    }
     // octet layout of the solve (mppi_scene_oct.hpp): the linear lanes read the bodies' inertia blocks from a copy without inertia
     // tensors; lane i stages body i
     constexpr bool kOctSolve = OSOLVE;
@@ -1040,7 +1048,10 @@ __global__ __launch_bounds__(kWave) void k_sim_step_scene(const DevModel *__rest
     const int K = cfg->K, nu = cfg->nu;
     const int k = blockIdx.x * kWave + threadIdx.x;
     if (k >= K) return;
-    const LMem L{lds + threadIdx.x, kWave};
+    LMem L{lds + threadIdx.x, kWave};
+    float light_rec[kLightFloats];   // (records of the light bodies' pairs: per lane, as in k_rollout_scene)
+    L.lp = light_rec;
+    L.lstride = 1;
     CModel &M = *(CModel *)m;
     SceneState<T> s;
     static_for<0, NB>([&](auto ic) {
@@ -1125,6 +1136,10 @@ __global__ __launch_bounds__(kWave) void k_sim_step_scene_quad(const DevModel *_
     LMem L{lds + (threadIdx.x >> 2), 16};
     L.cm = 11 * (int)(threadIdx.x >> 2);
     CModel &M = *(CModel *)m;
+    if (M.n_light_pairs != 0) {   // records of the light bodies' pairs: the tail of the sample's rows (scene_row_floats)
+        L.lp = lds + (threadIdx.x >> 2) + (size_t)scene_light_base<T>(M) * 16;
+        L.lstride = 16;
+    }
     SceneState<T> s;
     static_for<0, NB>([&](auto ic) {
         constexpr int i = ic;

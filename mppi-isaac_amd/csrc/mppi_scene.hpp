@@ -73,6 +73,11 @@ struct LMem {
     float ox = 0.f, oy = 0.f;
     // 11 x this sample's position in the row group (the component-minor shape-pose cache, shape_cached below)
     int cm = 0;
+    // records of the LIGHT bodies' pairs of this substep ("light bodies" below): element i of this sample at lp[i * lstride] - the tail
+    // of the sample's LDS rows in the kernels whose lanes share a sample, a per-lane array in the one-lane kernels; null: none
+    float *lp = nullptr;
+    int lstride = 0;
+    MPPI_HD float &lt(int i) const { return lp[(size_t)i * lstride]; }
     // octet layout of the articulated-body solve (mppi_scene_oct.hpp; rollout kernels of fixed-base trees of more than four bodies):
     // LDS address of THIS lane's view of the model's body blocks (angular lanes: the staged model's own, linear lanes: the copy
     // without inertia tensors); 0: the kernel has none - quad-layout solve
@@ -241,7 +246,11 @@ MPPI_HD ActorDraw actor_draw_slot(M &m, int slot, float mu_nominal, const LMem &
 
 // floats of one sample's LDS rows in the kernels whose lanes share a sample (incl. the shape-pose cache)
 template <class T, class M>
-MPPI_HD int scene_row_floats(M &m) { return SceneLayout<T>::floats(m.n_rb, m.n_rnd, m.n_shapes); }
+MPPI_HD int scene_light_base(M &m) { return SceneLayout<T>::floats(m.n_rb, m.n_rnd, m.n_shapes); }
+// records of the light bodies' pairs (see "light bodies"): kLightSlots x { wrench on the light body f'(6), damping C'(21), heavy frame | free slot << 8 }
+constexpr int kLightSlots = 4, kLightSlotFloats = 28, kLightFloats = kLightSlots * kLightSlotFloats;
+template <class T, class M>
+MPPI_HD int scene_row_floats(M &m) { return SceneLayout<T>::floats(m.n_rb, m.n_rnd, m.n_shapes) + (m.n_light_pairs != 0 ? kLightFloats : 0); }
 
 // extra floats per sample row of the kernels with a helper wavefront (kSplitOctPair): its accumulator set, two mask words and
 // the accelerations of the free actors it solves (6 each, at xch + 2)
@@ -514,6 +523,11 @@ MPPI_HD void pair_normalise(const Gains &P, PairAcc &a) {
     const float sc = frcp(fmaxf(P.npts, a.wsum));
     a.f = {sc * a.f.a, sc * a.f.l};
     a.rep = sc * a.rep;
+    if (P.mode >= 3) {  // (a light body's pair: the implicit law's damping block as well)
+        a.C.I = {sc * a.C.I.xx, sc * a.C.I.xy, sc * a.C.I.xz, sc * a.C.I.yy, sc * a.C.I.yz, sc * a.C.I.zz};
+        for (int j = 0; j < 9; j++) a.C.H[j] *= sc;
+        a.C.M = {sc * a.C.M.xx, sc * a.C.M.xy, sc * a.C.M.xz, sc * a.C.M.yy, sc * a.C.M.yz, sc * a.C.M.zz};
+    }
 }
 MPPI_HD void contact_point(const Gains &P, V3 p, V3 n, float depth, const SV &vA, const SV &vB, PairAcc &acc) {
     const V3 vr = vel_at(vA, p) - vel_at(vB, p);
@@ -540,7 +554,12 @@ MPPI_HD void contact_point(const Gains &P, V3 p, V3 n, float depth, const SV &vA
     // term in the implicit normal coefficient (unconditionally stable, no bounce at h = 25 ms); the
     // damper acts on approach and on separation (an approach-only damper toggles with the sign of v_n: resting jitter);
     // friction is implicit too (see below)
-    float a = ramp * (P.cn + P.kh);
+    // (modes 3 / 4, a light body held by robot links: damper and end-of-step spring are NOT ramped - the ramp's depth scale is the static
+    // sag of a body under its own weight, these contacts carry drive forces at a fraction of it, and a spring that is explicit for the
+    // most part throws a 22-gram finger link whose drive has saturated back out of the contact substep after substep; the ramp - over
+    // 1 / MPPI_LIGHT_RAMP_DIV of that depth, PairGain::inv_d0 - shapes their stick damper and their patch weights)
+    float a = P.mode >= 3 ? P.cn + P.kh : ramp * (P.cn + P.kh);
+    if (P.mode >= 3) acc.wsum += ramp;
     {  // never adhesive at the start velocity: a <= k depth / v_n while separating (branch-free; the raw reciprocal is enough)
 #if defined(__HIP_DEVICE_COMPILE__)
         const float cap = P.k * depth * __builtin_amdgcn_rcpf(fmaxf(vn, 1e-30f));
@@ -934,11 +953,23 @@ MPPI_HD void box_pair_fill(const Gains &P, const BoxRel &rel, const ShapeW &wa, 
     one.rep = {0.f, 0.f, 0.f};
     one.wsum = 0.f;
     one.any = false;
+    if (P.mode >= 3) {
+        one.C.I = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 9; j++) one.C.H[j] = 0.f;
+        one.C.M = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    }
     contact_point(P, pw, n, odepth, wa.v, wb.v, one);  // (mode 0: touches f, rep, wsum only)
     acc.f = {acc.f.a + deficit * one.f.a, acc.f.l + deficit * one.f.l};
     acc.rep = acc.rep + deficit * one.rep;
     acc.wsum += deficit * one.wsum;
     acc.any = true;
+    if (P.mode >= 3) {
+        acc.C.I.xx += deficit * one.C.I.xx; acc.C.I.xy += deficit * one.C.I.xy; acc.C.I.xz += deficit * one.C.I.xz;
+        acc.C.I.yy += deficit * one.C.I.yy; acc.C.I.yz += deficit * one.C.I.yz; acc.C.I.zz += deficit * one.C.I.zz;
+        for (int j = 0; j < 9; j++) acc.C.H[j] += deficit * one.C.H[j];
+        acc.C.M.xx += deficit * one.C.M.xx; acc.C.M.xy += deficit * one.C.M.xy; acc.C.M.xz += deficit * one.C.M.xz;
+        acc.C.M.yy += deficit * one.C.M.yy; acc.C.M.yz += deficit * one.C.M.yz; acc.C.M.zz += deficit * one.C.M.zz;
+    }
 }
 // box_points_in_box with the pair's normal: n (world, from B to A), nl = the direction in which the points of X leave Y, in Y's
 // frame (+-R_Y^T n)
@@ -1090,6 +1121,80 @@ MPPI_HD void sphere_sphere(const Gains &P, V3 pa, float ra, V3 pb, float rb, con
 constexpr int kDealtBroadPhaseMin = 16;  // candidate pairs above which the quad kernels deal the broad phase over the lanes
 // larger trees only: on the pushing scene (2-body tree, 11 pairs that are mostly near each other) the dealt pass is pure
 // overhead - measured +8 % on the octet kernel at equal state (1.386 -> 1.494 ms), as it was on the quad kernel
+// ---- light bodies ------------------------------------------------------------------------------
+// A free actor at least MPPI_LIGHT_BODY_RATIO times lighter than the robot that touches it (the 1-gram block of the reference's
+// examples/panda_pick between the fingers of a 17-kg arm; PhysX's implicit solver holds and lifts it, isaacgym_wrapper.py:29-36).  The
+// explicit law of two dynamic bodies is as stiff as the LIGHTER body can carry in an explicit step - 1.3 N/m for one gram at
+// h = 25 ms: a finger drive closes the fingers THROUGH the block - and its stick damper creeps at g h.  Such a pair (PairGeom::mode
+// 3: A is the robot link, 4: B) takes the implicit law of a static partner on BOTH bodies with the HEAVY body's gains, staggered
+// (oracle: light_pair_t): with C = J^T (b 1 + (a - b) n n^T) J over the pair's points and f its spring wrench,
+//   robot link X:  wrench = +-f - C (v_X+ - v_L)    C joins the link's articulated inertia like a static contact's; the light body is a
+//                                                   wall that moves with its velocity at the START of the substep;
+//   light body L:  wrench = -+f - C (v_L+ - v_X+)   solved AFTER the robot, against the link's velocity at the END of the substep
+//                                                   (light_link_velocities): slaved to the links that hold it without a substep of lag.
+// Both solves are unconditionally stable (a squeeze between two fingers contracts by m / (m + h C) per substep); what the robot feels of
+// the light body is its weight and an added mass h C while it accelerates.  fp32: the pair is evaluated in coordinates about the
+// light body's centre o - its 6x6 (inertia 1e-7 kg m^2 next to h C ~ 10 kg about the world origin) would lose the body's own
+// inertia to rounding otherwise; the robot's share is shifted to the world origin (light_shift), the light body's solve stays
+// about o (free_body_accel).  One record per contact-bearing pair carries (f', C', heavy frame) from the contact pass to that solve:
+// kLightSlots records per sample (a fifth simultaneous pair adds to the last record's).
+// 6x6 about the world origin from the one about the point o (motion E = [[1, 0], [-[o]x, 1]]: C_O = E^T C' E); o -> -o: the way back
+MPPI_HD AI light_shift(const AI &c, V3 o) {
+    // G = [o]x H'^T (3x3), PM = [o]x M'
+    const float Ht[9] = {c.H[0], c.H[3], c.H[6], c.H[1], c.H[4], c.H[7], c.H[2], c.H[5], c.H[8]};
+    const float Mm[9] = {c.M.xx, c.M.xy, c.M.xz, c.M.xy, c.M.yy, c.M.yz, c.M.xz, c.M.yz, c.M.zz};
+    float G[9], PM[9];
+    for (int j = 0; j < 3; j++) {  // columns
+        const V3 g = cross(o, V3{Ht[j], Ht[3 + j], Ht[6 + j]}), q = cross(o, V3{Mm[j], Mm[3 + j], Mm[6 + j]});
+        G[j] = g.x; G[3 + j] = g.y; G[6 + j] = g.z;
+        PM[j] = q.x; PM[3 + j] = q.y; PM[6 + j] = q.z;
+    }
+    // -P M' P = (P M') P^T: row r of PM crossed with o  ((X P^T)_r = -(X_r x o) ... X [o]x^T v = X (v x o)): rows: PMP_r = o x PM_r^T taken column-wise
+    float Q[9];  // Q = PM [o]x^T  ->  Q[r][:] = -(PM[r][:] x o) = o x PM[r][:]
+    for (int r = 0; r < 3; r++) {
+        const V3 q = cross(o, V3{PM[3 * r], PM[3 * r + 1], PM[3 * r + 2]});
+        Q[3 * r] = q.x; Q[3 * r + 1] = q.y; Q[3 * r + 2] = q.z;
+    }
+    AI out;
+    out.I = {c.I.xx + 2.f * G[0] + Q[0], c.I.xy + G[1] + G[3] + Q[1], c.I.xz + G[2] + G[6] + Q[2],
+             c.I.yy + 2.f * G[4] + Q[4], c.I.yz + G[5] + G[7] + Q[5], c.I.zz + 2.f * G[8] + Q[8]};
+    for (int j = 0; j < 9; j++) out.H[j] = c.H[j] + PM[j];
+    out.M = c.M;
+    return out;
+}
+MPPI_HD SV light_shift(const SV &f, V3 o) { return SV{f.a + cross(o, f.l), f.l}; }          // wrench about o -> about the world origin
+MPPI_HD SV light_motion_at(const SV &v, V3 o) { return SV{v.a, v.l + cross(v.a, o)}; }      // motion about the world origin -> about o
+// spatial velocities of the robot's frames at the END of the substep into the frames' velocity rows (their start-of-substep values
+// are not read again): the new joint rates - after the velocity and joint limits - on the joint axes of the substep's poses, a
+// floating base from its integrated root row
+template <class T, class M>
+MPPI_HD void light_link_velocities(M &m, const SceneState<T> &s, const LMem &L, bool leader) {
+    constexpr int NB = T::NB;
+    SV vb[T::NBASE];
+    static_for<0, T::NBASE>([&](auto rc) MPPI_LAMBDA {
+        constexpr int r = rc;
+        const float *bs = s.template base_row<r>();
+        const V3 w = loadv(bs + 10), vl = loadv(bs + 7);
+        vb[r] = m.floating ? SV{w, vl - cross(w, loadv(bs))} : SV{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+        if (m.floating && leader) {
+            const int o = (NB + r) * 18;
+            L[o + 12] = vb[r].a.x; L[o + 13] = vb[r].a.y; L[o + 14] = vb[r].a.z; L[o + 15] = vb[r].l.x; L[o + 16] = vb[r].l.y; L[o + 17] = vb[r].l.z;
+        }
+    });
+    SV v[NB ? NB : 1];
+    static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
+        constexpr int i = ic;
+        constexpr int par = T::par[i];
+        const int o = i * 18;
+        const V3 az = {L[o + 2], L[o + 5], L[o + 8]}, p = {L[o + 9], L[o + 10], L[o + 11]};
+        const float qd = s.qd[i];
+        const SV sj = m.b[i].k0.jtype == 0 ? SV{qd * az, qd * cross(p, az)} : SV{{0.f, 0.f, 0.f}, qd * az};
+        if constexpr (par < 0) v[i] = vb[base_of_parent(par)] + sj;
+        else v[i] = v[par < 0 ? 0 : par] + sj;
+        if (leader) { L[o + 12] = v[i].a.x; L[o + 13] = v[i].a.y; L[o + 14] = v[i].a.z; L[o + 15] = v[i].l.x; L[o + 16] = v[i].l.y; L[o + 17] = v[i].l.z; }
+    });
+}
+
 template <class T>
 constexpr bool dealt_broad_phase(int split) { return split_on_device(split) && T::NB > 4; }
 // Poses, per-sample sizes and broad-phase verdict of one candidate pair.
@@ -1193,6 +1298,12 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
     unsigned cf_touched = 0;
     const SV zero = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
     constexpr bool kCached = SPLIT != kSplitNone;
+    // records of the light bodies' pairs ("light bodies" above; never in the kernel with a helper wavefront: mppi_create gives a scene
+    // with such pairs the one-wavefront kernels): all free at the start of the pass
+    int n_light = 0;
+    if constexpr (!kPair)
+        if (m.n_light_pairs != 0 && split.sub == 0)
+            for (int sl = 0; sl < kLightSlots; sl++) L.lt(sl * kLightSlotFloats + 27) = __builtin_bit_cast(float, -1);
     if constexpr (kPair) {
         // dealt over both wavefronts (the owner posing all shapes before the first barrier, one barrier less, measured the same)
         shape_cache_update<T, true>(m, root, L, Split{split.sub + split.n * split.wave, 2 * split.n}, false);
@@ -1452,14 +1563,20 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
         // contact law of the survivors: second block of the pair (already here: requested one pair ahead)
         // (requested through the vector memory path in front of the broad phase instead: measured the same, 1.0427 vs 1.0396 ms)
         if constexpr (kLazyGains) Cg = load_block<PairGain>(m.pr[ip].c);
-        Gains P = {G.mode, Cg.mu, Cg.k, Cg.cn, Cg.ct, Cg.kh, Cg.inv_d0, Cg.npts};
+        // (the kernel with a helper wavefront never sees a light body's pair - mppi_create - and carries none of that code: its
+        // 256-register budget answered the run-time branches with 36 B more scratch per lane)
+        Gains P = {kPair ? (G.mode < 3 ? G.mode : 0) : G.mode, Cg.mu, Cg.k, Cg.cn, Cg.ct, Cg.kh, Cg.inv_d0, Cg.npts};
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (kPair) __builtin_assume(P.mode >= 0 && P.mode <= 2);
+#endif
         if (G.rnd) {  // per-sample friction (min of the two) and contact gains scaled with the per-sample reacting mass
             const float mua = robotA ? Cg.muA : da.mu;
             const float mub = !has_b ? Cg.mub : (robotB ? Cg.muB : db.mu);
             P.mu = fminf(mua, mub);
             const float ma = Cg.ma * da.ms, mb = Cg.mb * db.ms;
-            const float meff0 = G.mode == 0 ? Cg.ma * Cg.mb * frcp(Cg.ma + Cg.mb) : (G.mode == 1 ? Cg.ma : Cg.mb);
-            const float meff = G.mode == 0 ? ma * mb * frcp(ma + mb) : (G.mode == 1 ? ma : mb);
+            const bool useA = G.mode == 1 || (!kPair && G.mode == 3);   // (3 / 4: the gains of the HEAVY body, the robot link)
+            const float meff0 = G.mode == 0 ? Cg.ma * Cg.mb * frcp(Cg.ma + Cg.mb) : (useA ? Cg.ma : Cg.mb);
+            const float meff = G.mode == 0 ? ma * mb * frcp(ma + mb) : (useA ? ma : mb);
             const float sc = meff * frcp(meff0);
             P.k *= sc; P.cn *= sc; P.ct *= sc; P.kh *= sc;
         }
@@ -1469,8 +1586,19 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
             wa.v = frame_velocity(L, G.entA);
             if (has_b) wb.v = frame_velocity(L, entB);
         }
+        // a light body's pair: everything from here on in coordinates about that body's centre ("light bodies": its own inertia
+        // must survive fp32 next to the heavy body's gains); the contact geometry is translation invariant
+        const bool light = !kPair && G.mode >= 3;
+        V3 lo = {0.f, 0.f, 0.f};
+        if (light) {
+            const int el = G.mode == 3 ? entB : G.entA;
+            lo = V3{L[el * 18 + 9], L[el * 18 + 10], L[el * 18 + 11]};
+            wa.p = wa.p - lo; wb.p = wb.p - lo;
+            wa.v = light_motion_at(wa.v, lo); wb.v = light_motion_at(wb.v, lo);
+        }
         // two dynamic boxes: one normal for the pair (box_pair_sat), unless the model asks for the law of ABI <= 7
-        const bool pair_normal = G.mode == 0 && has_b && typeA == 0 && typeB == 0 && m.pair_normal != 0;
+        const bool dyn = G.mode == 0 || (!kPair && G.mode >= 3);
+        const bool pair_normal = dyn && has_b && typeA == 0 && typeB == 0 && m.pair_normal != 0;
         BoxSat sat;
         sat.hit = false;
         if (pair_normal) sat = box_pair_sat(rel, wa, hA, wb, hB);
@@ -1555,6 +1683,7 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
                 if (__builtin_amdgcn_ballot_w64(acc.any) != 0) {
                     if (G.mode == 0) group_reduce_explicit<SPLIT>(acc);  // two dynamic bodies: no implicit damping block to sum
                     else group_reduce<SPLIT>(acc);
+                    if (!kPair && G.mode >= 3) acc.wsum = group_allsum<SPLIT>(acc.wsum);   // (a light body's pair: patch weights as well)
                 }
 #endif
         }
@@ -1576,7 +1705,39 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
 #endif
         MPPI_SEC(14);  // feature points + cross-lane sum
         if (pair_normal && sat.hit) box_pair_fill(P, rel, wa, hA, wb, hB, sat.n, acc);
-        if (G.mode == 0 && acc.any) pair_normalise(P, acc);
+        if (dyn && acc.any) pair_normalise(P, acc);
+        if (light && acc.any) {
+            // ("light bodies") robot link: +-f + C' v_L(start) and C', shifted to the world origin, into the link's rows like a static
+            // contact's; light body: -+f and C' with the link's frame into the next free record (a fifth pair: onto the last one)
+            const bool heavyA = G.mode == 3;
+            const int eh = heavyA ? G.entA : entB, el = heavyA ? entB : G.entA;
+            const SV fA = acc.f, fB = {{-acc.f.a.x, -acc.f.a.y, -acc.f.a.z}, {-acc.f.l.x, -acc.f.l.y, -acc.f.l.z}};
+            const SV Cv = mul(acc.C, heavyA ? wb.v : wa.v);
+            const SV fh = light_shift((heavyA ? fA : fB) + Cv, lo), fl = heavyA ? fB : fA;
+            const AI Ch = light_shift(acc.C, lo);
+            const int sl = n_light < kLightSlots ? n_light : kLightSlots - 1;
+            const bool fresh = n_light < kLightSlots;
+            n_light++;
+            const int o = sl * kLightSlotFloats;
+            const float rec[27] = {fl.a.x, fl.a.y, fl.a.z, fl.l.x, fl.l.y, fl.l.z, acc.C.I.xx, acc.C.I.xy, acc.C.I.xz, acc.C.I.yy, acc.C.I.yz, acc.C.I.zz,
+                                   acc.C.H[0], acc.C.H[1], acc.C.H[2], acc.C.H[3], acc.C.H[4], acc.C.H[5], acc.C.H[6], acc.C.H[7], acc.C.H[8],
+                                   acc.C.M.xx, acc.C.M.xy, acc.C.M.xz, acc.C.M.yy, acc.C.M.yz, acc.C.M.zz};
+            const int ocf = kCfW + 3 * G.rbA, ob = kCfW + 3 * rbB;
+            cf_touched |= (1u << (G.rbA & 31)) | (1u << (rbB & 31));
+            touched |= 1u << eh;
+            const bool leader = !split_on_device(SPLIT) || split.sub == 0;
+            if (leader) {
+                if (fresh) {
+                    for (int j = 0; j < 27; j++) L.lt(o + j) = rec[j];
+                    L.lt(o + 27) = __builtin_bit_cast(float, eh | ((el - free_frame<T>(0)) << 8));
+                } else {
+                    for (int j = 0; j < 27; j++) L.lt(o + j) += rec[j];
+                }
+                acc_add(L, kAccW, eh, fh, &Ch);
+                L[ocf] += acc.rep.x; L[ocf + 1] += acc.rep.y; L[ocf + 2] += acc.rep.z;
+                L[ob] -= acc.rep.x; L[ob + 1] -= acc.rep.y; L[ob + 2] -= acc.rep.z;
+            }
+        } else
         if (acc.any) {
             const SV neg = {{-acc.f.a.x, -acc.f.a.y, -acc.f.a.z}, {-acc.f.l.x, -acc.f.l.y, -acc.f.l.z}};
             const int ocf = kCfW + 3 * G.rbA, ob = kCfW + 3 * (rbB >= 0 ? rbB : 0);
@@ -1861,6 +2022,42 @@ MPPI_HD SV free_body_accel(M &m, int f, const LMem &L, float h, int set1 = 0) {
     AI A;
     SV pA;
     V3 hw;
+    if (m.n_light_pairs != 0 && ((m.light_free >> f) & 1u) != 0u && L.lp != nullptr) {
+        // a LIGHT body ("light bodies" above): solved about its own centre o = p against the END-of-substep velocities of the robot
+        // links that touch it (light_link_velocities has put them into the frames' rows):
+        //   (I + h (C_s' + sum C_r')) a = -(v x* I v + C_s' v - f_s' - f_g) + sum [ f_r' + C_r' (v_X+ - v) ]
+        // C_s, f_s: its contacts with static geometry (the accumulator rows, shifted from the world origin to o), r: the records
+        const SV vo = light_motion_at(v, p);
+        rigid_world(R, V3{0.f, 0.f, 0.f}, fm, V3{0.f, 0.f, 0.f}, Ic6, vo, A, pA, hw);
+        SV fs;
+        AI Cs;
+        acc_load(L, SceneLayout<T>::kAcc, free_frame<T>(f), fs, Cs);
+        const V3 mo = {-p.x, -p.y, -p.z};
+        SV fe = light_shift(fs, mo);
+        AI C = light_shift(Cs, mo);
+        for (int sl = 0; sl < kLightSlots; sl++) {
+            const int o = sl * kLightSlotFloats;
+            const int tag = __builtin_bit_cast(int, L.lt(o + 27));
+            if (tag < 0 || (tag >> 8) != f) continue;
+            AI Cr;
+            Cr.I = {L.lt(o + 6), L.lt(o + 7), L.lt(o + 8), L.lt(o + 9), L.lt(o + 10), L.lt(o + 11)};
+            for (int j = 0; j < 9; j++) Cr.H[j] = L.lt(o + 12 + j);
+            Cr.M = {L.lt(o + 21), L.lt(o + 22), L.lt(o + 23), L.lt(o + 24), L.lt(o + 25), L.lt(o + 26)};
+            const SV vx = light_motion_at(frame_velocity(L, tag & 255), p);
+            const SV Cvx = mul(Cr, vx);
+            fe = {fe.a + V3{L.lt(o), L.lt(o + 1), L.lt(o + 2)} + Cvx.a, fe.l + V3{L.lt(o + 3), L.lt(o + 4), L.lt(o + 5)} + Cvx.l};
+            add_to(C, Cr);
+        }
+        const V3 g = F.gravity ? V3{m.g[0], m.g[1], m.g[2]} : V3{0.f, 0.f, 0.f};
+        const SV Cv = mul(C, vo);
+        pA = {pA.a + Cv.a - fe.a, pA.l + Cv.l - fe.l - fm * g};
+        A.I.xx += h * C.I.xx; A.I.xy += h * C.I.xy; A.I.xz += h * C.I.xz; A.I.yy += h * C.I.yy; A.I.yz += h * C.I.yz; A.I.zz += h * C.I.zz;
+        for (int j = 0; j < 9; j++) A.H[j] += h * C.H[j];
+        A.M.xx += h * C.M.xx; A.M.xy += h * C.M.xy; A.M.xz += h * C.M.xz; A.M.yy += h * C.M.yy; A.M.yz += h * C.M.yz; A.M.zz += h * C.M.zz;
+        const SV rhs = {{-pA.a.x, -pA.a.y, -pA.a.z}, {-pA.l.x, -pA.l.y, -pA.l.z}};
+        const SV ao = solve6(A, rhs);
+        return SV{ao.a, ao.l - cross(ao.a, p)};   // (about the world origin, what root_integrate takes)
+    }
     rigid_world(R, p, fm, V3{0.f, 0.f, 0.f}, Ic6, v, A, pA, hw);
     SV fe;
     AI C;
@@ -1898,8 +2095,10 @@ __device__ __forceinline__ void helper_free_bodies(M &m, const LMem &L, Split sp
     MPPI_BARRIER(4);
 }
 #endif
+// (leader: one lane of those that share the sample writes)
 template <class T, class M>
-MPPI_HD void step_free_bodies(M &m, SceneState<T> &s, const LMem &L, float h) {
+MPPI_HD void step_free_bodies(M &m, SceneState<T> &s, const LMem &L, float h, bool leader = true) {
+    if (m.n_light_pairs != 0 && L.lp != nullptr) light_link_velocities<T>(m, s, L, leader);
     for (int f = 0; f < kFreeSlots; f++)
         if (f < m.n_free) root_integrate(s.fr[f], free_body_accel<T>(m, f, L, h), h);
 }
@@ -2045,7 +2244,7 @@ MPPI_HD void step_scene(M &m0, const float *root, SceneState<T> &s, const float 
                 }
         } else
 #endif
-        step_free_bodies<T>(m, s, L, h);
+        step_free_bodies<T>(m, s, L, h, !split_on_device(SPLIT) || split.sub == 0);
         MPPI_SEC(7);
     }
 }

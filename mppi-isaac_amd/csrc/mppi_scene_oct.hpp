@@ -355,7 +355,7 @@ __device__ __forceinline__ void step_scene_oct(M &m0, MR &mr0, const float *root
             s.q[i] = qlane0(x);
             s.qd[i] = qlane0(v);
         });
-        step_free_bodies<T>(mr, s, L, h);
+        step_free_bodies<T>(mr, s, L, h, !split_on_device(SPLIT) || split.sub == 0);
         MPPI_SEC(7);
     }
 }

@@ -401,7 +401,7 @@ MPPI_HD void step_scene_quad(M &m0, MR &mr0, const float *root, SceneState<T> &s
             s.qd[i] = qlane0(v);
         });
         if (m.floating) root_integrate(s.base, abase, h);
-        step_free_bodies<T>(mr, s, L, h);
+        step_free_bodies<T>(mr, s, L, h, !split_on_device(SPLIT) || split.sub == 0);
         MPPI_SEC(7);
     }
 }

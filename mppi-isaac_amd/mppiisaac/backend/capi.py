@@ -13,7 +13,8 @@ MAX_BODIES, MAX_LINKS, MAX_ACTORS, MAX_NU, MAX_H, MAX_KNOTS, MAX_COST_W = 12, 24
 MAX_SHAPES, MAX_PAIRS, MAX_FREE, MAX_EXTRA_BASES = 64, 128, 4, 3
 SHAPE_BOX, SHAPE_SPHERE, SHAPE_DISC = 0, 1, 2
 CONTACT_POINT_NORMALS = 1  # Model.contact_flags bit 0
-ABI_VERSION = 8
+CONTACT_EXPLICIT_LIGHT = 2  # Model.contact_flags bit 1: the explicit law for a light body against a robot link (rounds 1-5)
+ABI_VERSION = 9
 # error codes of include/mppi_hip.h
 MPPI_OK, MPPI_EINVAL, MPPI_EHIP, MPPI_EUNSUPPORTED, MPPI_ESTATE = 0, -1, -2, -3, -4
 

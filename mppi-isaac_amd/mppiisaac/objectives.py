@@ -460,3 +460,85 @@ class MultiJackalObjective(ProgramObjective):
         out = [Term("robot_to_goal", "dist", (actor(self.robots[0]), actor(self.goal), 2))]
         return out + [Term("robot_to_goal", "dist", (actor(r), t, 2)) for r, t in zip(self.robots[1:], self.targets)]
 
+
+
+def specialise_program(terms: Sequence[Term], weights: dict, scene) -> capi.Cost:
+    """Term list -> mppi_cost_t: one of the IN-LINE kinds when the list has exactly that shape (the four workloads of BASELINE.json:
+    the rollout kernels evaluate those without the interpreter, and a contact-free scene keeps its octet-layout kernel), otherwise
+    the MPPI_COST_PROGRAM of `compile_program`.  Used for traced Objectives (mppiisaac/trace.py), whose Term lists carry numbers
+    as weights."""
+    def w_of(t):
+        return float(weights[t.weight] if isinstance(t.weight, str) else t.weight)
+
+    by_op = {}
+    for t in terms:
+        by_op.setdefault(t.op, []).append(t)
+    ops = {k: len(v) for k, v in by_op.items()}
+    is_link = lambda s: isinstance(s, tuple) and len(s) == 3 and s[0] == "link"
+    is_actor = lambda s: isinstance(s, tuple) and len(s) == 2 and s[0] == "actor"
+
+    def plain(kind, ws):
+        c = capi.Cost()
+        c.kind = kind
+        for i, v in enumerate(ws):
+            c.w[i] = float(v)
+        return c
+
+    def pair(t, n):
+        """(a, b) of a dist term over n components, or None"""
+        return (t.args[0], t.args[1]) if t.args[2] == n else None
+    # PANDA_REACH: w0 |link - actor|_3 + w1 tilt(link)
+    if ops == {"dist": 1, "tilt": 1} or ops == {"dist": 1}:
+        d = by_op["dist"][0]
+        p = pair(d, 3)
+        if p is not None:
+            lk = next((s for s in p if is_link(s)), None)
+            ac = next((s for s in p if is_actor(s)), None)
+            tl = by_op.get("tilt", [None])[0]
+            if lk is not None and ac is not None and (tl is None or tl.args[0] == lk) and lk[1] in [scene.env_cfg[i].name for i in scene.robot_ids]:
+                c = plain(capi.COST_PANDA_REACH, (w_of(d), w_of(tl) if tl is not None else 0.0))
+                c.link[0] = scene.rigid_body_index(lk[1], lk[2])
+                c.actor[0] = scene.actor_index(ac[1])
+                return c
+        p = pair(d, 2)
+        if p is not None and ops == {"dist": 1} and ("dof_xy",) in p:   # POINT_REACH: w |dof_xy - goal|_2
+            other = p[1] if p[0] == ("dof_xy",) else p[0]
+            c = plain(capi.COST_POINT_REACH, (w_of(d),))
+            if is_actor(other):
+                c.actor[0] = scene.actor_index(other[1])
+                return c
+            if isinstance(other, tuple) and len(other) == 3 and all(isinstance(v, float) for v in other):
+                c.actor[0] = -1
+                c.w[1], c.w[2] = other[0], other[1]
+                return c
+    # PANDA_PICK: w0 |hand - block|_3 + w1 |block - goal|_3 + w2 |F_table|_1 + w3 tilt(hand)
+    if ops == {"dist": 2, "force_l1": 1, "tilt": 1}:
+        tl, fo = by_op["tilt"][0], by_op["force_l1"][0]
+        hand = tl.args[0]
+        d_hb = next((t for t in by_op["dist"] if hand in t.args[:2] and t.args[2] == 3), None)
+        d_bg = next((t for t in by_op["dist"] if t is not d_hb and t.args[2] == 3 and is_actor(t.args[0]) and is_actor(t.args[1])), None)
+        if d_hb is not None and d_bg is not None and fo.args[2] == 3:
+            blk = d_hb.args[1] if d_hb.args[0] == hand else d_hb.args[0]
+            if is_actor(blk) and blk in d_bg.args[:2]:
+                goal = d_bg.args[1] if d_bg.args[0] == blk else d_bg.args[0]
+                c = plain(capi.COST_PANDA_PICK, (w_of(d_hb), w_of(d_bg), w_of(fo), w_of(tl)))
+                c.link[0] = scene.rigid_body_index(hand[1], hand[2])
+                c.link[1] = scene.rigid_body_index(fo.args[0], fo.args[1])
+                c.actor[0], c.actor[1] = scene.actor_index(blk[1]), scene.actor_index(goal[1])
+                return c
+    # BOXER_PUSH: pusher -> block, block -> goal (planar), |yaw - ref|, align, planar speed, |F_xy| of two obstacles (one weight)
+    if ops == {"dist": 2, "yaw_abs": 1, "align": 1, "force_l1": 2} or ops == {"dist": 2, "yaw_abs": 1, "align": 1, "force_l1": 2, "speed": 1}:
+        al, ya = by_op["align"][0], by_op["yaw_abs"][0]
+        pusher, blk, goal = al.args
+        f1, f2 = by_op["force_l1"]
+        sp = by_op.get("speed", [None])[0]
+        d_rb = next((t for t in by_op["dist"] if t.args[2] == 2 and set(t.args[:2]) == {pusher, blk}), None)
+        d_bg = next((t for t in by_op["dist"] if t.args[2] == 2 and set(t.args[:2]) == {goal, blk}), None)
+        if (d_rb is not None and d_bg is not None and d_rb is not d_bg and is_link(pusher) and is_actor(blk) and is_actor(goal) and ya.args[0] == blk
+                and f1.args[2] == f2.args[2] == 2 and w_of(f1) == w_of(f2) and (sp is None or (sp.args[0] == blk and sp.args[1] == 2))):
+            c = plain(capi.COST_BOXER_PUSH, (w_of(d_rb), w_of(d_bg), w_of(ya), w_of(al), w_of(sp) if sp is not None else 0.0, w_of(f1), float(ya.args[1])))
+            c.link[0] = scene.rigid_body_index(pusher[1], pusher[2])
+            c.link[1], c.link[2] = scene.rigid_body_index(f1.args[0], f1.args[1]), scene.rigid_body_index(f2.args[0], f2.args[1])
+            c.actor[0], c.actor[1] = scene.actor_index(blk[1]), scene.actor_index(goal[1])
+            return c
+    return compile_program(terms, weights, scene)

@@ -653,8 +653,16 @@ class IsaacGymWrapper:
         if self.num_envs == 1:
             from mppiisaac.utils.transport import register_host_mirror
             self._mirror = {"dof": np.zeros(2 * n, np.float32), "root": np.zeros(13 * A, np.float32), "fresh": False, "versions": None}
-            register_host_mirror(self._state_t["dof"], lambda: self._mirrored("dof"))
-            register_host_mirror(self._state_t["root"], lambda: self._mirrored("root"))
+            # (the registry is module-level: it holds the wrapper through a WEAK reference, or `del world` would never reach __del__
+            # and the HIP context, device buffers and pinned host blocks of every K = 1 wrapper would live as long as the process)
+            import weakref
+            me = weakref.ref(self)
+
+            def mirrored(which, me=me):
+                w = me()
+                return None if w is None else w._mirrored(which)
+            register_host_mirror(self._state_t["dof"], lambda: mirrored("dof"))
+            register_host_mirror(self._state_t["root"], lambda: mirrored("root"))
         self.reset_to_initial_poses()
 
     def stop_sim(self):

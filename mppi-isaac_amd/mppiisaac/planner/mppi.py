@@ -278,6 +278,42 @@ class MPPIPlanner:
         else:
             self._fused_cost_blob = None
 
+    # -- traced Objectives ---------------------------------------------------------------------
+    TRACE_RECHECK = 64   # commands between two validations of a traced cost program against the eager Objective
+
+    def set_trace_guard(self, on_fail: Optional[Callable]):
+        """`on_fail(detail)`: the fused cost is a program TRACED from a Python Objective (MPPIisaacPlanner._bind_objective) - on the
+        first command with it and every TRACE_RECHECK-th the same rollouts are also costed by the Objective itself (generic mode: the
+        horizon's states, one compute_cost call) and the per-sample trajectory costs compared; on_fail is told when they differ"""
+        if on_fail is None:
+            self._trace_guard = None
+        elif getattr(self, "_trace_guard", None) is None or self._trace_guard[0] is not on_fail.__self__:
+            self._trace_guard = [on_fail.__self__, on_fail, 0]
+
+    def _trace_check(self, state) -> bool:
+        """-> True when the traced program stands (the context then holds the FUSED rollout of this command, as on any other)"""
+        lib, ctx = self._lib, self._ctx
+        capi.check(lib, lib.mppi_sim_reset(ctx))
+        self.sim._needs_reset = False
+        done = self._horizon_batched(state)
+        if done != "reduced":
+            if not done and not self._replay_horizon(state):
+                self._horizon_eager(state)
+            capi.check(lib, lib.mppi_sim_finish(ctx))
+        self.sim._stale = True
+        S_py = self.get_costs()
+        capi.check(lib, lib.mppi_rollout(ctx))
+        S_k = self.get_costs()
+        fin = torch.isfinite(S_py) & torch.isfinite(S_k)
+        scale = float(S_py[fin].abs().max().clamp_min(1e-6)) if bool(fin.any()) else 1.0
+        err = float((S_py[fin] - S_k[fin]).abs().max()) if bool(fin.any()) else 0.0
+        # (contact-free rollouts agree to fp32 rounding; the states of a contact scene's DUMP instantiation and of its fused one are the
+        # same arithmetic, the costs differ by the Objective's own fp32 evaluation order)
+        if err <= 2e-3 * scale and bool((torch.isfinite(S_py) == torch.isfinite(S_k)).all()):
+            return True
+        self._trace_guard[1](f"trajectory costs differ by {err:.3g} of {scale:.3g}")
+        return False
+
     # -- one control iteration ---------------------------------------------------------------
     def command(self, state=None) -> torch.Tensor:
         lib, ctx = self._lib, self._ctx
@@ -292,8 +328,18 @@ class MPPIPlanner:
             # the state the rollout starts from (open loop); generic mode evaluates it at every rollout step
             pr = np.ascontiguousarray(np.stack([_prior_row(self._prior(state, t), self.nu) for t in range(self.T)]))
             capi.check(lib, lib.mppi_set_prior(ctx, capi.fptr(pr)))
+        guard = getattr(self, "_trace_guard", None) if self._fused_cost is not None else None
+        if guard is not None and not with_prior:
+            guard[2] += 1
+            if (guard[2] == 1 or guard[2] % self.TRACE_RECHECK == 0) and not self._trace_check(state):
+                self._fused_cost = None       # (this command: generic mode, below; the facade binds no program from now on)
+                self._fused_cost_blob = None
+                guard = None
+            elif guard[2] == 1 or guard[2] % self.TRACE_RECHECK == 0:
+                guard = "checked"             # (the fused rollout of this command has run inside the check)
         if self._fused_cost is not None:
-            capi.check(lib, lib.mppi_rollout(ctx))
+            if guard != "checked":
+                capi.check(lib, lib.mppi_rollout(ctx))
         else:
             # generic mode.  _horizon_batched returns "reduced" when the whole horizon went through the library in four launches
             # (rollout with the states kept -> materialise what the Objective reads -> [Objective] -> costs folded and reduced):

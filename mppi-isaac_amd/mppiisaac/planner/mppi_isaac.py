@@ -46,7 +46,58 @@ class MPPIisaacPlanner(object):
 
     def _bind_objective(self):
         spec = getattr(self.objective, "fused_spec", None)
-        self.mppi.set_fused_cost(spec(self.sim) if callable(spec) else None)
+        if callable(spec):
+            self.mppi.set_fused_cost(spec(self.sim))
+            self.mppi.set_trace_guard(None)
+            return
+        # an Objective that declares nothing for this backend (the reference's contract: compute_cost / reset / weights): its
+        # compute_cost is traced ONCE into a cost program (mppiisaac/trace.py) and runs inside the rollout kernel from then on,
+        # validated against the eager Objective on the first command and every 64th (MPPIPlanner.command).  Untraceable, or caught
+        # drifting: generic mode (reference mppi_isaac.py:57-69 on precomputed states), with the reason in the log, once.
+        cost = self._traced_spec()
+        self.mppi.set_fused_cost(cost)
+        if getattr(self, "_trace_fresh", False):    # a new trace (another Objective, other weights): validated on its first command
+            self._trace_fresh = False
+            self.mppi.set_trace_guard(None)
+        self.mppi.set_trace_guard(self._trace_failed if cost is not None else None)
+
+    def _traced_spec(self):
+        import os
+        if os.environ.get("MPPI_TRACE_OBJECTIVE", "1") == "0" or (self._prior_obj is not None and self.cfg.mppi.use_priors):
+            return None   # (a prior is evaluated at every rollout step on the stepped envs: generic mode)
+        w = getattr(self.objective, "weights", None)
+        key = (id(self.objective), tuple(sorted((str(k), float(v)) for k, v in w.items())) if isinstance(w, dict) else None, self.sim.generation)
+        cached = getattr(self, "_trace_cache", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        from mppiisaac import trace
+        from mppiisaac.objectives import specialise_program
+        cost = None
+        if getattr(self, "_trace_dropped", None) == id(self.objective):
+            pass   # (its traced program disagreed with it once: it stays in generic mode)
+        else:
+            try:
+                self.traced_terms = trace.trace_objective(self.objective, self.sim)
+                cost = specialise_program(self.traced_terms, {}, self.sim.scene)
+            except (trace.TraceError, ValueError) as e:
+                self.traced_terms = None
+                if getattr(self, "_trace_said", None) != (id(self.objective), str(e)):
+                    self._trace_said = (id(self.objective), str(e))
+                    import logging
+                    logging.getLogger("mppiisaac").warning("%s.compute_cost runs in generic mode (a Python call on the states of the whole "
+                                                           "horizon per command) - not traceable into a cost program: %s", type(self.objective).__name__, e)
+        self._trace_cache = (key, cost)
+        self._trace_fresh = True
+        return cost
+
+    def _trace_failed(self, detail: str):
+        """MPPIPlanner.command found the traced program and the eager Objective apart: generic mode from now on"""
+        import logging
+        logging.getLogger("mppiisaac").warning("%s: the cost program traced from compute_cost disagrees with the Objective (%s) - it depends on "
+                                               "more than the sim's getters and its weights; generic mode from here on", type(self.objective).__name__, detail)
+        self._trace_dropped = id(self.objective)
+        self._trace_cache = None
+        self.traced_terms = None
 
     def update_objective(self, objective):
         self.objective = objective

@@ -4,6 +4,9 @@ import torch
 
 
 def quaternion_to_yaw(quat: torch.Tensor) -> torch.Tensor:
+    if getattr(quat, "_mppi_sym", False):   # (an Objective being traced into a cost program: mppiisaac/trace.py)
+        from mppiisaac import trace
+        return trace.quaternion_to_yaw(quat)
     x, y, z, w = quat[:, 0], quat[:, 1], quat[:, 2], quat[:, 3]
     siny_cosp = 2.0 * (w * z + x * y)
     cosy_cosp = w * w + x * x - y * y - z * z
@@ -14,6 +17,9 @@ def quaternion_to_matrix(quaternions: torch.Tensor) -> torch.Tensor:
     """pytorch3d.transforms.quaternion_to_matrix (0.3.0; real-first (r,i,j,k) convention).  The
     reference examples call it on xyzw rows (examples/panda/planner.py:30-32); shipped here because
     pytorch3d is not a dependency of this backend."""
+    if getattr(quaternions, "_mppi_sym", False):
+        from mppiisaac import trace
+        return trace.quaternion_to_matrix(quaternions)
     r, i, j, k = torch.unbind(quaternions, -1)
     two_s = 2.0 / (quaternions * quaternions).sum(-1)
     o = torch.stack(
@@ -37,6 +43,9 @@ def _angle_from_tan(axis: str, other_axis: str, data, horizontal: bool, tait_bry
 
 def matrix_to_euler_angles(matrix: torch.Tensor, convention: str) -> torch.Tensor:
     """pytorch3d.transforms.matrix_to_euler_angles (0.3.0), e.g. convention "ZYX"."""
+    if getattr(matrix, "_mppi_sym", False):
+        from mppiisaac import trace
+        return trace.matrix_to_euler_angles(matrix, convention)
     idx = {"X": 0, "Y": 1, "Z": 2}
     i0, i2 = idx[convention[0]], idx[convention[2]]
     tait_bryan = i0 != i2

@@ -475,7 +475,10 @@ static void contact_point(int mode, real mu, real k, real cn, real ct, real kh, 
     /* Hunt-Crossley-style ramp of the velocity-proportional normal terms over the first contact_ramp_depth of penetration:
      * the contact force is continuous at touch-down (include/mppi_hip.h, mppi_model_t.contact_ramp_depth) */
     real ramp = 1;
-    if (g_ramp_depth > 0) { ramp = depth / g_ramp_depth; if (ramp > 1) ramp = 1; }
+    /* mode 3: the depth scale of the ramp is 1/MPPI_LIGHT_RAMP_DIV of the static sag (these contacts carry drive forces at a fraction
+     * of a millimetre: 20 N at 21 kN/m) - it shapes the stick damper and the patch weights only, see below */
+    const real rd = mode == 3 ? g_ramp_depth / (real)MPPI_LIGHT_RAMP_DIV : g_ramp_depth;
+    if (rd > 0) { ramp = depth / rd; if (ramp > 1) ramp = 1; }
     real va[3], vb[3], vr[3], vt[3];
     vel_at(vA, p, va); vel_at(vB, p, vb);
     for (int j = 0; j < 3; j++) vr[j] = va[j] - vb[j];
@@ -483,7 +486,7 @@ static void contact_point(int mode, real mu, real k, real cn, real ct, real kh, 
     for (int j = 0; j < 3; j++) vt[j] = vr[j] - vn * n[j];
     real vtn = (real)sqrt((double)(vt[0] * vt[0] + vt[1] * vt[1] + vt[2] * vt[2]));
     acc->any = 1;
-    acc->wsum += ramp;
+    acc->wsum += ramp;   /* (patch normalisation of two dynamic bodies, modes 0 and 3) */
     /* the stick cap of the friction viscosity ramps in with the penetration as well: a grazing contact (f_n -> 0) of a body at
      * rest (|v_t| -> 0) would otherwise get the full stick damper c_t from the ratio of two vanishing numbers */
     ct *= ramp;
@@ -498,7 +501,10 @@ static void contact_point(int mode, real mu, real k, real cn, real ct, real kh, 
     /* Kelvin-Voigt damper on approach AND separation (a law that damps the approach only switches c_n on and off with the
      * sign of v_n and keeps a body that rests on several points rocking at fp32 rounding level), capped so that the force at
      * the start velocity never turns adhesive: k depth - a v_n >= 0 */
-    real a = ramp * (cn + kh);
+    /* (mode 3, a light body held by robot links: damper and end-of-step spring are NOT ramped - a spring that is explicit for the most
+     * part throws a 22-gram finger link whose drive has saturated back out of the contact substep after substep, and with the full
+     * damper an impact at closing speed loses alpha / (alpha + beta) of its penetration per substep without leaving the contact) */
+    real a = mode == 3 ? cn + kh : ramp * (cn + kh);
     if (vn > 0 && a * vn > k * depth) a = k * depth / vn;
     real fn = k * depth - a * vn; if (fn < 0) fn = 0;
     real b = mu * fn / (vtn + (real)1e-9); if (ct < b) b = ct;
@@ -820,8 +826,32 @@ static int shape_entity(const mppi_model_t *m, const scene_info_t *si, const mpp
     return -1;
 }
 
-static void scene_contacts(const mppi_model_t *m, const scene_info_t *si, frame_t *fr, const real *root, real *cf) {
+/* A LIGHT free body against a link of a much heavier robot (round 6; a 1-gram block between the fingers of an arm, reference
+ * examples/panda_pick, conf/actors/panda_pick_block.yaml - PhysX's implicit solver holds and lifts it, isaacgym_wrapper.py:29-36):
+ * the explicit law of two dynamic bodies is as stiff as the LIGHTER body can carry in an explicit step (1.3 N/m for one gram at
+ * h = 25 ms - a finger drive closes the fingers THROUGH the block) and its stick damper creeps at g h.  Such a pair (the free actor
+ * weighs at most MPPI_LIGHT_BODY_MASS and the robot MPPI_LIGHT_BODY_RATIO times as much - heavier bodies carry pushing forces within
+ * millimetres under the explicit law, and keep it; not switched off by MPPI_CONTACT_EXPLICIT_LIGHT) takes the IMPLICIT law of a static partner on BOTH bodies,
+ * with the gains of the HEAVY one, staggered: with c = J^T (b 1 + (a - b) n n^T) J summed over the pair's points and f its spring wrench,
+ *   robot link X :  wrench = +-f - c (v_X+ - v_L)      c joins the link's articulated inertia (as for static geometry), the light
+ *                                                       body is a wall that moves with its velocity at the START of the substep;
+ *   light body L :  wrench = -+f - c (v_L+ - v_X+)     solved AFTER the robot, against the link's velocity at the END of the substep.
+ * Both solves are unconditionally stable (a squeeze between two fingers contracts by m / (m + h c) per substep); the light body is
+ * slaved to the links that hold it without a step of lag; what the robot feels of it is its weight and an added mass h c while it
+ * accelerates.  One record per contact-bearing pair carries c from the contact pass to the light body's solve. */
+typedef struct { int light, heavy; real C[36]; } light_pair_t;
+
+static int light_pair_mode(const mppi_model_t *m, const mppi_shape_t *A, const mppi_shape_t *B, real ma, real mb) {
+    if (m->contact_flags & MPPI_CONTACT_EXPLICIT_LIGHT) return 0;
+    const int ra = A->actor == m->robot_actor, rb = B->actor == m->robot_actor;
+    if (ra == rb) return 0;                                  /* a robot link against a free actor */
+    const real mh = ra ? ma : mb, ml = ra ? mb : ma;
+    return ml <= (real)MPPI_LIGHT_BODY_MASS && mh >= (real)MPPI_LIGHT_BODY_RATIO * ml;
+}
+
+static void scene_contacts(const mppi_model_t *m, const scene_info_t *si, frame_t *fr, const real *root, real *cf, light_pair_t *lp, int *n_lp) {
     real h = (real)(m->dt / m->substeps);
+    *n_lp = 0;
     int nf = m->n_bodies + si->nb + MPPI_MAX_FREE;
     g_ramp_depth = (real)m->contact_ramp_depth;
     for (int e = 0; e < nf; e++) { memset(fr[e].f, 0, sizeof fr[e].f); memset(fr[e].C, 0, sizeof fr[e].C); }
@@ -835,7 +865,10 @@ static void scene_contacts(const mppi_model_t *m, const scene_info_t *si, frame_
         real mua = (real)A->friction, mub = B ? (real)B->friction : (real)m->ground_friction;
         real mu = mua < mub ? mua : mub;
         int mode; real meff;
-        if (ma > 0 && mb > 0) { mode = 0; meff = ma * mb / (ma + mb); }
+        if (ma > 0 && mb > 0) {
+            mode = 0; meff = ma * mb / (ma + mb);
+            if (light_pair_mode(m, A, B, ma, mb)) { mode = 3; meff = ma > mb ? ma : mb; }
+        }
         else if (ma > 0) { mode = 1; meff = ma; }
         else { mode = 2; meff = mb; }
         int tb = B ? B->type : -1;
@@ -846,7 +879,8 @@ static void scene_contacts(const mppi_model_t *m, const scene_info_t *si, frame_
          * is divided by max(npts, sum of the points' ramps): the stiffness of the patch never exceeds the nominal one, and it is
          * continuous in the number of points that take part */
         const real npts_nom = npts;
-        if (mode == 0) npts = 1;
+        const int dyn = mode == 0 || mode == 3;   /* two dynamic bodies: patch-normalised, one normal per pair of boxes */
+        if (dyn) npts = 1;
         real k = (real)m->contact_alpha * meff / (h * h) / npts, cn = (real)m->contact_beta * meff / h / npts;
         real ct = (real)m->friction_beta * meff / h / npts, kh = (real)m->contact_alpha * meff / h / npts;
         shape_w_t wa, wb;
@@ -879,7 +913,7 @@ static void scene_contacts(const mppi_model_t *m, const scene_info_t *si, frame_
         } else {
             shape_world(m, B, eb, fr, root, &wb);
             if (A->type == MPPI_SHAPE_BOX && B->type == MPPI_SHAPE_BOX) {
-                if (mode == 0 && !(m->contact_flags & MPPI_CONTACT_POINT_NORMALS)) {
+                if (dyn && !(m->contact_flags & MPPI_CONTACT_POINT_NORMALS)) {
                     box_sat_t sat;
                     box_pair_sat(&wa, A->size, &wb, B->size, &sat);
                     if (sat.hit) {
@@ -891,6 +925,7 @@ static void scene_contacts(const mppi_model_t *m, const scene_info_t *si, frame_
                             memset(&one, 0, sizeof one);
                             contact_point(mode, mu, k, cn, ct, kh, sat.p, sat.n, sat.depth, wa.v, wb.v, &one);
                             for (int l = 0; l < 6; l++) acc.f[l] += deficit * one.f[l];
+                            for (int l = 0; l < 36; l++) acc.C[l] += deficit * one.C[l];   /* (mode 3; zero in mode 0) */
                             for (int l = 0; l < 3; l++) acc.rep[l] += deficit * one.rep[l];
                             acc.wsum += deficit * one.wsum;
                             acc.any = 1;
@@ -921,11 +956,23 @@ static void scene_contacts(const mppi_model_t *m, const scene_info_t *si, frame_
             }
         }
         if (!acc.any) continue;
-        if (mode == 0) {
+        if (dyn) {
             const real sc = 1 / (acc.wsum > npts_nom ? acc.wsum : npts_nom);
             for (int j = 0; j < 6; j++) acc.f[j] *= sc;
+            for (int j = 0; j < 36; j++) acc.C[j] *= sc;
             for (int j = 0; j < 3; j++) acc.rep[j] *= sc;
+        }
+        if (mode == 0) {
             for (int j = 0; j < 6; j++) { fr[ea].f[j] += acc.f[j]; fr[eb].f[j] -= acc.f[j]; }
+        } else if (mode == 3) {
+            const int heavy = ma > mb ? ea : eb, light = ma > mb ? eb : ea;
+            real Cv[6];
+            m6_vec(acc.C, fr[light].v, Cv);            /* the light body as a moving wall: + c v_L(start) on the link */
+            for (int j = 0; j < 6; j++) { fr[ea].f[j] += acc.f[j]; fr[eb].f[j] -= acc.f[j]; fr[heavy].f[j] += Cv[j]; }
+            for (int j = 0; j < 36; j++) { fr[ea].C[j] += acc.C[j]; fr[eb].C[j] += acc.C[j]; }
+            lp[*n_lp].light = light; lp[*n_lp].heavy = heavy;
+            memcpy(lp[*n_lp].C, acc.C, sizeof acc.C);
+            (*n_lp)++;
         } else if (mode == 1) {
             for (int j = 0; j < 6; j++) fr[ea].f[j] += acc.f[j];
             for (int j = 0; j < 36; j++) fr[ea].C[j] += acc.C[j];
@@ -1100,7 +1147,9 @@ void orc_scene_step(const mppi_model_t *m, real *root, real *q, real *qd, const 
     real *cf = (real *)calloc(3 * (size_t)m->n_rb + 3, sizeof(real));
     for (int s = 0; s < m->substeps; s++) {
         scene_frames(m, &si, root, q, qd, fr);
-        scene_contacts(m, &si, fr, root, cf);
+        light_pair_t lp[MPPI_MAX_PAIRS];
+        int n_lp = 0;
+        scene_contacts(m, &si, fr, root, cf, lp, &n_lp);
         real ff[NBMAX], vs[NBMAX], tau[NBMAX], kdh[NBMAX], qdd[NBMAX], abase[NBASEMAX][6];
         for (int i = 0; i < n; i++) {
             ff[i] = m->drive_mode == MPPI_DRIVE_EFFORT ? target[i] : (m->drive_mode == MPPI_DRIVE_POSITION ? kp * (target[i] - q[i]) : 0);
@@ -1129,6 +1178,26 @@ void orc_scene_step(const mppi_model_t *m, real *root, real *q, real *qd, const 
         }
         if (si.floating)
             for (int r = 0; r < si.nb; r++) root_integrate(root + 13 * base_actor(m, r), abase[r], h);
+        /* light bodies held by robot links (light_pair_t): the links' spatial velocities at the END of the substep - the new joint
+         * rates (after the velocity and joint limits) on the joint axes of the substep's poses, bases v + h a - enter their solve */
+        if (n_lp > 0) {
+            real vn[NFMAX][6];
+            for (int r = 0; r < si.nb; r++) for (int j = 0; j < 6; j++) vn[n + r][j] = si.floating ? fr[n + r].v[j] + h * abase[r][j] : 0;
+            for (int i = 0; i < n; i++) {
+                const mppi_body_t *b = &m->bodies[i];
+                real ax[3] = {(real)b->axis[0], (real)b->axis[1], (real)b->axis[2]}, aw[3], t[3], Sw[6];
+                m3_vec(fr[i].R, ax, aw);
+                if (b->jtype == MPPI_JOINT_REVOLUTE) { cross3(fr[i].p, aw, t); for (int j = 0; j < 3; j++) { Sw[j] = aw[j]; Sw[3 + j] = t[j]; } }
+                else for (int j = 0; j < 3; j++) { Sw[j] = 0; Sw[3 + j] = aw[j]; }
+                const real *vp = b->parent < 0 ? vn[n + (-1 - b->parent)] : vn[b->parent];
+                for (int j = 0; j < 6; j++) vn[i][j] = vp[j] + Sw[j] * qd[i];
+            }
+            for (int l = 0; l < n_lp; l++) {
+                real Cv[6];
+                m6_vec(lp[l].C, vn[lp[l].heavy], Cv);
+                for (int j = 0; j < 6; j++) fr[lp[l].light].f[j] += Cv[j];
+            }
+        }
         for (int f = 0; f < si.n_free; f++) {
             int a = si.free_actor[f];
             const mppi_actor_t *A = &m->actors[a];

@@ -41,8 +41,10 @@ int emu_rollout(const mppi_model_t *model, const mppi_config_t *cfg, const mppi_
         using T = decltype(topo);
         std::vector<float> v(viz ? (size_t)c.H * 3 * c.K : 0);
         if (is_scene(m)) {
-            std::vector<float> lmem(SceneLayout<T>::floats(m.n_rb, m.n_rnd, m.n_shapes));
+            std::vector<float> lmem(scene_row_floats<T>(m));
             LMem L{lmem.data(), 1};
+            L.lp = lmem.data() + scene_light_base<T>(m);   // (records of the light bodies' pairs: the tail of the rows)
+            L.lstride = 1;
             // as the rollout kernels do: start state relative to the robot's start position (mppi_scene.hpp root_relative)
             std::vector<float> rel(13 * m.n_actors);
             root_origin(m, root0, L.ox, L.oy);
@@ -127,8 +129,10 @@ int emu_scene_step_g(const mppi_model_t *model, float *dof, float *root, const f
     for (int i = 0; i < m.nb; i++) parents[i] = m.b[i].k0.parent;
     bool ok = dispatch_topology(m.nb, parents, [&](auto topo) {
         using T = decltype(topo);
-        std::vector<float> lmem(SceneLayout<T>::floats(m.n_rb, m.n_rnd, m.n_shapes));
+        std::vector<float> lmem(scene_row_floats<T>(m));
         LMem L{lmem.data(), 1};
+        L.lp = lmem.data() + scene_light_base<T>(m);
+        L.lstride = 1;
         SceneState<T> s;
         scene_init<T>(m, dof, root, s, sample_id, L);
         float target[MPPI_MAX_BODIES + 1], uu[kMaxNu] = {0};

@@ -730,3 +730,97 @@ def test_two_fixed_base_robots_of_an_env_meet_each_other(oracle64, tmp_path):
         assert 0.38 < min(gap) and 0.39 < gap[-1] < 0.4005, (off, min(gap), gap[-1])
         f1, f2 = cf[scene.rigid_body_index("point_robot", "base_link")], cf[scene.rigid_body_index("point_robot2", "base_link")]
         assert f1[0] < -1.0 and np.allclose(f1, -f2, atol=1e-9), (f1, f2)      # pushed apart, equal and opposite
+
+
+# ---------------------------------------------------------------- a light body held by robot links (round 6)
+def _gripper_over_block(oracle, explicit=False, gap=0.0205):
+    """panda_pick with the 40-mm, 1-gram block between the opened fingers (0.37 mm clear of each pad), in free air."""
+    from scipy.spatial.transform import Rotation as Rot
+    from mppiisaac.backend import capi
+    scene, m, cfg, cost, dof, root = panda_pick(K=8, H=4)
+    if explicit:
+        m.contact_flags |= capi.CONTACT_EXPLICIT_LIGHT
+    q, qd, ro = dof[0::2].astype(float).copy(), dof[1::2].astype(float).copy(), root.astype(float).copy()
+    q[7] = q[8] = gap
+    rb, _ = oracle.rigid_body_state(m, ro, q, qd)
+    lf, rf = scene.rigid_body_index("panda", "panda_leftfinger"), scene.rigid_body_index("panda", "panda_rightfinger")
+    blk = scene.actor_index("panda_pick_block")
+    Rl = Rot.from_quat(rb[lf, 3:7]).as_matrix()
+    ro[blk, :3] = 0.5 * (rb[lf, :3] + rb[rf, :3]) + Rl @ np.array([0.0, 0.0, 0.035])   # pads: 0 .. 54 mm along the finger's z
+    ro[blk, 3:7] = rb[lf, 3:7]
+    ro[blk, 7:13] = 0.0
+
+    def pad_centre(q_, qd_):
+        r, _ = oracle.rigid_body_state(m, ro, q_, qd_)
+        return 0.5 * (r[lf, :3] + r[rf, :3]) + Rot.from_quat(r[lf, 3:7]).as_matrix() @ np.array([0.0, 0.0, 0.035]), Rot.from_quat(r[lf, 3:7]).as_matrix()
+    return scene, m, q, qd, ro, blk, pad_centre
+
+
+def test_a_gripper_holds_and_lifts_a_one_gram_block(oracle64):
+    """reference examples/panda_pick (planner.py:24-53, conf/actors/panda_pick_block.yaml: mass 0.001): PhysX's implicit solver lets
+    the fingers close ON the block and the arm lift it (isaacgym_wrapper.py:29-36).  The explicit law of two dynamic bodies is as
+    stiff as the LIGHTER one can carry - 1.3 N/m: the finger drives close the fingers through the block (asserted below: that is
+    what MPPI_CONTACT_EXPLICIT_LIGHT restores).  With the pair implicit on both bodies ("light bodies"):
+    the fingers stop at the block's faces (< 2 mm in), the arm lifts 10 cm and the block follows within 5 mm, and at rest in
+    the closed gripper it creeps by less than 1 mm/s."""
+    scene, m, q, qd, ro, blk, pad_centre = _gripper_over_block(oracle64)
+    close = np.zeros(9); close[7] = close[8] = -0.1            # finger velocity drives (kd = 600, 20 N limit)
+    for _ in range(8):
+        ro, q, qd, cf = oracle64.scene_step(m, ro, q, qd, close)
+    pen = 0.5 * (0.040 - (q[7] + q[8] - 2 * 0.000133))          # pads' inner faces sit 0.133 mm inside the finger frames
+    assert 0.0 < pen < 2e-3, pen
+    assert abs(q[7] - q[8]) < 4e-3                              # the block is between the fingers, not squeezed out
+    pc0, R0 = pad_centre(q, qd)
+    off0 = R0.T @ (ro[blk, :3] - pc0)
+    assert np.abs(off0[:2]).max() < 1e-3 and abs(off0[2]) < 8e-3   # (it fell 6 mm before the pads had it)
+    squeeze = np.linalg.norm(cf[scene.rigid_body_index("panda", "panda_leftfinger")])
+    assert 15.0 < squeeze < 25.0                                # the drives' 20 N, not the 240 N of the first touch
+    lift = close.copy(); lift[1] = -0.3                         # shoulder up: the hand rises at ~8 cm/s
+    z0 = ro[blk, 2]
+    worst = 0.0
+    for _ in range(26):
+        ro, q, qd, cf = oracle64.scene_step(m, ro, q, qd, lift)
+        pc, R = pad_centre(q, qd)
+        worst = max(worst, np.abs(R.T @ (ro[blk, :3] - pc) - off0).max())
+    assert ro[blk, 2] - z0 > 0.10                               # lifted by more than 10 cm ...
+    assert worst < 5e-3, worst                                  # ... and never more than 5 mm from where the pads took it
+    for _ in range(20):
+        ro, q, qd, cf = oracle64.scene_step(m, ro, q, qd, close)
+    pc, R = pad_centre(q, qd)
+    rb, _ = oracle64.rigid_body_state(m, ro, q, qd)
+    v_pad = rb[scene.rigid_body_index("panda", "panda_leftfinger"), 7:10]
+    rel = R.T @ (ro[blk, 7:10] - v_pad)
+    assert abs(rel[2]) < 1e-3 and abs(rel[0]) < 1e-3, rel       # no creep along the pads (z: gravity)
+    assert np.abs(R.T @ (ro[blk, :3] - pc) - off0).max() < 5e-3
+    # the law of rounds 1-5: the fingers meet in the middle of the block
+    scene, m, q, qd, ro, blk, pad_centre = _gripper_over_block(oracle64, explicit=True)
+    for _ in range(8):
+        ro, q, qd, cf = oracle64.scene_step(m, ro, q, qd, close)
+    assert q[7] + q[8] < 0.005
+
+
+@pytest.mark.parametrize("lanes", [1, 8])
+def test_light_body_pairs_device_arithmetic_matches_oracle(lanes, hostemu, oracle64):
+    """the same grasp through the host build of the device functions (fp32, pair evaluated about the block's centre, records in
+    the sample's rows; lanes = 8: feature points dealt over an emulated octet), re-synchronised with the fp64 oracle every step"""
+    scene, m, q, qd, ro, blk, pad_centre = _gripper_over_block(oracle64)
+    close = np.zeros(9); close[7] = close[8] = -0.1
+    lift = close.copy(); lift[1] = -0.3
+    rb = np.zeros((m.n_rb, 13), np.float32)
+    cf = np.zeros((m.n_rb, 3), np.float32)
+    hostemu.emu_set_scene_split(lanes)
+    try:
+        worst_p = worst_v = worst_f = 0.0
+        for u, n in ((close, 8), (lift, 12), (close, 6)):
+            for _ in range(n):
+                de = np.zeros(18, np.float32)
+                de[0::2], de[1::2] = q, qd
+                re = f32(ro).copy()
+                assert hostemu.emu_scene_step(C.byref(m), fp(de), fp(re.reshape(-1)), fp(f32(u)), fp(rb), fp(cf)) == 0
+                ro, q, qd, cfo = oracle64.scene_step(m, ro, q, qd, u)
+                worst_p = max(worst_p, np.abs(re[:, 0:3] - ro[:, 0:3]).max(), np.abs(de[0::2] - q).max())
+                worst_v = max(worst_v, np.abs(re[blk, 7:10] - ro[blk, 7:10]).max(), np.abs(de[1::2] - qd).max())
+                worst_f = max(worst_f, np.abs(cf - cfo).max() / max(1.0, np.abs(cfo).max()))
+        assert worst_p < 2e-5 and worst_v < 2e-3 and worst_f < 5e-3, (worst_p, worst_v, worst_f)
+    finally:
+        hostemu.emu_set_scene_split(1)
