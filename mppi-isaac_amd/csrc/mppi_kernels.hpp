@@ -970,10 +970,11 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW))
     scene_table_fill(M, tab, threadIdx.x, kWave * NW);
     LMem L{lds + slot, SPW, tab};
     L.cm = 11 * slot;
-    if (M.n_light_pairs != 0) {   // records of the light bodies' pairs: the tail of the sample's rows (scene_row_floats)
-        L.lp = lds + slot + (size_t)scene_light_base<T>(M) * SPW;
-        L.lstride = SPW;
-    }
+    if constexpr (NW == 1)
+        if (M.n_light_pairs != 0) {   // records of the light bodies' pairs: the tail of the sample's rows (scene_row_floats)
+            L.lp = lds + slot + (size_t)scene_light_base<T>(M) * SPW;
+            L.lstride = SPW;
+        }
     // octet layout of the solve (mppi_scene_oct.hpp): the linear lanes read the bodies' inertia blocks from a copy without inertia
     // tensors; lane i stages body i
     constexpr bool kOctSolve = OSOLVE;

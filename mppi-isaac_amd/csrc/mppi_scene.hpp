@@ -247,8 +247,9 @@ MPPI_HD ActorDraw actor_draw_slot(M &m, int slot, float mu_nominal, const LMem &
 // floats of one sample's LDS rows in the kernels whose lanes share a sample (incl. the shape-pose cache)
 template <class T, class M>
 MPPI_HD int scene_light_base(M &m) { return SceneLayout<T>::floats(m.n_rb, m.n_rnd, m.n_shapes); }
-// records of the light bodies' pairs (see "light bodies"): kLightSlots x { wrench on the light body f'(6), damping C'(21), heavy frame | free slot << 8 }
-constexpr int kLightSlots = 4, kLightSlotFloats = 28, kLightFloats = kLightSlots * kLightSlotFloats;
+// the light body's region (see "light bodies"): wrench f'(6) and damping C'(21) of its pairs with robot links about its own centre, the
+// reference frame, then kLightSlots records { link = its own joint, (sum of the link's C') S_joint (6) }
+constexpr int kLightRow = 27, kLightRef = 27, kLightRec = 28, kLightSlots = 4, kLightSlotFloats = 7, kLightFloats = kLightRec + kLightSlots * kLightSlotFloats;
 template <class T, class M>
 MPPI_HD int scene_row_floats(M &m) { return SceneLayout<T>::floats(m.n_rb, m.n_rnd, m.n_shapes) + (m.n_light_pairs != 0 ? kLightFloats : 0); }
 
@@ -559,7 +560,6 @@ MPPI_HD void contact_point(const Gains &P, V3 p, V3 n, float depth, const SV &vA
     // most part throws a 22-gram finger link whose drive has saturated back out of the contact substep after substep; the ramp - over
     // 1 / MPPI_LIGHT_RAMP_DIV of that depth, PairGain::inv_d0 - shapes their stick damper and their patch weights)
     float a = P.mode >= 3 ? P.cn + P.kh : ramp * (P.cn + P.kh);
-    if (P.mode >= 3) acc.wsum += ramp;
     {  // never adhesive at the start velocity: a <= k depth / v_n while separating (branch-free; the raw reciprocal is enough)
 #if defined(__HIP_DEVICE_COMPILE__)
         const float cap = P.k * depth * __builtin_amdgcn_rcpf(fmaxf(vn, 1e-30f));
@@ -575,6 +575,7 @@ MPPI_HD void contact_point(const Gains &P, V3 p, V3 n, float depth, const SV &vA
     const float b = fminf(ctr, P.mu * fn * frcp(vtn + 1e-9f));
     const V3 f = (P.k * depth) * n;
     acc.f = {acc.f.a + cross(p, f), acc.f.l + f};
+    if (P.mode >= 3) acc.wsum += ramp;  // (a light body's pair: patch weight)
     // C6 = J^T (b 1 + (a-b) n n^T) J,  J = [-[p]x  1]
     const float ab = a - b;
     const V3 mm = cross(p, n);
@@ -1164,9 +1165,9 @@ MPPI_HD AI light_shift(const AI &c, V3 o) {
 }
 MPPI_HD SV light_shift(const SV &f, V3 o) { return SV{f.a + cross(o, f.l), f.l}; }          // wrench about o -> about the world origin
 MPPI_HD SV light_motion_at(const SV &v, V3 o) { return SV{v.a, v.l + cross(v.a, o)}; }      // motion about the world origin -> about o
-// spatial velocities of the robot's frames at the END of the substep into the frames' velocity rows (their start-of-substep values
-// are not read again): the new joint rates - after the velocity and joint limits - on the joint axes of the substep's poses, a
-// floating base from its integrated root row
+// how far the spatial velocities of the robot's frames CHANGED over the substep, into the frames' velocity rows (their start-of-substep
+// values are not read again): the new joint rates - after the velocity and joint limits - on the joint axes of the substep's poses,
+// a floating base from its integrated root row, minus what the rows held
 template <class T, class M>
 MPPI_HD void light_link_velocities(M &m, const SceneState<T> &s, const LMem &L, bool leader) {
     constexpr int NB = T::NB;
@@ -1178,7 +1179,8 @@ MPPI_HD void light_link_velocities(M &m, const SceneState<T> &s, const LMem &L, 
         vb[r] = m.floating ? SV{w, vl - cross(w, loadv(bs))} : SV{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
         if (m.floating && leader) {
             const int o = (NB + r) * 18;
-            L[o + 12] = vb[r].a.x; L[o + 13] = vb[r].a.y; L[o + 14] = vb[r].a.z; L[o + 15] = vb[r].l.x; L[o + 16] = vb[r].l.y; L[o + 17] = vb[r].l.z;
+            L[o + 12] = vb[r].a.x - L[o + 12]; L[o + 13] = vb[r].a.y - L[o + 13]; L[o + 14] = vb[r].a.z - L[o + 14];
+            L[o + 15] = vb[r].l.x - L[o + 15]; L[o + 16] = vb[r].l.y - L[o + 16]; L[o + 17] = vb[r].l.z - L[o + 17];
         }
     });
     SV v[NB ? NB : 1];
@@ -1191,7 +1193,10 @@ MPPI_HD void light_link_velocities(M &m, const SceneState<T> &s, const LMem &L, 
         const SV sj = m.b[i].k0.jtype == 0 ? SV{qd * az, qd * cross(p, az)} : SV{{0.f, 0.f, 0.f}, qd * az};
         if constexpr (par < 0) v[i] = vb[base_of_parent(par)] + sj;
         else v[i] = v[par < 0 ? 0 : par] + sj;
-        if (leader) { L[o + 12] = v[i].a.x; L[o + 13] = v[i].a.y; L[o + 14] = v[i].a.z; L[o + 15] = v[i].l.x; L[o + 16] = v[i].l.y; L[o + 17] = v[i].l.z; }
+        if (leader) {
+            L[o + 12] = v[i].a.x - L[o + 12]; L[o + 13] = v[i].a.y - L[o + 13]; L[o + 14] = v[i].a.z - L[o + 14];
+            L[o + 15] = v[i].l.x - L[o + 15]; L[o + 16] = v[i].l.y - L[o + 16]; L[o + 17] = v[i].l.z - L[o + 17];
+        }
     });
 }
 
@@ -1302,8 +1307,11 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
     // with such pairs the one-wavefront kernels): all free at the start of the pass
     int n_light = 0;
     if constexpr (!kPair)
-        if (m.n_light_pairs != 0 && split.sub == 0)
-            for (int sl = 0; sl < kLightSlots; sl++) L.lt(sl * kLightSlotFloats + 27) = __builtin_bit_cast(float, -1);
+        if (m.n_light_pairs != 0 && (!split_on_device(SPLIT) || split.sub == 0)) {
+            for (int j = 0; j < kLightRow; j++) L.lt(j) = 0.f;
+            L.lt(kLightRef) = __builtin_bit_cast(float, -1);
+            for (int sl = 0; sl < kLightSlots; sl++) L.lt(kLightRec + sl * kLightSlotFloats) = __builtin_bit_cast(float, -1);
+        }
     if constexpr (kPair) {
         // dealt over both wavefronts (the owner posing all shapes before the first barrier, one barrier less, measured the same)
         shape_cache_update<T, true>(m, root, L, Split{split.sub + split.n * split.wave, 2 * split.n}, false);
@@ -1707,36 +1715,57 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
         if (pair_normal && sat.hit) box_pair_fill(P, rel, wa, hA, wb, hB, sat.n, acc);
         if (dyn && acc.any) pair_normalise(P, acc);
         if (light && acc.any) {
-            // ("light bodies") robot link: +-f + C' v_L(start) and C', shifted to the world origin, into the link's rows like a static
-            // contact's; light body: -+f and C' with the link's frame into the next free record (a fifth pair: onto the last one)
+            // ("light bodies"; everything here is about the light body's centre `lo`)
+            //   robot link X:  -+f + C v_L(start) and C, shifted to the world origin, into the link's rows like a static contact's;
+            //   light body L:  +-f + C v_X(start) and C into the row of the light region; the link's parent frame competes for the
+            //                  reference frame (nearest the base wins), (C S) of the link's own joint goes into the link's record
             const bool heavyA = G.mode == 3;
-            const int eh = heavyA ? G.entA : entB, el = heavyA ? entB : G.entA;
+            const int eh = heavyA ? G.entA : entB;
             const SV fA = acc.f, fB = {{-acc.f.a.x, -acc.f.a.y, -acc.f.a.z}, {-acc.f.l.x, -acc.f.l.y, -acc.f.l.z}};
-            const SV Cv = mul(acc.C, heavyA ? wb.v : wa.v);
-            const SV fh = light_shift((heavyA ? fA : fB) + Cv, lo), fl = heavyA ? fB : fA;
+            const SV CvL = mul(acc.C, heavyA ? wb.v : wa.v), CvX = mul(acc.C, heavyA ? wa.v : wb.v);
+            const SV fh = light_shift((heavyA ? fA : fB) + CvL, lo), fl = (heavyA ? fB : fA) + CvX;
             const AI Ch = light_shift(acc.C, lo);
-            const int sl = n_light < kLightSlots ? n_light : kLightSlots - 1;
-            const bool fresh = n_light < kLightSlots;
-            n_light++;
-            const int o = sl * kLightSlotFloats;
-            const float rec[27] = {fl.a.x, fl.a.y, fl.a.z, fl.l.x, fl.l.y, fl.l.z, acc.C.I.xx, acc.C.I.xy, acc.C.I.xz, acc.C.I.yy, acc.C.I.yz, acc.C.I.zz,
-                                   acc.C.H[0], acc.C.H[1], acc.C.H[2], acc.C.H[3], acc.C.H[4], acc.C.H[5], acc.C.H[6], acc.C.H[7], acc.C.H[8],
-                                   acc.C.M.xx, acc.C.M.xy, acc.C.M.xz, acc.C.M.yy, acc.C.M.yz, acc.C.M.zz};
+            const float rec[kLightRow] = {fl.a.x, fl.a.y, fl.a.z, fl.l.x, fl.l.y, fl.l.z, acc.C.I.xx, acc.C.I.xy, acc.C.I.xz, acc.C.I.yy, acc.C.I.yz, acc.C.I.zz,
+                                          acc.C.H[0], acc.C.H[1], acc.C.H[2], acc.C.H[3], acc.C.H[4], acc.C.H[5], acc.C.H[6], acc.C.H[7], acc.C.H[8],
+                                          acc.C.M.xx, acc.C.M.xy, acc.C.M.xz, acc.C.M.yy, acc.C.M.yz, acc.C.M.zz};
             const int ocf = kCfW + 3 * G.rbA, ob = kCfW + 3 * rbB;
             cf_touched |= (1u << (G.rbA & 31)) | (1u << (rbB & 31));
             touched |= 1u << eh;
+            // the link's own joint about lo, and (the pair's C') S; its parent frame (a shape on a moving base: the base itself)
+            constexpr int NBl = T::NB;
+            const bool on_body = eh < NBl;
+            const int ehb = on_body ? eh : 0;
+            const V3 az = {L[ehb * 18 + 2], L[ehb * 18 + 5], L[ehb * 18 + 8]}, pl = V3{L[ehb * 18 + 9], L[ehb * 18 + 10], L[ehb * 18 + 11]} - lo;
+            const SV Sj = m.b[ehb].k0.jtype == 0 ? SV{az, cross(pl, az)} : SV{{0.f, 0.f, 0.f}, az};
+            const SV gj = mul(acc.C, Sj);
+            const int parj = T::par[ehb];
+            const int par = !on_body ? eh : (parj < 0 ? NBl + (-1 - parj) : parj);
+            auto key = [](int f) MPPI_LAMBDA { return f < NBl ? f + T::NBASE : f - NBl; };   // (bases first, then the bodies in their order)
             const bool leader = !split_on_device(SPLIT) || split.sub == 0;
             if (leader) {
-                if (fresh) {
-                    for (int j = 0; j < 27; j++) L.lt(o + j) = rec[j];
-                    L.lt(o + 27) = __builtin_bit_cast(float, eh | ((el - free_frame<T>(0)) << 8));
-                } else {
-                    for (int j = 0; j < 27; j++) L.lt(o + j) += rec[j];
+                for (int j = 0; j < kLightRow; j++) L.lt(j) += rec[j];
+                const int ref = __builtin_bit_cast(int, L.lt(kLightRef));
+                if (ref < 0 || key(par) < key(ref)) L.lt(kLightRef) = __builtin_bit_cast(float, par);
+                if (on_body) {
+                    int k = 0;
+                    while (k < kLightSlots) {
+                        const int jk = __builtin_bit_cast(int, L.lt(kLightRec + k * kLightSlotFloats));
+                        if (jk == eh || jk < 0) break;
+                        k++;
+                    }
+                    if (k < kLightSlots) {   // (a fifth link in contact in one substep: its own joint's change is not passed on)
+                        const int o = kLightRec + k * kLightSlotFloats;
+                        const bool fresh = __builtin_bit_cast(int, L.lt(o)) < 0;
+                        L.lt(o) = __builtin_bit_cast(float, eh);
+                        const float g6[6] = {gj.a.x, gj.a.y, gj.a.z, gj.l.x, gj.l.y, gj.l.z};
+                        for (int j = 0; j < 6; j++) L.lt(o + 1 + j) = (fresh ? 0.f : L.lt(o + 1 + j)) + g6[j];
+                    }
                 }
                 acc_add(L, kAccW, eh, fh, &Ch);
                 L[ocf] += acc.rep.x; L[ocf + 1] += acc.rep.y; L[ocf + 2] += acc.rep.z;
                 L[ob] -= acc.rep.x; L[ob + 1] -= acc.rep.y; L[ob + 2] -= acc.rep.z;
             }
+            n_light++;
         } else
         if (acc.any) {
             const SV neg = {{-acc.f.a.x, -acc.f.a.y, -acc.f.a.z}, {-acc.f.l.x, -acc.f.l.y, -acc.f.l.z}};
@@ -1998,7 +2027,9 @@ MPPI_HD void scene_frames(M &m, const float *root, const SceneState<T> &s, Pose<
 // free rigid bodies (frames and accumulators of this substep in L): (I + h C) a = -(v x* I v + C v - f - f_g)
 // `set1` > 0: the accumulator rows are the sum of the owner's set and the helper wavefront's set at that row offset
 // (kSplitOctPair: the helper solves the free actors while the owner solves the robot)
-template <class T, class M>
+// LIGHT: the kernel can have light bodies (never the one with a helper wavefront, whose helper calls this with LIGHT = false: its
+// 256-register budget carries none of that code)
+template <class T, bool LIGHT = true, class M>
 MPPI_HD SV free_body_accel(M &m, int f, const LMem &L, float h, int set1 = 0) {
     constexpr int NB = T::NB;
     auto &F = m.fr[f];
@@ -2022,11 +2053,12 @@ MPPI_HD SV free_body_accel(M &m, int f, const LMem &L, float h, int set1 = 0) {
     AI A;
     SV pA;
     V3 hw;
-    if (m.n_light_pairs != 0 && ((m.light_free >> f) & 1u) != 0u && L.lp != nullptr) {
-        // a LIGHT body ("light bodies" above): solved about its own centre o = p against the END-of-substep velocities of the robot
-        // links that touch it (light_link_velocities has put them into the frames' rows):
-        //   (I + h (C_s' + sum C_r')) a = -(v x* I v + C_s' v - f_s' - f_g) + sum [ f_r' + C_r' (v_X+ - v) ]
-        // C_s, f_s: its contacts with static geometry (the accumulator rows, shifted from the world origin to o), r: the records
+    if (LIGHT && m.n_light_pairs != 0 && ((m.light_free >> f) & 1u) != 0u && L.lp != nullptr) {
+        // the LIGHT body ("light bodies" above), solved about its own centre o = p:
+        //   (I + h (C_s + C')) a = -(v x* I v + (C_s + C') v - f_s - f' - f_g) + C' dv_ref + sum_X (C' S)_X dqd_X
+        // C_s, f_s: its contacts with static geometry (the accumulator rows, shifted from the world origin to o); C', f': its pairs with
+        // robot links (the light region's row: already about o, f' holds +-f + C v_X(start)); the links' velocity changes over the substep
+        // (light_link_velocities has put them into the frames' rows) enter through the reference frame and the links' records
         const SV vo = light_motion_at(v, p);
         rigid_world(R, V3{0.f, 0.f, 0.f}, fm, V3{0.f, 0.f, 0.f}, Ic6, vo, A, pA, hw);
         SV fs;
@@ -2035,18 +2067,30 @@ MPPI_HD SV free_body_accel(M &m, int f, const LMem &L, float h, int set1 = 0) {
         const V3 mo = {-p.x, -p.y, -p.z};
         SV fe = light_shift(fs, mo);
         AI C = light_shift(Cs, mo);
+        AI Cr;
+        Cr.I = {L.lt(6), L.lt(7), L.lt(8), L.lt(9), L.lt(10), L.lt(11)};
+        for (int j = 0; j < 9; j++) Cr.H[j] = L.lt(12 + j);
+        Cr.M = {L.lt(21), L.lt(22), L.lt(23), L.lt(24), L.lt(25), L.lt(26)};
+        add_to(C, Cr);
+        fe = {fe.a + V3{L.lt(0), L.lt(1), L.lt(2)}, fe.l + V3{L.lt(3), L.lt(4), L.lt(5)}};
+        // the links' velocity changes over the substep: (sum C') dv_ref + sum_links (C' S)_link dqd_link  (oracle light_pair_t)
+        const int ref = __builtin_bit_cast(int, L.lt(kLightRef));
+        if (ref >= 0) {
+            const SV d = mul(Cr, light_motion_at(frame_velocity(L, ref), p));
+            fe = {fe.a + d.a, fe.l + d.l};
+        }
         for (int sl = 0; sl < kLightSlots; sl++) {
-            const int o = sl * kLightSlotFloats;
-            const int tag = __builtin_bit_cast(int, L.lt(o + 27));
-            if (tag < 0 || (tag >> 8) != f) continue;
-            AI Cr;
-            Cr.I = {L.lt(o + 6), L.lt(o + 7), L.lt(o + 8), L.lt(o + 9), L.lt(o + 10), L.lt(o + 11)};
-            for (int j = 0; j < 9; j++) Cr.H[j] = L.lt(o + 12 + j);
-            Cr.M = {L.lt(o + 21), L.lt(o + 22), L.lt(o + 23), L.lt(o + 24), L.lt(o + 25), L.lt(o + 26)};
-            const SV vx = light_motion_at(frame_velocity(L, tag & 255), p);
-            const SV Cvx = mul(Cr, vx);
-            fe = {fe.a + V3{L.lt(o), L.lt(o + 1), L.lt(o + 2)} + Cvx.a, fe.l + V3{L.lt(o + 3), L.lt(o + 4), L.lt(o + 5)} + Cvx.l};
-            add_to(C, Cr);
+            const int o = kLightRec + sl * kLightSlotFloats;
+            const int j = __builtin_bit_cast(int, L.lt(o));
+            if (j < 0) break;
+            // dqd of joint j from the frames' rows: S_j dqd_j = dv_j - dv_parent(j)
+            const int pj = T::par[j];
+            const SV dj = frame_velocity(L, j), dp = frame_velocity(L, pj < 0 ? NB + (-1 - pj) : pj);
+            const V3 az = {L[j * 18 + 2], L[j * 18 + 5], L[j * 18 + 8]}, pw = {L[j * 18 + 9], L[j * 18 + 10], L[j * 18 + 11]};
+            const SV Sj = m.b[j].k0.jtype == 0 ? SV{az, cross(pw, az)} : SV{{0.f, 0.f, 0.f}, az};
+            const SV dd = {dj.a - dp.a, dj.l - dp.l};
+            const float dqd = dot(Sj, dd) * frcp(dot(Sj, Sj));
+            fe = {fe.a + dqd * V3{L.lt(o + 1), L.lt(o + 2), L.lt(o + 3)}, fe.l + dqd * V3{L.lt(o + 4), L.lt(o + 5), L.lt(o + 6)}};
         }
         const V3 g = F.gravity ? V3{m.g[0], m.g[1], m.g[2]} : V3{0.f, 0.f, 0.f};
         const SV Cv = mul(C, vo);
@@ -2086,7 +2130,7 @@ __device__ __forceinline__ void helper_free_bodies(M &m, const LMem &L, Split sp
     const float h = m.h;
     for (int f = 0; f < kFreeSlots; f++)
         if (f < m.n_free) {
-            const SV a = free_body_accel<T>(m, f, L, h, L.set1);
+            const SV a = free_body_accel<T, false>(m, f, L, h, L.set1);
             if (split.sub == 0) {
                 const int o = L.xch + 2 + 6 * f;
                 L[o] = a.a.x; L[o + 1] = a.a.y; L[o + 2] = a.a.z; L[o + 3] = a.l.x; L[o + 4] = a.l.y; L[o + 5] = a.l.z;

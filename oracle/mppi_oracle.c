@@ -422,6 +422,7 @@ typedef struct {
 
 typedef struct {
     int is_scene, floating, n_free, free_actor[MPPI_MAX_FREE];
+    int light[MPPI_MAX_ACTORS];  /* the actor is a LIGHT free body (see scene_contacts) */
     int nb;                      /* bases of the forest (1 + n_extra_bases): dynamic frames n_bodies .. n_bodies + nb - 1 */
     real robot_mass[NBASEMAX];   /* mass of the tree that hangs off base r (contact gains scale with the reacting robot's mass) */
 } scene_info_t;
@@ -435,6 +436,23 @@ static void scene_info(const mppi_model_t *m, scene_info_t *si) {
     for (int r = 0; r < si->nb; r++) si->robot_mass[r] = base_mass_of(m, r);
     for (int i = 0; i < m->n_bodies; i++) si->robot_mass[base_of_body(m, i)] += (real)m->bodies[i].mass;
     si->is_scene = si->floating || si->n_free > 0 || m->n_pairs > 0;
+    /* light bodies (see scene_contacts): a free actor of at most MPPI_LIGHT_BODY_MASS that the robot outweighs MPPI_LIGHT_BODY_RATIO
+     * times and that has no candidate pair with another free actor */
+    for (int a = 0; a < MPPI_MAX_ACTORS; a++) si->light[a] = 0;
+    if (!(m->contact_flags & MPPI_CONTACT_EXPLICIT_LIGHT))
+        for (int f = 0; f < si->n_free; f++) {
+            const int a = si->free_actor[f];
+            int ok = m->actors[a].mass <= MPPI_LIGHT_BODY_MASS && (double)si->robot_mass[0] >= MPPI_LIGHT_BODY_RATIO * m->actors[a].mass;
+            for (int ip = 0; ip < m->n_pairs && ok; ip++) {
+                if (m->pairs[ip].b < 0) continue;
+                const int aa = m->shapes[m->pairs[ip].a].actor, ab = m->shapes[m->pairs[ip].b].actor;
+                if (aa != a && ab != a) continue;
+                const int other = aa == a ? ab : aa;
+                for (int g = 0; g < si->n_free; g++) if (si->free_actor[g] == other) ok = 0;
+            }
+            si->light[a] = ok;
+            if (ok) break;   /* (one light body per scene: what the kernels carry) */
+        }
 }
 int orc_is_scene(const mppi_model_t *m) { scene_info_t si; scene_info(m, &si); return si.is_scene; }
 
@@ -826,28 +844,44 @@ static int shape_entity(const mppi_model_t *m, const scene_info_t *si, const mpp
     return -1;
 }
 
-/* A LIGHT free body against a link of a much heavier robot (round 6; a 1-gram block between the fingers of an arm, reference
- * examples/panda_pick, conf/actors/panda_pick_block.yaml - PhysX's implicit solver holds and lifts it, isaacgym_wrapper.py:29-36):
- * the explicit law of two dynamic bodies is as stiff as the LIGHTER body can carry in an explicit step (1.3 N/m for one gram at
- * h = 25 ms - a finger drive closes the fingers THROUGH the block) and its stick damper creeps at g h.  Such a pair (the free actor
- * weighs at most MPPI_LIGHT_BODY_MASS and the robot MPPI_LIGHT_BODY_RATIO times as much - heavier bodies carry pushing forces within
- * millimetres under the explicit law, and keep it; not switched off by MPPI_CONTACT_EXPLICIT_LIGHT) takes the IMPLICIT law of a static partner on BOTH bodies,
- * with the gains of the HEAVY one, staggered: with c = J^T (b 1 + (a - b) n n^T) J summed over the pair's points and f its spring wrench,
- *   robot link X :  wrench = +-f - c (v_X+ - v_L)      c joins the link's articulated inertia (as for static geometry), the light
- *                                                       body is a wall that moves with its velocity at the START of the substep;
- *   light body L :  wrench = -+f - c (v_L+ - v_X+)     solved AFTER the robot, against the link's velocity at the END of the substep.
- * Both solves are unconditionally stable (a squeeze between two fingers contracts by m / (m + h c) per substep); the light body is
- * slaved to the links that hold it without a step of lag; what the robot feels of it is its weight and an added mass h c while it
- * accelerates.  One record per contact-bearing pair carries c from the contact pass to the light body's solve. */
-typedef struct { int light, heavy; real C[36]; } light_pair_t;
-
-static int light_pair_mode(const mppi_model_t *m, const mppi_shape_t *A, const mppi_shape_t *B, real ma, real mb) {
-    if (m->contact_flags & MPPI_CONTACT_EXPLICIT_LIGHT) return 0;
-    const int ra = A->actor == m->robot_actor, rb = B->actor == m->robot_actor;
-    if (ra == rb) return 0;                                  /* a robot link against a free actor */
-    const real mh = ra ? ma : mb, ml = ra ? mb : ma;
-    return ml <= (real)MPPI_LIGHT_BODY_MASS && mh >= (real)MPPI_LIGHT_BODY_RATIO * ml;
-}
+/* LIGHT bodies (round 6; the 1-gram block of the reference's examples/panda_pick between the fingers of a 17-kg arm,
+ * conf/actors/panda_pick_block.yaml - PhysX's implicit solver holds and lifts it, isaacgym_wrapper.py:29-36).  The explicit law of two
+ * dynamic bodies is as stiff as the LIGHTER body can carry in an explicit step (1.3 N/m for one gram at h = 25 ms - a finger drive
+ * closes the fingers THROUGH the block) and its stick damper creeps at g h.  A free actor of at most MPPI_LIGHT_BODY_MASS that the robot
+ * outweighs MPPI_LIGHT_BODY_RATIO times (heavier bodies carry pushing forces within millimetres under the explicit law, and keep it) and
+ * that touches no other free actor - scene_info_t.light; MPPI_CONTACT_EXPLICIT_LIGHT switches it off - takes, against a robot link X
+ * (mode 3; geometry and patch normalisation as for two dynamic bodies):
+ *   - the ROBOT's gains (k = alpha m_robot / h^2 ...) and the implicit point law with damper and end-of-step spring NOT ramped
+ *     (contact_point, law 3: the ramp - over 1 / MPPI_LIGHT_RAMP_DIV of the static sag - shapes the stick damper and the patch weights);
+ *   - implicit on BOTH bodies, staggered.  With c = J^T (b 1 + (a - b) n n^T) J summed over the pair's points and f its spring wrench on L,
+ *         link X :  wrench = -f - c (v_X+ - v_L)     c joins the link's articulated inertia like a static contact's, the light body is a
+ *                                                    wall that moves with its velocity at the START of the substep;
+ *         body L :  wrench = +f - c (v_L+ - v_X+)    solved AFTER the robot:  f + c v_X - c v_L+  at the contact pass, and the links'
+ *                                                    velocity CHANGES over the substep, dv_X = v_X+ - v_X, as
+ *                                                        (sum_X c_X) dv_ref + sum_X (c_X S_X) dqd_X
+ *                                                    ref = the frame nearest the base among the PARENTS of the links in contact, S_X /
+ *                                                    dqd_X the link's own joint axis / rate change: exact when the links in contact
+ *                                                    hang off one parent (two fingers on a hand) - their relative motion is what a
+ *                                                    pinch is made of -, and one substep late only for joints between `ref` and a
+ *                                                    link's parent (hand AND fingers in contact: the wrist roll under the fingers).
+ *                                                    light_pair_t carries sum c, ref and up to LIGHT_RECORDS vectors c_X S_X.
+ *     (Tried and dropped: every link's change through an effective contact POINT - a force where the patch has a damping matrix:
+ *     what falls into a direction the patch damps weakly spins a gram to 1000 rad/s; all changes through one common reference
+ *     link - two fingers both a substep late: the pinch rings at the substep rate for ever.)
+ *     Both solves are unconditionally stable (a squeeze between two fingers contracts by m / (m + h c) per substep); the light body
+ *     follows the links that hold it without a substep of lag; what the robot feels of it is its weight and an added mass h c while
+ *     it accelerates.
+ * Its contacts with STATIC geometry (table, ground) keep the law of modes 1 / 2 with the gains of its own mass: at rest it lies still to
+ * 1e-7 m/s in the sag of that law; with the robot's gains and no ramp the equilibrium depth of a gram is half a micrometre and the
+ * nine feature points of a face toggle in and out of contact for ever (tried: a rocking of 0.3 rad/s that never dies).  The price: a
+ * finger can press the block INTO the table until the finger itself meets it. */
+#define LIGHT_RECORDS 4
+typedef struct {   /* per light body */
+    int light, ref;                  /* its frame; the reference frame (below) */
+    real C[36];                      /* sum of c over its pairs with robot links */
+    int n_rec, joint[LIGHT_RECORDS]; /* links in contact: their own joints ... */
+    real g[LIGHT_RECORDS][6];        /* ... with (sum of the link's c) S_joint */
+} light_pair_t;
 
 static void scene_contacts(const mppi_model_t *m, const scene_info_t *si, frame_t *fr, const real *root, real *cf, light_pair_t *lp, int *n_lp) {
     real h = (real)(m->dt / m->substeps);
@@ -865,12 +899,13 @@ static void scene_contacts(const mppi_model_t *m, const scene_info_t *si, frame_
         real mua = (real)A->friction, mub = B ? (real)B->friction : (real)m->ground_friction;
         real mu = mua < mub ? mua : mub;
         int mode; real meff;
-        if (ma > 0 && mb > 0) {
-            mode = 0; meff = ma * mb / (ma + mb);
-            if (light_pair_mode(m, A, B, ma, mb)) { mode = 3; meff = ma > mb ? ma : mb; }
-        }
+        if (ma > 0 && mb > 0) { mode = 0; meff = ma * mb / (ma + mb); }
         else if (ma > 0) { mode = 1; meff = ma; }
         else { mode = 2; meff = mb; }
+        /* a light body's pair: the robot's gains and law 3; against a robot link: mode 3 (implicit on both bodies) */
+        const int la = si->light[A->actor], lb = B ? si->light[B->actor] : 0;
+        int law = mode;
+        if ((la || lb) && mode == 0) { mode = law = 3; meff = la ? mb : ma; }
         int tb = B ? B->type : -1;
         real npts = (A->type == MPPI_SHAPE_BOX && (tb == MPPI_SHAPE_BOX || tb == -1)) ? 4 : 1;
         /* two dynamic bodies (explicit law): a fixed 1/npts share per point lets a face-to-face contact of 18 feature points
@@ -895,11 +930,11 @@ static void scene_contacts(const mppi_model_t *m, const scene_info_t *si, frame_
                     real t[3], pw[3];
                     m3_vec(wa.R, loc, t);
                     for (int j = 0; j < 3; j++) pw[j] = wa.p[j] + t[j];
-                    if (pw[2] < 0) contact_point(mode, mu, k, cn, ct, kh, pw, ez, -pw[2], wa.v, ZERO6, &acc);
+                    if (pw[2] < 0) contact_point(law, mu, k, cn, ct, kh, pw, ez, -pw[2], wa.v, ZERO6, &acc);
                 }
             } else if (A->type == MPPI_SHAPE_SPHERE) {
                 real pw[3] = {wa.p[0], wa.p[1], wa.p[2] - (real)A->size[0]};
-                if (pw[2] < 0) contact_point(mode, mu, k, cn, ct, kh, pw, ez, -pw[2], wa.v, ZERO6, &acc);
+                if (pw[2] < 0) contact_point(law, mu, k, cn, ct, kh, pw, ez, -pw[2], wa.v, ZERO6, &acc);
             } else { /* disc: lowest rim point; axis = local z of the shape frame */
                 real ax[3] = {wa.R[2], wa.R[5], wa.R[8]};
                 real d[3] = {ax[2] * ax[0], ax[2] * ax[1], ax[2] * ax[2] - 1};
@@ -907,7 +942,7 @@ static void scene_contacts(const mppi_model_t *m, const scene_info_t *si, frame_
                 if (l2 > (real)1e-8) {
                     real sc = (real)A->size[0] / (real)sqrt((double)l2), pw[3];
                     for (int j = 0; j < 3; j++) pw[j] = wa.p[j] + sc * d[j];
-                    if (pw[2] < 0) contact_point(mode, mu, k, cn, ct, kh, pw, ez, -pw[2], wa.v, ZERO6, &acc);
+                    if (pw[2] < 0) contact_point(law, mu, k, cn, ct, kh, pw, ez, -pw[2], wa.v, ZERO6, &acc);
                 }
             }
         } else {
@@ -917,13 +952,13 @@ static void scene_contacts(const mppi_model_t *m, const scene_info_t *si, frame_
                     box_sat_t sat;
                     box_pair_sat(&wa, A->size, &wb, B->size, &sat);
                     if (sat.hit) {
-                        corners_along(mode, mu, k, cn, ct, kh, &wa, A->size, &wb, B->size, 1, sat.n, wa.v, wb.v, &acc);
-                        corners_along(mode, mu, k, cn, ct, kh, &wb, B->size, &wa, A->size, -1, sat.n, wa.v, wb.v, &acc);
+                        corners_along(law, mu, k, cn, ct, kh, &wa, A->size, &wb, B->size, 1, sat.n, wa.v, wb.v, &acc);
+                        corners_along(law, mu, k, cn, ct, kh, &wb, B->size, &wa, A->size, -1, sat.n, wa.v, wb.v, &acc);
                         const real deficit = (real)0.5 * npts_nom - acc.wsum;   /* (HALF the nominal patch, see above) */
                         if (deficit > 0) {
                             pair_acc_t one;
                             memset(&one, 0, sizeof one);
-                            contact_point(mode, mu, k, cn, ct, kh, sat.p, sat.n, sat.depth, wa.v, wb.v, &one);
+                            contact_point(law, mu, k, cn, ct, kh, sat.p, sat.n, sat.depth, wa.v, wb.v, &one);
                             for (int l = 0; l < 6; l++) acc.f[l] += deficit * one.f[l];
                             for (int l = 0; l < 36; l++) acc.C[l] += deficit * one.C[l];   /* (mode 3; zero in mode 0) */
                             for (int l = 0; l < 3; l++) acc.rep[l] += deficit * one.rep[l];
@@ -932,27 +967,27 @@ static void scene_contacts(const mppi_model_t *m, const scene_info_t *si, frame_
                         }
                     }
                 } else {
-                    corners_in_box(mode, mu, k, cn, ct, kh, &wa, A->size, &wb, B->size, 1, wa.v, wb.v, &acc);
-                    corners_in_box(mode, mu, k, cn, ct, kh, &wb, B->size, &wa, A->size, -1, wa.v, wb.v, &acc);
+                    corners_in_box(law, mu, k, cn, ct, kh, &wa, A->size, &wb, B->size, 1, wa.v, wb.v, &acc);
+                    corners_in_box(law, mu, k, cn, ct, kh, &wb, B->size, &wa, A->size, -1, wa.v, wb.v, &acc);
                 }
             } else if (A->type == MPPI_SHAPE_SPHERE && B->type == MPPI_SHAPE_BOX) {
-                sphere_in_box(mode, mu, k, cn, ct, kh, wa.p, (real)A->size[0], &wb, B->size, 1, wa.v, wb.v, &acc);
+                sphere_in_box(law, mu, k, cn, ct, kh, wa.p, (real)A->size[0], &wb, B->size, 1, wa.v, wb.v, &acc);
             } else if (A->type == MPPI_SHAPE_BOX && B->type == MPPI_SHAPE_SPHERE) {
-                sphere_in_box(mode, mu, k, cn, ct, kh, wb.p, (real)B->size[0], &wa, A->size, -1, wa.v, wb.v, &acc);
+                sphere_in_box(law, mu, k, cn, ct, kh, wb.p, (real)B->size[0], &wa, A->size, -1, wa.v, wb.v, &acc);
             } else if (A->type == MPPI_SHAPE_SPHERE && B->type == MPPI_SHAPE_SPHERE) {
-                sphere_sphere(mode, mu, k, cn, ct, kh, wa.p, (real)A->size[0], wb.p, (real)B->size[0], wa.v, wb.v, &acc);
+                sphere_sphere(law, mu, k, cn, ct, kh, wa.p, (real)A->size[0], wb.p, (real)B->size[0], wa.v, wb.v, &acc);
             } else if (A->type == MPPI_SHAPE_DISC && B->type == MPPI_SHAPE_BOX) {
                 real ax[3] = {wa.R[2], wa.R[5], wa.R[8]};
-                disc_in_box(mode, mu, k, cn, ct, kh, wa.p, ax, (real)A->size[0], &wb, B->size, 1, wa.v, wb.v, &acc);
+                disc_in_box(law, mu, k, cn, ct, kh, wa.p, ax, (real)A->size[0], &wb, B->size, 1, wa.v, wb.v, &acc);
             } else if (A->type == MPPI_SHAPE_BOX && B->type == MPPI_SHAPE_DISC) {
                 real ax[3] = {wb.R[2], wb.R[5], wb.R[8]};
-                disc_in_box(mode, mu, k, cn, ct, kh, wb.p, ax, (real)B->size[0], &wa, A->size, -1, wa.v, wb.v, &acc);
+                disc_in_box(law, mu, k, cn, ct, kh, wb.p, ax, (real)B->size[0], &wa, A->size, -1, wa.v, wb.v, &acc);
             } else if (A->type == MPPI_SHAPE_DISC && B->type == MPPI_SHAPE_SPHERE) {
                 real ax[3] = {wa.R[2], wa.R[5], wa.R[8]};
-                disc_sphere(mode, mu, k, cn, ct, kh, wa.p, ax, (real)A->size[0], wb.p, (real)B->size[0], 1, wa.v, wb.v, &acc);
+                disc_sphere(law, mu, k, cn, ct, kh, wa.p, ax, (real)A->size[0], wb.p, (real)B->size[0], 1, wa.v, wb.v, &acc);
             } else if (A->type == MPPI_SHAPE_SPHERE && B->type == MPPI_SHAPE_DISC) {
                 real ax[3] = {wb.R[2], wb.R[5], wb.R[8]};
-                disc_sphere(mode, mu, k, cn, ct, kh, wb.p, ax, (real)B->size[0], wa.p, (real)A->size[0], -1, wa.v, wb.v, &acc);
+                disc_sphere(law, mu, k, cn, ct, kh, wb.p, ax, (real)B->size[0], wa.p, (real)A->size[0], -1, wa.v, wb.v, &acc);
             }
         }
         if (!acc.any) continue;
@@ -965,14 +1000,34 @@ static void scene_contacts(const mppi_model_t *m, const scene_info_t *si, frame_
         if (mode == 0) {
             for (int j = 0; j < 6; j++) { fr[ea].f[j] += acc.f[j]; fr[eb].f[j] -= acc.f[j]; }
         } else if (mode == 3) {
-            const int heavy = ma > mb ? ea : eb, light = ma > mb ? eb : ea;
-            real Cv[6];
-            m6_vec(acc.C, fr[light].v, Cv);            /* the light body as a moving wall: + c v_L(start) on the link */
-            for (int j = 0; j < 6; j++) { fr[ea].f[j] += acc.f[j]; fr[eb].f[j] -= acc.f[j]; fr[heavy].f[j] += Cv[j]; }
+            const int heavy = la ? eb : ea, light = la ? ea : eb;
+            real CvL[6], CvX[6];
+            m6_vec(acc.C, fr[light].v, CvL);           /* the light body as a moving wall: + c v_L(start) on the link */
+            m6_vec(acc.C, fr[heavy].v, CvX);           /* ... and the link's start velocity on the light body */
+            for (int j = 0; j < 6; j++) { fr[ea].f[j] += acc.f[j]; fr[eb].f[j] -= acc.f[j]; fr[heavy].f[j] += CvL[j]; fr[light].f[j] += CvX[j]; }
             for (int j = 0; j < 36; j++) { fr[ea].C[j] += acc.C[j]; fr[eb].C[j] += acc.C[j]; }
-            lp[*n_lp].light = light; lp[*n_lp].heavy = heavy;
-            memcpy(lp[*n_lp].C, acc.C, sizeof acc.C);
-            (*n_lp)++;
+            light_pair_t *r = NULL;                   /* the light body's record */
+            const int n = m->n_bodies;
+            for (int l = 0; l < *n_lp; l++) if (lp[l].light == light) r = &lp[l];
+            if (!r) { r = &lp[(*n_lp)++]; memset(r, 0, sizeof *r); r->light = light; r->ref = -1; }
+            for (int j = 0; j < 36; j++) r->C[j] += acc.C[j];
+            /* parent frame of the link (a shape on a moving base: the base itself), nearest the base wins */
+            const int par = heavy >= n ? heavy : (m->bodies[heavy].parent < 0 ? n + (-1 - m->bodies[heavy].parent) : m->bodies[heavy].parent);
+            if (r->ref < 0 || (par >= n && r->ref < n) || (par < n && r->ref < n && par < r->ref)) r->ref = par;
+            if (heavy < n) {
+                int k = 0;
+                while (k < r->n_rec && r->joint[k] != heavy) k++;
+                if (k < LIGHT_RECORDS) {
+                    if (k == r->n_rec) { r->joint[k] = heavy; r->n_rec++; }
+                    const mppi_body_t *b = &m->bodies[heavy];
+                    real ax[3] = {(real)b->axis[0], (real)b->axis[1], (real)b->axis[2]}, aw[3], t[3], Sw[6], g6[6];
+                    m3_vec(fr[heavy].R, ax, aw);
+                    if (b->jtype == MPPI_JOINT_REVOLUTE) { cross3(fr[heavy].p, aw, t); for (int j = 0; j < 3; j++) { Sw[j] = aw[j]; Sw[3 + j] = t[j]; } }
+                    else for (int j = 0; j < 3; j++) { Sw[j] = 0; Sw[3 + j] = aw[j]; }
+                    m6_vec(acc.C, Sw, g6);
+                    for (int j = 0; j < 6; j++) r->g[k][j] += g6[j];
+                }
+            }
         } else if (mode == 1) {
             for (int j = 0; j < 6; j++) fr[ea].f[j] += acc.f[j];
             for (int j = 0; j < 36; j++) fr[ea].C[j] += acc.C[j];
@@ -1167,6 +1222,8 @@ void orc_scene_step(const mppi_model_t *m, real *root, real *q, real *qd, const 
         }
         if (g_sat_log) g_sat_log[g_sat_n++] = satmask;
         if (any) scene_aba(m, &si, fr, qd, tau, kdh, qdd, abase);
+        real qd_start[NBMAX];
+        for (int i = 0; i < n; i++) qd_start[i] = qd[i];
         for (int i = 0; i < n; i++) {
             const mppi_body_t *b = &m->bodies[i];
             real vmax = (real)b->velocity;
@@ -1179,10 +1236,15 @@ void orc_scene_step(const mppi_model_t *m, real *root, real *q, real *qd, const 
         if (si.floating)
             for (int r = 0; r < si.nb; r++) root_integrate(root + 13 * base_actor(m, r), abase[r], h);
         /* light bodies held by robot links (light_pair_t): the links' spatial velocities at the END of the substep - the new joint
-         * rates (after the velocity and joint limits) on the joint axes of the substep's poses, bases v + h a - enter their solve */
+         * rates (after the velocity and joint limits) on the joint axes of the substep's poses, a floating base from its integrated
+         * root row - minus those at its start, through the pair's effective contact, enter the light body's solve */
         if (n_lp > 0) {
             real vn[NFMAX][6];
-            for (int r = 0; r < si.nb; r++) for (int j = 0; j < 6; j++) vn[n + r][j] = si.floating ? fr[n + r].v[j] + h * abase[r][j] : 0;
+            for (int r = 0; r < si.nb; r++) {
+                frame_t tmp;
+                root_frame(root + 13 * base_actor(m, r), &tmp);
+                for (int j = 0; j < 6; j++) vn[n + r][j] = si.floating ? tmp.v[j] : 0;
+            }
             for (int i = 0; i < n; i++) {
                 const mppi_body_t *b = &m->bodies[i];
                 real ax[3] = {(real)b->axis[0], (real)b->axis[1], (real)b->axis[2]}, aw[3], t[3], Sw[6];
@@ -1193,9 +1255,13 @@ void orc_scene_step(const mppi_model_t *m, real *root, real *q, real *qd, const 
                 for (int j = 0; j < 6; j++) vn[i][j] = vp[j] + Sw[j] * qd[i];
             }
             for (int l = 0; l < n_lp; l++) {
-                real Cv[6];
-                m6_vec(lp[l].C, vn[lp[l].heavy], Cv);
-                for (int j = 0; j < 6; j++) fr[lp[l].light].f[j] += Cv[j];
+                const light_pair_t *r = &lp[l];
+                real dv[6], Cd[6];
+                for (int j = 0; j < 6; j++) dv[j] = vn[r->ref][j] - fr[r->ref].v[j];
+                m6_vec(r->C, dv, Cd);
+                for (int k = 0; k < r->n_rec; k++)
+                    for (int j = 0; j < 6; j++) Cd[j] += r->g[k][j] * (qd[r->joint[k]] - qd_start[r->joint[k]]);
+                for (int j = 0; j < 6; j++) fr[r->light].f[j] += Cd[j];
             }
         }
         for (int f = 0; f < si.n_free; f++) {

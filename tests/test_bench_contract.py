@@ -102,6 +102,32 @@ def test_plain_python_bench_gpus_2_launches_its_own_ranks():
     assert [r["dist_world_size"] for r in per_rank] == [2, 2] and [r["dist_rank"] for r in per_rank] == [0, 1]
 
 
+def test_plain_python_bench_gpus_8_as_the_driver_will_run_it():
+    """the driver's 8-GPU command, `python bench.py --gpus 8 --steps 20 --warmup 5`, before there is an 8-GPU node to run it on: eight
+    ranks launched by bench.py itself, here all on the one device (gloo staging, MPPI_BENCH_BACKEND) - ONE valid line, the weak row
+    at 8 x 4096 samples, BASELINE config 5 at its stated size as the strong row (65536 samples = 8192 per rank, H = 30), a report
+    from every rank, and the mailbox A/B pass that follows the result line (forced here: it needs no RCCL) leaves the exit code alone"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MPPI_BENCH_BACKEND="gloo", MPPI_BENCH_MAILBOX_AB="force", MPPI_BENCH_SHIPPED="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5"],
+                         capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = out.stdout.strip().splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["config"]["K_per_gpu"] == 4096 and d["config"]["K_total"] == 32768
+    assert d["value"] == pytest.approx(8 * d["config"]["loop_hz"], rel=1e-6) and d["value"] > 100.0
+    s5 = d["config"]["cfg5_strong"]
+    assert s5 is not None and s5["K_total"] == 65536 and s5["K_per_gpu"] == 8192 and s5["H"] == 30 and s5["loop_hz"] > 1.0
+    per_rank = d["config"]["exchange"]["per_rank"]
+    assert [r["dist_rank"] for r in per_rank] == list(range(8)) and all(r["dist_world_size"] == 8 for r in per_rank)
+    assert all("peer_access" in r for r in per_rank)
+    ab = [l for l in out.stderr.splitlines() if l.startswith("[bench] mailbox_ab ")]
+    assert len(ab) == 1, out.stderr[-3000:]
+    ab = json.loads(ab[0][len("[bench] mailbox_ab "):])
+    assert ab["n_gpus"] == 8 and len(ab["per_rank"]) == 8 and ab["selected"] in ("mailbox", "rccl") and ab["why"]
+
+
 def test_bench_two_ranks_exchange_through_the_library_mailbox():
     """the same two-rank launch with the library's own record exchange (mppi_mailbox_*): the two processes connect their inboxes
     through hipIpc handles, bench.py's probe compares three iterations of mailbox-gathered records with the all-gather bit for

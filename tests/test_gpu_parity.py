@@ -323,7 +323,7 @@ CLOSED_LOOP_STATES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "g
 
 @pytest.mark.parametrize("make,name,K,H,nu,states", [
     (boxer_push, "boxer_push", 8192, 25, 2, ("recorded", "68_9", "13_20")),
-    (panda_pick, "panda_pick", 8192, 30, 9, ("recorded", "77_20"))])
+    (panda_pick, "panda_pick", 8192, 30, 9, ("recorded", "held", "violent9", "violent20"))])
 def test_contact_rich_states_match_oracle(make, name, K, H, nu, states, lib, oracle64, monkeypatch):
     """BASELINE configs 4 and 5 where the controller actually works: `recorded` = the closed-loop state after some hundred
     iterations (block against the chassis and an obstacle / gripper over the block on the table; tests/golden/
@@ -341,6 +341,7 @@ def test_contact_rich_states_match_oracle(make, name, K, H, nu, states, lib, ora
     Z = np.load(CLOSED_LOOP_STATES)
     scene, m, cfg, cost, dof0, root0 = make(K=K, H=H)
     ex = load_config({"defaults": [{"mppi": name}, {"isaacgym": "normal"}]}, overrides={"mppi.num_samples": K, "mppi.horizon": H})
+    problems = []   # (every state is measured and printed before anything is asserted)
     for st in states:
         dof, root = Z[f"{name}_{st}_dof"], Z[f"{name}_{st}_root"]
         U = Z[f"{name}_{st}_U"] if f"{name}_{st}_U" in Z.files else np.zeros((H, nu), np.float32)
@@ -362,21 +363,42 @@ def test_contact_rich_states_match_oracle(make, name, K, H, nu, states, lib, ora
         print(fmt(f"{name} {st}", r) + f" | shared-lane vs one-lane kernel (K samples) within 1e-3 {np.mean(rl <= 1e-3):.4f} "
               f"1e-2 {np.mean(rl <= 1e-2):.4f} max {rl.max():.1e}")
         umax = max(abs(cfg.u_max[j]) for j in range(nu))
-        if st == "recorded":
-            # where the controller works: >= 98 % within 1e-3, 99.9 % within 1e-2 - and the samples beyond 1e-3 carry less than
+        lanes = (float(np.mean(rl <= 1e-3)), float(np.mean(rl <= 1e-2)))
+        light = name == "panda_pick"    # (round 6: the one-gram block's pairs with robot links are implicit on both bodies, robot's gains)
+        if st == "held":
+            # round 6, the gripper HOLDING the one-gram block in the air (tools/record_closed_loop_states.py panda_pick:70:400).  Nearly
+            # every rollout from here lets go of it - the sampled finger rates saturate at +-0.2 m/s - and a gram that is flicked,
+            # falls and bounces parts from its fp64 twin within steps (fp32 host build of the same arithmetic vs the oracle on the CPU:
+            # 97.7 % within 1e-4 after ONE step, 82 % after four).  Asserted is what the controller consumes: the weight the disagreeing
+            # samples carry, the normaliser, the nominal update - and that half of the samples still agree to 1e-2.
+            # Measured (profiles/r06c_gpu_tests.txt): 57 % within 1e-3, 83 % within 1e-2; weight beyond 1e-3: 7e-8 of eta; eta 1.8e-4;
+            # update 7e-5 = 4e-4 |u_max|.
+            want = [("weight", r["weight_mass_outside_1e-3"] < 1e-3), ("update", r["update_max_abs_diff"] <= 1e-2 * umax),
+                    ("eta", r["eta_rel_err"] < 1e-2), ("half within 1e-2", r["within_1e-2"] >= 0.5)]
+        elif st == "recorded":
+            # where the controller works: >= 99.5 % within 1e-3, 99.9 % within 1e-2 - and the samples beyond 1e-3 carry less than
             # 1e-3 of eta; swapping the kernel's weights for the oracle's moves the nominal update by < 1e-3 |u_max|
-            # measured (profiles/r04a_gpu_tests.txt, all 8192): pushing 99.87 % within 1e-3, max 4.6e-3; gripper 99.99 %, max 1.3e-3 with the
-            # quad-layout solve and 99.95 % / 4 samples up to 4.3e-2 with the octet-layout solve (r04k): rollouts amplify a last-bit
-            # difference by up to 4e4, WHICH samples sit on that edge depends on the rounding - the fp32 build of the
-            # oracle parts from the fp64 one on 3 samples of this state, max 4.3e-2 as well
-            assert r["within_1e-3"] >= 0.995 and r["within_1e-2"] >= 0.999
-            assert r["weight_mass_outside_1e-3"] < 1e-3 and r["update_max_abs_diff"] <= 1e-3 * umax
-            assert np.mean(rl <= 1e-3) >= 0.98 and np.mean(rl <= 1e-2) >= 0.998
+            # measured (profiles/r04a_gpu_tests.txt, all 8192): pushing 99.87 % within 1e-3, max 4.6e-3; gripper (round 4: the hand over the
+            # block, touching nothing) 99.99 %; round 6 (`recorded` = the hand AT the block on the table, fingers and palm touching it
+            # under the stiff light-body law): 99.72 % / 99.93 %, weight beyond 1e-3 3e-48 - but the nominal update moves by 1.4e-3 =
+            # 7e-3 |u_max|: the softmax of conf/mppi/panda_pick.yaml (lambda 0.05 on costs of 237) turns a cost difference of 1e-3 ABSOLUTE -
+            # 5e-6 relative, far inside every band above - into 2 % of a weight (fp32 host build vs oracle, 2048 samples on the CPU:
+            # the four samples that share 99.9 % of eta differ by 2e-5 ... 1.1e-3).  Bound for this scene: 2e-2 |u_max|.
+            want = [("within", r["within_1e-3"] >= 0.995 and r["within_1e-2"] >= 0.999), ("weight", r["weight_mass_outside_1e-3"] < 1e-3),
+                    ("update", r["update_max_abs_diff"] <= (2e-2 if light else 1e-3) * umax), ("lanes", lanes[0] >= 0.98 and lanes[1] >= 0.998)]
+        elif light and st == "violent20":
+            # the block in FREE FALL 5 cm under the opened gripper, 0.73 m/s, about to land on the table (sample 4685 of the `held` state's
+            # rollouts after 20 steps): every rollout's cost from here is decided by the landing - 26 |F_table| of the substep in which
+            # the corners arrive - and so is the order of the cheapest samples: 94 % within 1e-3, but the disagreeing 6 % INCLUDE the
+            # samples that carry the weight (502 beyond 1e-3 carrying all of eta, the update moves by 0.4).  Not a state the closed loop
+            # plans from (the cost of that rollout is 1500 x the median); kept as the measured worst case, asserted loosely.
+            want = [("within", r["within_1e-3"] >= 0.9 and r["within_1e-2"] >= 0.95), ("lanes", lanes[0] >= 0.9 and lanes[1] >= 0.95)]
         else:
             # measured: 99.7 - 99.99 % within 1e-3, 99.96 - 100 % within 1e-2 (the tumbling samples: max 0.17 / 0.13, weight 0)
-            assert r["within_1e-3"] >= 0.99 and r["within_1e-2"] >= 0.999
-            assert r["weight_mass_outside_1e-3"] < 1e-3 and r["update_max_abs_diff"] <= 1e-2 * umax
-            assert np.mean(rl <= 1e-3) >= 0.96 and np.mean(rl <= 1e-2) >= 0.99
+            want = [("within", r["within_1e-3"] >= 0.99 and r["within_1e-2"] >= 0.999), ("weight", r["weight_mass_outside_1e-3"] < 1e-3),
+                    ("update", r["update_max_abs_diff"] <= 1e-2 * umax), ("lanes", lanes[0] >= 0.96 and lanes[1] >= 0.99)]
+        problems += [f"{name} {st}: {what}" for what, ok in want if not ok]
+    assert not problems, problems
 
 
 def test_single_call_evaluation_is_revalidated_and_dropped_when_the_objective_drifts(lib, monkeypatch):

@@ -47,9 +47,9 @@ def test_per_step_states_of_all_samples_against_the_oracle(make, name, K, H, nu,
     Z = np.load(CLOSED_LOOP_STATES)
     scene, m, cfg, cost, dof0, root0 = make(K=K, H=H)
     n_cmp = 12
-    for st in ("initial", "recorded"):
-        dof, root = (dof0, root0) if st == "initial" else (Z[f"{name}_recorded_dof"], Z[f"{name}_recorded_root"])
-        U = Z[f"{name}_recorded_U"] if st == "recorded" and f"{name}_recorded_U" in Z.files else np.zeros((H, nu), np.float32)
+    for st in ("initial", "recorded") + (("held",) if f"{name}_held_dof" in Z.files else ()):
+        dof, root = (dof0, root0) if st == "initial" else (Z[f"{name}_{st}_dof"], Z[f"{name}_{st}_root"])
+        U = Z[f"{name}_{st}_U"] if st != "initial" and f"{name}_{st}_U" in Z.files else np.zeros((H, nu), np.float32)
         c = Ctx(m, cfg, cost)
         c.call("mppi_sample", C.c_uint32(0)); c.set_state(dof, root); c.set_U(U)
         eps = c.get("mppi_get_noise", (H, nu, K))
@@ -71,6 +71,12 @@ def test_per_step_states_of_all_samples_against_the_oracle(make, name, K, H, nu,
         for t in range(n_cmp):
             print(f"   {t + 1:4d} |  {frac[t, 0]:.4f}   {frac[t, 1]:.4f}   {frac[t, 2]:.4f}   {frac[t, 3]:.4f} | {np.median(err[t]):.1e}  {err[t].max():.1e}")
         print("   more than 0.1 % of the samples outside a band from step: " + ", ".join(f"{b:g}: {'never (12 steps)' if s is None else s + 1}" for b, s in left.items()))
+        if st == "held":
+            # the gripper holding the one-gram block (round 6): rollouts that let go of it are chaotic from the first step on (see
+            # test_contact_rich_states_match_oracle) - asserted: 99 % within 1e-3 after the first step, the median sample within 1e-3
+            # after twelve, 80 % within 1e-2 throughout
+            assert frac[0, 2] >= 0.99 and np.median(err[-1]) <= 1e-3 and frac[:, 3].min() >= 0.8
+            continue
         # before the chaotic regime: EVERY sample within 1e-4 over the first steps, the typical sample within 1e-5 for all twelve
         assert err[:first_steps].max() <= 1e-4, err[:first_steps].max()
         assert np.median(err[-1]) <= 1e-4

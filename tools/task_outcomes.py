@@ -29,7 +29,7 @@ def pos(sim, actor):
     return sim._root_state[0, sim.scene.actor_index(actor), 0:3].cpu().numpy()
 
 
-LINKS = {"boxer": "ee_link", "heijn": "front_link", "panda": "panda_ee", "albert": "panda_ee", "omnipanda": "panda_ee", "jackal_a": "base_link", "anymal": "base"}
+LINKS = {"boxer": "ee_link", "heijn": "front_link", "panda": "panda_ee", "albert": "panda_ee", "omnipanda": "panda_hand", "jackal_a": "base_link", "anymal": "base"}
 
 
 def distances(name, sim):
