@@ -504,7 +504,8 @@ def facade_loop(wl_name, objective, device, steps, warmup, profile_to=None):
     finally:
         gc.enable()
     facade_loop.last_latency_ms = {"median": float(np.median(np.diff(stamps)) * 1e3), "p5": float(np.percentile(np.diff(stamps), 5) * 1e3),
-                                   "p95": float(np.percentile(np.diff(stamps), 95) * 1e3), "max": float(np.diff(stamps).max() * 1e3)}
+                                   "p95": float(np.percentile(np.diff(stamps), 95) * 1e3), "max": float(np.diff(stamps).max() * 1e3),
+                                   "over_1ms": [(int(i), round(float(v) * 1e3, 2)) for i, v in enumerate(np.diff(stamps)) if v > 1e-3][:12]}
     dist = None
     if wl_name == "panda_reach":
         ee = world.get_actor_link_by_name("panda", "panda_ee_tip")[0, 0:3].cpu().numpy()
@@ -526,6 +527,7 @@ def facade_loop(wl_name, objective, device, steps, warmup, profile_to=None):
             f.write(buf.getvalue())
     # which path ran: the in-kernel cost kind the planner bound (a traced Objective says so), or generic mode
     fc = planner.mppi._fused_cost
+    facade_loop.last_checks = getattr(planner.mppi, "trace_check_ms", None)
     facade_loop.last_mode = ("generic (torch on the simulated horizon)" if fc is None else
                              ("traced -> " if getattr(planner.mppi, "_trace_guard", None) is not None else "declared -> ") + f"in-kernel cost kind {fc.kind}")
     # (the K = 1 wrapper registers host mirrors that hold it alive - stop it explicitly, `del` alone leaks the context)
@@ -555,7 +557,7 @@ def facade_rows(wl_name, device):
         finally:
             os.environ.pop("MPPI_TRACE_OBJECTIVE", None)
         rows[key] = {"value": hz, "ms_per_step": ms, "steps": n, "final_ee_to_goal_m": dist, "latency_ms": facade_loop.last_latency_ms,
-                     "mode": facade_loop.last_mode}
+                     "mode": facade_loop.last_mode, "trace_validations_ms": facade_loop.last_checks}
     return rows
 
 

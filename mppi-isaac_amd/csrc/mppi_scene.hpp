@@ -566,9 +566,14 @@ MPPI_HD void contact_point(const Gains &P, V3 p, V3 n, float depth, const SV &vA
 #else
         const float cap = P.k * depth / fmaxf(vn, 1e-30f);
 #endif
-        a = vn > 0.f ? fminf(a, cap) : a;
+        // (a light body's pair: NO cap, and the Coulomb limit comes from the spring alone.  A contact that relaxes by alpha / (alpha + beta)
+        // per substep separates faster than its spring alone would push in every substep after an impact; the capped damper of the
+        // robot's gains on a 22-gram finger - h a = tens of kilograms - is honey: the finger keeps its rebound velocity until it has
+        // left the contact, its effort drive closes it again at full speed, the grip chatters with a period of four substeps and
+        // f_n = 0 drops the block.  Uncapped, the implicit solve balances spring, damper and drive within one substep.)
+        a = vn > 0.f && P.mode < 3 ? fminf(a, cap) : a;
     }
-    const float fn = fmaxf(0.f, P.k * depth - a * vn);
+    const float fn = P.mode >= 3 ? P.k * depth : fmaxf(0.f, P.k * depth - a * vn);
     // Coulomb friction as an implicit secant viscosity b = min(c_t, mu fn / |v_t|): equals the stick damper
     // at small slip, delivers mu*fn while sliding, and - being implicit - can never reverse the slip
     // velocity (an explicit mu*fn chatters: the yaw inertia seen by a wheel contact is far below the mass)
@@ -1123,22 +1128,35 @@ constexpr int kDealtBroadPhaseMin = 16;  // candidate pairs above which the quad
 // larger trees only: on the pushing scene (2-body tree, 11 pairs that are mostly near each other) the dealt pass is pure
 // overhead - measured +8 % on the octet kernel at equal state (1.386 -> 1.494 ms), as it was on the quad kernel
 // ---- light bodies ------------------------------------------------------------------------------
-// A free actor at least MPPI_LIGHT_BODY_RATIO times lighter than the robot that touches it (the 1-gram block of the reference's
+// A free actor of at most MPPI_LIGHT_BODY_MASS that the robot outweighs MPPI_LIGHT_BODY_RATIO times (the 1-gram block of the reference's
 // examples/panda_pick between the fingers of a 17-kg arm; PhysX's implicit solver holds and lifts it, isaacgym_wrapper.py:29-36).  The
 // explicit law of two dynamic bodies is as stiff as the LIGHTER body can carry in an explicit step - 1.3 N/m for one gram at
-// h = 25 ms: a finger drive closes the fingers THROUGH the block - and its stick damper creeps at g h.  Such a pair (PairGeom::mode
-// 3: A is the robot link, 4: B) takes the implicit law of a static partner on BOTH bodies with the HEAVY body's gains, staggered
-// (oracle: light_pair_t): with C = J^T (b 1 + (a - b) n n^T) J over the pair's points and f its spring wrench,
-//   robot link X:  wrench = +-f - C (v_X+ - v_L)    C joins the link's articulated inertia like a static contact's; the light body is a
+// h = 25 ms: a finger drive closes the fingers THROUGH the block - and its stick damper creeps at g h.  A pair of the light body with
+// a robot link (PairGeom::mode 3: A is the link, 4: B; mppi_pack.hpp: one light body per scene, none that touches another free actor)
+// takes the implicit law of a static partner on BOTH bodies with the ROBOT's gains, damper and end-of-step spring not ramped
+// (contact_point), staggered (oracle: light_pair_t).  With C = J^T (b 1 + (a - b) n n^T) J over the pair's points, f its spring wrench:
+//   robot link X:  wrench = -+f - C (v_X+ - v_L)    C joins the link's articulated inertia like a static contact's; the light body is a
 //                                                   wall that moves with its velocity at the START of the substep;
-//   light body L:  wrench = -+f - C (v_L+ - v_X+)   solved AFTER the robot, against the link's velocity at the END of the substep
-//                                                   (light_link_velocities): slaved to the links that hold it without a substep of lag.
+//   light body L:  wrench = +-f - C (v_L+ - v_X+)   solved AFTER the robot (free_body_accel): +-f + C v_X - C v_L+ from the contact pass,
+//                                                   and the links' velocity CHANGES over the substep as
+//                                                       (sum_X C_X) dv_ref + sum_X (C_X S_X) dqd_X
+//                                                   ref = the frame nearest the base among the PARENTS of the links in contact, S_X / dqd_X
+//                                                   the link's own joint axis / rate change (light_link_velocities): exact when the links
+//                                                   hang off one parent - two fingers on a hand: their relative motion is what a pinch is
+//                                                   made of -, one substep late only for joints between `ref` and a link's parent.
 // Both solves are unconditionally stable (a squeeze between two fingers contracts by m / (m + h C) per substep); what the robot feels of
-// the light body is its weight and an added mass h C while it accelerates.  fp32: the pair is evaluated in coordinates about the
-// light body's centre o - its 6x6 (inertia 1e-7 kg m^2 next to h C ~ 10 kg about the world origin) would lose the body's own
-// inertia to rounding otherwise; the robot's share is shifted to the world origin (light_shift), the light body's solve stays
-// about o (free_body_accel).  One record per contact-bearing pair carries (f', C', heavy frame) from the contact pass to that solve:
-// kLightSlots records per sample (a fifth simultaneous pair adds to the last record's).
+// the light body is its weight and an added mass h C while it accelerates.  Its contacts with STATIC geometry keep the law of modes
+// 1 / 2 with the gains of its own mass (at rest it lies still to 1e-7 m/s in that law's sag; with the robot's gains the nine feature
+// points of a face toggle in and out of a half-micrometre contact for ever).
+// fp32: the pair is evaluated in coordinates about the light body's centre `lo` - its 6x6 (inertia 1e-7 kg m^2 next to h C ~ 10 kg about
+// the world origin) would lose the body's own inertia to rounding otherwise; the robot's share is shifted to the world origin
+// (light_shift), the light body's solve stays about lo.  Storage: kLightFloats per sample - (f', C') about lo, the reference frame,
+// kLightSlots records (link, C S) - behind the sample's LDS rows (a per-lane array in the one-lane kernels): 56 floats, the gripper
+// scene's kernel keeps four workgroups per CU (a record of C per pair, 112 floats, took it to three: 1.87 -> 3.0 ms).
+// Tried and dropped (tests/test_scene_kat.py::test_light_body_law_survives_random_gripper_motion caught both): every link's change
+// through an effective contact POINT - a force where the patch has a damping matrix: what falls into a direction the patch damps weakly
+// spins a gram to 1000 rad/s -; all changes through one common reference link - two fingers both a substep late: the pinch rings at the
+// substep rate for ever.
 // 6x6 about the world origin from the one about the point o (motion E = [[1, 0], [-[o]x, 1]]: C_O = E^T C' E); o -> -o: the way back
 MPPI_HD AI light_shift(const AI &c, V3 o) {
     // G = [o]x H'^T (3x3), PM = [o]x M'

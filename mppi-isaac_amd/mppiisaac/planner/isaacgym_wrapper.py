@@ -295,6 +295,10 @@ class Scene:
     # measurements and for the known-answer tests of the laws before round 5
     ROBOT_ROBOT_PAIRS = _os.environ.get("MPPI_ROBOT_ROBOT_PAIRS", "1") != "0"
     BOX_PAIR_NORMAL = _os.environ.get("MPPI_BOX_PAIR_NORMAL", "1") != "0"
+    # round 6: a free actor of at most 0.25 kg that the robot outweighs 100 times is held IMPLICITLY by the links that touch it
+    # (mppi_model_t.contact_flags bit 1, DESIGN.md 3 "light bodies"; reference examples/panda_pick: the 1-gram block).  True restores the
+    # explicit law of rounds 1-5 - a gripper closes through the block - for measurements and the tests that show the difference
+    EXPLICIT_LIGHT = _os.environ.get("MPPI_EXPLICIT_LIGHT", "0") == "1"
     # The penalty contact's stiffness is tied to the integration step, k = alpha m / h^2 (what an explicit step of length h can carry):
     # a body at rest sags |g| h^2 / alpha into what it rests on - 7.7 mm at the 25 ms of conf/isaacgym/normal.yaml, 12 CENTIMETRES at
     # the 100 ms of conf/isaacgym/push.yaml (dt 0.1, substeps 1: fine for PhysX's implicit solver; here the block of heijn_push sank
@@ -544,7 +548,7 @@ class Scene:
         m.contact_alpha, m.contact_beta, m.friction_beta = self.CONTACT_ALPHA, self.CONTACT_BETA, self.FRICTION_BETA
         substeps = self.substeps()
         hsub = float(self.cfg.dt) / substeps
-        m.contact_flags = 0 if self.BOX_PAIR_NORMAL else capi.CONTACT_POINT_NORMALS
+        m.contact_flags = (0 if self.BOX_PAIR_NORMAL else capi.CONTACT_POINT_NORMALS) | (capi.CONTACT_EXPLICIT_LIGHT if self.EXPLICIT_LIGHT else 0)
         m.contact_ramp_depth = (abs(GRAVITY[2]) * hsub * hsub / self.CONTACT_ALPHA) if self.CONTACT_RAMP_DEPTH is None else float(self.CONTACT_RAMP_DEPTH)
         m.randomize_seed = int(self.randomize_seed)
         if self.robot.dof_mode not in DRIVE_GAINS:

@@ -293,6 +293,8 @@ class MPPIPlanner:
     def _trace_check(self, state) -> bool:
         """-> True when the traced program stands (the context then holds the FUSED rollout of this command, as on any other)"""
         lib, ctx = self._lib, self._ctx
+        import time
+        clk = [time.perf_counter()]
         capi.check(lib, lib.mppi_sim_reset(ctx))
         self.sim._needs_reset = False
         done = self._horizon_batched(state)
@@ -301,15 +303,24 @@ class MPPIPlanner:
                 self._horizon_eager(state)
             capi.check(lib, lib.mppi_sim_finish(ctx))
         self.sim._stale = True
-        S_py = self.get_costs()
+        clk.append(time.perf_counter())
+        S_py = self._costs_np()
+        clk.append(time.perf_counter())
         capi.check(lib, lib.mppi_rollout(ctx))
-        S_k = self.get_costs()
-        fin = torch.isfinite(S_py) & torch.isfinite(S_k)
-        scale = float(S_py[fin].abs().max().clamp_min(1e-6)) if bool(fin.any()) else 1.0
-        err = float((S_py[fin] - S_k[fin]).abs().max()) if bool(fin.any()) else 0.0
+        S_k = self._costs_np()
+        clk.append(time.perf_counter())
+        # (what the validations cost, for whoever reports rates: [Objective on the horizon, wait for its costs, fused rollout] in ms)
+        self.trace_check_ms = getattr(self, "trace_check_ms", []) + [[round(1e3 * (b - a), 3) for a, b in zip(clk, clk[1:])]]
+        # numpy, not torch, for the host-side comparison: a torch op on CPU tensors wakes the OpenMP pool - one spinning thread per
+        # hardware thread of the host (256 on the MI355X boxes) - and inside a container with a CPU quota (16 cores there) the whole
+        # process is then throttled for the rest of the scheduler period: measured as 50-70 ms stalls of kernel launches a few dozen
+        # commands AFTER a validation, one per ~180 commands, gone with OMP_NUM_THREADS=1 (tools/exp/facade_spikes.py)
+        fin = np.isfinite(S_py) & np.isfinite(S_k)
+        scale = max(float(np.abs(S_py[fin]).max()), 1e-6) if fin.any() else 1.0
+        err = float(np.abs(S_py[fin] - S_k[fin]).max()) if fin.any() else 0.0
         # (contact-free rollouts agree to fp32 rounding; the states of a contact scene's DUMP instantiation and of its fused one are the
         # same arithmetic, the costs differ by the Objective's own fp32 evaluation order)
-        if err <= 2e-3 * scale and bool((torch.isfinite(S_py) == torch.isfinite(S_k)).all()):
+        if err <= 2e-3 * scale and bool((np.isfinite(S_py) == np.isfinite(S_k)).all()):
             return True
         self._trace_guard[1](f"trajectory costs differ by {err:.3g} of {scale:.3g}")
         return False
@@ -759,10 +770,13 @@ class MPPIPlanner:
             self.sim.visualize_link_buffer = list(self._graph_viz)
         return True
 
-    def get_costs(self) -> torch.Tensor:
+    def _costs_np(self) -> np.ndarray:
         S = np.zeros(self.K, np.float32)
         capi.check(self._lib, self._lib.mppi_get_costs(self._ctx, capi.fptr(S)))
-        return torch.from_numpy(S)
+        return S
+
+    def get_costs(self) -> torch.Tensor:
+        return torch.from_numpy(self._costs_np())
 
 
 def _prior_row(p, nu: int) -> np.ndarray:

@@ -523,8 +523,16 @@ static void contact_point(int mode, real mu, real k, real cn, real ct, real kh, 
      * part throws a 22-gram finger link whose drive has saturated back out of the contact substep after substep, and with the full
      * damper an impact at closing speed loses alpha / (alpha + beta) of its penetration per substep without leaving the contact) */
     real a = mode == 3 ? cn + kh : ramp * (cn + kh);
-    if (vn > 0 && a * vn > k * depth) a = k * depth / vn;
+    if (mode != 3 && vn > 0 && a * vn > k * depth) a = k * depth / vn;
     real fn = k * depth - a * vn; if (fn < 0) fn = 0;
+    /* (mode 3: no cap, and the Coulomb limit is taken from the spring alone.  The cap replaces a by k depth / v_n whenever the pair
+     * separates faster than the spring alone would push it - which a contact that relaxes by alpha / (alpha + beta) per substep does in
+     * EVERY substep after an impact; with the robot's gains on a 22-gram finger that capped damper (h a = tens of kilograms) is honey:
+     * the finger keeps its rebound velocity until it has left the contact, its effort drive closes it again at full speed, and the
+     * grip chatters with a period of four substeps while f_n = 0 lets the block fall (omnipanda_effort, 6 N per finger).  Uncapped,
+     * the implicit solve puts the finger at the velocity where spring, damper and drive balance within one substep; the price is a
+     * contact that holds an OPENING finger back for the one or two substeps its last fraction of a millimetre takes to relax.) */
+    if (mode == 3) fn = k * depth;
     real b = mu * fn / (vtn + (real)1e-9); if (ct < b) b = ct;
     real f[3];
     for (int j = 0; j < 3; j++) f[j] = k * depth * n[j];

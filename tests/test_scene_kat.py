@@ -847,3 +847,44 @@ def test_light_body_law_survives_random_gripper_motion(oracle64):
             assert np.isfinite(ro1).all() and np.isfinite(q1).all() and np.isfinite(cf).all(), (trial, t)
             worst = max(worst, np.abs(ro1[blk, 7:10]).max())
     assert worst < 8.0, worst    # (free fall from the gripper to the ground: 2.6 m/s; a finger flicking it: a few m/s)
+
+
+def test_the_mobile_manipulator_holds_and_lifts_its_block(oracle64):
+    """reference examples/omni_panda_pick: the omnipanda (three base joints, arm, gripper; EFFORT drives, conf/actors/omnipanda_effort.yaml)
+    and the 0.1-kg block of conf/actors/block2.yaml - 427 times lighter than the robot, at most MPPI_LIGHT_BODY_MASS: a light body.  Closing
+    forces of 6 N per finger (conf/mppi/omnipanda_effort.yaml u_max) hold it against its weight of 1 N, a shoulder torque lifts it."""
+    from scipy.spatial.transform import Rotation as Rot
+    scene = build_scene(["omnipanda_effort", "xaxis", "yaxis", "block2", "table2", "goal"], [[1.0, 2.0, 0.0]], isaacgym="pick")
+    m = scene.to_c()
+    dof, root = scene.initial_state()
+    q, qd, ro = dof[0::2].astype(float).copy(), dof[1::2].astype(float).copy(), root.astype(float).copy()
+    q[10] = q[11] = 0.0205
+    rb, _ = oracle64.rigid_body_state(m, ro, q, qd)
+    lf, rf = scene.rigid_body_index("omnipanda", "panda_leftfinger"), scene.rigid_body_index("omnipanda", "panda_rightfinger")
+    blk = scene.actor_index("panda_pick_block")
+    Rl = Rot.from_quat(rb[lf, 3:7]).as_matrix()
+    ro[blk, :3] = 0.5 * (rb[lf, :3] + rb[rf, :3]) + Rl @ np.array([0.0, 0.0, 0.035])
+    ro[blk, 3:7] = rb[lf, 3:7]
+    ro[blk, 7:13] = 0.0
+    squeeze = np.zeros(12); squeeze[10] = squeeze[11] = -6.0
+
+    def pads_now():
+        rb, _ = oracle64.rigid_body_state(m, ro, q, qd)
+        hand = scene.rigid_body_index("omnipanda", "panda_hand")
+        pads = 0.5 * (rb[lf, :3] + rb[rf, :3]) + Rot.from_quat(rb[lf, 3:7]).as_matrix() @ np.array([0.0, 0.0, 0.035])
+        return pads, rb[hand, 7:10] + np.cross(rb[hand, 10:13], pads - rb[hand, :3])      # (the point of the hand between the pads)
+
+    for _ in range(10):
+        ro, q, qd, cf = oracle64.scene_step(m, ro, q, qd, squeeze)
+    z_held = ro[blk, 2]
+    pads, v_pads = pads_now()
+    # the pads stop at its faces (not closed to zero: the grip neither chatters nor lets it through) ...
+    assert 0.0 < 0.5 * (0.040 - (q[10] + q[11] - 2 * 0.000133)) < 2e-3
+    # ... and it hangs between them, 1 N of weight on 2 x 6 N of grip: it slipped by millimetres while the 0.5-mm gaps closed, and now moves
+    # with the hand (whose arm, effort-driven and without a torque, sags under the block's weight)
+    assert np.abs(ro[blk, :3] - pads).max() < 6e-3 and np.abs(ro[blk, 7:10] - v_pads).max() < 5e-3, (ro[blk, :3] - pads, ro[blk, 7:10] - v_pads)
+    lift = squeeze.copy(); lift[4] = -20.0                                         # shoulder torque (gravity is off for the arm)
+    for _ in range(20):
+        ro, q, qd, cf = oracle64.scene_step(m, ro, q, qd, lift)
+    pads, v_pads = pads_now()
+    assert ro[blk, 2] > z_held + 0.05 and np.abs(ro[blk, :3] - pads).max() < 0.012, (ro[blk, :3], pads)
