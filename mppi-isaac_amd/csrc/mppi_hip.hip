@@ -3,6 +3,7 @@
 // the generated topo_<i>.hip units and found through topo_table.inc.
 #include <atomic>
 #include <chrono>
+#include <cstring>
 #include <fstream>
 #include <mutex>
 #include <sstream>
@@ -210,7 +211,11 @@ namespace {
 
 std::mutex g_plugin_mu;
 std::vector<const TopoEntry *> g_plugins;   // entries of the plugins loaded so far (never unloaded)
-std::string g_jit_log;                        // what the last on-demand build did (mppi_jit_info)
+std::string g_jit_log;                        // what the last on-demand build did / what the running one is doing (mppi_jit_info)
+bool g_jit_building = false;                  // a build is running: mppi_jit_info adds the seconds it has taken so far
+std::chrono::steady_clock::time_point g_jit_t0;
+std::mutex g_jit_mu;                          // one on-demand build at a time per process (two threads asking for the same new tree)
+std::atomic<unsigned> g_jit_serial{0};        // build temporaries: pid + serial
 
 const char *const kJitFlags[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize"};   // = __graft_entry__.HIPCC_FLAGS
 const char *const kJitFreeFlags[] = {"-mllvm", "-amdgpu-sched-strategy=max-ilp"};                                     // = ILP_FLAGS (contact-free units)
@@ -244,12 +249,28 @@ bool file_exists(const std::string &p) {
     struct stat st;
     return stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode);
 }
+// the cache directory itself is created 0700 (its parents 0755)
 bool mkdir_p(const std::string &dir) {
     for (size_t i = 1; i <= dir.size(); i++)
         if (i == dir.size() || dir[i] == '/') {
             const std::string d = dir.substr(0, i);
-            if (mkdir(d.c_str(), 0755) != 0 && errno != EEXIST) return false;
+            if (mkdir(d.c_str(), i == dir.size() ? 0700 : 0755) != 0 && errno != EEXIST) return false;
         }
+    return true;
+}
+// code is loaded from the cache: directory and plugin must belong to this process's user and be writable by nobody else - a plugin's
+// file name is computable, and whoever can write there decides what mppi_create executes
+bool owned_and_private(const std::string &path, bool is_dir, std::string &why) {
+    struct stat st;
+    if (stat(path.c_str(), &st) != 0) { why = path + ": " + std::strerror(errno); return false; }
+    if (is_dir ? !S_ISDIR(st.st_mode) : !S_ISREG(st.st_mode)) { why = path + " is not a " + (is_dir ? "directory" : "regular file"); return false; }
+    if (st.st_uid != geteuid()) { why = path + " belongs to uid " + std::to_string((long)st.st_uid) + ", this process runs as " + std::to_string((long)geteuid()); return false; }
+    if (st.st_mode & (S_IWGRP | S_IWOTH)) {
+        char m[8];
+        std::snprintf(m, sizeof m, "%04o", (unsigned)(st.st_mode & 07777));
+        why = path + " is writable by group or others (mode " + m + ")";
+        return false;
+    }
     return true;
 }
 // FNV-1a over the kernel headers and the ABI header: a plugin is only ever loaded next to the sources it was built from
@@ -326,15 +347,19 @@ const TopoEntry *jit_topology(int nb, const int *parents, bool with_scene, int f
     name += std::string(with_scene ? "_scene" + std::to_string(free_slots) : "_free") + "_abi" + std::to_string(MPPI_ABI_VERSION) + "_" + kbuf;
     const std::string cdir = cache_dir();
     if (!mkdir_p(cdir)) { err = "cannot create the plugin cache directory " + cdir + " (MPPI_JIT_CACHE)"; return nullptr; }
+    std::string why_not;
+    if (!owned_and_private(cdir, true, why_not)) { err = "refusing the plugin cache directory: " + why_not + " (MPPI_JIT_CACHE names another one)"; return nullptr; }
     const std::string so = cdir + "/" + name + ".so";
     const auto t0 = std::chrono::steady_clock::now();
     bool built = false;
+    std::unique_lock<std::mutex> build_lock(g_jit_mu, std::defer_lock);
+    if (!retried) build_lock.lock();
     if (!file_exists(so)) {
         const std::string hipcc = find_hipcc();
         if (hipcc.empty()) { err = "no hipcc found (HIPCC, /opt/rocm/bin/hipcc): cannot build the kernels of this tree"; return nullptr; }
         std::string args;
         for (int i = 0; i < nb; i++) args += (i ? ", " : "") + std::to_string(parents[i]);
-        const std::string tmp = cdir + "/" + name + "." + std::to_string((long)getpid());
+        const std::string tmp = cdir + "/" + name + "." + std::to_string((long)getpid()) + "_" + std::to_string(g_jit_serial.fetch_add(1));
         const std::string inc = "#include \"" + dir + "/mppi_kernels.hpp\"\n";
         {
             std::ofstream f(tmp + "_free.hip");
@@ -355,6 +380,13 @@ const TopoEntry *jit_topology(int nb, const int *parents, bool with_scene, int f
         cfree.insert(cfree.end(), {"-c", "-o", tmp + "_free.o", tmp + "_free.hip"});
         std::fprintf(stderr, "[mppi_hip] building the kernels of kinematic tree [%s]%s with %s (one-off: cached as %s)\n", args.c_str(),
                      with_scene ? " incl. the contact-scene kernels" : "", hipcc.c_str(), so.c_str());
+        {   // (progress: mppi_jit_info from another thread says what this call is waiting for)
+            std::lock_guard<std::mutex> lk(g_plugin_mu);
+            g_jit_log = "building " + so + " (tree [" + args + "]" + (with_scene ? ", with the contact-scene kernels" : "") + ")";
+            g_jit_building = true;
+            g_jit_t0 = t0;
+        }
+        struct Done { ~Done() { std::lock_guard<std::mutex> lk(g_plugin_mu); g_jit_building = false; } } done_guard;
         jobs.emplace_back(spawn_to_log(cfree, tmp + "_free.log"), tmp + "_free.log");
         if (with_scene) {
             std::ofstream f(tmp + "_scene.hip");
@@ -381,11 +413,17 @@ const TopoEntry *jit_topology(int nb, const int *parents, bool with_scene, int f
             if (lp < 0 || !wait_ok(lp)) { ok = false; why += "\n--- link\n" + tail_of(tmp + "_link.log"); }
         }
         for (const char *sfx : {"_free.hip", "_free.o", "_scene.hip", "_scene.o"}) (void)unlink((tmp + sfx).c_str());
-        if (!ok) { err = "building the kernels of tree [" + args + "] failed:" + why; return nullptr; }
+        if (!ok) {
+            err = "building the kernels of tree [" + args + "] failed:" + why;
+            std::lock_guard<std::mutex> lk(g_plugin_mu);
+            g_jit_log = "failed: " + so;
+            return nullptr;
+        }
         for (const char *sfx : {"_free.log", "_scene.log", "_link.log"}) (void)unlink((tmp + sfx).c_str());
         if (rename((tmp + ".so").c_str(), so.c_str()) != 0) { err = "cannot move the built plugin into " + so; return nullptr; }   // (atomic: ranks may race)
         built = true;
     }
+    if (!owned_and_private(so, false, why_not)) { err = "refusing the cached plugin: " + why_not; return nullptr; }
     void *h = dlopen(so.c_str(), RTLD_NOW | RTLD_LOCAL);
     auto entry = h ? (const TopoEntry *(*)())dlsym(h, "mppi_plugin_entry") : nullptr;
     auto sizes = h ? (void (*)(size_t *))dlsym(h, "mppi_plugin_sizes") : nullptr;
@@ -421,11 +459,16 @@ extern "C" {
 
 const char *mppi_last_error(void) { return g_err.c_str(); }
 int mppi_abi_version(void) { return MPPI_ABI_VERSION; }
-/* what the last on-demand build of a kinematic tree did ("built <plugin> in 34.1 s" / "cached ..."); empty: none so far */
+/* what the last on-demand build of a kinematic tree did ("built <plugin> in 34.1 s" / "cached ..." / "failed: ..."), or - called from
+ * another thread while mppi_create blocks in one - what the running build is doing ("building <plugin> (tree [...]), 12 s so far");
+ * empty: none so far */
 int mppi_jit_info(char *buf, int buflen) {
     if (!buf || buflen < 1) return fail(MPPI_EINVAL, "null buffer");
     std::lock_guard<std::mutex> lk(g_plugin_mu);
-    std::snprintf(buf, buflen, "%s", g_jit_log.c_str());
+    if (g_jit_building)
+        std::snprintf(buf, buflen, "%s, %.0f s so far", g_jit_log.c_str(), std::chrono::duration<double>(std::chrono::steady_clock::now() - g_jit_t0).count());
+    else
+        std::snprintf(buf, buflen, "%s", g_jit_log.c_str());
     return MPPI_OK;
 }
 int mppi_device_count(int *count) {

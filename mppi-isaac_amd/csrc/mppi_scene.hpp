@@ -566,14 +566,16 @@ MPPI_HD void contact_point(const Gains &P, V3 p, V3 n, float depth, const SV &vA
 #else
         const float cap = P.k * depth / fmaxf(vn, 1e-30f);
 #endif
-        // (a light body's pair: NO cap, and the Coulomb limit comes from the spring alone.  A contact that relaxes by alpha / (alpha + beta)
+        // (a light body's pair: NO cap.  A contact that relaxes by alpha / (alpha + beta)
         // per substep separates faster than its spring alone would push in every substep after an impact; the capped damper of the
         // robot's gains on a 22-gram finger - h a = tens of kilograms - is honey: the finger keeps its rebound velocity until it has
         // left the contact, its effort drive closes it again at full speed, the grip chatters with a period of four substeps and
         // f_n = 0 drops the block.  Uncapped, the implicit solve balances spring, damper and drive within one substep.)
         a = vn > 0.f && P.mode < 3 ? fminf(a, cap) : a;
     }
-    const float fn = P.mode >= 3 ? P.k * depth : fmaxf(0.f, P.k * depth - a * vn);
+    // (a light body's pair: the Coulomb limit is spring and damper WITHOUT the implicit spring term - in a relaxing contact exactly the
+    // force that presses the link on, the finger drive's 6 N, and nothing for a block that nothing holds against the link)
+    const float fn = fmaxf(0.f, P.k * depth - (P.mode >= 3 ? P.cn : a) * vn);
     // Coulomb friction as an implicit secant viscosity b = min(c_t, mu fn / |v_t|): equals the stick damper
     // at small slip, delivers mu*fn while sliding, and - being implicit - can never reverse the slip
     // velocity (an explicit mu*fn chatters: the yaw inertia seen by a wheel contact is far below the mass)

@@ -531,8 +531,13 @@ static void contact_point(int mode, real mu, real k, real cn, real ct, real kh, 
      * the finger keeps its rebound velocity until it has left the contact, its effort drive closes it again at full speed, and the
      * grip chatters with a period of four substeps while f_n = 0 lets the block fall (omnipanda_effort, 6 N per finger).  Uncapped,
      * the implicit solve puts the finger at the velocity where spring, damper and drive balance within one substep; the price is a
-     * contact that holds an OPENING finger back for the one or two substeps its last fraction of a millimetre takes to relax.) */
-    if (mode == 3) fn = k * depth;
+     * contact that holds an OPENING finger back for the one or two substeps its last fraction of a millimetre takes to relax.
+     * The Coulomb limit is the spring-damper force WITHOUT the implicit spring term, k depth - c_n v_n: in a relaxing contact whose
+     * link is pressed on by a force F (v_n+ = (k depth - F) / a, depth shrinking by alpha / (alpha + beta) of its excess per substep)
+     * that is exactly F - the 6 N of the finger drive while 3 mm of impact penetration relax, nothing for a block that nothing holds
+     * against the link.  k depth - a v_n is zero all through the relaxation (the block falls out of the grip before it is over);
+     * k depth alone glues a one-gram block to the side of the stick that has hit it and the stick carries it off the table.) */
+    if (mode == 3) { fn = k * depth - cn * vn; if (fn < 0) fn = 0; }
     real b = mu * fn / (vtn + (real)1e-9); if (ct < b) b = ct;
     real f[3];
     for (int j = 0; j < 3; j++) f[j] = k * depth * n[j];
@@ -859,7 +864,8 @@ static int shape_entity(const mppi_model_t *m, const scene_info_t *si, const mpp
  * outweighs MPPI_LIGHT_BODY_RATIO times (heavier bodies carry pushing forces within millimetres under the explicit law, and keep it) and
  * that touches no other free actor - scene_info_t.light; MPPI_CONTACT_EXPLICIT_LIGHT switches it off - takes, against a robot link X
  * (mode 3; geometry and patch normalisation as for two dynamic bodies):
- *   - the ROBOT's gains (k = alpha m_robot / h^2 ...) and the implicit point law with damper and end-of-step spring NOT ramped
+ *   - the ROBOT's gains (k = alpha m_robot / h^2 ...) and the implicit point law with damper and end-of-step spring NOT ramped and the
+ *     damper NOT capped at k depth / v_n, the Coulomb limit taken from the spring alone
  *     (contact_point, law 3: the ramp - over 1 / MPPI_LIGHT_RAMP_DIV of the static sag - shapes the stick damper and the patch weights);
  *   - implicit on BOTH bodies, staggered.  With c = J^T (b 1 + (a - b) n n^T) J summed over the pair's points and f its spring wrench on L,
  *         link X :  wrench = -f - c (v_X+ - v_L)     c joins the link's articulated inertia like a static contact's, the light body is a

@@ -62,10 +62,10 @@ def test_panda_pick_lifts_the_block_and_carries_it_towards_the_goal(run):
     iteration 300, block -> goal (xy) 1.12 -> 0.46 m."""
     r = closed_loop(run, "panda_pick", 700)
     rest = r[40:80, 2].min()                       # lying on the table (0.157: table top 0.14 + half the block - the penalty sag)
-    print(f"panda_pick: block rests at z = {rest:.3f}, highest {r[:, 2].max():.3f}, block -> goal (xy) {r[0, 4]:.3f} -> {r[-1, 4]:.3f} m (closest {r[:, 4].min():.3f}), "
+    print(f"panda_pick: block rests at z = {rest:.3f}, highest after it has come to rest {r[80:, 2].max():.3f}, block -> goal (xy) {r[0, 4]:.3f} -> {r[-1, 4]:.3f} m (closest {r[:, 4].min():.3f}), "
           f"hand at the block (< 3 cm) in {np.mean(r[:, 3] < 0.03):.2f} of the iterations")
     assert 0.15 < rest < 0.165
-    assert r[:, 2].max() > rest + 0.10             # picked up: more than 10 cm above where it lay
+    assert r[80:, 2].max() > rest + 0.10           # picked up: more than 10 cm above where it lay (it is dropped from 0.48 at the start)
     assert r[:, 4].min() < r[0, 4] - 0.4           # ... and carried: 40 cm closer to the goal than it started
     # the explicit law of rounds 1-5: the hand reaches the block, the block never leaves the table
     e = closed_loop(run, "panda_pick", 400, explicit_light=True)
@@ -81,3 +81,16 @@ def test_pushing_tasks_are_no_worse_than_before(run):
         r = closed_loop(run, name, steps)
         print(f"{name}: block -> goal (xy) {r[0, 4]:.3f} -> {r[-1, 4]:.3f} m")
         assert r[-1, 4] < bound and np.isfinite(r).all(), (name, r[-1])
+
+
+def test_omni_panda_pick_drives_to_the_table_and_stops_at_its_edge(run):
+    """reference examples/omni_panda_pick: the mobile manipulator crosses two metres of floor and brings its hand to the table - and stops
+    at the table's EDGE, 0.26 m short of the block (profiles/r06h_task_outcomes.txt).  That is the example's own cost in this contact
+    model, not the grasp (tests/test_scene_kat.py::test_the_mobile_manipulator_holds_and_lifts_its_block holds and lifts the 0.1-kg block
+    with the same 6-N finger efforts): the hand is drawn to the block's CENTRE, 2 cm above the table top, while the fingertips - boxes
+    around the finger meshes - reach 11 cm below the hand frame; they scrape over the table top as soon as the base advances (20-50 N,
+    oracle replay of the final state) and the objective's `collision` weight on the table's contact force stops the approach.  A horizon
+    of six steps does not find the way up and over.  Asserted: what it does reach."""
+    r = closed_loop(run, "omni_panda_pick", 900)
+    print(f"omni_panda_pick: hand -> block {r[0, 3]:.3f} -> {r[-1, 3]:.3f} m, block z {r[-1, 2]:.3f}")
+    assert np.isfinite(r).all() and r[-1, 3] < 0.35 and abs(r[-1, 2] - r[100, 2]) < 5e-3      # at the table; the block lies where it fell
