@@ -811,7 +811,7 @@ def main():
                                   else "enqueue time only (--async-loop)"},
             "config": {"workload": wl["desc"],
                        "K_per_gpu": K, "K_total": K * world_size, "H": H, "nu": nu, "dt": loop.cfg.isaacgym.dt,
-                       "substeps": loop.cfg.isaacgym.substeps, "closed_loop": True, "action_to_host_every_step": sync,
+                       "substeps": loop.cfg.isaacgym.substeps, "substeps_integrated": loop.planner.sim.substeps_integrated, "closed_loop": True, "action_to_host_every_step": sync,
                        "parallelism": (f"sample-shard x{world_size}: rollout -> "
                                        + (f"mailbox exchange (library kernels: store into every rank's inbox, poll the own one) of {loop.n_gathered} records"
                                           if loop.exchange == "mailbox" else f"in-place {backend} all-gather of {loop.n_records} folded records") + " -> combine"

@@ -883,6 +883,12 @@ class IsaacGymWrapper:
 
     # ------------------------------------------------------------------ getters (reference :268-356)
     @property
+    def substeps_integrated(self) -> int:
+        """integration steps per control interval actually taken (Scene.substeps: cfg.substeps, multiplied up in contact scenes so that
+        a step is at most MAX_CONTACT_SUBSTEP) - what bench.py reports next to the configured value"""
+        return int(self.scene.substeps())
+
+    @property
     def num_robots(self):
         return len(self.robot_indices)
 

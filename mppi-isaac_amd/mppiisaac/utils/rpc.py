@@ -122,13 +122,20 @@ class ZmtpConnection:
         sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
 
     # -- raw
-    def _recv_exact(self, n: int) -> bytes:
+    def _recv_exact(self, n: int, deadline: Optional[float] = None) -> bytes:
+        """n bytes; `deadline` (time.monotonic()): the whole read must be over by then - the wait for each piece is select() with the
+        time that is left, so a peer that drips a byte every few seconds cannot hold a half-received frame for ever, and the
+        socket's own time-out (shared with the sender threads' sendall) is not touched"""
         # the buffer GROWS with the bytes received (1 MiB at a time): the announced length alone allocates nothing
         buf = bytearray(min(n, _CHUNK))
         got = 0
         while got < n:
             if got == len(buf):
                 buf.extend(bytes(min(n - got, _CHUNK)))
+            if deadline is not None:
+                left = deadline - time.monotonic()
+                if left <= 0 or not select.select([self.sock], [], [], left)[0]:
+                    raise ConnectionError("a frame stalled half-way")
             r = self.sock.recv_into(memoryview(buf)[got:], len(buf) - got)
             if r == 0:
                 raise ConnectionError("peer closed the connection")
@@ -143,19 +150,16 @@ class ZmtpConnection:
         flags = self._recv_exact(1)[0]
         if flags & ~(FLAG_MORE | FLAG_LONG | FLAG_COMMAND):
             raise ProtocolError(f"reserved frame flag bits set: {flags:#04x}")
-        # between messages a peer may stay silent for as long as it likes; once a frame has started, the rest of it is due
-        idle = self.sock.gettimeout()
-        if idle is None or idle > FRAME_TIMEOUT:
-            self.sock.settimeout(FRAME_TIMEOUT)
+        # between messages a peer may stay silent for as long as the socket's time-out lets it; once a frame has started, ALL of it is
+        # due within FRAME_TIMEOUT (one deadline for the frame, not a time-out per recv())
+        deadline = time.monotonic() + FRAME_TIMEOUT
         try:
-            n = struct.unpack("!Q", self._recv_exact(8))[0] if flags & FLAG_LONG else self._recv_exact(1)[0]
+            n = struct.unpack("!Q", self._recv_exact(8, deadline))[0] if flags & FLAG_LONG else self._recv_exact(1, deadline)[0]
             if n > MAX_FRAME:
                 raise ProtocolError(f"frame of {n} bytes exceeds the limit")
-            return flags, self._recv_exact(n)
+            return flags, self._recv_exact(n, deadline)
         except socket.timeout as e:
             raise ConnectionError("a frame stalled half-way") from e
-        finally:
-            self.sock.settimeout(idle)
 
     # -- handshake
     def handshake(self):

@@ -366,33 +366,31 @@ def test_contact_rich_states_match_oracle(make, name, K, H, nu, states, lib, ora
         lanes = (float(np.mean(rl <= 1e-3)), float(np.mean(rl <= 1e-2)))
         light = name == "panda_pick"    # (round 6: the one-gram block's pairs with robot links are implicit on both bodies, robot's gains)
         if st == "held":
-            # round 6, the gripper HOLDING the one-gram block in the air (tools/record_closed_loop_states.py panda_pick:70:400).  Nearly
-            # every rollout from here lets go of it - the sampled finger rates saturate at +-0.2 m/s - and a gram that is flicked,
-            # falls and bounces parts from its fp64 twin within steps (fp32 host build of the same arithmetic vs the oracle on the CPU:
-            # 97.7 % within 1e-4 after ONE step, 82 % after four).  Asserted is what the controller consumes: the weight the disagreeing
-            # samples carry, the normaliser, the nominal update - and that half of the samples still agree to 1e-2.
-            # Measured (profiles/r06c_gpu_tests.txt): 57 % within 1e-3, 83 % within 1e-2; weight beyond 1e-3: 7e-8 of eta; eta 1.8e-4;
-            # update 7e-5 = 4e-4 |u_max|.
+            # round 6, the gripper HOLDING the one-gram block 10 cm above the table, on its way (tools/record_closed_loop_states.py
+            # panda_pick:40:lift).  Many rollouts from here let go of it - the sampled finger rates saturate at +-0.2 m/s - and a gram
+            # that is flicked, falls and bounces parts from its fp64 twin within steps; the two fp32 kernels (shared-lane, one-lane)
+            # part from each other just as often.  Asserted is what the controller consumes: the weight the disagreeing samples carry,
+            # the normaliser, the nominal update - and that half of the samples still agree to 1e-2.
+            # Measured (profiles/r06k_gpu_tests.txt): 89.9 % within 1e-3, 94.4 % within 1e-2; 828 samples beyond 1e-3 carrying 6e-14 of
+            # eta; eta 1.6e-10; the update moves by 6.5e-11.
             want = [("weight", r["weight_mass_outside_1e-3"] < 1e-3), ("update", r["update_max_abs_diff"] <= 1e-2 * umax),
                     ("eta", r["eta_rel_err"] < 1e-2), ("half within 1e-2", r["within_1e-2"] >= 0.5)]
         elif st == "recorded":
             # where the controller works: >= 99.5 % within 1e-3, 99.9 % within 1e-2 - and the samples beyond 1e-3 carry less than
             # 1e-3 of eta; swapping the kernel's weights for the oracle's moves the nominal update by < 1e-3 |u_max|
-            # measured (profiles/r04a_gpu_tests.txt, all 8192): pushing 99.87 % within 1e-3, max 4.6e-3; gripper (round 4: the hand over the
-            # block, touching nothing) 99.99 %; round 6 (`recorded` = the hand AT the block on the table, fingers and palm touching it
-            # under the stiff light-body law): 99.72 % / 99.93 %, weight beyond 1e-3 3e-48 - but the nominal update moves by 1.4e-3 =
-            # 7e-3 |u_max|: the softmax of conf/mppi/panda_pick.yaml (lambda 0.05 on costs of 237) turns a cost difference of 1e-3 ABSOLUTE -
-            # 5e-6 relative, far inside every band above - into 2 % of a weight (fp32 host build vs oracle, 2048 samples on the CPU:
-            # the four samples that share 99.9 % of eta differ by 2e-5 ... 1.1e-3).  Bound for this scene: 2e-2 |u_max|.
+            # measured (profiles/r04a_gpu_tests.txt, all 8192): pushing 99.87 % within 1e-3, max 4.6e-3; gripper, round 6 (`recorded` =
+            # the hand closing on the block that lies on the table, 40 iterations into the task): 100 % within 1e-3 (max 1.5e-4), the
+            # update moves by 6.3e-5.  The gripper scene's bound on the update is 2e-2 |u_max|: the softmax of conf/mppi/panda_pick.yaml
+            # (lambda 0.05 on costs of ~240) turns a cost difference of 1e-3 ABSOLUTE - 5e-6 relative, far inside every band above -
+            # into 2 % of a weight, and a state with fingers and palm ON the block (the recording of r06d) moved it by 7e-3 |u_max|.
             want = [("within", r["within_1e-3"] >= 0.995 and r["within_1e-2"] >= 0.999), ("weight", r["weight_mass_outside_1e-3"] < 1e-3),
                     ("update", r["update_max_abs_diff"] <= (2e-2 if light else 1e-3) * umax), ("lanes", lanes[0] >= 0.98 and lanes[1] >= 0.998)]
-        elif light and st == "violent20":
-            # the block in FREE FALL 5 cm under the opened gripper, 0.73 m/s, about to land on the table (sample 4685 of the `held` state's
-            # rollouts after 20 steps): every rollout's cost from here is decided by the landing - 26 |F_table| of the substep in which
-            # the corners arrive - and so is the order of the cheapest samples: 94 % within 1e-3, but the disagreeing 6 % INCLUDE the
-            # samples that carry the weight (502 beyond 1e-3 carrying all of eta, the update moves by 0.4).  Not a state the closed loop
-            # plans from (the cost of that rollout is 1500 x the median); kept as the measured worst case, asserted loosely.
-            want = [("within", r["within_1e-3"] >= 0.9 and r["within_1e-2"] >= 0.95), ("lanes", lanes[0] >= 0.9 and lanes[1] >= 0.95)]
+        elif light:
+            # violent states DERIVED FROM `held`: the block flung out of the gripper, the arm at its joint stops (the samples with the
+            # highest finite cost of that state's rollouts, 9 and 20 steps in).  Measured (r06k): 98.75 / 99.01 % within 1e-3, 99.5 /
+            # 99.65 % within 1e-2, weight beyond 1e-3 <= 6e-40, update <= 2e-6; the two fp32 kernels agree on 98.4 / 98.7 %.
+            want = [("within", r["within_1e-3"] >= 0.97 and r["within_1e-2"] >= 0.99), ("weight", r["weight_mass_outside_1e-3"] < 1e-3),
+                    ("update", r["update_max_abs_diff"] <= 1e-2 * umax), ("lanes", lanes[0] >= 0.96 and lanes[1] >= 0.985)]
         else:
             # measured: 99.7 - 99.99 % within 1e-3, 99.96 - 100 % within 1e-2 (the tumbling samples: max 0.17 / 0.13, weight 0)
             want = [("within", r["within_1e-3"] >= 0.99 and r["within_1e-2"] >= 0.999), ("weight", r["weight_mass_outside_1e-3"] < 1e-3),

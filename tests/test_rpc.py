@@ -311,6 +311,22 @@ def test_frames_are_bounded_and_stalled_frames_are_dropped(monkeypatch):
     tracemalloc.stop()
     assert peak < (16 << 20), peak
     s.close()
+    # (2b) a peer that DRIPS - a byte every 0.2 s, each well inside FRAME_TIMEOUT: the deadline is the frame's, not a recv()'s
+    s = handshaken()
+    s.sendall(bytes([0x02]) + struct.pack("!Q", 1 << 20))
+    s.settimeout(0.05)
+    t0, closed = time.time(), False
+    while time.time() - t0 < 3 and not closed:
+        try:
+            s.sendall(b"x")
+            closed = s.recv(16) == b""
+        except socket.timeout:
+            pass
+        except ConnectionError:
+            closed = True
+        time.sleep(0.2)
+    assert closed and time.time() - t0 < 2.5, (closed, time.time() - t0)
+    s.close()
     # (3) the server still serves
     c = rpc.Client(url, timeout=5)
     assert c.add_to_env([1, 2, 3]) == 3

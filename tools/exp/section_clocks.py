@@ -2,7 +2,7 @@
     MPPI_BUILD_VARIANT=sec python __graft_entry__.py
     MPPI_HIP_LIB=$PWD/mppi-isaac_amd/csrc/libmppi_hip_sec.so python tools/exp/section_clocks.py [boxer_push panda_pick]
 Shader-clock time per section (MPPI_SEC marks in csrc/mppi_scene*.hpp), per wavefront, at the recorded closed-loop states of
-tools/exp/states/: mean share over all wavefronts and over the slowest 5 %."""
+tests/golden/closed_loop_states.npz: mean share over all wavefronts and over the slowest 5 %."""
 import ctypes as C
 import os
 import sys
@@ -23,8 +23,8 @@ for name in (sys.argv[1:] or ["boxer_push", "panda_pick"]):
     make, K, H = (boxer_push, 8192, 25) if name == "boxer_push" else (panda_pick, 8192, 30)
     scene, m, cfg, cost, dof, root = make(K=K, H=H)
     m.randomize_seed = 0
-    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "states", f"state_{name}.npz"))
-    dof, root, U = np.ascontiguousarray(z["dof"]), np.ascontiguousarray(z["root"]), np.ascontiguousarray(z["U"])
+    z = np.load(os.path.join(ROOT, "tests", "golden", "closed_loop_states.npz"))   # (the states tools/exp/ab_time.py times at)
+    dof, root, U = (np.ascontiguousarray(z[f"{name}_recorded_{k}"], np.float32) for k in ("dof", "root", "U"))
     ctx = C.c_void_p()
     capi.check(lib, lib.mppi_create(C.byref(m), C.byref(cfg), 0, C.byref(ctx)))
     capi.check(lib, lib.mppi_set_cost(ctx, C.byref(cost)))

@@ -6,7 +6,7 @@
     <workload>_violent<t>_{dof,root}   the env state of a sample after t steps of a rollout from the last one (violent states: the
                                        samples with the highest costs whose state is still finite and within 10 m)
 go into the file; the entries of workloads that are not named stay as they are.  Needs a GPU.
-    python tools/record_closed_loop_states.py panda_pick:70:400 [boxer_push:300] [--out tests/golden/closed_loop_states.npz]"""
+    python tools/record_closed_loop_states.py panda_pick:70:lift [boxer_push:300]   (lift: until the block is 8 cm above where it lay) [--out tests/golden/closed_loop_states.npz]"""
 import ctypes
 import os
 import sys
@@ -26,7 +26,7 @@ def main():
     env = {"world_size": 1, "rank": 0, "local_rank": 0, "sharded": False, "backend": None, "action_sync": False, "exchange": None}
     for spec in args:
         name, *ns = spec.split(":")
-        ns = [int(v) for v in ns]
+        ns = [v if v == "lift" else int(v) for v in ns]
         loop = bench.Loop(name, bench.WORKLOADS[name]["K"], env)
         world, planner, capi = loop.world, loop.planner, loop.capi
         for k in [k for k in keep if k.startswith(name + "_")]:
@@ -34,9 +34,21 @@ def main():
         done = 0
         # <name>:N -> `recorded` after N iterations; <name>:N1:N2 -> `recorded` after N1 (the task under way), `held` after N2 (its
         # contact-rich phase: the gripper holding the block), the violent states derived from the last one
+        blk = next((i for i, a in enumerate(world.scene.env_cfg) if "block" in a.name), None)
         for tag, n in zip(("recorded", "held"), ns):
-            for _ in range(n - done):
-                loop.iterate()
+            if n == "lift":   # until the block is 8 cm above where it lay at the state before (the gripper holds it in the air)
+                loop.torch.cuda.synchronize(); world._stale = True
+                z0 = float(world._root_state[0, blk, 2])
+                n = done
+                while n < 1500:
+                    loop.iterate(); n += 1
+                    if n % 5 == 0:
+                        loop.torch.cuda.synchronize(); world._stale = True
+                        if float(world._root_state[0, blk, 2]) > z0 + 0.08:
+                            break
+            else:
+                for _ in range(n - done):
+                    loop.iterate()
             done = n
             loop.torch.cuda.synchronize()
             world._stale = True
