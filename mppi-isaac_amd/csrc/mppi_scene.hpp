@@ -2073,7 +2073,9 @@ MPPI_HD SV free_body_accel(M &m, int f, const LMem &L, float h, int set1 = 0) {
     AI A;
     SV pA;
     V3 hw;
-    if (LIGHT && m.n_light_pairs != 0 && ((m.light_free >> f) & 1u) != 0u && L.lp != nullptr) {
+    // (a light body that no robot link touches in this substep - no reference frame recorded, contact_forces - is an ordinary free
+    // body: the branch below exists for the robot's gains next to a gram's inertia)
+    if (LIGHT && m.n_light_pairs != 0 && ((m.light_free >> f) & 1u) != 0u && L.lp != nullptr && __builtin_bit_cast(int, L.lt(kLightRef)) >= 0) {
         // the LIGHT body ("light bodies" above), solved about its own centre o = p:
         //   (I + h (C_s + C')) a = -(v x* I v + (C_s + C') v - f_s - f' - f_g) + C' dv_ref + sum_X (C' S)_X dqd_X
         // C_s, f_s: its contacts with static geometry (the accumulator rows, shifted from the world origin to o); C', f': its pairs with
@@ -2095,7 +2097,7 @@ MPPI_HD SV free_body_accel(M &m, int f, const LMem &L, float h, int set1 = 0) {
         fe = {fe.a + V3{L.lt(0), L.lt(1), L.lt(2)}, fe.l + V3{L.lt(3), L.lt(4), L.lt(5)}};
         // the links' velocity changes over the substep: (sum C') dv_ref + sum_links (C' S)_link dqd_link  (oracle light_pair_t)
         const int ref = __builtin_bit_cast(int, L.lt(kLightRef));
-        if (ref >= 0) {
+        {
             const SV d = mul(Cr, light_motion_at(frame_velocity(L, ref), p));
             fe = {fe.a + d.a, fe.l + d.l};
         }
@@ -2162,7 +2164,10 @@ __device__ __forceinline__ void helper_free_bodies(M &m, const LMem &L, Split sp
 // (leader: one lane of those that share the sample writes)
 template <class T, class M>
 MPPI_HD void step_free_bodies(M &m, SceneState<T> &s, const LMem &L, float h, bool leader = true) {
-    if (m.n_light_pairs != 0 && L.lp != nullptr) light_link_velocities<T>(m, s, L, leader);
+    // (only a sample whose light body met a link in this substep reads the links' velocity changes - a reference frame is recorded then,
+    // contact_forces; the others skip the pass over the frames' rows: 108 LDS operations per substep that the gripper scene at 65 536
+    // samples, most of them nowhere near the block, paid as 128 -> 101 Hz)
+    if (m.n_light_pairs != 0 && L.lp != nullptr && __builtin_bit_cast(int, L.lt(kLightRef)) >= 0) light_link_velocities<T>(m, s, L, leader);
     for (int f = 0; f < kFreeSlots; f++)
         if (f < m.n_free) root_integrate(s.fr[f], free_body_accel<T>(m, f, L, h), h);
 }

@@ -425,3 +425,67 @@ def test_unseen_kinematic_tree_is_built_on_demand_without_a_gpu(tmp_path, monkey
     assert os.path.getsize(os.path.join(str(tmp_path / "jit"), name4)) > 100000
     if rc == 0:
         lib.mppi_destroy(ctx)
+
+
+def test_plugin_cache_is_private_and_foreign_plugins_are_refused(tmp_path, monkeypatch):
+    """the plugin of an unseen tree is code that mppi_create loads: the cache directory is created 0700, and a directory or a cached
+    plugin that somebody else could have written (group / other write bits; another owner) is refused BEFORE dlopen - the file name of a
+    plugin is computable from the tree and the public sources (round-5 advice).  mppi_jit_info says what a running build is doing."""
+    import ctypes as C
+    import subprocess
+    import sys
+    import test_gpu_runtime_tree as T
+    jit = str(tmp_path / "jit")
+    script = f'''
+import ctypes as C, os, sys, threading, time
+sys.path[:0] = [{os.path.join(ROOT, "tests")!r}, {os.path.join(ROOT, "mppi-isaac_amd")!r}, {ROOT!r}]
+import numpy as np
+import test_gpu_runtime_tree as T
+from mppiisaac.backend import capi
+from mppiisaac.planner.isaacgym_wrapper import Scene
+from mppiisaac.planner.mppi import make_config, MPPIConfig
+from mppiisaac.utils.config_store import load_config
+from mppiisaac.utils.isaacgym_utils import load_actor_cfgs, load_asset
+env = load_actor_cfgs([{str(tmp_path / "arm4.yaml")!r}, "goal"])
+sc = Scene(env, load_config({{"defaults": [{{"isaacgym": "normal"}}]}}).isaacgym, [load_asset(a) for a in env if a.type == "robot"])
+m, cfg = sc.to_c(), make_config(MPPIConfig(num_samples=64, horizon=8, noise_sigma=np.eye(4).tolist()), viz_link=-1)
+lib = capi.load_library()
+seen = []
+def watch():
+    buf = C.create_string_buffer(512)
+    while not seen or seen[-1] != "done":
+        lib.mppi_jit_info(buf, 512)
+        if buf.value and (not seen or seen[-1] != buf.value.decode()):
+            seen.append(buf.value.decode())
+        time.sleep(0.2)
+t = threading.Thread(target=watch, daemon=True); t.start()
+ctx = C.c_void_p()
+rc = lib.mppi_create(C.byref(m), C.byref(cfg), 0, C.byref(ctx))
+print("RC", rc, lib.mppi_last_error().decode()[:300].replace("\\n", " "))
+print("SEEN", [s[:40] for s in seen])
+'''
+    urdf4, actor4 = str(tmp_path / "b4.urdf"), str(tmp_path / "arm4.yaml")
+    T.write_branched_urdf(urdf4, tail=False)
+    T.actor_yaml(actor4, urdf4, init_joint_pose=[0.0] * 8)
+    env = dict(os.environ, MPPI_JIT_CACHE=jit)
+
+    def run():
+        r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
+        assert "RC " in r.stdout, r.stderr[-2000:]
+        return r.stdout
+    out = run()                                                     # (1) builds; the directory is private; the build was visible as it ran
+    assert (os.stat(jit).st_mode & 0o777) == 0o700
+    plugin = [f for f in os.listdir(jit) if f.endswith(".so")]
+    assert len(plugin) == 1 and "refusing" not in out
+    seen = out.split("SEEN", 1)[1]
+    assert "building " in seen, out                                 # mppi_jit_info from another thread while mppi_create blocked
+    os.chmod(os.path.join(jit, plugin[0]), 0o664)                   # (2) the cached plugin is group-writable: refused, not loaded
+    out = run()
+    assert "refusing the cached plugin" in out and "writable by group or others" in out, out
+    os.chmod(os.path.join(jit, plugin[0]), 0o644)
+    os.chmod(jit, 0o770)                                            # (3) ... and so is a cache directory others can write into
+    out = run()
+    assert "refusing the plugin cache directory" in out, out
+    os.chmod(jit, 0o700)
+    out = run()                                                     # (4) private again: the cached plugin is loaded
+    assert "refusing" not in out, out
