@@ -58,8 +58,8 @@ def closed_loop(run, name, steps, explicit_light=False):
 def test_panda_pick_lifts_the_block_and_carries_it_towards_the_goal(run):
     """reference examples/panda_pick (planner.py:24-53): 40 |ee - block| + 10 |block - goal| + 26 |F_table| + 2 tilt.  The goal of
     conf/actors/goal.yaml, (1, 1, 0.5), is beyond the arm's reach: the task is done as far as it can be when the block has been
-    picked off the table and carried towards it.  Measured (profiles/r06c_task_outcomes.txt): block 18 cm above the table at
-    iteration 300, block -> goal (xy) 1.12 -> 0.46 m."""
+    picked off the table and carried towards it.  Measured (profiles/r06m_task_outcomes.txt): block 19 cm above the table at
+    iteration 450, block -> goal (xy) 1.12 -> 0.47 m."""
     r = closed_loop(run, "panda_pick", 700)
     rest = r[40:80, 2].min()                       # lying on the table (0.157: table top 0.14 + half the block - the penalty sag)
     print(f"panda_pick: block rests at z = {rest:.3f}, highest after it has come to rest {r[80:, 2].max():.3f}, block -> goal (xy) {r[0, 4]:.3f} -> {r[-1, 4]:.3f} m (closest {r[:, 4].min():.3f}), "
@@ -87,8 +87,8 @@ def test_omni_panda_pick_drives_to_the_table_and_stops_at_its_edge(run):
     """reference examples/omni_panda_pick: the mobile manipulator crosses two metres of floor and brings its hand to the table - and stops
     at the table's EDGE, 0.26 m short of the block (profiles/r06h_task_outcomes.txt).  That is the example's own cost in this contact
     model, not the grasp (tests/test_scene_kat.py::test_the_mobile_manipulator_holds_and_lifts_its_block holds and lifts the 0.1-kg block
-    with the same 6-N finger efforts): the hand is drawn to the block's CENTRE, 2 cm above the table top, while the fingertips - boxes
-    around the finger meshes - reach 11 cm below the hand frame; they scrape over the table top as soon as the base advances (20-50 N,
+    with the same 6-N finger efforts): the hand is drawn to the block's CENTRE, 2 cm above the table top, while the fingertips reach 11 cm below the hand frame
+    (as the real gripper's do: 58 mm of hand, 54 mm of finger); they scrape over the table top as soon as the base advances (20-50 N,
     oracle replay of the final state) and the objective's `collision` weight on the table's contact force stops the approach.  A horizon
     of six steps does not find the way up and over.  Asserted: what it does reach."""
     r = closed_loop(run, "omni_panda_pick", 900)
