@@ -879,6 +879,7 @@ __global__ __launch_bounds__(kWave) void k_rollout_scene(const DevModel *__restr
     float light_rec[kLightFloats];
     L.lp = light_rec;
     L.lstride = 1;
+    if (((CModel *)m)->n_light_pairs != 0) light_region_reset(L);
     // start state in rollout coordinates (relative to the robot's start position, mppi_scene.hpp root_relative)
     __shared__ float s_root[13 * kMaxActors];
     root_origin(*(CModel *)m, x0_root, L.ox, L.oy);
@@ -974,6 +975,7 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW))
         if (M.n_light_pairs != 0) {   // records of the light bodies' pairs: the tail of the sample's rows (scene_row_floats)
             L.lp = lds + slot + (size_t)scene_light_base<T>(M) * SPW;
             L.lstride = SPW;
+            light_region_reset(L);
         }
     // octet layout of the solve (mppi_scene_oct.hpp): the linear lanes read the bodies' inertia blocks from a copy without inertia
     // tensors; lane i stages body i
@@ -1054,6 +1056,7 @@ __global__ __launch_bounds__(kWave) void k_sim_step_scene(const DevModel *__rest
     L.lp = light_rec;
     L.lstride = 1;
     CModel &M = *(CModel *)m;
+    if (M.n_light_pairs != 0) light_region_reset(L);
     SceneState<T> s;
     static_for<0, NB>([&](auto ic) {
         constexpr int i = ic;
@@ -1140,6 +1143,7 @@ __global__ __launch_bounds__(kWave) void k_sim_step_scene_quad(const DevModel *_
     if (M.n_light_pairs != 0) {   // records of the light bodies' pairs: the tail of the sample's rows (scene_row_floats)
         L.lp = lds + (threadIdx.x >> 2) + (size_t)scene_light_base<T>(M) * 16;
         L.lstride = 16;
+        light_region_reset(L);
     }
     SceneState<T> s;
     static_for<0, NB>([&](auto ic) {

@@ -252,6 +252,14 @@ MPPI_HD int scene_light_base(M &m) { return SceneLayout<T>::floats(m.n_rb, m.n_r
 constexpr int kLightRow = 27, kLightRef = 27, kLightRec = 28, kLightSlots = 4, kLightSlotFloats = 7, kLightFloats = kLightRec + kLightSlots * kLightSlotFloats;
 template <class T, class M>
 MPPI_HD int scene_row_floats(M &m) { return SceneLayout<T>::floats(m.n_rb, m.n_rnd, m.n_shapes) + (m.n_light_pairs != 0 ? kLightFloats : 0); }
+// the light region of a sample with nothing in it: zero row, no reference frame, no link records.  Written once where the region is set
+// up (the kernels, tests/hostemu) and again by contact_forces only after a pass that recorded a pair - a reference frame is set
+// then: 32 LDS writes per substep that the samples nowhere near the block do not pay
+MPPI_HD void light_region_reset(const LMem &L) {
+    for (int j = 0; j < kLightRow; j++) L.lt(j) = 0.f;
+    L.lt(kLightRef) = __builtin_bit_cast(float, -1);
+    for (int sl = 0; sl < kLightSlots; sl++) L.lt(kLightRec + sl * kLightSlotFloats) = __builtin_bit_cast(float, -1);
+}
 
 // extra floats per sample row of the kernels with a helper wavefront (kSplitOctPair): its accumulator set, two mask words and
 // the accelerations of the free actors it solves (6 each, at xch + 2)
@@ -1324,14 +1332,10 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
     const SV zero = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
     constexpr bool kCached = SPLIT != kSplitNone;
     // records of the light bodies' pairs ("light bodies" above; never in the kernel with a helper wavefront: mppi_create gives a scene
-    // with such pairs the one-wavefront kernels): all free at the start of the pass
+    // with such pairs the one-wavefront kernels): all free at the start of the pass (light_region_reset: only where the last pass left something)
     int n_light = 0;
     if constexpr (!kPair)
-        if (m.n_light_pairs != 0 && (!split_on_device(SPLIT) || split.sub == 0)) {
-            for (int j = 0; j < kLightRow; j++) L.lt(j) = 0.f;
-            L.lt(kLightRef) = __builtin_bit_cast(float, -1);
-            for (int sl = 0; sl < kLightSlots; sl++) L.lt(kLightRec + sl * kLightSlotFloats) = __builtin_bit_cast(float, -1);
-        }
+        if (m.n_light_pairs != 0 && (!split_on_device(SPLIT) || split.sub == 0) && __builtin_bit_cast(int, L.lt(kLightRef)) >= 0) light_region_reset(L);
     if constexpr (kPair) {
         // dealt over both wavefronts (the owner posing all shapes before the first barrier, one barrier less, measured the same)
         shape_cache_update<T, true>(m, root, L, Split{split.sub + split.n * split.wave, 2 * split.n}, false);

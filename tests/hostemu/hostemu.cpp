@@ -45,6 +45,7 @@ int emu_rollout(const mppi_model_t *model, const mppi_config_t *cfg, const mppi_
             LMem L{lmem.data(), 1};
             L.lp = lmem.data() + scene_light_base<T>(m);   // (records of the light bodies' pairs: the tail of the rows)
             L.lstride = 1;
+            if (m.n_light_pairs != 0) light_region_reset(L);
             // as the rollout kernels do: start state relative to the robot's start position (mppi_scene.hpp root_relative)
             std::vector<float> rel(13 * m.n_actors);
             root_origin(m, root0, L.ox, L.oy);
@@ -133,6 +134,7 @@ int emu_scene_step_g(const mppi_model_t *model, float *dof, float *root, const f
         LMem L{lmem.data(), 1};
         L.lp = lmem.data() + scene_light_base<T>(m);
         L.lstride = 1;
+        if (m.n_light_pairs != 0) light_region_reset(L);
         SceneState<T> s;
         scene_init<T>(m, dof, root, s, sample_id, L);
         float target[MPPI_MAX_BODIES + 1], uu[kMaxNu] = {0};
