@@ -11,6 +11,11 @@ Tolerances (fp32 device arithmetic vs the fp64 oracle), AS ASSERTE
   the recorded closed-loop states >= 99.5 % within 1e-3 and >= 99.9 % within 1e-2; at states derived from violent rollouts
   >= 99 % / 99.9 %; EVERYWHERE the samples beyond 1e-3 carry < 1e-3 of the softmax normaliser eta (measured: 0 - they are the
   expensive, tumbling ones) and replacing the kernel's costs by the oracle's moves the nominal update by <= 1e-3 |u_max|.
+  Exceptions, each stated where it is asserted: the gripper scene under the light-body law of round 6 (`held`: the weight / eta /
+  update bounds and half of the samples within 1e-2; states derived from it >= 97 % / 99 %; the update bound of that scene is
+  2e-2 |u_max|: test_contact_rich_states_match_oracle), and per-sample RANDOMISED actors (test_randomised_actors_per_sample: >= 98 %
+  within 1e-3, at most 2 % beyond 1e-2, max < 0.1, the weight bound - pushed blocks of different sizes touch down a substep apart in
+  fp32 and fp64 in a few expensive samples).
   Where along the horizon a sample leaves the oracle: tests/test_gpu_state_parity.py (per-step states of all K samples)."""
 import ctypes as C
 import os
