@@ -1766,8 +1766,18 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
             const int par = !on_body ? eh : (parj < 0 ? NBl + (-1 - parj) : parj);
             auto key = [](int f) MPPI_LAMBDA { return f < NBl ? f + T::NBASE : f - NBl; };   // (bases first, then the bodies in their order)
             const bool leader = !split_on_device(SPLIT) || split.sub == 0;
+            // (kernels whose lanes share a sample: the leader adds inside the LDS unit - ds_add_f32, no read - wait - add - write round trip
+            // per word; 27 + 27 + 6 + 6 words per active light pair, four pairs on a held block: the read-modify-write form was 13 % of
+            // the gripper scene's kernel at the `held` state)
+            constexpr bool kLdsAdd = split_on_device(SPLIT);
+            auto add_to = [&](float &x, float v) MPPI_LAMBDA {
+#if defined(__HIP_DEVICE_COMPILE__)
+                if constexpr (kLdsAdd) { lds_add(x, v); return; }
+#endif
+                x += v;
+            };
             if (leader) {
-                for (int j = 0; j < kLightRow; j++) L.lt(j) += rec[j];
+                for (int j = 0; j < kLightRow; j++) add_to(L.lt(j), rec[j]);
                 const int ref = __builtin_bit_cast(int, L.lt(kLightRef));
                 if (ref < 0 || key(par) < key(ref)) L.lt(kLightRef) = __builtin_bit_cast(float, par);
                 if (on_body) {
@@ -1782,12 +1792,17 @@ MPPI_HD unsigned contact_forces(M &m, const float *root, const LMem &L, unsigned
                         const bool fresh = __builtin_bit_cast(int, L.lt(o)) < 0;
                         L.lt(o) = __builtin_bit_cast(float, eh);
                         const float g6[6] = {gj.a.x, gj.a.y, gj.a.z, gj.l.x, gj.l.y, gj.l.z};
-                        for (int j = 0; j < 6; j++) L.lt(o + 1 + j) = (fresh ? 0.f : L.lt(o + 1 + j)) + g6[j];
+                        if (fresh) for (int j = 0; j < 6; j++) L.lt(o + 1 + j) = g6[j];
+                        else for (int j = 0; j < 6; j++) add_to(L.lt(o + 1 + j), g6[j]);
                     }
                 }
-                acc_add(L, kAccW, eh, fh, &Ch);
-                L[ocf] += acc.rep.x; L[ocf + 1] += acc.rep.y; L[ocf + 2] += acc.rep.z;
-                L[ob] -= acc.rep.x; L[ob + 1] -= acc.rep.y; L[ob + 2] -= acc.rep.z;
+                const int oa = kAccW + eh * 27;
+                const float row[27] = {fh.a.x, fh.a.y, fh.a.z, fh.l.x, fh.l.y, fh.l.z, Ch.I.xx, Ch.I.xy, Ch.I.xz, Ch.I.yy, Ch.I.yz, Ch.I.zz,
+                                       Ch.H[0], Ch.H[1], Ch.H[2], Ch.H[3], Ch.H[4], Ch.H[5], Ch.H[6], Ch.H[7], Ch.H[8],
+                                       Ch.M.xx, Ch.M.xy, Ch.M.xz, Ch.M.yy, Ch.M.yz, Ch.M.zz};
+                for (int j = 0; j < 27; j++) add_to(L[oa + j], row[j]);   // (= acc_add(L, kAccW, eh, fh, &Ch))
+                add_to(L[ocf], acc.rep.x); add_to(L[ocf + 1], acc.rep.y); add_to(L[ocf + 2], acc.rep.z);
+                add_to(L[ob], -acc.rep.x); add_to(L[ob + 1], -acc.rep.y); add_to(L[ob + 2], -acc.rep.z);
             }
             n_light++;
         } else

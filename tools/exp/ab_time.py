@@ -29,8 +29,9 @@ for w in workloads:
     make, K, H = SPEC[w]
     scene, m, cfg, cost, dof, root = make(K=K, H=H)
     U = np.zeros((H, cfg.nu), np.float32)
-    if f"{w}_recorded_dof" in Z.files:
-        dof, root, U = Z[f"{w}_recorded_dof"], Z[f"{w}_recorded_root"], Z[f"{w}_recorded_U"]
+    st = os.environ.get("STATE", "recorded")   # (STATE=held: the gripper scene's second recorded state)
+    if f"{w}_{st}_dof" in Z.files:
+        dof, root, U = Z[f"{w}_{st}_dof"], Z[f"{w}_{st}_root"], Z[f"{w}_{st}_U"]
     ctxs = []
     for name, lib in libs:
         ctx = C.c_void_p()

@@ -24,7 +24,8 @@ for name in (sys.argv[1:] or ["boxer_push", "panda_pick"]):
     scene, m, cfg, cost, dof, root = make(K=K, H=H)
     m.randomize_seed = 0
     z = np.load(os.path.join(ROOT, "tests", "golden", "closed_loop_states.npz"))   # (the states tools/exp/ab_time.py times at)
-    dof, root, U = (np.ascontiguousarray(z[f"{name}_recorded_{k}"], np.float32) for k in ("dof", "root", "U"))
+    st = os.environ.get("STATE", "recorded")   # (STATE=held: the gripper scene's second recorded state)
+    dof, root, U = (np.ascontiguousarray(z[f"{name}_{st}_{k}"], np.float32) for k in ("dof", "root", "U"))
     ctx = C.c_void_p()
     capi.check(lib, lib.mppi_create(C.byref(m), C.byref(cfg), 0, C.byref(ctx)))
     capi.check(lib, lib.mppi_set_cost(ctx, C.byref(cost)))
