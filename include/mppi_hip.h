@@ -48,6 +48,12 @@ extern "C" {
 #define MPPI_LIGHT_BODY_MASS 0.25
 #define MPPI_LIGHT_BODY_RATIO 100
 #define MPPI_LIGHT_RAMP_DIV 16
+/* free actors: the angular velocity of a free rigid body is limited to this [rad/s] at the end of every substep - Isaac Gym's
+ * AssetOptions.max_angular_velocity, whose default the reference keeps (isaacgym_utils.py:15: gymapi.AssetOptions() as it comes;
+ * PhysX clamps every rigid body of the asset).  A one-gram block pinched at an angle between two gripper pads leaves like a squeezed
+ * seed, at metres per second and hundreds of rad/s; at h = 25 ms that is more than a radian per substep, and every contact it meets
+ * afterwards is evaluated at a pose that is gone by the end of the substep */
+#define MPPI_MAX_ANGULAR_VELOCITY 64.0
 #define MPPI_MAX_FREE 4      /* free (non-fixed) box/sphere actors per env (the shipped kernels carry 2 slots; scenes with
                               * 3-4 free actors get their kernels built on demand, see mppi_create)          */
 #define MPPI_MAX_EXTRA_BASES 3 /* moving-base robots per env beyond the first (ABI 7)         */

@@ -1151,7 +1151,7 @@ constexpr int kDealtBroadPhaseMin = 16;  // candidate pairs above which the quad
 //                                                   and the links' velocity CHANGES over the substep as
 //                                                       (sum_X C_X) dv_ref + sum_X (C_X S_X) dqd_X
 //                                                   ref = the frame nearest the base among the PARENTS of the links in contact, S_X / dqd_X
-//                                                   the link's own joint axis / rate change (light_link_velocities): exact when the links
+//                                                   the link's own joint axis / rate change (light_reference_change, step_free_bodies): exact when the links
 //                                                   hang off one parent - two fingers on a hand: their relative motion is what a pinch is
 //                                                   made of -, one substep late only for joints between `ref` and a link's parent.
 // Both solves are unconditionally stable (a squeeze between two fingers contracts by m / (m + h C) per substep); what the robot feels of
@@ -1193,23 +1193,27 @@ MPPI_HD AI light_shift(const AI &c, V3 o) {
 }
 MPPI_HD SV light_shift(const SV &f, V3 o) { return SV{f.a + cross(o, f.l), f.l}; }          // wrench about o -> about the world origin
 MPPI_HD SV light_motion_at(const SV &v, V3 o) { return SV{v.a, v.l + cross(v.a, o)}; }      // motion about the world origin -> about o
-// how far the spatial velocities of the robot's frames CHANGED over the substep, into the frames' velocity rows (their start-of-substep
-// values are not read again): the new joint rates - after the velocity and joint limits - on the joint axes of the substep's poses,
-// a floating base from its integrated root row, minus what the rows held
+// how far the spatial velocity of the light bodies' REFERENCE frame changed over the substep: the changes dqd of the joint rates - after
+// the velocity and joint limits - on the joint axes of the substep's poses, summed down the tree (a floating base: its integrated root
+// row minus the velocity its frame row holds); only the reference frame's change is kept (the links' own joints enter the light body's
+// solve through dqd itself).  (Until the end of round 6 every frame's change went into the frames' velocity rows and free_body_accel
+// read them back: 162 LDS operations per substep + 18 per record, 16 % of the gripper kernel's time with the block in the gripper.)
 template <class T, class M>
-MPPI_HD void light_link_velocities(M &m, const SceneState<T> &s, const LMem &L, bool leader) {
+MPPI_HD SV light_reference_change(M &m, const SceneState<T> &s, const LMem &L, const float *dqd, int ref) {
     constexpr int NB = T::NB;
+    SV out = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
     SV vb[T::NBASE];
     static_for<0, T::NBASE>([&](auto rc) MPPI_LAMBDA {
         constexpr int r = rc;
-        const float *bs = s.template base_row<r>();
-        const V3 w = loadv(bs + 10), vl = loadv(bs + 7);
-        vb[r] = m.floating ? SV{w, vl - cross(w, loadv(bs))} : SV{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-        if (m.floating && leader) {
-            const int o = (NB + r) * 18;
-            L[o + 12] = vb[r].a.x - L[o + 12]; L[o + 13] = vb[r].a.y - L[o + 13]; L[o + 14] = vb[r].a.z - L[o + 14];
-            L[o + 15] = vb[r].l.x - L[o + 15]; L[o + 16] = vb[r].l.y - L[o + 16]; L[o + 17] = vb[r].l.z - L[o + 17];
+        vb[r] = SV{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+        if (m.floating) {
+            const float *bs = s.template base_row<r>();
+            const V3 w = loadv(bs + 10), vl = loadv(bs + 7);
+            const SV now = SV{w, vl - cross(w, loadv(bs))};
+            const SV was = frame_velocity(L, NB + r);
+            vb[r] = SV{now.a - was.a, now.l - was.l};
         }
+        if (ref == NB + r) out = vb[r];
     });
     SV v[NB ? NB : 1];
     static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
@@ -1217,15 +1221,13 @@ MPPI_HD void light_link_velocities(M &m, const SceneState<T> &s, const LMem &L, 
         constexpr int par = T::par[i];
         const int o = i * 18;
         const V3 az = {L[o + 2], L[o + 5], L[o + 8]}, p = {L[o + 9], L[o + 10], L[o + 11]};
-        const float qd = s.qd[i];
-        const SV sj = m.b[i].k0.jtype == 0 ? SV{qd * az, qd * cross(p, az)} : SV{{0.f, 0.f, 0.f}, qd * az};
+        const float dq = dqd[i];
+        const SV sj = m.b[i].k0.jtype == 0 ? SV{dq * az, dq * cross(p, az)} : SV{{0.f, 0.f, 0.f}, dq * az};
         if constexpr (par < 0) v[i] = vb[base_of_parent(par)] + sj;
         else v[i] = v[par < 0 ? 0 : par] + sj;
-        if (leader) {
-            L[o + 12] = v[i].a.x - L[o + 12]; L[o + 13] = v[i].a.y - L[o + 13]; L[o + 14] = v[i].a.z - L[o + 14];
-            L[o + 15] = v[i].l.x - L[o + 15]; L[o + 16] = v[i].l.y - L[o + 16]; L[o + 17] = v[i].l.z - L[o + 17];
-        }
+        if (ref == i) out = v[i];
     });
+    return out;
 }
 
 template <class T>
@@ -1907,6 +1909,19 @@ MPPI_HD void root_integrate(float *rs, const SV &a, float h) {
     rs[10] = w.x; rs[11] = w.y; rs[12] = w.z;
 }
 
+// ... of a FREE actor: and its angular velocity limited to MPPI_MAX_ANGULAR_VELOCITY (Isaac Gym's AssetOptions default, include/mppi_hip.h:
+// a one-gram block that a gripper has squeezed out like a seed would otherwise turn by more than a radian per substep)
+MPPI_HD void free_integrate(float *rs, const SV &a, float h) {
+    root_integrate(rs, a, h);
+    const V3 w = loadv(rs + 10);
+    const float w2 = dot(w, w);
+    constexpr float wm = (float)MPPI_MAX_ANGULAR_VELOCITY;
+    if (w2 > wm * wm) {
+        const float sc = wm * frsqrt(w2);
+        rs[10] = sc * w.x; rs[11] = sc * w.y; rs[12] = sc * w.z;
+    }
+}
+
 // spatial velocity / acceleration of the bases of the forest (one: every model but an env of several moving-base robots)
 template <class T>
 struct BaseSV {
@@ -2069,7 +2084,7 @@ MPPI_HD void scene_frames(M &m, const float *root, const SceneState<T> &s, Pose<
 // LIGHT: the kernel can have light bodies (never the one with a helper wavefront, whose helper calls this with LIGHT = false: its
 // 256-register budget carries none of that code)
 template <class T, bool LIGHT = true, class M>
-MPPI_HD SV free_body_accel(M &m, int f, const LMem &L, float h, int set1 = 0) {
+MPPI_HD SV free_body_accel(M &m, int f, const LMem &L, float h, int set1 = 0, const SV *dv_ref = nullptr, const float *dqd = nullptr) {
     constexpr int NB = T::NB;
     auto &F = m.fr[f];
     M3 R;
@@ -2094,12 +2109,12 @@ MPPI_HD SV free_body_accel(M &m, int f, const LMem &L, float h, int set1 = 0) {
     V3 hw;
     // (a light body that no robot link touches in this substep - no reference frame recorded, contact_forces - is an ordinary free
     // body: the branch below exists for the robot's gains next to a gram's inertia)
-    if (LIGHT && m.n_light_pairs != 0 && ((m.light_free >> f) & 1u) != 0u && L.lp != nullptr && __builtin_bit_cast(int, L.lt(kLightRef)) >= 0) {
+    if (LIGHT && dv_ref != nullptr && m.n_light_pairs != 0 && ((m.light_free >> f) & 1u) != 0u && L.lp != nullptr && __builtin_bit_cast(int, L.lt(kLightRef)) >= 0) {
         // the LIGHT body ("light bodies" above), solved about its own centre o = p:
         //   (I + h (C_s + C')) a = -(v x* I v + (C_s + C') v - f_s - f' - f_g) + C' dv_ref + sum_X (C' S)_X dqd_X
         // C_s, f_s: its contacts with static geometry (the accumulator rows, shifted from the world origin to o); C', f': its pairs with
         // robot links (the light region's row: already about o, f' holds +-f + C v_X(start)); the links' velocity changes over the substep
-        // (light_link_velocities has put them into the frames' rows) enter through the reference frame and the links' records
+        // (dv_ref, dqd: step_free_bodies) enter through the reference frame and the links' records
         const SV vo = light_motion_at(v, p);
         rigid_world(R, V3{0.f, 0.f, 0.f}, fm, V3{0.f, 0.f, 0.f}, Ic6, vo, A, pA, hw);
         SV fs;
@@ -2115,23 +2130,17 @@ MPPI_HD SV free_body_accel(M &m, int f, const LMem &L, float h, int set1 = 0) {
         add_to(C, Cr);
         fe = {fe.a + V3{L.lt(0), L.lt(1), L.lt(2)}, fe.l + V3{L.lt(3), L.lt(4), L.lt(5)}};
         // the links' velocity changes over the substep: (sum C') dv_ref + sum_links (C' S)_link dqd_link  (oracle light_pair_t)
-        const int ref = __builtin_bit_cast(int, L.lt(kLightRef));
-        {
-            const SV d = mul(Cr, light_motion_at(frame_velocity(L, ref), p));
+        {   // (dv_ref: light_reference_change, about the world origin)
+            const SV d = mul(Cr, light_motion_at(*dv_ref, p));
             fe = {fe.a + d.a, fe.l + d.l};
         }
         for (int sl = 0; sl < kLightSlots; sl++) {
             const int o = kLightRec + sl * kLightSlotFloats;
             const int j = __builtin_bit_cast(int, L.lt(o));
             if (j < 0) break;
-            // dqd of joint j from the frames' rows: S_j dqd_j = dv_j - dv_parent(j)
-            const int pj = T::par[j];
-            const SV dj = frame_velocity(L, j), dp = frame_velocity(L, pj < 0 ? NB + (-1 - pj) : pj);
-            const V3 az = {L[j * 18 + 2], L[j * 18 + 5], L[j * 18 + 8]}, pw = {L[j * 18 + 9], L[j * 18 + 10], L[j * 18 + 11]};
-            const SV Sj = m.b[j].k0.jtype == 0 ? SV{az, cross(pw, az)} : SV{{0.f, 0.f, 0.f}, az};
-            const SV dd = {dj.a - dp.a, dj.l - dp.l};
-            const float dqd = dot(Sj, dd) * frcp(dot(Sj, Sj));
-            fe = {fe.a + dqd * V3{L.lt(o + 1), L.lt(o + 2), L.lt(o + 3)}, fe.l + dqd * V3{L.lt(o + 4), L.lt(o + 5), L.lt(o + 6)}};
+            float dq = 0.f;   // the rate change of the link's own joint (a select over the tree's joints: j comes out of the record)
+            static_for<0, NB>([&](auto ic) MPPI_LAMBDA { dq = j == (int)ic ? dqd[ic] : dq; });
+            fe = {fe.a + dq * V3{L.lt(o + 1), L.lt(o + 2), L.lt(o + 3)}, fe.l + dq * V3{L.lt(o + 4), L.lt(o + 5), L.lt(o + 6)}};
         }
         const V3 g = F.gravity ? V3{m.g[0], m.g[1], m.g[2]} : V3{0.f, 0.f, 0.f};
         const SV Cv = mul(C, vo);
@@ -2180,15 +2189,17 @@ __device__ __forceinline__ void helper_free_bodies(M &m, const LMem &L, Split sp
     MPPI_BARRIER(4);
 }
 #endif
-// (leader: one lane of those that share the sample writes)
+// dqd: how far the joint rates changed over the substep (new - old, after the limits; the three step functions hand it over) - a light
+// body's solve wants the velocity changes of the links that touch it ("light bodies")
 template <class T, class M>
-MPPI_HD void step_free_bodies(M &m, SceneState<T> &s, const LMem &L, float h, bool leader = true) {
-    // (only a sample whose light body met a link in this substep reads the links' velocity changes - a reference frame is recorded then,
-    // contact_forces; the others skip the pass over the frames' rows: 108 LDS operations per substep that the gripper scene at 65 536
-    // samples, most of them nowhere near the block, paid as 128 -> 101 Hz)
-    if (m.n_light_pairs != 0 && L.lp != nullptr && __builtin_bit_cast(int, L.lt(kLightRef)) >= 0) light_link_velocities<T>(m, s, L, leader);
+MPPI_HD void step_free_bodies(M &m, SceneState<T> &s, const LMem &L, float h, const float *dqd) {
+    // (only a sample whose light body met a link in this substep - a reference frame is recorded then, contact_forces - pays for any of
+    // it: the gripper scene at 65 536 samples, most of them nowhere near the block, paid 128 -> 101 Hz before)
+    SV dv_ref = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    const int ref = m.n_light_pairs != 0 && L.lp != nullptr ? __builtin_bit_cast(int, L.lt(kLightRef)) : -1;
+    if (ref >= 0) dv_ref = light_reference_change<T>(m, s, L, dqd, ref);
     for (int f = 0; f < kFreeSlots; f++)
-        if (f < m.n_free) root_integrate(s.fr[f], free_body_accel<T>(m, f, L, h), h);
+        if (f < m.n_free) free_integrate(s.fr[f], free_body_accel<T>(m, f, L, h, 0, &dv_ref, dqd), h);
 }
 
 // The kernel with a helper wavefront lives on half the register file (256 registers), and the candidate-pair loop alone wants
@@ -2308,6 +2319,7 @@ MPPI_HD void step_scene(M &m0, const float *root, SceneState<T> &s, const float 
         });
         if (any) aba_scene<T>(*launder(mp), P, vbase, s.qd, tau, kdh, L, qdd, abase);
         MPPI_SEC(6);
+        float dqd[NB ? NB : 1];   // (rate changes of the substep: step_free_bodies)
         static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
             constexpr int i = ic;
             const BodyK1 b = load_block<BodyK1>(m.b[i].k1);
@@ -2317,6 +2329,7 @@ MPPI_HD void step_scene(M &m0, const float *root, SceneState<T> &s, const float 
             const float lo = m.b[i].k0.lower, hi = m.b[i].k0.upper;
             if (lo > -INFINITY || hi < INFINITY) joint_limit(s.q[i], x, v, lo, hi, 1.f / h);
             s.q[i] = x;
+            dqd[i] = v - s.qd[i];
             s.qd[i] = v;
         });
         if (m.floating)
@@ -2328,11 +2341,11 @@ MPPI_HD void step_scene(M &m0, const float *root, SceneState<T> &s, const float 
             for (int f = 0; f < kFreeSlots; f++)
                 if (f < m.n_free) {
                     const int o = L.xch + 2 + 6 * f;
-                    root_integrate(s.fr[f], SV{{L[o], L[o + 1], L[o + 2]}, {L[o + 3], L[o + 4], L[o + 5]}}, h);
+                    free_integrate(s.fr[f], SV{{L[o], L[o + 1], L[o + 2]}, {L[o + 3], L[o + 4], L[o + 5]}}, h);
                 }
         } else
 #endif
-        step_free_bodies<T>(m, s, L, h, !split_on_device(SPLIT) || split.sub == 0);
+        step_free_bodies<T>(m, s, L, h, dqd);
         MPPI_SEC(7);
     }
 }

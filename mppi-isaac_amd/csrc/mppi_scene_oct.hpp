@@ -344,6 +344,7 @@ __device__ __forceinline__ void step_scene_oct(M &m0, MR &mr0, const float *root
             oct_scene_solve<T>(*launder(mrp), prep, tau, kdh, qdd);
         }
         MPPI_SEC(6);
+        float dqd[NB ? NB : 1];   // (rate changes of the substep: step_free_bodies)
         static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
             constexpr int i = ic;
             const JointLimits b = lim[i];
@@ -353,9 +354,11 @@ __device__ __forceinline__ void step_scene_oct(M &m0, MR &mr0, const float *root
             v = qclamp(v, vlo, vhi);
             const QF x = qclamp(x0 + h * v, lo, hi);
             s.q[i] = qlane0(x);
-            s.qd[i] = qlane0(v);
+            const float vn = qlane0(v);
+            dqd[i] = vn - s.qd[i];
+            s.qd[i] = vn;
         });
-        step_free_bodies<T>(mr, s, L, h, !split_on_device(SPLIT) || split.sub == 0);
+        step_free_bodies<T>(mr, s, L, h, dqd);
         MPPI_SEC(7);
     }
 }

@@ -388,6 +388,7 @@ MPPI_HD void step_scene_quad(M &m0, MR &mr0, const float *root, SceneState<T> &s
             quad_aba_solve<T>(*launder(mrp), P, prep, tau, kdh, qdd, abase);
         }
         MPPI_SEC(6);
+        float dqd[NB ? NB : 1];   // (rate changes of the substep: step_free_bodies)
         static_for<0, NB>([&](auto ic) MPPI_LAMBDA {
             constexpr int i = ic;
             const JointLimits b = lim[i];
@@ -398,10 +399,12 @@ MPPI_HD void step_scene_quad(M &m0, MR &mr0, const float *root, SceneState<T> &s
             v = qclamp(v, vlo, vhi);
             const QF x = qclamp(x0 + h * v, lo, hi);
             s.q[i] = qlane0(x);
-            s.qd[i] = qlane0(v);
+            const float vn = qlane0(v);
+            dqd[i] = vn - s.qd[i];
+            s.qd[i] = vn;
         });
         if (m.floating) root_integrate(s.base, abase, h);
-        step_free_bodies<T>(mr, s, L, h, !split_on_device(SPLIT) || split.sub == 0);
+        step_free_bodies<T>(mr, s, L, h, dqd);
         MPPI_SEC(7);
     }
 }

@@ -1299,6 +1299,11 @@ void orc_scene_step(const mppi_model_t *m, real *root, real *q, real *qd, const 
             for (int j = 0; j < 36; j++) I6[j] += h * F->C[j];
             solve6(I6, b6);
             root_integrate(root + 13 * a, b6, h);
+            {   /* free actors: |w| <= MPPI_MAX_ANGULAR_VELOCITY (Isaac Gym's AssetOptions default, include/mppi_hip.h) */
+                real *w = root + 13 * a + 10;
+                const real w2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], wm = (real)MPPI_MAX_ANGULAR_VELOCITY;
+                if (w2 > wm * wm) { const real sc = wm / (real)sqrt((double)w2); w[0] *= sc; w[1] *= sc; w[2] *= sc; }
+            }
         }
     }
     if (cf_out) memcpy(cf_out, cf, sizeof(real) * 3 * m->n_rb);

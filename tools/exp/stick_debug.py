@@ -11,10 +11,15 @@ name, steps, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 Scene.EXPLICIT_LIGHT = "explicit" in sys.argv
 cfg = run.config(name)
 planner = run.make_planner(name, cfg)
-dofs, roots = [], []
+_orig = planner.sim.__class__.apply_robot_cmd
+def _spy(self, u, *a, **k):
+    self._last_cmd = np.asarray(u.detach().cpu().numpy() if hasattr(u, "detach") else u, float).reshape(-1).copy()
+    return _orig(self, u, *a, **k)
+planner.sim.__class__.apply_robot_cmd = _spy
+dofs, roots, cmds = [], [], []
 def hook(i, sim):
-    dofs.append(sim._dof_state[0].cpu().numpy().copy()); roots.append(sim._root_state[0].cpu().numpy().copy())
+    dofs.append(sim._dof_state[0].cpu().numpy().copy()); roots.append(sim._root_state[0].cpu().numpy().copy()); cmds.append(np.asarray(getattr(sim, '_last_cmd', np.zeros(1)), float))
 first, last, rate = run.run_world(name, cfg, planner, steps, report=False, hook=hook)
-np.savez_compressed(out, dof=np.array(dofs), root=np.array(roots))
+np.savez_compressed(out, dof=np.array(dofs), root=np.array(roots), cmd=np.array(cmds))
 print(name, "cost", first, "->", last, "rate", rate)
 planner.sim.stop_sim()
