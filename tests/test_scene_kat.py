@@ -888,3 +888,30 @@ def test_the_mobile_manipulator_holds_and_lifts_its_block(oracle64):
         ro, q, qd, cf = oracle64.scene_step(m, ro, q, qd, lift)
     pads, v_pads = pads_now()
     assert ro[blk, 2] > z_held + 0.05 and np.abs(ro[blk, :3] - pads).max() < 0.012, (ro[blk, :3], pads)
+
+
+def test_a_free_actor_spins_no_faster_than_the_engine_lets_it(hostemu, oracle64):
+    """Isaac Gym's AssetOptions.max_angular_velocity (64 rad/s by default, which the reference keeps: isaacgym_utils.py:15) limits every rigid
+    body's angular velocity; here for free actors (include/mppi_hip.h MPPI_MAX_ANGULAR_VELOCITY): the block of the gripper scene thrown up
+    spinning at 300 rad/s leaves its first substep at 64 rad/s about the same axis, its linear velocity is what gravity makes of it -
+    oracle and the host build of the device functions alike."""
+    scene, m, cfg, cost, dof, root = panda_pick(K=32, H=12)
+    blk = scene.actor_index("panda_pick_block")
+    ro = root.astype(float).copy()
+    ro[blk, 0:3] = [0.5, 0.0, 1.0]
+    axis = np.array([2.0, -1.0, 2.0]) / 3.0
+    ro[blk, 7:10] = [0.3, 0.0, 1.0]
+    ro[blk, 10:13] = 300.0 * axis
+    q, qd = dof[0::2].astype(float), dof[1::2].astype(float)
+    r1, _, _, _ = oracle64.scene_step(m, ro.copy(), q.copy(), qd.copy(), np.zeros(9))
+    w = r1[blk, 10:13]
+    assert np.linalg.norm(w) == pytest.approx(64.0, rel=1e-9) and np.allclose(w / 64.0, axis, atol=1e-6)
+    assert r1[blk, 7:10] == pytest.approx([0.3, 0.0, 1.0 + m.gravity[2] * m.dt], abs=1e-9)
+    de = np.ascontiguousarray(np.stack([q, qd], 1).reshape(-1), np.float32)
+    re = np.ascontiguousarray(ro, np.float32)
+    rb, cf = np.zeros((m.n_rb, 13), np.float32), np.zeros((m.n_rb, 3), np.float32)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    assert hostemu.emu_scene_step(C.byref(m), fp(de), fp(re.reshape(-1)), fp(np.zeros(9, np.float32)), fp(rb), fp(cf)) == 0
+    # (fp32: the world-frame inertia of the spinning cube is isotropic to rounding only - the axis moves by 6e-4 in that one substep)
+    assert np.linalg.norm(re[blk, 10:13]) == pytest.approx(64.0, rel=1e-5) and np.allclose(re[blk, 10:13] / 64.0, axis, atol=2e-3)
+    np.testing.assert_allclose(re[blk, 0:3], r1[blk, 0:3], atol=1e-5)
