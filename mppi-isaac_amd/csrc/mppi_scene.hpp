@@ -2180,7 +2180,21 @@ __device__ __forceinline__ void helper_free_bodies(M &m, const LMem &L, Split sp
     const float h = m.h;
     for (int f = 0; f < kFreeSlots; f++)
         if (f < m.n_free) {
-            const SV a = free_body_accel<T, false>(m, f, L, h, L.set1);
+            SV a = free_body_accel<T, false>(m, f, L, h, L.set1);
+            {   // the angular-velocity limit of free actors (free_integrate) HERE, as the acceleration that lands on it: the owner, full at 256
+                // registers, integrates with the plain root_integrate (the limit inside its integration cost it 24 B of scratch per lane).
+                // alpha' = (w_limited - w) / h;  the body origin's acceleration a_O + alpha x p + w x v stays what it was
+                const int o = free_frame<T>(f) * 18;
+                const V3 p = {L[o + 9], L[o + 10], L[o + 11]}, w = {L[o + 12], L[o + 13], L[o + 14]};
+                const V3 w1 = w + h * a.a;
+                const float w2 = dot(w1, w1);
+                constexpr float wm = (float)MPPI_MAX_ANGULAR_VELOCITY;
+                if (w2 > wm * wm) {
+                    const V3 al = (wm * frsqrt(w2)) * w1 - w;
+                    const V3 an = frcp(h) * al;
+                    a = SV{an, a.l + cross(a.a - an, p)};
+                }
+            }
             if (split.sub == 0) {
                 const int o = L.xch + 2 + 6 * f;
                 L[o] = a.a.x; L[o + 1] = a.a.y; L[o + 2] = a.a.z; L[o + 3] = a.l.x; L[o + 4] = a.l.y; L[o + 5] = a.l.z;
@@ -2341,7 +2355,7 @@ MPPI_HD void step_scene(M &m0, const float *root, SceneState<T> &s, const float 
             for (int f = 0; f < kFreeSlots; f++)
                 if (f < m.n_free) {
                     const int o = L.xch + 2 + 6 * f;
-                    free_integrate(s.fr[f], SV{{L[o], L[o + 1], L[o + 2]}, {L[o + 3], L[o + 4], L[o + 5]}}, h);
+                    root_integrate(s.fr[f], SV{{L[o], L[o + 1], L[o + 2]}, {L[o + 3], L[o + 4], L[o + 5]}}, h);   // (the limit: helper_free_bodies)
                 }
         } else
 #endif
