@@ -376,7 +376,7 @@ def test_contact_rich_states_match_oracle(make, name, K, H, nu, states, lib, ora
             # that is flicked, falls and bounces parts from its fp64 twin within steps; the two fp32 kernels (shared-lane, one-lane)
             # part from each other just as often.  Asserted is what the controller consumes: the weight the disagreeing samples carry,
             # the normaliser, the nominal update - and that half of the samples still agree to 1e-2.
-            # Measured (profiles/r06u_gpu_tests.txt): 89.5 % within 1e-3, 94.4 % within 1e-2; 858 samples beyond 1e-3 carrying 5e-15 of
+            # Measured (profiles/r06w_gpu_tests.txt): 89.5 % within 1e-3, 94.4 % within 1e-2; 858 samples beyond 1e-3 carrying 5e-15 of
             # eta; eta 2.8e-9; the update moves by 1.1e-9.
             want = [("weight", r["weight_mass_outside_1e-3"] < 1e-3), ("update", r["update_max_abs_diff"] <= 1e-2 * umax),
                     ("eta", r["eta_rel_err"] < 1e-2), ("half within 1e-2", r["within_1e-2"] >= 0.5)]
@@ -392,7 +392,7 @@ def test_contact_rich_states_match_oracle(make, name, K, H, nu, states, lib, ora
                     ("update", r["update_max_abs_diff"] <= (2e-2 if light else 1e-3) * umax), ("lanes", lanes[0] >= 0.98 and lanes[1] >= 0.998)]
         elif light:
             # violent states DERIVED FROM `held`: the block flung out of the gripper, the arm at its joint stops (the samples with the
-            # highest finite cost of that state's rollouts, 9 and 20 steps in).  Measured (r06u): 98.68 / 99.01 % within 1e-3, 99.45 /
+            # highest finite cost of that state's rollouts, 9 and 20 steps in).  Measured (r06w): 98.68 / 99.01 % within 1e-3, 99.45 /
             # 99.65 % within 1e-2, weight beyond 1e-3 <= 6e-40, update <= 9e-7; the two fp32 kernels agree on 98.8 / 98.7 %.
             want = [("within", r["within_1e-3"] >= 0.97 and r["within_1e-2"] >= 0.99), ("weight", r["weight_mass_outside_1e-3"] < 1e-3),
                     ("update", r["update_max_abs_diff"] <= 1e-2 * umax), ("lanes", lanes[0] >= 0.96 and lanes[1] >= 0.985)]
