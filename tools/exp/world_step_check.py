@@ -19,7 +19,7 @@ def hook(i, sim):
     if prev:
         m = sim.scene.to_c()
         u = np.asarray(sim._last_cmd, float)     # (the command of THIS iteration took the previous state here)
-        ro, q, qd, cf = o.scene_step(m, prev["root"].copy(), prev["dof"][0::2].copy(), prev["dof"][1::2].copy(), u)
+        ro, q, qd, cf = o.scene_step(m, prev["root"].copy(), prev["dof"][0::2].copy(), prev["dof"][1::2].copy(), o.cmd_map(m, u))
         e = max(np.abs(ro[:, :3] - root[:, :3]).max(), np.abs(q - dof[0::2]).max())
         worst.append((e, i))
         if e > 1e-3 or not np.isfinite(e):
