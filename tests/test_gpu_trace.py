@@ -1,7 +1,6 @@
 """Reference-style Python Objectives traced into cost programs, on the GPU: the traced programs through the in-kernel interpreter
 against the reference's golden costs; the planner binds them, validates them against the eager Objective and falls back to generic
 mode - saying why - when an Objective cannot be traced or drifts (mppiisaac/trace.py)."""
-import ctypes as C
 import logging
 
 import numpy as np

@@ -1,6 +1,4 @@
 """mppiisaac/trace.py: reference-style Python Objectives traced into cost programs."""
-import json
-import os
 
 import numpy as np
 import pytest
