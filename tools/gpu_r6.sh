@@ -37,7 +37,7 @@ if [[ $WHAT == *prof* ]]; then
   cd $REPO; for t in ${TAG} ${TAG}_boxer ${TAG}_pick; do python tools/summarise_profile.py $t > /dev/null 2>&1; done
   mkdir -p $OUT/profiles && cp profiles/${TAG}* $OUT/profiles/ 2>/dev/null; cp profiles/pmc_latest.json profiles/sq_latest.json $OUT/profiles/ 2>/dev/null
 fi
-for f in $OUT/bench*.json; do [ -f $f ] && python - "$f" <<'PY'
+for f in $OUT/bench*.json; do [ -f $f ] || continue; python - "$f" <<'PY'
 import json, sys
 try:
     d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
@@ -46,3 +46,4 @@ except Exception as e:
     print(sys.argv[1], "unreadable:", e)
 PY
 done
+exit 0
